@@ -1,0 +1,214 @@
+"""Pins the oracle's factor restatements: the reference's own known-answer values
+(gtsam_fusion/test/UnitTests.cpp) and central-difference checks of every Jacobian
+against the stated retraction (Pose3 full Expmap; vector add for velocity / bias)."""
+import numpy as np
+import pytest
+
+
+def rand_state(rng, scale=1.0):
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    if q[0] < 0:
+        q = -q
+    return np.concatenate([q, rng.normal(size=3) * 5 * scale, rng.normal(size=3) * 3,
+                           rng.normal(size=3) * 0.05, rng.normal(size=3) * 0.01])
+
+
+def make_pim(oracle, rng, n=8, dt=0.005, bhat=None):
+    prm = oracle.carla_imu_params()
+    p = oracle.pim_new(np.zeros(6) if bhat is None else bhat)
+    for _ in range(n):
+        acc = np.array([0.3, -0.2, 9.81]) + rng.normal(size=3) * 0.5
+        gyr = rng.normal(size=3) * 0.3
+        oracle.pim_integrate(p, prm, acc, gyr, dt)
+    return p, prm
+
+
+def test_kat_imu_manager_test1(oracle):
+    """UnitTests.cpp:58-66: dV = 0.0175, dP = 0.0011875 (all axes) for IMU samples at
+    t=0 (0), 0.1 (0.1), 0.2 (0.2) integrated by getFactor(start=0, end=0.15)."""
+    t = np.array([0.0, 0.1, 0.2])
+    acc = np.repeat([[0.0], [0.1], [0.2]], 3, axis=1)
+    gyro = acc.copy()
+    prm = oracle.make_imu_params(1e-6, 1e-6, 1e-8, 1e-4, 1e-6, 1e-4, gravity=(0, 0, 9.81))
+    pim, head, n = oracle.imu_get_factor(t, acc, gyro, 0, 0.0, 0.15, np.zeros(6), prm)
+    f = oracle.pim_fields(pim)
+    assert n == 2 and head == 2           # sample at 0.2 stays in the buffer (IMUManager.cpp:57-66)
+    np.testing.assert_allclose(f["d"][6:9], 0.0175, rtol=1e-6)      # EXPECT_FLOAT_EQ tolerance
+    np.testing.assert_allclose(f["d"][3:6], 0.0011875, rtol=1e-6)
+    np.testing.assert_allclose(f["dt"], 0.15, rtol=1e-15)
+    # rotation is about (1,1,1), parallel to the acceleration: exact values
+    np.testing.assert_allclose(f["d"][6:9], 0.0175, rtol=1e-13)
+    np.testing.assert_allclose(f["d"][3:6], 0.0011875, rtol=1e-13)
+
+
+def test_get_factor_buffer_semantics(oracle):
+    """IMUManager.cpp:35-54: samples <= start are dropped, samples < end are consumed."""
+    t = np.arange(0, 1.0, 0.05)
+    acc = np.tile([0, 0, 9.81], (t.size, 1)); gyro = np.zeros((t.size, 3))
+    prm = oracle.carla_imu_params()
+    pim, head, n = oracle.imu_get_factor(t, acc, gyro, 0, 0.1, 0.27, np.zeros(6), prm)
+    # dropped 0,0.05,0.1 ; integrated 0.15,0.2,0.25 ; interpolated to 0.27 using 0.3
+    assert head == 6 and n == 4
+    np.testing.assert_allclose(pim.dt, 0.17, rtol=1e-14)
+    pim2, head2, n2 = oracle.imu_get_factor(t, acc, gyro, head, 0.27, 0.47, np.zeros(6), prm)
+    assert head2 == 10 and n2 == 5
+    np.testing.assert_allclose(pim2.dt, 0.2, rtol=1e-14)
+
+
+def test_pim_bias_jacobians_fd(oracle):
+    """preintegrated(bhat + d) ~= preintegrated(bhat) + H d  (H = d preint / d bias)."""
+    meas = np.random.default_rng(7).normal(size=(10, 6)) * [0.5, 0.5, 0.5, 0.3, 0.3, 0.3] + [0, 0, 9.81, 0, 0, 0]
+    prm = oracle.carla_imu_params()
+
+    def integ(bhat):
+        p = oracle.pim_new(bhat)
+        for m in meas:
+            oracle.pim_integrate(p, prm, m[:3], m[3:], 0.01)
+        return oracle.pim_fields(p)
+    b0 = np.array([0.02, -0.01, 0.03, 0.004, -0.002, 0.001])
+    f0 = integ(b0)
+    h = 1e-6
+    Hn = np.zeros((9, 6))
+    for i in range(6):
+        e = np.zeros(6); e[i] = h
+        Hn[:, i] = (integ(b0 + e)["d"] - integ(b0 - e)["d"]) / (2 * h)
+    np.testing.assert_allclose(f0["H"], Hn, atol=2e-9)
+
+
+def test_pim_covariance_properties(oracle):
+    rng = np.random.default_rng(8)
+    p, prm = make_pim(oracle, rng, n=7)
+    f = oracle.pim_fields(p)
+    cov = f["cov"]
+    np.testing.assert_allclose(cov, cov.T, atol=1e-20)
+    assert np.all(np.linalg.eigvalsh(cov) > 0)
+    # bias random walk blocks are exactly dt_total * cov (F bias block = I, GTSAM D_a_a / D_g_g)
+    np.testing.assert_allclose(np.diag(cov)[9:12], 7 * 0.005 * 1e-4, rtol=1e-12)
+    np.testing.assert_allclose(np.diag(cov)[12:15], 7 * 0.005 * 1e-6, rtol=1e-12)
+    # first step from zero covariance: P1 = G Q G^T with theta block (gyro+int)/dt * (dt Jr^-1)^2
+    p1 = oracle.pim_new(np.zeros(6))
+    oracle.pim_integrate(p1, prm, [0, 0, 9.81], [0.1, 0.2, 0.3], 0.005)
+    c1 = oracle.pim_fields(p1)["cov"]
+    np.testing.assert_allclose(c1[:3, :3], np.eye(3) * 0.005 * (1e-6 + 1e-4), rtol=1e-12, atol=1e-22)
+    np.testing.assert_allclose(c1[6:9, 6:9], np.eye(3) * 0.005 * (1e-6 + 1e-4), rtol=1e-12, atol=1e-22)
+    np.testing.assert_allclose(c1[3:6, 3:6], np.eye(3) * 0.005 * 1e-8, rtol=1e-12, atol=1e-24)
+    # sqrt information: R upper, R^T R = cov^-1
+    R = oracle.unpack_upper(oracle.sqrt_info_upper(cov), 15)
+    np.testing.assert_allclose(R.T @ R @ cov, np.eye(15), atol=1e-8)
+    assert np.all(np.diag(R) > 0)
+
+
+def _pose_retract(oracle, x, d15):
+    return oracle.retract(x, d15)
+
+
+def test_imu_factor_jacobian_fd(oracle):
+    rng = np.random.default_rng(9)
+    bhat = np.array([0.01, -0.02, 0.015, 0.002, 0.001, -0.003])
+    p, prm = make_pim(oracle, rng, n=8, bhat=bhat)
+    rec = oracle.pim_to_record(p)
+    g = np.array([0, 0, -9.81])
+    xi = rand_state(rng)
+    xj = oracle.predict(rec, g, xi)
+    # perturb xj away from the prediction so that the residual is not ~0
+    xj = oracle.retract(xj, rng.normal(size=15) * 0.02)
+    r0, J = oracle.imu_factor(rec, g, xi, xj, whiten=False)
+    # column blocks -> (which state, tangent slice)
+    cols = [(0, slice(0, 6), 0), (0, slice(6, 9), 6), (1, slice(0, 6), 9), (1, slice(6, 9), 15),
+            (0, slice(9, 15), 18), (1, slice(9, 15), 24)]
+    h = 1e-6
+    Jn = np.zeros((15, 30))
+    for which, sl, c0 in cols:
+        for k in range(sl.start, sl.stop):
+            d = np.zeros(15); d[k] = h
+            xs = [xi, xj]
+            xp = list(xs); xm = list(xs)
+            xp[which] = oracle.retract(xs[which], d)
+            xm[which] = oracle.retract(xs[which], -d)
+            rp, _ = oracle.imu_factor(rec, g, xp[0], xp[1], whiten=False)
+            rm, _ = oracle.imu_factor(rec, g, xm[0], xm[1], whiten=False)
+            Jn[:, c0 + k - sl.start] = (rp - rm) / (2 * h)
+    np.testing.assert_allclose(J, Jn, atol=5e-8)
+    # whitening = R * (unwhitened)
+    R = oracle.unpack_upper(rec[70:], 15)
+    rw, Jw = oracle.imu_factor(rec, g, xi, xj, whiten=True)
+    np.testing.assert_allclose(rw, R @ r0, rtol=1e-13)
+    np.testing.assert_allclose(Jw, R @ J, rtol=1e-12, atol=1e-9)
+
+
+def test_imu_residual_zero_at_prediction(oracle):
+    rng = np.random.default_rng(10)
+    p, prm = make_pim(oracle, rng, n=6)
+    rec = oracle.pim_to_record(p)
+    g = np.array([0, 0, -9.81])
+    xi = rand_state(rng)
+    xj = oracle.predict(rec, g, xi)
+    r, _ = oracle.imu_factor(rec, g, xi, xj, whiten=False)
+    np.testing.assert_allclose(r, 0, atol=1e-12)
+
+
+def make_between(oracle, rng, cov=None):
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    cov = np.diag([0.1] * 6) if cov is None else cov
+    return np.concatenate([q, rng.normal(size=3), oracle.sqrt_info_upper(cov)])
+
+
+@pytest.mark.parametrize("small", [False, True])
+def test_between_factor_jacobian_fd(oracle, small):
+    rng = np.random.default_rng(11)
+    A = rng.normal(size=(6, 6)); cov = A @ A.T + np.eye(6)
+    rec = make_between(oracle, rng, cov)
+    xa = rand_state(rng)
+    if small:   # xb close to xa * meas  => small residual (the operating regime)
+        Rm = oracle.quat_to_rot(rec[:4]); Ra = oracle.quat_to_rot(xa[:4])
+        xb = xa.copy()
+        xb[:4] = oracle.rot_to_quat(Ra @ Rm)
+        xb[4:7] = xa[4:7] + Ra @ rec[4:7]
+        xb = oracle.retract(xb, np.concatenate([rng.normal(size=6) * 1e-3, np.zeros(9)]))
+    else:
+        xb = rand_state(rng)
+    r0, Ja, Jb = oracle.between_factor(rec, xa, xb, whiten=False)
+    h = 1e-6
+    Jan, Jbn = np.zeros((6, 6)), np.zeros((6, 6))
+    for k in range(6):
+        d = np.zeros(15); d[k] = h
+        Jan[:, k] = (oracle.between_factor(rec, oracle.retract(xa, d), xb, False)[0]
+                     - oracle.between_factor(rec, oracle.retract(xa, -d), xb, False)[0]) / (2 * h)
+        Jbn[:, k] = (oracle.between_factor(rec, xa, oracle.retract(xb, d), False)[0]
+                     - oracle.between_factor(rec, xa, oracle.retract(xb, -d), False)[0]) / (2 * h)
+    np.testing.assert_allclose(Ja, Jan, atol=2e-8)
+    np.testing.assert_allclose(Jb, Jbn, atol=2e-8)
+    R = oracle.unpack_upper(rec[7:], 6)
+    rw, Jaw, Jbw = oracle.between_factor(rec, xa, xb, whiten=True)
+    np.testing.assert_allclose(rw, R @ r0, rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(Jaw, R @ Ja, rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(Jbw, R @ Jb, rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(R.T @ R, np.linalg.inv(cov), rtol=1e-10)
+
+
+def test_between_kat_sensor_manager_test1(oracle):
+    """UnitTests.cpp:186-233: odom (0,0,0,q=I) -> (1,1,1,q=(.5,.5,.5,.5)): measured translation
+    (1,1,1); with the measurement equal to the true relative pose the residual is zero."""
+    xa = np.zeros(16); xa[0] = 1
+    xb = np.zeros(16); xb[:4] = 0.5; xb[4:7] = 1
+    rec = np.concatenate([[0.5, 0.5, 0.5, 0.5], [1, 1, 1], oracle.sqrt_info_upper(np.eye(6) * 0.1)])
+    r, _, _ = oracle.between_factor(rec, xa, xb)
+    np.testing.assert_allclose(r, 0, atol=1e-15)
+
+
+def test_prior_factor_fd(oracle):
+    rng = np.random.default_rng(12)
+    mean = rand_state(rng)
+    sig = np.array([1e-6] * 3 + [5e-5] * 3 + [1e-5] * 3 + [1e-7] * 6)   # GraphManager.cpp:27-31
+    rec = np.concatenate([mean, sig])
+    x = oracle.retract(mean, rng.normal(size=15) * 0.05)
+    r0, J = oracle.prior_factor(rec, x)
+    h = 1e-7
+    Jn = np.zeros((15, 15))
+    for k in range(15):
+        d = np.zeros(15); d[k] = h
+        Jn[:, k] = (oracle.prior_factor(rec, oracle.retract(x, d))[0]
+                    - oracle.prior_factor(rec, oracle.retract(x, -d))[0]) / (2 * h)
+    np.testing.assert_allclose(J * sig[:, None], Jn * sig[:, None], atol=5e-8)
+    r1, _ = oracle.prior_factor(rec, mean)
+    np.testing.assert_allclose(r1, 0, atol=1e-9)

@@ -1,0 +1,128 @@
+/*
+ * vilfusion.h -- C ABI of libvilfusion.so, the MI355X (gfx950) drop-in for the arithmetic
+ * behind gtsam_fusion's GraphManager / IMUManager.
+ *
+ * The reference has no FFI layer: the only seam on its hot path is the public C++ API of
+ * VILFusion::GraphManager (gtsam_fusion/include/gtsam_fusion/GraphManager.h:40-96) and
+ * VILFusion::IMUManager (gtsam_fusion/include/gtsam_fusion/IMUManager.h:22-27).  Each entry
+ * point below cites the reference member it replaces.  All pointers are borrowed for the
+ * duration of the call; outputs are caller-allocated; no call throws; every call returns an
+ * int status (0 = VF_OK, <0 = error, message via vf_last_error()).  No torch / GTSAM types.
+ *
+ * Layout conventions (host side of the ABI, plain AoS, float64):
+ *   quaternion (w,x,y,z);  state16 = q(4) t(3) v(3) bias_acc(3) bias_gyro(3);
+ *   tangent15 = dtheta(3) dp(3) dv(3) dba(3) dbg(3);  Pose3 tangent order [rot, trans].
+ *   imu record (190)     = dt, delta(9), bias_hat(6), H(9x6 row-major), R(120 packed upper)
+ *   between record (28)  = q_meas(4), t_meas(3), R(21 packed upper), R^T R = cov^-1
+ *   prior record (31)    = mean state16, sigma(15)
+ * On the device these live as AoSoA tiles of 64 factors (DESIGN.md "Data layout in HBM").
+ */
+#ifndef VILFUSION_H
+#define VILFUSION_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VF_OK 0
+#define VF_ERR_INVALID (-1)       /* bad argument */
+#define VF_ERR_BAD_KEY (-2)       /* unknown / out-of-window key */
+#define VF_ERR_NOT_SPD (-3)       /* covariance not symmetric positive definite */
+#define VF_ERR_INDETERMINATE (-4) /* normal equations not positive definite */
+#define VF_ERR_DEVICE (-5)        /* HIP runtime error */
+#define VF_ERR_CAPACITY (-6)      /* window / slot capacity exceeded */
+#define VF_ERR_NO_DEVICE (-7)     /* no gfx950 device visible: the library never falls back to CPU */
+
+#define VF_STATE_DIM 16
+#define VF_TANGENT_DIM 15
+#define VF_IMU_RECORD 190
+#define VF_BTW_RECORD 28
+#define VF_PRIOR_RECORD 31
+#define VF_MAX_BANDWIDTH 3
+
+const char* vf_last_error(void);
+const char* vf_version(void);
+int vf_device_count(int* count);
+
+/* ===================================================================== engine (batch)
+ * B independent windows of up to `capacity` keyframes on one GPU.  This is the form the
+ * hot path takes on the device; the GraphManager handle below is an engine with B = 1. */
+typedef struct vf_engine vf_engine;
+
+typedef struct {
+    int windows;            /* B */
+    int capacity;           /* keyframes per window, rounded up to a multiple of 64 */
+    int bandwidth;          /* max |a-b| of a between factor, 1..VF_MAX_BANDWIDTH */
+    int device;             /* HIP device ordinal */
+    double gravity[3];      /* n_gravity; MakeSharedU => (0,0,-9.81) (ImuManagerRos.cpp:16) */
+    double lambda0, lambda_up, lambda_down, lambda_min, lambda_max; /* LM damping schedule */
+} vf_engine_opts;
+
+void vf_engine_default_opts(vf_engine_opts* o);
+int vf_engine_create(const vf_engine_opts* o, vf_engine** out);
+void vf_engine_destroy(vf_engine* e);
+
+/* host -> device staging (each converts AoS records to the AoSoA device layout) */
+int vf_engine_set_range(vf_engine* e, int window, int lo, int hi); /* active keyframes [lo,hi) */
+int vf_engine_set_states(vf_engine* e, int window, int k0, int n, const double* state16);
+int vf_engine_get_states(vf_engine* e, int window, int k0, int n, double* state16);
+/* imu factor slot k holds the CombinedImuFactor X(k-1),V(k-1),X(k),V(k),B(k-1),B(k)
+ * (IMUManager.cpp:68-73) */
+int vf_engine_set_imu(vf_engine* e, int window, int k0, int n, const double* rec190);
+/* BetweenFactor<Pose3>(X(a), X(b)) (GraphManager.cpp:86); stored in the slot of b; a < b,
+ * b - a <= bandwidth; at most one between factor may end at a keyframe. */
+int vf_engine_set_between(vf_engine* e, int window, int n, const int32_t* a, const int32_t* b,
+                          const double* rec28);
+int vf_engine_clear_between(vf_engine* e, int window, int k0, int n);
+/* the three priors of GraphManager.cpp:27-35 as one diagonal 15-row factor on keyframe k */
+int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec31);
+
+/* ---- hot-path stages (asynchronous on the engine's HIP stream) ---- */
+/* K1+K2+priors: residual + whitened Jacobian of every factor, at the current (which=0) or
+ * trial (which=1) states.  Replaces the linearisation inside ISAM2::update
+ * (GraphManager.cpp:126). */
+int vf_engine_linearize(vf_engine* e, int which);
+/* K3: block-banded J^T J, J^T r of the current linearisation */
+int vf_engine_assemble(vf_engine* e);
+/* K4: (H + lambda I) delta = -g by block-banded Cholesky, one wavefront per window */
+int vf_engine_solve(vf_engine* e);
+/* K5: trial = current (+) delta ; then linearize(which=1) + accept/reject */
+int vf_engine_retract(vf_engine* e);
+int vf_engine_decide(vf_engine* e, int init);
+/* `iterations` LM trials (linearize once, then {assemble, solve, retract, linearize(trial),
+ * decide} per trial).  Replaces ISAM2::update + calculateEstimate (GraphManager.cpp:126-127). */
+int vf_engine_iterate(vf_engine* e, int iterations);
+/* slide every window by one keyframe: hi += 1 (new keyframe's state predicted from its IMU
+ * factor, GraphManager.cpp:152-160), lo += 1 and re-anchor the prior at the new oldest
+ * keyframe's current estimate. */
+int vf_engine_slide(vf_engine* e, const double* prior_sigma15);
+int vf_engine_predict(vf_engine* e, int window, int k0, int n); /* states k0..k0+n-1 from k-1 */
+int vf_engine_sync(vf_engine* e);
+
+/* ---- read-back (synchronises) ---- */
+int vf_engine_read_imu_lin(vf_engine* e, int window, int which, int k0, int n, double* r15, double* J450);
+int vf_engine_read_between_lin(vf_engine* e, int window, int which, int k0, int n, double* r6,
+                               double* Ja36, double* Jb36);
+int vf_engine_read_normal(vf_engine* e, int window, int k0, int n, double* Hband, double* g15);
+int vf_engine_read_delta(vf_engine* e, int window, int k0, int n, double* delta15);
+int vf_engine_read_lm(vf_engine* e, int window, double* cost, double* lambda, int* accepted,
+                      int* rejected, int* solve_failures);
+
+/* ---- measurement: time `reps` launches of one stage with HIP events on the engine stream ---- */
+#define VF_STAGE_LINEARIZE_IMU 1
+#define VF_STAGE_LINEARIZE_BTW 2
+#define VF_STAGE_ASSEMBLE 3
+#define VF_STAGE_SOLVE 4
+#define VF_STAGE_RETRACT 5
+#define VF_STAGE_DECIDE 6
+int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms);
+/* HIP-event time of a whole vf_engine_iterate(iterations) */
+int vf_engine_time_iterate(vf_engine* e, int iterations, float* ms);
+int vf_engine_counts(vf_engine* e, int64_t* n_imu, int64_t* n_between, int64_t* n_keyframes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

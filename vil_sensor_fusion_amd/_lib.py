@@ -1,0 +1,62 @@
+"""ctypes loader for libvilfusion.so.  Fails loudly: there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libvilfusion.so")
+
+
+class VilFusionError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libvilfusion error {code}: {msg}")
+        self.code = code
+
+
+def lib_path() -> str:
+    return _SO
+
+
+class EngineOptsC(C.Structure):
+    _fields_ = [("windows", C.c_int), ("capacity", C.c_int), ("bandwidth", C.c_int),
+                ("device", C.c_int), ("gravity", C.c_double * 3),
+                ("lambda0", C.c_double), ("lambda_up", C.c_double), ("lambda_down", C.c_double),
+                ("lambda_min", C.c_double), ("lambda_max", C.c_double)]
+
+
+_lib = None
+
+# every symbol include/vilfusion.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "vf_last_error", "vf_version", "vf_device_count",
+    "vf_engine_default_opts", "vf_engine_create", "vf_engine_destroy",
+    "vf_engine_set_range", "vf_engine_set_states", "vf_engine_get_states", "vf_engine_set_imu",
+    "vf_engine_set_between", "vf_engine_clear_between", "vf_engine_set_prior",
+    "vf_engine_linearize", "vf_engine_assemble", "vf_engine_solve", "vf_engine_retract",
+    "vf_engine_decide", "vf_engine_iterate", "vf_engine_slide", "vf_engine_predict",
+    "vf_engine_sync",
+    "vf_engine_read_imu_lin", "vf_engine_read_between_lin", "vf_engine_read_normal",
+    "vf_engine_read_delta", "vf_engine_read_lm",
+    "vf_engine_time_stage", "vf_engine_time_iterate", "vf_engine_counts",
+]
+
+
+def lib():
+    """Load libvilfusion.so (built by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise VilFusionError(-7, f"{_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        l = C.CDLL(_SO)
+        l.vf_last_error.restype = C.c_char_p
+        l.vf_version.restype = C.c_char_p
+        l.vf_engine_destroy.restype = None
+        l.vf_engine_default_opts.restype = None
+        _lib = l
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise VilFusionError(rc, lib().vf_last_error().decode())

@@ -1,0 +1,515 @@
+// vf_engine.hip -- host side of the batch engine behind include/vilfusion.h.
+// Owns the HBM-resident problem (vf::View), stages host AoS records into the AoSoA device
+// layout, and sequences the hot-path kernels on one HIP stream.  There is no CPU fallback:
+// without a gfx950 device every entry point fails with VF_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vilfusion.h"
+#include "vf_kernels.hpp"
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(VF_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+}  // namespace
+
+struct vf_engine {
+    vf::View v{};
+    vf_engine_opts opts{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<void*> allocs;
+    double* stage = nullptr;  // device staging buffer (AoS)
+    size_t stage_bytes = 0;
+    double* sigma_dev = nullptr;
+    std::vector<int> h_lo, h_hi;  // host mirror of the active ranges
+
+    template <typename T>
+    int alloc(T** p, size_t n, bool zero = true) {
+        void* q = nullptr;
+        HIPCHK(hipMalloc(&q, n * sizeof(T)));
+        allocs.push_back(q);
+        if (zero) HIPCHK(hipMemsetAsync(q, 0, n * sizeof(T), stream));
+        *p = (T*)q;
+        return VF_OK;
+    }
+    int ensure_stage(size_t bytes) {
+        if (bytes <= stage_bytes) return VF_OK;
+        if (stage) HIPCHK(hipFree(stage));
+        stage = nullptr;
+        stage_bytes = 0;
+        HIPCHK(hipMalloc((void**)&stage, bytes));
+        stage_bytes = bytes;
+        return VF_OK;
+    }
+};
+
+extern "C" {
+
+const char* vf_last_error(void) { return g_err.c_str(); }
+const char* vf_version(void) { return "vilfusion-mi355x 0.1 (gfx950, float64)"; }
+
+int vf_device_count(int* count) {
+    if (!count) return fail(VF_ERR_INVALID, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(VF_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return VF_OK;
+}
+
+void vf_engine_default_opts(vf_engine_opts* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->windows = 1;
+    o->capacity = 1088;
+    o->bandwidth = 3;
+    o->device = 0;
+    o->gravity[0] = 0.0; o->gravity[1] = 0.0; o->gravity[2] = -9.81;
+    // gtsam::LevenbergMarquardtParams defaults (the optimiser commented out at
+    // GraphManager.cpp:128-129): lambdaInitial 1e-5, lambdaFactor 10
+    o->lambda0 = 1e-5; o->lambda_up = 10.0; o->lambda_down = 10.0;
+    o->lambda_min = 1e-12; o->lambda_max = 1e10;
+}
+
+int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
+    if (!o || !out) return fail(VF_ERR_INVALID, "null argument");
+    if (o->windows < 1 || o->capacity < 2) return fail(VF_ERR_INVALID, "windows >= 1 and capacity >= 2 required");
+    if (o->bandwidth < 1 || o->bandwidth > VF_MAX_BANDWIDTH)
+        return fail(VF_ERR_INVALID, "bandwidth must be in 1..%d", VF_MAX_BANDWIDTH);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(VF_ERR_NO_DEVICE, "no HIP device visible; libvilfusion has no CPU path");
+    if (o->device < 0 || o->device >= ndev) return fail(VF_ERR_INVALID, "device %d out of range (%d)", o->device, ndev);
+    HIPCHK(hipSetDevice(o->device));
+    vf_engine* e = new vf_engine();
+    e->opts = *o;
+    vf::View& v = e->v;
+    v.B = o->windows;
+    v.M = (o->capacity + 63) / 64 * 64;
+    v.G = (long)v.B * v.M;
+    for (int i = 0; i < 3; i++) v.grav[i] = o->gravity[i];
+    v.lam_up = o->lambda_up; v.lam_down = o->lambda_down; v.lam_min = o->lambda_min; v.lam_max = o->lambda_max;
+    HIPCHK(hipStreamCreate(&e->stream));
+    HIPCHK(hipEventCreate(&e->ev0));
+    HIPCHK(hipEventCreate(&e->ev1));
+    const size_t G = (size_t)v.G, tiles = G / 64;
+    int rc = VF_OK;
+#define AL(p, n) if ((rc = e->alloc(&(p), (n))) != VF_OK) { vf_engine_destroy(e); return rc; }
+    AL(v.x, 2 * 16 * G);
+    AL(v.imu_in, tiles * vf::IMU_IN * 64);
+    AL(v.imu_out, 2 * tiles * vf::IMU_OUT * 64);
+    AL(v.btw_a, G);
+    AL(v.btw_in, tiles * vf::BTW_IN * 64);
+    AL(v.btw_out, 2 * tiles * vf::BTW_OUT * 64);
+    AL(v.prior_k, (size_t)v.B);
+    AL(v.prior_in, (size_t)v.B * vf::PRIOR_IN);
+    AL(v.prior_out, 2 * (size_t)v.B * vf::PRIOR_OUT);
+    AL(v.H, G * vf::HROW);
+    AL(v.gvec, G * 15);
+    AL(v.delta, G * 15);
+    AL(v.Lp, G * vf::PANEL);
+    AL(v.lo, (size_t)v.B);
+    AL(v.hi, (size_t)v.B);
+    AL(v.sel, (size_t)v.B);
+    AL(v.fail, (size_t)v.B);
+    AL(v.lambda, (size_t)v.B);
+    AL(v.cost, (size_t)v.B);
+    AL(v.n_acc, (size_t)v.B);
+    AL(v.n_rej, (size_t)v.B);
+    AL(v.n_fail, (size_t)v.B);
+    AL(e->sigma_dev, 16);
+#undef AL
+    HIPCHK(hipMemsetAsync(v.btw_a, 0xff, G * sizeof(int), e->stream));   // -1 = empty slot
+    HIPCHK(hipMemsetAsync(v.prior_k, 0xff, v.B * sizeof(int), e->stream));
+    std::vector<double> lam((size_t)v.B, o->lambda0);
+    HIPCHK(hipMemcpyAsync(v.lambda, lam.data(), v.B * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->h_lo.assign(v.B, 0);
+    e->h_hi.assign(v.B, 0);
+    *out = e;
+    return VF_OK;
+}
+
+void vf_engine_destroy(vf_engine* e) {
+    if (!e) return;
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (void* p : e->allocs) (void)hipFree(p);
+    if (e->stage) (void)hipFree(e->stage);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+static int check_window(vf_engine* e, int window) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (window < 0 || window >= e->v.B) return fail(VF_ERR_INVALID, "window %d out of range", window);
+    return VF_OK;
+}
+static int check_range(vf_engine* e, int window, int k0, int n) {
+    int rc = check_window(e, window);
+    if (rc) return rc;
+    if (k0 < 0 || n < 0 || k0 + n > e->v.M) return fail(VF_ERR_BAD_KEY, "keyframes [%d,%d) outside capacity %d", k0, k0 + n, e->v.M);
+    return VF_OK;
+}
+
+int vf_engine_set_range(vf_engine* e, int window, int lo, int hi) {
+    int rc = check_window(e, window);
+    if (rc) return rc;
+    if (lo < 0 || hi < lo || hi > e->v.M) return fail(VF_ERR_BAD_KEY, "bad range [%d,%d)", lo, hi);
+    HIPCHK(hipMemcpyAsync(e->v.lo + window, &lo, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->v.hi + window, &hi, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->h_lo[window] = lo;
+    e->h_hi[window] = hi;
+    return VF_OK;
+}
+
+int vf_engine_set_states(vf_engine* e, int window, int k0, int n, const double* s) {
+    int rc = check_range(e, window, k0, n);
+    if (rc) return rc;
+    if (!s) return fail(VF_ERR_INVALID, "null states");
+    if (n == 0) return VF_OK;
+    const size_t bytes = (size_t)n * 16 * sizeof(double);
+    if ((rc = e->ensure_stage(bytes))) return rc;
+    HIPCHK(hipMemcpyAsync(e->stage, s, bytes, hipMemcpyHostToDevice, e->stream));
+    const long g0 = (long)window * e->v.M + k0;
+    // both buffers get the value so that "current" is well defined whatever sel is
+    vf::launch_scatter_states(e->stage, e->v.x, e->v.G, 0, g0, n, e->stream);
+    vf::launch_scatter_states(e->stage, e->v.x, e->v.G, 1, g0, n, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return VF_OK;
+}
+
+int vf_engine_get_states(vf_engine* e, int window, int k0, int n, double* s) {
+    int rc = check_range(e, window, k0, n);
+    if (rc) return rc;
+    if (!s) return fail(VF_ERR_INVALID, "null states");
+    if (n == 0) return VF_OK;
+    const size_t bytes = (size_t)n * 16 * sizeof(double);
+    if ((rc = e->ensure_stage(bytes))) return rc;
+    const long g0 = (long)window * e->v.M + k0;
+    vf::launch_gather_states(e->v.x, e->stage, e->v.G, e->v.sel, e->v.M, 0, g0, n, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(s, e->stage, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return VF_OK;
+}
+
+int vf_engine_set_imu(vf_engine* e, int window, int k0, int n, const double* rec) {
+    int rc = check_range(e, window, k0, n);
+    if (rc) return rc;
+    if (!rec) return fail(VF_ERR_INVALID, "null records");
+    if (n == 0) return VF_OK;
+    const size_t bytes = (size_t)n * vf::IMU_IN * sizeof(double);
+    if ((rc = e->ensure_stage(bytes))) return rc;
+    HIPCHK(hipMemcpyAsync(e->stage, rec, bytes, hipMemcpyHostToDevice, e->stream));
+    vf::launch_scatter(e->stage, e->v.imu_in, (long)window * e->v.M + k0, n, vf::IMU_IN, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return VF_OK;
+}
+
+int vf_engine_set_between(vf_engine* e, int window, int n, const int32_t* a, const int32_t* b, const double* rec) {
+    int rc = check_window(e, window);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!a || !b || !rec))) return fail(VF_ERR_INVALID, "null argument");
+    const int M = e->v.M, W = e->opts.bandwidth;
+    for (int i = 0; i < n; i++) {
+        if (a[i] < 0 || b[i] >= M || a[i] >= b[i]) return fail(VF_ERR_BAD_KEY, "between factor %d: need 0 <= a < b < capacity (a=%d b=%d)", i, a[i], b[i]);
+        if (b[i] - a[i] > W) return fail(VF_ERR_CAPACITY, "between factor %d spans %d keyframes > bandwidth %d", i, b[i] - a[i], W);
+    }
+    // records go to the slot of b: runs of consecutive b are staged in one scatter
+    int i = 0;
+    while (i < n) {
+        int j = i + 1;
+        while (j < n && b[j] == b[j - 1] + 1) j++;
+        const int cnt = j - i;
+        const size_t bytes = (size_t)cnt * vf::BTW_IN * sizeof(double);
+        if ((rc = e->ensure_stage(bytes))) return rc;
+        HIPCHK(hipMemcpyAsync(e->stage, rec + (size_t)i * vf::BTW_IN, bytes, hipMemcpyHostToDevice, e->stream));
+        const long g0 = (long)window * M + b[i];
+        vf::launch_scatter(e->stage, e->v.btw_in, g0, cnt, vf::BTW_IN, e->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(e->v.btw_a + g0, a + i, cnt * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        i = j;
+    }
+    return VF_OK;
+}
+
+int vf_engine_clear_between(vf_engine* e, int window, int k0, int n) {
+    int rc = check_range(e, window, k0, n);
+    if (rc) return rc;
+    if (n == 0) return VF_OK;
+    HIPCHK(hipMemsetAsync(e->v.btw_a + (long)window * e->v.M + k0, 0xff, n * sizeof(int), e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return VF_OK;
+}
+
+int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec) {
+    int rc = check_range(e, window, k, 1);
+    if (rc) return rc;
+    if (!rec) return fail(VF_ERR_INVALID, "null record");
+    for (int i = 0; i < 15; i++)
+        if (!(rec[16 + i] > 0.0)) return fail(VF_ERR_NOT_SPD, "prior sigma %d must be > 0", i);
+    HIPCHK(hipMemcpyAsync(e->v.prior_in + (size_t)window * vf::PRIOR_IN, rec, vf::PRIOR_IN * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->v.prior_k + window, &k, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return VF_OK;
+}
+
+// ------------------------------------------------------------------ stages
+int vf_engine_linearize(vf_engine* e, int which) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    which = which ? 1 : 0;
+    vf::launch_linearize_imu(e->v, which, e->stream);
+    vf::launch_linearize_between(e->v, which, e->stream);
+    vf::launch_linearize_prior(e->v, which, e->stream);
+    HIPCHK(hipGetLastError());
+    return VF_OK;
+}
+int vf_engine_assemble(vf_engine* e) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    vf::launch_assemble(e->v, e->stream);
+    HIPCHK(hipGetLastError());
+    return VF_OK;
+}
+int vf_engine_solve(vf_engine* e) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    vf::launch_band_solve(e->v, e->stream);
+    HIPCHK(hipGetLastError());
+    return VF_OK;
+}
+int vf_engine_retract(vf_engine* e) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    vf::launch_retract(e->v, e->stream);
+    HIPCHK(hipGetLastError());
+    return VF_OK;
+}
+int vf_engine_decide(vf_engine* e, int init) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    vf::launch_decide(e->v, init ? 1 : 0, e->stream);
+    HIPCHK(hipGetLastError());
+    return VF_OK;
+}
+int vf_engine_iterate(vf_engine* e, int iterations) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (iterations < 0) return fail(VF_ERR_INVALID, "iterations < 0");
+    // every solve starts from lambda0, as a fresh LevenbergMarquardtOptimizer would
+    std::vector<double> lam((size_t)e->v.B, e->opts.lambda0);
+    HIPCHK(hipMemcpyAsync(e->v.lambda, lam.data(), e->v.B * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    int rc;
+    if ((rc = vf_engine_linearize(e, 0))) return rc;
+    if ((rc = vf_engine_decide(e, 1))) return rc;
+    for (int it = 0; it < iterations; it++) {
+        if ((rc = vf_engine_assemble(e))) return rc;
+        if ((rc = vf_engine_solve(e))) return rc;
+        if ((rc = vf_engine_retract(e))) return rc;
+        if ((rc = vf_engine_linearize(e, 1))) return rc;
+        if ((rc = vf_engine_decide(e, 0))) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));  // lam is a host temporary
+    return VF_OK;
+}
+
+int vf_engine_predict(vf_engine* e, int window, int k0, int n) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (window >= e->v.B || k0 < 1 || n < 0 || k0 + n > e->v.M) return fail(VF_ERR_BAD_KEY, "bad predict range");
+    if (n == 0) return VF_OK;
+    vf::launch_predict(e->v, window, k0, n, e->stream);
+    HIPCHK(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_engine_slide(vf_engine* e, const double* prior_sigma15) {
+    if (!e || !prior_sigma15) return fail(VF_ERR_INVALID, "null argument");
+    for (int w = 0; w < e->v.B; w++)
+        if (e->h_hi[w] >= e->v.M) return fail(VF_ERR_CAPACITY, "window %d has no free keyframe slot", w);
+    HIPCHK(hipMemcpyAsync(e->sigma_dev, prior_sigma15, 15 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    vf::launch_slide(e->v, e->sigma_dev, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));  // sigma is a caller temporary
+    for (int w = 0; w < e->v.B; w++) { e->h_lo[w]++; e->h_hi[w]++; }
+    return VF_OK;
+}
+
+int vf_engine_sync(vf_engine* e) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return VF_OK;
+}
+
+// ------------------------------------------------------------------ read-back
+static int read_sel(vf_engine* e, int window, int* sel) {
+    HIPCHK(hipMemcpyAsync(sel, e->v.sel + window, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return VF_OK;
+}
+
+int vf_engine_read_imu_lin(vf_engine* e, int window, int which, int k0, int n, double* r15, double* J450) {
+    int rc = check_range(e, window, k0, n);
+    if (rc) return rc;
+    if (n == 0) return VF_OK;
+    int sel = 0;
+    if ((rc = read_sel(e, window, &sel))) return rc;
+    const int b = sel ^ (which ? 1 : 0);
+    const size_t bytes = (size_t)n * vf::IMU_OUT * sizeof(double);
+    if ((rc = e->ensure_stage(bytes))) return rc;
+    const double* src = e->v.imu_out + (size_t)b * (size_t)(e->v.G / 64) * vf::IMU_OUT * 64;
+    vf::launch_gather(src, e->stage, (long)window * e->v.M + k0, n, vf::IMU_OUT, e->stream);
+    HIPCHK(hipGetLastError());
+    std::vector<double> h((size_t)n * vf::IMU_OUT);
+    HIPCHK(hipMemcpyAsync(h.data(), e->stage, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < n; i++) {
+        if (r15) memcpy(r15 + (size_t)i * 15, h.data() + (size_t)i * vf::IMU_OUT, 15 * sizeof(double));
+        if (J450) memcpy(J450 + (size_t)i * 450, h.data() + (size_t)i * vf::IMU_OUT + 15, 450 * sizeof(double));
+    }
+    return VF_OK;
+}
+
+int vf_engine_read_between_lin(vf_engine* e, int window, int which, int k0, int n, double* r6, double* Ja, double* Jb) {
+    int rc = check_range(e, window, k0, n);
+    if (rc) return rc;
+    if (n == 0) return VF_OK;
+    int sel = 0;
+    if ((rc = read_sel(e, window, &sel))) return rc;
+    const int b = sel ^ (which ? 1 : 0);
+    const size_t bytes = (size_t)n * vf::BTW_OUT * sizeof(double);
+    if ((rc = e->ensure_stage(bytes))) return rc;
+    const double* src = e->v.btw_out + (size_t)b * (size_t)(e->v.G / 64) * vf::BTW_OUT * 64;
+    vf::launch_gather(src, e->stage, (long)window * e->v.M + k0, n, vf::BTW_OUT, e->stream);
+    HIPCHK(hipGetLastError());
+    std::vector<double> h((size_t)n * vf::BTW_OUT);
+    HIPCHK(hipMemcpyAsync(h.data(), e->stage, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < n; i++) {
+        const double* p = h.data() + (size_t)i * vf::BTW_OUT;
+        if (r6) memcpy(r6 + (size_t)i * 6, p, 6 * sizeof(double));
+        if (Ja) memcpy(Ja + (size_t)i * 36, p + 6, 36 * sizeof(double));
+        if (Jb) memcpy(Jb + (size_t)i * 36, p + 42, 36 * sizeof(double));
+    }
+    return VF_OK;
+}
+
+int vf_engine_read_normal(vf_engine* e, int window, int k0, int n, double* Hband, double* g15) {
+    int rc = check_range(e, window, k0, n);
+    if (rc) return rc;
+    if (n == 0) return VF_OK;
+    const size_t g0 = (size_t)window * e->v.M + k0;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (Hband) HIPCHK(hipMemcpy(Hband, e->v.H + g0 * vf::HROW, (size_t)n * vf::HROW * sizeof(double), hipMemcpyDeviceToHost));
+    if (g15) HIPCHK(hipMemcpy(g15, e->v.gvec + g0 * 15, (size_t)n * 15 * sizeof(double), hipMemcpyDeviceToHost));
+    return VF_OK;
+}
+
+int vf_engine_read_delta(vf_engine* e, int window, int k0, int n, double* d) {
+    int rc = check_range(e, window, k0, n);
+    if (rc) return rc;
+    if (n == 0 || !d) return VF_OK;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(d, e->v.delta + ((size_t)window * e->v.M + k0) * 15, (size_t)n * 15 * sizeof(double), hipMemcpyDeviceToHost));
+    return VF_OK;
+}
+
+int vf_engine_read_lm(vf_engine* e, int window, double* cost, double* lambda, int* acc, int* rej, int* fails) {
+    int rc = check_window(e, window);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (cost) HIPCHK(hipMemcpy(cost, e->v.cost + window, sizeof(double), hipMemcpyDeviceToHost));
+    if (lambda) HIPCHK(hipMemcpy(lambda, e->v.lambda + window, sizeof(double), hipMemcpyDeviceToHost));
+    if (acc) HIPCHK(hipMemcpy(acc, e->v.n_acc + window, sizeof(int), hipMemcpyDeviceToHost));
+    if (rej) HIPCHK(hipMemcpy(rej, e->v.n_rej + window, sizeof(int), hipMemcpyDeviceToHost));
+    if (fails) HIPCHK(hipMemcpy(fails, e->v.n_fail + window, sizeof(int), hipMemcpyDeviceToHost));
+    return VF_OK;
+}
+
+// ------------------------------------------------------------------ measurement
+int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms) {
+    if (!e || !avg_ms || reps < 1) return fail(VF_ERR_INVALID, "bad argument");
+    auto run = [&]() {
+        switch (stage) {
+            case VF_STAGE_LINEARIZE_IMU: vf::launch_linearize_imu(e->v, 0, e->stream); break;
+            case VF_STAGE_LINEARIZE_BTW: vf::launch_linearize_between(e->v, 0, e->stream); break;
+            case VF_STAGE_ASSEMBLE: vf::launch_assemble(e->v, e->stream); break;
+            case VF_STAGE_SOLVE: vf::launch_band_solve(e->v, e->stream); break;
+            case VF_STAGE_RETRACT: vf::launch_retract(e->v, e->stream); break;
+            case VF_STAGE_DECIDE: vf::launch_decide(e->v, 1, e->stream); break;
+            default: break;
+        }
+    };
+    if (stage < VF_STAGE_LINEARIZE_IMU || stage > VF_STAGE_DECIDE) return fail(VF_ERR_INVALID, "unknown stage %d", stage);
+    run();  // warm
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipEventRecord(e->ev0, e->stream));
+    for (int i = 0; i < reps; i++) run();
+    HIPCHK(hipEventRecord(e->ev1, e->stream));
+    HIPCHK(hipEventSynchronize(e->ev1));
+    HIPCHK(hipGetLastError());
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    *avg_ms = ms / reps;
+    return VF_OK;
+}
+
+int vf_engine_time_iterate(vf_engine* e, int iterations, float* ms) {
+    if (!e || !ms) return fail(VF_ERR_INVALID, "bad argument");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipEventRecord(e->ev0, e->stream));
+    int rc = vf_engine_iterate(e, iterations);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(e->ev1, e->stream));
+    HIPCHK(hipEventSynchronize(e->ev1));
+    HIPCHK(hipEventElapsedTime(ms, e->ev0, e->ev1));
+    return VF_OK;
+}
+
+int vf_engine_counts(vf_engine* e, int64_t* n_imu, int64_t* n_btw, int64_t* n_kf) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    std::vector<int> a((size_t)e->v.G);
+    HIPCHK(hipMemcpy(a.data(), e->v.btw_a, a.size() * sizeof(int), hipMemcpyDeviceToHost));
+    int64_t ni = 0, nb = 0, nk = 0;
+    for (int w = 0; w < e->v.B; w++) {
+        const int lo = e->h_lo[w], hi = e->h_hi[w];
+        if (hi <= lo) continue;
+        nk += hi - lo;
+        ni += hi - lo - 1;
+        for (int k = lo + 1; k < hi; k++) {
+            const int aa = a[(size_t)w * e->v.M + k];
+            if (aa >= lo && aa < k) nb++;
+        }
+    }
+    if (n_imu) *n_imu = ni;
+    if (n_btw) *n_btw = nb;
+    if (n_kf) *n_kf = nk;
+    return VF_OK;
+}
+
+}  // extern "C"

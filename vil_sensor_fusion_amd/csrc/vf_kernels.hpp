@@ -1,0 +1,64 @@
+// vf_kernels.hpp -- device view of an engine and the kernel launch interface.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vf {
+
+constexpr int TILE = 64;        // AoSoA tile = one wavefront of factors
+constexpr int IMU_IN = 190;     // dt, delta(9), bhat(6), H(54), R packed upper (120)
+constexpr int IMU_OUT = 465;    // r(15), J(15x30 row-major)
+constexpr int BTW_IN = 28;      // q(4), t(3), R packed upper (21)
+constexpr int BTW_OUT = 78;     // r(6), Ja(36), Jb(36)
+constexpr int PRIOR_IN = 31;    // mean state (16), sigma (15)
+constexpr int PRIOR_OUT = 240;  // r(15), J(15x15)
+constexpr int NBLK = 4;         // band blocks stored per keyframe (bandwidth 3 + diagonal)
+constexpr int HROW = NBLK * 225;
+constexpr int PANEL = 61 * 15;  // Cholesky panel rows 0..59 + forward-substituted rhs row
+
+// Device-resident problem: B windows x M keyframe slots (G = B*M).  See DESIGN.md.
+struct View {
+    int B, M;
+    long G;
+    double grav[3];
+    double* x;          // [2][16][G]          states, SoA, double-buffered (current / trial)
+    double* imu_in;     // [G/64][190][64]     AoSoA
+    double* imu_out;    // [2][G/64][465][64]  AoSoA, double-buffered
+    int* btw_a;         // [G]                 local index of key a (b = slot), -1 = empty
+    double* btw_in;     // [G/64][28][64]
+    double* btw_out;    // [2][G/64][78][64]
+    int* prior_k;       // [B]                 local keyframe index, -1 = none
+    double* prior_in;   // [B][31]
+    double* prior_out;  // [2][B][240]
+    double* H;          // [G][4][15][15]      block d of row k = H[k][k-d]
+    double* gvec;       // [G][15]
+    double* delta;      // [G][15]
+    double* Lp;         // [G][61][15]         Cholesky panels + y
+    int* lo;            // [B] active range [lo, hi)
+    int* hi;
+    int* sel;           // [B] which buffer is current
+    int* fail;          // [B] solve failure flag of the current trial
+    double* lambda;     // [B]
+    double* cost;       // [B]
+    int* n_acc;         // [B]
+    int* n_rej;
+    int* n_fail;
+    double lam_up, lam_down, lam_min, lam_max;
+};
+
+void launch_linearize_imu(const View& v, int which, hipStream_t s);
+void launch_linearize_between(const View& v, int which, hipStream_t s);
+void launch_linearize_prior(const View& v, int which, hipStream_t s);
+void launch_assemble(const View& v, hipStream_t s);
+void launch_band_solve(const View& v, hipStream_t s);
+void launch_retract(const View& v, hipStream_t s);
+void launch_decide(const View& v, int init, hipStream_t s);
+void launch_predict(const View& v, int window, int k0, int n, hipStream_t s);
+void launch_slide(const View& v, const double* sigma15_dev, hipStream_t s);
+// AoS <-> AoSoA staging
+void launch_scatter(const double* aos, double* aosoa, long g0, long n, int nf, hipStream_t s);
+void launch_gather(const double* aosoa, double* aos, long g0, long n, int nf, hipStream_t s);
+void launch_scatter_states(const double* aos, double* x, long G, int buf, long g0, long n, hipStream_t s);
+void launch_gather_states(const double* x, double* aos, long G, const int* sel, int M, int which, long g0, long n, hipStream_t s);
+
+}  // namespace vf

@@ -1,0 +1,172 @@
+"""Python handle on the batch engine of libvilfusion.so (numpy in / numpy out).
+
+Mirrors the C ABI one to one (include/vilfusion.h); all arithmetic happens on the GPU."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+IMU_RECORD, BTW_RECORD, PRIOR_RECORD = 190, 28, 31
+STAGES = {"linearize_imu": 1, "linearize_between": 2, "assemble": 3, "solve": 4, "retract": 5,
+          "decide": 6}
+# GraphManager.cpp:27-31: pose (rad x3, m x3), velocity, bias prior sigmas
+REFERENCE_PRIOR_SIGMAS = np.array([1e-6] * 3 + [5e-5] * 3 + [1e-5] * 3 + [1e-7] * 6)
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+@dataclass
+class EngineOpts:
+    windows: int = 1
+    capacity: int = 1088
+    bandwidth: int = 3
+    device: int = 0
+    gravity: tuple = (0.0, 0.0, -9.81)
+    lambda0: float = 1e-5
+    lambda_up: float = 10.0
+    lambda_down: float = 10.0
+    lambda_min: float = 1e-12
+    lambda_max: float = 1e10
+
+
+class Engine:
+    def __init__(self, opts: EngineOpts = EngineOpts()):
+        self._l = _lib.lib()
+        o = _lib.EngineOptsC()
+        self._l.vf_engine_default_opts(C.byref(o))
+        o.windows, o.capacity, o.bandwidth, o.device = opts.windows, opts.capacity, opts.bandwidth, opts.device
+        o.gravity[:] = list(opts.gravity)
+        o.lambda0, o.lambda_up, o.lambda_down = opts.lambda0, opts.lambda_up, opts.lambda_down
+        o.lambda_min, o.lambda_max = opts.lambda_min, opts.lambda_max
+        self._h = C.c_void_p()
+        check(self._l.vf_engine_create(C.byref(o), C.byref(self._h)))
+        self.opts = opts
+        self.capacity = (opts.capacity + 63) // 64 * 64
+        self.windows = opts.windows
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.vf_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- staging
+    def set_range(self, window, lo, hi):
+        check(self._l.vf_engine_set_range(self._h, window, lo, hi))
+
+    def set_states(self, window, k0, states):
+        s = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 16)
+        check(self._l.vf_engine_set_states(self._h, window, k0, s.shape[0], _d(s)))
+
+    def get_states(self, window, k0, n):
+        s = np.zeros((n, 16))
+        check(self._l.vf_engine_get_states(self._h, window, k0, n, _d(s)))
+        return s
+
+    def set_imu(self, window, k0, rec):
+        r = np.ascontiguousarray(rec, dtype=np.float64).reshape(-1, IMU_RECORD)
+        check(self._l.vf_engine_set_imu(self._h, window, k0, r.shape[0], _d(r)))
+
+    def set_between(self, window, a, b, rec):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        b = np.ascontiguousarray(b, dtype=np.int32)
+        r = np.ascontiguousarray(rec, dtype=np.float64).reshape(-1, BTW_RECORD)
+        assert a.size == b.size == r.shape[0]
+        check(self._l.vf_engine_set_between(self._h, window, a.size, _i(a), _i(b), _d(r)))
+
+    def clear_between(self, window, k0, n):
+        check(self._l.vf_engine_clear_between(self._h, window, k0, n))
+
+    def set_prior(self, window, k, rec):
+        r = np.ascontiguousarray(rec, dtype=np.float64).reshape(PRIOR_RECORD)
+        check(self._l.vf_engine_set_prior(self._h, window, k, _d(r)))
+
+    # ---- stages
+    def linearize(self, which=0):
+        check(self._l.vf_engine_linearize(self._h, which))
+
+    def assemble(self):
+        check(self._l.vf_engine_assemble(self._h))
+
+    def solve(self):
+        check(self._l.vf_engine_solve(self._h))
+
+    def retract(self):
+        check(self._l.vf_engine_retract(self._h))
+
+    def decide(self, init=False):
+        check(self._l.vf_engine_decide(self._h, int(init)))
+
+    def iterate(self, iterations):
+        check(self._l.vf_engine_iterate(self._h, iterations))
+
+    def slide(self, prior_sigma=REFERENCE_PRIOR_SIGMAS):
+        s = np.ascontiguousarray(prior_sigma, dtype=np.float64)
+        check(self._l.vf_engine_slide(self._h, _d(s)))
+
+    def predict(self, window, k0, n):
+        check(self._l.vf_engine_predict(self._h, window, k0, n))
+
+    def sync(self):
+        check(self._l.vf_engine_sync(self._h))
+
+    # ---- read-back
+    def read_imu_lin(self, window, k0, n, which=0):
+        r, J = np.zeros((n, 15)), np.zeros((n, 15, 30))
+        check(self._l.vf_engine_read_imu_lin(self._h, window, which, k0, n, _d(r), _d(J)))
+        return r, J
+
+    def read_between_lin(self, window, k0, n, which=0):
+        r, Ja, Jb = np.zeros((n, 6)), np.zeros((n, 6, 6)), np.zeros((n, 6, 6))
+        check(self._l.vf_engine_read_between_lin(self._h, window, which, k0, n, _d(r), _d(Ja), _d(Jb)))
+        return r, Ja, Jb
+
+    def read_normal(self, window, k0, n):
+        H, g = np.zeros((n, 4, 15, 15)), np.zeros((n, 15))
+        check(self._l.vf_engine_read_normal(self._h, window, k0, n, _d(H), _d(g)))
+        return H, g
+
+    def read_delta(self, window, k0, n):
+        d = np.zeros((n, 15))
+        check(self._l.vf_engine_read_delta(self._h, window, k0, n, _d(d)))
+        return d
+
+    def read_lm(self, window):
+        cost, lam = C.c_double(), C.c_double()
+        acc, rej, fails = C.c_int(), C.c_int(), C.c_int()
+        check(self._l.vf_engine_read_lm(self._h, window, C.byref(cost), C.byref(lam), C.byref(acc),
+                                        C.byref(rej), C.byref(fails)))
+        return dict(cost=cost.value, lam=lam.value, accepted=acc.value, rejected=rej.value,
+                    solve_failures=fails.value)
+
+    # ---- measurement
+    def time_stage(self, stage, reps=10):
+        ms = C.c_float()
+        check(self._l.vf_engine_time_stage(self._h, STAGES[stage], reps, C.byref(ms)))
+        return ms.value
+
+    def time_iterate(self, iterations):
+        ms = C.c_float()
+        check(self._l.vf_engine_time_iterate(self._h, iterations, C.byref(ms)))
+        return ms.value
+
+    def counts(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        check(self._l.vf_engine_counts(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(imu=a.value, between=b.value, keyframes=c.value)

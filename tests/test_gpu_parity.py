@@ -84,7 +84,24 @@ def test_assemble_parity(setup, oracle):
         assert abs(eng.read_lm(w)["cost"] - cost) <= 1e-10 * cost
 
 
+def band_matvec(H, lam, x):
+    """(H + lam I) x for the block-banded storage (block d of row k = H[k][k-d])."""
+    n = H.shape[0]
+    y = lam * x.copy()
+    for k in range(n):
+        y[k] += H[k, 0] @ x[k]
+        for d in range(1, min(k, 3) + 1):
+            y[k] += H[k, d] @ x[k - d]
+            y[k - d] += H[k, d].T @ x[k]
+    return y
+
+
 def test_band_solve_parity(setup, oracle):
+    """The normal equations are ill conditioned (prior information 1e14 next to between-factor
+    information 1e1), so two correct Cholesky orderings agree only to cond*eps in the step.
+    Gate: (a) the GPU step solves the GPU's own system to backward-stable accuracy, in extended
+    precision; (b) it is at least as accurate as the oracle's scalar banded Cholesky; (c) the
+    two steps agree to 1e-3 relative (forward error, printed)."""
     eng, probs = setup
     eng.linearize(0)
     eng.assemble()
@@ -94,11 +111,15 @@ def test_band_solve_parity(setup, oracle):
         d = eng.read_delta(w, 0, N)
         rc, do = oracle.band_solve(H, g, 1e-5)
         assert rc == 0
-        # compare in the energy norm-free way: relative to the largest step component
-        print("band solve relative error", relerr(d, do))
-        assert relerr(d, do) < 1e-7
-        # and the residual of the linear system the GPU claims to have solved
-        win = helpers.oracle_window(oracle, probs[w])
+        Hl, gl = H.astype(np.longdouble), g.astype(np.longdouble)
+        res_gpu = band_matvec(Hl, np.longdouble(1e-5), d.astype(np.longdouble)) + gl
+        res_or = band_matvec(Hl, np.longdouble(1e-5), do.astype(np.longdouble)) + gl
+        scale = np.abs(gl).max()
+        bg, bo = float(np.abs(res_gpu).max() / scale), float(np.abs(res_or).max() / scale)
+        print(f"band solve: backward error gpu {bg:.3e} oracle {bo:.3e}; forward diff {relerr(d, do):.3e}")
+        assert bg < 1e-9
+        assert bg < 50 * bo + 1e-13
+        assert relerr(d, do) < 1e-3
         assert eng.read_lm(w)["solve_failures"] == 0
 
 

@@ -79,6 +79,19 @@ int vf_engine_clear_between(vf_engine* e, int window, int k0, int n);
 /* the three priors of GraphManager.cpp:27-35 as one diagonal 15-row factor on keyframe k */
 int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec31);
 
+/* K0: IMU preintegration on the device.  Factor i (keyframe k0+i) integrates
+ * steps[step_off[i] .. step_off[i+1]) (7 doubles each: dt, acc xyz, gyro xyz) with bias estimate
+ * bias_hat6[i]; the result (mean, bias Jacobians, R = chol_upper(preintMeasCov^-1)) lands in the
+ * factor's device record.  Replaces PreintegratedCombinedMeasurements::resetIntegrationAndSetBias
+ * + integrateMeasurement as driven by IMUManager::getFactor (IMUManager.cpp:42-64). */
+typedef struct {
+    double acc_cov, gyro_cov, integration_cov;          /* ImuManagerRos.cpp:22-24,30-32 */
+    double bias_acc_cov, bias_omega_cov, bias_acc_omega_int; /* ImuManagerRos.cpp:20-21,25,28-29,33 */
+} vf_imu_params;
+int vf_engine_preintegrate(vf_engine* e, int window, int k0, int n, const int32_t* step_off,
+                           const double* steps7, const double* bias_hat6, const vf_imu_params* p);
+int vf_engine_get_imu(vf_engine* e, int window, int k0, int n, double* rec190);
+
 /* ---- hot-path stages (asynchronous on the engine's HIP stream) ---- */
 /* K1+K2+priors: residual + whitened Jacobian of every factor, at the current (which=0) or
  * trial (which=1) states.  Replaces the linearisation inside ISAM2::update
@@ -107,6 +120,10 @@ int vf_engine_read_between_lin(vf_engine* e, int window, int which, int k0, int 
                                double* Ja36, double* Jb36);
 int vf_engine_read_normal(vf_engine* e, int window, int k0, int n, double* Hband, double* g15);
 int vf_engine_read_delta(vf_engine* e, int window, int k0, int n, double* delta15);
+/* Cholesky panels of the last vf_engine_solve: per keyframe 43x15 row-major = rows of L in the
+ * keyframe's 15 columns for [k:15][k+1:15][k+2:pose 6][k+3:pose 6] + the forward-substituted
+ * rhs row; the diagonal entries hold 1/L_cc. */
+int vf_engine_read_panels(vf_engine* e, int window, int k0, int n, double* panels645);
 int vf_engine_read_lm(vf_engine* e, int window, double* cost, double* lambda, int* accepted,
                       int* rejected, int* solve_failures);
 
@@ -121,6 +138,56 @@ int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms);
 /* HIP-event time of a whole vf_engine_iterate(iterations) */
 int vf_engine_time_iterate(vf_engine* e, int iterations, float* ms);
 int vf_engine_counts(vf_engine* e, int64_t* n_imu, int64_t* n_between, int64_t* n_keyframes);
+
+/* ===================================================================== GraphManager surface
+ * Drop-in for VILFusion::GraphManager + VILFusion::IMUManager.  ROS-free, usable in simulated
+ * time, every call thread-safe (GraphManager.h:4-6): the same two-lock discipline as the
+ * reference (_graphMutex for ingestion, _stateMutex for the estimate; GraphManager.h:103-104),
+ * vf_solve releases the ingestion lock before optimising and runs callbacks on the solving
+ * thread inside the state lock (GraphManager.cpp:104-138). */
+typedef struct vf_graph vf_graph;
+
+typedef struct {
+    int capacity;    /* keyframe slots on the device (keys 0..capacity-1) */
+    int lag;         /* fixed-lag window length in keyframes; 0 = smooth the whole history */
+    int iterations;  /* LM trials per vf_solve */
+    int device;
+    double prior_sigma[15]; /* X0/V0/B0 prior sigmas; default GraphManager.cpp:27-31 */
+} vf_graph_opts;
+
+/* (time, pose q_wxyz, position, velocity, bias[acc,gyro]) -- GraphManager::OptimizationCallback
+ * (GraphManager.h:38) */
+typedef void (*vf_callback)(void* user, double time, const double q[4], const double t[3],
+                            const double v[3], const double bias[6]);
+
+void vf_graph_default_opts(vf_graph_opts* o);
+/* GraphManager::GraphManager(imuManager) + IMUManager::IMUManager(params) + getImuParams
+ * (GraphManager.cpp:15-44, IMUManager.cpp:13-17, ImuManagerRos.cpp:14-36) */
+int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** out);
+void vf_destroy(vf_graph* g);
+/* IMUManager::addIMUMeasurement (IMUManager.cpp:19-25) */
+int vf_add_imu(vf_graph* g, double time, const double acc[3], const double gyro[3]);
+/* GraphManager::reserveNode (GraphManager.cpp:51-69): 1-based key, key 0 is the prior node */
+int vf_reserve_node(vf_graph* g, double time, uint64_t* key_out);
+/* GraphManager::addBetweenFactor (GraphManager.cpp:83-88) with noiseModel::Gaussian::Covariance
+ * (SensorManagerRos.cpp:99); cov is 6x6 row-major in Pose3 tangent order [rot, trans] */
+int vf_add_between(vf_graph* g, uint64_t prev_key, uint64_t cur_key, const double q_wxyz[4],
+                   const double t[3], const double cov36[36]);
+/* GraphManager::solve (GraphManager.cpp:101-141) */
+int vf_solve(vf_graph* g);
+/* GraphManager::getState / getBias / getMostRecentPoseTime (GraphManager.cpp:164-178, 71-75) */
+int vf_get_state(vf_graph* g, double q[4], double t[3], double v[3], double bias[6]);
+int vf_get_bias(vf_graph* g, double bias[6]);
+int vf_most_recent_pose_time(vf_graph* g, double* time, uint64_t* key);
+/* GraphManager::addOptimizationCallback (GraphManager.cpp:96-99) */
+int vf_set_callback(vf_graph* g, vf_callback cb, void* user);
+/* GraphManager::graph()->size(): factors staged since the last solve (3 priors at start +
+ * between factors; IMU factors wait in the queue, GraphManager.cpp:66,150) and the queue length */
+int vf_graph_staged(vf_graph* g, int* staged_factors, int* queued_imu_factors);
+/* smoothed states of keys [key0, key0+n) after the last solve (extra; iSAM2 calculateEstimate) */
+int vf_get_trajectory(vf_graph* g, uint64_t key0, int n, double* state16);
+/* preintegrated record of the factor ending at `key` (extra; firstFactor->preintegratedMeasurements()) */
+int vf_get_imu_factor(vf_graph* g, uint64_t key, double* rec190);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,152 @@
+"""-m gpu: K0 (device preintegration) and the GraphManager C ABI against the oracle and the
+reference's known answers (gtsam_fusion/test/UnitTests.cpp)."""
+import numpy as np
+import pytest
+
+from tests import helpers
+from vil_sensor_fusion_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_preintegrate_parity(oracle):
+    """K0 vs the oracle's PreintegratedCombinedMeasurements restatement: mean, bias Jacobians and
+    R = chol_upper(cov^-1).  Tolerances: 1e-12 relative on mean/H, 1e-9 on R (R comes from two
+    different but mathematically identical routes: cov^-1 -> LLT (oracle, as GTSAM) vs reverse
+    Cholesky -> triangular inverse (device); they agree to cond(cov) * eps)."""
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    n = 64
+    seq = synth.make_sequence(3, n)
+    eng = Engine(EngineOpts(windows=1, capacity=n))
+    bias = np.array([0.01, -0.02, 0.015, 0.002, 0.001, -0.003])
+    eng.preintegrate(0, 1, seq.imu_off[1:], seq.imu_steps, bias, synth.CARLA_IMU_COV)
+    got = eng.get_imu(0, 1, n - 1)
+    prm = oracle.carla_imu_params()
+    worst = dict(mean=0.0, H=0.0, R=0.0, info=0.0)
+    for k in range(1, n):
+        p = oracle.pim_new(bias)
+        for s in seq.imu_steps[seq.imu_off[k]:seq.imu_off[k + 1]]:
+            oracle.pim_integrate(p, prm, s[1:4], s[4:7], s[0])
+        rec = oracle.pim_to_record(p)
+        g = got[k - 1]
+        worst["mean"] = max(worst["mean"], np.abs(g[:16] - rec[:16]).max() / np.abs(rec[:16]).max())
+        worst["H"] = max(worst["H"], np.abs(g[16:70] - rec[16:70]).max() / np.abs(rec[16:70]).max())
+        worst["R"] = max(worst["R"], np.abs(g[70:] - rec[70:]).max() / np.abs(rec[70:]).max())
+        Rg, Ro = oracle.unpack_upper(g[70:], 15), oracle.unpack_upper(rec[70:], 15)
+        cov = oracle.pim_fields(p)["cov"]
+        worst["info"] = max(worst["info"], np.abs(Rg.T @ Rg @ cov - np.eye(15)).max())
+    print("K0 worst relative errors", worst)
+    assert worst["mean"] < 1e-12 and worst["H"] < 1e-12 and worst["R"] < 1e-9 and worst["info"] < 1e-7
+
+
+def test_kat_imu_manager_test1():
+    """UnitTests.cpp:58-66 through the C ABI: dV = 0.0175, dP = 0.0011875 on every axis."""
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    gm = GraphManager(capacity=64)
+    for t, a in ((0.0, 0.0), (0.1, 0.1), (0.2, 0.2)):
+        gm.addIMUMeasurement(t, [a] * 3, [a] * 3)
+    key = gm.reserveNode(0.15)
+    assert key == 1 and gm.getMostRecentPoseTime() == (0.15, 1)
+    assert gm.graphSize() == 3 and gm.imuQueueSize() == 1      # priors staged, IMU factor queued
+    gm.solve()
+    assert gm.graphSize() == 0 and gm.imuQueueSize() == 0      # GraphManager.cpp:112-113
+    rec = gm.imuFactor(1)
+    np.testing.assert_allclose(rec[0], 0.15, rtol=1e-15)
+    np.testing.assert_allclose(rec[7:10], 0.0175, rtol=1e-6)   # EXPECT_FLOAT_EQ
+    np.testing.assert_allclose(rec[4:7], 0.0011875, rtol=1e-6)
+    np.testing.assert_allclose(rec[7:10], 0.0175, rtol=1e-13)
+    np.testing.assert_allclose(rec[4:7], 0.0011875, rtol=1e-13)
+
+
+def _drive(gm_factory, oracle, seq, solve_every=10):
+    """Feed a synthetic sequence through the GraphManager API as the ROS node would."""
+    from vil_sensor_fusion_amd.sensor_manager import Odometry, SensorManager
+    gm = gm_factory()
+    got = []
+    gm.addOptimizationCallback(lambda t, q, p, v, b: got.append((t, q.copy(), p.copy(), v.copy(), b.copy())))
+    return gm, got
+
+
+def test_graph_manager_end_to_end_vs_oracle(oracle):
+    """Whole API path (IMU ingest -> reserveNode -> addBetweenFactor -> solve) on a synthetic
+    clip, compared with the oracle solving the same graph built from the same raw data."""
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    n = 80
+    seq = synth.make_sequence(5, n)
+    gm = GraphManager(capacity=128, iterations=6)
+    calls = []
+    gm.addOptimizationCallback(lambda t, q, p, v, b: calls.append(t))
+    # raw IMU stream re-created from the per-factor steps is not possible (steps are already cut),
+    # so feed the generator's own samples
+    traj_t = synth.IMU_PHASE + np.arange(0, int((seq.kf_time[-1] + 0.5) * synth.IMU_RATE)) / synth.IMU_RATE
+    traj = synth.Trajectory(seq.seed, seq.kf_time[-1] + 1.0)
+    rng = np.random.default_rng([seq.seed, 0xBEEF])
+    acc = traj.specific_force(traj_t) + rng.normal(size=(traj_t.size, 3)) * synth.IMU_NOISE
+    gyr = traj.body_rate(traj_t) + rng.normal(size=(traj_t.size, 3)) * synth.IMU_NOISE
+    # the anchor X(0) of the GraphManager is identity at the first buffered IMU stamp; shift the
+    # problem so that keyframe 0 of the sequence is that anchor: only relative quantities matter
+    # for the comparison with the oracle, which gets the same anchor.
+    i_imu = 0
+    keys = {}
+    # first IMU sample defines the start of the first factor (IMUManager.cpp:76-79)
+    for k in range(1, n):
+        while i_imu < traj_t.size and traj_t[i_imu] <= seq.kf_time[k] + 0.01:
+            gm.addIMUMeasurement(traj_t[i_imu], acc[i_imu], gyr[i_imu]); i_imu += 1
+        keys[k] = gm.reserveNode(seq.kf_time[k])
+        assert keys[k] == k
+        for a, b, q, t, c in zip(seq.btw_a, seq.btw_b, seq.btw_q, seq.btw_t, seq.btw_cov):
+            if b == k and a >= 1:
+                gm.addBetweenFactor(keys[a], keys[b], (q, t), np.eye(6) * c)
+    gm.solve()
+    assert len(calls) == 1 and calls[0] == seq.kf_time[n - 1]
+    xs = gm.trajectory(0, n)
+    # oracle on the identical graph: same IMU cutting rule, zero bias estimate, identity anchor
+    prm = oracle.carla_imu_params()
+    recs = np.zeros((n, 190)); head = 0
+    t_all = traj_t[:i_imu]
+    start = t_all[0]
+    for k in range(1, n):
+        pim, head, _ = oracle.imu_get_factor(t_all, acc[:i_imu], gyr[:i_imu], head, start, seq.kf_time[k], np.zeros(6), prm)
+        # only samples ingested before reserveNode(k) were visible to the GraphManager
+        recs[k] = oracle.pim_to_record(pim)
+        start = seq.kf_time[k]
+    # visibility: reserveNode(k) saw samples up to kf_time[k] + 0.01 -> the interpolating sample exists
+    np.testing.assert_allclose(gm.imuFactor(5)[:16], recs[5][:16], rtol=1e-11, atol=1e-14)
+    g = np.array([0, 0, -9.81])
+    states = np.zeros((n, 16)); states[0, 0] = 1.0
+    for k in range(1, n):
+        states[k] = oracle.predict(recs[k], g, states[k - 1])
+    m = seq.btw_a >= 1
+    from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
+    prob = dict(n=n, states=states, imu=recs, btw_a=seq.btw_a[m], btw_b=seq.btw_b[m],
+                btw=synth.between_records(seq)[m],
+                prior=synth.prior_record(states[0], REFERENCE_PRIOR_SIGMAS), gravity=g)
+    win = helpers.oracle_window(oracle, prob)
+    costs, acc_flags, _ = win.lm(iterations=6)
+    ate, rot = helpers.ate(xs, win.states)
+    print(f"GraphManager vs oracle: ATE {ate:.3e} m, rot {rot:.3e} rad, oracle cost {costs[0]:.3e} -> {costs[-1]:.3e}")
+    assert ate <= 1e-6 and rot <= 1e-6
+    (q, t), v, b = gm.getState()
+    np.testing.assert_allclose(t, xs[-1, 4:7])
+    np.testing.assert_allclose(gm.getBias(), xs[-1, 10:16])
+
+
+def test_graph_manager_errors():
+    from vil_sensor_fusion_amd import VilFusionError
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    gm = GraphManager(capacity=64)
+    with pytest.raises(VilFusionError) as ei:
+        gm.reserveNode(0.1)                       # no IMU buffered (reference: UB on empty deque)
+    assert ei.value.code == -4
+    gm.addIMUMeasurement(0.0, [0, 0, 9.81], [0, 0, 0])
+    gm.addIMUMeasurement(0.05, [0, 0, 9.81], [0, 0, 0])
+    k1 = gm.reserveNode(0.04)
+    with pytest.raises(VilFusionError) as ei:
+        gm.addBetweenFactor(1, 1, ([1, 0, 0, 0], [0, 0, 0]), np.eye(6))
+    assert ei.value.code == -2
+    with pytest.raises(VilFusionError) as ei:
+        gm.addBetweenFactor(0, 1, ([1, 0, 0, 0], [0, 0, 0]), -np.eye(6))
+    assert ei.value.code == -3
+    gm.solve()
+    (q, t), v, b = gm.getState()
+    assert abs(np.linalg.norm(q) - 1) < 1e-12

@@ -25,6 +25,20 @@ class EngineOptsC(C.Structure):
                 ("lambda_min", C.c_double), ("lambda_max", C.c_double)]
 
 
+class ImuParamsC(C.Structure):
+    _fields_ = [("acc_cov", C.c_double), ("gyro_cov", C.c_double), ("integration_cov", C.c_double),
+                ("bias_acc_cov", C.c_double), ("bias_omega_cov", C.c_double),
+                ("bias_acc_omega_int", C.c_double)]
+
+
+class GraphOptsC(C.Structure):
+    _fields_ = [("capacity", C.c_int), ("lag", C.c_int), ("iterations", C.c_int), ("device", C.c_int),
+                ("prior_sigma", C.c_double * 15)]
+
+
+CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                       C.POINTER(C.c_double), C.POINTER(C.c_double))
+
 _lib = None
 
 # every symbol include/vilfusion.h declares (checked by tests/test_abi.py)
@@ -37,8 +51,12 @@ SYMBOLS = [
     "vf_engine_decide", "vf_engine_iterate", "vf_engine_slide", "vf_engine_predict",
     "vf_engine_sync",
     "vf_engine_read_imu_lin", "vf_engine_read_between_lin", "vf_engine_read_normal",
-    "vf_engine_read_delta", "vf_engine_read_lm",
+    "vf_engine_read_delta", "vf_engine_read_panels", "vf_engine_read_lm",
     "vf_engine_time_stage", "vf_engine_time_iterate", "vf_engine_counts",
+    "vf_engine_preintegrate", "vf_engine_get_imu",
+    "vf_graph_default_opts", "vf_create", "vf_destroy", "vf_add_imu", "vf_reserve_node",
+    "vf_add_between", "vf_solve", "vf_get_state", "vf_get_bias", "vf_most_recent_pose_time",
+    "vf_set_callback", "vf_graph_staged", "vf_get_trajectory", "vf_get_imu_factor",
 ]
 
 
@@ -53,6 +71,8 @@ def lib():
         l.vf_version.restype = C.c_char_p
         l.vf_engine_destroy.restype = None
         l.vf_engine_default_opts.restype = None
+        l.vf_graph_default_opts.restype = None
+        l.vf_destroy.restype = None
         _lib = l
     return _lib
 

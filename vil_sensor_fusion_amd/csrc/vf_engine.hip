@@ -67,6 +67,7 @@ struct vf_engine {
 extern "C" {
 
 const char* vf_last_error(void) { return g_err.c_str(); }
+void vf_set_last_error_(const char* msg) { g_err = msg ? msg : ""; }  // used by vf_graph.cpp
 const char* vf_version(void) { return "vilfusion-mi355x 0.1 (gfx950, float64)"; }
 
 int vf_device_count(int* count) {
@@ -284,6 +285,50 @@ int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec) {
     return VF_OK;
 }
 
+int vf_engine_preintegrate(vf_engine* e, int window, int k0, int n, const int32_t* off, const double* steps,
+                           const double* bhat, const vf_imu_params* p) {
+    int rc = check_range(e, window, k0, n);
+    if (rc) return rc;
+    if (!off || !bhat || !p) return fail(VF_ERR_INVALID, "null argument");
+    if (n == 0) return VF_OK;
+    if (k0 < 1) return fail(VF_ERR_BAD_KEY, "imu factor slot 0 does not exist (factor k links k-1 -> k)");
+    const int total = off[n];
+    if (off[0] < 0 || total < off[0] || (total > 0 && !steps)) return fail(VF_ERR_INVALID, "bad step offsets");
+    for (int i = 0; i < n; i++)
+        if (off[i + 1] <= off[i]) return fail(VF_ERR_INDETERMINATE, "imu factor for keyframe %d has no IMU steps", k0 + i);
+    int* d_off = nullptr; double* d_steps = nullptr; double* d_bhat = nullptr; int* d_status = nullptr;
+    HIPCHK(hipMalloc((void**)&d_off, (n + 1) * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&d_steps, (size_t)(total > 0 ? total : 1) * 7 * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&d_bhat, (size_t)n * 6 * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&d_status, sizeof(int)));
+    HIPCHK(hipMemcpyAsync(d_off, off, (n + 1) * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    if (total > 0) HIPCHK(hipMemcpyAsync(d_steps, steps, (size_t)total * 7 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d_bhat, bhat, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int), e->stream));
+    vf::ImuCov c{p->acc_cov, p->gyro_cov, p->integration_cov, p->bias_acc_cov, p->bias_omega_cov, p->bias_acc_omega_int};
+    vf::launch_preintegrate(e->v, (long)window * e->v.M + k0, n, d_off, d_steps, d_bhat, c, d_status, e->stream);
+    HIPCHK(hipGetLastError());
+    int status = 0;
+    HIPCHK(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    (void)hipFree(d_off); (void)hipFree(d_steps); (void)hipFree(d_bhat); (void)hipFree(d_status);
+    if (status) return fail(VF_ERR_NOT_SPD, "preintegrated covariance not positive definite");
+    return VF_OK;
+}
+
+int vf_engine_get_imu(vf_engine* e, int window, int k0, int n, double* rec) {
+    int rc = check_range(e, window, k0, n);
+    if (rc) return rc;
+    if (n == 0 || !rec) return VF_OK;
+    const size_t bytes = (size_t)n * vf::IMU_IN * sizeof(double);
+    if ((rc = e->ensure_stage(bytes))) return rc;
+    vf::launch_gather(e->v.imu_in, e->stage, (long)window * e->v.M + k0, n, vf::IMU_IN, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(rec, e->stage, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return VF_OK;
+}
+
 // ------------------------------------------------------------------ stages
 int vf_engine_linearize(vf_engine* e, int which) {
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
@@ -435,6 +480,15 @@ int vf_engine_read_delta(vf_engine* e, int window, int k0, int n, double* d) {
     if (n == 0 || !d) return VF_OK;
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(d, e->v.delta + ((size_t)window * e->v.M + k0) * 15, (size_t)n * 15 * sizeof(double), hipMemcpyDeviceToHost));
+    return VF_OK;
+}
+
+int vf_engine_read_panels(vf_engine* e, int window, int k0, int n, double* panels) {
+    int rc = check_range(e, window, k0, n);
+    if (rc) return rc;
+    if (n == 0 || !panels) return VF_OK;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(panels, e->v.Lp + ((size_t)window * e->v.M + k0) * vf::PANEL, (size_t)n * vf::PANEL * sizeof(double), hipMemcpyDeviceToHost));
     return VF_OK;
 }
 

@@ -1,0 +1,363 @@
+// vf_graph.cpp -- host-side mirror of VILFusion::GraphManager + VILFusion::IMUManager behind the
+// C ABI (include/vilfusion.h "GraphManager surface").
+//
+// Only bookkeeping lives here: key numbering, the IMU sample deque and how IMUManager::getFactor
+// cuts it (which samples are dropped / integrated / interpolated), the queue of not-yet-added
+// IMU factors, staged between factors, the two mutexes and the callbacks.  Every number that
+// depends on the factor math -- preintegration (K0), initial-value prediction, linearisation,
+// the LM solve -- is computed by the HIP engine; there is no CPU fallback.
+//
+// Reference: gtsam_fusion/src/gtsam_fusion/GraphManager.cpp, IMUManager.cpp.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vilfusion.h"
+
+namespace {
+
+struct ImuSample { double t, acc[3], gyro[3]; };
+struct PendingImu {            // one queued CombinedImuFactor (GraphManager::_imuQueue)
+    uint64_t key;              // X(key-1) -> X(key)
+    std::vector<double> steps; // 7 per step: dt, acc, gyro
+    double bias[6];            // getBias() at reserveNode time (GraphManager.cpp:61)
+};
+struct PendingBetween { uint64_t a, b; double rec[VF_BTW_RECORD]; };
+
+// R upper-triangular, R^T R = cov^-1 (noiseModel::Gaussian::Covariance, SensorManagerRos.cpp:99).
+// 6x6 noise-model construction is factor *construction*, done once per measurement on the host
+// exactly where the reference does it.
+bool sqrt_info_upper6(const double* cov, double* Rp) {
+    // reverse Cholesky cov = U U^T (U upper) then R = U^-1
+    double U[36] = {0}, T[36] = {0};
+    for (int j = 5; j >= 0; j--) {
+        double d = cov[j * 6 + j];
+        for (int l = j + 1; l < 6; l++) d -= U[j * 6 + l] * U[j * 6 + l];
+        if (!(d > 0.0) || !std::isfinite(d)) return false;
+        const double ujj = std::sqrt(d);
+        U[j * 6 + j] = ujj;
+        for (int i = 0; i < j; i++) {
+            double a = 0.5 * (cov[i * 6 + j] + cov[j * 6 + i]);
+            for (int l = j + 1; l < 6; l++) a -= U[i * 6 + l] * U[j * 6 + l];
+            U[i * 6 + j] = a / ujj;
+        }
+    }
+    for (int c = 0; c < 6; c++) {
+        T[c * 6 + c] = 1.0 / U[c * 6 + c];
+        for (int r = c - 1; r >= 0; r--) {
+            double a = 0.0;
+            for (int l = r + 1; l <= c; l++) a += U[r * 6 + l] * T[l * 6 + c];
+            T[r * 6 + c] = -a / U[r * 6 + r];
+        }
+    }
+    int o = 0;
+    for (int r = 0; r < 6; r++)
+        for (int c = r; c < 6; c++) Rp[o++] = T[r * 6 + c];
+    return true;
+}
+
+}  // namespace
+
+struct vf_graph {
+    vf_engine* eng = nullptr;
+    vf_graph_opts opts{};
+    vf_imu_params imu{};
+    // guarded by graph_mutex (GraphManager::_graphMutex + IMUManager::_bufferMutex)
+    std::mutex graph_mutex, buffer_mutex;
+    std::deque<ImuSample> buffer;
+    std::deque<PendingImu> imu_queue;
+    std::vector<PendingBetween> staged_between;
+    int staged_count = 3;  // the three priors (GraphManager.cpp:33-35)
+    uint64_t current_key = 0;
+    double last_pose_time = -1.0;
+    std::vector<double> key_time;  // time of each reserved key
+    // guarded by state_mutex (GraphManager::_stateMutex)
+    std::mutex state_mutex;
+    double state[16] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t solved_key = 0;  // keys [0, solved_key] hold states on the device
+    int lo = 0;
+    std::vector<std::pair<vf_callback, void*>> callbacks;
+};
+
+extern "C" {
+
+// defined in vf_engine.hip: graph-level messages go to the same thread-local vf_last_error()
+void vf_set_last_error_(const char* msg);
+
+static int gerr(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    vf_set_last_error_(buf);
+    return code;
+}
+
+void vf_graph_default_opts(vf_graph_opts* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->capacity = 4096;
+    o->lag = 0;
+    o->iterations = 5;
+    o->device = 0;
+    // GraphManager.cpp:27-31: rad,rad,rad,m,m,m ; m/s ; bias
+    const double s[15] = {1e-6, 1e-6, 1e-6, 5e-5, 5e-5, 5e-5, 1e-5, 1e-5, 1e-5, 1e-7, 1e-7, 1e-7, 1e-7, 1e-7, 1e-7};
+    memcpy(o->prior_sigma, s, sizeof(s));
+}
+
+int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** out) {
+    if (!imu || !out) return gerr(VF_ERR_INVALID, "null argument");
+    vf_graph_opts o;
+    if (opts) o = *opts; else vf_graph_default_opts(&o);
+    if (o.capacity < 8 || o.iterations < 0 || o.lag < 0) return gerr(VF_ERR_INVALID, "bad graph options");
+    if (o.lag != 0 && o.lag < 4) return gerr(VF_ERR_INVALID, "lag must be 0 or >= 4 keyframes");
+    const double covs[6] = {imu->acc_cov, imu->gyro_cov, imu->integration_cov, imu->bias_acc_cov, imu->bias_omega_cov, imu->bias_acc_omega_int};
+    for (double c : covs)
+        if (!(c > 0.0) || !std::isfinite(c)) return gerr(VF_ERR_NOT_SPD, "IMU covariances must be finite and > 0");
+    vf_engine_opts eo;
+    vf_engine_default_opts(&eo);
+    eo.windows = 1;
+    eo.capacity = o.capacity;
+    eo.device = o.device;
+    vf_engine* eng = nullptr;
+    int rc = vf_engine_create(&eo, &eng);
+    if (rc) return rc;
+    vf_graph* g = new vf_graph();
+    g->eng = eng;
+    g->opts = o;
+    g->imu = *imu;
+    g->key_time.push_back(-1.0);
+    // X(0)=identity, V(0)=0, B(0)=0 with the three priors (GraphManager.cpp:20-35)
+    double rec[VF_PRIOR_RECORD] = {0};
+    rec[0] = 1.0;
+    memcpy(rec + 16, o.prior_sigma, sizeof(double) * 15);
+    if ((rc = vf_engine_set_states(eng, 0, 0, 1, g->state)) || (rc = vf_engine_set_prior(eng, 0, 0, rec)) ||
+        (rc = vf_engine_set_range(eng, 0, 0, 1))) {
+        vf_engine_destroy(eng);
+        delete g;
+        return rc;
+    }
+    *out = g;
+    return VF_OK;
+}
+
+void vf_destroy(vf_graph* g) {
+    if (!g) return;
+    vf_engine_destroy(g->eng);
+    delete g;
+}
+
+int vf_add_imu(vf_graph* g, double time, const double acc[3], const double gyro[3]) {
+    if (!g || !acc || !gyro) return gerr(VF_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->buffer_mutex);  // IMUManager.cpp:21
+    ImuSample s;
+    s.t = time;
+    memcpy(s.acc, acc, sizeof(s.acc));
+    memcpy(s.gyro, gyro, sizeof(s.gyro));
+    g->buffer.push_back(s);
+    return VF_OK;
+}
+
+// IMUManager::getFactor (IMUManager.cpp:27-74): which samples are dropped, integrated and
+// interpolated.  The integration itself happens on the device at solve time (K0).
+static void cut_imu_segment(vf_graph* g, double start, double end, std::vector<double>& steps) {
+    std::lock_guard<std::mutex> lk(g->buffer_mutex);
+    ImuSample prev{};
+    while (!g->buffer.empty() && g->buffer.front().t <= start) {  // :35-40
+        prev = g->buffer.front();
+        g->buffer.pop_front();
+    }
+    prev.t = start;  // :44
+    while (!g->buffer.empty() && g->buffer.front().t < end) {  // :46-54
+        const ImuSample m = g->buffer.front();
+        g->buffer.pop_front();
+        const double st[7] = {m.t - prev.t, m.acc[0], m.acc[1], m.acc[2], m.gyro[0], m.gyro[1], m.gyro[2]};
+        steps.insert(steps.end(), st, st + 7);
+        prev = m;
+    }
+    if (!g->buffer.empty()) {  // :57-66, the interpolated sample stays in the buffer
+        const ImuSample& f = g->buffer.front();
+        const double w = (end - prev.t) / (f.t - prev.t);
+        double st[7] = {end - prev.t, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 3; i++) {
+            st[1 + i] = w * f.acc[i] + (1.0 - w) * prev.acc[i];
+            st[4 + i] = w * f.gyro[i] + (1.0 - w) * prev.gyro[i];
+        }
+        steps.insert(steps.end(), st, st + 7);
+    }
+}
+
+int vf_reserve_node(vf_graph* g, double time, uint64_t* key_out) {
+    if (!g || !key_out) return gerr(VF_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->graph_mutex);  // GraphManager.cpp:54
+    if ((int)(g->current_key + 1) >= g->opts.capacity) return gerr(VF_ERR_CAPACITY, "keyframe capacity %d exhausted", g->opts.capacity);
+    double start;
+    if (g->current_key + 1 > 1) {
+        start = g->last_pose_time;  // :59-61
+    } else {
+        // first node integrates from the oldest buffered sample (IMUManager.cpp:76-79)
+        std::lock_guard<std::mutex> bl(g->buffer_mutex);
+        if (g->buffer.empty()) return gerr(VF_ERR_INDETERMINATE, "reserveNode before any IMU measurement");
+        start = g->buffer.front().t;
+    }
+    PendingImu p;
+    p.key = g->current_key + 1;
+    {
+        std::lock_guard<std::mutex> sl(g->state_mutex);  // getBias(): lock order graph -> state
+        memcpy(p.bias, g->state + 10, sizeof(p.bias));
+    }
+    cut_imu_segment(g, start, time, p.steps);
+    g->current_key++;
+    g->imu_queue.push_back(std::move(p));
+    g->last_pose_time = time;
+    g->key_time.push_back(time);
+    *key_out = g->current_key;
+    return VF_OK;
+}
+
+int vf_most_recent_pose_time(vf_graph* g, double* time, uint64_t* key) {
+    if (!g) return gerr(VF_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->graph_mutex);
+    if (time) *time = g->last_pose_time;
+    if (key) *key = g->current_key;
+    return VF_OK;
+}
+
+int vf_add_between(vf_graph* g, uint64_t prev, uint64_t cur, const double q[4], const double t[3], const double cov[36]) {
+    if (!g || !q || !t || !cov) return gerr(VF_ERR_INVALID, "null argument");
+    PendingBetween b;
+    b.a = prev;
+    b.b = cur;
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (!(n > 0.0) || !std::isfinite(n)) return gerr(VF_ERR_INVALID, "between rotation is not a quaternion");
+    for (int i = 0; i < 4; i++) b.rec[i] = q[i] / n;  // gtsam::Rot3(w,x,y,z) normalises
+    for (int i = 0; i < 3; i++) b.rec[4 + i] = t[i];
+    if (!sqrt_info_upper6(cov, b.rec + 7)) return gerr(VF_ERR_NOT_SPD, "between covariance is not symmetric positive definite");
+    std::lock_guard<std::mutex> lk(g->graph_mutex);  // GraphManager.cpp:85
+    if (prev >= cur || cur > g->current_key) return gerr(VF_ERR_BAD_KEY, "between factor keys (%llu, %llu) not reserved in order", (unsigned long long)prev, (unsigned long long)cur);
+    if (cur - prev > VF_MAX_BANDWIDTH) return gerr(VF_ERR_CAPACITY, "between factor spans %llu keyframes (max %d)", (unsigned long long)(cur - prev), VF_MAX_BANDWIDTH);
+    for (const auto& s : g->staged_between)
+        if (s.b == cur) return gerr(VF_ERR_CAPACITY, "a between factor already ends at key %llu", (unsigned long long)cur);
+    g->staged_between.push_back(b);
+    g->staged_count++;
+    return VF_OK;
+}
+
+int vf_set_callback(vf_graph* g, vf_callback cb, void* user) {
+    if (!g || !cb) return gerr(VF_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->state_mutex);
+    g->callbacks.emplace_back(cb, user);
+    return VF_OK;
+}
+
+int vf_graph_staged(vf_graph* g, int* staged, int* queued) {
+    if (!g) return gerr(VF_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->graph_mutex);
+    if (staged) *staged = g->staged_count;
+    if (queued) *queued = (int)g->imu_queue.size();
+    return VF_OK;
+}
+
+int vf_solve(vf_graph* g) {
+    if (!g) return gerr(VF_ERR_INVALID, "null argument");
+    // ---- under _graphMutex: emptyImuQueue + snapshot of the staged factors (GraphManager.cpp:104-114)
+    std::deque<PendingImu> imus;
+    std::vector<PendingBetween> betweens;
+    uint64_t last_key;
+    double last_time;
+    {
+        std::lock_guard<std::mutex> lk(g->graph_mutex);
+        imus.swap(g->imu_queue);
+        betweens.swap(g->staged_between);
+        g->staged_count = 0;  // _graph->resize(0)
+        last_key = g->current_key;
+        last_time = g->last_pose_time;
+    }
+    std::lock_guard<std::mutex> sl(g->state_mutex);  // :117
+    int rc;
+    if (!imus.empty()) {
+        // K0 on the device for all queued factors, then the initial values by IMU prediction
+        // (GraphManager.cpp:150-160).  Keys are consecutive by construction.
+        const int n = (int)imus.size();
+        const uint64_t k0 = imus.front().key;
+        std::vector<int32_t> off(n + 1, 0);
+        std::vector<double> steps, bias((size_t)n * 6);
+        for (int i = 0; i < n; i++) {
+            off[i + 1] = off[i] + (int)(imus[i].steps.size() / 7);
+            steps.insert(steps.end(), imus[i].steps.begin(), imus[i].steps.end());
+            memcpy(&bias[(size_t)i * 6], imus[i].bias, sizeof(double) * 6);
+        }
+        if ((rc = vf_engine_preintegrate(g->eng, 0, (int)k0, n, off.data(), steps.data(), bias.data(), &g->imu))) return rc;
+        if ((rc = vf_engine_predict(g->eng, 0, (int)k0, n))) return rc;
+    }
+    if (!betweens.empty()) {
+        std::vector<int32_t> a(betweens.size()), b(betweens.size());
+        std::vector<double> rec(betweens.size() * VF_BTW_RECORD);
+        // the engine wants runs sorted by b
+        std::vector<size_t> order(betweens.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = i;
+        for (size_t i = 1; i < order.size(); i++)
+            for (size_t j = i; j > 0 && betweens[order[j]].b < betweens[order[j - 1]].b; j--) std::swap(order[j], order[j - 1]);
+        for (size_t i = 0; i < order.size(); i++) {
+            a[i] = (int32_t)betweens[order[i]].a;
+            b[i] = (int32_t)betweens[order[i]].b;
+            memcpy(&rec[i * VF_BTW_RECORD], betweens[order[i]].rec, sizeof(double) * VF_BTW_RECORD);
+        }
+        if ((rc = vf_engine_set_between(g->eng, 0, (int)a.size(), a.data(), b.data(), rec.data()))) return rc;
+    }
+    // fixed-lag window: re-anchor the priors on the new oldest keyframe at its current estimate
+    int lo = g->lo;
+    if (g->opts.lag > 0 && (int)last_key + 1 - lo > g->opts.lag) {
+        lo = (int)last_key + 1 - g->opts.lag;
+        double rec[VF_PRIOR_RECORD];
+        if ((rc = vf_engine_get_states(g->eng, 0, lo, 1, rec))) return rc;
+        memcpy(rec + 16, g->opts.prior_sigma, sizeof(double) * 15);
+        if ((rc = vf_engine_set_prior(g->eng, 0, lo, rec))) return rc;
+        g->lo = lo;
+    }
+    if ((rc = vf_engine_set_range(g->eng, 0, lo, (int)last_key + 1))) return rc;
+    if ((rc = vf_engine_iterate(g->eng, g->opts.iterations))) return rc;   // ISAM2::update + calculateEstimate
+    int fails = 0;
+    if ((rc = vf_engine_read_lm(g->eng, 0, nullptr, nullptr, nullptr, nullptr, &fails))) return rc;
+    if ((rc = vf_engine_get_states(g->eng, 0, (int)last_key, 1, g->state))) return rc;  // :131-133
+    g->solved_key = last_key;
+    for (auto& cb : g->callbacks)  // :135-138, on the solving thread, inside _stateMutex
+        cb.first(cb.second, last_time, g->state, g->state + 4, g->state + 7, g->state + 10);
+    if (fails > 0 && fails >= g->opts.iterations && g->opts.iterations > 0)
+        return gerr(VF_ERR_INDETERMINATE, "normal equations not positive definite in every LM trial (underdetermined graph?)");
+    return VF_OK;
+}
+
+int vf_get_state(vf_graph* g, double q[4], double t[3], double v[3], double bias[6]) {
+    if (!g) return gerr(VF_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->state_mutex);
+    if (q) memcpy(q, g->state, sizeof(double) * 4);
+    if (t) memcpy(t, g->state + 4, sizeof(double) * 3);
+    if (v) memcpy(v, g->state + 7, sizeof(double) * 3);
+    if (bias) memcpy(bias, g->state + 10, sizeof(double) * 6);
+    return VF_OK;
+}
+
+int vf_get_bias(vf_graph* g, double bias[6]) { return vf_get_state(g, nullptr, nullptr, nullptr, bias); }
+
+int vf_get_trajectory(vf_graph* g, uint64_t key0, int n, double* state16) {
+    if (!g || !state16) return gerr(VF_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->state_mutex);
+    if (n < 0 || key0 + (uint64_t)n > g->solved_key + 1) return gerr(VF_ERR_BAD_KEY, "keys [%llu, %llu) not solved yet", (unsigned long long)key0, (unsigned long long)(key0 + n));
+    return vf_engine_get_states(g->eng, 0, (int)key0, n, state16);
+}
+
+int vf_get_imu_factor(vf_graph* g, uint64_t key, double* rec190) {
+    if (!g || !rec190) return gerr(VF_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->state_mutex);
+    if (key < 1 || key > g->solved_key) return gerr(VF_ERR_BAD_KEY, "imu factor %llu not on the device yet", (unsigned long long)key);
+    return vf_engine_get_imu(g->eng, 0, (int)key, 1, rec190);
+}
+
+}  // extern "C"

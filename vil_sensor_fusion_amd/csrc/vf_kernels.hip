@@ -64,6 +64,133 @@ VF_DI void white9(const double (&R)[45], const double (&u)[9], double (&o)[9]) {
     }
 }
 
+// ------------------------------------------------------------------------------------ K0
+// IMU preintegration, one lane per factor: PreintegratedCombinedMeasurements::integrateMeasurement
+// over the factor's steps (mean, bias Jacobians, 15x15 covariance; GTSAM 4.0.x tangent form),
+// then the noise model R = chol_upper(cov^-1) of the CombinedImuFactor built at
+// gtsam_fusion/src/gtsam_fusion/IMUManager.cpp:68-73.  Runs once per factor (not per LM
+// iteration); the 15x15 work uses per-lane local arrays.
+__global__ void __launch_bounds__(64) k_preintegrate(View v, long g0, int n, const int* __restrict__ off,
+                                                    const double* __restrict__ steps,
+                                                    const double* __restrict__ bhat6, ImuCov prm, int* status) {
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= n) return;
+    const double* bh = bhat6 + (size_t)f * 6;
+    const V3 bacc = v3(bh[0], bh[1], bh[2]), bgyr = v3(bh[3], bh[4], bh[5]);
+    V3 th = v3(0, 0, 0), pos = v3(0, 0, 0), vel = v3(0, 0, 0);
+    double dtij = 0.0;
+    double Hb[54], P[225], F[225], T[225];
+    for (int i = 0; i < 54; i++) Hb[i] = 0.0;
+    for (int i = 0; i < 225; i++) P[i] = 0.0;
+    for (int s = off[f]; s < off[f + 1]; s++) {
+        const double* st = steps + (size_t)s * 7;
+        const double dt = st[0], dt22 = 0.5 * dt * dt;
+        const V3 acc = v3(st[1], st[2], st[3]) - bacc, om = v3(st[4], st[5], st[6]) - bgyr;
+        const M3 Jr = so3_jr(th), invD = so3_jr_inv(th);
+        const V3 wt = mul(invD, om);
+        const M3 R = qrot(qexp(th));
+        const V3 anav = mul(R, acc);
+        const M3 wH = mul(invD, so3_jr_apply_dtheta(th, wt));   // -w_tangent_H_theta
+        const M3 aH = mul(mulSkew(R, neg(acc)), Jr);            // a_nav_H_theta
+        // F = [[A, Fb], [0, I]]
+        for (int i = 0; i < 225; i++) F[i] = 0.0;
+        for (int i = 0; i < 15; i++) F[i * 15 + i] = 1.0;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                F[i * 15 + j] -= wH.a[i * 3 + j] * dt;
+                F[(3 + i) * 15 + j] = aH.a[i * 3 + j] * dt22;
+                F[(6 + i) * 15 + j] = aH.a[i * 3 + j] * dt;
+                F[i * 15 + 12 + j] = -invD.a[i * 3 + j] * dt;   // theta_H_biasOmega = -C.top
+                F[(6 + i) * 15 + 9 + j] = -R.a[i * 3 + j] * dt; // vel_H_biasAcc = -B.bottom
+            }
+        for (int i = 0; i < 3; i++) F[(3 + i) * 15 + 6 + i] = dt;
+        // bias Jacobians: H <- A H - [B | C]
+        {
+            double Hn[54];
+            for (int i = 0; i < 9; i++)
+                for (int j = 0; j < 6; j++) {
+                    double a = 0.0;
+                    for (int l = 0; l < 9; l++) a = fma(F[i * 15 + l], Hb[l * 6 + j], a);
+                    Hn[i * 6 + j] = a;
+                }
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {
+                    Hn[(3 + i) * 6 + j] -= R.a[i * 3 + j] * dt22;
+                    Hn[(6 + i) * 6 + j] -= R.a[i * 3 + j] * dt;
+                    Hn[i * 6 + 3 + j] -= invD.a[i * 3 + j] * dt;
+                }
+            for (int i = 0; i < 54; i++) Hb[i] = Hn[i];
+        }
+        // mean
+        th = th + dt * wt;
+        pos = pos + dt * vel + dt22 * anav;
+        vel = vel + dt * anav;
+        dtij += dt;
+        // covariance: P <- F P F^T + G Q G^T
+        for (int i = 0; i < 15; i++)
+            for (int j = 0; j < 15; j++) {
+                double a = 0.0;
+                for (int l = 0; l < 15; l++) a = fma(F[i * 15 + l], P[l * 15 + j], a);
+                T[i * 15 + j] = a;
+            }
+        for (int i = 0; i < 15; i++)
+            for (int j = 0; j < 15; j++) {
+                double a = 0.0;
+                for (int l = 0; l < 15; l++) a = fma(T[i * 15 + l], F[j * 15 + l], a);
+                P[i * 15 + j] = a;
+            }
+        const double sv = (prm.acc + prm.bias_int) * dt, sr = (prm.gyro + prm.bias_int) * dt;
+        const M3 RRt = mulBT(R, R), DDt = mulBT(invD, invD);
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) {
+                P[(6 + i) * 15 + 6 + j] += sv * RRt.a[i * 3 + j];   // (1/dt) vHb (aCov+int) vHb^T
+                P[i * 15 + j] += sr * DDt.a[i * 3 + j];             // (1/dt) tHb (wCov+int) tHb^T
+            }
+            P[(3 + i) * 15 + 3 + i] += dt * prm.integration;
+            P[(9 + i) * 15 + 9 + i] += dt * prm.bias_acc;
+            P[(12 + i) * 15 + 12 + i] += dt * prm.bias_omega;
+        }
+    }
+    // R upper with R^T R = P^-1: reverse Cholesky P = U U^T (U upper), R = U^-1
+    bool ok = true;
+    for (int i = 0; i < 225; i++) F[i] = 0.0;   // F <- U
+    for (int j = 14; j >= 0; j--) {
+        double d = P[j * 15 + j];
+        for (int l = j + 1; l < 15; l++) d = fma(-F[j * 15 + l], F[j * 15 + l], d);
+        if (!(d > 0.0)) { ok = false; d = 1.0; }
+        const double ujj = sqrt(d);
+        F[j * 15 + j] = ujj;
+        for (int i = 0; i < j; i++) {
+            double a = 0.5 * (P[i * 15 + j] + P[j * 15 + i]);
+            for (int l = j + 1; l < 15; l++) a = fma(-F[i * 15 + l], F[j * 15 + l], a);
+            F[i * 15 + j] = a / ujj;
+        }
+    }
+    for (int i = 0; i < 225; i++) T[i] = 0.0;   // T <- U^-1 (upper)
+    for (int c = 0; c < 15; c++) {
+        T[c * 15 + c] = 1.0 / F[c * 15 + c];
+        for (int r = c - 1; r >= 0; r--) {
+            double a = 0.0;
+            for (int l = r + 1; l <= c; l++) a = fma(F[r * 15 + l], T[l * 15 + c], a);
+            T[r * 15 + c] = -a / F[r * 15 + r];
+        }
+    }
+    const long gk = g0 + f;
+    double* out = v.imu_in + (size_t)(gk >> 6) * IMU_IN * TILE + (gk & 63);
+#define OUTF(i) out[(size_t)(i) * TILE]
+    OUTF(0) = dtij;
+    OUTF(1) = th.x; OUTF(2) = th.y; OUTF(3) = th.z;
+    OUTF(4) = pos.x; OUTF(5) = pos.y; OUTF(6) = pos.z;
+    OUTF(7) = vel.x; OUTF(8) = vel.y; OUTF(9) = vel.z;
+    for (int i = 0; i < 6; i++) OUTF(10 + i) = bh[i];
+    for (int i = 0; i < 54; i++) OUTF(16 + i) = Hb[i];
+    int o = 70;
+    for (int r = 0; r < 15; r++)
+        for (int c = r; c < 15; c++) OUTF(o++) = T[r * 15 + c];
+#undef OUTF
+    if (!ok || off[f + 1] == off[f]) atomicOr(status, 1);
+}
+
 // ------------------------------------------------------------------------------------ K1
 // Algorithmic traffic per factor: 222 doubles in (2 states x 16, record 190), 465 out.
 __global__ void __launch_bounds__(256) k_linearize_imu(View v, int which) {
@@ -533,117 +660,221 @@ VF_DI double readlane_d(double x, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// One wavefront per window.  Right-looking block Cholesky over a circular 4-keyframe (60x60)
-// window held in LDS; the 61-row panel of step k (60 matrix rows + the rhs row, which makes the
-// forward substitution free) is factorised in registers: lane r holds row r, pivots and
-// multipliers are broadcast with v_readlane.  Latency-bound by construction (sequential in k).
+// v_rsq_f64 is good to 2^29 ulp (rel. 2^-23); two Newton steps reach full double precision.
+VF_DI double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double t = x * y;
+    double e = fma(-t, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    t = x * y;
+    e = fma(-t, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    return y;
+}
+
+// One wavefront per window.  Right-looking block Cholesky of the block-banded normal matrix,
+// exploiting its profile: IMU factors couple consecutive keyframes in all 15 dof, between
+// factors couple keyframes up to 3 apart in the 6 pose dof only, so the active set while
+// eliminating keyframe k is  [k: 15] [k+1: 15] [k+2: pose 6] [k+3: pose 6]  = 42 rows, plus
+// the right-hand side carried as a 43rd row (forward substitution for free).
+//   * the 43x15 panel is factorised in registers: lane p owns row p, pivots/multipliers are
+//     broadcast with v_readlane, 1/sqrt by v_rsq_f64 + 2 Newton steps (no IEEE sqrt/div chain);
+//   * the 405 trailing entries are spread evenly over the 64 lanes (7 dot products each) and
+//     applied to a circular 4-keyframe window kept in LDS;
+//   * the next block row of H is prefetched from HBM before the panel and dropped into the
+//     slot the pivot keyframe frees.
+// Sequential in k, hence latency-bound; see DESIGN.md "K4" for the cycle budget.
+constexpr int PROWS = 43;
+constexpr int LDW = 61;
+
 __global__ void __launch_bounds__(64) k_band_solve(View v) {
     const int w = blockIdx.x, lane = threadIdx.x;
     const int lo = v.lo[w], hi = v.hi[w], n = hi - lo;
     if (n <= 0) return;
-    __shared__ double Wd[60 * 61];
+    __shared__ double Wd[60 * LDW];
     __shared__ double Gd[64];
-    __shared__ double P[PANEL + 1];
+    __shared__ double P[PROWS * 15 + 3];
     __shared__ double dl[64];
     const double lam = v.lambda[w];
     const size_t base = (size_t)w * v.M + lo;
     int failed = 0;
 
-    auto load_row = [&](int kk) {
-        const int bi = kk & 3;
+    // panel row of this lane: segment (keyframe offset) and dof
+    const int pd = lane < 15 ? 0 : (lane < 30 ? 1 : (lane < 36 ? 2 : 3));
+    const int pa = lane < 15 ? lane : (lane < 30 ? lane - 15 : (lane < 36 ? lane - 30 : lane - 36));
+    // the 7 trailing entries of this lane: e = lane + 64 j -> (row pr in 15..42, col pc in 15..min(pr,41))
+    int t_rd[7], t_ra[7], t_cd[7], t_ca[7], t_pr[7], t_pc[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        int e = lane + 64 * j, r = 0;
+        if (e >= 405) e = 404;                       // duplicates are masked below
+        while (r < 26 && e > r) { e -= r + 1; r++; } // row r of the 27-triangle, then the rhs row
+        int pr, pc;
+        if (r < 26 || e <= 26) { pr = 15 + r; pc = 15 + e; }
+        if (r == 26 && e > 26) { pr = 42; pc = 15 + (e - 27); }
+        t_pr[j] = pr; t_pc[j] = pc;
+        t_rd[j] = pr < 30 ? 1 : (pr < 36 ? 2 : 3);
+        t_ra[j] = pr < 30 ? pr - 15 : (pr < 36 ? pr - 30 : pr - 36);
+        t_cd[j] = pc < 30 ? 1 : (pc < 36 ? 2 : 3);
+        t_ca[j] = pc < 30 ? pc - 15 : (pc < 36 ? pc - 30 : pc - 36);
+    }
+    // block-row load map: idx = lane + 64 j over a 15x15 block
+    int l_a[4], l_c[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int idx = lane + 64 * j;
+        l_a[j] = idx / 15;
+        l_c[j] = idx - l_a[j] * 15;
+    }
+    const int q_a = lane / 6, q_c = lane - q_a * 6;  // 6x6 pose block map (lane < 36)
+
+    double h0[4], h1[4], h2 = 0.0, h3 = 0.0, hg = 0.0;
+    auto fetch_row = [&](int kk) {   // HBM -> registers
         if (kk < n) {
             const double* Hk = v.H + (base + kk) * HROW;
-            for (int e = lane; e < HROW; e += 64) {
-                const int d = e / 225, rem = e - d * 225, a = rem / 15, c = rem - a * 15;
-                double val = (kk - d >= 0) ? Hk[e] : 0.0;
-                if (d == 0 && a == c) val += lam;
-                Wd[(bi * 15 + a) * 61 + ((kk - d) & 3) * 15 + c] = val;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int idx = lane + 64 * j;
+                const bool in = idx < 225;
+                h0[j] = in ? Hk[idx] : 0.0;
+                h1[j] = (in && kk >= 1) ? Hk[225 + idx] : 0.0;
             }
-            if (lane < 15) Gd[bi * 15 + lane] = -v.gvec[(base + kk) * 15 + lane];
-        } else {
-            for (int e = lane; e < HROW; e += 64) {
-                const int d = e / 225, rem = e - d * 225, a = rem / 15, c = rem - a * 15;
-                Wd[(bi * 15 + a) * 61 + ((kk - d) & 3) * 15 + c] = (d == 0 && a == c) ? 1.0 : 0.0;
-            }
-            if (lane < 15) Gd[bi * 15 + lane] = 0.0;
+            h2 = (lane < 36 && kk >= 2) ? Hk[450 + q_a * 15 + q_c] : 0.0;
+            h3 = (lane < 36 && kk >= 3) ? Hk[675 + q_a * 15 + q_c] : 0.0;
+            hg = lane < 15 ? -v.gvec[(base + kk) * 15 + lane] : 0.0;
+        } else {   // beyond the window: identity rows
+#pragma unroll
+            for (int j = 0; j < 4; j++) { h0[j] = 0.0; h1[j] = 0.0; }
+            h2 = h3 = hg = 0.0;
         }
     };
-    for (int kk = 0; kk < 4; kk++) load_row(kk);
+    auto commit_row = [&](int kk) {  // registers -> LDS slot of keyframe kk
+        const int s = (kk & 3) * 15;
+        const int c1 = ((kk - 1) & 3) * 15, c2 = ((kk - 2) & 3) * 15, c3 = ((kk - 3) & 3) * 15;
+        const bool real = kk < n;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (lane + 64 * j < 225) {
+                double d0 = h0[j];
+                if (l_a[j] == l_c[j]) d0 = real ? d0 + lam : 1.0;
+                Wd[(s + l_a[j]) * LDW + s + l_c[j]] = d0;
+                Wd[(s + l_a[j]) * LDW + c1 + l_c[j]] = h1[j];
+            }
+        }
+        // d = 2, 3: pose rows only; columns 6..14 start at zero and fill in during elimination
+#pragma unroll
+        for (int it = 0; it < 2; it++) {   // 6x15 entries; every lane takes part in the shuffles
+            const int e = lane + 64 * it;
+            const int a = e / 15, c = e - a * 15;
+            const bool valid = e < 90, ld = valid && c < 6;
+            const int owner = ld ? a * 6 + c : 0;   // lanes < 36 hold the 6x6 pose block (q_a, q_c)
+            const double x2 = __shfl(h2, owner), x3 = __shfl(h3, owner);
+            if (valid) {
+                Wd[(s + a) * LDW + c2 + c] = ld ? x2 : 0.0;
+                Wd[(s + a) * LDW + c3 + c] = ld ? x3 : 0.0;
+            }
+        }
+        if (lane < 15) Gd[s + lane] = hg;
+    };
+    for (int kk = 0; kk < 4; kk++) {
+        fetch_row(kk);
+        commit_row(kk);
+    }
     __syncthreads();
 
-    const int rd = lane / 15, ra = lane - rd * 15;  // lane < 60: block offset / row in block
     for (int k = 0; k < n; k++) {
-        const int bi0 = k & 3;
-        const int ri = (((k + rd) & 3) * 15 + ra) * 61;  // this lane's row in the circular window
+        const int s0 = (k & 3) * 15;
+        fetch_row(k + 4);  // in flight during the panel factorisation
+        const int ri = ((((k + pd) & 3) * 15) + pa) * LDW;
         double p[15];
 #pragma unroll
         for (int c = 0; c < 15; c++)
-            p[c] = lane < 60 ? Wd[ri + bi0 * 15 + c] : (lane == 60 ? Gd[bi0 * 15 + c] : 0.0);
-        // panel factorisation (columns of the pivot block)
+            p[c] = lane < 42 ? Wd[ri + s0 + c] : (lane == 42 ? Gd[s0 + c] : 0.0);
+        double dinv = 0.0;
 #pragma unroll
         for (int c = 0; c < 15; c++) {
             double dv = readlane_d(p[c], c);
             if (!(dv > 0.0)) { failed = 1; dv = 1.0; }
-            const double inv = 1.0 / sqrt(dv);
+            const double inv = fast_rsqrt(dv);
             p[c] *= inv;
+            if (lane == c) dinv = inv;
 #pragma unroll
             for (int c2 = c + 1; c2 < 15; c2++) {
                 const double l = readlane_d(p[c], c2);
                 p[c2] = fma(-p[c], l, p[c2]);
             }
         }
-        if (lane < 61) {
+        if (lane < PROWS) {
 #pragma unroll
-            for (int c = 0; c < 15; c++) P[lane * 15 + c] = p[c];
+            for (int c = 0; c < 15; c++) P[lane * 15 + c] = (lane == c) ? dinv : p[c];  // diagonal holds 1/L_cc
         }
         __syncthreads();
         {   // panel -> HBM (coalesced), kept for the back substitution
             double* Lk = v.Lp + (base + k) * PANEL;
             for (int e = lane; e < PANEL; e += 64) Lk[e] = P[e];
         }
-        // trailing update of the remaining 45x45 window and of the rhs row
-        if (lane >= 15 && lane < 61) {
-#pragma unroll 1
-            for (int dc = 1; dc <= 3; dc++) {
-                const int cb = ((k + dc) & 3) * 15;
-#pragma unroll 1
-                for (int c2 = 0; c2 < 15; c2++) {
-                    const int pr = dc * 15 + c2;
-                    if (lane < pr) continue;
-                    double s = 0.0;
 #pragma unroll
-                    for (int c = 0; c < 15; c++) s = fma(p[c], P[pr * 15 + c], s);
-                    if (lane < 60) Wd[ri + cb + c2] -= s;
-                    else Gd[cb + c2] -= s;
+        for (int j = 0; j < 7; j++) {
+            if (lane + 64 * j < 405) {
+                const double* a = P + t_pr[j] * 15;
+                const double* b = P + t_pc[j] * 15;
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < 14; c += 2) {
+                    s1 = fma(a[c], b[c], s1);
+                    s2 = fma(a[c + 1], b[c + 1], s2);
                 }
+                s1 = fma(a[14], b[14], s1) + s2;
+                const int cj = (((k + t_cd[j]) & 3) * 15) + t_ca[j];
+                if (t_pr[j] < 42) Wd[((((k + t_rd[j]) & 3) * 15) + t_ra[j]) * LDW + cj] -= s1;
+                else Gd[cj] -= s1;
             }
         }
         __syncthreads();
-        load_row(k + 4);  // the pivot block's slot is free now
+        commit_row(k + 4);  // the pivot keyframe's slot is free now
         __syncthreads();
     }
 
-    // back substitution: delta_k = L_kk^-T (y_k - sum_d L[k+d][k]^T delta_{k+d})
+    // back substitution: delta_k = L_kk^-T (y_k - sum_p L[p][k-cols]^T delta(p)), p over rows 15..41
     if (lane < 60) dl[lane] = 0.0;
+    const int part = lane >> 4, cc = lane & 15;          // 4 partial sums per column
+    const int p_lo = 15 + part * 7, p_hi = part == 3 ? 42 : p_lo + 7;
+    double nxt[11];
+    {
+        const double* Lk = v.Lp + (base + n - 1) * PANEL;
+#pragma unroll
+        for (int j = 0; j < 11; j++) nxt[j] = (lane + 64 * j < PANEL) ? Lk[lane + 64 * j] : 0.0;
+    }
     __syncthreads();
     for (int k = n - 1; k >= 0; k--) {
-        const double* Lk = v.Lp + (base + k) * PANEL;
-        for (int e = lane; e < PANEL; e += 64) P[e] = Lk[e];
+#pragma unroll
+        for (int j = 0; j < 11; j++)
+            if (lane + 64 * j < PANEL) P[lane + 64 * j] = nxt[j];
         __syncthreads();
+        if (k > 0) {  // prefetch the next panel while this one is consumed
+            const double* Lk = v.Lp + (base + k - 1) * PANEL;
+#pragma unroll
+            for (int j = 0; j < 11; j++) nxt[j] = (lane + 64 * j < PANEL) ? Lk[lane + 64 * j] : 0.0;
+        }
         double s = 0.0;
-        if (lane < 15) {
-            s = P[60 * 15 + lane];
-#pragma unroll 1
-            for (int r = 15; r < 60; r++) {
-                const int dd = r / 15, a = r - dd * 15;
-                s = fma(-P[r * 15 + lane], dl[((k + dd) & 3) * 15 + a], s);
+        if (cc < 15) {
+            for (int pp = p_lo; pp < p_hi; pp++) {
+                const int d = pp < 30 ? 1 : (pp < 36 ? 2 : 3);
+                const int a = pp < 30 ? pp - 15 : (pp < 36 ? pp - 30 : pp - 36);
+                s = fma(P[pp * 15 + cc], dl[((k + d) & 3) * 15 + a], s);
             }
         }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        double lcol[15];   // column `lane` of L_kk below the diagonal, and 1/L_cc on the diagonal
+#pragma unroll
+        for (int c = 0; c < 15; c++) lcol[c] = lane < 15 ? P[c * 15 + lane] : 0.0;
+        s = lane < 15 ? P[42 * 15 + lane] - s : 0.0;
 #pragma unroll
         for (int c = 14; c >= 0; c--) {
-            const double xc = readlane_d(s, c) / P[c * 15 + c];
+            const double xc = readlane_d(s, c) * readlane_d(lcol[c], c);
             if (lane == c) s = xc;
-            else if (lane < c) s = fma(-P[c * 15 + lane], xc, s);
+            else if (lane < c) s = fma(-lcol[c], xc, s);
         }
         __syncthreads();
         if (lane < 15) {
@@ -838,6 +1069,10 @@ __global__ void k_gather_states(const double* x, double* aos, long G, const int*
 // ------------------------------------------------------------------------------------ launchers
 static inline unsigned nblk(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
+void launch_preintegrate(const View& v, long g0, int n, const int* off, const double* steps, const double* bhat6,
+                         const ImuCov& prm, int* status, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_preintegrate, dim3(nblk(n, 64)), dim3(64), 0, s, v, g0, n, off, steps, bhat6, prm, status);
+}
 void launch_linearize_imu(const View& v, int which, hipStream_t s) {
     hipLaunchKernelGGL(k_linearize_imu, dim3(nblk(v.G, 256)), dim3(256), 0, s, v, which);
 }

@@ -14,7 +14,7 @@ constexpr int PRIOR_IN = 31;    // mean state (16), sigma (15)
 constexpr int PRIOR_OUT = 240;  // r(15), J(15x15)
 constexpr int NBLK = 4;         // band blocks stored per keyframe (bandwidth 3 + diagonal)
 constexpr int HROW = NBLK * 225;
-constexpr int PANEL = 61 * 15;  // Cholesky panel rows 0..59 + forward-substituted rhs row
+constexpr int PANEL = 43 * 15;  // Cholesky panel: 42 active rows + forward-substituted rhs row
 
 // Device-resident problem: B windows x M keyframe slots (G = B*M).  See DESIGN.md.
 struct View {
@@ -33,7 +33,7 @@ struct View {
     double* H;          // [G][4][15][15]      block d of row k = H[k][k-d]
     double* gvec;       // [G][15]
     double* delta;      // [G][15]
-    double* Lp;         // [G][61][15]         Cholesky panels + y
+    double* Lp;         // [G][43][15]         Cholesky panels + y
     int* lo;            // [B] active range [lo, hi)
     int* hi;
     int* sel;           // [B] which buffer is current
@@ -46,6 +46,10 @@ struct View {
     double lam_up, lam_down, lam_min, lam_max;
 };
 
+// isotropic IMU covariances (ImuManagerRos.cpp:20-33)
+struct ImuCov { double acc, gyro, integration, bias_acc, bias_omega, bias_int; };
+void launch_preintegrate(const View& v, long g0, int n, const int* off, const double* steps, const double* bhat6,
+                         const ImuCov& prm, int* status, hipStream_t s);
 void launch_linearize_imu(const View& v, int which, hipStream_t s);
 void launch_linearize_between(const View& v, int which, hipStream_t s);
 void launch_linearize_prior(const View& v, int which, hipStream_t s);

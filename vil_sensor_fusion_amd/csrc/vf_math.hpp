@@ -113,6 +113,19 @@ VF_DI CoefABC coef_abc(double x) {
     }
     return c;
 }
+// dB = B'(th)/th, dC = C'(th)/th
+struct CoefD { double dB, dC; };
+VF_DI CoefD coef_dbdc(double x, const CoefABC& c) {
+    CoefD d;
+    if (x < SERIES_X) {
+        d.dB = fma(x, fma(x, fma(x, fma(x, fma(x, 1.0 / 7264857600.0, -1.0 / 47900160.0), 1.0 / 453600.0), -1.0 / 6720.0), 1.0 / 180.0), -1.0 / 12.0);
+        d.dC = fma(x, fma(x, fma(x, fma(x, fma(x, 1.0 / 108972864000.0, -1.0 / 622702080.0), 1.0 / 4989600.0), -1.0 / 60480.0), 1.0 / 1260.0), -1.0 / 60.0);
+    } else {
+        d.dB = (c.A - 2.0 * c.B) / x;
+        d.dC = (c.B - 3.0 * c.C) / x;
+    }
+    return d;
+}
 // E = 1/th^2 - (1+cos)/(2 th sin): coefficient of W^2 in J_r^{-1}; dE = E'(th)/th
 VF_DI double coef_e(double x) {
     if (x < SERIES_X)
@@ -205,6 +218,30 @@ VF_DI M3 so3_jr_inv_e(V3 w, double E) {  // I + W/2 + E W^2 with a given E
     return J;
 }
 VF_DI M3 so3_jr_inv(V3 w) { return so3_jr_inv_e(w, coef_e(dot(w, w))); }
+
+// d/dtheta [ J_r(theta) c ] for fixed c (so3::DexpFunctor::applyDexp H1), used by the
+// tangent preintegration's A matrix
+VF_DI M3 so3_jr_apply_dtheta(V3 th, V3 c) {
+    const double x = dot(th, th);
+    const CoefABC k = coef_abc(x);
+    const CoefD d = coef_dbdc(x, k);
+    const V3 txc = cross(th, c), ttxc = cross(th, txc);
+    const double tc = dot(th, c);
+    M3 D;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double v = -vget(txc, i) * d.dB * vget(th, j) + vget(ttxc, i) * d.dC * vget(th, j) +
+                       k.C * (vget(th, i) * vget(c, j) - 2.0 * vget(c, i) * vget(th, j));
+            if (i == j) v += k.C * tc;
+            D.a[i * 3 + j] = v;
+        }
+    const M3 S = skew(c);
+#pragma unroll
+    for (int i = 0; i < 9; i++) D.a[i] += k.B * S.a[i];
+    return D;
+}
 
 // ---- SE(3) ----
 // Logmap of (q, t): xi = [w, u], u = (I - W/2 + E W^2) t

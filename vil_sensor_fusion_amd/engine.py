@@ -97,6 +97,21 @@ class Engine:
         r = np.ascontiguousarray(rec, dtype=np.float64).reshape(PRIOR_RECORD)
         check(self._l.vf_engine_set_prior(self._h, window, k, _d(r)))
 
+    def preintegrate(self, window, k0, step_off, steps, bias_hat, imu_cov):
+        """K0 on the device: factors for keyframes k0..k0+n-1 from raw IMU steps (n = len(step_off)-1)."""
+        off = np.ascontiguousarray(step_off, dtype=np.int32)
+        st = np.ascontiguousarray(steps, dtype=np.float64).reshape(-1, 7)
+        n = off.size - 1
+        bh = np.ascontiguousarray(np.broadcast_to(np.asarray(bias_hat, dtype=np.float64), (n, 6)))
+        p = _lib.ImuParamsC(imu_cov["acc"], imu_cov["gyro"], imu_cov["integration"], imu_cov["bias_acc"],
+                            imu_cov["bias_omega"], imu_cov["bias_acc_omega_int"])
+        check(self._l.vf_engine_preintegrate(self._h, window, k0, n, _i(off), _d(st), _d(bh), C.byref(p)))
+
+    def get_imu(self, window, k0, n):
+        r = np.zeros((n, IMU_RECORD))
+        check(self._l.vf_engine_get_imu(self._h, window, k0, n, _d(r)))
+        return r
+
     # ---- stages
     def linearize(self, which=0):
         check(self._l.vf_engine_linearize(self._h, which))
@@ -146,6 +161,11 @@ class Engine:
         d = np.zeros((n, 15))
         check(self._l.vf_engine_read_delta(self._h, window, k0, n, _d(d)))
         return d
+
+    def read_panels(self, window, k0, n):
+        p = np.zeros((n, 43, 15))
+        check(self._l.vf_engine_read_panels(self._h, window, k0, n, _d(p)))
+        return p
 
     def read_lm(self, window):
         cost, lam = C.c_double(), C.c_double()

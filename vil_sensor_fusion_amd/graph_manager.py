@@ -1,0 +1,119 @@
+"""Python mirror of VILFusion::GraphManager / IMUManager over the C ABI.
+
+Method names, argument meaning and error behaviour follow the reference
+(gtsam_fusion/include/gtsam_fusion/GraphManager.h:40-96, IMUManager.h:22-27) so that the
+reference's own test timelines (gtsam_fusion/test/UnitTests.cpp) read the same here.  Poses are
+(q_wxyz, t) tuples instead of gtsam::Pose3; noise is a 6x6 covariance in Pose3 tangent order
+[rot, trans] (what SensorManagerRos.cpp:99 wraps into noiseModel::Gaussian::Covariance).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+# gtsam_fusion/config/carla/fusion_params.yaml:22-27
+CARLA_IMU = dict(acc=1e-6, gyro=1e-6, integration=1e-8, bias_acc=1e-4, bias_omega=1e-6,
+                 bias_acc_omega_int=1e-4)
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class GraphManager:
+    """GraphManager(imuManager): the IMU manager is folded in (addIMUMeasurement)."""
+
+    def __init__(self, imu_params=CARLA_IMU, capacity=4096, lag=0, iterations=5, device=0,
+                 prior_sigma=None):
+        self._l = _lib.lib()
+        p = _lib.ImuParamsC(imu_params["acc"], imu_params["gyro"], imu_params["integration"],
+                            imu_params["bias_acc"], imu_params["bias_omega"],
+                            imu_params["bias_acc_omega_int"])
+        o = _lib.GraphOptsC()
+        self._l.vf_graph_default_opts(C.byref(o))
+        o.capacity, o.lag, o.iterations, o.device = capacity, lag, iterations, device
+        if prior_sigma is not None:
+            o.prior_sigma[:] = list(prior_sigma)
+        self._h = C.c_void_p()
+        check(self._l.vf_create(C.byref(p), C.byref(o), C.byref(self._h)))
+        self._cbs = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.vf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # IMUManager::addIMUMeasurement
+    def addIMUMeasurement(self, time, accel, gyro):
+        a = np.ascontiguousarray(accel, dtype=np.float64)
+        w = np.ascontiguousarray(gyro, dtype=np.float64)
+        check(self._l.vf_add_imu(self._h, C.c_double(time), _d(a), _d(w)))
+
+    def reserveNode(self, time) -> int:
+        key = C.c_uint64()
+        check(self._l.vf_reserve_node(self._h, C.c_double(time), C.byref(key)))
+        return key.value
+
+    def getMostRecentPoseTime(self):
+        t, k = C.c_double(), C.c_uint64()
+        check(self._l.vf_most_recent_pose_time(self._h, C.byref(t), C.byref(k)))
+        return t.value, k.value
+
+    def addBetweenFactor(self, previousKey, currentKey, betweenPose, noiseCovariance):
+        q = np.ascontiguousarray(betweenPose[0], dtype=np.float64)
+        t = np.ascontiguousarray(betweenPose[1], dtype=np.float64)
+        cov = np.ascontiguousarray(noiseCovariance, dtype=np.float64).reshape(6, 6)
+        check(self._l.vf_add_between(self._h, C.c_uint64(previousKey), C.c_uint64(currentKey), _d(q),
+                                     _d(t), _d(cov)))
+
+    def solve(self):
+        check(self._l.vf_solve(self._h))
+
+    def addOptimizationCallback(self, callback):
+        """callback(time, q_wxyz, t, v, bias) -- GraphManager::OptimizationCallback"""
+        def tramp(_user, time, q, t, v, b):
+            callback(time, np.array(q[:4]), np.array(t[:3]), np.array(v[:3]), np.array(b[:6]))
+        cb = _lib.CALLBACK(tramp)
+        self._cbs.append(cb)
+        check(self._l.vf_set_callback(self._h, cb, None))
+
+    def getState(self):
+        q, t, v, b = np.zeros(4), np.zeros(3), np.zeros(3), np.zeros(6)
+        check(self._l.vf_get_state(self._h, _d(q), _d(t), _d(v), _d(b)))
+        return (q, t), v, b
+
+    def getBias(self):
+        b = np.zeros(6)
+        check(self._l.vf_get_bias(self._h, _d(b)))
+        return b
+
+    def graphSize(self):
+        """graph()->size(): factors staged since the last solve (3 priors initially)."""
+        s, q = C.c_int(), C.c_int()
+        check(self._l.vf_graph_staged(self._h, C.byref(s), C.byref(q)))
+        return s.value
+
+    def imuQueueSize(self):
+        s, q = C.c_int(), C.c_int()
+        check(self._l.vf_graph_staged(self._h, C.byref(s), C.byref(q)))
+        return q.value
+
+    def trajectory(self, key0, n):
+        s = np.zeros((n, 16))
+        check(self._l.vf_get_trajectory(self._h, C.c_uint64(key0), n, _d(s)))
+        return s
+
+    def imuFactor(self, key):
+        r = np.zeros(190)
+        check(self._l.vf_get_imu_factor(self._h, C.c_uint64(key), _d(r)))
+        return r

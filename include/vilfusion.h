@@ -139,6 +139,44 @@ int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms);
 int vf_engine_time_iterate(vf_engine* e, int iterations, float* ms);
 int vf_engine_counts(vf_engine* e, int64_t* n_imu, int64_t* n_between, int64_t* n_keyframes);
 
+/* ===================================================================== degeneracy metrics (K6)
+ * Batched form of the reference's per-message metric calls:
+ *   y[0] = 0 ; y[i] = metric(mat_now = mats[i], mat_prev = mats[i-1], pose_now, pose_prev)
+ * (apply_degen_function, vil_fusion/python/make_prettier_graphs.py:547-576).
+ * mats: (count,6,6) row-major; pose: (count,6) [x y z roll pitch yaw] or NULL; dtype 0 = f64,
+ * 1 = f32 (mats/pose/out all of that type); subset 0 = all 6x6, 1 = trans [0:3,0:3],
+ * 2 = rot [3:6,3:6].  metric ids follow degen_funcs
+ * (vil_fusion/python/degeneracy_detection_functions.py:283-303) then condition_number,
+ * differential_entropy.  reps/kernel_ms: optional HIP-event timing of the kernel alone. */
+#define VF_METRIC_D_OPT 0
+#define VF_METRIC_D_OPT_RATIO 1
+#define VF_METRIC_A_OPT 2
+#define VF_METRIC_A_OPT_RATIO 3
+#define VF_METRIC_E_OPT 4
+#define VF_METRIC_E_OPT_RATIO 5
+#define VF_METRIC_MAX_EIGEN 6
+#define VF_METRIC_MAX_EIGEN_RATIO 7
+#define VF_METRIC_JENSEN_BREGMAN 8
+#define VF_METRIC_CORRELATION_MATRIX_DISTANCE 9
+#define VF_METRIC_KULLBACK_LEIBLER 10
+#define VF_METRIC_NORM_FROBENIUS 11
+#define VF_METRIC_NORM_FROBENIUS_RATIO 12
+#define VF_METRIC_NORM_NUCLEAR 13
+#define VF_METRIC_NORM_NUCLEAR_RATIO 14
+#define VF_METRIC_NORM_1 15
+#define VF_METRIC_NORM_1_RATIO 16
+#define VF_METRIC_NORM_2 17
+#define VF_METRIC_NORM_2_RATIO 18
+#define VF_METRIC_CONDITION_NUMBER 19
+#define VF_METRIC_DIFFERENTIAL_ENTROPY 20
+int vf_degeneracy_batch(const void* mats, const void* pose, int count, int dtype, int subset, int metric,
+                        void* out, int reps, float* kernel_ms);
+/* The shipped gate (gtsam_fusion/src/degerate_odometry_filter.cpp:29-47): float32 log det of the
+ * rotation (3,3) and translation (0,0) 3x3 blocks of the 36-float LOAM Hessian; keep[i] = 0 when
+ * either is below its threshold (fusion_params.yaml:35-36: 11.5 / 28.9). */
+int vf_dopt_filter_f32(const float* hessians36, int count, float rot_thr, float trans_thr, float* rot_dopt,
+                       float* trans_dopt, unsigned char* keep);
+
 /* ===================================================================== GraphManager surface
  * Drop-in for VILFusion::GraphManager + VILFusion::IMUManager.  ROS-free, usable in simulated
  * time, every call thread-safe (GraphManager.h:4-6): the same two-lock discipline as the

@@ -1,0 +1,541 @@
+// vf_degeneracy.hip -- K6: batched degeneracy metrics on 6x6 information / covariance matrices
+// and their 3x3 translation / rotation blocks, one lane per message, everything in registers.
+//
+// Replaces the per-message numpy/LAPACK calls of the reference's metric library
+// (vil_fusion/python/degeneracy_detection_functions.py:38-251) as driven by
+// apply_degen_function (vil_fusion/python/make_prettier_graphs.py:547-576) and by the online
+// node (vil_fusion/src/vil_fusion/degeneracy_detection.py:115-130), and the shipped float32
+// D-optimality gate (gtsam_fusion/src/degerate_odometry_filter.cpp:29-47).
+//
+// Small-matrix kernels: cyclic Jacobi for symmetric eigenvalues, one-sided (Hestenes) Jacobi for
+// singular values, LU with partial pivoting for det / inverse, all with compile-time indices so
+// a 6x6 lives in 36 registers.  float64 and float32 instantiations (fp32 tolerance sweep).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/vilfusion.h"
+
+extern "C" void vf_set_last_error_(const char* msg);
+
+namespace {
+
+#define DI __device__ __forceinline__
+
+template <typename T> struct Lim;
+template <> struct Lim<double> { static constexpr double eps = 2.220446049250313e-16; static constexpr int sweeps = 12; };
+template <> struct Lim<float> { static constexpr float eps = 1.1920929e-07f; static constexpr int sweeps = 8; };
+
+template <typename T> DI T t_sqrt(T x) { return sqrt(x); }
+template <typename T> DI T t_abs(T x) { return fabs(x); }
+
+// symmetric eigenvalues, cyclic Jacobi (two-sided rotations on the full matrix)
+template <typename T, int N>
+DI void jacobi_eig(T (&a)[N * N], T (&ev)[N]) {
+#pragma unroll 1
+    for (int sweep = 0; sweep < Lim<T>::sweeps; sweep++) {
+#pragma unroll
+        for (int p = 0; p < N - 1; p++)
+#pragma unroll
+            for (int q = p + 1; q < N; q++) {
+                const T apq = a[p * N + q];
+                if (apq != T(0)) {
+                    const T theta = (a[q * N + q] - a[p * N + p]) / (T(2) * apq);
+                    const T t = copysign(T(1), theta) / (t_abs(theta) + t_sqrt(theta * theta + T(1)));
+                    const T c = T(1) / t_sqrt(t * t + T(1)), s = t * c;
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        const T akp = a[k * N + p], akq = a[k * N + q];
+                        a[k * N + p] = c * akp - s * akq;
+                        a[k * N + q] = s * akp + c * akq;
+                    }
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        const T apk = a[p * N + k], aqk = a[q * N + k];
+                        a[p * N + k] = c * apk - s * aqk;
+                        a[q * N + k] = s * apk + c * aqk;
+                    }
+                }
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) ev[i] = a[i * N + i];
+}
+
+// singular values of a general matrix, one-sided Jacobi on the columns
+template <typename T, int N>
+DI void jacobi_svd(T (&a)[N * N], T (&sv)[N]) {
+#pragma unroll 1
+    for (int sweep = 0; sweep < Lim<T>::sweeps; sweep++) {
+#pragma unroll
+        for (int p = 0; p < N - 1; p++)
+#pragma unroll
+            for (int q = p + 1; q < N; q++) {
+                T al = 0, be = 0, ga = 0;
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    al = fma(a[k * N + p], a[k * N + p], al);
+                    be = fma(a[k * N + q], a[k * N + q], be);
+                    ga = fma(a[k * N + p], a[k * N + q], ga);
+                }
+                if (t_abs(ga) > Lim<T>::eps * T(0.01) * t_sqrt(al * be) && ga != T(0)) {
+                    const T zeta = (be - al) / (T(2) * ga);
+                    const T t = copysign(T(1), zeta) / (t_abs(zeta) + t_sqrt(T(1) + zeta * zeta));
+                    const T c = T(1) / t_sqrt(T(1) + t * t), s = c * t;
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        const T akp = a[k * N + p], akq = a[k * N + q];
+                        a[k * N + p] = c * akp - s * akq;
+                        a[k * N + q] = s * akp + c * akq;
+                    }
+                }
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        T s = 0;
+#pragma unroll
+        for (int k = 0; k < N; k++) s = fma(a[k * N + i], a[k * N + i], s);
+        sv[i] = t_sqrt(s);
+    }
+}
+
+// LU with partial pivoting (row swaps by predicated moves): log|det| as numpy.linalg.slogdet()[1]
+template <typename T, int N>
+DI T lu_logabsdet(const T (&m)[N * N]) {
+    T a[N * N];
+#pragma unroll
+    for (int i = 0; i < N * N; i++) a[i] = m[i];
+    T logabs = T(0);
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        int piv = c;
+        T best = t_abs(a[c * N + c]);
+#pragma unroll
+        for (int r = c + 1; r < N; r++) {
+            const T v = t_abs(a[r * N + c]);
+            if (v > best) { best = v; piv = r; }
+        }
+#pragma unroll
+        for (int r = c + 1; r < N; r++)
+            if (piv == r) {
+#pragma unroll
+                for (int k = 0; k < N; k++) { const T t = a[c * N + k]; a[c * N + k] = a[r * N + k]; a[r * N + k] = t; }
+            }
+        const T d = a[c * N + c];
+        logabs += log(t_abs(d));
+        const T inv = T(1) / d;
+#pragma unroll
+        for (int r = c + 1; r < N; r++) {
+            const T f = a[r * N + c] * inv;
+#pragma unroll
+            for (int k = c + 1; k < N; k++) a[r * N + k] = fma(-f, a[c * N + k], a[r * N + k]);
+        }
+    }
+    return logabs;
+}
+
+// plain determinant with the swap parity applied
+template <typename T, int N>
+DI T lu_det(const T (&m)[N * N]) {
+    T a[N * N];
+#pragma unroll
+    for (int i = 0; i < N * N; i++) a[i] = m[i];
+    T det = T(1);
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        int piv = c;
+        T best = t_abs(a[c * N + c]);
+#pragma unroll
+        for (int r = c + 1; r < N; r++) {
+            const T v = t_abs(a[r * N + c]);
+            if (v > best) { best = v; piv = r; }
+        }
+#pragma unroll
+        for (int r = c + 1; r < N; r++)
+            if (piv == r) {
+#pragma unroll
+                for (int k = 0; k < N; k++) { const T t = a[c * N + k]; a[c * N + k] = a[r * N + k]; a[r * N + k] = t; }
+                det = -det;
+            }
+        const T d = a[c * N + c];
+        det *= d;
+        const T inv = T(1) / d;
+#pragma unroll
+        for (int r = c + 1; r < N; r++) {
+            const T f = a[r * N + c] * inv;
+#pragma unroll
+            for (int k = c + 1; k < N; k++) a[r * N + k] = fma(-f, a[c * N + k], a[r * N + k]);
+        }
+    }
+    return det;
+}
+
+// inverse by Gauss-Jordan with partial pivoting
+template <typename T, int N>
+DI void gj_inverse(const T (&m)[N * N], T (&inv)[N * N]) {
+    T a[N * N];
+#pragma unroll
+    for (int i = 0; i < N * N; i++) { a[i] = m[i]; inv[i] = T(0); }
+#pragma unroll
+    for (int i = 0; i < N; i++) inv[i * N + i] = T(1);
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        int piv = c;
+        T best = t_abs(a[c * N + c]);
+#pragma unroll
+        for (int r = c + 1; r < N; r++) {
+            const T v = t_abs(a[r * N + c]);
+            if (v > best) { best = v; piv = r; }
+        }
+#pragma unroll
+        for (int r = c + 1; r < N; r++)
+            if (piv == r) {
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    T t = a[c * N + k]; a[c * N + k] = a[r * N + k]; a[r * N + k] = t;
+                    t = inv[c * N + k]; inv[c * N + k] = inv[r * N + k]; inv[r * N + k] = t;
+                }
+            }
+        const T ip = T(1) / a[c * N + c];
+#pragma unroll
+        for (int k = 0; k < N; k++) { a[c * N + k] *= ip; inv[c * N + k] *= ip; }
+#pragma unroll
+        for (int r = 0; r < N; r++)
+            if (r != c) {
+                const T f = a[r * N + c];
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    a[r * N + k] = fma(-f, a[c * N + k], a[r * N + k]);
+                    inv[r * N + k] = fma(-f, inv[c * N + k], inv[r * N + k]);
+                }
+            }
+    }
+}
+
+template <typename T, int N>
+DI void matmul(const T (&a)[N * N], const T (&b)[N * N], T (&c)[N * N]) {
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            T s = 0;
+#pragma unroll
+            for (int k = 0; k < N; k++) s = fma(a[i * N + k], b[k * N + j], s);
+            c[i * N + j] = s;
+        }
+}
+
+// eigenvalues of now * prev^-1 for SPD prev: similar to L^-1 now L^-T with prev = L L^T
+template <typename T, int N>
+DI void ratio_eig(const T (&now)[N * N], const T (&prev)[N * N], T (&ev)[N], bool& ok) {
+    T L[N * N];
+#pragma unroll
+    for (int i = 0; i < N * N; i++) L[i] = T(0);
+    ok = true;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        T s = prev[j * N + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s = fma(-L[j * N + k], L[j * N + k], s);
+        if (!(s > T(0))) { ok = false; s = T(1); }
+        const T ljj = t_sqrt(s);
+        L[j * N + j] = ljj;
+#pragma unroll
+        for (int i = j + 1; i < N; i++) {
+            T v = T(0.5) * (prev[i * N + j] + prev[j * N + i]);
+#pragma unroll
+            for (int k = 0; k < j; k++) v = fma(-L[i * N + k], L[j * N + k], v);
+            L[i * N + j] = v / ljj;
+        }
+    }
+    // Y = L^-1 now (forward substitution on each column), S = Y L^-T (same on rows)
+    T Y[N * N], S[N * N];
+#pragma unroll
+    for (int c = 0; c < N; c++)
+#pragma unroll
+        for (int r = 0; r < N; r++) {
+            T v = T(0.5) * (now[r * N + c] + now[c * N + r]);
+#pragma unroll
+            for (int k = 0; k < r; k++) v = fma(-L[r * N + k], Y[k * N + c], v);
+            Y[r * N + c] = v / L[r * N + r];
+        }
+#pragma unroll
+    for (int r = 0; r < N; r++)
+#pragma unroll
+        for (int c = 0; c < N; c++) {
+            T v = Y[r * N + c];
+#pragma unroll
+            for (int k = 0; k < c; k++) v = fma(-L[c * N + k], S[r * N + k], v);
+            S[r * N + c] = v / L[c * N + c];
+        }
+#pragma unroll
+    for (int r = 0; r < N; r++)
+#pragma unroll
+        for (int c = r + 1; c < N; c++) { const T m = T(0.5) * (S[r * N + c] + S[c * N + r]); S[r * N + c] = m; S[c * N + r] = m; }
+    jacobi_eig<T, N>(S, ev);
+}
+
+enum Metric { D_OPT, D_OPT_RATIO, A_OPT, A_OPT_RATIO, E_OPT, E_OPT_RATIO, MAX_EIGEN, MAX_EIGEN_RATIO, JENSEN_BREGMAN,
+              CORR_DIST, KULLBACK_LEIBLER, NORM_FRO, NORM_FRO_RATIO, NORM_NUC, NORM_NUC_RATIO, NORM_1, NORM_1_RATIO,
+              NORM_2, NORM_2_RATIO, COND_NUMBER, DIFF_ENTROPY, N_METRICS };
+
+template <typename T, int N>
+DI T norm1(const T (&a)[N * N]) {
+    T best = 0;
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        T s = 0;
+#pragma unroll
+        for (int r = 0; r < N; r++) s += t_abs(a[r * N + c]);
+        best = s > best ? s : best;
+    }
+    return best;
+}
+template <typename T, int N>
+DI T normfro(const T (&a)[N * N]) {
+    T s = 0;
+#pragma unroll
+    for (int i = 0; i < N * N; i++) s = fma(a[i], a[i], s);
+    return t_sqrt(s);
+}
+
+// mats: (T,6,6) row-major, pose (T,6) or null; off = 0 (all / trans) or 3 (rot); out[0] = 0
+template <typename T, int N>
+__global__ void __launch_bounds__(64) k_degeneracy(const T* __restrict__ mats, const T* __restrict__ pose, int count, int off,
+                                                   int metric, T* __restrict__ out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    if (i == 0) { out[0] = T(0); return; }   // make_prettier_graphs.py:562-563
+    T now[N * N], prev[N * N];
+#pragma unroll
+    for (int r = 0; r < N; r++)
+#pragma unroll
+        for (int c = 0; c < N; c++) {
+            now[r * N + c] = mats[(size_t)i * 36 + (off + r) * 6 + off + c];
+            prev[r * N + c] = mats[(size_t)(i - 1) * 36 + (off + r) * 6 + off + c];
+        }
+    const T nan = T(NAN);
+    T y = nan;
+    const bool is_ratio = metric == D_OPT_RATIO || metric == A_OPT_RATIO || metric == NORM_FRO_RATIO ||
+                          metric == NORM_NUC_RATIO || metric == NORM_1_RATIO || metric == NORM_2_RATIO;
+    T ratio[N * N];
+    if (is_ratio) {
+        T pinv[N * N];
+        gj_inverse<T, N>(prev, pinv);
+        matmul<T, N>(now, pinv, ratio);
+    }
+    switch (metric) {
+        case D_OPT: case D_OPT_RATIO: {
+            const T la = (metric == D_OPT) ? lu_logabsdet<T, N>(now) : lu_logabsdet<T, N>(ratio);
+            y = exp(la / T(N));
+        } break;
+        case A_OPT: case A_OPT_RATIO: {
+            T s = 0;
+#pragma unroll
+            for (int k = 0; k < N; k++) s += (metric == A_OPT) ? now[k * N + k] : ratio[k * N + k];
+            y = s;
+        } break;
+        case E_OPT: case MAX_EIGEN: {
+            T s[N * N], ev[N];
+#pragma unroll
+            for (int r = 0; r < N; r++)
+#pragma unroll
+                for (int c = 0; c < N; c++) s[r * N + c] = T(0.5) * (now[r * N + c] + now[c * N + r]);
+            jacobi_eig<T, N>(s, ev);
+            T lo = ev[0], hi = ev[0];
+#pragma unroll
+            for (int k = 1; k < N; k++) { lo = ev[k] < lo ? ev[k] : lo; hi = ev[k] > hi ? ev[k] : hi; }
+            y = metric == E_OPT ? lo : hi;
+        } break;
+        case E_OPT_RATIO: case MAX_EIGEN_RATIO: {
+            T ev[N];
+            bool ok;
+            ratio_eig<T, N>(now, prev, ev, ok);
+            T lo = ev[0], hi = ev[0];
+#pragma unroll
+            for (int k = 1; k < N; k++) { lo = ev[k] < lo ? ev[k] : lo; hi = ev[k] > hi ? ev[k] : hi; }
+            y = ok ? (metric == E_OPT_RATIO ? lo : hi) : nan;
+        } break;
+        case JENSEN_BREGMAN: {
+            T avg[N * N], prod[N * N];
+#pragma unroll
+            for (int k = 0; k < N * N; k++) avg[k] = (now[k] + prev[k]) / T(2);
+            matmul<T, N>(now, prev, prod);
+            y = lu_logabsdet<T, N>(avg) - T(0.5) * lu_det<T, N>(prod);
+        } break;
+        case CORR_DIST: {   // elementwise-product quirk: only the diagonal of the "correlation" survives
+            T tr = 0, fx = 0, fy = 0;
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const T dn = t_sqrt(now[k * N + k]), dp = t_sqrt(prev[k * N + k]);
+                if (!(dn > T(0)) || !(dp > T(0))) ok = false;
+                const T cn = (T(1) / dn) * now[k * N + k] * (T(1) / dn), cp = (T(1) / dp) * prev[k * N + k] * (T(1) / dp);
+                tr = fma(cn, cp, tr);
+                fx = fma(cn, cn, fx);
+                fy = fma(cp, cp, fy);
+            }
+            y = ok ? T(1) - tr / (t_sqrt(fx) * t_sqrt(fy)) : nan;
+        } break;
+        case KULLBACK_LEIBLER: {   // E1 = prev, E2 = now
+            T e2i[N * N], m[N * N];
+            gj_inverse<T, N>(now, e2i);
+            matmul<T, N>(e2i, prev, m);
+            T a = 0;
+#pragma unroll
+            for (int k = 0; k < N; k++) a += m[k * N + k] - T(1);
+            T du[N], b = 0;
+#pragma unroll
+            for (int k = 0; k < N; k++) du[k] = pose ? pose[(size_t)(i - 1) * 6 + off + k] - pose[(size_t)i * 6 + off + k] : T(0);
+#pragma unroll
+            for (int r = 0; r < N; r++) {
+                T s = 0;
+#pragma unroll
+                for (int c = 0; c < N; c++) s = fma(e2i[r * N + c], du[c], s);
+                b = fma(du[r], s, b);
+            }
+            const T c = log(t_abs(lu_det<T, N>(now)) / t_abs(lu_det<T, N>(prev)));
+            y = T(0.5) * (a + b + c);
+        } break;
+        case NORM_FRO: y = normfro<T, N>(now); break;
+        case NORM_FRO_RATIO: y = normfro<T, N>(ratio); break;
+        case NORM_1: y = norm1<T, N>(now); break;
+        case NORM_1_RATIO: y = norm1<T, N>(ratio); break;
+        case NORM_NUC: case NORM_2: case COND_NUMBER: case NORM_NUC_RATIO: case NORM_2_RATIO: {
+            T w[N * N], sv[N];
+            const bool r = metric == NORM_NUC_RATIO || metric == NORM_2_RATIO;
+#pragma unroll
+            for (int k = 0; k < N * N; k++) w[k] = r ? ratio[k] : now[k];
+            jacobi_svd<T, N>(w, sv);
+            T lo = sv[0], hi = sv[0], sum = 0;
+#pragma unroll
+            for (int k = 0; k < N; k++) { lo = sv[k] < lo ? sv[k] : lo; hi = sv[k] > hi ? sv[k] : hi; sum += sv[k]; }
+            y = (metric == NORM_NUC || metric == NORM_NUC_RATIO) ? sum : ((metric == COND_NUMBER) ? -(hi / lo) : hi);
+        } break;
+        case DIFF_ENTROPY: {
+            const T x = pow(T(2.0 * 3.141592653589793 * 2.718281828459045), T(N));
+            const T d = x * lu_det<T, N>(now);
+            y = d > T(0) ? T(0.5) * log(d) : nan;
+        } break;
+        default: break;
+    }
+    out[i] = y;
+}
+
+// degerate_odometry_filter.cpp:29-47 (float32): hessian (row-major floats) copied into a
+// column-major Eigen matrix, rotation = block(3,3), translation = block(0,0), log(det)
+__global__ void k_dopt_filter(const float* __restrict__ h, int count, float rot_thr, float trans_thr,
+                              float* __restrict__ rot, float* __restrict__ trans, unsigned char* __restrict__ keep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float* m = h + (size_t)i * 36;
+    auto det3 = [&](int o) {   // Eigen(r,c) = m[c*6 + r]
+        auto E = [&](int r, int c) { return m[(o + c) * 6 + o + r]; };
+        return E(0, 0) * (E(1, 1) * E(2, 2) - E(1, 2) * E(2, 1)) - E(0, 1) * (E(1, 0) * E(2, 2) - E(1, 2) * E(2, 0)) +
+               E(0, 2) * (E(1, 0) * E(2, 1) - E(1, 1) * E(2, 0));
+    };
+    const float r = logf(det3(3)), t = logf(det3(0));
+    rot[i] = r;
+    trans[i] = t;
+    keep[i] = !(r < rot_thr || t < trans_thr);
+}
+
+int derr(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    vf_set_last_error_(buf);
+    return code;
+}
+#define HIPCHK(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) return derr(VF_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+template <typename T>
+int run_batch(const void* mats, const void* pose, int count, int subset, int metric, void* out, int reps, float* kernel_ms) {
+    T *d_m = nullptr, *d_p = nullptr, *d_o = nullptr;
+    const size_t mb = (size_t)count * 36 * sizeof(T), pb = (size_t)count * 6 * sizeof(T), ob = (size_t)count * sizeof(T);
+    HIPCHK(hipMalloc((void**)&d_m, mb));
+    HIPCHK(hipMalloc((void**)&d_o, ob));
+    HIPCHK(hipMemcpy(d_m, mats, mb, hipMemcpyHostToDevice));
+    if (pose) {
+        HIPCHK(hipMalloc((void**)&d_p, pb));
+        HIPCHK(hipMemcpy(d_p, pose, pb, hipMemcpyHostToDevice));
+    }
+    const int off = subset == 2 ? 3 : 0;
+    const dim3 grid((count + 63) / 64), block(64);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    auto launch = [&]() {
+        if (subset == 0) hipLaunchKernelGGL((k_degeneracy<T, 6>), grid, block, 0, 0, d_m, d_p, count, off, metric, d_o);
+        else hipLaunchKernelGGL((k_degeneracy<T, 3>), grid, block, 0, 0, d_m, d_p, count, off, metric, d_o);
+    };
+    launch();
+    HIPCHK(hipDeviceSynchronize());
+    if (kernel_ms && reps > 0) {
+        HIPCHK(hipEventRecord(e0, 0));
+        for (int r = 0; r < reps; r++) launch();
+        HIPCHK(hipEventRecord(e1, 0));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        *kernel_ms = ms / reps;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, d_o, ob, hipMemcpyDeviceToHost));
+    (void)hipFree(d_m); (void)hipFree(d_o);
+    if (d_p) (void)hipFree(d_p);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return VF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vf_degeneracy_batch(const void* mats, const void* pose, int count, int dtype, int subset, int metric, void* out,
+                        int reps, float* kernel_ms) {
+    if (!mats || !out || count < 0) return derr(VF_ERR_INVALID, "null argument");
+    if (metric < 0 || metric >= N_METRICS) return derr(VF_ERR_INVALID, "unknown metric %d", metric);
+    if (subset < 0 || subset > 2) return derr(VF_ERR_INVALID, "subset must be 0 (all), 1 (trans) or 2 (rot)");
+    if (dtype != 0 && dtype != 1) return derr(VF_ERR_INVALID, "dtype must be 0 (f64) or 1 (f32)");
+    if (metric == KULLBACK_LEIBLER && !pose) return derr(VF_ERR_INVALID, "kullback_leibler needs poses");
+    if (count == 0) return VF_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return derr(VF_ERR_NO_DEVICE, "no HIP device visible; libvilfusion has no CPU path");
+    return dtype == 0 ? run_batch<double>(mats, pose, count, subset, metric, out, reps, kernel_ms)
+                      : run_batch<float>(mats, pose, count, subset, metric, out, reps, kernel_ms);
+}
+
+int vf_dopt_filter_f32(const float* hessians, int count, float rot_thr, float trans_thr, float* rot_dopt,
+                       float* trans_dopt, unsigned char* keep) {
+    if (!hessians || !rot_dopt || !trans_dopt || !keep || count < 0) return derr(VF_ERR_INVALID, "null argument");
+    if (count == 0) return VF_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return derr(VF_ERR_NO_DEVICE, "no HIP device visible; libvilfusion has no CPU path");
+    float *d_h = nullptr, *d_r = nullptr, *d_t = nullptr;
+    unsigned char* d_k = nullptr;
+    HIPCHK(hipMalloc((void**)&d_h, (size_t)count * 36 * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&d_r, count * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&d_t, count * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&d_k, count));
+    HIPCHK(hipMemcpy(d_h, hessians, (size_t)count * 36 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_dopt_filter, dim3((count + 255) / 256), dim3(256), 0, 0, d_h, count, rot_thr, trans_thr, d_r, d_t, d_k);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(rot_dopt, d_r, count * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(trans_dopt, d_t, count * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(keep, d_k, count, hipMemcpyDeviceToHost));
+    (void)hipFree(d_h); (void)hipFree(d_r); (void)hipFree(d_t); (void)hipFree(d_k);
+    return VF_OK;
+}
+
+}  // extern "C"

@@ -17,6 +17,7 @@
 // window in LDS).
 #include "vf_kernels.hpp"
 #include "vf_math.hpp"
+#include <cstdlib>
 
 namespace vf {
 
@@ -687,7 +688,7 @@ VF_DI double fast_rsqrt(double x) {
 constexpr int PROWS = 43;
 constexpr int LDW = 61;
 
-__global__ void __launch_bounds__(64) k_band_solve(View v) {
+__global__ void __launch_bounds__(64) k_band_solve(View v, int ablate) {
     const int w = blockIdx.x, lane = threadIdx.x;
     const int lo = v.lo[w], hi = v.hi[w], n = hi - lo;
     if (n <= 0) return;
@@ -791,6 +792,7 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
         for (int c = 0; c < 15; c++)
             p[c] = lane < 42 ? Wd[ri + s0 + c] : (lane == 42 ? Gd[s0 + c] : 0.0);
         double dinv = 0.0;
+        if (!(ablate & 4))
 #pragma unroll
         for (int c = 0; c < 15; c++) {
             double dv = readlane_d(p[c], c);
@@ -809,10 +811,11 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
             for (int c = 0; c < 15; c++) P[lane * 15 + c] = (lane == c) ? dinv : p[c];  // diagonal holds 1/L_cc
         }
         __syncthreads();
-        {   // panel -> HBM (coalesced), kept for the back substitution
+        if (!(ablate & 8)) {   // panel -> HBM (coalesced), kept for the back substitution
             double* Lk = v.Lp + (base + k) * PANEL;
             for (int e = lane; e < PANEL; e += 64) Lk[e] = P[e];
         }
+        if (!(ablate & 1))
 #pragma unroll
         for (int j = 0; j < 7; j++) {
             if (lane + 64 * j < 405) {
@@ -836,6 +839,7 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
     }
 
     // back substitution: delta_k = L_kk^-T (y_k - sum_p L[p][k-cols]^T delta(p)), p over rows 15..41
+    if (ablate & 2) { if (lane == 0) v.fail[w] = failed; return; }
     if (lane < 60) dl[lane] = 0.0;
     const int part = lane >> 4, cc = lane & 15;          // 4 partial sums per column
     const int p_lo = 15 + part * 7, p_hi = part == 3 ? 42 : p_lo + 7;
@@ -1086,7 +1090,8 @@ void launch_assemble(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_assemble, dim3(nblk(v.G, 64)), dim3(64), 0, s, v);
 }
 void launch_band_solve(const View& v, hipStream_t s) {
-    hipLaunchKernelGGL(k_band_solve, dim3(v.B), dim3(64), 0, s, v);
+    static const int ablate = getenv("VF_SOLVE_ABLATE") ? atoi(getenv("VF_SOLVE_ABLATE")) : 0;  // timing experiments only
+    hipLaunchKernelGGL(k_band_solve, dim3(v.B), dim3(64), 0, s, v, ablate);
 }
 void launch_retract(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_retract, dim3(nblk(v.G, 256)), dim3(256), 0, s, v);

@@ -44,4 +44,14 @@ if bench:
     b = json.load(open(bench))
     lines += ["", "bench.py line of the same configuration (un-profiled run):", "", "```json", json.dumps(b), "```"]
 open(os.path.join(out, f"{tag}_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
+# per-factor HBM traffic of K1 for bench.py's roofline.traffic (needs the factor count of the run)
+if bench:
+    n_imu = json.load(open(bench))["config"]["factors_per_gpu"]["imu"]
+    k = "vf::k_linearize_imu"
+    per = (2 * f[k][1] + w[k][1]) * 1024 / n_imu
+    json.dump({"k1_bytes_per_imu_factor": per, "read_bytes_per_imu_factor": 2 * f[k][1] * 1024 / n_imu,
+               "write_bytes_per_imu_factor": w[k][1] * 1024 / n_imu,
+               "source": f"profiles/{tag}_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
+                         "read = 2*FETCH_SIZE*1024 per MI355X_MICROARCH.md, write = WRITE_SIZE*1024)"},
+              open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print("\n".join(lines[:16]))

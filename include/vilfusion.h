@@ -120,10 +120,10 @@ int vf_engine_read_between_lin(vf_engine* e, int window, int which, int k0, int 
                                double* Ja36, double* Jb36);
 int vf_engine_read_normal(vf_engine* e, int window, int k0, int n, double* Hband, double* g15);
 int vf_engine_read_delta(vf_engine* e, int window, int k0, int n, double* delta15);
-/* Cholesky panels of the last vf_engine_solve: per keyframe 43x15 row-major = rows of L in the
- * keyframe's 15 columns for [k:15][k+1:15][k+2:pose 6][k+3:pose 6] + the forward-substituted
- * rhs row; the diagonal entries hold 1/L_cc. */
-int vf_engine_read_panels(vf_engine* e, int window, int k0, int n, double* panels645);
+/* Cholesky panels of the last vf_engine_solve: per keyframe 43 rows x 16 doubles (15 used) =
+ * rows of L in the keyframe's 15 columns for [k+1:15][k+2:pose 6][k+3:pose 6] (27 rows), the
+ * forward-substituted rhs row (1), and L_kk^-T (15 rows, upper triangular). */
+int vf_engine_read_panels(vf_engine* e, int window, int k0, int n, double* panels688);
 int vf_engine_read_lm(vf_engine* e, int window, double* cost, double* lambda, int* accepted,
                       int* rejected, int* solve_failures);
 

@@ -50,6 +50,9 @@ __host__ __device__ constexpr int off15(int r) { return r * 15 - r * (r - 1) / 2
 __host__ __device__ constexpr int idx9(int a, int b) { return a * 9 - a * (a - 1) / 2 + (b - a); }
 __host__ __device__ constexpr int off6(int r) { return r * 6 - r * (r - 1) / 2; }
 
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
 VF_DI double col3(const M3& A, int r, int c) { return A.a[r * 3 + c]; }
 
 // o[a] = sum_{b >= a, LO <= b < HI} R11(a,b) u[b]   (upper-triangular 9x9 times sparse column)
@@ -464,193 +467,201 @@ __global__ void k_linearize_prior(View v, int which) {
 }
 
 // ------------------------------------------------------------------------------------ K3
-// Owner-computes: lane = keyframe k. Deterministic (no atomics).
+// Block-sparse J^T J / J^T r, owner-computes per keyframe, deterministic (no atomics):
 //   H[k][k]   = Jj^T Jj (imu k) + Ji^T Ji (imu k+1) + between (as b at k, as a at k+d) + prior
 //   H[k][k-1] = Jj^T Ji (imu k) + Jb^T Ja (between a=k-1)
 //   H[k][k-d] = Jb^T Ja (between a=k-d), pose 6x6 only
+// One 256-thread block per tile of 16 keyframes.  The tile's 17 IMU linearisations (r | J) are
+// staged once into LDS with coalesced 128-byte segments (every J entry leaves HBM exactly once),
+// then each wave forms the 16x16 blocks of [J r]^T [J r] for 4 keyframes with
+// v_mfma_f64_16x16x4 (column 15 of a tile carries J^T r, so the gradient comes for free) and
+// writes the H block rows coalesced straight from the MFMA C layout.  The 6x6 between terms and
+// the prior are added on the VALU from LDS before the store.
 __host__ __device__ constexpr int imu_col(int side_j, int c) {
     return c < 9 ? c + (side_j ? 9 : 0) : c + 9 + (side_j ? 6 : 0);
 }
-__host__ __device__ constexpr int tri(int a, int b) { return a * (a + 1) / 2 + b; }  // a >= b
+constexpr int AT = 16;          // keyframes per block
+constexpr int LJS = 465;        // LDS stride of one factor's (r | J), odd
+constexpr int LBS = 79;         // LDS stride of one between linearisation (78 + pad), odd
 
-template <int SIDE_J>
-VF_DI void acc_imu_diag(const double* __restrict__ f, double (&D)[120], double (&g)[15]) {
-#pragma unroll 1
-    for (int r = 0; r < 15; r++) {
-        double x[15];
-#pragma unroll
-        for (int c = 0; c < 15; c++) x[c] = f[(size_t)(15 + r * 30 + imu_col(SIDE_J, c)) * TILE];
-        const double rr = f[(size_t)r * TILE];
-#pragma unroll
-        for (int a = 0; a < 15; a++) {
-            g[a] = fma(x[a], rr, g[a]);
-#pragma unroll
-            for (int b = 0; b <= a; b++) D[tri(a, b)] = fma(x[a], x[b], D[tri(a, b)]);
-        }
-    }
-}
-
-__global__ void __launch_bounds__(64) k_assemble(View v) {
-    const long gk = (long)blockIdx.x * 64 + threadIdx.x;
-    if (gk >= v.G) return;
-    const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
+__global__ void __launch_bounds__(256) k_assemble(View v) {
+    const long gk0 = (long)blockIdx.x * AT;
+    if (gk0 >= v.G) return;
+    const int w = (int)(gk0 / v.M), k0 = (int)(gk0 - (long)w * v.M);
     const int lo = v.lo[w], hi = v.hi[w];
-    if (k < lo || k >= hi) return;
+    if (k0 + AT <= lo || k0 >= hi) return;   // no active keyframe in this tile (uniform)
     const int b = v.sel[w];
+    const int tid = threadIdx.x;
     const size_t tiles = (size_t)(v.G >> 6);
     const double* imu_out = v.imu_out + (size_t)b * tiles * IMU_OUT * TILE;
     const double* btw_out = v.btw_out + (size_t)b * tiles * BTW_OUT * TILE;
-    auto imu_f = [&](long g) { return imu_out + (size_t)(g >> 6) * IMU_OUT * TILE + (g & 63); };
-    auto btw_f = [&](long g) { return btw_out + (size_t)(g >> 6) * BTW_OUT * TILE + (g & 63); };
-    double* Hk = v.H + (size_t)gk * HROW;
+    __shared__ double LJ[(AT + 1) * LJS];
+    __shared__ double LB[(AT + 3) * LBS];
+    __shared__ int s_a[AT + 3];
 
-    double D[120], g[15];
+    // ---- stage (r | J) of factors k0 .. k0+15: thread = (field group, factor), 128-B segments.
+    // All of a thread's global loads are issued before the first LDS write (38 loads in flight
+    // per thread) so that the tile costs one HBM round trip, not one per batch.
+    {
+        const int fac = tid & 15, fg = tid >> 4;
+        const int k = k0 + fac;
+        const bool ok = k > lo && k < hi;
+        const double* src = imu_out + (size_t)(gk0 >> 6) * IMU_OUT * TILE + (gk0 & 63) + fac;
+        double tj[30];
 #pragma unroll
-    for (int i = 0; i < 120; i++) D[i] = 0.0;
+        for (int it = 0; it < 30; it++) {
+            const int f = it * 16 + fg;
+            tj[it] = (ok && f < IMU_OUT) ? src[(size_t)f * TILE] : 0.0;
+        }
+        // factor k0+16 (its i-side feeds H[k0+15][k0+15]); it may live in the next AoSoA tile
+        const int k16 = k0 + AT;
+        const bool ok16 = k16 > lo && k16 < hi;
+        const long g16 = gk0 + AT;
+        const double* src16 = imu_out + (size_t)(g16 >> 6) * IMU_OUT * TILE + (g16 & 63);
+        double t16[2];
 #pragma unroll
-    for (int i = 0; i < 15; i++) g[i] = 0.0;
-
-    const bool has_in = k > lo;         // imu factor k (k-1 -> k)
-    const bool has_out = k + 1 < hi;    // imu factor k+1 (k -> k+1)
-    if (has_in) acc_imu_diag<1>(imu_f(gk), D, g);
-    if (has_out) acc_imu_diag<0>(imu_f(gk + 1), D, g);
-
-    // between factor ending here (as b)
-    const int a_here = has_in ? v.btw_a[gk] : -1;
-    const bool btw_here = a_here >= lo && a_here < k;
-    if (btw_here) {
-        const double* f = btw_f(gk);
-#pragma unroll 1
-        for (int r = 0; r < 6; r++) {
-            double x[6];
+        for (int j = 0; j < 2; j++) {
+            const int f = tid + 256 * j;
+            t16[j] = (ok16 && f < IMU_OUT) ? src16[(size_t)f * TILE] : 0.0;
+        }
+        // between linearisations of slots k0 .. k0+18
+        double tb[6];
 #pragma unroll
-            for (int c = 0; c < 6; c++) x[c] = f[(size_t)(42 + r * 6 + c) * TILE];
-            const double rr = f[(size_t)r * TILE];
+        for (int j = 0; j < 6; j++) {
+            const int e = tid + 256 * j;
+            const int sl = e / BTW_OUT, f = e - sl * BTW_OUT;
+            const int ks = k0 + sl;
+            const long gs = gk0 + sl;
+            tb[j] = (e < (AT + 3) * BTW_OUT && ks > lo && ks < hi) ? btw_out[((size_t)(gs >> 6) * BTW_OUT + f) * TILE + (gs & 63)] : 0.0;
+        }
+        if (tid < AT + 3) {
+            const int ks = k0 + tid;
+            int a = -1;
+            if (ks > lo && ks < hi) { a = v.btw_a[gk0 + tid]; if (a < lo || a >= ks) a = -1; }
+            s_a[tid] = a;
+        }
 #pragma unroll
-            for (int a = 0; a < 6; a++) {
-                g[a] = fma(x[a], rr, g[a]);
+        for (int it = 0; it < 30; it++) {
+            const int f = it * 16 + fg;
+            if (f < IMU_OUT) LJ[fac * LJS + f] = tj[it];
+        }
 #pragma unroll
-                for (int c = 0; c <= a; c++) D[tri(a, c)] = fma(x[a], x[c], D[tri(a, c)]);
-            }
+        for (int j = 0; j < 2; j++) {
+            const int f = tid + 256 * j;
+            if (f < IMU_OUT) LJ[AT * LJS + f] = t16[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const int e = tid + 256 * j;
+            if (e < (AT + 3) * BTW_OUT) { const int sl = e / BTW_OUT; LB[sl * LBS + (e - sl * BTW_OUT)] = tb[j]; }
         }
     }
-    // between factors starting here (as a), stored in the slot of their b = k + d
-#pragma unroll 1
-    for (int d = 1; d <= 3; d++) {
-        if (k + d >= hi) break;
-        if (v.btw_a[gk + d] != k) continue;
-        const double* f = btw_f(gk + d);
-#pragma unroll 1
-        for (int r = 0; r < 6; r++) {
-            double x[6];
-#pragma unroll
-            for (int c = 0; c < 6; c++) x[c] = f[(size_t)(6 + r * 6 + c) * TILE];
-            const double rr = f[(size_t)r * TILE];
-#pragma unroll
-            for (int a = 0; a < 6; a++) {
-                g[a] = fma(x[a], rr, g[a]);
-#pragma unroll
-                for (int c = 0; c <= a; c++) D[tri(a, c)] = fma(x[a], x[c], D[tri(a, c)]);
-            }
-        }
-    }
-    if (v.prior_k[w] == k) {
-        const double* f = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT;
-#pragma unroll 1
-        for (int r = 0; r < 15; r++) {
-            double x[15];
-#pragma unroll
-            for (int c = 0; c < 15; c++) x[c] = f[15 + r * 15 + c];
-            const double rr = f[r];
-#pragma unroll
-            for (int a = 0; a < 15; a++) {
-                g[a] = fma(x[a], rr, g[a]);
-#pragma unroll
-                for (int c = 0; c <= a; c++) D[tri(a, c)] = fma(x[a], x[c], D[tri(a, c)]);
-            }
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 15; a++) {
-        v.gvec[(size_t)gk * 15 + a] = g[a];
-#pragma unroll
-        for (int c = 0; c < 15; c++) Hk[a * 15 + c] = (c <= a) ? D[tri(a, c)] : D[tri(c, a)];
-    }
+    __syncthreads();
 
-    // off-diagonal block d=1: Jj^T Ji of imu factor k (+ between a = k-1 in the pose 6x6)
-    if (has_in) {
-        const double* f = imu_f(gk);
-#pragma unroll 1
-        for (int cb = 0; cb < 3; cb++) {  // 5 columns of Ji at a time
-            double O[75];
+    const int wv = tid >> 6, lane = tid & 63;
+    const int ci = lane & 15, kq = lane >> 4;
+    const int colI = ci < 15 ? 15 + imu_col(0, ci) : -1, colJ = ci < 15 ? 15 + imu_col(1, ci) : -1;
+    auto load_ops = [&](int lf, double (&ai)[4], double (&aj)[4]) {
+        const double* F = LJ + lf * LJS;
 #pragma unroll
-            for (int i = 0; i < 75; i++) O[i] = 0.0;
-#pragma unroll 1
-            for (int r = 0; r < 15; r++) {
-                double xj[15], xi[5];
-#pragma unroll
-                for (int c = 0; c < 15; c++) xj[c] = f[(size_t)(15 + r * 30 + imu_col(1, c)) * TILE];
-#pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    const int cc = cb * 5 + c;  // runtime (cb) -> compute the column index arithmetically
-                    const int col = cc < 9 ? cc : cc + 9;
-                    xi[c] = f[(size_t)(15 + r * 30 + col) * TILE];
-                }
-#pragma unroll
-                for (int a = 0; a < 15; a++)
-#pragma unroll
-                    for (int c = 0; c < 5; c++) O[a * 5 + c] = fma(xj[a], xi[c], O[a * 5 + c]);
+        for (int q = 0; q < 4; q++) {
+            const int row = 4 * q + kq;
+            if (row < 15) {
+                ai[q] = ci < 15 ? F[row * 30 + colI] : F[row];
+                aj[q] = ci < 15 ? F[row * 30 + colJ] : F[row];
+            } else {
+                ai[q] = 0.0;
+                aj[q] = 0.0;
             }
-            if (btw_here && a_here == k - 1 && cb < 2) {
-                const double* fb = btw_f(gk);
+        }
+    };
+    // 6-row dot products on a between linearisation in LDS: offsets 6 = Ja, 42 = Jb, 0 = r
+    auto bdot = [&](int sl, int offA, int a, int offB, int bb) {
+        const double* Bq = LB + sl * LBS;
+        double sum = 0.0;
+#pragma unroll
+        for (int r6 = 0; r6 < 6; r6++) sum = fma(Bq[offA + r6 * 6 + a], Bq[offB + r6 * 6 + bb], sum);
+        return sum;
+    };
+    auto bdotr = [&](int sl, int offA, int a) {
+        const double* Bq = LB + sl * LBS;
+        double sum = 0.0;
+#pragma unroll
+        for (int r6 = 0; r6 < 6; r6++) sum = fma(Bq[offA + r6 * 6 + a], Bq[r6], sum);
+        return sum;
+    };
+
+    d4_t D = {0, 0, 0, 0};
+    const int lf0 = 4 * wv;
 #pragma unroll 1
-                for (int r = 0; r < 6; r++) {
-                    double xb[6];
+    for (int lf = lf0; lf <= lf0 + 4; lf++) {
+        double ai[4], aj[4];
+        load_ops(lf, ai, aj);
+        if (lf > lf0) {
+            // ---- finish keyframe kf = lf-1: D += Ji^T Ji of factor lf, add 6x6 terms, store
 #pragma unroll
-                    for (int c = 0; c < 6; c++) xb[c] = fb[(size_t)(42 + r * 6 + c) * TILE];
+            for (int q = 0; q < 4; q++) D = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[q], ai[q], D, 0, 0, 0);
+            const int kl = lf - 1, k = k0 + kl;
+            if (k >= lo && k < hi) {
+                const long gk = gk0 + kl;
+                double* Hk = v.H + (size_t)gk * HROW;
+                const bool btw_here = s_a[kl] >= 0;
+                const bool is_prior = v.prior_k[w] == k;
+                const double* Pq = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT;
 #pragma unroll
-                    for (int c = 0; c < 5; c++) {
-                        const int cc = cb * 5 + c;
-                        if (cc < 6) {
-                            const double xa = fb[(size_t)(6 + r * 6 + cc) * TILE];
+                for (int r = 0; r < 4; r++) {
+                    const int a = kq + 4 * r;
+                    double val = D[r];
+                    if (a < 6 && (ci < 6 || ci == 15)) {
+                        if (btw_here) val += ci == 15 ? bdotr(kl, 42, a) : bdot(kl, 42, a, 42, ci);
 #pragma unroll
-                            for (int a = 0; a < 6; a++) O[a * 5 + c] = fma(xb[a], xa, O[a * 5 + c]);
-                        }
+                        for (int d = 1; d <= 3; d++)
+                            if (s_a[kl + d] == k) val += ci == 15 ? bdotr(kl + d, 6, a) : bdot(kl + d, 6, a, 6, ci);
+                    }
+                    if (is_prior && a < 15) {
+                        double sum = 0.0;
+                        for (int rr = 0; rr < 15; rr++)
+                            sum = fma(Pq[15 + rr * 15 + a], ci < 15 ? Pq[15 + rr * 15 + ci] : Pq[rr], sum);
+                        val += sum;
+                    }
+                    if (a < 15) {
+                        if (ci < 15) Hk[a * 15 + ci] = val;
+                        else v.gvec[(size_t)gk * 15 + a] = val;
                     }
                 }
             }
-#pragma unroll
-            for (int a = 0; a < 15; a++)
-#pragma unroll
-                for (int c = 0; c < 5; c++) Hk[225 + a * 15 + cb * 5 + c] = O[a * 5 + c];
         }
-    }
-    // blocks d=2,3: pose 6x6 from a between factor with a = k-d (zero otherwise)
-#pragma unroll 1
-    for (int d = 2; d <= 3; d++) {
-        double O[36];
+        if (lf < lf0 + 4) {
+            // ---- keyframe kf = lf: off-diagonal block Jj^T Ji, pose-only blocks, start D = Jj^T Jj
+            d4_t O = {0, 0, 0, 0};
+            D = (d4_t){0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 36; i++) O[i] = 0.0;
-        if (btw_here && a_here == k - d) {
-            const double* fb = btw_f(gk);
-#pragma unroll 1
-            for (int r = 0; r < 6; r++) {
-                double xb[6], xa[6];
+            for (int q = 0; q < 4; q++) {
+                O = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[q], ai[q], O, 0, 0, 0);
+                D = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[q], aj[q], D, 0, 0, 0);
+            }
+            const int kl = lf, k = k0 + kl;
+            if (k >= lo && k < hi) {
+                double* Hk = v.H + (size_t)(gk0 + kl) * HROW;
+                const int ak = s_a[kl];
+                const int dk = ak >= 0 ? k - ak : 0;   // 1..3 when a between factor ends here
+                if (k > lo) {
 #pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    xb[c] = fb[(size_t)(42 + r * 6 + c) * TILE];
-                    xa[c] = fb[(size_t)(6 + r * 6 + c) * TILE];
+                    for (int r = 0; r < 4; r++) {
+                        const int a = kq + 4 * r;
+                        double val = O[r];
+                        if (dk == 1 && a < 6 && ci < 6) val += bdot(kl, 42, a, 6, ci);
+                        if (a < 15 && ci < 15) Hk[225 + a * 15 + ci] = val;
+                    }
                 }
-#pragma unroll
-                for (int a = 0; a < 6; a++)
-#pragma unroll
-                    for (int c = 0; c < 6; c++) O[a * 6 + c] = fma(xb[a], xa[c], O[a * 6 + c]);
+                if (lane < 36) {
+                    const int a6 = lane / 6, b6 = lane - a6 * 6;
+                    const double x = (dk >= 2) ? bdot(kl, 42, a6, 6, b6) : 0.0;
+                    Hk[450 + a6 * 15 + b6] = dk == 2 ? x : 0.0;
+                    Hk[675 + a6 * 15 + b6] = dk == 3 ? x : 0.0;
+                }
             }
         }
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-            for (int c = 0; c < 6; c++) Hk[d * 225 + a * 15 + c] = O[a * 6 + c];
     }
 }
 
@@ -676,69 +687,111 @@ VF_DI double fast_rsqrt(double x) {
 // One wavefront per window.  Right-looking block Cholesky of the block-banded normal matrix,
 // exploiting its profile: IMU factors couple consecutive keyframes in all 15 dof, between
 // factors couple keyframes up to 3 apart in the 6 pose dof only, so the active set while
-// eliminating keyframe k is  [k: 15] [k+1: 15] [k+2: pose 6] [k+3: pose 6]  = 42 rows, plus
-// the right-hand side carried as a 43rd row (forward substitution for free).
-//   * the 43x15 panel is factorised in registers: lane p owns row p, pivots/multipliers are
-//     broadcast with v_readlane, 1/sqrt by v_rsq_f64 + 2 Newton steps (no IEEE sqrt/div chain);
-//   * the 405 trailing entries are spread evenly over the 64 lanes (7 dot products each) and
-//     applied to a circular 4-keyframe window kept in LDS;
-//   * the next block row of H is prefetched from HBM before the panel and dropped into the
-//     slot the pivot keyframe frees.
-// Sequential in k, hence latency-bound; see DESIGN.md "K4" for the cycle budget.
-constexpr int PROWS = 43;
+// eliminating keyframe k is  [k: 15] [k+1: 15] [k+2: pose 6] [k+3: pose 6]  = 42 rows.
+// The panel of step k has 58 rows, one per lane:
+//     0..14  pivot block          15..41  sub-diagonal rows        42  right-hand side
+//    43..57  identity  -> after the column operations these rows hold L_kk^-T
+// (the rhs row makes the forward substitution free, the identity rows turn the back substitution
+// into a mat-vec instead of a 15-step triangular chain).
+//   * panel factorisation in registers: pivots/multipliers broadcast with v_readlane, 1/sqrt by
+//     v_rsq_f64 + 2 Newton steps; the next pivot's rsq chain is started as soon as its column has
+//     been updated, so it overlaps the remaining rank-1 updates of the current column;
+//   * Schur update of the trailing 28x27 block (27 active rows + rhs) = C - P P^T on the matrix
+//     cores: 3 lower tiles x 4 k-steps of v_mfma_f64_16x16x4, operands straight from the LDS panel;
+//   * trailing window: circular 4-keyframe LDS buffer.  The k loop is unrolled by 4 so that the
+//     slot arithmetic ((k+d)&3) is a compile-time constant: every LDS address is a per-lane
+//     constant plus an immediate; the next block row of H is prefetched from HBM one step ahead;
+//   * panel rows 15..57 go to HBM straight from registers, one 128-byte line per lane.
+// One-wave workgroup: LDS operations of a wave retire in issue order, so cross-lane hand-offs
+// through LDS need no s_barrier and no vmcnt(0) (which __syncthreads() carries and which would
+// stall every step on the in-flight HBM prefetch); a compiler barrier + lgkmcnt(0) is enough.
+// Sequential in k, hence latency-bound; see DESIGN.md "K4" for the measured cycle budget.
 constexpr int LDW = 61;
+constexpr int PSTR = 16;                 // doubles per panel row in HBM (15 used): one 128-B line
+constexpr int S_WD = 0;                  // LDS map (doubles)
+constexpr int S_GD = 60 * LDW;           // 3660: rhs, circular
+constexpr int S_DUMP = S_GD + 64;        // sink for masked-off lanes
+constexpr int S_P = S_DUMP + 64;         // panel rows 15..42 at stride 15 (conflict-free column reads)
+constexpr int S_DL = S_P + 43 * 15;      // back-substitution: delta of the 3 following keyframes
+constexpr int S_TOTAL = S_DL + 64;
+#define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+template <int N> struct IC { static constexpr int value = N; };
 
-__global__ void __launch_bounds__(64) k_band_solve(View v, int ablate) {
+__global__ void __launch_bounds__(64) k_band_solve(View v) {
     const int w = blockIdx.x, lane = threadIdx.x;
     const int lo = v.lo[w], hi = v.hi[w], n = hi - lo;
     if (n <= 0) return;
-    __shared__ double Wd[60 * LDW];
-    __shared__ double Gd[64];
-    __shared__ double P[PROWS * 15 + 3];
-    __shared__ double dl[64];
+    __shared__ double S[S_TOTAL];
     const double lam = v.lambda[w];
     const size_t base = (size_t)w * v.M + lo;
     int failed = 0;
 
-    // panel row of this lane: segment (keyframe offset) and dof
+    // ---- per-lane constants -------------------------------------------------------------
+    // panel row of this lane: segment (keyframe offset) and dof; lane 42 reads the rhs, lanes 43+
+    // read the sink (and are overwritten with identity rows)
     const int pd = lane < 15 ? 0 : (lane < 30 ? 1 : (lane < 36 ? 2 : 3));
     const int pa = lane < 15 ? lane : (lane < 30 ? lane - 15 : (lane < 36 ? lane - 30 : lane - 36));
-    // the 7 trailing entries of this lane: e = lane + 64 j -> (row pr in 15..42, col pc in 15..min(pr,41))
-    int t_rd[7], t_ra[7], t_cd[7], t_ca[7], t_pr[7], t_pc[7];
+    int ri_ph[4];   // LDS offset of (this lane's row, column 0 of the pivot slot) per phase
 #pragma unroll
-    for (int j = 0; j < 7; j++) {
-        int e = lane + 64 * j, r = 0;
-        if (e >= 405) e = 404;                       // duplicates are masked below
-        while (r < 26 && e > r) { e -= r + 1; r++; } // row r of the 27-triangle, then the rhs row
-        int pr, pc;
-        if (r < 26 || e <= 26) { pr = 15 + r; pc = 15 + e; }
-        if (r == 26 && e > 26) { pr = 42; pc = 15 + (e - 27); }
-        t_pr[j] = pr; t_pc[j] = pc;
-        t_rd[j] = pr < 30 ? 1 : (pr < 36 ? 2 : 3);
-        t_ra[j] = pr < 30 ? pr - 15 : (pr < 36 ? pr - 30 : pr - 36);
-        t_cd[j] = pc < 30 ? 1 : (pc < 36 ? 2 : 3);
-        t_ca[j] = pc < 30 ? pc - 15 : (pc < 36 ? pc - 30 : pc - 36);
+    for (int ph = 0; ph < 4; ph++) {
+        const int s0 = ph * 15;
+        ri_ph[ph] = lane < 42 ? S_WD + ((((ph + pd) & 3) * 15) + pa) * LDW + s0
+                              : (lane == 42 ? S_GD + s0 : S_DUMP);
     }
-    // block-row load map: idx = lane + 64 j over a 15x15 block
-    int l_a[4], l_c[4];
+    const bool id_row = lane >= 43 && lane < 58;
+    const int id_col = lane - 43;
+    // Schur write-back targets (MFMA C layout): tile t in {(0,0),(1,0),(1,1)}, register r:
+    //   i = 16*Ti + (lane>>4) + 4r (trailing row, 27 = rhs), j = 16*Tj + (lane&15)
+    int tgt_ph[4][12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) {
+        const int t = q >> 2, r = q & 3;
+        const int Ti = t == 0 ? 0 : 1, Tj = t == 2 ? 1 : 0;
+        const int i = 16 * Ti + (lane >> 4) + 4 * r, j = 16 * Tj + (lane & 15);
+        const int rs = i < 15 ? 1 : (i < 21 ? 2 : 3), ra = i < 15 ? i : (i < 21 ? i - 15 : i - 21);
+        const int cs = j < 15 ? 1 : (j < 21 ? 2 : 3), ca = j < 15 ? j : (j < 21 ? j - 15 : j - 21);
+        const bool valid = i <= 27 && j <= 26 && j <= i;
+#pragma unroll
+        for (int ph = 0; ph < 4; ph++) {
+            const int cj = (((ph + cs) & 3) * 15) + ca;
+            tgt_ph[ph][q] = !valid ? S_DUMP + lane
+                                   : (i == 27 ? S_GD + cj : S_WD + ((((ph + rs) & 3) * 15) + ra) * LDW + cj);
+        }
+    }
+    // MFMA operands: P[15 + 16*T + (lane&15)][4*q + (lane>>4)], zero outside the 28x15 panel
+    const int o_k = lane >> 4;
+    const int o_p0 = S_P + (lane & 15) * 15 + o_k;           // tile 0: panel rows 15..30
+    const int o_p1 = S_P + (16 + (lane & 15)) * 15 + o_k;    // tile 1: panel rows 31..46 (valid to 42)
+    const bool o_ok1 = 31 + (lane & 15) <= 42;
+    // block-row commit map: idx = lane + 64 j over a 15x15 block -> (a, c)
+    int cm_off[4], cm_diag = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int idx = lane + 64 * j;
-        l_a[j] = idx / 15;
-        l_c[j] = idx - l_a[j] * 15;
+        const int idx = lane + 64 * j, a = idx / 15, c = idx - a * 15;
+        cm_off[j] = a * LDW + c;
+        if (a == c && idx < 225) cm_diag |= 1 << j;
     }
     const int q_a = lane / 6, q_c = lane - q_a * 6;  // 6x6 pose block map (lane < 36)
+    int cp_off[2], cp_owner[2], cp_flag = 0;         // 6x15 pose-row strips of the d = 2,3 blocks
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int e = lane + 64 * it, a = e / 15, c = e - a * 15;
+        cp_off[it] = a * LDW + c;
+        cp_owner[it] = (e < 90 && c < 6) ? a * 6 + c : 0;
+        if (e < 90) cp_flag |= 1 << (2 * it);
+        if (e < 90 && c < 6) cp_flag |= 2 << (2 * it);
+    }
 
+    // ---- H block row prefetch (HBM -> registers) and commit (registers -> LDS slot) ---------
     double h0[4], h1[4], h2 = 0.0, h3 = 0.0, hg = 0.0;
-    auto fetch_row = [&](int kk) {   // HBM -> registers
+    auto fetch_row = [&](int kk) {
         if (kk < n) {
             const double* Hk = v.H + (base + kk) * HROW;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int idx = lane + 64 * j;
-                const bool in = idx < 225;
-                h0[j] = in ? Hk[idx] : 0.0;
-                h1[j] = (in && kk >= 1) ? Hk[225 + idx] : 0.0;
+                const bool in = lane + 64 * j < 225;
+                h0[j] = in ? Hk[lane + 64 * j] : 0.0;
+                h1[j] = (in && kk >= 1) ? Hk[225 + lane + 64 * j] : 0.0;
             }
             h2 = (lane < 36 && kk >= 2) ? Hk[450 + q_a * 15 + q_c] : 0.0;
             h3 = (lane < 36 && kk >= 3) ? Hk[675 + q_a * 15 + q_c] : 0.0;
@@ -749,143 +802,194 @@ __global__ void __launch_bounds__(64) k_band_solve(View v, int ablate) {
             h2 = h3 = hg = 0.0;
         }
     };
-    auto commit_row = [&](int kk) {  // registers -> LDS slot of keyframe kk
-        const int s = (kk & 3) * 15;
-        const int c1 = ((kk - 1) & 3) * 15, c2 = ((kk - 2) & 3) * 15, c3 = ((kk - 3) & 3) * 15;
-        const bool real = kk < n;
+    auto commit_row = [&](auto ph, bool real) {   // keyframe kk with kk & 3 == PH
+        constexpr int PH = decltype(ph)::value;
+        constexpr int s = PH * 15, c1 = ((PH + 3) & 3) * 15, c2 = ((PH + 2) & 3) * 15, c3 = ((PH + 1) & 3) * 15;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (lane + 64 * j < 225) {
                 double d0 = h0[j];
-                if (l_a[j] == l_c[j]) d0 = real ? d0 + lam : 1.0;
-                Wd[(s + l_a[j]) * LDW + s + l_c[j]] = d0;
-                Wd[(s + l_a[j]) * LDW + c1 + l_c[j]] = h1[j];
+                if (cm_diag & (1 << j)) d0 = real ? d0 + lam : 1.0;
+                S[S_WD + s * LDW + s + cm_off[j]] = d0;
+                S[S_WD + s * LDW + c1 + cm_off[j]] = h1[j];
             }
         }
-        // d = 2, 3: pose rows only; columns 6..14 start at zero and fill in during elimination
 #pragma unroll
-        for (int it = 0; it < 2; it++) {   // 6x15 entries; every lane takes part in the shuffles
-            const int e = lane + 64 * it;
-            const int a = e / 15, c = e - a * 15;
-            const bool valid = e < 90, ld = valid && c < 6;
-            const int owner = ld ? a * 6 + c : 0;   // lanes < 36 hold the 6x6 pose block (q_a, q_c)
-            const double x2 = __shfl(h2, owner), x3 = __shfl(h3, owner);
-            if (valid) {
-                Wd[(s + a) * LDW + c2 + c] = ld ? x2 : 0.0;
-                Wd[(s + a) * LDW + c3 + c] = ld ? x3 : 0.0;
+        for (int it = 0; it < 2; it++) {   // every lane takes part in the shuffles
+            const double x2 = __shfl(h2, cp_owner[it]), x3 = __shfl(h3, cp_owner[it]);
+            if (cp_flag & (1 << (2 * it))) {
+                const bool ld = cp_flag & (2 << (2 * it));
+                S[S_WD + s * LDW + c2 + cp_off[it]] = ld ? x2 : 0.0;
+                S[S_WD + s * LDW + c3 + cp_off[it]] = ld ? x3 : 0.0;
             }
         }
-        if (lane < 15) Gd[s + lane] = hg;
+        if (lane < 15) S[S_GD + s + lane] = hg;
     };
-    for (int kk = 0; kk < 4; kk++) {
-        fetch_row(kk);
-        commit_row(kk);
-    }
-    __syncthreads();
+    fetch_row(0); commit_row(IC<0>{}, 0 < n);
+    fetch_row(1); commit_row(IC<1>{}, 1 < n);
+    fetch_row(2); commit_row(IC<2>{}, 2 < n);
+    fetch_row(3); commit_row(IC<3>{}, 3 < n);
+    WSYNC();
 
-    for (int k = 0; k < n; k++) {
-        const int s0 = (k & 3) * 15;
-        fetch_row(k + 4);  // in flight during the panel factorisation
-        const int ri = ((((k + pd) & 3) * 15) + pa) * LDW;
+    // ---- one elimination step, phase PH = k & 3 compile-time --------------------------------
+    auto step = [&](auto ph, int k) {
+        constexpr int PH = decltype(ph)::value;
+        fetch_row(k + 4);  // in flight during the whole step
         double p[15];
 #pragma unroll
-        for (int c = 0; c < 15; c++)
-            p[c] = lane < 42 ? Wd[ri + s0 + c] : (lane == 42 ? Gd[s0 + c] : 0.0);
-        double dinv = 0.0;
-        if (!(ablate & 4))
+        for (int c = 0; c < 15; c++) p[c] = S[ri_ph[PH] + c];
+        if (id_row) {
+#pragma unroll
+            for (int c = 0; c < 15; c++) p[c] = (id_col == c) ? 1.0 : 0.0;
+        }
+        // panel factorisation, software-pipelined: inv for column c+1 is started right after
+        // column c+1 has received its update from column c
+        double dv = readlane_d(p[0], 0);
+        if (!(dv > 0.0)) { failed = 1; dv = 1.0; }
+        double inv = fast_rsqrt(dv);
 #pragma unroll
         for (int c = 0; c < 15; c++) {
-            double dv = readlane_d(p[c], c);
-            if (!(dv > 0.0)) { failed = 1; dv = 1.0; }
-            const double inv = fast_rsqrt(dv);
             p[c] *= inv;
-            if (lane == c) dinv = inv;
+            if (c + 1 < 15) {
+                const double l1 = readlane_d(p[c], c + 1);
+                p[c + 1] = fma(-p[c], l1, p[c + 1]);
+                dv = readlane_d(p[c + 1], c + 1);
+                if (!(dv > 0.0)) { failed = 1; dv = 1.0; }
+                inv = fast_rsqrt(dv);
+            }
 #pragma unroll
-            for (int c2 = c + 1; c2 < 15; c2++) {
+            for (int c2 = c + 2; c2 < 15; c2++) {
                 const double l = readlane_d(p[c], c2);
                 p[c2] = fma(-p[c], l, p[c2]);
             }
         }
-        if (lane < PROWS) {
+        // sub-panel + rhs -> LDS (MFMA operands); rows 15..57 -> HBM, one 128-B line per lane
+        if (lane >= 15 && lane < 43) {
 #pragma unroll
-            for (int c = 0; c < 15; c++) P[lane * 15 + c] = (lane == c) ? dinv : p[c];  // diagonal holds 1/L_cc
+            for (int c = 0; c < 15; c++) S[S_P + (lane - 15) * 15 + c] = p[c];
         }
-        __syncthreads();
-        if (!(ablate & 8)) {   // panel -> HBM (coalesced), kept for the back substitution
-            double* Lk = v.Lp + (base + k) * PANEL;
-            for (int e = lane; e < PANEL; e += 64) Lk[e] = P[e];
-        }
-        if (!(ablate & 1))
+        if (lane >= 15 && lane < 58) {
+            d2_t* Lk = (d2_t*)(v.Lp + (base + k) * PANEL + (size_t)(lane - 15) * PSTR);
 #pragma unroll
-        for (int j = 0; j < 7; j++) {
-            if (lane + 64 * j < 405) {
-                const double* a = P + t_pr[j] * 15;
-                const double* b = P + t_pc[j] * 15;
-                double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-                for (int c = 0; c < 14; c += 2) {
-                    s1 = fma(a[c], b[c], s1);
-                    s2 = fma(a[c + 1], b[c + 1], s2);
-                }
-                s1 = fma(a[14], b[14], s1) + s2;
-                const int cj = (((k + t_cd[j]) & 3) * 15) + t_ca[j];
-                if (t_pr[j] < 42) Wd[((((k + t_rd[j]) & 3) * 15) + t_ra[j]) * LDW + cj] -= s1;
-                else Gd[cj] -= s1;
-            }
+            for (int c = 0; c < 7; c++) { d2_t t; t.x = p[2 * c]; t.y = p[2 * c + 1]; Lk[c] = t; }
+            d2_t t; t.x = p[14]; t.y = 0.0; Lk[7] = t;
         }
-        __syncthreads();
-        commit_row(k + 4);  // the pivot keyframe's slot is free now
-        __syncthreads();
+        WSYNC();
+        // Schur update on the matrix cores: acc[t] = P_Ti P_Tj^T for the 3 lower 16x16 tiles
+        d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+        double a0[4], a1[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const bool kok = 4 * q + o_k < 15;
+            a0[q] = kok ? S[o_p0 + 4 * q] : 0.0;
+            a1[q] = (kok && o_ok1) ? S[o_p1 + 4 * q] : 0.0;
+        }
+        double cur[12];
+#pragma unroll
+        for (int q = 0; q < 12; q++) cur[q] = S[tgt_ph[PH][q]];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], a0[q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], a0[q], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], a1[q], acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            const int t = q >> 2, r = q & 3;
+            const double val = t == 0 ? acc0[r] : (t == 1 ? acc1[r] : acc2[r]);
+            S[tgt_ph[PH][q]] = cur[q] - val;
+        }
+        WSYNC();
+        commit_row(ph, k + 4 < n);  // keyframe k+4 takes the slot the pivot keyframe frees
+        WSYNC();
+    };
+    {
+        int k = 0;
+        for (; k + 4 <= n; k += 4) {
+            step(IC<0>{}, k);
+            step(IC<1>{}, k + 1);
+            step(IC<2>{}, k + 2);
+            step(IC<3>{}, k + 3);
+        }
+        if (k < n) { step(IC<0>{}, k); k++; }
+        if (k < n) { step(IC<1>{}, k); k++; }
+        if (k < n) { step(IC<2>{}, k); k++; }
     }
 
-    // back substitution: delta_k = L_kk^-T (y_k - sum_p L[p][k-cols]^T delta(p)), p over rows 15..41
-    if (ablate & 2) { if (lane == 0) v.fail[w] = failed; return; }
-    if (lane < 60) dl[lane] = 0.0;
-    const int part = lane >> 4, cc = lane & 15;          // 4 partial sums per column
-    const int p_lo = 15 + part * 7, p_hi = part == 3 ? 42 : p_lo + 7;
-    double nxt[11];
-    {
-        const double* Lk = v.Lp + (base + n - 1) * PANEL;
+    // ---- back substitution: delta_k = L_kk^-T (y_k - sum_p L[p][k-cols]^T delta(p)) -----------
+    // Panel rows in HBM: 0..26 sub-diagonal rows (p = 15..41), 27 = y, 28..42 = L_kk^-T.
+    // Lane r < 43 holds row r in registers; rows 0..27 go through LDS for the column sums,
+    // L^-T stays in the registers of lanes 28..42.
+    if (lane < 60) S[S_DL + lane] = 0.0;
+    d2_t nx[8];
+    auto load_panel = [&](int k) {
+        const d2_t* Lk = (const d2_t*)(v.Lp + (base + k) * PANEL + (size_t)(lane < 43 ? lane : 0) * PSTR);
 #pragma unroll
-        for (int j = 0; j < 11; j++) nxt[j] = (lane + 64 * j < PANEL) ? Lk[lane + 64 * j] : 0.0;
-    }
-    __syncthreads();
-    for (int k = n - 1; k >= 0; k--) {
+        for (int c = 0; c < 8; c++) nx[c] = Lk[c];
+    };
+    load_panel(n - 1);
+    WSYNC();
+    auto back = [&](auto ph, int k) {
+        constexpr int PH = decltype(ph)::value;
+        constexpr int b1 = S_DL + ((PH + 1) & 3) * 15, b2 = S_DL + ((PH + 2) & 3) * 15, b3 = S_DL + ((PH + 3) & 3) * 15;
+        double row[15];
 #pragma unroll
-        for (int j = 0; j < 11; j++)
-            if (lane + 64 * j < PANEL) P[lane + 64 * j] = nxt[j];
-        __syncthreads();
-        if (k > 0) {  // prefetch the next panel while this one is consumed
-            const double* Lk = v.Lp + (base + k - 1) * PANEL;
+        for (int c = 0; c < 7; c++) { row[2 * c] = nx[c].x; row[2 * c + 1] = nx[c].y; }
+        row[14] = nx[7].x;
+        if (k > 0) load_panel(k - 1);   // prefetch while this panel is consumed
+        if (lane < 28) {
 #pragma unroll
-            for (int j = 0; j < 11; j++) nxt[j] = (lane + 64 * j < PANEL) ? Lk[lane + 64 * j] : 0.0;
+            for (int c = 0; c < 15; c++) S[S_P + lane * 15 + c] = row[c];
         }
+        WSYNC();
         double s = 0.0;
-        if (cc < 15) {
-            for (int pp = p_lo; pp < p_hi; pp++) {
-                const int d = pp < 30 ? 1 : (pp < 36 ? 2 : 3);
-                const int a = pp < 30 ? pp - 15 : (pp < 36 ? pp - 30 : pp - 36);
-                s = fma(P[pp * 15 + cc], dl[((k + d) & 3) * 15 + a], s);
-            }
-        }
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        double lcol[15];   // column `lane` of L_kk below the diagonal, and 1/L_cc on the diagonal
-#pragma unroll
-        for (int c = 0; c < 15; c++) lcol[c] = lane < 15 ? P[c * 15 + lane] : 0.0;
-        s = lane < 15 ? P[42 * 15 + lane] - s : 0.0;
-#pragma unroll
-        for (int c = 14; c >= 0; c--) {
-            const double xc = readlane_d(s, c) * readlane_d(lcol[c], c);
-            if (lane == c) s = xc;
-            else if (lane < c) s = fma(-lcol[c], xc, s);
-        }
-        __syncthreads();
         if (lane < 15) {
-            dl[(k & 3) * 15 + lane] = s;
-            v.delta[(base + k) * 15 + lane] = s;
+            double pv[27], dv[27];
+#pragma unroll
+            for (int a = 0; a < 27; a++) pv[a] = S[S_P + a * 15 + lane];
+#pragma unroll
+            for (int a = 0; a < 15; a++) dv[a] = S[b1 + a];
+#pragma unroll
+            for (int a = 0; a < 6; a++) { dv[15 + a] = S[b2 + a]; dv[21 + a] = S[b3 + a]; }
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 27; a += 3) {
+                s0 = fma(pv[a], dv[a], s0);
+                s1 = fma(pv[a + 1], dv[a + 1], s1);
+                s2 = fma(pv[a + 2], dv[a + 2], s2);
+            }
+            s = S[S_P + 27 * 15 + lane] - ((s0 + s1) + s2);
         }
-        __syncthreads();
+        // x = L^-T s on lanes 28..42 (row c of L^-T in registers), s broadcast by v_readlane
+        double x0 = 0.0, x1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 15; c++) {
+            const double sc = readlane_d(s, c);
+            if (c & 1) x1 = fma(row[c], sc, x1);
+            else x0 = fma(row[c], sc, x0);
+        }
+        const double x = x0 + x1;
+        WSYNC();
+        if (lane >= 28 && lane < 43) {
+            S[S_DL + PH * 15 + lane - 28] = x;
+            v.delta[(base + k) * 15 + lane - 28] = x;
+        }
+        WSYNC();
+    };
+    {
+        int k = n - 1;
+        // bring k to phase 3 boundary, then run groups of four
+        while (k >= 0 && (k & 3) != 3) {
+            const int ph = k & 3;
+            if (ph == 2) back(IC<2>{}, k); else if (ph == 1) back(IC<1>{}, k); else back(IC<0>{}, k);
+            k--;
+        }
+        for (; k >= 3; k -= 4) {
+            back(IC<3>{}, k);
+            back(IC<2>{}, k - 1);
+            back(IC<1>{}, k - 2);
+            back(IC<0>{}, k - 3);
+        }
     }
     if (lane == 0) v.fail[w] = failed;
 }
@@ -1087,11 +1191,10 @@ void launch_linearize_prior(const View& v, int which, hipStream_t s) {
     hipLaunchKernelGGL(k_linearize_prior, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, which);
 }
 void launch_assemble(const View& v, hipStream_t s) {
-    hipLaunchKernelGGL(k_assemble, dim3(nblk(v.G, 64)), dim3(64), 0, s, v);
+    hipLaunchKernelGGL(k_assemble, dim3(nblk(v.G, AT)), dim3(256), 0, s, v);
 }
 void launch_band_solve(const View& v, hipStream_t s) {
-    static const int ablate = getenv("VF_SOLVE_ABLATE") ? atoi(getenv("VF_SOLVE_ABLATE")) : 0;  // timing experiments only
-    hipLaunchKernelGGL(k_band_solve, dim3(v.B), dim3(64), 0, s, v, ablate);
+    hipLaunchKernelGGL(k_band_solve, dim3(v.B), dim3(64), 0, s, v);
 }
 void launch_retract(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_retract, dim3(nblk(v.G, 256)), dim3(256), 0, s, v);

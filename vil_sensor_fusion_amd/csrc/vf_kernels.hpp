@@ -14,7 +14,7 @@ constexpr int PRIOR_IN = 31;    // mean state (16), sigma (15)
 constexpr int PRIOR_OUT = 240;  // r(15), J(15x15)
 constexpr int NBLK = 4;         // band blocks stored per keyframe (bandwidth 3 + diagonal)
 constexpr int HROW = NBLK * 225;
-constexpr int PANEL = 43 * 15;  // Cholesky panel: 42 active rows + forward-substituted rhs row
+constexpr int PANEL = 43 * 16;  // Cholesky panel in HBM: 43 rows (27 sub-diagonal, rhs, 15 of L^-T), one 128-B line each
 
 // Device-resident problem: B windows x M keyframe slots (G = B*M).  See DESIGN.md.
 struct View {
@@ -33,7 +33,7 @@ struct View {
     double* H;          // [G][4][15][15]      block d of row k = H[k][k-d]
     double* gvec;       // [G][15]
     double* delta;      // [G][15]
-    double* Lp;         // [G][43][15]         Cholesky panels + y
+    double* Lp;         // [G][43][16]         Cholesky panels (15 of 16 columns used)
     int* lo;            // [B] active range [lo, hi)
     int* hi;
     int* sel;           // [B] which buffer is current

@@ -163,7 +163,7 @@ class Engine:
         return d
 
     def read_panels(self, window, k0, n):
-        p = np.zeros((n, 43, 15))
+        p = np.zeros((n, 43, 16))
         check(self._l.vf_engine_read_panels(self._h, window, k0, n, _d(p)))
         return p
 

@@ -710,11 +710,19 @@ constexpr int LDW = 61;
 constexpr int PSTR = 16;                 // doubles per panel row in HBM (15 used): one 128-B line
 constexpr int S_WD = 0;                  // LDS map (doubles)
 constexpr int S_GD = 60 * LDW;           // 3660: rhs, circular
-constexpr int S_DUMP = S_GD + 64;        // sink for masked-off lanes
-constexpr int S_P = S_DUMP + 64;         // panel rows 15..42 at stride 15 (conflict-free column reads)
+constexpr int S_DUMP = S_GD + 64;        // write sink for masked-off lanes (never read)
+constexpr int S_ZERO = S_DUMP + 96;      // 16 zeros: read source for masked-off lanes
+constexpr int S_ID = S_ZERO + 16;        // 15x15 identity: panel rows of the L^-T lanes
+constexpr int S_P = S_ID + 225;          // panel rows 15..42 at stride 15 (conflict-free column reads)
 constexpr int S_DL = S_P + 43 * 15;      // back-substitution: delta of the 3 following keyframes
 constexpr int S_TOTAL = S_DL + 64;
 #define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#ifdef VF_SOLVE_STAMPS   // diagnostic build only (scratch/build_stamps.sh); never in the shipped library
+__device__ unsigned long long g_stamps[16];
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _t; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); if (w == 0) st[i] += _t - tprev; tprev = _t; } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 template <int N> struct IC { static constexpr int value = N; };
 
 __global__ void __launch_bounds__(64) k_band_solve(View v) {
@@ -726,20 +734,20 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
     const size_t base = (size_t)w * v.M + lo;
     int failed = 0;
 
-    // ---- per-lane constants -------------------------------------------------------------
-    // panel row of this lane: segment (keyframe offset) and dof; lane 42 reads the rhs, lanes 43+
-    // read the sink (and are overwritten with identity rows)
+    // ---- per-lane constants.  Every LDS access below is branch-free: masked-off lanes read the
+    // zero cells / write the sink, so no exec-mask juggling (and no SGPR spills) in the k loop.
+    for (int e = lane; e < 16 + 225; e += 64) S[S_ZERO + e] = (e >= 16 && (e - 16) % 16 == 0) ? 1.0 : 0.0;
     const int pd = lane < 15 ? 0 : (lane < 30 ? 1 : (lane < 36 ? 2 : 3));
     const int pa = lane < 15 ? lane : (lane < 30 ? lane - 15 : (lane < 36 ? lane - 30 : lane - 36));
-    int ri_ph[4];   // LDS offset of (this lane's row, column 0 of the pivot slot) per phase
+    int ri_ph[4];   // LDS offset of (this lane's panel row, column 0 of the pivot slot) per phase
 #pragma unroll
     for (int ph = 0; ph < 4; ph++) {
         const int s0 = ph * 15;
         ri_ph[ph] = lane < 42 ? S_WD + ((((ph + pd) & 3) * 15) + pa) * LDW + s0
-                              : (lane == 42 ? S_GD + s0 : S_DUMP);
+                  : (lane == 42 ? S_GD + s0 : (lane < 58 ? S_ID + (lane - 43) * 15 : S_ZERO));
     }
-    const bool id_row = lane >= 43 && lane < 58;
-    const int id_col = lane - 43;
+    // lanes 58..63 read 15 consecutive cells from S_ZERO: S_ZERO has 16 zeros -> a zero row
+    const int pw_off = (lane >= 15 && lane < 43) ? S_P + (lane - 15) * 15 : S_DUMP + 16;   // sub-panel -> LDS
     // Schur write-back targets (MFMA C layout): tile t in {(0,0),(1,0),(1,1)}, register r:
     //   i = 16*Ti + (lane>>4) + 4r (trailing row, 27 = rhs), j = 16*Tj + (lane&15)
     int tgt_ph[4][12];
@@ -754,94 +762,102 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
 #pragma unroll
         for (int ph = 0; ph < 4; ph++) {
             const int cj = (((ph + cs) & 3) * 15) + ca;
-            tgt_ph[ph][q] = !valid ? S_DUMP + lane
+            tgt_ph[ph][q] = !valid ? S_DUMP + 32 + lane
                                    : (i == 27 ? S_GD + cj : S_WD + ((((ph + rs) & 3) * 15) + ra) * LDW + cj);
         }
     }
-    // MFMA operands: P[15 + 16*T + (lane&15)][4*q + (lane>>4)], zero outside the 28x15 panel
-    const int o_k = lane >> 4;
-    const int o_p0 = S_P + (lane & 15) * 15 + o_k;           // tile 0: panel rows 15..30
-    const int o_p1 = S_P + (16 + (lane & 15)) * 15 + o_k;    // tile 1: panel rows 31..46 (valid to 42)
-    const bool o_ok1 = 31 + (lane & 15) <= 42;
-    // block-row commit map: idx = lane + 64 j over a 15x15 block -> (a, c)
-    int cm_off[4], cm_diag = 0;
+    // MFMA operands: P[15 + 16*T + (lane&15)][4*q + (lane>>4)]; outside the 28x15 panel -> zero cell
+    int op0[4], op1[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int kc = 4 * q + (lane >> 4);
+        op0[q] = kc < 15 ? S_P + (lane & 15) * 15 + kc : S_ZERO;
+        op1[q] = (kc < 15 && 31 + (lane & 15) <= 42) ? S_P + (16 + (lane & 15)) * 15 + kc : S_ZERO;
+    }
+    // block-row commit map: idx = lane + 64 j over a 15x15 block -> (a, c); diagonal gets +lambda
+    int cm_off[4];
+    double cm_lam[4], cm_one[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int idx = lane + 64 * j, a = idx / 15, c = idx - a * 15;
-        cm_off[j] = a * LDW + c;
-        if (a == c && idx < 225) cm_diag |= 1 << j;
+        const bool in = idx < 225;
+        cm_off[j] = in ? a * LDW + c : -1;
+        cm_lam[j] = (in && a == c) ? lam : 0.0;
+        cm_one[j] = (in && a == c) ? 1.0 : 0.0;
     }
     const int q_a = lane / 6, q_c = lane - q_a * 6;  // 6x6 pose block map (lane < 36)
-    int cp_off[2], cp_owner[2], cp_flag = 0;         // 6x15 pose-row strips of the d = 2,3 blocks
+    int cp_off[2], cp_owner[2];
+    double cp_keep[2];                               // 6x15 pose-row strips of the d = 2,3 blocks
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         const int e = lane + 64 * it, a = e / 15, c = e - a * 15;
-        cp_off[it] = a * LDW + c;
+        cp_off[it] = e < 90 ? a * LDW + c : -1;
         cp_owner[it] = (e < 90 && c < 6) ? a * 6 + c : 0;
-        if (e < 90) cp_flag |= 1 << (2 * it);
-        if (e < 90 && c < 6) cp_flag |= 2 << (2 * it);
+        cp_keep[it] = (e < 90 && c < 6) ? 1.0 : 0.0;
     }
+    WSYNC();
 
     // ---- H block row prefetch (HBM -> registers) and commit (registers -> LDS slot) ---------
-    double h0[4], h1[4], h2 = 0.0, h3 = 0.0, hg = 0.0;
-    auto fetch_row = [&](int kk) {
-        if (kk < n) {
-            const double* Hk = v.H + (base + kk) * HROW;
+    // (passed by value: captured-by-reference scalars ended up in scratch memory)
+    struct HRow { double h0[4], h1[4], h2, h3, hg; };
+    const double* __restrict__ Hbase = v.H + base * HROW;
+    const double* __restrict__ gbase = v.gvec + base * 15;
+    double* __restrict__ Lbase = v.Lp + base * PANEL;
+    double* __restrict__ dbase = v.delta + base * 15;
+    auto fetch_row = [=](int kk) {
+        HRow r;
+        const bool real = kk < n;
+        const double* Hk = Hbase + (size_t)(real ? kk : 0) * HROW;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const bool in = lane + 64 * j < 225;
-                h0[j] = in ? Hk[lane + 64 * j] : 0.0;
-                h1[j] = (in && kk >= 1) ? Hk[225 + lane + 64 * j] : 0.0;
-            }
-            h2 = (lane < 36 && kk >= 2) ? Hk[450 + q_a * 15 + q_c] : 0.0;
-            h3 = (lane < 36 && kk >= 3) ? Hk[675 + q_a * 15 + q_c] : 0.0;
-            hg = lane < 15 ? -v.gvec[(base + kk) * 15 + lane] : 0.0;
-        } else {   // beyond the window: identity rows
-#pragma unroll
-            for (int j = 0; j < 4; j++) { h0[j] = 0.0; h1[j] = 0.0; }
-            h2 = h3 = hg = 0.0;
+        for (int j = 0; j < 4; j++) {
+            const bool in = real && lane + 64 * j < 225;
+            r.h0[j] = in ? Hk[lane + 64 * j] : 0.0;
+            r.h1[j] = (in && kk >= 1) ? Hk[225 + lane + 64 * j] : 0.0;
         }
+        r.h2 = (real && lane < 36 && kk >= 2) ? Hk[450 + q_a * 15 + q_c] : 0.0;
+        r.h3 = (real && lane < 36 && kk >= 3) ? Hk[675 + q_a * 15 + q_c] : 0.0;
+        r.hg = (real && lane < 15) ? gbase[(size_t)kk * 15 + lane] : 0.0;   // negated at commit (a use here would stall on vmcnt)
+        return r;
     };
-    auto commit_row = [&](auto ph, bool real) {   // keyframe kk with kk & 3 == PH
+    auto commit_row = [&](auto ph, const HRow r, bool real) {   // keyframe kk with kk & 3 == PH
         constexpr int PH = decltype(ph)::value;
         constexpr int s = PH * 15, c1 = ((PH + 3) & 3) * 15, c2 = ((PH + 2) & 3) * 15, c3 = ((PH + 1) & 3) * 15;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            if (lane + 64 * j < 225) {
-                double d0 = h0[j];
-                if (cm_diag & (1 << j)) d0 = real ? d0 + lam : 1.0;
-                S[S_WD + s * LDW + s + cm_off[j]] = d0;
-                S[S_WD + s * LDW + c1 + cm_off[j]] = h1[j];
-            }
+            const bool in = cm_off[j] >= 0;
+            const double d0 = r.h0[j] + (real ? cm_lam[j] : cm_one[j]);
+            S[in ? S_WD + s * LDW + s + cm_off[j] : S_DUMP + 32 + lane] = d0;
+            S[in ? S_WD + s * LDW + c1 + cm_off[j] : S_DUMP + 32 + lane] = r.h1[j];
         }
 #pragma unroll
         for (int it = 0; it < 2; it++) {   // every lane takes part in the shuffles
-            const double x2 = __shfl(h2, cp_owner[it]), x3 = __shfl(h3, cp_owner[it]);
-            if (cp_flag & (1 << (2 * it))) {
-                const bool ld = cp_flag & (2 << (2 * it));
-                S[S_WD + s * LDW + c2 + cp_off[it]] = ld ? x2 : 0.0;
-                S[S_WD + s * LDW + c3 + cp_off[it]] = ld ? x3 : 0.0;
-            }
+            const double x2 = __shfl(r.h2, cp_owner[it]) * cp_keep[it], x3 = __shfl(r.h3, cp_owner[it]) * cp_keep[it];
+            const bool in = cp_off[it] >= 0;
+            S[in ? S_WD + s * LDW + c2 + cp_off[it] : S_DUMP + 32 + lane] = x2;
+            S[in ? S_WD + s * LDW + c3 + cp_off[it] : S_DUMP + 32 + lane] = x3;
         }
-        if (lane < 15) S[S_GD + s + lane] = hg;
+        S[lane < 15 ? S_GD + s + lane : S_DUMP + 32 + lane] = -r.hg;
     };
-    fetch_row(0); commit_row(IC<0>{}, 0 < n);
-    fetch_row(1); commit_row(IC<1>{}, 1 < n);
-    fetch_row(2); commit_row(IC<2>{}, 2 < n);
-    fetch_row(3); commit_row(IC<3>{}, 3 < n);
+    commit_row(IC<0>{}, fetch_row(0), 0 < n);
+    commit_row(IC<1>{}, fetch_row(1), 1 < n);
+    commit_row(IC<2>{}, fetch_row(2), 2 < n);
+    commit_row(IC<3>{}, fetch_row(3), 3 < n);
     WSYNC();
+    const int n4 = (n + 3) & ~3;   // steps beyond n eliminate identity rows (no effect); saves remainder copies
 
+#ifdef VF_SOLVE_STAMPS
+    unsigned long long st[16] = {0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
     // ---- one elimination step, phase PH = k & 3 compile-time --------------------------------
-    auto step = [&](auto ph, int k) {
+    // `pend` = block row of keyframe k+4 (fetched during the previous step); this step fetches k+5.
+    auto step = [&](auto ph, int k, HRow& pend) {
         constexpr int PH = decltype(ph)::value;
-        fetch_row(k + 4);  // in flight during the whole step
+        STAMP(0);
+        const HRow ahead = fetch_row(k + 5);   // two steps of slack for the HBM round trip
         double p[15];
 #pragma unroll
         for (int c = 0; c < 15; c++) p[c] = S[ri_ph[PH] + c];
-        if (id_row) {
-#pragma unroll
-            for (int c = 0; c < 15; c++) p[c] = (id_col == c) ? 1.0 : 0.0;
-        }
+        STAMP(1);
         // panel factorisation, software-pipelined: inv for column c+1 is started right after
         // column c+1 has received its update from column c
         double dv = readlane_d(p[0], 0);
@@ -863,27 +879,23 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
                 p[c2] = fma(-p[c], l, p[c2]);
             }
         }
+        STAMP(2);
         // sub-panel + rhs -> LDS (MFMA operands); rows 15..57 -> HBM, one 128-B line per lane
-        if (lane >= 15 && lane < 43) {
 #pragma unroll
-            for (int c = 0; c < 15; c++) S[S_P + (lane - 15) * 15 + c] = p[c];
-        }
-        if (lane >= 15 && lane < 58) {
-            d2_t* Lk = (d2_t*)(v.Lp + (base + k) * PANEL + (size_t)(lane - 15) * PSTR);
+        for (int c = 0; c < 15; c++) S[pw_off + c] = p[c];
+        if (lane >= 15 && lane < 58 && k < n) {
+            d2_t* Lk = (d2_t*)(Lbase + (size_t)k * PANEL + (size_t)(lane - 15) * PSTR);
 #pragma unroll
             for (int c = 0; c < 7; c++) { d2_t t; t.x = p[2 * c]; t.y = p[2 * c + 1]; Lk[c] = t; }
             d2_t t; t.x = p[14]; t.y = 0.0; Lk[7] = t;
         }
         WSYNC();
+        STAMP(3);
         // Schur update on the matrix cores: acc[t] = P_Ti P_Tj^T for the 3 lower 16x16 tiles
         d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
         double a0[4], a1[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const bool kok = 4 * q + o_k < 15;
-            a0[q] = kok ? S[o_p0 + 4 * q] : 0.0;
-            a1[q] = (kok && o_ok1) ? S[o_p1 + 4 * q] : 0.0;
-        }
+        for (int q = 0; q < 4; q++) { a0[q] = S[op0[q]]; a1[q] = S[op1[q]]; }
         double cur[12];
 #pragma unroll
         for (int q = 0; q < 12; q++) cur[q] = S[tgt_ph[PH][q]];
@@ -900,53 +912,60 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
             S[tgt_ph[PH][q]] = cur[q] - val;
         }
         WSYNC();
-        commit_row(ph, k + 4 < n);  // keyframe k+4 takes the slot the pivot keyframe frees
+        STAMP(4);
+        commit_row(ph, pend, k + 4 < n);  // keyframe k+4 takes the slot the pivot keyframe frees
+        pend = ahead;
         WSYNC();
+        STAMP(5);
     };
     {
-        int k = 0;
-        for (; k + 4 <= n; k += 4) {
-            step(IC<0>{}, k);
-            step(IC<1>{}, k + 1);
-            step(IC<2>{}, k + 2);
-            step(IC<3>{}, k + 3);
+        HRow pend = fetch_row(4);
+#pragma unroll 1
+        for (int k = 0; k < n4; k += 4) {
+            step(IC<0>{}, k, pend);
+            step(IC<1>{}, k + 1, pend);
+            step(IC<2>{}, k + 2, pend);
+            step(IC<3>{}, k + 3, pend);
         }
-        if (k < n) { step(IC<0>{}, k); k++; }
-        if (k < n) { step(IC<1>{}, k); k++; }
-        if (k < n) { step(IC<2>{}, k); k++; }
     }
 
     // ---- back substitution: delta_k = L_kk^-T (y_k - sum_p L[p][k-cols]^T delta(p)) -----------
     // Panel rows in HBM: 0..26 sub-diagonal rows (p = 15..41), 27 = y, 28..42 = L_kk^-T.
     // Lane r < 43 holds row r in registers; rows 0..27 go through LDS for the column sums,
-    // L^-T stays in the registers of lanes 28..42.
-    if (lane < 60) S[S_DL + lane] = 0.0;
-    d2_t nx[8];
-    auto load_panel = [&](int k) {
-        const d2_t* Lk = (const d2_t*)(v.Lp + (base + k) * PANEL + (size_t)(lane < 43 ? lane : 0) * PSTR);
+    // L^-T stays in the registers of lanes 28..42.  Panels are prefetched two steps ahead.
+    S[S_DL + lane] = 0.0;
+    struct PRow { d2_t x[8]; };
+    auto load_panel = [=](int k) {   // k >= n or k < 0: any valid panel is loaded and zeroed at use (no use here: no stall)
+        PRow r;
+        const d2_t* Lk = (const d2_t*)(Lbase + (size_t)((k < n && k >= 0) ? k : 0) * PANEL + (size_t)(lane < 43 ? lane : 0) * PSTR);
 #pragma unroll
-        for (int c = 0; c < 8; c++) nx[c] = Lk[c];
+        for (int c = 0; c < 8; c++) r.x[c] = Lk[c];
+        return r;
     };
-    load_panel(n - 1);
+    const int bw_off = lane < 28 ? S_P + lane * 15 : S_DUMP + 16;
+    const int col = lane < 15 ? lane : 0;
+    const int dl_w = (lane >= 28 && lane < 43) ? S_DL + lane - 28 : S_DUMP + 32 + lane;
     WSYNC();
-    auto back = [&](auto ph, int k) {
+    auto back = [&](auto ph, int k, PRow& cur_p, PRow& nxt_p) {
         constexpr int PH = decltype(ph)::value;
         constexpr int b1 = S_DL + ((PH + 1) & 3) * 15, b2 = S_DL + ((PH + 2) & 3) * 15, b3 = S_DL + ((PH + 3) & 3) * 15;
+        STAMP(6);
         double row[15];
+        const double keep = k < n ? 1.0 : 0.0;   // identity tail beyond the window: zero panel
 #pragma unroll
-        for (int c = 0; c < 7; c++) { row[2 * c] = nx[c].x; row[2 * c + 1] = nx[c].y; }
-        row[14] = nx[7].x;
-        if (k > 0) load_panel(k - 1);   // prefetch while this panel is consumed
-        if (lane < 28) {
+        for (int c = 0; c < 7; c++) { row[2 * c] = keep * cur_p.x[c].x; row[2 * c + 1] = keep * cur_p.x[c].y; }
+        row[14] = keep * cur_p.x[7].x;
+        cur_p = nxt_p;
+        nxt_p = load_panel(k - 2);   // two steps ahead
 #pragma unroll
-            for (int c = 0; c < 15; c++) S[S_P + lane * 15 + c] = row[c];
-        }
+        for (int c = 0; c < 15; c++) S[bw_off + c] = row[c];
         WSYNC();
-        double s = 0.0;
-        if (lane < 15) {
+        STAMP(7);
+        double s;
+        {
             double pv[27], dv[27];
 #pragma unroll
-            for (int a = 0; a < 27; a++) pv[a] = S[S_P + a * 15 + lane];
+            for (int a = 0; a < 27; a++) pv[a] = S[S_P + a * 15 + col];
 #pragma unroll
             for (int a = 0; a < 15; a++) dv[a] = S[b1 + a];
 #pragma unroll
@@ -958,8 +977,9 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
                 s1 = fma(pv[a + 1], dv[a + 1], s1);
                 s2 = fma(pv[a + 2], dv[a + 2], s2);
             }
-            s = S[S_P + 27 * 15 + lane] - ((s0 + s1) + s2);
+            s = S[S_P + 27 * 15 + col] - ((s0 + s1) + s2);
         }
+        STAMP(8);
         // x = L^-T s on lanes 28..42 (row c of L^-T in registers), s broadcast by v_readlane
         double x0 = 0.0, x1 = 0.0;
 #pragma unroll
@@ -969,30 +989,34 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
             else x0 = fma(row[c], sc, x0);
         }
         const double x = x0 + x1;
+        STAMP(9);
         WSYNC();
-        if (lane >= 28 && lane < 43) {
-            S[S_DL + PH * 15 + lane - 28] = x;
-            v.delta[(base + k) * 15 + lane - 28] = x;
-        }
+        S[(lane >= 28 && lane < 43) ? S_DL + PH * 15 + lane - 28 : dl_w] = x;
+        if (lane >= 28 && lane < 43 && k < n) dbase[(size_t)k * 15 + lane - 28] = x;
         WSYNC();
+        STAMP(10);
     };
     {
-        int k = n - 1;
-        // bring k to phase 3 boundary, then run groups of four
-        while (k >= 0 && (k & 3) != 3) {
-            const int ph = k & 3;
-            if (ph == 2) back(IC<2>{}, k); else if (ph == 1) back(IC<1>{}, k); else back(IC<0>{}, k);
-            k--;
-        }
-        for (; k >= 3; k -= 4) {
-            back(IC<3>{}, k);
-            back(IC<2>{}, k - 1);
-            back(IC<1>{}, k - 2);
-            back(IC<0>{}, k - 3);
+        PRow cur_p = load_panel(n4 - 1), nxt_p = load_panel(n4 - 2);
+#pragma unroll 1
+        for (int k = n4 - 1; k >= 3; k -= 4) {
+            back(IC<3>{}, k, cur_p, nxt_p);
+            back(IC<2>{}, k - 1, cur_p, nxt_p);
+            back(IC<1>{}, k - 2, cur_p, nxt_p);
+            back(IC<0>{}, k - 3, cur_p, nxt_p);
         }
     }
+#ifdef VF_SOLVE_STAMPS
+    if (w == 0 && lane == 0) for (int i = 0; i < 16; i++) g_stamps[i] = st[i];
+#endif
     if (lane == 0) v.fail[w] = failed;
 }
+#ifdef VF_SOLVE_STAMPS
+extern "C" int vf_debug_solve_stamps(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
 
 // ------------------------------------------------------------------------------------ K5
 __global__ void __launch_bounds__(256) k_retract(View v) {

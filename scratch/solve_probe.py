@@ -12,4 +12,4 @@ for w in range(B):
     eng.set_states(w, 0, seq.gt_states[:1]); eng.set_prior(w, 0, synth.prior_record(seq.gt_states[0], REFERENCE_PRIOR_SIGMAS))
     eng.set_range(w, 0, 1); eng.predict(w, 1, N - 1); eng.set_range(w, 0, N)
 eng.linearize(0); eng.decide(init=True); eng.assemble(); eng.sync()
-print('solve ms', eng.time_stage('solve', 5), 'assemble ms', eng.time_stage('assemble', 5))
+print('solve ms', eng.time_stage('solve', 5), 'assemble ms', eng.time_stage('assemble', 5), 'k1', eng.time_stage('linearize_imu', 5), 'k2', eng.time_stage('linearize_between', 5))

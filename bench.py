@@ -103,12 +103,16 @@ def main():
     from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
     info = D.rank_info()
     dist = None
+    # VF_BENCH_BACKEND=gloo + VF_BENCH_SHARE_GPU=1 let two ranks share GPU 0 (control-plane smoke test
+    # on a 1-GPU box); the driver's N-GPU runs use RCCL ("nccl") with one rank per GPU.
+    backend = os.environ.get("VF_BENCH_BACKEND", "nccl")
+    gpu = 0 if os.environ.get("VF_BENCH_SHARE_GPU") else info.local_rank
     if info.world > 1:
-        torch.cuda.set_device(info.local_rank)
-        dist = D.init(backend="nccl", device_id=torch.device("cuda", info.local_rank))
-    dev = torch.device("cuda", info.local_rank)
+        torch.cuda.set_device(gpu)
+        dist = D.init(backend=backend, device_id=torch.device("cuda", gpu) if backend == "nccl" else None)
+    dev = torch.device("cuda", gpu)
 
-    eng = make_engine(args, info.rank, info.local_rank, args.windows)
+    eng = make_engine(args, info.rank, gpu, args.windows)
 
     def fence():
         D.barrier(dist)
@@ -126,7 +130,7 @@ def main():
     for _ in range(args.steps):
         one_step(eng)
     fence()
-    dt = D.max_over_ranks(dist, time.perf_counter() - t0, device=dev if dist is not None else "cpu")
+    dt = D.max_over_ranks(dist, time.perf_counter() - t0, device=dev if (dist is not None and backend == "nccl") else "cpu")
     summaries = D.gather_summaries(dist, dict(rank=info.rank, keyframes=args.windows * args.steps))
 
     if info.rank == 0:
@@ -164,7 +168,7 @@ def main():
         }
         if not args.no_single_window:
             # latency of the same update on ONE window (what a single vehicle sees)
-            one = make_engine(args, 7777, info.local_rank, 1)
+            one = make_engine(args, 7777, gpu, 1)
             for _ in range(2):
                 one_step(one)
             one.sync()

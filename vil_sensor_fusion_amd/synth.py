@@ -178,7 +178,7 @@ class Sequence:
 def make_sequence(seed: int, n_kf: int, vio: bool = True, lidar: bool = True) -> Sequence:
     """n_kf keyframes interleaving camera (20 Hz) and LiDAR (10 Hz) stamps; keyframe 0 is the
     anchor (the reference's prior node X(0), GraphManager.cpp:20-35)."""
-    horizon = n_kf * CAM_DT + 1.0
+    horizon = n_kf * LIDAR_DT + 1.0      # enough stamps whichever sources are enabled
     cam = np.arange(0, int(horizon / CAM_DT) + 1) * CAM_DT
     lid = np.arange(0, int(horizon / LIDAR_DT) + 1) * LIDAR_DT + LIDAR_PHASE
     times = np.concatenate([cam if vio else [], lid if lidar else []])

@@ -3,7 +3,7 @@
 
 One *step* = one fixed-lag update of every window in the batch: append one keyframe (its IMU
 factor and between factor are already resident in HBM; its initial value comes from the IMU
-prediction, GraphManager.cpp:152-160), drop the oldest one (re-anchor the prior), then K
+prediction, GraphManager.cpp:152-160), marginalise the oldest one into a dense prior (Schur complement, K-marg), then K
 Levenberg-Marquardt trials, each = linearise ALL factors of the window (K1+K2) -> block-banded
 J^T J (K3) -> banded Cholesky solve (K4) -> retract + cost + accept/reject (K5).
 value = (windows on all ranks) * steps / max-over-ranks time: one new keyframe per window per step.
@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-window", action="store_true")
+    ap.add_argument("--reanchor", action="store_true", help="drop the oldest keyframe by re-anchoring tight priors instead of marginalising it")
     args = ap.parse_args()
 
     import torch
@@ -120,7 +121,7 @@ def main():
         eng.sync()
 
     def one_step(e):
-        e.slide(REFERENCE_PRIOR_SIGMAS)
+        e.slide(REFERENCE_PRIOR_SIGMAS, marginalize=not args.reanchor)
         e.iterate(args.iterations)
 
     for _ in range(args.warmup):

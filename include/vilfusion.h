@@ -107,10 +107,19 @@ int vf_engine_decide(vf_engine* e, int init);
 /* `iterations` LM trials (linearize once, then {assemble, solve, retract, linearize(trial),
  * decide} per trial).  Replaces ISAM2::update + calculateEstimate (GraphManager.cpp:126-127). */
 int vf_engine_iterate(vf_engine* e, int iterations);
+/* Fixed-lag marginalisation of every window's oldest keyframe (no reference code: the
+ * reference's iSAM2 graph is unbounded): Schur complement of all factors touching it, at the
+ * current linearisation, into a dense Gaussian prior on [next: 15 dof][next+1: pose][next+2:
+ * pose].  Needs >= 4 keyframes per window and a preceding vf_engine_iterate / linearize. */
+int vf_engine_marginalize(vf_engine* e);
+/* lo += 1 on every window (call after vf_engine_marginalize) */
+int vf_engine_drop_oldest(vf_engine* e);
 /* slide every window by one keyframe: hi += 1 (new keyframe's state predicted from its IMU
- * factor, GraphManager.cpp:152-160), lo += 1 and re-anchor the prior at the new oldest
- * keyframe's current estimate. */
-int vf_engine_slide(vf_engine* e, const double* prior_sigma15);
+ * factor, GraphManager.cpp:152-160), lo += 1.  marginalize != 0: the dropped keyframe is
+ * marginalised into the dense prior above; marginalize == 0: the priors of GraphManager.cpp:27-35
+ * are re-anchored on the new oldest keyframe at its current estimate (conditioning, overconfident). */
+int vf_engine_slide(vf_engine* e, const double* prior_sigma15, int marginalize);
+int vf_engine_read_marginal(vf_engine* e, int window, int* on, double* xbar48, double* L729, double* eta27);
 int vf_engine_predict(vf_engine* e, int window, int k0, int n); /* states k0..k0+n-1 from k-1 */
 int vf_engine_sync(vf_engine* e);
 

@@ -40,6 +40,15 @@ class Pim(C.Structure):
                 ("H", C.c_double * 54), ("cov", C.c_double * 225)]
 
 
+class Marg(C.Structure):
+    _fields_ = [("on", C.c_int), ("k0", C.c_int), ("xbar", C.c_double * 48), ("L", C.c_double * 729),
+                ("eta", C.c_double * 27)]
+
+    def arrays(self):
+        return dict(on=self.on, k0=self.k0, xbar=np.array(self.xbar[:]).reshape(3, 16),
+                    L=np.array(self.L[:]).reshape(27, 27), eta=np.array(self.eta[:]))
+
+
 class Problem(C.Structure):
     _fields_ = [("n_kf", C.c_int), ("states", C.POINTER(C.c_double)),
                 ("n_imu", C.c_int), ("imu_i", C.POINTER(C.c_int32)), ("imu_j", C.POINTER(C.c_int32)),
@@ -48,7 +57,7 @@ class Problem(C.Structure):
                 ("btw_data", C.POINTER(C.c_double)),
                 ("n_prior", C.c_int), ("prior_k", C.POINTER(C.c_int32)),
                 ("prior_data", C.POINTER(C.c_double)),
-                ("gravity", C.c_double * 3)]
+                ("gravity", C.c_double * 3), ("marg", C.POINTER(Marg))]
 
 
 class LmOpts(C.Structure):
@@ -273,11 +282,26 @@ class Window:
         p.n_prior = self.prior_k.size
         p.prior_k, p.prior_data = _i(self.prior_k), _d(self.prior_data)
         p.gravity[:] = list(gravity)
+        p.marg = None
+        self.marg = None
         self.c = p
 
     @property
     def n_kf(self):
         return self.states.shape[0]
+
+    def set_marg(self, marg):
+        """attach a marginal prior (oracle.Marg, k0 window-local) or None"""
+        self.marg = marg
+        self.c.marg = C.pointer(marg) if marg is not None else None
+
+    def marginalize(self, m=0):
+        """Schur complement of every factor touching keyframe m onto [m+1:15][m+2:pose][m+3:pose]."""
+        out = Marg()
+        rc = lib().vfo_marginalize(C.byref(self.c), C.c_int(m), C.byref(out))
+        if rc != 0:
+            raise np.linalg.LinAlgError("marginalisation failed")
+        return out
 
     def cost(self):
         return lib().vfo_cost(C.byref(self.c))

@@ -23,6 +23,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+static double marg_cost(const vfo_marg* m, const double* states, double* grad);
+
 /* ------------------------------------------------------------------ small dense helpers */
 
 static void mm(const double* A, const double* B, double* C, int m, int k, int n) {
@@ -802,6 +804,50 @@ void vfo_retract(const double x[16], const double delta[15], double out[16]) {
     for (int i = 0; i < 9; i++) out[7 + i] = x[7 + i] + delta[6 + i];
 }
 
+/* ------------------------------------------------------------------ marginal prior */
+
+/* tangent index map of the 27-vector: keyframe offset and dof */
+static void marg_index(int i, int* kf, int* dof) {
+    if (i < 15) { *kf = 0; *dof = i; }
+    else if (i < 21) { *kf = 1; *dof = i - 15; }
+    else { *kf = 2; *dof = i - 21; }
+}
+
+void vfo_marg_delta(const vfo_marg* m, const double* states, double d[27]) {
+    for (int j = 0; j < 3; j++) {
+        const double* xb = m->xbar + 16 * j;
+        const double* x = states + 16 * (m->k0 + j);
+        double Rb[9], Rx[9], RbT[9], Re[9], dt[3], te[3], xi[6];
+        vfo_quat_to_rot(xb, Rb);
+        vfo_quat_to_rot(x, Rx);
+        tr3(Rb, RbT);
+        mm(RbT, Rx, Re, 3, 3, 3);
+        for (int i = 0; i < 3; i++) dt[i] = x[4 + i] - xb[4 + i];
+        mv(RbT, dt, te, 3, 3);
+        vfo_se3_log(Re, te, xi);   /* Local(xbar, x) for the Pose3 full-Expmap chart */
+        if (j == 0) {
+            memcpy(d, xi, sizeof(double) * 6);
+            for (int i = 0; i < 9; i++) d[6 + i] = x[7 + i] - xb[7 + i];
+        } else {
+            memcpy(d + 15 + 6 * (j - 1), xi, sizeof(double) * 6);
+        }
+    }
+}
+
+/* cost 0.5 d^T L d + eta^T d ; optionally the gradient L d + eta */
+static double marg_cost(const vfo_marg* m, const double* states, double* grad) {
+    double d[27], g[27];
+    vfo_marg_delta(m, states, d);
+    mv(m->L, d, g, 27, 27);
+    double c = 0.0;
+    for (int i = 0; i < 27; i++) {
+        c += 0.5 * d[i] * g[i] + m->eta[i] * d[i];
+        g[i] += m->eta[i];
+    }
+    if (grad) memcpy(grad, g, sizeof(g));
+    return c;
+}
+
 /* ------------------------------------------------------------------ window problem */
 
 int vfo_bandwidth(const vfo_problem* p) {
@@ -814,6 +860,7 @@ int vfo_bandwidth(const vfo_problem* p) {
         int d = abs(p->btw_b[f] - p->btw_a[f]);
         if (d > w) w = d;
     }
+    if (p->marg && p->marg->on && w < 2) w = 2;   /* the marginal prior couples k0 and k0+2 */
     return w;
 }
 
@@ -836,6 +883,7 @@ double vfo_cost(const vfo_problem* p) {
         vfo_prior_factor(p->prior_data + (size_t)f * VFO_PRIOR_DATA, p->states + 16 * p->prior_k[f], r, J);
         for (int i = 0; i < 15; i++) c += 0.5 * r[i] * r[i];
     }
+    if (p->marg && p->marg->on) c += marg_cost(p->marg, p->states, NULL);
     return c;
 }
 
@@ -938,7 +986,138 @@ double vfo_assemble(const vfo_problem* p, int w, double* Hband, double* g, int n
             g[k * 15 + j] += s;
         }
     }
+    if (p->marg && p->marg->on) {
+        const vfo_marg* m = p->marg;
+        double gm[27];
+        cost += marg_cost(m, p->states, gm);
+        for (int i = 0; i < 27; i++) {
+            int ki, di;
+            marg_index(i, &ki, &di);
+            g[(m->k0 + ki) * 15 + di] += gm[i];
+            for (int j = 0; j < 27; j++) {
+                int kj, dj;
+                marg_index(j, &kj, &dj);
+                if (kj > ki) continue;               /* lower block triangle only */
+                HB(m->k0 + ki, ki - kj)[di * 15 + dj] += m->L[i * 27 + j];
+            }
+        }
+    }
     return cost;
+}
+
+int vfo_marginalize(const vfo_problem* p, int m, vfo_marg* out) {
+    /* variables [m:15][m+1:15][m+2 pose:6][m+3 pose:6] = 42; only factors touching m */
+    double A[42 * 42], b[42];
+    memset(A, 0, sizeof(A));
+    memset(b, 0, sizeof(b));
+    static const int OFF[4] = {0, 15, 30, 36};
+    for (int f = 0; f < p->n_imu; f++) {
+        if (p->imu_i[f] != m) continue;
+        if (p->imu_j[f] != m + 1) return -1;
+        double r[15], J[450];
+        vfo_imu_factor(p->imu_data + (size_t)f * VFO_IMU_DATA, p->gravity, p->states + 16 * m,
+                       p->states + 16 * (m + 1), 1, r, J);
+        for (int a = 0; a < 30; a++) {
+            const int ia = a < 15 ? IMU_COL_I[a] : IMU_COL_J[a - 15];
+            for (int r0 = 0; r0 < 15; r0++) b[a] += J[r0 * 30 + ia] * r[r0];
+            for (int c = 0; c < 30; c++) {
+                const int ic = c < 15 ? IMU_COL_I[c] : IMU_COL_J[c - 15];
+                double s = 0;
+                for (int r0 = 0; r0 < 15; r0++) s += J[r0 * 30 + ia] * J[r0 * 30 + ic];
+                A[a * 42 + c] += s;
+            }
+        }
+    }
+    for (int f = 0; f < p->n_btw; f++) {
+        if (p->btw_a[f] != m) continue;
+        const int d = p->btw_b[f] - m;
+        if (d < 1 || d > 3) return -1;
+        double r[6], Ja[36], Jb[36];
+        vfo_between_factor(p->btw_data + (size_t)f * VFO_BTW_DATA, p->states + 16 * m,
+                           p->states + 16 * (m + d), 1, r, Ja, Jb);
+        const int ob = OFF[d];
+        for (int a = 0; a < 6; a++) {
+            for (int r0 = 0; r0 < 6; r0++) { b[a] += Ja[r0 * 6 + a] * r[r0]; b[ob + a] += Jb[r0 * 6 + a] * r[r0]; }
+            for (int c = 0; c < 6; c++) {
+                double saa = 0, sab = 0, sbb = 0;
+                for (int r0 = 0; r0 < 6; r0++) {
+                    saa += Ja[r0 * 6 + a] * Ja[r0 * 6 + c];
+                    sab += Jb[r0 * 6 + a] * Ja[r0 * 6 + c];
+                    sbb += Jb[r0 * 6 + a] * Jb[r0 * 6 + c];
+                }
+                A[a * 42 + c] += saa;
+                A[(ob + a) * 42 + c] += sab;
+                A[c * 42 + ob + a] += sab;
+                A[(ob + a) * 42 + ob + c] += sbb;
+            }
+        }
+    }
+    for (int f = 0; f < p->n_prior; f++) {
+        if (p->prior_k[f] != m) continue;
+        double r[15], J[225];
+        vfo_prior_factor(p->prior_data + (size_t)f * VFO_PRIOR_DATA, p->states + 16 * m, r, J);
+        for (int a = 0; a < 15; a++) {
+            for (int r0 = 0; r0 < 15; r0++) b[a] += J[r0 * 15 + a] * r[r0];
+            for (int c = 0; c < 15; c++) {
+                double s = 0;
+                for (int r0 = 0; r0 < 15; r0++) s += J[r0 * 15 + a] * J[r0 * 15 + c];
+                A[a * 42 + c] += s;
+            }
+        }
+    }
+    if (p->marg && p->marg->on) {
+        if (p->marg->k0 != m) return -1;
+        static const int MAP[27] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20,
+                                    30, 31, 32, 33, 34, 35};
+        double gm[27];
+        marg_cost(p->marg, p->states, gm);
+        for (int i = 0; i < 27; i++) {
+            b[MAP[i]] += gm[i];
+            for (int j = 0; j < 27; j++) A[MAP[i] * 42 + MAP[j]] += p->marg->L[i * 27 + j];
+        }
+    }
+    /* Cholesky of the 15x15 pivot block, then Schur complement onto the remaining 27 */
+    double Lm[225];
+    memset(Lm, 0, sizeof(Lm));
+    for (int j = 0; j < 15; j++) {
+        double s = A[j * 42 + j];
+        for (int k = 0; k < j; k++) s -= Lm[j * 15 + k] * Lm[j * 15 + k];
+        if (!(s > 0.0)) return -1;
+        Lm[j * 15 + j] = sqrt(s);
+        for (int i = j + 1; i < 15; i++) {
+            double v = A[i * 42 + j];
+            for (int k = 0; k < j; k++) v -= Lm[i * 15 + k] * Lm[j * 15 + k];
+            Lm[i * 15 + j] = v / Lm[j * 15 + j];
+        }
+    }
+    double Y[27 * 15], y1[15];   /* Y = A21 L^-T, y1 = L^-1 b1 */
+    for (int r0 = 0; r0 < 27; r0++)
+        for (int c = 0; c < 15; c++) {
+            double v = A[(15 + r0) * 42 + c];
+            for (int k = 0; k < c; k++) v -= Y[r0 * 15 + k] * Lm[c * 15 + k];
+            Y[r0 * 15 + c] = v / Lm[c * 15 + c];
+        }
+    for (int c = 0; c < 15; c++) {
+        double v = b[c];
+        for (int k = 0; k < c; k++) v -= Lm[c * 15 + k] * y1[k];
+        y1[c] = v / Lm[c * 15 + c];
+    }
+    memset(out, 0, sizeof(*out));
+    out->on = 1;
+    out->k0 = m + 1;
+    for (int i = 0; i < 27; i++) {
+        double e = b[15 + i];
+        for (int k = 0; k < 15; k++) e -= Y[i * 15 + k] * y1[k];
+        out->eta[i] = e;
+        for (int j = 0; j < 27; j++) {
+            double s = A[(15 + i) * 42 + 15 + j];
+            for (int k = 0; k < 15; k++) s -= Y[i * 15 + k] * Y[j * 15 + k];
+            out->L[i * 27 + j] = s;
+        }
+    }
+    /* the 27 kept dofs are [m+1: 15][m+2 pose][m+3 pose]: exactly rows 15..41 of the 42-vector */
+    memcpy(out->xbar, p->states + 16 * (m + 1), sizeof(double) * 48);
+    return 0;
 }
 
 int vfo_band_solve(int n_kf, int w, const double* Hband, const double* g, double lambda,

@@ -103,6 +103,18 @@ void vfo_prior_factor(const double rec[VFO_PRIOR_DATA], const double x[16], doub
 void vfo_retract(const double x[16], const double delta[15], double out[16]);
 
 /* ---- window problem + LM ---- */
+/* Marginal prior left by marginalising the keyframe in front of the window (fixed-lag, SURVEY
+ * section 8f-3; no reference code -- the reference's iSAM2 never marginalises).  Gaussian on
+ * d = [Local(xbar_0 -> x_k0) (15) ; pose part of Local(xbar_1 -> x_k0+1) (6) ; same for k0+2 (6)]:
+ *   cost(d) = 0.5 d^T L d + eta^T d,  fixed linearisation point xbar, dLocal/dx taken as identity. */
+typedef struct {
+    int on;                      /* 0 = absent */
+    int k0;                      /* first keyframe (window-local index) */
+    double xbar[48];             /* linearisation states of k0, k0+1, k0+2 */
+    double L[729];               /* 27x27 information, row-major */
+    double eta[27];              /* gradient at d = 0 */
+} vfo_marg;
+
 typedef struct {
     int n_kf;
     double* states;              /* n_kf*16, in/out */
@@ -110,6 +122,7 @@ typedef struct {
     int n_btw;  const int32_t* btw_a;  const int32_t* btw_b;  const double* btw_data;
     int n_prior; const int32_t* prior_k; const double* prior_data;
     double gravity[3];
+    const vfo_marg* marg;        /* optional marginal prior (NULL = none) */
 } vfo_problem;
 
 typedef struct {
@@ -131,6 +144,13 @@ int vfo_band_solve(int n_kf, int w, const double* Hband, const double* g, double
 /* Fixed-trip LM; costs_out[iterations+1] (cost after each iteration, [0] = initial),
  * accepted_out[iterations]. Returns final lambda. */
 double vfo_lm(vfo_problem* p, const vfo_lm_opts* o, double* costs_out, int* accepted_out);
+
+/* d (27) of a marginal prior at the current states */
+void vfo_marg_delta(const vfo_marg* m, const double* states, double d[27]);
+/* Marginalise keyframe m (window-local; must be the oldest one): Schur complement of all factors
+ * touching m (its prior / marginal prior, imu factor m -> m+1, between factors starting at m),
+ * linearised at the current states, onto [m+1: 15][m+2: pose][m+3: pose]. out->k0 = m+1. */
+int vfo_marginalize(const vfo_problem* p, int m, vfo_marg* out);
 
 #ifdef __cplusplus
 }

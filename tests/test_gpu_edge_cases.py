@@ -98,9 +98,9 @@ def test_ragged_batch_and_determinism(oracle):
         assert ate <= 1e-6 and rot <= 1e-6, (w, ate, rot)
 
 
-def test_slide_matches_oracle(oracle):
-    """Fixed-lag update path of bench.py: slide (predict new keyframe, drop oldest, re-anchor
-    prior at the current estimate) + K LM trials, three times, against the oracle doing the same."""
+def test_slide_reanchor_matches_oracle(oracle):
+    """Fallback fixed-lag update: slide (predict new keyframe, drop oldest, re-anchor the prior at
+    the current estimate) + K LM trials, three times, against the oracle doing the same."""
     from vil_sensor_fusion_amd import Engine, EngineOpts
     N, S = 40, 3
     seq = synth.make_sequence(41, N + S)
@@ -113,7 +113,7 @@ def test_slide_matches_oracle(oracle):
     win.lm(iterations=4)
     states[:N] = win.states
     for s in range(1, S + 1):
-        eng.slide(REFERENCE_PRIOR_SIGMAS)
+        eng.slide(REFERENCE_PRIOR_SIGMAS, marginalize=False)
         eng.iterate(4)
         # oracle: predict the new keyframe from the current estimate, re-anchor, solve
         states[N + s - 1] = oracle.predict(prob["imu"][N + s - 1], prob["gravity"], states[N + s - 2])
@@ -141,3 +141,89 @@ def test_indeterminate_system_is_flagged(oracle):
     lm = eng.read_lm(0)
     assert lm["accepted"] == 0 and lm["rejected"] == 3     # NaN cost never accepted (NaN compares false)
     assert lm["solve_failures"] >= 1
+
+
+def _oracle_window(oracle, prob, states, lo, hi, marg, with_prior):
+    m = (prob["btw_a"] >= lo) & (prob["btw_b"] < hi)
+    ks = np.arange(lo + 1, hi)
+    pk = np.array([0], dtype=np.int32) if with_prior else np.zeros(0, dtype=np.int32)
+    pd = prob["prior"].reshape(1, -1) if with_prior else np.zeros((0, 31))
+    w = oracle.Window(states[lo:hi], ks - 1 - lo, ks - lo, prob["imu"][lo + 1:hi], prob["btw_a"][m] - lo,
+                      prob["btw_b"][m] - lo, prob["btw"][m], pk, pd, prob["gravity"])
+    if marg is not None:
+        w.set_marg(marg)
+    return w
+
+
+def test_marginal_prior_and_fixed_lag_slides_match_oracle(oracle):
+    """bench.py's update path: marginalise the oldest keyframe (Schur complement into a dense
+    prior), slide, K LM trials -- five times -- against the oracle doing the same; the marginal
+    prior itself (27x27 information, gradient, linearisation states) is compared after every slide."""
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    N, S = 40, 5
+    seq = synth.make_sequence(43, N + S)
+    prob = helpers.build_problem(oracle, seq)
+    eng = Engine(EngineOpts(windows=2, capacity=64))     # second window: ragged companion
+    helpers.load_engine(eng, 0, prob, lo=0, hi=N)
+    helpers.load_engine(eng, 1, prob, lo=0, hi=N - 7)
+    eng.iterate(4)
+    states = prob["states"].copy()
+    win = _oracle_window(oracle, prob, states, 0, N, None, True)
+    win.lm(iterations=4)
+    states[:N] = win.states
+    marg = None
+    for s in range(1, S + 1):
+        eng.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)
+        got = eng.read_marginal(0)
+        prev = _oracle_window(oracle, prob, states, s - 1, N + s - 1, marg, s == 1)
+        marg = prev.marginalize(0)
+        exp = marg.arrays()
+        assert got["on"] == 1
+        scale = np.abs(exp["L"]).max()
+        np.testing.assert_allclose(got["L"], exp["L"], atol=1e-9 * scale)
+        np.testing.assert_allclose(got["eta"], exp["eta"], atol=1e-9 * max(np.abs(exp["eta"]).max(), 1e-6 * scale))
+        np.testing.assert_allclose(got["xbar"], exp["xbar"], atol=1e-12)
+        eng.iterate(4)
+        marg.k0 = 0
+        states[N + s - 1] = oracle.predict(prob["imu"][N + s - 1], prob["gravity"], states[N + s - 2])
+        win = _oracle_window(oracle, prob, states, s, N + s, marg, False)
+        costs, acc, _ = win.lm(iterations=4)
+        states[s:N + s] = win.states
+        ate, rot = helpers.ate(eng.get_states(0, s, N), win.states)
+        lm = eng.read_lm(0)
+        print(f"marginalised slide {s}: ATE {ate:.3e} rot {rot:.3e} cost gpu {lm['cost']:.9e} oracle {costs[-1]:.9e}")
+        assert ate <= 1e-6 and rot <= 1e-6
+        assert abs(lm["cost"] - costs[-1]) <= 1e-6 * max(abs(costs[-1]), 1e-9)
+
+
+def test_graph_manager_fixed_lag_marginalises(oracle):
+    """GraphManager with lag: the window never exceeds `lag` keyframes and the estimate stays
+    close to the unbounded (full-history) smoother on the same stream."""
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    n = 70
+    seq = synth.make_sequence(44, n)
+    traj_t = synth.IMU_PHASE + np.arange(0, int((seq.kf_time[-1] + 0.5) * synth.IMU_RATE)) / synth.IMU_RATE
+    traj = synth.Trajectory(seq.seed, seq.kf_time[-1] + 1.0)
+    rng = np.random.default_rng([seq.seed, 0xBEEF])
+    acc = traj.specific_force(traj_t) + rng.normal(size=(traj_t.size, 3)) * synth.IMU_NOISE
+    gyr = traj.body_rate(traj_t) + rng.normal(size=(traj_t.size, 3)) * synth.IMU_NOISE
+    out = {}
+    for name, lag in (("full", 0), ("lag", 24)):
+        gm = GraphManager(capacity=128, iterations=5, lag=lag)
+        i_imu = 0
+        for k in range(1, n):
+            while i_imu < traj_t.size and traj_t[i_imu] <= seq.kf_time[k] + 0.01:
+                gm.addIMUMeasurement(traj_t[i_imu], acc[i_imu], gyr[i_imu]); i_imu += 1
+            gm.reserveNode(seq.kf_time[k])
+            for a, b, q, t, c in zip(seq.btw_a, seq.btw_b, seq.btw_q, seq.btw_t, seq.btw_cov):
+                if b == k and a >= 1:
+                    gm.addBetweenFactor(int(a), int(b), (q, t), np.eye(6) * c)
+            if k % 2 == 0:
+                gm.solve()
+        gm.solve()
+        out[name] = gm.getState()
+    (qf, tf), vf_, bf = out["full"]
+    (ql, tl), vl, bl = out["lag"]
+    dpos = np.linalg.norm(tf - tl)
+    print("fixed-lag (24) vs full-history smoother, last pose difference [m]:", dpos)
+    assert dpos < 5e-3

@@ -42,6 +42,7 @@ struct vf_engine {
     double* stage = nullptr;  // device staging buffer (AoS)
     size_t stage_bytes = 0;
     double* sigma_dev = nullptr;
+    int* status_dev = nullptr;
     std::vector<int> h_lo, h_hi;  // host mirror of the active ranges
 
     template <typename T>
@@ -129,6 +130,11 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.prior_k, (size_t)v.B);
     AL(v.prior_in, (size_t)v.B * vf::PRIOR_IN);
     AL(v.prior_out, 2 * (size_t)v.B * vf::PRIOR_OUT);
+    AL(v.mp_on, (size_t)v.B);
+    AL(v.mp_x, (size_t)v.B * 48);
+    AL(v.mp_L, (size_t)v.B * 729);
+    AL(v.mp_eta, (size_t)v.B * 27);
+    AL(v.mp_out, 2 * (size_t)v.B * 28);
     AL(v.H, G * vf::HROW);
     AL(v.gvec, G * 15);
     AL(v.delta, G * 15);
@@ -143,6 +149,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.n_rej, (size_t)v.B);
     AL(v.n_fail, (size_t)v.B);
     AL(e->sigma_dev, 16);
+    AL(e->status_dev, 4);
 #undef AL
     HIPCHK(hipMemsetAsync(v.btw_a, 0xff, G * sizeof(int), e->stream));   // -1 = empty slot
     HIPCHK(hipMemsetAsync(v.prior_k, 0xff, v.B * sizeof(int), e->stream));
@@ -281,6 +288,7 @@ int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec) {
         if (!(rec[16 + i] > 0.0)) return fail(VF_ERR_NOT_SPD, "prior sigma %d must be > 0", i);
     HIPCHK(hipMemcpyAsync(e->v.prior_in + (size_t)window * vf::PRIOR_IN, rec, vf::PRIOR_IN * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->v.prior_k + window, &k, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(e->v.mp_on + window, 0, sizeof(int), e->stream));   // a fresh anchor replaces any marginal prior
     HIPCHK(hipStreamSynchronize(e->stream));
     return VF_OK;
 }
@@ -392,15 +400,56 @@ int vf_engine_predict(vf_engine* e, int window, int k0, int n) {
     return VF_OK;
 }
 
-int vf_engine_slide(vf_engine* e, const double* prior_sigma15) {
+int vf_engine_marginalize(vf_engine* e) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    for (int w = 0; w < e->v.B; w++)
+        if (e->h_hi[w] - e->h_lo[w] < 4) return fail(VF_ERR_INVALID, "window %d: marginalisation needs >= 4 keyframes", w);
+    HIPCHK(hipMemsetAsync(e->status_dev, 0, sizeof(int), e->stream));
+    vf::launch_marginalize(e->v, e->status_dev, e->stream);
+    HIPCHK(hipGetLastError());
+    int status = 0;
+    HIPCHK(hipMemcpyAsync(&status, e->status_dev, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (status) return fail(VF_ERR_INDETERMINATE, "marginalisation: pivot block of the oldest keyframe not positive definite");
+    return VF_OK;
+}
+
+int vf_engine_drop_oldest(vf_engine* e) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    for (int w = 0; w < e->v.B; w++) {
+        if (e->h_hi[w] - e->h_lo[w] < 2) return fail(VF_ERR_INVALID, "window %d too short", w);
+        const int lo = e->h_lo[w] + 1;
+        HIPCHK(hipMemcpyAsync(e->v.lo + w, &lo, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int w = 0; w < e->v.B; w++) e->h_lo[w]++;
+    return VF_OK;
+}
+
+int vf_engine_slide(vf_engine* e, const double* prior_sigma15, int marginalize) {
     if (!e || !prior_sigma15) return fail(VF_ERR_INVALID, "null argument");
     for (int w = 0; w < e->v.B; w++)
         if (e->h_hi[w] >= e->v.M) return fail(VF_ERR_CAPACITY, "window %d has no free keyframe slot", w);
+    if (marginalize) {
+        int rc = vf_engine_marginalize(e);
+        if (rc) return rc;
+    }
     HIPCHK(hipMemcpyAsync(e->sigma_dev, prior_sigma15, 15 * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    vf::launch_slide(e->v, e->sigma_dev, e->stream);
+    vf::launch_slide(e->v, e->sigma_dev, marginalize ? 0 : 1, e->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));  // sigma is a caller temporary
     for (int w = 0; w < e->v.B; w++) { e->h_lo[w]++; e->h_hi[w]++; }
+    return VF_OK;
+}
+
+int vf_engine_read_marginal(vf_engine* e, int window, int* on, double* xbar48, double* L729, double* eta27) {
+    int rc = check_window(e, window);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (on) HIPCHK(hipMemcpy(on, e->v.mp_on + window, sizeof(int), hipMemcpyDeviceToHost));
+    if (xbar48) HIPCHK(hipMemcpy(xbar48, e->v.mp_x + (size_t)window * 48, 48 * sizeof(double), hipMemcpyDeviceToHost));
+    if (L729) HIPCHK(hipMemcpy(L729, e->v.mp_L + (size_t)window * 729, 729 * sizeof(double), hipMemcpyDeviceToHost));
+    if (eta27) HIPCHK(hipMemcpy(eta27, e->v.mp_eta + (size_t)window * 27, 27 * sizeof(double), hipMemcpyDeviceToHost));
     return VF_OK;
 }
 

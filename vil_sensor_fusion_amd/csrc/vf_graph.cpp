@@ -311,16 +311,15 @@ int vf_solve(vf_graph* g) {
         }
         if ((rc = vf_engine_set_between(g->eng, 0, (int)a.size(), a.data(), b.data(), rec.data()))) return rc;
     }
-    // fixed-lag window: re-anchor the priors on the new oldest keyframe at its current estimate
+    // fixed-lag window: marginalise the keyframes that fall out of the lag, one at a time, at the
+    // linearisation of the previous solve (their factors have not changed since)
     int lo = g->lo;
-    if (g->opts.lag > 0 && (int)last_key + 1 - lo > g->opts.lag) {
-        lo = (int)last_key + 1 - g->opts.lag;
-        double rec[VF_PRIOR_RECORD];
-        if ((rc = vf_engine_get_states(g->eng, 0, lo, 1, rec))) return rc;
-        memcpy(rec + 16, g->opts.prior_sigma, sizeof(double) * 15);
-        if ((rc = vf_engine_set_prior(g->eng, 0, lo, rec))) return rc;
-        g->lo = lo;
+    while (g->opts.lag > 0 && (int)last_key + 1 - lo > g->opts.lag && (int)g->solved_key - lo >= 3) {
+        if ((rc = vf_engine_marginalize(g->eng))) return rc;
+        if ((rc = vf_engine_drop_oldest(g->eng))) return rc;
+        lo++;
     }
+    g->lo = lo;
     if ((rc = vf_engine_set_range(g->eng, 0, lo, (int)last_key + 1))) return rc;
     if ((rc = vf_engine_iterate(g->eng, g->opts.iterations))) return rc;   // ISAM2::update + calculateEstimate
     int fails = 0;

@@ -444,12 +444,49 @@ __global__ void __launch_bounds__(256) k_linearize_between(View v, int which) {
 }
 
 // ------------------------------------------------------------------------------------ K2b
+// delta of the marginal prior: [Local(xbar0 -> x_lo) (15); pose Local for lo+1 (6); lo+2 (6)]
+VF_DI void marg_delta(const View& v, int w, int b, double (&d)[27]) {
+    const int lo = v.lo[w];
+    const double* xb = v.mp_x + (size_t)w * 48;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const long gk = (long)w * v.M + lo + j;
+        const State s = load_state(v, b, gk);
+        const Q4 qb = q4(xb[16 * j], xb[16 * j + 1], xb[16 * j + 2], xb[16 * j + 3]);
+        const V3 tb = v3(xb[16 * j + 4], xb[16 * j + 5], xb[16 * j + 6]);
+        const Xi6 xi = se3_log(qmul(qconj(qb), s.q), mulT(qrot(qb), s.t - tb));
+        const int o = j == 0 ? 0 : 15 + 6 * (j - 1);
+        d[o] = xi.w.x; d[o + 1] = xi.w.y; d[o + 2] = xi.w.z; d[o + 3] = xi.u.x; d[o + 4] = xi.u.y; d[o + 5] = xi.u.z;
+        if (j == 0) {
+            d[6] = s.vel.x - xb[7]; d[7] = s.vel.y - xb[8]; d[8] = s.vel.z - xb[9];
+            d[9] = s.ba.x - xb[10]; d[10] = s.ba.y - xb[11]; d[11] = s.ba.z - xb[12];
+            d[12] = s.bg.x - xb[13]; d[13] = s.bg.y - xb[14]; d[14] = s.bg.z - xb[15];
+        }
+    }
+}
+
 __global__ void k_linearize_prior(View v, int which) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= v.B) return;
+    const int b = v.sel[w] ^ which;
+    if (v.mp_on[w] && v.hi[w] - v.lo[w] >= 3) {
+        // marginal prior: gm = L d + eta, cost = 0.5 d^T L d + eta^T d (fixed linearisation point)
+        double d[27];
+        marg_delta(v, w, b, d);
+        const double* L = v.mp_L + (size_t)w * 729;
+        const double* eta = v.mp_eta + (size_t)w * 27;
+        double* out = v.mp_out + ((size_t)b * v.B + w) * 28;
+        double cost = 0.0;
+        for (int i = 0; i < 27; i++) {
+            double g = 0.0;
+            for (int j = 0; j < 27; j++) g = fma(L[i * 27 + j], d[j], g);
+            cost += d[i] * (0.5 * g + eta[i]);
+            out[i] = g + eta[i];
+        }
+        out[27] = cost;
+    }
     const int k = v.prior_k[w];
     if (k < v.lo[w] || k >= v.hi[w]) return;
-    const int b = v.sel[w] ^ which;
     const long gk = (long)w * v.M + k;
     const double* in = v.prior_in + (size_t)w * PRIOR_IN;
     double* out = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT;
@@ -621,6 +658,9 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
                 const bool btw_here = s_a[kl] >= 0;
                 const bool is_prior = v.prior_k[w] == k;
                 const double* Pq = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT;
+                const int mo = (v.mp_on[w] && hi - lo >= 3) ? k - lo : 99;   // 0,1,2: rows of the marginal prior
+                const double* ML = v.mp_L + (size_t)w * 729;
+                const double* Mg = v.mp_out + ((size_t)b * v.B + w) * 28;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int a = kq + 4 * r;
@@ -636,6 +676,11 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
                         for (int rr = 0; rr < 15; rr++)
                             sum = fma(Pq[15 + rr * 15 + a], ci < 15 ? Pq[15 + rr * 15 + ci] : Pq[rr], sum);
                         val += sum;
+                    }
+                    if (mo == 0 && a < 15) val += ci < 15 ? ML[a * 27 + ci] : Mg[a];
+                    if ((mo == 1 || mo == 2) && a < 6 && (ci < 6 || ci == 15)) {
+                        const int ob = mo == 1 ? 15 : 21;
+                        val += ci < 6 ? ML[(ob + a) * 27 + ob + ci] : Mg[ob + a];
                     }
                     if (a < 15) {
                         if (ci < 15) __builtin_nontemporal_store(val, Hk + a * 15 + ci);
@@ -658,20 +703,30 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
                 double* Hk = v.H + (size_t)(gk0 + kl) * HROW;
                 const int ak = s_a[kl];
                 const int dk = ak >= 0 ? k - ak : 0;   // 1..3 when a between factor ends here
+                const int mo2 = (v.mp_on[w] && hi - lo >= 3) ? k - lo : 99;
+                const double* ML2 = v.mp_L + (size_t)w * 729;
                 if (k > lo) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int a = kq + 4 * r;
                         double val = O[r];
                         if (dk == 1 && a < 6 && ci < 6) val += bdot(kl, 42, a, 6, ci);
+                        if (mo2 == 1 && a < 6 && ci < 15) val += ML2[(15 + a) * 27 + ci];            // (lo+1 pose) x (lo: 15)
+                        if (mo2 == 2 && a < 6 && ci < 6) val += ML2[(21 + a) * 27 + 15 + ci];        // (lo+2 pose) x (lo+1 pose)
                         if (a < 15 && ci < 15) __builtin_nontemporal_store(val, Hk + 225 + a * 15 + ci);
                     }
                 }
                 if (lane < 36) {
                     const int a6 = lane / 6, b6 = lane - a6 * 6;
                     const double x = (dk >= 2) ? bdot(kl, 42, a6, 6, b6) : 0.0;
-                    Hk[450 + a6 * 15 + b6] = dk == 2 ? x : 0.0;
+                    Hk[450 + a6 * 15 + b6] = (dk == 2 ? x : 0.0) + (mo2 == 2 ? ML2[(21 + a6) * 27 + b6] : 0.0);
                     Hk[675 + a6 * 15 + b6] = dk == 3 ? x : 0.0;
+                }
+                // the marginal prior couples (lo+2 pose) with all 15 dof of lo: columns 6..14 of the
+                // d=2 strip (the solver reads them only for the window's third keyframe)
+                if (mo2 == 2 && lane < 54) {
+                    const int a6 = lane / 9, b9 = 6 + lane - a6 * 9;
+                    Hk[450 + a6 * 15 + b9] = ML2[(21 + a6) * 27 + b9];
                 }
             }
         }
@@ -798,21 +853,22 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
         cm_lam[j] = (in && a == c) ? lam : 0.0;
         cm_one[j] = (in && a == c) ? 1.0 : 0.0;
     }
-    const int q_a = lane / 6, q_c = lane - q_a * 6;  // 6x6 pose block map (lane < 36)
-    int cp_off[2], cp_owner[2];
-    double cp_keep[2];                               // 6x15 pose-row strips of the d = 2,3 blocks
+    int cp_off[2], cp_src[2];                        // 6x15 pose-row strips of the d = 2,3 blocks
+    double cp_pose[2], cp_rest[2];
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         const int e = lane + 64 * it, a = e / 15, c = e - a * 15;
         cp_off[it] = e < 90 ? a * LDW + c : -1;
-        cp_owner[it] = (e < 90 && c < 6) ? a * 6 + c : 0;
-        cp_keep[it] = (e < 90 && c < 6) ? 1.0 : 0.0;
+        cp_src[it] = e < 90 ? a * 15 + c : 0;
+        cp_pose[it] = (e < 90 && c < 6) ? 1.0 : 0.0;    // pose x pose part (between factors)
+        cp_rest[it] = (e < 90 && c >= 6) ? 1.0 : 0.0;   // columns 6..14: only the marginal prior fills them
     }
+    const double mp_third = (v.mp_on[w] && n >= 3) ? 1.0 : 0.0;
     WSYNC();
 
     // ---- H block row prefetch (HBM -> registers) and commit (registers -> LDS slot) ---------
     // (passed by value: captured-by-reference scalars ended up in scratch memory)
-    struct HRow { double h0[4], h1[4], h2, h3, hg; };
+    struct HRow { double h0[4], h1[4], h2[2], h3[2], hg; };
     const double* __restrict__ Hbase = v.H + base * HROW;
     const double* __restrict__ gbase = v.gvec + base * 15;
     double* __restrict__ Lbase = v.Lp + base * PANEL;
@@ -827,12 +883,16 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
             r.h0[j] = in ? Hk[lane + 64 * j] : 0.0;
             r.h1[j] = (in && kk >= 1) ? Hk[225 + lane + 64 * j] : 0.0;
         }
-        r.h2 = (real && lane < 36 && kk >= 2) ? Hk[450 + q_a * 15 + q_c] : 0.0;
-        r.h3 = (real && lane < 36 && kk >= 3) ? Hk[675 + q_a * 15 + q_c] : 0.0;
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const bool in = real && cp_off[it] >= 0;
+            r.h2[it] = (in && kk >= 2) ? Hk[450 + cp_src[it]] : 0.0;
+            r.h3[it] = (in && kk >= 3) ? Hk[675 + cp_src[it]] : 0.0;
+        }
         r.hg = (real && lane < 15) ? gbase[(size_t)kk * 15 + lane] : 0.0;   // negated at commit (a use here would stall on vmcnt)
         return r;
     };
-    auto commit_row = [&](auto ph, const HRow r, bool real) {   // keyframe kk with kk & 3 == PH
+    auto commit_row = [&](auto ph, const HRow r, bool real, int kk) {   // keyframe kk with kk & 3 == PH
         constexpr int PH = decltype(ph)::value;
         constexpr int s = PH * 15, c1 = ((PH + 3) & 3) * 15, c2 = ((PH + 2) & 3) * 15, c3 = ((PH + 1) & 3) * 15;
 #pragma unroll
@@ -842,19 +902,20 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
             S[in ? S_WD + s * LDW + s + cm_off[j] : S_DUMP + 32 + lane] = d0;
             S[in ? S_WD + s * LDW + c1 + cm_off[j] : S_DUMP + 32 + lane] = r.h1[j];
         }
+        const double third = kk == 2 ? mp_third : 0.0;
 #pragma unroll
-        for (int it = 0; it < 2; it++) {   // every lane takes part in the shuffles
-            const double x2 = __shfl(r.h2, cp_owner[it]) * cp_keep[it], x3 = __shfl(r.h3, cp_owner[it]) * cp_keep[it];
+        for (int it = 0; it < 2; it++) {
+            const double x2 = r.h2[it] * (cp_pose[it] + third * cp_rest[it]), x3 = r.h3[it] * cp_pose[it];
             const bool in = cp_off[it] >= 0;
             S[in ? S_WD + s * LDW + c2 + cp_off[it] : S_DUMP + 32 + lane] = x2;
             S[in ? S_WD + s * LDW + c3 + cp_off[it] : S_DUMP + 32 + lane] = x3;
         }
         S[lane < 15 ? S_GD + s + lane : S_DUMP + 32 + lane] = -r.hg;
     };
-    commit_row(IC<0>{}, fetch_row(0), 0 < n);
-    commit_row(IC<1>{}, fetch_row(1), 1 < n);
-    commit_row(IC<2>{}, fetch_row(2), 2 < n);
-    commit_row(IC<3>{}, fetch_row(3), 3 < n);
+    commit_row(IC<0>{}, fetch_row(0), 0 < n, 0);
+    commit_row(IC<1>{}, fetch_row(1), 1 < n, 1);
+    commit_row(IC<2>{}, fetch_row(2), 2 < n, 2);
+    commit_row(IC<3>{}, fetch_row(3), 3 < n, 3);
     WSYNC();
     const int n4 = (n + 3) & ~3;   // steps beyond n eliminate identity rows (no effect); saves remainder copies
 
@@ -926,7 +987,7 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
         }
         WSYNC();
         STAMP(4);
-        commit_row(ph, pend, k + 4 < n);  // keyframe k+4 takes the slot the pivot keyframe frees
+        commit_row(ph, pend, k + 4 < n, k + 4);  // keyframe k+4 takes the slot the pivot keyframe frees
         pend = ahead;
         WSYNC();
         STAMP(5);
@@ -1082,6 +1143,7 @@ __global__ void __launch_bounds__(256) k_decide(View v, int init) {
             const double* f = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT;
             for (int r = 0; r < 15; r++) s = fma(f[r], f[r], s);
         }
+        if (v.mp_on[w] && hi - lo >= 3) s += 2.0 * v.mp_out[((size_t)b * v.B + w) * 28 + 27];
     }
     __shared__ double red[256];
     red[tid] = s;
@@ -1159,8 +1221,108 @@ __global__ void k_predict(View v, int window, int k0, int n) {
     }
 }
 
-// fixed-lag slide by one keyframe: hi += 1 (predict the new state), lo += 1, re-anchor the prior
-__global__ void k_slide(View v, const double* sigma15) {
+// Fixed-lag marginalisation of the oldest keyframe m = lo: the Schur complement of
+// every factor touching m -- its prior or marginal prior, the IMU factor m -> m+1, the between
+// factors starting at m -- taken at the current linearisation (buffer `sel`), onto
+// [m+1: 15][m+2: pose 6][m+3: pose 6].  One wave per window, 42x42 system in LDS, Gaussian
+// elimination of the 15 leading columns (no square roots).  Runs once per slide.
+__global__ void __launch_bounds__(64) k_marginalize(View v, int* status) {
+    const int w = blockIdx.x, lane = threadIdx.x;
+    const int lo = v.lo[w], hi = v.hi[w];
+    if (hi - lo < 4) { if (lane == 0) atomicOr(status, 2); return; }
+    const int b = v.sel[w];
+    const size_t tiles = (size_t)(v.G >> 6);
+    const long g0 = (long)w * v.M + lo;
+    __shared__ double A[42 * 43];
+    __shared__ double bv[42];
+    const double* imu = v.imu_out + (size_t)b * tiles * IMU_OUT * TILE + (size_t)((g0 + 1) >> 6) * IMU_OUT * TILE + ((g0 + 1) & 63);
+    auto JI = [&](int r, int c30) { return imu[(size_t)(15 + r * 30 + c30) * TILE]; };
+    const bool has_prior = v.prior_k[w] == lo;
+    const bool has_mp = v.mp_on[w] != 0;
+    const double* Pq = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT;
+    const double* ML = v.mp_L + (size_t)w * 729;
+    const double* Mg = v.mp_out + ((size_t)b * v.B + w) * 28;
+    int bd[3];   // between factor m -> m+d present?
+    for (int d = 1; d <= 3; d++) bd[d - 1] = (v.btw_a[g0 + d] == lo);
+    auto BT = [&](int d, int f) {
+        const long gs = g0 + d;
+        return v.btw_out[(size_t)b * tiles * BTW_OUT * TILE + ((size_t)(gs >> 6) * BTW_OUT + f) * TILE + (gs & 63)];
+    };
+    // index maps of the 42-vector: [m:15][m+1:15][m+2 pose][m+3 pose]
+    auto imu_c = [](int i) { return i < 15 ? imu_col(0, i) : imu_col(1, i - 15); };   // i < 30
+    auto mp_i = [](int i) { return i < 15 ? i : (i < 21 ? i : (i >= 30 && i < 36 ? i - 9 : -1)); };   // 42-index -> 27-index
+    for (int e = lane; e < 42 * 42 + 42; e += 64) {
+        const bool is_b = e >= 42 * 42;
+        const int i = is_b ? e - 42 * 42 : e / 42, j = is_b ? -1 : e - (e / 42) * 42;
+        double sum = 0.0;
+        if (i < 30 && (is_b || j < 30)) {   // IMU factor m -> m+1
+            const int ci = imu_c(i);
+            for (int r = 0; r < 15; r++) sum = fma(JI(r, ci), is_b ? imu[(size_t)r * TILE] : JI(r, imu_c(j)), sum);
+        }
+        for (int d = 1; d <= 3; d++) {      // between factors m -> m+d: Ja on m pose, Jb on (m+d) pose
+            if (!bd[d - 1]) continue;
+            const int ob = d == 1 ? 15 : (d == 2 ? 30 : 36);
+            const int ia = i < 6 ? i : -1, ib = (i >= ob && i < ob + 6) ? i - ob : -1;
+            const int ja = (!is_b && j < 6) ? j : -1, jb = (!is_b && j >= ob && j < ob + 6) ? j - ob : -1;
+            if (ia < 0 && ib < 0) continue;
+            if (!is_b && ja < 0 && jb < 0) continue;
+            for (int r = 0; r < 6; r++) {
+                const double xi = ia >= 0 ? BT(d, 6 + r * 6 + ia) : BT(d, 42 + r * 6 + ib);
+                const double xj = is_b ? BT(d, r) : (ja >= 0 ? BT(d, 6 + r * 6 + ja) : BT(d, 42 + r * 6 + jb));
+                sum = fma(xi, xj, sum);
+            }
+        }
+        if (has_prior && i < 15 && (is_b || j < 15))
+            for (int r = 0; r < 15; r++) sum = fma(Pq[15 + r * 15 + i], is_b ? Pq[r] : Pq[15 + r * 15 + j], sum);
+        if (has_mp) {
+            const int mi = mp_i(i), mj = is_b ? 0 : mp_i(j);
+            if (mi >= 0 && mj >= 0) sum += is_b ? Mg[mi] : ML[mi * 27 + mj];
+        }
+        if (is_b) bv[i] = sum; else A[i * 43 + j] = sum;
+    }
+    __syncthreads();
+    int bad = 0;
+    for (int c = 0; c < 15; c++) {
+        const double d = A[c * 43 + c];
+        if (!(d > 0.0)) bad = 1;
+        const double inv = 1.0 / d;
+        __syncthreads();
+        // rank-1 update of the trailing (41-c)x(41-c) block and of b, entry-parallel; column c and
+        // b[c] are only read in this step, so one pass is hazard-free
+        const int m = 41 - c;
+        for (int e = lane; e < m * m + m; e += 64) {
+            const bool is_b = e >= m * m;
+            const int i = c + 1 + (is_b ? e - m * m : e / m), j = is_b ? -1 : c + 1 + (e - (e / m) * m);
+            const double u = A[i * 43 + c] * inv * (is_b ? bv[c] : A[j * 43 + c]);
+            if (is_b) bv[i] -= u; else A[i * 43 + j] -= u;
+        }
+        __syncthreads();
+    }
+    // new marginal prior on [m+1:15][m+2 pose][m+3 pose] = rows 15..41, relinearised at the current states
+    for (int e = lane; e < 729 + 27; e += 64) {
+        if (e < 729) { const int i = e / 27, j = e - i * 27; v.mp_L[(size_t)w * 729 + e] = 0.5 * (A[(15 + i) * 43 + 15 + j] + A[(15 + j) * 43 + 15 + i]); }
+        else {
+            // also the "linearised" form at the new linearisation point (d = 0: gradient eta, cost 0),
+            // so that a second marginalisation can follow without an intervening linearise
+            const double et = bv[15 + e - 729];
+            v.mp_eta[(size_t)w * 27 + e - 729] = et;
+            v.mp_out[((size_t)0 * v.B + w) * 28 + e - 729] = et;
+            v.mp_out[((size_t)1 * v.B + w) * 28 + e - 729] = et;
+        }
+    }
+    if (lane == 0) { v.mp_out[((size_t)0 * v.B + w) * 28 + 27] = 0.0; v.mp_out[((size_t)1 * v.B + w) * 28 + 27] = 0.0; }
+    if (lane < 48) { const int j = lane / 16, c = lane - j * 16; v.mp_x[(size_t)w * 48 + lane] = XS(b, c, g0 + 1 + j); }
+    if (lane == 0) {
+        v.mp_on[w] = 1;
+        v.prior_k[w] = -1;
+        if (bad) atomicOr(status, 1);
+    }
+}
+
+// fixed-lag slide by one keyframe: hi += 1 (predict the new state), lo += 1, and either re-anchor
+// the diagonal prior on the new oldest keyframe (reanchor = 1) or keep the marginal prior that
+// k_marginalize just produced (reanchor = 0)
+__global__ void k_slide(View v, const double* sigma15, int reanchor) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= v.B) return;
     const int b = v.sel[w];
@@ -1170,8 +1332,10 @@ __global__ void k_slide(View v, const double* sigma15) {
     store_state(v, b, gnew, predict_state(v, load_state(v, b, gnew - 1), gnew));
     v.hi[w] = hi + 1;
     v.lo[w] = lo + 1;
+    if (!reanchor) return;
     const long ganchor = (long)w * v.M + lo + 1;
     v.prior_k[w] = lo + 1;
+    v.mp_on[w] = 0;
     double* pin = v.prior_in + (size_t)w * PRIOR_IN;
     for (int c = 0; c < 16; c++) pin[c] = XS(b, c, ganchor);
     for (int c = 0; c < 15; c++) pin[16 + c] = sigma15[c];
@@ -1243,8 +1407,11 @@ void launch_predict(const View& v, int window, int k0, int n, hipStream_t s) {
     if (window >= 0) hipLaunchKernelGGL(k_predict, dim3(1), dim3(1), 0, s, v, window, k0, n);
     else hipLaunchKernelGGL(k_predict, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, window, k0, n);
 }
-void launch_slide(const View& v, const double* sigma15_dev, hipStream_t s) {
-    hipLaunchKernelGGL(k_slide, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, sigma15_dev);
+void launch_slide(const View& v, const double* sigma15_dev, int reanchor, hipStream_t s) {
+    hipLaunchKernelGGL(k_slide, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, sigma15_dev, reanchor);
+}
+void launch_marginalize(const View& v, int* status, hipStream_t s) {
+    hipLaunchKernelGGL(k_marginalize, dim3(v.B), dim3(64), 0, s, v, status);
 }
 void launch_scatter(const double* aos, double* aosoa, long g0, long n, int nf, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_scatter, dim3(nblk(n * nf, 256)), dim3(256), 0, s, aos, aosoa, g0, n, nf);

@@ -30,6 +30,12 @@ struct View {
     int* prior_k;       // [B]                 local keyframe index, -1 = none
     double* prior_in;   // [B][31]
     double* prior_out;  // [2][B][240]
+    // marginal prior left by fixed-lag marginalisation: Gaussian on [lo: 15][lo+1: pose 6][lo+2: pose 6]
+    int* mp_on;         // [B]
+    double* mp_x;       // [B][3][16]   linearisation states
+    double* mp_L;       // [B][27][27]  information
+    double* mp_eta;     // [B][27]      gradient at the linearisation point
+    double* mp_out;     // [2][B][28]   L d + eta (27) and the cost 0.5 d^T L d + eta^T d
     double* H;          // [G][4][15][15]      block d of row k = H[k][k-d]
     double* gvec;       // [G][15]
     double* delta;      // [G][15]
@@ -58,7 +64,8 @@ void launch_band_solve(const View& v, hipStream_t s);
 void launch_retract(const View& v, hipStream_t s);
 void launch_decide(const View& v, int init, hipStream_t s);
 void launch_predict(const View& v, int window, int k0, int n, hipStream_t s);
-void launch_slide(const View& v, const double* sigma15_dev, hipStream_t s);
+void launch_slide(const View& v, const double* sigma15_dev, int reanchor, hipStream_t s);
+void launch_marginalize(const View& v, int* status, hipStream_t s);
 // AoS <-> AoSoA staging
 void launch_scatter(const double* aos, double* aosoa, long g0, long n, int nf, hipStream_t s);
 void launch_gather(const double* aosoa, double* aos, long g0, long n, int nf, hipStream_t s);

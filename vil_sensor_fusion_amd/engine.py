@@ -131,9 +131,22 @@ class Engine:
     def iterate(self, iterations):
         check(self._l.vf_engine_iterate(self._h, iterations))
 
-    def slide(self, prior_sigma=REFERENCE_PRIOR_SIGMAS):
+    def slide(self, prior_sigma=REFERENCE_PRIOR_SIGMAS, marginalize=True):
+        """Fixed-lag slide by one keyframe; marginalize=False re-anchors tight priors instead."""
         s = np.ascontiguousarray(prior_sigma, dtype=np.float64)
-        check(self._l.vf_engine_slide(self._h, _d(s)))
+        check(self._l.vf_engine_slide(self._h, _d(s), int(marginalize)))
+
+    def marginalize(self):
+        check(self._l.vf_engine_marginalize(self._h))
+
+    def drop_oldest(self):
+        check(self._l.vf_engine_drop_oldest(self._h))
+
+    def read_marginal(self, window):
+        on = C.c_int()
+        x, L, eta = np.zeros((3, 16)), np.zeros((27, 27)), np.zeros(27)
+        check(self._l.vf_engine_read_marginal(self._h, window, C.byref(on), _d(x), _d(L), _d(eta)))
+        return dict(on=on.value, xbar=x, L=L, eta=eta)
 
     def predict(self, window, k0, n):
         check(self._l.vf_engine_predict(self._h, window, k0, n))

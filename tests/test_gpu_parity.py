@@ -141,3 +141,23 @@ def test_lm_trajectory_parity(setup, oracle):
         assert abs(lm["cost"] - costs[-1]) <= 1e-6 * max(costs[-1], 1e-12)
         gt_ate, _ = helpers.ate(xs, synth.make_sequence(w, N).gt_states)
         print("   ATE vs ground truth", gt_ate)
+
+
+@pytest.mark.parametrize("n,iters", [(1000, 5), (10000, 3)])
+def test_full_size_windows_vs_oracle(oracle, n, iters):
+    """BASELINE.json configs at full size: the 1000-pose window the metric is quoted on and the
+    10 000-pose global smoother (here on one GPU), LM trajectory against the oracle."""
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    seq = synth.make_sequence(seed=5, n_kf=n)
+    prob = helpers.build_problem(oracle, seq)
+    eng = Engine(EngineOpts(windows=1, capacity=n))
+    helpers.load_engine(eng, 0, prob)
+    eng.iterate(iters)
+    win = helpers.oracle_window(oracle, prob)
+    costs, acc, _ = win.lm(iterations=iters)
+    ate, rot = helpers.ate(eng.get_states(0, 0, n), win.states)
+    lm = eng.read_lm(0)
+    print(f"N={n}: ATE {ate:.3e} m rot {rot:.3e} rad; cost gpu {lm['cost']:.6e} oracle {costs[-1]:.6e}; "
+          f"accepted gpu {lm['accepted']} oracle {int(acc.sum())}")
+    assert ate <= 1e-6 and rot <= 1e-6
+    assert lm["solve_failures"] == 0

@@ -143,6 +143,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.hi, (size_t)v.B);
     AL(v.sel, (size_t)v.B);
     AL(v.fail, (size_t)v.B);
+    AL(v.fresh, (size_t)v.B);
     AL(v.lambda, (size_t)v.B);
     AL(v.cost, (size_t)v.B);
     AL(v.n_acc, (size_t)v.B);
@@ -341,6 +342,8 @@ int vf_engine_get_imu(vf_engine* e, int window, int k0, int n, double* rec) {
 int vf_engine_linearize(vf_engine* e, int which) {
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     which = which ? 1 : 0;
+    // a new linearisation of the CURRENT states invalidates H, g
+    if (!which) HIPCHK(hipMemsetAsync(e->v.fresh, 0x01, e->v.B * sizeof(int), e->stream));
     vf::launch_linearize_imu(e->v, which, e->stream);
     vf::launch_linearize_between(e->v, which, e->stream);
     vf::launch_linearize_prior(e->v, which, e->stream);
@@ -568,6 +571,8 @@ int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms) {
         }
     };
     if (stage < VF_STAGE_LINEARIZE_IMU || stage > VF_STAGE_DECIDE) return fail(VF_ERR_INVALID, "unknown stage %d", stage);
+    // time the full-work form of K3 (inside iterate() it is skipped for windows whose last trial was rejected)
+    if (stage == VF_STAGE_ASSEMBLE) HIPCHK(hipMemsetAsync(e->v.fresh, 0x01, e->v.B * sizeof(int), e->stream));
     run();  // warm
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipEventRecord(e->ev0, e->stream));

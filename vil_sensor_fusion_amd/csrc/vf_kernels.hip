@@ -540,6 +540,9 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
     const int w = (int)(gk0 / v.M), k0 = (int)(gk0 - (long)w * v.M);
     const int lo = v.lo[w], hi = v.hi[w];
     if (k0 + AT <= lo || k0 >= hi) return;   // no active keyframe in this tile (uniform)
+    // a rejected LM trial leaves the current linearisation, hence H and g, unchanged: nothing to do
+    // (k_decide clears `fresh` on reject; accept / init / slide set it)
+    if (!v.fresh[w]) return;
     const int b = v.sel[w];
     const int tid = threadIdx.x;
     const size_t tiles = (size_t)(v.G >> 6);
@@ -1157,9 +1160,11 @@ __global__ void __launch_bounds__(256) k_decide(View v, int init) {
         if (init) {
             v.cost[w] = c;
             v.fail[w] = 0;
+            v.fresh[w] = 1;
         } else {
             const bool ok = (v.fail[w] == 0) && (c < v.cost[w]);
             if (v.fail[w]) v.n_fail[w] += 1;
+            v.fresh[w] = ok ? 1 : 0;
             if (ok) {
                 v.sel[w] ^= 1;
                 v.cost[w] = c;

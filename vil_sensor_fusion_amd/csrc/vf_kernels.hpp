@@ -44,6 +44,7 @@ struct View {
     int* hi;
     int* sel;           // [B] which buffer is current
     int* fail;          // [B] solve failure flag of the current trial
+    int* fresh;         // [B] 1 = the current linearisation changed since H, g were last assembled
     double* lambda;     // [B]
     double* cost;       // [B]
     int* n_acc;         // [B]

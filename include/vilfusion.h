@@ -121,6 +121,10 @@ int vf_engine_drop_oldest(vf_engine* e);
 int vf_engine_slide(vf_engine* e, const double* prior_sigma15, int marginalize);
 int vf_engine_read_marginal(vf_engine* e, int window, int* on, double* xbar48, double* L729, double* eta27);
 int vf_engine_predict(vf_engine* e, int window, int k0, int n); /* states k0..k0+n-1 from k-1 */
+/* Reclaim keyframe slots: move the live keyframes [shift, capacity) of every window down to slot 0
+ * (states, factor records, linearisations, between sources, ranges, prior keys).  shift must be
+ * a multiple of 64 and <= every window's lo.  Lets a fixed-lag smoother run indefinitely. */
+int vf_engine_compact(vf_engine* e, int shift);
 int vf_engine_sync(vf_engine* e);
 
 /* ---- read-back (synchronises) ---- */

@@ -227,3 +227,57 @@ def test_graph_manager_fixed_lag_marginalises(oracle):
     dpos = np.linalg.norm(tf - tl)
     print("fixed-lag (24) vs full-history smoother, last pose difference [m]:", dpos)
     assert dpos < 5e-3
+
+
+def test_engine_compaction_preserves_the_problem(oracle):
+    """vf_engine_compact moves the live keyframes down by whole AoSoA tiles; solving after the
+    move gives bitwise the same states as solving without it."""
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    seq = synth.make_sequence(45, 200)
+    prob = helpers.build_problem(oracle, seq, perturb=0.01)
+    lo, hi = 70, 190
+    outs = []
+    for compact in (False, True):
+        eng = Engine(EngineOpts(windows=2, capacity=256))
+        for w in range(2):
+            q = dict(prob); q["prior"] = synth.prior_record(prob["states"][lo], REFERENCE_PRIOR_SIGMAS)
+            helpers.load_engine(eng, w, q, lo=lo, hi=hi - 5 * w)
+        eng.iterate(2)
+        eng.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)     # a marginal prior must survive the move too
+        shift = 0
+        if compact:
+            shift = 64
+            eng.compact(shift)
+        eng.iterate(3)
+        outs.append(eng.get_states(0, lo + 1 - shift, hi - lo))
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_graph_manager_runs_past_its_capacity_with_a_lag():
+    """lag mode + compaction: 330 keyframes through a 192-slot GraphManager give the same final
+    state as through a 512-slot one (no compaction needed there)."""
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    n = 330
+    seq = synth.make_sequence(46, n)
+    traj_t = synth.IMU_PHASE + np.arange(0, int((seq.kf_time[-1] + 0.5) * synth.IMU_RATE)) / synth.IMU_RATE
+    traj = synth.Trajectory(seq.seed, seq.kf_time[-1] + 1.0)
+    rng = np.random.default_rng([seq.seed, 0xBEEF])
+    acc = traj.specific_force(traj_t) + rng.normal(size=(traj_t.size, 3)) * synth.IMU_NOISE
+    gyr = traj.body_rate(traj_t) + rng.normal(size=(traj_t.size, 3)) * synth.IMU_NOISE
+    finals = []
+    for cap in (512, 192):
+        gm = GraphManager(capacity=cap, iterations=3, lag=40)
+        i_imu = 0
+        for k in range(1, n):
+            while i_imu < traj_t.size and traj_t[i_imu] <= seq.kf_time[k] + 0.01:
+                gm.addIMUMeasurement(traj_t[i_imu], acc[i_imu], gyr[i_imu]); i_imu += 1
+            assert gm.reserveNode(seq.kf_time[k]) == k
+            for a, b, q, t, c in zip(seq.btw_a, seq.btw_b, seq.btw_q, seq.btw_t, seq.btw_cov):
+                if b == k and a >= 1:
+                    gm.addBetweenFactor(int(a), int(b), (q, t), np.eye(6) * c)
+            if k % 3 == 0:
+                gm.solve()
+        gm.solve()
+        (q, t), v, b = gm.getState()
+        finals.append(np.concatenate([q, t, v, b]))
+    np.testing.assert_array_equal(finals[0], finals[1])

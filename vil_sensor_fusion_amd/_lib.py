@@ -54,7 +54,7 @@ SYMBOLS = [
     "vf_engine_read_delta", "vf_engine_read_panels", "vf_engine_read_lm",
     "vf_engine_time_stage", "vf_engine_time_iterate", "vf_engine_counts",
     "vf_engine_preintegrate", "vf_engine_get_imu",
-    "vf_engine_marginalize", "vf_engine_drop_oldest", "vf_engine_read_marginal",
+    "vf_engine_marginalize", "vf_engine_drop_oldest", "vf_engine_read_marginal", "vf_engine_compact",
     "vf_graph_default_opts", "vf_create", "vf_destroy", "vf_add_imu", "vf_reserve_node",
     "vf_add_between", "vf_solve", "vf_get_state", "vf_get_bias", "vf_most_recent_pose_time",
     "vf_set_callback", "vf_graph_staged", "vf_get_trajectory", "vf_get_imu_factor",

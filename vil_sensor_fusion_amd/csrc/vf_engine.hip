@@ -456,6 +456,69 @@ int vf_engine_read_marginal(vf_engine* e, int window, int* on, double* xbar48, d
     return VF_OK;
 }
 
+// Move the live keyframes [shift, M) of every window to [0, M - shift): frees `shift` slots at the
+// end.  shift must be a multiple of 64 (whole AoSoA tiles) and <= every window's lo.
+int vf_engine_compact(vf_engine* e, int shift) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    vf::View& v = e->v;
+    if (shift <= 0 || shift % 64 != 0 || shift >= v.M) return fail(VF_ERR_INVALID, "shift must be a positive multiple of 64 below the capacity");
+    for (int w = 0; w < v.B; w++)
+        if (e->h_lo[w] < shift) return fail(VF_ERR_BAD_KEY, "window %d: lo %d < shift %d (live keyframes would be lost)", w, e->h_lo[w], shift);
+    const size_t keepk = (size_t)(v.M - shift);              // slots kept per window
+    // staging buffer: the largest per-window segment moved at once (imu_out tiles)
+    const size_t seg_max = (keepk / 64) * vf::IMU_OUT * 64;
+    int rc = e->ensure_stage(seg_max * sizeof(double));
+    if (rc) return rc;
+    auto move = [&](double* base, size_t per_slot_window_stride, size_t src_off, size_t n) -> int {
+        // base + w*stride + src_off  ->  base + w*stride, n doubles, via the staging buffer
+        for (int w = 0; w < v.B; w++) {
+            double* dst = base + (size_t)w * per_slot_window_stride;
+            vf::launch_shift_copy(dst + src_off, e->stage, (long)n, e->stream);
+            vf::launch_shift_copy(e->stage, dst, (long)n, e->stream);
+        }
+        HIPCHK(hipGetLastError());
+        return VF_OK;
+    };
+    const size_t G = (size_t)v.G, tilesG = G / 64, tilesM = (size_t)v.M / 64, tshift = (size_t)shift / 64;
+    // states: [2][16][G] -> per (buf, comp) plane, per window a run of M doubles
+    for (int bc = 0; bc < 32; bc++)
+        if ((rc = move(v.x + (size_t)bc * G, (size_t)v.M, (size_t)shift, keepk))) return rc;
+    // AoSoA arrays: per window tilesM tiles of nf*64 doubles
+    struct { double* p; int nf; int bufs; } arrs[] = {{v.imu_in, vf::IMU_IN, 1}, {v.imu_out, vf::IMU_OUT, 2},
+                                                       {v.btw_in, vf::BTW_IN, 1}, {v.btw_out, vf::BTW_OUT, 2}};
+    for (auto& a : arrs)
+        for (int bf = 0; bf < a.bufs; bf++) {
+            const size_t tile = (size_t)a.nf * 64;
+            if ((rc = move(a.p + (size_t)bf * tilesG * tile, tilesM * tile, tshift * tile, (tilesM - tshift) * tile))) return rc;
+        }
+    // between-factor source indices: move (as raw 4-byte ints, staged through the double buffer) then rebase
+    {
+        int* stage_i = (int*)e->stage;
+        for (int w = 0; w < v.B; w++) {
+            int* dst = v.btw_a + (size_t)w * v.M;
+            HIPCHK(hipMemcpyAsync(stage_i, dst + shift, keepk * sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(dst, stage_i, keepk * sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+            HIPCHK(hipMemsetAsync(dst + keepk, 0xff, (size_t)shift * sizeof(int), e->stream));
+        }
+        vf::launch_shift_btw_a(v.btw_a, v.G, v.M, shift, e->stream);
+        HIPCHK(hipGetLastError());
+    }
+    // window ranges and prior keys
+    std::vector<int> lo(v.B), hi(v.B), pk(v.B);
+    HIPCHK(hipMemcpyAsync(pk.data(), v.prior_k, v.B * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int w = 0; w < v.B; w++) {
+        e->h_lo[w] -= shift; e->h_hi[w] -= shift;
+        lo[w] = e->h_lo[w]; hi[w] = e->h_hi[w];
+        if (pk[w] >= 0) pk[w] -= shift;
+    }
+    HIPCHK(hipMemcpyAsync(v.lo, lo.data(), v.B * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(v.hi, hi.data(), v.B * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(v.prior_k, pk.data(), v.B * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return VF_OK;
+}
+
 int vf_engine_sync(vf_engine* e) {
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     HIPCHK(hipStreamSynchronize(e->stream));

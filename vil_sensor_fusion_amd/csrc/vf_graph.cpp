@@ -80,7 +80,8 @@ struct vf_graph {
     std::mutex state_mutex;
     double state[16] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t solved_key = 0;  // keys [0, solved_key] hold states on the device
-    int lo = 0;
+    int lo = 0;               // slot of the oldest keyframe in the window
+    uint64_t key_base = 0;    // slot = key - key_base (advances by multiples of 64 on compaction)
     std::vector<std::pair<vf_callback, void*>> callbacks;
 };
 
@@ -196,7 +197,8 @@ static void cut_imu_segment(vf_graph* g, double start, double end, std::vector<d
 int vf_reserve_node(vf_graph* g, double time, uint64_t* key_out) {
     if (!g || !key_out) return gerr(VF_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(g->graph_mutex);  // GraphManager.cpp:54
-    if ((int)(g->current_key + 1) >= g->opts.capacity) return gerr(VF_ERR_CAPACITY, "keyframe capacity %d exhausted", g->opts.capacity);
+    if (g->opts.lag == 0 && (int)(g->current_key + 1) >= g->opts.capacity)
+        return gerr(VF_ERR_CAPACITY, "keyframe capacity %d exhausted (unbounded history; set a lag to smooth indefinitely)", g->opts.capacity);
     double start;
     if (g->current_key + 1 > 1) {
         start = g->last_pose_time;  // :59-61
@@ -281,11 +283,20 @@ int vf_solve(vf_graph* g) {
     }
     std::lock_guard<std::mutex> sl(g->state_mutex);  // :117
     int rc;
+    // fixed-lag mode: reclaim slots below the window when the new keyframes would not fit
+    if (g->opts.lag > 0 && (int)(last_key - g->key_base) + 1 > g->opts.capacity) {
+        const int shift = (g->lo / 64) * 64;
+        if (shift <= 0) return gerr(VF_ERR_CAPACITY, "capacity %d too small for lag %d plus the keyframes added per solve", g->opts.capacity, g->opts.lag);
+        if ((rc = vf_engine_compact(g->eng, shift))) return rc;
+        g->lo -= shift;
+        g->key_base += shift;
+        if ((int)(last_key - g->key_base) + 1 > g->opts.capacity) return gerr(VF_ERR_CAPACITY, "capacity %d exhausted even after compaction", g->opts.capacity);
+    }
     if (!imus.empty()) {
         // K0 on the device for all queued factors, then the initial values by IMU prediction
         // (GraphManager.cpp:150-160).  Keys are consecutive by construction.
         const int n = (int)imus.size();
-        const uint64_t k0 = imus.front().key;
+        const uint64_t k0 = imus.front().key - g->key_base;
         std::vector<int32_t> off(n + 1, 0);
         std::vector<double> steps, bias((size_t)n * 6);
         for (int i = 0; i < n; i++) {
@@ -305,26 +316,27 @@ int vf_solve(vf_graph* g) {
         for (size_t i = 1; i < order.size(); i++)
             for (size_t j = i; j > 0 && betweens[order[j]].b < betweens[order[j - 1]].b; j--) std::swap(order[j], order[j - 1]);
         for (size_t i = 0; i < order.size(); i++) {
-            a[i] = (int32_t)betweens[order[i]].a;
-            b[i] = (int32_t)betweens[order[i]].b;
+            a[i] = (int32_t)(betweens[order[i]].a - g->key_base);
+            b[i] = (int32_t)(betweens[order[i]].b - g->key_base);
             memcpy(&rec[i * VF_BTW_RECORD], betweens[order[i]].rec, sizeof(double) * VF_BTW_RECORD);
         }
         if ((rc = vf_engine_set_between(g->eng, 0, (int)a.size(), a.data(), b.data(), rec.data()))) return rc;
     }
     // fixed-lag window: marginalise the keyframes that fall out of the lag, one at a time, at the
     // linearisation of the previous solve (their factors have not changed since)
+    const int last_slot = (int)(last_key - g->key_base);
     int lo = g->lo;
-    while (g->opts.lag > 0 && (int)last_key + 1 - lo > g->opts.lag && (int)g->solved_key - lo >= 3) {
+    while (g->opts.lag > 0 && last_slot + 1 - lo > g->opts.lag && (int)(g->solved_key - g->key_base) - lo >= 3) {
         if ((rc = vf_engine_marginalize(g->eng))) return rc;
         if ((rc = vf_engine_drop_oldest(g->eng))) return rc;
         lo++;
     }
     g->lo = lo;
-    if ((rc = vf_engine_set_range(g->eng, 0, lo, (int)last_key + 1))) return rc;
+    if ((rc = vf_engine_set_range(g->eng, 0, lo, last_slot + 1))) return rc;
     if ((rc = vf_engine_iterate(g->eng, g->opts.iterations))) return rc;   // ISAM2::update + calculateEstimate
     int fails = 0;
     if ((rc = vf_engine_read_lm(g->eng, 0, nullptr, nullptr, nullptr, nullptr, &fails))) return rc;
-    if ((rc = vf_engine_get_states(g->eng, 0, (int)last_key, 1, g->state))) return rc;  // :131-133
+    if ((rc = vf_engine_get_states(g->eng, 0, last_slot, 1, g->state))) return rc;  // :131-133
     g->solved_key = last_key;
     for (auto& cb : g->callbacks)  // :135-138, on the solving thread, inside _stateMutex
         cb.first(cb.second, last_time, g->state, g->state + 4, g->state + 7, g->state + 10);
@@ -349,14 +361,15 @@ int vf_get_trajectory(vf_graph* g, uint64_t key0, int n, double* state16) {
     if (!g || !state16) return gerr(VF_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(g->state_mutex);
     if (n < 0 || key0 + (uint64_t)n > g->solved_key + 1) return gerr(VF_ERR_BAD_KEY, "keys [%llu, %llu) not solved yet", (unsigned long long)key0, (unsigned long long)(key0 + n));
-    return vf_engine_get_states(g->eng, 0, (int)key0, n, state16);
+    if (key0 < g->key_base) return gerr(VF_ERR_BAD_KEY, "key %llu has been compacted away (oldest retained key %llu)", (unsigned long long)key0, (unsigned long long)g->key_base);
+    return vf_engine_get_states(g->eng, 0, (int)(key0 - g->key_base), n, state16);
 }
 
 int vf_get_imu_factor(vf_graph* g, uint64_t key, double* rec190) {
     if (!g || !rec190) return gerr(VF_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(g->state_mutex);
-    if (key < 1 || key > g->solved_key) return gerr(VF_ERR_BAD_KEY, "imu factor %llu not on the device yet", (unsigned long long)key);
-    return vf_engine_get_imu(g->eng, 0, (int)key, 1, rec190);
+    if (key < 1 || key > g->solved_key || key < g->key_base + 1) return gerr(VF_ERR_BAD_KEY, "imu factor %llu not on the device", (unsigned long long)key);
+    return vf_engine_get_imu(g->eng, 0, (int)(key - g->key_base), 1, rec190);
 }
 
 }  // extern "C"

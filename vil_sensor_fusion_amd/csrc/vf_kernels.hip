@@ -1346,6 +1346,25 @@ __global__ void k_slide(View v, const double* sigma15, int reanchor) {
     for (int c = 0; c < 15; c++) pin[16 + c] = sigma15[c];
 }
 
+// ------------------------------------------------------------------------------------ compaction
+// Shift the live part of every window down by `shift` slots (a multiple of 64, so AoSoA tiles
+// move whole).  Source and destination ranges of a window may overlap, hence the staging copy
+// through `tmp` (sized for one array at a time by the host).  Element e of a per-window array
+// with `per` doubles (or ints) per slot-tile unit.
+__global__ void k_shift_copy(const double* __restrict__ src, double* __restrict__ dst, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+__global__ void k_shift_btw_a(int* a, long G, int M, int shift) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const int k = (int)(g % M);
+    // after the move, slot k holds what was in slot k + shift; indices of `a` drop by shift
+    const int v0 = a[g];
+    (void)k;
+    a[g] = v0 >= shift ? v0 - shift : -1;
+}
+
 // ------------------------------------------------------------------------------------ staging
 __global__ void k_scatter(const double* aos, double* aosoa, long g0, long n, int nf) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1417,6 +1436,12 @@ void launch_slide(const View& v, const double* sigma15_dev, int reanchor, hipStr
 }
 void launch_marginalize(const View& v, int* status, hipStream_t s) {
     hipLaunchKernelGGL(k_marginalize, dim3(v.B), dim3(64), 0, s, v, status);
+}
+void launch_shift_copy(const double* src, double* dst, long n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_shift_copy, dim3(nblk(n, 256)), dim3(256), 0, s, src, dst, n);
+}
+void launch_shift_btw_a(int* a, long G, int M, int shift, hipStream_t s) {
+    hipLaunchKernelGGL(k_shift_btw_a, dim3(nblk(G, 256)), dim3(256), 0, s, a, G, M, shift);
 }
 void launch_scatter(const double* aos, double* aosoa, long g0, long n, int nf, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_scatter, dim3(nblk(n * nf, 256)), dim3(256), 0, s, aos, aosoa, g0, n, nf);

@@ -67,6 +67,8 @@ void launch_decide(const View& v, int init, hipStream_t s);
 void launch_predict(const View& v, int window, int k0, int n, hipStream_t s);
 void launch_slide(const View& v, const double* sigma15_dev, int reanchor, hipStream_t s);
 void launch_marginalize(const View& v, int* status, hipStream_t s);
+void launch_shift_copy(const double* src, double* dst, long n, hipStream_t s);
+void launch_shift_btw_a(int* a, long G, int M, int shift, hipStream_t s);
 // AoS <-> AoSoA staging
 void launch_scatter(const double* aos, double* aosoa, long g0, long n, int nf, hipStream_t s);
 void launch_gather(const double* aosoa, double* aos, long g0, long n, int nf, hipStream_t s);

@@ -136,6 +136,9 @@ class Engine:
         s = np.ascontiguousarray(prior_sigma, dtype=np.float64)
         check(self._l.vf_engine_slide(self._h, _d(s), int(marginalize)))
 
+    def compact(self, shift):
+        check(self._l.vf_engine_compact(self._h, shift))
+
     def marginalize(self):
         check(self._l.vf_engine_marginalize(self._h))
 

@@ -963,8 +963,13 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
         if (lane >= 15 && lane < 58 && k < n) {
             d2_t* Lk = (d2_t*)(Lbase + (size_t)k * PANEL + (size_t)(lane - 15) * PSTR);
 #pragma unroll
+#ifdef VF_K4_NT
             for (int c = 0; c < 7; c++) { d2_t t; t.x = p[2 * c]; t.y = p[2 * c + 1]; __builtin_nontemporal_store(t, Lk + c); }
             d2_t t; t.x = p[14]; t.y = 0.0; __builtin_nontemporal_store(t, Lk + 7);
+#else
+            for (int c = 0; c < 7; c++) { d2_t t; t.x = p[2 * c]; t.y = p[2 * c + 1]; Lk[c] = t; }
+            d2_t t; t.x = p[14]; t.y = 0.0; Lk[7] = t;
+#endif
         }
         WSYNC();
         STAMP(3);

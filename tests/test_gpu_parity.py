@@ -161,3 +161,30 @@ def test_full_size_windows_vs_oracle(oracle, n, iters):
           f"accepted gpu {lm['accepted']} oracle {int(acc.sum())}")
     assert ate <= 1e-6 and rot <= 1e-6
     assert lm["solve_failures"] == 0
+
+
+@pytest.mark.parametrize("extra_windows", [0, 300])
+def test_both_solver_forms_vs_oracle(oracle, extra_windows):
+    """The band solver has two forms: two waves per window from both ends (used for <= 256
+    windows) and one wave per window (more windows).  Empty extra windows select the second."""
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    n = 333                                   # not a multiple of 4: pads on the reverse sweep
+    seq = synth.make_sequence(seed=9, n_kf=n)
+    prob = helpers.build_problem(oracle, seq, perturb=0.01)
+    eng = Engine(EngineOpts(windows=1 + extra_windows, capacity=n + 3))
+    helpers.load_engine(eng, 0, prob)
+    eng.linearize(0); eng.assemble(); eng.solve()
+    H, g = eng.read_normal(0, 0, n)
+    d = eng.read_delta(0, 0, n)
+    rc, do = oracle.band_solve(H, g, 1e-5)
+    Hl, gl = H.astype(np.longdouble), g.astype(np.longdouble)
+    bg = float(np.abs(band_matvec(Hl, np.longdouble(1e-5), d.astype(np.longdouble)) + gl).max() / np.abs(gl).max())
+    bo = float(np.abs(band_matvec(Hl, np.longdouble(1e-5), do.astype(np.longdouble)) + gl).max() / np.abs(gl).max())
+    print(f"extra={extra_windows}: backward error gpu {bg:.3e} oracle {bo:.3e} forward diff {relerr(d, do):.3e}")
+    assert bg < 1e-9 and bg < 50 * bo + 1e-13 and relerr(d, do) < 1e-3
+    eng.iterate(5)
+    win = helpers.oracle_window(oracle, prob)
+    win.lm(iterations=5)
+    ate, rot = helpers.ate(eng.get_states(0, 0, n), win.states)
+    assert ate <= 1e-6 and rot <= 1e-6
+    assert eng.read_lm(0)["solve_failures"] == 0

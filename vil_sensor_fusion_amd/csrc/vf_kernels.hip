@@ -796,14 +796,35 @@ __device__ unsigned long long g_stamps[16];
 #endif
 template <int N> struct IC { static constexpr int value = N; };
 
-__global__ void __launch_bounds__(64) k_band_solve(View v) {
-    const int w = blockIdx.x, lane = threadIdx.x;
+// TW = false: one wave sweeps the whole window (throughput form, one window per SIMD).
+// TW = true : burn-at-both-ends (twisted) factorisation for one-window latency: wave 0 eliminates
+//   keyframes 0 .. t-1 forwards, wave 1 eliminates n-1 .. t+3 backwards (the same code on the
+//   reversed sequence: block d of reversed row j is H[j+d][d]^T), they meet at a dense 45x45 system
+//   for keyframes t, t+1, t+2, and the two back substitutions run concurrently.  No extra flops.
+constexpr int MID_LD = 47;                      // 45 columns + rhs + pad
+constexpr int MID_TOTAL = 45 * MID_LD + 48;     // + the 45 solved increments handed to both waves
+template <bool TW>
+__device__ __forceinline__ void band_solve_body(const View& v, double* __restrict__ S, double* __restrict__ S_other,
+                                                double* __restrict__ MID, const int w, const int lane, const int wave) {
     const int lo = v.lo[w], hi = v.hi[w], n = hi - lo;
-    if (n <= 0) return;
-    __shared__ double S[S_TOTAL];
     const double lam = v.lambda[w];
     const size_t base = (size_t)w * v.M + lo;
     int failed = 0;
+    // sweep geometry: sweep index kk -> window keyframe j(kk); kinds of rows: 0 real, 1 identity, 2 zero
+    const bool rev = TW && wave == 1;
+    const int tsp = TW ? (((n - 3) / 2) & ~3) : 0;                 // split keyframe (multiple of 4)
+    const int cr = TW ? n - tsp - 3 : 0;                            // pivots of the reverse sweep
+    const int qpad = TW ? ((4 - (cr & 3)) & 3) : 0;                 // identity pads in front of it
+    const int cnt = !TW ? ((n + 3) & ~3) : (rev ? cr + qpad : tsp); // pivots of this sweep (multiple of 4)
+    auto row_kind = [=](int kk) {
+        if (!TW) return kk < n ? 0 : 1;
+        if (!rev) return kk < tsp + 3 ? 0 : 1;
+        if (kk < qpad) return 1;
+        const int j = n - 1 - (kk - qpad);
+        return j >= tsp + 3 ? 0 : (j >= tsp ? 2 : 1);
+    };
+    auto kf_of = [=](int kk) { return rev ? n - 1 - (kk - qpad) : kk; };   // window-local keyframe of a real row
+    auto pivot_real = [=](int kk) { return !TW ? kk < n : (rev ? kk >= qpad : true); };
 
     // ---- per-lane constants.  Every LDS access below is branch-free: masked-off lanes read the
     // zero cells / write the sink, so no exec-mask juggling (and no SGPR spills) in the k loop.
@@ -846,7 +867,7 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
         op1[q] = (kc < 15 && 31 + (lane & 15) <= 42) ? S_P + (16 + (lane & 15)) * 15 + kc : S_ZERO;
     }
     // block-row commit map: idx = lane + 64 j over a 15x15 block -> (a, c); diagonal gets +lambda
-    int cm_off[4];
+    int cm_off[4], cm_srcT[4];
     double cm_lam[4], cm_one[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -855,18 +876,20 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
         cm_off[j] = in ? a * LDW + c : -1;
         cm_lam[j] = (in && a == c) ? lam : 0.0;
         cm_one[j] = (in && a == c) ? 1.0 : 0.0;
+        cm_srcT[j] = in ? c * 15 + a : 0;            // transposed read for the reverse sweep
     }
-    int cp_off[2], cp_src[2];                        // 6x15 pose-row strips of the d = 2,3 blocks
+    int cp_off[2], cp_src[2], cp_srcT[2];            // 6x15 pose-row strips of the d = 2,3 blocks
     double cp_pose[2], cp_rest[2];
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         const int e = lane + 64 * it, a = e / 15, c = e - a * 15;
         cp_off[it] = e < 90 ? a * LDW + c : -1;
         cp_src[it] = e < 90 ? a * 15 + c : 0;
+        cp_srcT[it] = (e < 90 && c < 6) ? c * 15 + a : 0;   // reverse sweep: pose x pose block, transposed
         cp_pose[it] = (e < 90 && c < 6) ? 1.0 : 0.0;    // pose x pose part (between factors)
         cp_rest[it] = (e < 90 && c >= 6) ? 1.0 : 0.0;   // columns 6..14: only the marginal prior fills them
     }
-    const double mp_third = (v.mp_on[w] && n >= 3) ? 1.0 : 0.0;
+    const double mp_third = (v.mp_on[w] && n >= 3 && !rev) ? 1.0 : 0.0;
     WSYNC();
 
     // ---- H block row prefetch (HBM -> registers) and commit (registers -> LDS slot) ---------
@@ -878,30 +901,55 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
     double* __restrict__ dbase = v.delta + base * 15;
     auto fetch_row = [=](int kk) {
         HRow r;
-        const bool real = kk < n;
-        const double* Hk = Hbase + (size_t)(real ? kk : 0) * HROW;
+        const bool real = row_kind(kk) == 0;
+        if (!rev) {
+            const double* Hk = Hbase + (size_t)(real ? kk : 0) * HROW;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const bool in = real && lane + 64 * j < 225;
-            r.h0[j] = in ? Hk[lane + 64 * j] : 0.0;
-            r.h1[j] = (in && kk >= 1) ? Hk[225 + lane + 64 * j] : 0.0;
-        }
+            for (int j = 0; j < 4; j++) {
+                const bool in = real && lane + 64 * j < 225;
+                r.h0[j] = in ? Hk[lane + 64 * j] : 0.0;
+                r.h1[j] = (in && kk >= 1) ? Hk[225 + lane + 64 * j] : 0.0;
+            }
 #pragma unroll
-        for (int it = 0; it < 2; it++) {
-            const bool in = real && cp_off[it] >= 0;
-            r.h2[it] = (in && kk >= 2) ? Hk[450 + cp_src[it]] : 0.0;
-            r.h3[it] = (in && kk >= 3) ? Hk[675 + cp_src[it]] : 0.0;
+            for (int it = 0; it < 2; it++) {
+                const bool in = real && cp_off[it] >= 0;
+                r.h2[it] = (in && kk >= 2) ? Hk[450 + cp_src[it]] : 0.0;
+                r.h3[it] = (in && kk >= 3) ? Hk[675 + cp_src[it]] : 0.0;
+            }
+            r.hg = (real && lane < 15) ? gbase[(size_t)kk * 15 + lane] : 0.0;   // negated at commit (a use here would stall on vmcnt)
+        } else {
+            // reversed sequence: block d of row j couples j with j+d = H[j+d][d]^T (pose x pose for d >= 2).
+            // Rows t, t+1, t+2 (kind 2) keep only their couplings to the reverse part (j+d >= t+3):
+            // their diagonal blocks, mutual couplings and rhs belong to the forward sweep's window.
+            const int kind = row_kind(kk);
+            const bool has = kind == 0 || kind == 2;
+            const int j = has ? n - 1 - (kk - qpad) : 0, back = kk - qpad;
+            const double* Hj = Hbase + (size_t)j * HROW;
+            const bool l1 = has && back >= 1 && j + 1 >= tsp + 3, l2 = has && back >= 2 && j + 2 >= tsp + 3,
+                       l3 = has && back >= 3 && j + 3 >= tsp + 3;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const bool in = lane + 64 * jj < 225;
+                r.h0[jj] = (in && real) ? Hj[lane + 64 * jj] : 0.0;
+                r.h1[jj] = (in && l1) ? Hj[HROW + 225 + cm_srcT[jj]] : 0.0;
+            }
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const bool in = cp_off[it] >= 0 && cp_pose[it] > 0.0;
+                r.h2[it] = (in && l2) ? Hj[2 * HROW + 450 + cp_srcT[it]] : 0.0;
+                r.h3[it] = (in && l3) ? Hj[3 * HROW + 675 + cp_srcT[it]] : 0.0;
+            }
+            r.hg = (real && lane < 15) ? gbase[(size_t)j * 15 + lane] : 0.0;
         }
-        r.hg = (real && lane < 15) ? gbase[(size_t)kk * 15 + lane] : 0.0;   // negated at commit (a use here would stall on vmcnt)
         return r;
     };
-    auto commit_row = [&](auto ph, const HRow r, bool real, int kk) {   // keyframe kk with kk & 3 == PH
+    auto commit_row = [&](auto ph, const HRow r, int kind, int kk) {   // sweep row kk with kk & 3 == PH
         constexpr int PH = decltype(ph)::value;
         constexpr int s = PH * 15, c1 = ((PH + 3) & 3) * 15, c2 = ((PH + 2) & 3) * 15, c3 = ((PH + 1) & 3) * 15;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const bool in = cm_off[j] >= 0;
-            const double d0 = r.h0[j] + (real ? cm_lam[j] : cm_one[j]);
+            const double d0 = r.h0[j] + (kind == 0 ? cm_lam[j] : (kind == 1 ? cm_one[j] : 0.0));
             S[in ? S_WD + s * LDW + s + cm_off[j] : S_DUMP + 32 + lane] = d0;
             S[in ? S_WD + s * LDW + c1 + cm_off[j] : S_DUMP + 32 + lane] = r.h1[j];
         }
@@ -915,12 +963,12 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
         }
         S[lane < 15 ? S_GD + s + lane : S_DUMP + 32 + lane] = -r.hg;
     };
-    commit_row(IC<0>{}, fetch_row(0), 0 < n, 0);
-    commit_row(IC<1>{}, fetch_row(1), 1 < n, 1);
-    commit_row(IC<2>{}, fetch_row(2), 2 < n, 2);
-    commit_row(IC<3>{}, fetch_row(3), 3 < n, 3);
+    commit_row(IC<0>{}, fetch_row(0), row_kind(0), 0);
+    commit_row(IC<1>{}, fetch_row(1), row_kind(1), 1);
+    commit_row(IC<2>{}, fetch_row(2), row_kind(2), 2);
+    commit_row(IC<3>{}, fetch_row(3), row_kind(3), 3);
     WSYNC();
-    const int n4 = (n + 3) & ~3;   // steps beyond n eliminate identity rows (no effect); saves remainder copies
+    const int n4 = cnt;   // pivots of this sweep; identity rows beyond the real ones are eliminated harmlessly
 
 #ifdef VF_SOLVE_STAMPS
     unsigned long long st[16] = {0}, tprev = __builtin_amdgcn_s_memtime();
@@ -960,8 +1008,8 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
         // sub-panel + rhs -> LDS (MFMA operands); rows 15..57 -> HBM, one 128-B line per lane
 #pragma unroll
         for (int c = 0; c < 15; c++) S[pw_off + c] = p[c];
-        if (lane >= 15 && lane < 58 && k < n) {
-            d2_t* Lk = (d2_t*)(Lbase + (size_t)k * PANEL + (size_t)(lane - 15) * PSTR);
+        if (lane >= 15 && lane < 58 && pivot_real(k)) {
+            d2_t* Lk = (d2_t*)(Lbase + (size_t)kf_of(k) * PANEL + (size_t)(lane - 15) * PSTR);
 #pragma unroll
 #ifdef VF_K4_NT
             for (int c = 0; c < 7; c++) { d2_t t; t.x = p[2 * c]; t.y = p[2 * c + 1]; __builtin_nontemporal_store(t, Lk + c); }
@@ -995,7 +1043,7 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
         }
         WSYNC();
         STAMP(4);
-        commit_row(ph, pend, k + 4 < n, k + 4);  // keyframe k+4 takes the slot the pivot keyframe frees
+        commit_row(ph, pend, row_kind(k + 4), k + 4);  // row k+4 takes the slot the pivot keyframe frees
         pend = ahead;
         WSYNC();
         STAMP(5);
@@ -1016,10 +1064,65 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
     // Lane r < 43 holds row r in registers; rows 0..27 go through LDS for the column sums,
     // L^-T stays in the registers of lanes 28..42.  Panels are prefetched two steps ahead.
     S[S_DL + lane] = 0.0;
+    if constexpr (TW) {
+        __syncthreads();   // both forward sweeps done; their trailing windows are in S (left) / S_other
+        if (wave == 0) {
+            // dense 45x45 system of keyframes t, t+1, t+2 = left window (original H of these rows +
+            // left Schur terms) + right window (Schur terms only: its rows were committed as zeros,
+            // reversed order => transposed blocks).  Only regions that are written are read.
+            const int sR[3] = {((qpad + n - 1 - tsp) & 3) * 15, ((qpad + n - 2 - tsp) & 3) * 15, ((qpad + n - 3 - tsp) & 3) * 15};
+            for (int e = lane; e < 45 * 46; e += 64) {
+                const int i = e / 46, jc = e - i * 46;
+                const int oi = i / 15, ai = i - oi * 15;
+                double val;
+                if (jc == 45) {
+                    val = S[S_GD + oi * 15 + ai] + S_other[S_GD + sR[oi] + ai];
+                } else {
+                    const int hi_i = i >= jc ? i : jc, lo_i = i >= jc ? jc : i;     // symmetric: fill both triangles
+                    const int oa = hi_i / 15, a = hi_i - oa * 15, ob = lo_i / 15, bb = lo_i - ob * 15;
+                    double vl = 0.0, vr = 0.0;
+                    if (oa - ob < 2 || a < 6) vl = S[S_WD + (oa * 15 + a) * LDW + ob * 15 + bb];
+                    // right window: row = keyframe with the larger sweep index = the smaller keyframe (ob)
+                    if (oa == ob) vr = S_other[S_WD + (sR[oa] + a) * LDW + sR[oa] + bb];
+                    else if (oa - ob == 1 || bb < 6) vr = S_other[S_WD + (sR[ob] + bb) * LDW + sR[oa] + a];
+                    val = vl + vr;
+                }
+                MID[i * MID_LD + jc] = val;
+            }
+            WSYNC();
+            for (int c = 0; c < 45; c++) {       // Gaussian elimination (SPD: no pivoting), entry-parallel
+                const double piv = MID[c * MID_LD + c];
+                if (!(piv > 0.0)) failed = 1;
+                const double inv = 1.0 / piv;
+                const int m = 44 - c;
+                for (int e = lane; e < m * (m + 1); e += 64) {
+                    const int i = c + 1 + e / (m + 1), jc = c + 1 + (e - (e / (m + 1)) * (m + 1));
+                    MID[i * MID_LD + jc] -= MID[i * MID_LD + c] * inv * MID[c * MID_LD + jc];
+                }
+                WSYNC();
+            }
+            for (int i = 44; i >= 0; i--) {      // back substitution on the upper triangle
+                const double xi = MID[i * MID_LD + 45] / MID[i * MID_LD + i];
+                if (lane < i) MID[lane * MID_LD + 45] -= MID[lane * MID_LD + i] * xi;
+                if (lane == 0) MID[45 * MID_LD + i] = xi;
+                WSYNC();
+            }
+            if (lane < 45) dbase[(size_t)tsp * 15 + lane] = MID[45 * MID_LD + lane];
+        }
+        __syncthreads();
+        // increments of the keyframes just beyond this sweep's last pivot, in its own slot order
+        if (!rev) {          // rows t (15), t+1, t+2 at sweep indices tsp, tsp+1, tsp+2 (tsp % 4 == 0)
+            if (lane < 45) S[S_DL + lane] = MID[45 * MID_LD + lane];
+        } else {             // sweep indices cnt, cnt+1, cnt+2 <-> keyframes t+2, t+1, t
+            if (lane < 45) { const int o = lane / 15, a = lane - o * 15; S[S_DL + ((cnt + o) & 3) * 15 + a] = MID[45 * MID_LD + (2 - o) * 15 + a]; }
+        }
+        WSYNC();
+    }
     struct PRow { d2_t x[8]; };
-    auto load_panel = [=](int k) {   // k >= n or k < 0: any valid panel is loaded and zeroed at use (no use here: no stall)
+    auto load_panel = [=](int k) {   // not a real pivot: any valid panel is loaded and zeroed at use (no use here: no stall)
         PRow r;
-        const d2_t* Lk = (const d2_t*)(Lbase + (size_t)((k < n && k >= 0) ? k : 0) * PANEL + (size_t)(lane < 43 ? lane : 0) * PSTR);
+        const bool ok = k >= 0 && k < cnt && pivot_real(k);
+        const d2_t* Lk = (const d2_t*)(Lbase + (size_t)(ok ? kf_of(k) : 0) * PANEL + (size_t)(lane < 43 ? lane : 0) * PSTR);
 #pragma unroll
         for (int c = 0; c < 8; c++) r.x[c] = Lk[c];
         return r;
@@ -1033,7 +1136,7 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
         constexpr int b1 = S_DL + ((PH + 1) & 3) * 15, b2 = S_DL + ((PH + 2) & 3) * 15, b3 = S_DL + ((PH + 3) & 3) * 15;
         STAMP(6);
         double row[15];
-        const double keep = k < n ? 1.0 : 0.0;   // identity tail beyond the window: zero panel
+        const double keep = pivot_real(k) ? 1.0 : 0.0;   // identity rows: zero panel
 #pragma unroll
         for (int c = 0; c < 7; c++) { row[2 * c] = keep * cur_p.x[c].x; row[2 * c + 1] = keep * cur_p.x[c].y; }
         row[14] = keep * cur_p.x[7].x;
@@ -1074,7 +1177,7 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
         STAMP(9);
         WSYNC();
         S[(lane >= 28 && lane < 43) ? S_DL + PH * 15 + lane - 28 : dl_w] = x;
-        if (lane >= 28 && lane < 43 && k < n) dbase[(size_t)k * 15 + lane - 28] = x;
+        if (lane >= 28 && lane < 43 && pivot_real(k)) dbase[(size_t)kf_of(k) * 15 + lane - 28] = x;
         WSYNC();
         STAMP(10);
     };
@@ -1091,8 +1194,32 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
 #ifdef VF_SOLVE_STAMPS
     if (w == 0 && lane == 0) for (int i = 0; i < 16; i++) g_stamps[i] = st[i];
 #endif
-    if (lane == 0) v.fail[w] = failed;
+    if constexpr (TW) { if (lane == 0 && failed) atomicOr(v.fail + w, 1); }
+    else { if (lane == 0) v.fail[w] = failed; }
 }
+
+__global__ void __launch_bounds__(64) k_band_solve(View v) {
+    const int w = blockIdx.x;
+    if (v.hi[w] - v.lo[w] <= 0) return;
+    __shared__ double S[S_TOTAL];
+    band_solve_body<false>(v, S, nullptr, nullptr, w, threadIdx.x, 0);
+}
+
+// two waves per window (see band_solve_body); windows shorter than 32 keyframes are left to wave 0 alone
+__global__ void __launch_bounds__(128) k_band_solve_tw(View v) {
+    const int w = blockIdx.x;
+    const int n = v.hi[w] - v.lo[w];
+    if (n <= 0) return;
+    __shared__ double S2[2 * S_TOTAL];
+    __shared__ double MID[MID_TOTAL];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (n < 32) {
+        if (wave == 0) band_solve_body<false>(v, S2, nullptr, nullptr, w, lane, 0);
+        return;
+    }
+    band_solve_body<true>(v, S2 + wave * S_TOTAL, S2 + (1 - wave) * S_TOTAL, MID, w, lane, wave);
+}
+
 #ifdef VF_SOLVE_STAMPS
 extern "C" int vf_debug_solve_stamps(unsigned long long* out) {
     (void)hipDeviceSynchronize();
@@ -1424,7 +1551,10 @@ void launch_assemble(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_assemble, dim3(nblk(v.G, AT)), dim3(256), 0, s, v);
 }
 void launch_band_solve(const View& v, hipStream_t s) {
-    hipLaunchKernelGGL(k_band_solve, dim3(v.B), dim3(64), 0, s, v);
+    // few windows: two waves per window from both ends (latency); many: one wave per window (throughput)
+    static const int tw_max = getenv("VF_TWISTED_MAX_WINDOWS") ? atoi(getenv("VF_TWISTED_MAX_WINDOWS")) : 256;
+    if (v.B <= tw_max) hipLaunchKernelGGL(k_band_solve_tw, dim3(v.B), dim3(128), 0, s, v);
+    else hipLaunchKernelGGL(k_band_solve, dim3(v.B), dim3(64), 0, s, v);
 }
 void launch_retract(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_retract, dim3(nblk(v.G, 256)), dim3(256), 0, s, v);

@@ -150,3 +150,54 @@ def test_graph_manager_errors():
     gm.solve()
     (q, t), v, b = gm.getState()
     assert abs(np.linalg.norm(q) - 1) < 1e-12
+
+
+def test_graph_manager_is_thread_safe(oracle):
+    """GraphManager.h:4-6: "All public functions are thread-safe".  IMU ingestion from one thread
+    while another reserves nodes / adds factors / solves must give the same result as the same
+    calls made from one thread (the call order per stream is what matters)."""
+    import threading
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    n = 40
+    seq = synth.make_sequence(8, n)
+    traj_t = synth.IMU_PHASE + np.arange(0, int((seq.kf_time[-1] + 0.5) * synth.IMU_RATE)) / synth.IMU_RATE
+    traj = synth.Trajectory(seq.seed, seq.kf_time[-1] + 1.0)
+    acc, gyr = traj.specific_force(traj_t), traj.body_rate(traj_t)
+
+    def run(threaded):
+        gm = GraphManager(capacity=64, iterations=4)
+        fed = [0]
+        cv = threading.Condition()
+
+        def feeder():
+            for i in range(traj_t.size):
+                gm.addIMUMeasurement(traj_t[i], acc[i], gyr[i])
+                with cv:
+                    fed[0] = i + 1
+                    cv.notify_all()
+        th = threading.Thread(target=feeder)
+        if threaded:
+            th.start()
+        else:
+            feeder()
+        for k in range(1, n):
+            need = int(np.searchsorted(traj_t, seq.kf_time[k] + 0.01))
+            with cv:
+                cv.wait_for(lambda: fed[0] >= need)
+            # a node may only see the samples up to `need`: emulate by waiting, then reserving; later
+            # samples that are already buffered are beyond `end` and stay in the deque
+            gm.reserveNode(seq.kf_time[k])
+            for a, b, q, t, c in zip(seq.btw_a, seq.btw_b, seq.btw_q, seq.btw_t, seq.btw_cov):
+                if b == k and a >= 1:
+                    gm.addBetweenFactor(int(a), int(b), (q, t), np.eye(6) * c)
+            if k % 5 == 0:
+                gm.solve()
+        if threaded:
+            th.join()
+        gm.solve()
+        (q, t), v, b = gm.getState()
+        return np.concatenate([q, t, v, b])
+    a, b = run(False), run(True)
+    # with the whole stream pre-fed (a) every reserveNode interpolates with the next sample, exactly
+    # as in the threaded run where the feeder is ahead; the estimates must agree to rounding
+    np.testing.assert_allclose(a, b, rtol=0, atol=1e-9)

@@ -8,4 +8,4 @@ for f in vf_kernels vf_engine vf_degeneracy; do
 done
 wait
 g++ -O2 -std=c++17 -fPIC -c vf_graph.cpp -o build_stamps/vf_graph.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch/libvilfusion_stamps.so build_stamps/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libvilfusion_stamps.so build_stamps/*.o

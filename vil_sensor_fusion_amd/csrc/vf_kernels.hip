@@ -788,7 +788,7 @@ constexpr int S_P = S_ID + 225;          // panel rows 15..42 at stride 15 (conf
 constexpr int S_DL = S_P + 43 * 15;      // back-substitution: delta of the 3 following keyframes
 constexpr int S_TOTAL = S_DL + 64;
 #define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#ifdef VF_SOLVE_STAMPS   // diagnostic build only (scratch/build_stamps.sh); never in the shipped library
+#ifdef VF_SOLVE_STAMPS   // diagnostic build only (tools/build_stamps.sh); never in the shipped library
 __device__ unsigned long long g_stamps[16];
 #define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _t; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); if (w == 0) st[i] += _t - tprev; tprev = _t; } while (0)
 #else

@@ -201,3 +201,27 @@ def test_graph_manager_is_thread_safe(oracle):
     # with the whole stream pre-fed (a) every reserveNode interpolates with the next sample, exactly
     # as in the threaded run where the feeder is ahead; the estimates must agree to rounding
     np.testing.assert_allclose(a, b, rtol=0, atol=1e-9)
+
+
+def test_integration_timeline_on_the_gpu():
+    """IntegrationTest.integrationTest1 (UnitTests.cpp:236-393) through the real GraphManager:
+    staged factors before solve() = 3 priors + 2 between, 4 IMU factors queued; solve() empties
+    both (graph()->size() == 0 afterwards, :385) and yields a finite state at the last key."""
+    from tests.test_sensor_manager import _integration_timeline
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    from vil_sensor_fusion_amd.sensor_manager import SensorManager
+    gm = GraphManager(capacity=64)
+    kw = dict(optimize_after_odom=False, covariance_linear=0.1, covariance_angular=0.01, max_time_skip=1e9)
+    lidar, image = SensorManager(gm, **kw), SensorManager(gm, **kw)
+    _integration_timeline(gm, lidar, image, imu=lambda t: gm.addIMUMeasurement(t, [0, 0, 9.81], [0, 0, 0]))
+    assert gm.graphSize() == 5 and gm.imuQueueSize() == 4
+    assert gm.getMostRecentPoseTime() == (1.27, 4)
+    times = []
+    gm.addOptimizationCallback(lambda t, q, p, v, b: times.append(t))
+    gm.solve()
+    assert gm.graphSize() == 0 and gm.imuQueueSize() == 0 and times == [1.27]
+    (q, t), v, b = gm.getState()
+    assert np.all(np.isfinite(np.concatenate([q, t, v, b])))
+    # stationary IMU (specific force = +g, Z up), identity odometry: the vehicle stays put
+    np.testing.assert_allclose(t, 0, atol=1e-6)
+    np.testing.assert_allclose(q, [1, 0, 0, 0], atol=1e-9)

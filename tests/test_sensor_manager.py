@@ -87,3 +87,39 @@ def test_unmatched_and_time_skip():
     sm.sensorCallback(0.40)
     assert not sm.odometryCallback(Odometry(0.40, [2, 0, 0], [1, 0, 0, 0]))     # gap >= max_time_skip (:47)
     assert len(gm.between) == 1
+
+
+def _integration_timeline(gm, lidar, image, imu=None):
+    """The scripted 1.35 s timeline of IntegrationTest.integrationTest1 (UnitTests.cpp:236-380):
+    IMU every 0.05 s from 0.1, images at 0.27/0.47/0.87/1.07, lidar clouds at 0.67/1.27, each sensor
+    message followed by its odometry message with the same stamp (all poses identity)."""
+    I = [1.0, 0, 0, 0]
+    events = [(t, "imu") for t in np.round(np.arange(0.1, 1.3501, 0.05), 2)]
+    events += [(t, "image") for t in (0.27, 0.47, 0.87, 1.07)] + [(t, "lidar") for t in (0.67, 1.27)]
+    for t, kind in sorted(events, key=lambda e: (e[0], e[1] != "imu")):
+        if kind == "imu":
+            if imu is not None:
+                imu(t)
+        else:
+            sm = image if kind == "image" else lidar
+            sm.sensorCallback(t)
+            sm.odometryCallback(Odometry(t, [0, 0, 0], I))
+
+
+def test_integration_timeline_structure():
+    """Under the CURRENT reference code (the test file itself is stale) the timeline
+    reserves 4 nodes (images 0.47/0.87/1.07, lidar 1.27: each source ignores sensor messages until
+    its first odometry, SensorManagerRos.h:93) and stages 2 between factors (image keys 1->2, 2->3)
+    on top of the 3 priors; the 4 IMU factors wait in the queue (GraphManager.cpp:66)."""
+    gm = FakeGraphManager()
+    kw = dict(optimize_after_odom=False, covariance_linear=0.1, covariance_angular=0.01, max_time_skip=1e9)
+    lidar, image = SensorManager(gm, **kw), SensorManager(gm, **kw)
+    _integration_timeline(gm, lidar, image)
+    assert gm.key == 4
+    assert [(a, b) for a, b, _, _ in gm.between] == [(1, 2), (2, 3)]
+    assert gm.nrFactors() == 5
+    # with the Carla max_time_skip (0.1 s) the 0.4 s / 0.2 s gaps suppress both factors (:47)
+    gm2 = FakeGraphManager()
+    kw["max_time_skip"] = 0.1
+    _integration_timeline(gm2, SensorManager(gm2, **kw), SensorManager(gm2, **kw))
+    assert gm2.key == 4 and gm2.between == []

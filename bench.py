@@ -108,7 +108,7 @@ def main():
     # on a 1-GPU box); the driver's N-GPU runs use RCCL ("nccl") with one rank per GPU.
     backend = os.environ.get("VF_BENCH_BACKEND", "nccl")
     gpu = 0 if os.environ.get("VF_BENCH_SHARE_GPU") else info.local_rank
-    if info.world > 1:
+    if info.world > 1 or os.environ.get("VF_FORCE_DIST"):
         torch.cuda.set_device(gpu)
         dist = D.init(backend=backend, device_id=torch.device("cuda", gpu) if backend == "nccl" else None)
     dev = torch.device("cuda", gpu)

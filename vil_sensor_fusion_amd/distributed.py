@@ -36,7 +36,7 @@ def shard_windows(total_windows: int, rank: int, world: int):
 def init(backend: str | None = None, device_id=None):
     """Initialise the default process group when WORLD_SIZE > 1; returns torch.distributed or None."""
     info = rank_info()
-    if info.world <= 1:
+    if info.world <= 1 and not os.environ.get("VF_FORCE_DIST"):   # VF_FORCE_DIST: 1-rank smoke test of the backend
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -188,3 +188,59 @@ def test_both_solver_forms_vs_oracle(oracle, extra_windows):
     ate, rot = helpers.ate(eng.get_states(0, 0, n), win.states)
     assert ate <= 1e-6 and rot <= 1e-6
     assert eng.read_lm(0)["solve_failures"] == 0
+
+
+def test_dense_noise_models_and_san_rafael_imu(oracle):
+    """Coverage beyond the Carla config: between factors with dense 6x6 covariances
+    (use_odom_covariance = true, SensorManagerRos.cpp:85-88) and the San Rafael IMU covariances
+    (config/san_rafael/fusion_params.yaml:20-25), K0 + K1 + K2 + LM against the oracle."""
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    n = 96
+    seq = synth.make_sequence(seed=12, n_kf=n)
+    rng = np.random.default_rng(12)
+    san_rafael = dict(acc=1e-6, gyro=1e-6, integration=1e-8, bias_acc=1e-3, bias_omega=1e-6, bias_acc_omega_int=1e-5)
+    prm = oracle.make_imu_params(san_rafael["acc"], san_rafael["gyro"], san_rafael["integration"],
+                                 san_rafael["bias_acc"], san_rafael["bias_omega"], san_rafael["bias_acc_omega_int"])
+    bias = np.array([0.02, -0.01, 0.03, 1e-3, -2e-3, 5e-4])
+    recs = np.zeros((n, 190))
+    for k in range(1, n):
+        p = oracle.pim_new(bias)
+        for s in seq.imu_steps[seq.imu_off[k]:seq.imu_off[k + 1]]:
+            oracle.pim_integrate(p, prm, s[1:4], s[4:7], s[0])
+        recs[k] = oracle.pim_to_record(p)
+    btw = synth.between_records(seq)
+    for i in range(btw.shape[0]):
+        A = rng.normal(size=(6, 6))
+        cov = 0.05 * (A @ A.T) / 6 + np.diag([0.02, 0.02, 0.02, 0.1, 0.1, 0.1])
+        btw[i, 7:] = oracle.sqrt_info_upper(cov)
+    g = np.array([0.0, 0.0, -9.81])
+    states = np.zeros((n, 16)); states[0] = seq.gt_states[0]; states[0, 10:] = bias
+    for k in range(1, n):
+        states[k] = oracle.retract(oracle.predict(recs[k], g, states[k - 1]), rng.normal(size=15) * 0.01)
+    from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
+    prob = dict(n=n, states=states, imu=recs, btw_a=seq.btw_a, btw_b=seq.btw_b, btw=btw,
+                prior=synth.prior_record(states[0], REFERENCE_PRIOR_SIGMAS), gravity=g)
+    eng = Engine(EngineOpts(windows=1, capacity=n))
+    # K0 on the device with the same parameters and bias estimate
+    eng.preintegrate(0, 1, seq.imu_off[1:], seq.imu_steps, bias, san_rafael)
+    got = eng.get_imu(0, 1, n - 1)
+    assert np.abs(got[:, :70] - recs[1:, :70]).max() < 1e-12 * max(1.0, np.abs(recs[1:, :70]).max())
+    assert np.abs(got[:, 70:] - recs[1:, 70:]).max() < 1e-8 * np.abs(recs[1:, 70:]).max()
+    helpers.load_engine(eng, 0, prob)      # (overwrites the device records with the oracle's: same to 1e-8)
+    eng.linearize(0)
+    r, J = eng.read_imu_lin(0, 1, n - 1)
+    rb, Ja, Jb = eng.read_between_lin(0, 0, n)
+    worst = 0.0
+    for k in range(1, n):
+        ro, Jo = oracle.imu_factor(recs[k], g, states[k - 1], states[k])
+        worst = max(worst, relerr(r[k - 1], ro), relerr(J[k - 1], Jo))
+    for a, b, rec in zip(seq.btw_a, seq.btw_b, btw):
+        ro, Jao, Jbo = oracle.between_factor(rec, states[a], states[b])
+        worst = max(worst, relerr(rb[b], ro), relerr(Ja[b], Jao), relerr(Jb[b], Jbo))
+    print("dense-noise linearisation worst relative error", worst)
+    assert worst < 1e-10
+    eng.iterate(5)
+    win = helpers.oracle_window(oracle, prob)
+    win.lm(iterations=5)
+    ate, rot = helpers.ate(eng.get_states(0, 0, n), win.states)
+    assert ate <= 1e-6 and rot <= 1e-6

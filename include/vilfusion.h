@@ -58,6 +58,9 @@ typedef struct {
     int device;             /* HIP device ordinal */
     double gravity[3];      /* n_gravity; MakeSharedU => (0,0,-9.81) (ImuManagerRos.cpp:16) */
     double lambda0, lambda_up, lambda_down, lambda_min, lambda_max; /* LM damping schedule */
+    int chunks;             /* K4 form: 0 = one sweep per window (two-sided when windows <= 256);
+                               P >= 2 = partitioned solve, P chunks per window joined by 45-dof
+                               separators (one-window latency; per-GPU piece of the time-sharded smoother) */
 } vf_engine_opts;
 
 void vf_engine_default_opts(vf_engine_opts* o);

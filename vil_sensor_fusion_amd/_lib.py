@@ -22,7 +22,7 @@ class EngineOptsC(C.Structure):
     _fields_ = [("windows", C.c_int), ("capacity", C.c_int), ("bandwidth", C.c_int),
                 ("device", C.c_int), ("gravity", C.c_double * 3),
                 ("lambda0", C.c_double), ("lambda_up", C.c_double), ("lambda_down", C.c_double),
-                ("lambda_min", C.c_double), ("lambda_max", C.c_double)]
+                ("lambda_min", C.c_double), ("lambda_max", C.c_double), ("chunks", C.c_int)]
 
 
 class ImuParamsC(C.Structure):

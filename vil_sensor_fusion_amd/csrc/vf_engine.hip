@@ -102,6 +102,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     if (o->windows < 1 || o->capacity < 2) return fail(VF_ERR_INVALID, "windows >= 1 and capacity >= 2 required");
     if (o->bandwidth < 1 || o->bandwidth > VF_MAX_BANDWIDTH)
         return fail(VF_ERR_INVALID, "bandwidth must be in 1..%d", VF_MAX_BANDWIDTH);
+    if (o->chunks < 0 || o->chunks > 4096) return fail(VF_ERR_INVALID, "chunks must be in 0..4096");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(VF_ERR_NO_DEVICE, "no HIP device visible; libvilfusion has no CPU path");
@@ -139,6 +140,15 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.gvec, G * 15);
     AL(v.delta, G * 15);
     AL(v.Lp, G * vf::PANEL);
+    v.P = o->chunks >= 2 ? o->chunks : 0;
+    if (v.P) {
+        const size_t BP = (size_t)v.B * v.P;
+        AL(v.Vp, G * vf::VROW);
+        AL(v.sepR, BP * vf::SEPM);
+        AL(v.sepS, BP * vf::SEPM);
+        AL(v.sepC, BP * vf::SEP * vf::SEP);
+        AL(v.sepL, BP * vf::SEPL);
+    }
     AL(v.lo, (size_t)v.B);
     AL(v.hi, (size_t)v.B);
     AL(v.sel, (size_t)v.B);

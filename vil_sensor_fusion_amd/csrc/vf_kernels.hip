@@ -803,19 +803,31 @@ template <int N> struct IC { static constexpr int value = N; };
 //   for keyframes t, t+1, t+2, and the two back substitutions run concurrently.  No extra flops.
 constexpr int MID_LD = 47;                      // 45 columns + rhs + pad
 constexpr int MID_TOTAL = 45 * MID_LD + 48;     // + the 45 solved increments handed to both waves
-template <bool TW>
+// MODE 2 / 3 (partitioned solve, K4p): the forward / backward sweep of ONE chunk of a window.  The
+//   forward sweep eliminates the chunk's `ni` interior keyframes and leaves the partially reduced
+//   45x45 block (+ rhs) of the 3 separator keyframes that follow in `sep_out`; couplings to
+//   keyframes in front of the chunk (the left separator) are dropped here and carried by the spike
+//   kernel.  The backward sweep starts from the separator increments already in v.delta.
+enum { SOLVE_FULL = 0, SOLVE_TWISTED = 1, SOLVE_CHUNK_FWD = 2, SOLVE_CHUNK_BWD = 3 };
+template <int MODE>
 __device__ __forceinline__ void band_solve_body(const View& v, double* __restrict__ S, double* __restrict__ S_other,
-                                                double* __restrict__ MID, const int w, const int lane, const int wave) {
-    const int lo = v.lo[w], hi = v.hi[w], n = hi - lo;
+                                                double* __restrict__ MID, const int w, const int lane, const int wave,
+                                                const ChunkGeom cg = ChunkGeom{0, 0, 0}, double* __restrict__ sep_out = nullptr) {
+    constexpr bool TW = MODE == SOLVE_TWISTED;
+    constexpr bool CH = MODE == SOLVE_CHUNK_FWD || MODE == SOLVE_CHUNK_BWD;
+    const int lo = v.lo[w], hi = v.hi[w];
+    const int n = CH ? cg.ni + (cg.has_sep ? 3 : 0) : hi - lo;     // real rows of this sweep
     const double lam = v.lambda[w];
-    const size_t base = (size_t)w * v.M + lo;
+    const size_t base = (size_t)w * v.M + lo + (CH ? cg.i0 : 0);
     int failed = 0;
     // sweep geometry: sweep index kk -> window keyframe j(kk); kinds of rows: 0 real, 1 identity, 2 zero
     const bool rev = TW && wave == 1;
     const int tsp = TW ? (((n - 3) / 2) & ~3) : 0;                 // split keyframe (multiple of 4)
     const int cr = TW ? n - tsp - 3 : 0;                            // pivots of the reverse sweep
     const int qpad = TW ? ((4 - (cr & 3)) & 3) : 0;                 // identity pads in front of it
-    const int cnt = !TW ? ((n + 3) & ~3) : (rev ? cr + qpad : tsp); // pivots of this sweep (multiple of 4)
+    const int npiv = CH ? cg.ni : n;                                // real pivots of a one-directional sweep
+    const int cnt = !TW ? ((CH && cg.has_sep) ? cg.ni : ((npiv + 3) & ~3))
+                        : (rev ? cr + qpad : tsp);                  // pivots of this sweep (multiple of 4)
     auto row_kind = [=](int kk) {
         if (!TW) return kk < n ? 0 : 1;
         if (!rev) return kk < tsp + 3 ? 0 : 1;
@@ -824,7 +836,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         return j >= tsp + 3 ? 0 : (j >= tsp ? 2 : 1);
     };
     auto kf_of = [=](int kk) { return rev ? n - 1 - (kk - qpad) : kk; };   // window-local keyframe of a real row
-    auto pivot_real = [=](int kk) { return !TW ? kk < n : (rev ? kk >= qpad : true); };
+    auto pivot_real = [=](int kk) { return !TW ? kk < npiv : (rev ? kk >= qpad : true); };
 
     // ---- per-lane constants.  Every LDS access below is branch-free: masked-off lanes read the
     // zero cells / write the sink, so no exec-mask juggling (and no SGPR spills) in the k loop.
@@ -889,7 +901,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         cp_pose[it] = (e < 90 && c < 6) ? 1.0 : 0.0;    // pose x pose part (between factors)
         cp_rest[it] = (e < 90 && c >= 6) ? 1.0 : 0.0;   // columns 6..14: only the marginal prior fills them
     }
-    const double mp_third = (v.mp_on[w] && n >= 3 && !rev) ? 1.0 : 0.0;
+    const double mp_third = (v.mp_on[w] && n >= 3 && !rev && (!CH || cg.i0 == 0)) ? 1.0 : 0.0;
     WSYNC();
 
     // ---- H block row prefetch (HBM -> registers) and commit (registers -> LDS slot) ---------
@@ -963,22 +975,22 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         }
         S[lane < 15 ? S_GD + s + lane : S_DUMP + 32 + lane] = -r.hg;
     };
+    const int n4 = cnt;   // pivots of this sweep; identity rows beyond the real ones are eliminated harmlessly
+#ifdef VF_SOLVE_STAMPS
+    unsigned long long st[16] = {0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
+    if constexpr (MODE != SOLVE_CHUNK_BWD) {
     commit_row(IC<0>{}, fetch_row(0), row_kind(0), 0);
     commit_row(IC<1>{}, fetch_row(1), row_kind(1), 1);
     commit_row(IC<2>{}, fetch_row(2), row_kind(2), 2);
     commit_row(IC<3>{}, fetch_row(3), row_kind(3), 3);
     WSYNC();
-    const int n4 = cnt;   // pivots of this sweep; identity rows beyond the real ones are eliminated harmlessly
-
-#ifdef VF_SOLVE_STAMPS
-    unsigned long long st[16] = {0}, tprev = __builtin_amdgcn_s_memtime();
-#endif
     // ---- one elimination step, phase PH = k & 3 compile-time --------------------------------
-    // `pend` = block row of keyframe k+4 (fetched during the previous step); this step fetches k+5.
-    auto step = [&](auto ph, int k, HRow& pend) {
+    // `pend`, `pend2` = block rows of keyframes k+4, k+5 (fetched one and two steps ago); this step fetches k+6.
+    auto step = [&](auto ph, int k, HRow& pend, HRow& pend2) {
         constexpr int PH = decltype(ph)::value;
         STAMP(0);
-        const HRow ahead = fetch_row(k + 5);   // two steps of slack for the HBM round trip
+        const HRow ahead = fetch_row(k + 6);   // three steps of slack for the HBM round trip
         double p[15];
 #pragma unroll
         for (int c = 0; c < 15; c++) p[c] = S[ri_ph[PH] + c];
@@ -1044,19 +1056,43 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         WSYNC();
         STAMP(4);
         commit_row(ph, pend, row_kind(k + 4), k + 4);  // row k+4 takes the slot the pivot keyframe frees
-        pend = ahead;
+        pend = pend2;
+        pend2 = ahead;
         WSYNC();
         STAMP(5);
     };
     {
         HRow pend = fetch_row(4);
+        HRow pend2 = fetch_row(5);
 #pragma unroll 1
         for (int k = 0; k < n4; k += 4) {
-            step(IC<0>{}, k, pend);
-            step(IC<1>{}, k + 1, pend);
-            step(IC<2>{}, k + 2, pend);
-            step(IC<3>{}, k + 3, pend);
+            step(IC<0>{}, k, pend, pend2);
+            step(IC<1>{}, k + 1, pend, pend2);
+            step(IC<2>{}, k + 2, pend, pend2);
+            step(IC<3>{}, k + 3, pend, pend2);
         }
+    }
+    }   // forward sweep
+    if constexpr (MODE == SOLVE_CHUNK_FWD) {
+        // the 3 separator keyframes sit in slots 0..2 (cnt is a multiple of 4): their block
+        // (own H + lambda + Schur terms of this chunk's interior) and rhs go to sep_out [45][46]
+        if (cg.has_sep) {
+            for (int e = lane; e < SEP * 46; e += 64) {
+                const int i = e / 46, jc = e - i * 46;
+                const int oi = i / 15, ai = i - oi * 15;
+                double val = 0.0;
+                if (jc == 45) {
+                    val = S[S_GD + oi * 15 + ai];
+                } else {
+                    const int hi_i = i >= jc ? i : jc, lo_i = i >= jc ? jc : i;
+                    const int oa = hi_i / 15, a = hi_i - oa * 15, ob = lo_i / 15, bb = lo_i - ob * 15;
+                    if (oa - ob < 2 || a < 6) val = S[S_WD + (oa * 15 + a) * LDW + ob * 15 + bb];
+                }
+                sep_out[e] = val;
+            }
+        }
+        if (lane == 0 && failed) atomicOr(v.fail + w, 1);
+        return;
     }
 
     // ---- back substitution: delta_k = L_kk^-T (y_k - sum_p L[p][k-cols]^T delta(p)) -----------
@@ -1064,6 +1100,12 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     // Lane r < 43 holds row r in registers; rows 0..27 go through LDS for the column sums,
     // L^-T stays in the registers of lanes 28..42.  Panels are prefetched two steps ahead.
     S[S_DL + lane] = 0.0;
+    if constexpr (MODE == SOLVE_CHUNK_BWD) {
+        WSYNC();
+        // increments of the separator keyframes (solved by k_sep_solve) start the recursion
+        if (cg.has_sep && lane < SEP) S[S_DL + lane] = dbase[(size_t)cg.ni * 15 + lane];
+        WSYNC();
+    }
     if constexpr (TW) {
         __syncthreads();   // both forward sweeps done; their trailing windows are in S (left) / S_other
         if (wave == 0) {
@@ -1194,15 +1236,15 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #ifdef VF_SOLVE_STAMPS
     if (w == 0 && lane == 0) for (int i = 0; i < 16; i++) g_stamps[i] = st[i];
 #endif
-    if constexpr (TW) { if (lane == 0 && failed) atomicOr(v.fail + w, 1); }
-    else { if (lane == 0) v.fail[w] = failed; }
+    if constexpr (MODE == SOLVE_FULL) { if (lane == 0) v.fail[w] = failed; }
+    else { if (lane == 0 && failed) atomicOr(v.fail + w, 1); }
 }
 
 __global__ void __launch_bounds__(64) k_band_solve(View v) {
     const int w = blockIdx.x;
     if (v.hi[w] - v.lo[w] <= 0) return;
     __shared__ double S[S_TOTAL];
-    band_solve_body<false>(v, S, nullptr, nullptr, w, threadIdx.x, 0);
+    band_solve_body<SOLVE_FULL>(v, S, nullptr, nullptr, w, threadIdx.x, 0);
 }
 
 // two waves per window (see band_solve_body); windows shorter than 32 keyframes are left to wave 0 alone
@@ -1214,10 +1256,312 @@ __global__ void __launch_bounds__(128) k_band_solve_tw(View v) {
     __shared__ double MID[MID_TOTAL];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (n < 32) {
-        if (wave == 0) band_solve_body<false>(v, S2, nullptr, nullptr, w, lane, 0);
+        if (wave == 0) band_solve_body<SOLVE_FULL>(v, S2, nullptr, nullptr, w, lane, 0);
         return;
     }
-    band_solve_body<true>(v, S2 + wave * S_TOTAL, S2 + (1 - wave) * S_TOTAL, MID, w, lane, wave);
+    band_solve_body<SOLVE_TWISTED>(v, S2 + wave * S_TOTAL, S2 + (1 - wave) * S_TOTAL, MID, w, lane, wave);
+}
+
+// ------------------------------------------------------------------------------------ K4p
+// Partitioned solve of one window by P chunks (latency form for few windows, and the per-GPU piece of
+// the time-sharded smoother).  Keyframes:  [I_0][S_0][I_1][S_1] ... [I_{P-1}],  S_c = 3 keyframes = 45 dof.
+//   1. k_chunk_forward : every chunk eliminates its interior I_c with the band sweep above (couplings to
+//                        its left separator dropped); leaves R_c = H[S_c,S_c] + lambda I - F^T A^-1 F, rhs.
+//   2. k_chunk_spike   : V = L_c^-1 E (E = coupling of I_c to S_{c-1}) by forward substitution through the
+//                        stored panels, on the matrix cores; gives -E^T A^-1 E, -E^T A^-1 g (left
+//                        separator), -F^T A^-1 E (coupling S_c x S_{c-1}) and the spike rows V for step 4.
+//   3. k_sep_solve     : block-tridiagonal system of the P-1 separators (45-dof blocks).
+//   4. k_chunk_rhs     : y_k -= V_k delta(S_{c-1})  in the stored panels.
+//   5. k_chunk_back    : the band back substitution of every chunk, started from delta(S_c).
+// Same arithmetic as one sweep up to the elimination order (a nested-dissection ordering of the same
+// Cholesky factorisation); tests/test_gpu_partitioned.py compares the increments of the two forms.
+__global__ void __launch_bounds__(64) k_chunk_forward(View v) {
+    const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
+    const int n = v.hi[w] - v.lo[w];
+    if (n <= 0) return;
+    const int Pe = chunk_count(n, P);
+    if (c >= Pe) return;
+    __shared__ double S[S_TOTAL];
+    band_solve_body<SOLVE_CHUNK_FWD>(v, S, nullptr, nullptr, w, threadIdx.x, 0, chunk_geom(n, Pe, c),
+                                     v.sepR + ((size_t)w * P + c) * SEPM);
+}
+__global__ void __launch_bounds__(64) k_chunk_back(View v) {
+    const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
+    const int n = v.hi[w] - v.lo[w];
+    if (n <= 0) return;
+    const int Pe = chunk_count(n, P);
+    if (c >= Pe) return;
+    __shared__ double S[S_TOTAL];
+    band_solve_body<SOLVE_CHUNK_BWD>(v, S, nullptr, nullptr, w, threadIdx.x, 0, chunk_geom(n, Pe, c), nullptr);
+}
+
+// One wave per chunk c >= 1.  W = the not yet substituted part of E for the next 4 keyframes, V_k = L_kk^-1 W_k,
+// all kept as 16x16 tiles in the MFMA accumulator layout (row = (lane>>4) + 4r, column = lane & 15), which
+// is also the B-operand layout of v_mfma_f64_16x16x4: results feed the next product without leaving
+// registers.  Three column tiles cover the 45 separator columns.
+__global__ void __launch_bounds__(64) k_chunk_spike(View v) {
+    const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
+    const int lo = v.lo[w], n = v.hi[w] - lo;
+    if (n <= 0) return;
+    const int Pe = chunk_count(n, P);
+    if (c == 0 || c >= Pe) return;
+    const ChunkGeom cg = chunk_geom(n, Pe, c);
+    const int lane = threadIdx.x, li = lane & 15, lq = lane >> 4;
+    const size_t base = (size_t)w * v.M + lo + cg.i0;
+    const double* __restrict__ Hb = v.H + base * HROW;
+    const double* __restrict__ Lb = v.Lp + base * PANEL;
+    double* __restrict__ Vb = v.Vp + base * VROW;
+
+    // E rows of interior keyframe kk (0..2): block d = kk + 3 - o of its H row couples it to separator
+    // keyframe o (0..2); d = 1 is a full 15x15 block (IMU factor), d = 2, 3 pose x pose only
+    auto e_val = [&](int kk, int a, int j) -> double {
+        if (j >= SEP || a >= 15 || kk >= cg.ni) return 0.0;
+        const int o = j / 15, cc = j - o * 15, d = kk + 3 - o;
+        if (d > 3) return 0.0;
+        const double* Hk = Hb + (size_t)kk * HROW;
+        if (d == 1) return Hk[225 + a * 15 + cc];
+        return (a < 6 && cc < 6) ? Hk[225 * d + a * 15 + cc] : 0.0;
+    };
+    d4_t Wa[3], Wb[3], Wcd[3];   // W of keyframes k, k+1 and (pose rows of) k+2 | k+3 stacked at rows 0..7 | 8..15
+#pragma unroll
+    for (int J = 0; J < 3; J++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int a = lq + 4 * r, j = 16 * J + li;
+            Wa[J][r] = e_val(0, a, j);
+            Wb[J][r] = e_val(1, a, j);
+            Wcd[J][r] = r < 2 ? e_val(2, a, j) : 0.0;
+        }
+    }
+    d4_t acc[6];                 // sum_k V_k^T [V_k | y_k], tiles (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+#pragma unroll
+    for (int t = 0; t < 6; t++) acc[t] = (d4_t){0, 0, 0, 0};
+
+    struct Ops { double linv[4], x1[4], x23[4], y[4]; };
+    // panel rows: 0..14 L[k+1][k], 15..20 L[k+2 pose][k], 21..26 L[k+3 pose][k], 27 y_k, 28..42 L_kk^-T
+    const int r23 = li < 6 ? 15 + li : ((li >= 8 && li < 14) ? 21 + li - 8 : -1);
+    auto load_ops = [&](int k) {
+        Ops o;
+        const double* Pk = Lb + (size_t)(k < cg.ni ? k : 0) * PANEL;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int cq = 4 * q + lq;
+            const bool ck = cq < 15;
+            o.linv[q] = ck ? Pk[(28 + cq) * 16 + li] : 0.0;
+            o.x1[q] = (ck && li < 15) ? Pk[li * 16 + cq] : 0.0;
+            o.x23[q] = (ck && r23 >= 0) ? Pk[r23 * 16 + cq] : 0.0;
+            o.y[q] = ck ? Pk[27 * 16 + cq] : 0.0;
+        }
+        return o;
+    };
+    Ops nxt = load_ops(0);
+#pragma unroll 1
+    for (int k = 0; k < cg.ni; k++) {
+        const Ops o = nxt;
+        nxt = load_ops(k + 1);
+        d4_t V[3];
+#pragma unroll
+        for (int J = 0; J < 3; J++) {
+            V[J] = (d4_t){0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 4; q++) V[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.linv[q], Wa[J][q], V[J], 0, 0, 0);
+        }
+#pragma unroll
+        for (int J = 0; J < 3; J++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                Wb[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(-o.x1[q], V[J][q], Wb[J], 0, 0, 0);
+                Wcd[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(-o.x23[q], V[J][q], Wcd[J], 0, 0, 0);
+            }
+        }
+        // V^T [V | y]: y_k rides in column 45 (tile 2, lane & 15 == 13), where V is identically zero
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const double v2y = V[2][q] + (li == 13 ? o.y[q] : 0.0);
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[0][q], V[0][q], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[0][q], V[1][q], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[0][q], v2y, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[1][q], V[1][q], acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[1][q], v2y, acc[4], 0, 0, 0);
+            acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[2][q], v2y, acc[5], 0, 0, 0);
+        }
+        // spike rows of keyframe k -> HBM (k_chunk_rhs reads them back)
+        double* Vk = Vb + (size_t)k * VROW;
+#pragma unroll
+        for (int J = 0; J < 3; J++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int a = lq + 4 * r;
+                if (a < 15) Vk[a * 48 + 16 * J + li] = V[J][r];
+            }
+        if (k + 1 < cg.ni) {
+            // advance one keyframe: new E rows only exist for the first three keyframes (already in W)
+#pragma unroll
+            for (int J = 0; J < 3; J++) {
+                Wa[J] = Wb[J];
+                Wb[J] = (d4_t){Wcd[J][0], Wcd[J][1], 0.0, 0.0};
+                Wcd[J] = (d4_t){Wcd[J][2], Wcd[J][3], 0.0, 0.0};
+            }
+        }
+    }
+    // ---- outputs --------------------------------------------------------------------------------
+    double* Sm = v.sepS + ((size_t)w * P + c) * SEPM;    // -(V^T V), -(V^T y): added to separator c-1
+    auto put = [&](const d4_t& t, int I, int J) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = 16 * I + lq + 4 * r, j = 16 * J + li;
+            if (i < SEP && j < 46) {
+                Sm[i * 46 + j] = -t[r];
+                if (I != J && j < SEP) Sm[j * 46 + i] = -t[r];
+            }
+        }
+    };
+    put(acc[0], 0, 0); put(acc[1], 0, 1); put(acc[2], 0, 2); put(acc[3], 1, 1); put(acc[4], 1, 2); put(acc[5], 2, 2);
+    if (cg.has_sep) {
+        // what is left in W belongs to the right separator: rows i1 (15), i1+1 and i1+2 (pose rows)
+        double* Cm = v.sepC + ((size_t)w * P + c) * SEP * SEP;
+#pragma unroll
+        for (int J = 0; J < 3; J++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int a = lq + 4 * r, j = 16 * J + li;
+                if (j < SEP && a < 15) {
+                    Cm[a * SEP + j] = Wb[J][r];
+                    Cm[(15 + a) * SEP + j] = r < 2 ? Wcd[J][r] : 0.0;
+                    Cm[(30 + a) * SEP + j] = r < 2 ? Wcd[J][r + 2] : 0.0;
+                }
+            }
+    }
+}
+
+// y_k -= V_k delta(left separator) for every interior keyframe of the chunks c >= 1
+__global__ void __launch_bounds__(256) k_chunk_rhs(View v) {
+    const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
+    const int lo = v.lo[w], n = v.hi[w] - lo;
+    if (n <= 0) return;
+    const int Pe = chunk_count(n, P);
+    if (c == 0 || c >= Pe) return;
+    const ChunkGeom cg = chunk_geom(n, Pe, c);
+    const size_t base = (size_t)w * v.M + lo + cg.i0;
+    __shared__ double dl[SEP];
+    if (threadIdx.x < SEP) dl[threadIdx.x] = v.delta[(base - 3) * 15 + threadIdx.x];
+    __syncthreads();
+    for (int e = threadIdx.x; e < cg.ni * 15; e += 256) {
+        const int k = e / 15, a = e - k * 15;
+        const double* Vr = v.Vp + (base + k) * VROW + a * 48;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < SEP; j += 3) {
+            s0 = fma(Vr[j], dl[j], s0);
+            s1 = fma(Vr[j + 1], dl[j + 1], s1);
+            s2 = fma(Vr[j + 2], dl[j + 2], s2);
+        }
+        v.Lp[(base + k) * PANEL + 27 * 16 + a] -= (s0 + s1) + s2;
+    }
+}
+
+// Block-tridiagonal Cholesky of the separator chain, one workgroup per window.  Step s works on the
+// 90 x 90 (+ rhs) matrix [D_s, C_s^T; C_s, D_{s+1}] in LDS: 45 right-looking pivots leave the Schur
+// complement of separator s+1 in the lower block, which moves up for the next step.
+constexpr int SQ = 91;                       // LDS row stride (odd: conflict-free column walks), column 90 = rhs
+__global__ void __launch_bounds__(256) k_sep_solve(View v) {
+    const int P = v.P, w = blockIdx.x, tid = threadIdx.x;
+    const int lo = v.lo[w], n = v.hi[w] - lo;
+    if (n <= 0) return;
+    const int Pe = chunk_count(n, P), m = Pe - 1;
+    if (m <= 0) return;
+    __shared__ double A[90 * SQ];
+    __shared__ double dnext[SEP], tvec[SEP];
+    __shared__ int s_fail;
+    if (tid == 0) s_fail = 0;
+    const double* R = v.sepR + (size_t)w * P * SEPM;
+    const double* Sx = v.sepS + (size_t)w * P * SEPM;
+    const double* Cx = v.sepC + (size_t)w * P * SEP * SEP;
+    double* Lx = v.sepL + (size_t)w * P * SEPL;
+    // D_0 = R_0 + S_1
+    for (int e = tid; e < SEP * 46; e += 256) {
+        const int i = e / 46, j = e - i * 46;
+        A[i * SQ + (j == 45 ? 90 : j)] = R[e] + Sx[SEPM + e];
+    }
+    __syncthreads();
+    for (int s = 0; s < m; s++) {
+        const bool more = s + 1 < m;
+        const int rows = more ? 90 : 45;
+        if (more) {
+            for (int e = tid; e < SEP * SEP; e += 256) {
+                const int i = e / SEP, j = e - i * SEP;
+                A[(45 + i) * SQ + j] = Cx[(size_t)(s + 1) * SEP * SEP + e];
+            }
+            for (int e = tid; e < SEP * 46; e += 256) {
+                const int i = e / 46, j = e - i * 46;
+                A[(45 + i) * SQ + (j == 45 ? 90 : 45 + j)] = R[(size_t)(s + 1) * SEPM + e] + (s + 2 <= m ? Sx[(size_t)(s + 2) * SEPM + e] : 0.0);
+            }
+        }
+        __syncthreads();
+        for (int cpiv = 0; cpiv < SEP; cpiv++) {
+            const double piv = A[cpiv * SQ + cpiv];
+            if (!(piv > 0.0)) { if (tid == 0) s_fail = 1; }
+            const double l = (piv > 0.0) ? 1.0 / sqrt(piv) : 1.0;
+            __syncthreads();
+            for (int i = cpiv + tid; i < rows; i += 256) A[i * SQ + cpiv] *= l;
+            if (tid == 255) A[cpiv * SQ + 90] *= l;
+            __syncthreads();
+            const int T = rows - 1 - cpiv;            // trailing rows cpiv+1 .. rows-1; columns the same + rhs
+            for (int e = tid; e < T * (T + 1); e += 256) {
+                const int ii = e / (T + 1), jj = e - ii * (T + 1);
+                const int i = cpiv + 1 + ii;
+                if (jj == T) A[i * SQ + 90] -= A[i * SQ + cpiv] * A[cpiv * SQ + 90];
+                else if (jj <= ii) { const int j = cpiv + 1 + jj; A[i * SQ + j] -= A[i * SQ + cpiv] * A[j * SQ + cpiv]; }
+            }
+            __syncthreads();
+        }
+        // keep the factor columns (90 x 45) and y (45) for the back substitution
+        for (int e = tid; e < rows * 46; e += 256) {
+            const int i = e / 46, j = e - i * 46;
+            if (j < SEP) Lx[(size_t)s * SEPL + e] = A[i * SQ + j];
+            else if (i < SEP) Lx[(size_t)s * SEPL + e] = A[i * SQ + 90];
+        }
+        __syncthreads();
+        if (more) {
+            // Schur complement of separator s+1 (lower triangle + rhs) moves to the top-left block
+            for (int e = tid; e < SEP * 46; e += 256) {
+                const int i = e / 46, j = e - i * 46;
+                if (j == 45) A[i * SQ + 90] = A[(45 + i) * SQ + 90];
+                else if (j <= i) A[i * SQ + j] = A[(45 + i) * SQ + 45 + j];
+            }
+            __syncthreads();
+        }
+    }
+    // ---- back substitution along the chain, last separator first --------------------------------
+    for (int s = m - 1; s >= 0; s--) {
+        const bool more = s + 1 < m;
+        const double* Ls = Lx + (size_t)s * SEPL;
+        for (int e = tid; e < SEP * 46; e += 256) {
+            const int i = e / 46, j = e - i * 46;
+            A[i * SQ + (j == 45 ? 90 : j)] = Ls[e];
+        }
+        if (tid < SEP) {
+            double t = Ls[tid * 46 + 45];
+            if (more)
+                for (int i = 0; i < SEP; i++) t = fma(-Ls[(45 + i) * 46 + tid], dnext[i], t);
+            tvec[tid] = t;
+        }
+        __syncthreads();
+        for (int cc = SEP - 1; cc >= 0; cc--) {
+            const double x = tvec[cc] / A[cc * SQ + cc];
+            __syncthreads();
+            if (tid < cc) tvec[tid] -= A[cc * SQ + tid] * x;
+            if (tid == cc) tvec[cc] = x;
+            __syncthreads();
+        }
+        const ChunkGeom cg = chunk_geom(n, Pe, s);
+        if (tid < SEP) {
+            dnext[tid] = tvec[tid];
+            v.delta[((size_t)w * v.M + lo + cg.i0 + cg.ni) * 15 + tid] = tvec[tid];
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && s_fail) atomicOr(v.fail + w, 1);
 }
 
 #ifdef VF_SOLVE_STAMPS
@@ -1550,7 +1894,16 @@ void launch_linearize_prior(const View& v, int which, hipStream_t s) {
 void launch_assemble(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_assemble, dim3(nblk(v.G, AT)), dim3(256), 0, s, v);
 }
+void launch_partitioned_solve(const View& v, hipStream_t s) {
+    const unsigned nb = (unsigned)v.B * (unsigned)v.P;
+    hipLaunchKernelGGL(k_chunk_forward, dim3(nb), dim3(64), 0, s, v);
+    hipLaunchKernelGGL(k_chunk_spike, dim3(nb), dim3(64), 0, s, v);
+    hipLaunchKernelGGL(k_sep_solve, dim3(v.B), dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_chunk_rhs, dim3(nb), dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_chunk_back, dim3(nb), dim3(64), 0, s, v);
+}
 void launch_band_solve(const View& v, hipStream_t s) {
+    if (v.P >= 2) { launch_partitioned_solve(v, s); return; }
     // few windows: two waves per window from both ends (latency); many: one wave per window (throughput)
     static const int tw_max = getenv("VF_TWISTED_MAX_WINDOWS") ? atoi(getenv("VF_TWISTED_MAX_WINDOWS")) : 256;
     if (v.B <= tw_max) hipLaunchKernelGGL(k_band_solve_tw, dim3(v.B), dim3(128), 0, s, v);

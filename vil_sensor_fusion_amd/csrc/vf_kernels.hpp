@@ -15,6 +15,28 @@ constexpr int PRIOR_OUT = 240;  // r(15), J(15x15)
 constexpr int NBLK = 4;         // band blocks stored per keyframe (bandwidth 3 + diagonal)
 constexpr int HROW = NBLK * 225;
 constexpr int PANEL = 43 * 16;  // Cholesky panel in HBM: 43 rows (27 sub-diagonal, rhs, 15 of L^-T), one 128-B line each
+// partitioned solve (K4p): a window is cut into P chunks separated by 3-keyframe (45-dof) separators
+constexpr int SEP = 45;
+constexpr int SEPM = SEP * 46;  // 45x45 block + right-hand side column
+constexpr int SEPL = 90 * 46;   // factor columns of one separator elimination: 90 rows x (45 + y)
+constexpr int VROW = 15 * 48;   // spike rows of one keyframe: 15 dof x 45 separator columns (48 stored)
+
+// chunk geometry of an n-keyframe window cut into (at most) P chunks: interiors of L keyframes
+// (L a multiple of 4), 3 separator keyframes between consecutive chunks, the last chunk takes the rest
+__host__ __device__ inline int chunk_len(int n, int P) { return ((n - 3 * (P - 1)) / P) & ~3; }
+__host__ __device__ inline int chunk_count(int n, int P) {
+    while (P > 1 && chunk_len(n, P) < 8) P--;
+    return P < 1 ? 1 : P;
+}
+struct ChunkGeom { int i0, ni, has_sep; };   // first interior keyframe (window-local), interior count, separator follows
+__host__ __device__ inline ChunkGeom chunk_geom(int n, int Pe, int c) {
+    const int L = chunk_len(n, Pe);
+    ChunkGeom g;
+    g.i0 = c * (L + 3);
+    g.has_sep = c < Pe - 1;
+    g.ni = g.has_sep ? L : n - g.i0;
+    return g;
+}
 
 // Device-resident problem: B windows x M keyframe slots (G = B*M).  See DESIGN.md.
 struct View {
@@ -40,6 +62,13 @@ struct View {
     double* gvec;       // [G][15]
     double* delta;      // [G][15]
     double* Lp;         // [G][43][16]         Cholesky panels (15 of 16 columns used)
+    // partitioned solve (allocated when P >= 2)
+    int P;              // chunks per window (0/1 = whole-window sweeps)
+    double* Vp;         // [G][15][48]         spikes: L^-1 (coupling of the chunk interior to its left separator)
+    double* sepR;       // [B][P][45][46]      separator block + rhs left by the forward sweep of chunk c
+    double* sepS;       // [B][P][45][46]      Schur term of chunk c on its LEFT separator (c >= 1)
+    double* sepC;       // [B][P][45][45]      coupling (right separator of chunk c) x (left separator of chunk c)
+    double* sepL;       // [B][P][90][46]      factor columns of the separator chain (for its back substitution)
     int* lo;            // [B] active range [lo, hi)
     int* hi;
     int* sel;           // [B] which buffer is current

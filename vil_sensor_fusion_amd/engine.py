@@ -38,6 +38,7 @@ class EngineOpts:
     lambda_down: float = 10.0
     lambda_min: float = 1e-12
     lambda_max: float = 1e10
+    chunks: int = 0          # K4 form: 0 = one sweep per window, P >= 2 = partitioned solve (P chunks + separators)
 
 
 class Engine:
@@ -49,6 +50,7 @@ class Engine:
         o.gravity[:] = list(opts.gravity)
         o.lambda0, o.lambda_up, o.lambda_down = opts.lambda0, opts.lambda_up, opts.lambda_down
         o.lambda_min, o.lambda_max = opts.lambda_min, opts.lambda_max
+        o.chunks = opts.chunks
         self._h = C.c_void_p()
         check(self._l.vf_engine_create(C.byref(o), C.byref(self._h)))
         self.opts = opts

@@ -1,5 +1,5 @@
 import sys, os, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from vil_sensor_fusion_amd import _lib
 if len(sys.argv) > 1 and sys.argv[1] != 'base':
     _lib._SO = os.path.abspath(f'scratch/libvf_{sys.argv[1]}.so')

@@ -787,6 +787,12 @@ constexpr int S_ID = S_ZERO + 16;        // 15x15 identity: panel rows of the L^
 constexpr int S_P = S_ID + 225;          // panel rows 15..42 at stride 15 (conflict-free column reads)
 constexpr int S_DL = S_P + 43 * 15;      // back-substitution: delta of the 3 following keyframes
 constexpr int S_TOTAL = S_DL + 64;
+// chunk forward sweep with a spike follower (k_chunk_forward): the panel of step k (43 rows x 15, then a
+// zero cell and a write sink) stays in a 4-slot LDS ring for the second wave; two hand-shake cells follow
+constexpr int RING_SLOT = 664;
+constexpr int S_PROG = S_P + 4 * RING_SLOT;   // panels completed by the sweep
+constexpr int S_CONS = S_PROG + 1;            // panels consumed by the follower
+constexpr int S_TOTAL_RING = S_PROG + 8;
 #define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #ifdef VF_SOLVE_STAMPS   // diagnostic build only (tools/build_stamps.sh); never in the shipped library
 __device__ unsigned long long g_stamps[16];
@@ -795,6 +801,13 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP(i) do {} while (0)
 #endif
 template <int N> struct IC { static constexpr int value = N; };
+// uncached read of an LDS cell another wave of the workgroup writes (hand-shake counters)
+VF_DI double lds_peek(const double* p) {
+    double x;
+    const unsigned addr = (unsigned)(size_t)p;    // low half of a flat LDS address = LDS offset
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(addr) : "memory");
+    return x;
+}
 
 // TW = false: one wave sweeps the whole window (throughput form, one window per SIMD).
 // TW = true : burn-at-both-ends (twisted) factorisation for one-window latency: wave 0 eliminates
@@ -851,7 +864,17 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
                   : (lane == 42 ? S_GD + s0 : (lane < 58 ? S_ID + (lane - 43) * 15 : S_ZERO));
     }
     // lanes 58..63 read 15 consecutive cells from S_ZERO: S_ZERO has 16 zeros -> a zero row
-    const int pw_off = (lane >= 15 && lane < 43) ? S_P + (lane - 15) * 15 : S_DUMP + 16;   // sub-panel -> LDS
+    constexpr bool RINGM = MODE == SOLVE_CHUNK_FWD;        // panels also feed the spike follower (LDS ring)
+    constexpr int RSLOT = RINGM ? RING_SLOT : 0;
+    const int pw_off = (lane >= 15 && lane < (RINGM ? 58 : 43)) ? S_P + (lane - 15) * 15
+                                                                : (RINGM ? S_P + 646 : S_DUMP + 16);   // sub-panel -> LDS
+    if constexpr (RINGM) {
+        if (lane < 4) S[S_P + lane * RING_SLOT + 645] = 0.0;
+        if (lane == 4) S[S_PROG] = 0.0;
+        if (lane == 5) S[S_CONS] = 0.0;
+    }
+    const int op_zero = RINGM ? S_P + 645 : S_ZERO;
+    const bool follower = RINGM && cg.i0 > 0;              // chunk 0 has no left separator, hence no spike
     // Schur write-back targets (MFMA C layout): tile t in {(0,0),(1,0),(1,1)}, register r:
     //   i = 16*Ti + (lane>>4) + 4r (trailing row, 27 = rhs), j = 16*Tj + (lane&15)
     int tgt_ph[4][12];
@@ -875,8 +898,8 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int kc = 4 * q + (lane >> 4);
-        op0[q] = kc < 15 ? S_P + (lane & 15) * 15 + kc : S_ZERO;
-        op1[q] = (kc < 15 && 31 + (lane & 15) <= 42) ? S_P + (16 + (lane & 15)) * 15 + kc : S_ZERO;
+        op0[q] = kc < 15 ? S_P + (lane & 15) * 15 + kc : op_zero;
+        op1[q] = (kc < 15 && 31 + (lane & 15) <= 42) ? S_P + (16 + (lane & 15)) * 15 + kc : op_zero;
     }
     // block-row commit map: idx = lane + 64 j over a 15x15 block -> (a, c); diagonal gets +lambda
     int cm_off[4], cm_srcT[4];
@@ -1018,8 +1041,12 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         }
         STAMP(2);
         // sub-panel + rhs -> LDS (MFMA operands); rows 15..57 -> HBM, one 128-B line per lane
+        if constexpr (RINGM) {
+            // slot PH still holds the panel of step k-4: wait until the follower has read it
+            if (follower) while (lds_peek(S + S_CONS) < (double)(k - 3)) __builtin_amdgcn_s_sleep(1);
+        }
 #pragma unroll
-        for (int c = 0; c < 15; c++) S[pw_off + c] = p[c];
+        for (int c = 0; c < 15; c++) S[pw_off + PH * RSLOT + c] = p[c];
         if (lane >= 15 && lane < 58 && pivot_real(k)) {
             d2_t* Lk = (d2_t*)(Lbase + (size_t)kf_of(k) * PANEL + (size_t)(lane - 15) * PSTR);
 #pragma unroll
@@ -1032,12 +1059,13 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #endif
         }
         WSYNC();
+        if constexpr (RINGM) { if (lane == 0) S[S_PROG] = (double)(k + 1); }   // panel k is complete in its ring slot
         STAMP(3);
         // Schur update on the matrix cores: acc[t] = P_Ti P_Tj^T for the 3 lower 16x16 tiles
         d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
         double a0[4], a1[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { a0[q] = S[op0[q]]; a1[q] = S[op1[q]]; }
+        for (int q = 0; q < 4; q++) { a0[q] = S[op0[q] + PH * RSLOT]; a1[q] = S[op1[q] + PH * RSLOT]; }
         double cur[12];
 #pragma unroll
         for (int q = 0; q < 12; q++) cur[q] = S[tgt_ph[PH][q]];
@@ -1265,51 +1293,28 @@ __global__ void __launch_bounds__(128) k_band_solve_tw(View v) {
 // ------------------------------------------------------------------------------------ K4p
 // Partitioned solve of one window by P chunks (latency form for few windows, and the per-GPU piece of
 // the time-sharded smoother).  Keyframes:  [I_0][S_0][I_1][S_1] ... [I_{P-1}],  S_c = 3 keyframes = 45 dof.
-//   1. k_chunk_forward : every chunk eliminates its interior I_c with the band sweep above (couplings to
-//                        its left separator dropped); leaves R_c = H[S_c,S_c] + lambda I - F^T A^-1 F, rhs.
-//   2. k_chunk_spike   : V = L_c^-1 E (E = coupling of I_c to S_{c-1}) by forward substitution through the
-//                        stored panels, on the matrix cores; gives -E^T A^-1 E, -E^T A^-1 g (left
-//                        separator), -F^T A^-1 E (coupling S_c x S_{c-1}) and the spike rows V for step 4.
+//   1. k_chunk_forward : wave 0 of every chunk eliminates its interior I_c with the band sweep above
+//                        (couplings to its left separator dropped); leaves R_c = H[S_c,S_c] + lambda I
+//                        - F^T A^-1 F and the rhs.
+//   2.  (same kernel)    wave 1 follows one step behind with the spike V = L_c^-1 E (E = coupling of I_c to
+//                        S_{c-1}): forward substitution through the panels (LDS ring) on the matrix cores;
+//                        gives -E^T A^-1 E, -E^T A^-1 g (left separator), -F^T A^-1 E (coupling
+//                        S_c x S_{c-1}) and the spike rows V for step 4.
 //   3. k_sep_solve     : block-tridiagonal system of the P-1 separators (45-dof blocks).
 //   4. k_chunk_rhs     : y_k -= V_k delta(S_{c-1})  in the stored panels.
 //   5. k_chunk_back    : the band back substitution of every chunk, started from delta(S_c).
 // Same arithmetic as one sweep up to the elimination order (a nested-dissection ordering of the same
 // Cholesky factorisation); tests/test_gpu_partitioned.py compares the increments of the two forms.
-__global__ void __launch_bounds__(64) k_chunk_forward(View v) {
-    const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
-    const int n = v.hi[w] - v.lo[w];
-    if (n <= 0) return;
-    const int Pe = chunk_count(n, P);
-    if (c >= Pe) return;
-    __shared__ double S[S_TOTAL];
-    band_solve_body<SOLVE_CHUNK_FWD>(v, S, nullptr, nullptr, w, threadIdx.x, 0, chunk_geom(n, Pe, c),
-                                     v.sepR + ((size_t)w * P + c) * SEPM);
-}
-__global__ void __launch_bounds__(64) k_chunk_back(View v) {
-    const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
-    const int n = v.hi[w] - v.lo[w];
-    if (n <= 0) return;
-    const int Pe = chunk_count(n, P);
-    if (c >= Pe) return;
-    __shared__ double S[S_TOTAL];
-    band_solve_body<SOLVE_CHUNK_BWD>(v, S, nullptr, nullptr, w, threadIdx.x, 0, chunk_geom(n, Pe, c), nullptr);
-}
-
-// One wave per chunk c >= 1.  W = the not yet substituted part of E for the next 4 keyframes, V_k = L_kk^-1 W_k,
-// all kept as 16x16 tiles in the MFMA accumulator layout (row = (lane>>4) + 4r, column = lane & 15), which
-// is also the B-operand layout of v_mfma_f64_16x16x4: results feed the next product without leaving
-// registers.  Three column tiles cover the 45 separator columns.
-__global__ void __launch_bounds__(64) k_chunk_spike(View v) {
-    const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
-    const int lo = v.lo[w], n = v.hi[w] - lo;
-    if (n <= 0) return;
-    const int Pe = chunk_count(n, P);
-    if (c == 0 || c >= Pe) return;
-    const ChunkGeom cg = chunk_geom(n, Pe, c);
-    const int lane = threadIdx.x, li = lane & 15, lq = lane >> 4;
+// Spike of chunk c >= 1 (second wave of k_chunk_forward).  W = the not yet substituted part of E for the
+// next 4 keyframes, V_k = L_kk^-1 W_k, all kept as 16x16 tiles in the MFMA accumulator layout
+// (row = (lane>>4) + 4r, column = lane & 15), which is also the B-operand layout of v_mfma_f64_16x16x4:
+// results feed the next product without leaving registers.  Three column tiles cover the 45 separator
+// columns.  The panel of step k is read from the LDS ring slot k & 3 once the sweep has published it.
+__device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int c, ChunkGeom cg, int lane) {
+    const int P = v.P, lo = v.lo[w];
+    const int li = lane & 15, lq = lane >> 4;
     const size_t base = (size_t)w * v.M + lo + cg.i0;
     const double* __restrict__ Hb = v.H + base * HROW;
-    const double* __restrict__ Lb = v.Lp + base * PANEL;
     double* __restrict__ Vb = v.Vp + base * VROW;
 
     // E rows of interior keyframe kk (0..2): block d = kk + 3 - o of its H row couples it to separator
@@ -1337,47 +1342,47 @@ __global__ void __launch_bounds__(64) k_chunk_spike(View v) {
 #pragma unroll
     for (int t = 0; t < 6; t++) acc[t] = (d4_t){0, 0, 0, 0};
 
-    struct Ops { double linv[4], x1[4], x23[4], y[4]; };
     // panel rows: 0..14 L[k+1][k], 15..20 L[k+2 pose][k], 21..26 L[k+3 pose][k], 27 y_k, 28..42 L_kk^-T
+    // (LDS ring slot: row stride 15, cell 645 = 0.0 for the masked lanes)
     const int r23 = li < 6 ? 15 + li : ((li >= 8 && li < 14) ? 21 + li - 8 : -1);
-    auto load_ops = [&](int k) {
-        Ops o;
-        const double* Pk = Lb + (size_t)(k < cg.ni ? k : 0) * PANEL;
+    int o_linv[4], o_x1[4], o_x23[4], o_y[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int cq = 4 * q + lq;
-            const bool ck = cq < 15;
-            o.linv[q] = ck ? Pk[(28 + cq) * 16 + li] : 0.0;
-            o.x1[q] = (ck && li < 15) ? Pk[li * 16 + cq] : 0.0;
-            o.x23[q] = (ck && r23 >= 0) ? Pk[r23 * 16 + cq] : 0.0;
-            o.y[q] = ck ? Pk[27 * 16 + cq] : 0.0;
-        }
-        return o;
-    };
-    Ops nxt = load_ops(0);
+    for (int q = 0; q < 4; q++) {
+        const int cq = 4 * q + lq;
+        const bool ck = cq < 15;
+        o_linv[q] = (ck && li < 15) ? (28 + cq) * 15 + li : 645;
+        o_x1[q] = (ck && li < 15) ? li * 15 + cq : 645;
+        o_x23[q] = (ck && r23 >= 0) ? r23 * 15 + cq : 645;
+        o_y[q] = (ck && li == 13) ? 27 * 15 + cq : 645;
+    }
 #pragma unroll 1
     for (int k = 0; k < cg.ni; k++) {
-        const Ops o = nxt;
-        nxt = load_ops(k + 1);
+        while (lds_peek(S + S_PROG) < (double)(k + 1)) __builtin_amdgcn_s_sleep(1);
+        const double* Pk = S + S_P + (k & 3) * RING_SLOT;
+        double linv[4], x1[4], x23[4], yv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { linv[q] = Pk[o_linv[q]]; x1[q] = -Pk[o_x1[q]]; x23[q] = -Pk[o_x23[q]]; yv[q] = Pk[o_y[q]]; }
+        WSYNC();
+        if (lane == 0) S[S_CONS] = (double)(k + 1);      // slot may be reused
         d4_t V[3];
 #pragma unroll
         for (int J = 0; J < 3; J++) {
             V[J] = (d4_t){0, 0, 0, 0};
 #pragma unroll
-            for (int q = 0; q < 4; q++) V[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.linv[q], Wa[J][q], V[J], 0, 0, 0);
+            for (int q = 0; q < 4; q++) V[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(linv[q], Wa[J][q], V[J], 0, 0, 0);
         }
 #pragma unroll
         for (int J = 0; J < 3; J++) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                Wb[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(-o.x1[q], V[J][q], Wb[J], 0, 0, 0);
-                Wcd[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(-o.x23[q], V[J][q], Wcd[J], 0, 0, 0);
+                Wb[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[q], V[J][q], Wb[J], 0, 0, 0);
+                Wcd[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(x23[q], V[J][q], Wcd[J], 0, 0, 0);
             }
         }
         // V^T [V | y]: y_k rides in column 45 (tile 2, lane & 15 == 13), where V is identically zero
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const double v2y = V[2][q] + (li == 13 ? o.y[q] : 0.0);
+            const double v2y = V[2][q] + yv[q];
             acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[0][q], V[0][q], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[0][q], V[1][q], acc[1], 0, 0, 0);
             acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[0][q], v2y, acc[2], 0, 0, 0);
@@ -1434,6 +1439,29 @@ __global__ void __launch_bounds__(64) k_chunk_spike(View v) {
     }
 }
 
+// wave 0: forward sweep of the chunk; wave 1 (chunks c >= 1): the spike, one step behind, fed from the LDS ring
+__global__ void __launch_bounds__(128) k_chunk_forward(View v) {
+    const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
+    const int n = v.hi[w] - v.lo[w];
+    if (n <= 0) return;
+    const int Pe = chunk_count(n, P);
+    if (c >= Pe) return;
+    __shared__ double S[S_TOTAL_RING];
+    const ChunkGeom cg = chunk_geom(n, Pe, c);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 0) band_solve_body<SOLVE_CHUNK_FWD>(v, S, nullptr, nullptr, w, lane, 0, cg, v.sepR + ((size_t)w * P + c) * SEPM);
+    else if (c > 0) chunk_spike(v, S, w, c, cg, lane);
+}
+__global__ void __launch_bounds__(64) k_chunk_back(View v) {
+    const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
+    const int n = v.hi[w] - v.lo[w];
+    if (n <= 0) return;
+    const int Pe = chunk_count(n, P);
+    if (c >= Pe) return;
+    __shared__ double S[S_TOTAL];
+    band_solve_body<SOLVE_CHUNK_BWD>(v, S, nullptr, nullptr, w, threadIdx.x, 0, chunk_geom(n, Pe, c), nullptr);
+}
+
 // y_k -= V_k delta(left separator) for every interior keyframe of the chunks c >= 1
 __global__ void __launch_bounds__(256) k_chunk_rhs(View v) {
     const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
@@ -1460,108 +1488,181 @@ __global__ void __launch_bounds__(256) k_chunk_rhs(View v) {
     }
 }
 
-// Block-tridiagonal Cholesky of the separator chain, one workgroup per window.  Step s works on the
-// 90 x 90 (+ rhs) matrix [D_s, C_s^T; C_s, D_{s+1}] in LDS: 45 right-looking pivots leave the Schur
-// complement of separator s+1 in the lower block, which moves up for the next step.
-constexpr int SQ = 91;                       // LDS row stride (odd: conflict-free column walks), column 90 = rhs
+// Block-tridiagonal Cholesky of the separator chain, one workgroup per window.  Step s factors the
+// 136-row panel of separator s, one row per thread, 45 columns in registers:
+//     0..44  D_s (pivot block)    45..89  C_s (coupling to separator s+1)    90  rhs    91..135  identity
+// Column operations as in the band solver: after 45 pivots the rows hold L_ss, Z = C_s L_ss^-T, y and
+// L_ss^-T.  Multipliers cross waves through a double-buffered LDS column (one barrier per pivot).
+// D_{s+1} -= Z Z^T, rhs_{s+1} -= Z y: four waves, 12 columns each, Z rows broadcast from LDS.
+// The back substitution walks the chain in reverse with mat-vecs on the saved Z / L^-T (prefetched).
+constexpr int ZS = 46;                       // LDS row stride of the Z / D blocks (45 columns + rhs)
 __global__ void __launch_bounds__(256) k_sep_solve(View v) {
-    const int P = v.P, w = blockIdx.x, tid = threadIdx.x;
+    const int P = v.P, w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lo = v.lo[w], n = v.hi[w] - lo;
     if (n <= 0) return;
     const int Pe = chunk_count(n, P), m = Pe - 1;
     if (m <= 0) return;
-    __shared__ double A[90 * SQ];
-    __shared__ double dnext[SEP], tvec[SEP];
-    __shared__ int s_fail;
-    if (tid == 0) s_fail = 0;
-    const double* R = v.sepR + (size_t)w * P * SEPM;
-    const double* Sx = v.sepS + (size_t)w * P * SEPM;
-    const double* Cx = v.sepC + (size_t)w * P * SEP * SEP;
-    double* Lx = v.sepL + (size_t)w * P * SEPL;
-    // D_0 = R_0 + S_1
-    for (int e = tid; e < SEP * 46; e += 256) {
-        const int i = e / 46, j = e - i * 46;
-        A[i * SQ + (j == 45 ? 90 : j)] = R[e] + Sx[SEPM + e];
+    __shared__ __attribute__((aligned(16))) double colbuf[2][48];
+    __shared__ __attribute__((aligned(16))) double Zs[46 * ZS];   // Z rows 0..44, y = row 45
+    __shared__ __attribute__((aligned(16))) double Dn[92 * ZS];   // panel input: D rows 0..44, C rows 45..89, rhs row 90, zero row 91
+    __shared__ double dnext[48], tv[48];
+    const double* __restrict__ R = v.sepR + (size_t)w * P * SEPM;
+    const double* __restrict__ Sx = v.sepS + (size_t)w * P * SEPM;
+    const double* __restrict__ Cx = v.sepC + (size_t)w * P * SEP * SEP;
+    double* __restrict__ Lx = v.sepL + (size_t)w * P * SEPL;    // per separator: [91][45] = Z (45), y, L^-T (45)
+    int failed = 0;
+    // staging maps (branch-free): element e of a 45x46 block (D | rhs) and of a 45x45 coupling block
+    int d_src[9], d_dst[9], c_src[8], c_dst[8];
+    double d_on[9], c_on[8];
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+        const int e = tid + 256 * q, i = e / 46, j = e - i * 46;
+        const bool in = e < SEP * 46;
+        d_src[q] = in ? e : 0;
+        d_dst[q] = !in ? 91 * ZS + 45 : (j == 45 ? 90 * ZS + i : i * ZS + j);   // (row 91, column 45) is never read
+        d_on[q] = in ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int e = tid + 256 * q, i = e / SEP, j = e - i * SEP;
+        const bool in = e < SEP * SEP;
+        c_src[q] = in ? e : 0;
+        c_dst[q] = in ? (45 + i) * ZS + j : 91 * ZS + 45;
+        c_on[q] = in ? 1.0 : 0.0;
+    }
+    for (int e = tid; e < 92 * ZS; e += 256) Dn[e] = 0.0;
+    __syncthreads();
+    {
+        const double c1 = m > 1 ? 1.0 : 0.0;
+        const size_t co = m > 1 ? (size_t)SEP * SEP : 0;
+#pragma unroll
+        for (int q = 0; q < 9; q++) Dn[d_dst[q]] = d_on[q] * (R[d_src[q]] + Sx[SEPM + d_src[q]]);
+#pragma unroll
+        for (int q = 0; q < 8; q++) Dn[c_dst[q]] = c1 * c_on[q] * Cx[co + c_src[q]];
     }
     __syncthreads();
+    const int prow = (tid < 91 ? tid : 91) * ZS;       // this thread's panel row in Dn (91 = zeros)
+    const int idc = tid - 91;                          // identity rows: 1 at column idc
+    const int cb_w = tid < 45 ? tid : 47;              // colbuf slot (47 = sink)
+#pragma unroll 1
     for (int s = 0; s < m; s++) {
         const bool more = s + 1 < m;
-        const int rows = more ? 90 : 45;
-        if (more) {
-            for (int e = tid; e < SEP * SEP; e += 256) {
-                const int i = e / SEP, j = e - i * SEP;
-                A[(45 + i) * SQ + j] = Cx[(size_t)(s + 1) * SEP * SEP + e];
-            }
-            for (int e = tid; e < SEP * 46; e += 256) {
-                const int i = e / 46, j = e - i * 46;
-                A[(45 + i) * SQ + (j == 45 ? 90 : 45 + j)] = R[(size_t)(s + 1) * SEPM + e] + (s + 2 <= m ? Sx[(size_t)(s + 2) * SEPM + e] : 0.0);
+        double p[SEP];
+#pragma unroll
+        for (int c = 0; c < SEP; c++) p[c] = Dn[prow + c] + (c == idc ? 1.0 : 0.0);
+        // prefetch the inputs of step s+1: D_{s+1} = R_{s+1} + S_{s+2} (+ rhs) and C_{s+1}
+        double d0[9], c0[8];
+        {
+            const double f1 = more ? 1.0 : 0.0, f2 = s + 2 <= m ? 1.0 : 0.0, f3 = s + 2 < m ? 1.0 : 0.0;
+            const size_t o1 = more ? (size_t)(s + 1) * SEPM : 0, o2 = s + 2 <= m ? (size_t)(s + 2) * SEPM : 0;
+            const size_t o3 = s + 2 < m ? (size_t)(s + 2) * SEP * SEP : 0;
+#pragma unroll
+            for (int q = 0; q < 9; q++) d0[q] = d_on[q] * (f1 * R[o1 + d_src[q]] + f1 * f2 * Sx[o2 + d_src[q]]);
+#pragma unroll
+            for (int q = 0; q < 8; q++) c0[q] = f3 * c_on[q] * Cx[o3 + c_src[q]];
+        }
+        __syncthreads();   // Dn consumed
+#pragma unroll
+        for (int c = 0; c < SEP; c++) {
+            colbuf[c & 1][cb_w] = p[c];
+            __syncthreads();
+            double piv = colbuf[c & 1][c];
+            if (!(piv > 0.0)) { failed = 1; piv = 1.0; }
+            const double inv = fast_rsqrt(piv);
+            p[c] *= inv;
+            const double pc = -p[c] * inv;
+#pragma unroll
+            for (int c2 = c + 1; c2 < SEP; c2++) p[c2] = fma(pc, colbuf[c & 1][c2], p[c2]);
+        }
+        // factor rows -> HBM (back substitution), Z and y -> LDS (Schur update), next inputs -> LDS
+        if (tid >= 45 && tid < 136) {
+            double* dst = Lx + (size_t)s * SEPL + (size_t)(tid - 45) * SEP;
+#pragma unroll
+            for (int c = 0; c < SEP; c++) dst[c] = p[c];
+        }
+        if (tid >= 45 && tid <= 90) {
+#pragma unroll
+            for (int c = 0; c < SEP; c++) Zs[(tid - 45) * ZS + c] = p[c];
+        }
+#pragma unroll
+        for (int q = 0; q < 9; q++) Dn[d_dst[q]] = d0[q];
+#pragma unroll
+        for (int q = 0; q < 8; q++) Dn[c_dst[q]] = c0[q];
+        __syncthreads();
+        if (more && lane < 45) {
+            double zr[SEP];
+#pragma unroll
+            for (int c = 0; c < SEP; c++) zr[c] = Zs[lane * ZS + c];
+            const int j0 = 12 * wave, j1 = wave == 3 ? 46 : j0 + 12;
+#pragma unroll 1
+            for (int j = j0; j < j1; j++) {
+                double d0s = 0.0, d1s = 0.0, d2s = 0.0;
+#pragma unroll
+                for (int c = 0; c < SEP; c += 3) {
+                    d0s = fma(zr[c], Zs[j * ZS + c], d0s);
+                    d1s = fma(zr[c + 1], Zs[j * ZS + c + 1], d1s);
+                    d2s = fma(zr[c + 2], Zs[j * ZS + c + 2], d2s);
+                }
+                Dn[j == 45 ? 90 * ZS + lane : lane * ZS + j] -= (d0s + d1s) + d2s;
             }
         }
         __syncthreads();
-        for (int cpiv = 0; cpiv < SEP; cpiv++) {
-            const double piv = A[cpiv * SQ + cpiv];
-            if (!(piv > 0.0)) { if (tid == 0) s_fail = 1; }
-            const double l = (piv > 0.0) ? 1.0 / sqrt(piv) : 1.0;
-            __syncthreads();
-            for (int i = cpiv + tid; i < rows; i += 256) A[i * SQ + cpiv] *= l;
-            if (tid == 255) A[cpiv * SQ + 90] *= l;
-            __syncthreads();
-            const int T = rows - 1 - cpiv;            // trailing rows cpiv+1 .. rows-1; columns the same + rhs
-            for (int e = tid; e < T * (T + 1); e += 256) {
-                const int ii = e / (T + 1), jj = e - ii * (T + 1);
-                const int i = cpiv + 1 + ii;
-                if (jj == T) A[i * SQ + 90] -= A[i * SQ + cpiv] * A[cpiv * SQ + 90];
-                else if (jj <= ii) { const int j = cpiv + 1 + jj; A[i * SQ + j] -= A[i * SQ + cpiv] * A[j * SQ + cpiv]; }
-            }
-            __syncthreads();
-        }
-        // keep the factor columns (90 x 45) and y (45) for the back substitution
-        for (int e = tid; e < rows * 46; e += 256) {
-            const int i = e / 46, j = e - i * 46;
-            if (j < SEP) Lx[(size_t)s * SEPL + e] = A[i * SQ + j];
-            else if (i < SEP) Lx[(size_t)s * SEPL + e] = A[i * SQ + 90];
-        }
-        __syncthreads();
-        if (more) {
-            // Schur complement of separator s+1 (lower triangle + rhs) moves to the top-left block
-            for (int e = tid; e < SEP * 46; e += 256) {
-                const int i = e / 46, j = e - i * 46;
-                if (j == 45) A[i * SQ + 90] = A[(45 + i) * SQ + 90];
-                else if (j <= i) A[i * SQ + j] = A[(45 + i) * SQ + 45 + j];
-            }
-            __syncthreads();
-        }
     }
     // ---- back substitution along the chain, last separator first --------------------------------
+    // threads 0..44: t = y - Z^T delta(next) (column `tid` of Z); threads 64..108: delta = L^-T t (row tid-64)
+    auto load_vec = [&](int s, double (&x)[SEP], double& yv) {
+        const double* Ls = Lx + (size_t)(s < 0 ? 0 : s) * SEPL;
+        if (tid < 45) {
+#pragma unroll
+            for (int i = 0; i < SEP; i++) x[i] = Ls[i * SEP + tid];
+            yv = Ls[45 * SEP + tid];
+        } else if (tid >= 64 && tid < 109) {
+#pragma unroll
+            for (int c = 0; c < SEP; c++) x[c] = Ls[(size_t)(46 + tid - 64) * SEP + c];
+        }
+    };
+    __threadfence_block();
+    double cur[SEP], nxt[SEP], ycur = 0.0, ynxt = 0.0;
+#pragma unroll
+    for (int c = 0; c < SEP; c++) { cur[c] = 0.0; nxt[c] = 0.0; }
+    load_vec(m - 1, cur, ycur);
+    if (tid < 48) dnext[tid] = 0.0;
+    __syncthreads();
+#pragma unroll 1
     for (int s = m - 1; s >= 0; s--) {
-        const bool more = s + 1 < m;
-        const double* Ls = Lx + (size_t)s * SEPL;
-        for (int e = tid; e < SEP * 46; e += 256) {
-            const int i = e / 46, j = e - i * 46;
-            A[i * SQ + (j == 45 ? 90 : j)] = Ls[e];
-        }
-        if (tid < SEP) {
-            double t = Ls[tid * 46 + 45];
-            if (more)
-                for (int i = 0; i < SEP; i++) t = fma(-Ls[(45 + i) * 46 + tid], dnext[i], t);
-            tvec[tid] = t;
-        }
-        __syncthreads();
-        for (int cc = SEP - 1; cc >= 0; cc--) {
-            const double x = tvec[cc] / A[cc * SQ + cc];
-            __syncthreads();
-            if (tid < cc) tvec[tid] -= A[cc * SQ + tid] * x;
-            if (tid == cc) tvec[cc] = x;
-            __syncthreads();
-        }
-        const ChunkGeom cg = chunk_geom(n, Pe, s);
-        if (tid < SEP) {
-            dnext[tid] = tvec[tid];
-            v.delta[((size_t)w * v.M + lo + cg.i0 + cg.ni) * 15 + tid] = tvec[tid];
+        if (s > 0) load_vec(s - 1, nxt, ynxt);
+        if (tid < 45) {
+            double t0 = ycur, t1 = 0.0, t2 = 0.0;
+            if (s + 1 < m) {
+#pragma unroll
+                for (int i = 0; i < SEP; i += 3) {
+                    t0 = fma(-cur[i], dnext[i], t0);
+                    t1 = fma(-cur[i + 1], dnext[i + 1], t1);
+                    t2 = fma(-cur[i + 2], dnext[i + 2], t2);
+                }
+            }
+            tv[tid] = (t0 + t1) + t2;
         }
         __syncthreads();
+        if (tid >= 64 && tid < 109) {
+            double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+#pragma unroll
+            for (int c = 0; c < SEP; c += 3) {
+                x0 = fma(cur[c], tv[c], x0);
+                x1 = fma(cur[c + 1], tv[c + 1], x1);
+                x2 = fma(cur[c + 2], tv[c + 2], x2);
+            }
+            const double x = (x0 + x1) + x2;
+            dnext[tid - 64] = x;
+            const ChunkGeom cg = chunk_geom(n, Pe, s);
+            v.delta[((size_t)w * v.M + lo + cg.i0 + cg.ni) * 15 + tid - 64] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < SEP; c++) cur[c] = nxt[c];
+        ycur = ynxt;
     }
-    if (tid == 0 && s_fail) atomicOr(v.fail + w, 1);
+    if (failed && tid == 0) atomicOr(v.fail + w, 1);
 }
 
 #ifdef VF_SOLVE_STAMPS
@@ -1896,8 +1997,7 @@ void launch_assemble(const View& v, hipStream_t s) {
 }
 void launch_partitioned_solve(const View& v, hipStream_t s) {
     const unsigned nb = (unsigned)v.B * (unsigned)v.P;
-    hipLaunchKernelGGL(k_chunk_forward, dim3(nb), dim3(64), 0, s, v);
-    hipLaunchKernelGGL(k_chunk_spike, dim3(nb), dim3(64), 0, s, v);
+    hipLaunchKernelGGL(k_chunk_forward, dim3(nb), dim3(128), 0, s, v);
     hipLaunchKernelGGL(k_sep_solve, dim3(v.B), dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_chunk_rhs, dim3(nb), dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_chunk_back, dim3(nb), dim3(64), 0, s, v);

@@ -23,7 +23,12 @@ constexpr int VROW = 15 * 48;   // spike rows of one keyframe: 15 dof x 45 separ
 
 // chunk geometry of an n-keyframe window cut into (at most) P chunks: interiors of L keyframes
 // (L a multiple of 4), 3 separator keyframes between consecutive chunks, the last chunk takes the rest
-__host__ __device__ inline int chunk_len(int n, int P) { return ((n - 3 * (P - 1)) / P) & ~3; }
+__host__ __device__ inline int chunk_len(int n, int P) {
+    const int total = n - 3 * (P - 1);                 // interior keyframes
+    if (total < 8 * P) return total > 0 ? (total / P) & ~3 : 0;
+    const int up = ((total + P - 1) / P + 3) & ~3;     // round up: the last chunk gets the (smaller) rest
+    return n - (P - 1) * (up + 3) >= 8 ? up : (total / P) & ~3;
+}
 __host__ __device__ inline int chunk_count(int n, int P) {
     while (P > 1 && chunk_len(n, P) < 8) P--;
     return P < 1 ? 1 : P;

@@ -1,5 +1,7 @@
 import sys, os, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from vil_sensor_fusion_amd import _lib
+if os.environ.get('VF_VARIANT'): _lib._SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libvf_' + os.environ['VF_VARIANT'] + '.so')
 from vil_sensor_fusion_amd import Engine, EngineOpts, synth
 from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000

@@ -1488,184 +1488,236 @@ __global__ void __launch_bounds__(256) k_chunk_rhs(View v) {
     }
 }
 
-// Block-tridiagonal Cholesky of the separator chain, one workgroup per window.  Step s factors the
-// 136-row panel of separator s, one row per thread, 45 columns in registers:
-//     0..44  D_s (pivot block)    45..89  C_s (coupling to separator s+1)    90  rhs    91..135  identity
-// Column operations as in the band solver: after 45 pivots the rows hold L_ss, Z = C_s L_ss^-T, y and
-// L_ss^-T.  Multipliers cross waves through a double-buffered LDS column (one barrier per pivot).
-// D_{s+1} -= Z Z^T, rhs_{s+1} -= Z y: four waves, 12 columns each, Z rows broadcast from LDS.
-// The back substitution walks the chain in reverse with mat-vecs on the saved Z / L^-T (prefetched).
+// Block-tridiagonal Cholesky of the separator chain, one workgroup (3 waves) per window.
+// Forward: step s factors the 91-row panel of separator s, one row per thread of waves 0-1, 45 columns in
+// registers:     0..44  D_s (pivot block)      45..89  C_s (coupling to separator s+1)      90  rhs
+// Column operations as in the band solver: after 45 pivots the rows hold L_ss, Z = C_s L_ss^-T and y.
+// Column c of the pivot rows crosses the waves through a triple-buffered LDS column (one LDS-only barrier
+// per pivot); only column c+1 is updated on the critical path, the others after the next barrier in the
+// shadow of its rsqrt.  Wave 2 owns no rows: it stages the inputs of step s+1 (global -> registers at the
+// start of the step, -> LDS after the pivots) so that no global latency sits on the chain.
+// D_{s+1} -= Z Z^T, rhs_{s+1} -= Z y: nine 16x16 MFMA tiles, three per wave, operands from the Z rows in LDS.
+// Backward: wave 0 solves L_ss^T delta_s = y_s - Z_s^T delta_{s+1} (increment broadcast by v_readlane,
+// no barriers inside a separator) while waves 1-2 copy the factor of separator s-1 from HBM into LDS.
+// Measured cost and what bounds it: DESIGN.md "K4p".
 constexpr int ZS = 46;                       // LDS row stride of the Z / D blocks (45 columns + rhs)
-__global__ void __launch_bounds__(256) k_sep_solve(View v) {
-    const int P = v.P, w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+constexpr int LXS = 96;                      // HBM: factor of one separator, column-major [45][96]: rows 0..44 L, 45..89 Z, 90 y
+constexpr int FS = 97;                       // LDS row stride of the factor copy (odd: conflict-free row walks)
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for
+// the stager's global loads and the factor stores at every one of the 45 pivot barriers of a step
+#define LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#ifdef VF_SOLVE_STAMPS
+__device__ unsigned long long g_sep_stamps[16];
+#define SSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _t; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); sst[i] += _t - stprev; stprev = _t; } while (0)
+#else
+#define SSTAMP(i) do {} while (0)
+#endif
+static_assert(SEPL >= SEP * LXS, "factor block does not fit its HBM slot");
+__global__ void __launch_bounds__(192) k_sep_solve(View v) {
+    const int P = v.P, w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches on the role
     const int lo = v.lo[w], n = v.hi[w] - lo;
     if (n <= 0) return;
     const int Pe = chunk_count(n, P), m = Pe - 1;
     if (m <= 0) return;
-    __shared__ __attribute__((aligned(16))) double colbuf[2][48];
-    __shared__ __attribute__((aligned(16))) double Zs[46 * ZS];   // Z rows 0..44, y = row 45
-    __shared__ __attribute__((aligned(16))) double Dn[92 * ZS];   // panel input: D rows 0..44, C rows 45..89, rhs row 90, zero row 91
-    __shared__ double dnext[48], tv[48];
+    __shared__ __attribute__((aligned(16))) double colbuf[3][48];  // column c of the pivot rows (47 = sink of the other rows)
+    __shared__ __attribute__((aligned(16))) double Zs[46 * ZS];    // Z rows 0..44, y = row 45
+    __shared__ __attribute__((aligned(16))) double Dn[92 * ZS];    // panel input: D rows 0..44, C rows 45..89, rhs row 90, zero row 91
+    __shared__ double Fb[2][SEP * FS];                             // backward sweep: factor of the current / next separator
+    __shared__ double dnext[48];
     const double* __restrict__ R = v.sepR + (size_t)w * P * SEPM;
-    const double* __restrict__ Sx = v.sepS + (size_t)w * P * SEPM;
+    const double* __restrict__ Sx = v.sepS + (size_t)w * P * SEPM;      // slot 0 is never written: 2070 zeros
     const double* __restrict__ Cx = v.sepC + (size_t)w * P * SEP * SEP;
-    double* __restrict__ Lx = v.sepL + (size_t)w * P * SEPL;    // per separator: [91][45] = Z (45), y, L^-T (45)
+    double* __restrict__ Lx = v.sepL + (size_t)w * P * SEPL;
     int failed = 0;
-    // staging maps (branch-free): element e of a 45x46 block (D | rhs) and of a 45x45 coupling block
-    int d_src[9], d_dst[9], c_src[8], c_dst[8];
-    double d_on[9], c_on[8];
-#pragma unroll
-    for (int q = 0; q < 9; q++) {
-        const int e = tid + 256 * q, i = e / 46, j = e - i * 46;
-        const bool in = e < SEP * 46;
-        d_src[q] = in ? e : 0;
-        d_dst[q] = !in ? 91 * ZS + 45 : (j == 45 ? 90 * ZS + i : i * ZS + j);   // (row 91, column 45) is never read
-        d_on[q] = in ? 1.0 : 0.0;
-    }
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const int e = tid + 256 * q, i = e / SEP, j = e - i * SEP;
-        const bool in = e < SEP * SEP;
-        c_src[q] = in ? e : 0;
-        c_dst[q] = in ? (45 + i) * ZS + j : 91 * ZS + 45;
-        c_on[q] = in ? 1.0 : 0.0;
-    }
-    for (int e = tid; e < 92 * ZS; e += 256) Dn[e] = 0.0;
+    for (int e = tid; e < 92 * ZS; e += 192) Dn[e] = 0.0;
     __syncthreads();
-    {
-        const double c1 = m > 1 ? 1.0 : 0.0;
-        const size_t co = m > 1 ? (size_t)SEP * SEP : 0;
-#pragma unroll
-        for (int q = 0; q < 9; q++) Dn[d_dst[q]] = d_on[q] * (R[d_src[q]] + Sx[SEPM + d_src[q]]);
-#pragma unroll
-        for (int q = 0; q < 8; q++) Dn[c_dst[q]] = c1 * c_on[q] * Cx[co + c_src[q]];
-    }
+    // staged element (i, j) of a [45][46] (D | rhs) block / of a [45][45] coupling block -> panel input
+    auto dst_d = [](int e) { const int i = e / 46, j = e - i * 46; return e < SEP * 46 ? (j == 45 ? 90 * ZS + i : i * ZS + j) : 91 * ZS + 45; };
+    auto dst_c = [](int e) { const int i = e / SEP, j = e - i * SEP; return e < SEP * SEP ? (45 + i) * ZS + j : 91 * ZS + 45; };
+    for (int e = tid; e < SEP * 46; e += 192) Dn[dst_d(e)] = R[e] + Sx[SEPM + e];
+    if (m > 1) for (int e = tid; e < SEP * SEP; e += 192) Dn[dst_c(e)] = Cx[(size_t)SEP * SEP + e];
     __syncthreads();
     const int prow = (tid < 91 ? tid : 91) * ZS;       // this thread's panel row in Dn (91 = zeros)
-    const int idc = tid - 91;                          // identity rows: 1 at column idc
-    const int cb_w = tid < 45 ? tid : 47;              // colbuf slot (47 = sink)
+    double* col_w = &colbuf[0][tid < 45 ? tid : 47];   // one base register + immediates (nothing per-column to hoist)
+    // LDS reads at compile-time addresses go through ONE opaque base register so that every access is
+    // base + immediate (otherwise each constant address is materialised in its own VGPR, hoisted out of
+    // the loop, and the register file is gone: the reads then serialise on a single destination register)
+    int zero_v;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
+    const double* cb = &colbuf[0][0] + zero_v;
+#ifndef VF_SEP_SKIP
+#define VF_SEP_SKIP 0
+#endif
+#ifdef VF_SOLVE_STAMPS
+    unsigned long long sst[16] = {0}, stprev = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll 1
     for (int s = 0; s < m; s++) {
         const bool more = s + 1 < m;
-        double p[SEP];
+        SSTAMP(0);
+        if (wave == 2) {
+            // ---- stager: D_{s+1} = R_{s+1} + S_{s+2} (+ rhs) and C_{s+1}.  Absent terms read the zero slot, so the
+            // loads are unconditional and nothing is computed on them before the pivot barriers are behind us.
+            int sz;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(sz));      // opaque zero: keeps the element maps inside the loop
+            const double* pa = more ? R + (size_t)(s + 1) * SEPM : Sx;
+            const double* pb = (more && s + 2 <= m) ? Sx + (size_t)(s + 2) * SEPM : Sx;
+            const double* pc = s + 2 < m ? Cx + (size_t)(s + 2) * SEP * SEP : Sx;
+            LDS_BARRIER();   // Dn consumed (the stager arrives first: nothing of its work sits in front of the pivots)
+            // one slice of the staging work (3 loads + 2 destinations) between two pivot barriers, so that the
+            // stager is never the last wave to arrive
+            double ba[33], bb[33], bc[33];
+            int da[33], dc[33];
 #pragma unroll
-        for (int c = 0; c < SEP; c++) p[c] = Dn[prow + c] + (c == idc ? 1.0 : 0.0);
-        // prefetch the inputs of step s+1: D_{s+1} = R_{s+1} + S_{s+2} (+ rhs) and C_{s+1}
-        double d0[9], c0[8];
-        {
-            const double f1 = more ? 1.0 : 0.0, f2 = s + 2 <= m ? 1.0 : 0.0, f3 = s + 2 < m ? 1.0 : 0.0;
-            const size_t o1 = more ? (size_t)(s + 1) * SEPM : 0, o2 = s + 2 <= m ? (size_t)(s + 2) * SEPM : 0;
-            const size_t o3 = s + 2 < m ? (size_t)(s + 2) * SEP * SEP : 0;
-#pragma unroll
-            for (int q = 0; q < 9; q++) d0[q] = d_on[q] * (f1 * R[o1 + d_src[q]] + f1 * f2 * Sx[o2 + d_src[q]]);
-#pragma unroll
-            for (int q = 0; q < 8; q++) c0[q] = f3 * c_on[q] * Cx[o3 + c_src[q]];
-        }
-        __syncthreads();   // Dn consumed
-#pragma unroll
-        for (int c = 0; c < SEP; c++) {
-            colbuf[c & 1][cb_w] = p[c];
-            __syncthreads();
-            double piv = colbuf[c & 1][c];
-            if (!(piv > 0.0)) { failed = 1; piv = 1.0; }
-            const double inv = fast_rsqrt(piv);
-            p[c] *= inv;
-            const double pc = -p[c] * inv;
-#pragma unroll
-            for (int c2 = c + 1; c2 < SEP; c2++) p[c2] = fma(pc, colbuf[c & 1][c2], p[c2]);
-        }
-        // factor rows -> HBM (back substitution), Z and y -> LDS (Schur update), next inputs -> LDS
-        if (tid >= 45 && tid < 136) {
-            double* dst = Lx + (size_t)s * SEPL + (size_t)(tid - 45) * SEP;
-#pragma unroll
-            for (int c = 0; c < SEP; c++) dst[c] = p[c];
-        }
-        if (tid >= 45 && tid <= 90) {
-#pragma unroll
-            for (int c = 0; c < SEP; c++) Zs[(tid - 45) * ZS + c] = p[c];
-        }
-#pragma unroll
-        for (int q = 0; q < 9; q++) Dn[d_dst[q]] = d0[q];
-#pragma unroll
-        for (int q = 0; q < 8; q++) Dn[c_dst[q]] = c0[q];
-        __syncthreads();
-        if (more && lane < 45) {
-            double zr[SEP];
-#pragma unroll
-            for (int c = 0; c < SEP; c++) zr[c] = Zs[lane * ZS + c];
-            const int j0 = 12 * wave, j1 = wave == 3 ? 46 : j0 + 12;
-#pragma unroll 1
-            for (int j = j0; j < j1; j++) {
-                double d0s = 0.0, d1s = 0.0, d2s = 0.0;
-#pragma unroll
-                for (int c = 0; c < SEP; c += 3) {
-                    d0s = fma(zr[c], Zs[j * ZS + c], d0s);
-                    d1s = fma(zr[c + 1], Zs[j * ZS + c + 1], d1s);
-                    d2s = fma(zr[c + 2], Zs[j * ZS + c + 2], d2s);
+            for (int c = 0; c < SEP; c++) {
+                if (c < 33 && !(VF_SEP_SKIP & 4)) {
+                    const int e = lane + 64 * c + sz, ed = e < SEP * 46 ? e : 0;
+                    ba[c] = pa[ed];
+                    bb[c] = pb[ed];
+                    da[c] = dst_d(e);
+                    bc[c] = pc[e < SEP * SEP ? e : 0];
+                    dc[c] = dst_c(e);
                 }
-                Dn[j == 45 ? 90 * ZS + lane : lane * ZS + j] -= (d0s + d1s) + d2s;
+                if (!(VF_SEP_SKIP & 4)) LDS_BARRIER();
+            }
+#pragma unroll
+            for (int q = 0; q < 33; q++) { Dn[da[q]] = ba[q] + bb[q]; Dn[dc[q]] = bc[q]; }
+        } else {
+            // ---- panel rows ----
+            double p[SEP];
+#pragma unroll
+            for (int c = 0; c < SEP; c++) p[c] = Dn[prow + c];
+            LDS_BARRIER();   // Dn consumed
+            SSTAMP(1);
+            double pc_prev = 0.0;
+#pragma unroll
+            for (int c = 0; c < ((VF_SEP_SKIP & 4) ? 0 : SEP); c++) {
+                col_w[(c % 3) * 48] = p[c];
+                LDS_BARRIER();
+                double piv = cb[(c % 3) * 48 + c];
+                double mv[SEP];          // multipliers of the previous pivot: all LDS reads in flight together
+                if (c > 0) {
+#pragma unroll
+                    for (int c2 = c + 1; c2 < SEP; c2++) mv[c2] = cb[((c - 1) % 3) * 48 + c2];
+                }
+                __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler serialises read -> wait -> fma pairs)
+                if (!(piv > 0.0)) { failed = 1; piv = 1.0; }
+                const double inv = fast_rsqrt(piv);
+                if (c > 0) {
+#pragma unroll
+                    for (int c2 = c + 1; c2 < SEP; c2++) p[c2] = fma(pc_prev, mv[c2], p[c2]);
+                }
+                p[c] *= inv;
+                pc_prev = -p[c] * inv;
+                if (c + 1 < SEP) p[c + 1] = fma(pc_prev, cb[(c % 3) * 48 + c + 1], p[c + 1]);
+            }
+            SSTAMP(2);
+            // factor rows -> HBM, column-major: one contiguous 8-byte-per-lane store per column
+            if (tid < 91 && !(VF_SEP_SKIP & 1)) {
+                double* dst = Lx + (size_t)s * SEPL + tid;
+#pragma unroll
+                for (int c = 0; c < SEP; c++) dst[c * LXS] = p[c];
+            }
+            if (tid >= 45 && tid <= 90) {
+#pragma unroll
+                for (int c = 0; c < SEP; c++) Zs[(tid - 45) * ZS + c] = p[c];
             }
         }
-        __syncthreads();
+        LDS_BARRIER();
+        SSTAMP(3);
+        if (more && !(VF_SEP_SKIP & 2)) {
+            // D_{s+1} -= Z Z^T, rhs_{s+1} -= Z y on the matrix cores: 3 x 3 tiles of 16 x 16, three per wave,
+            // K = 45 (12 steps of 4); both operands come from the Z rows in LDS (row 45 = y)
+            const int li = lane & 15, lq = lane >> 4;
+#pragma unroll 1
+            for (int t = wave; t < 9; t += 3) {
+                const int I = t / 3, J = t - I * 3;
+                const int ri = 16 * I + li, rj = 16 * J + li;
+                const int oa = ri < 45 ? ri * ZS : 0, ob = rj < 46 ? rj * ZS : 0;   // rows beyond Z: masked below
+                d4_t acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 12; q++) {
+                    const int kc = 4 * q + lq;
+                    const double a = (ri < 45 && kc < 45) ? Zs[oa + kc] : 0.0;
+                    const double bq = (rj < 46 && kc < 45) ? Zs[ob + kc] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int i = 16 * I + lq + 4 * r, j = 16 * J + li;
+                    if (i < 45 && j < 46) Dn[j == 45 ? 90 * ZS + i : i * ZS + j] -= acc[r];
+                }
+            }
+        }
+        LDS_BARRIER();
     }
+    SSTAMP(4);
+    __syncthreads();   // the factor blocks in HBM (written by other threads of the workgroup) are read back below
     // ---- back substitution along the chain, last separator first --------------------------------
-    // threads 0..44: t = y - Z^T delta(next) (column `tid` of Z); threads 64..108: delta = L^-T t (row tid-64)
-    auto load_vec = [&](int s, double (&x)[SEP], double& yv) {
-        const double* Ls = Lx + (size_t)(s < 0 ? 0 : s) * SEPL;
-        if (tid < 45) {
+    // HBM -> LDS copy of one factor block: [45 columns][91 rows], rows contiguous -> Fb[c * FS + r]
+    // (all loads of a thread are issued before the first LDS write: 34 independent round trips, not 34 serial ones)
+    auto copy_factor = [&](int s, int buf, int t0) {     // 128 threads: t0 = 0..127
+        const double* Ls = Lx + (size_t)s * SEPL;
+        double x[34];
 #pragma unroll
-            for (int i = 0; i < SEP; i++) x[i] = Ls[i * SEP + tid];
-            yv = Ls[45 * SEP + tid];
-        } else if (tid >= 64 && tid < 109) {
+        for (int q = 0; q < 34; q++) { const int e = t0 + 128 * q; x[q] = Ls[e < SEP * LXS ? e : 0]; }
 #pragma unroll
-            for (int c = 0; c < SEP; c++) x[c] = Ls[(size_t)(46 + tid - 64) * SEP + c];
+        for (int q = 0; q < 34; q++) {
+            const int e = t0 + 128 * q, c = e / LXS, r = e - c * LXS;
+            if (e < SEP * LXS && r < 91) Fb[buf][c * FS + r] = x[q];
         }
     };
-    __threadfence_block();
-    double cur[SEP], nxt[SEP], ycur = 0.0, ynxt = 0.0;
-#pragma unroll
-    for (int c = 0; c < SEP; c++) { cur[c] = 0.0; nxt[c] = 0.0; }
-    load_vec(m - 1, cur, ycur);
+    if (wave != 0) copy_factor(m - 1, (m - 1) & 1, tid - 64);
     if (tid < 48) dnext[tid] = 0.0;
     __syncthreads();
 #pragma unroll 1
-    for (int s = m - 1; s >= 0; s--) {
-        if (s > 0) load_vec(s - 1, nxt, ynxt);
-        if (tid < 45) {
-            double t0 = ycur, t1 = 0.0, t2 = 0.0;
+    for (int s = (VF_SEP_SKIP & 8) ? -1 : m - 1; s >= 0; s--) {
+        if (wave != 0) {
+            if (s > 0) copy_factor(s - 1, (s - 1) & 1, tid - 64);
+        } else {
+            // thread j < 45 owns column j: F[j * FS + r] = L[r][j] (r >= j), Z[i][j] at row 45 + i, y_j at row 90
+            const double* F = Fb[s & 1] + (lane < 45 ? lane : 0) * FS;
+            double t0 = F[90], t1 = 0.0, t2 = 0.0;
             if (s + 1 < m) {
 #pragma unroll
                 for (int i = 0; i < SEP; i += 3) {
-                    t0 = fma(-cur[i], dnext[i], t0);
-                    t1 = fma(-cur[i + 1], dnext[i + 1], t1);
-                    t2 = fma(-cur[i + 2], dnext[i + 2], t2);
+                    t0 = fma(-F[45 + i], dnext[i], t0);
+                    t1 = fma(-F[45 + i + 1], dnext[i + 1], t1);
+                    t2 = fma(-F[45 + i + 2], dnext[i + 2], t2);
                 }
             }
-            tv[tid] = (t0 + t1) + t2;
-        }
-        __syncthreads();
-        if (tid >= 64 && tid < 109) {
-            double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+            double t = (t0 + t1) + t2;
+            double Lc[SEP];
 #pragma unroll
-            for (int c = 0; c < SEP; c += 3) {
-                x0 = fma(cur[c], tv[c], x0);
-                x1 = fma(cur[c + 1], tv[c + 1], x1);
-                x2 = fma(cur[c + 2], tv[c + 2], x2);
+            for (int c = 0; c < SEP; c++) Lc[c] = F[c];
+            const double invd = 1.0 / F[lane < 45 ? lane : 0];       // 1 / L_jj
+            // L^T x = t, last unknown first: x_c = t_c / L_cc, then t_j -= L[c][j] x_c for j < c
+#pragma unroll
+            for (int c = SEP - 1; c >= 0; c--) {
+                const double xc = readlane_d(t * invd, c);
+                t = lane == c ? xc : (lane < c ? fma(-Lc[c], xc, t) : t);
             }
-            const double x = (x0 + x1) + x2;
-            dnext[tid - 64] = x;
-            const ChunkGeom cg = chunk_geom(n, Pe, s);
-            v.delta[((size_t)w * v.M + lo + cg.i0 + cg.ni) * 15 + tid - 64] = x;
+            if (lane < 45) {
+                dnext[lane] = t;
+                const ChunkGeom cg = chunk_geom(n, Pe, s);
+                v.delta[((size_t)w * v.M + lo + cg.i0 + cg.ni) * 15 + lane] = t;
+            }
         }
         __syncthreads();
-#pragma unroll
-        for (int c = 0; c < SEP; c++) cur[c] = nxt[c];
-        ycur = ynxt;
     }
+    SSTAMP(5);
+#ifdef VF_SOLVE_STAMPS
+    if (w == 0 && tid == 0) for (int i = 0; i < 16; i++) g_sep_stamps[i] = sst[i];
+#endif
     if (failed && tid == 0) atomicOr(v.fail + w, 1);
 }
 
 #ifdef VF_SOLVE_STAMPS
+extern "C" int vf_debug_sep_stamps(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sep_stamps), 16 * sizeof(unsigned long long));
+}
 extern "C" int vf_debug_solve_stamps(unsigned long long* out) {
     (void)hipDeviceSynchronize();
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long));
@@ -1998,7 +2050,7 @@ void launch_assemble(const View& v, hipStream_t s) {
 void launch_partitioned_solve(const View& v, hipStream_t s) {
     const unsigned nb = (unsigned)v.B * (unsigned)v.P;
     hipLaunchKernelGGL(k_chunk_forward, dim3(nb), dim3(128), 0, s, v);
-    hipLaunchKernelGGL(k_sep_solve, dim3(v.B), dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_sep_solve, dim3(v.B), dim3(192), 0, s, v);
     hipLaunchKernelGGL(k_chunk_rhs, dim3(nb), dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_chunk_back, dim3(nb), dim3(64), 0, s, v);
 }

@@ -18,7 +18,7 @@ constexpr int PANEL = 43 * 16;  // Cholesky panel in HBM: 43 rows (27 sub-diagon
 // partitioned solve (K4p): a window is cut into P chunks separated by 3-keyframe (45-dof) separators
 constexpr int SEP = 45;
 constexpr int SEPM = SEP * 46;  // 45x45 block + right-hand side column
-constexpr int SEPL = 90 * 46;   // factor columns of one separator elimination: 90 rows x (45 + y)
+constexpr int SEPL = 45 * 96;   // factor of one separator elimination, column-major [45][96]: L (45 rows), Z (45), y
 constexpr int VROW = 15 * 48;   // spike rows of one keyframe: 15 dof x 45 separator columns (48 stored)
 
 // chunk geometry of an n-keyframe window cut into (at most) P chunks: interiors of L keyframes
@@ -73,7 +73,7 @@ struct View {
     double* sepR;       // [B][P][45][46]      separator block + rhs left by the forward sweep of chunk c
     double* sepS;       // [B][P][45][46]      Schur term of chunk c on its LEFT separator (c >= 1)
     double* sepC;       // [B][P][45][45]      coupling (right separator of chunk c) x (left separator of chunk c)
-    double* sepL;       // [B][P][90][46]      factor columns of the separator chain (for its back substitution)
+    double* sepL;       // [B][P][45][96]      factors of the separator chain, column-major (for its back substitution)
     int* lo;            // [B] active range [lo, hi)
     int* hi;
     int* sel;           // [B] which buffer is current

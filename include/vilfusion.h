@@ -58,9 +58,10 @@ typedef struct {
     int device;             /* HIP device ordinal */
     double gravity[3];      /* n_gravity; MakeSharedU => (0,0,-9.81) (ImuManagerRos.cpp:16) */
     double lambda0, lambda_up, lambda_down, lambda_min, lambda_max; /* LM damping schedule */
-    int chunks;             /* K4 form: 0 = one sweep per window (two-sided when windows <= 256);
-                               P >= 2 = partitioned solve, P chunks per window joined by 45-dof
-                               separators (one-window latency; per-GPU piece of the time-sharded smoother) */
+    int chunks;             /* K4 form.  0 = chosen from the batch size: up to 32 windows -> partitioned
+                               solve (chunks joined by 45-dof separators, about sqrt(0.22 n) of them for an
+                               n-keyframe window: one-window latency); more windows -> one sweep per window
+                               (throughput).  1 = always sweeps.  P >= 2 = partitioned solve with P chunks. */
 } vf_engine_opts;
 
 void vf_engine_default_opts(vf_engine_opts* o);

@@ -143,35 +143,37 @@ def test_lm_trajectory_parity(setup, oracle):
         print("   ATE vs ground truth", gt_ate)
 
 
-@pytest.mark.parametrize("n,iters", [(1000, 5), (10000, 3)])
-def test_full_size_windows_vs_oracle(oracle, n, iters):
+@pytest.mark.parametrize("n,iters,chunks", [(1000, 5, 0), (1000, 5, 1), (10000, 3, 0), (10000, 3, 1)])
+def test_full_size_windows_vs_oracle(oracle, n, iters, chunks):
     """BASELINE.json configs at full size: the 1000-pose window the metric is quoted on and the
-    10 000-pose global smoother (here on one GPU), LM trajectory against the oracle."""
+    10 000-pose global smoother (here on one GPU), LM trajectory against the oracle; with the
+    partitioned solve (chunks=0: what one window gets by default) and with whole-window sweeps."""
     from vil_sensor_fusion_amd import Engine, EngineOpts
     seq = synth.make_sequence(seed=5, n_kf=n)
     prob = helpers.build_problem(oracle, seq)
-    eng = Engine(EngineOpts(windows=1, capacity=n))
+    eng = Engine(EngineOpts(windows=1, capacity=n, chunks=chunks))
     helpers.load_engine(eng, 0, prob)
     eng.iterate(iters)
     win = helpers.oracle_window(oracle, prob)
     costs, acc, _ = win.lm(iterations=iters)
     ate, rot = helpers.ate(eng.get_states(0, 0, n), win.states)
     lm = eng.read_lm(0)
-    print(f"N={n}: ATE {ate:.3e} m rot {rot:.3e} rad; cost gpu {lm['cost']:.6e} oracle {costs[-1]:.6e}; "
+    print(f"N={n} chunks={chunks}: ATE {ate:.3e} m rot {rot:.3e} rad; cost gpu {lm['cost']:.6e} oracle {costs[-1]:.6e}; "
           f"accepted gpu {lm['accepted']} oracle {int(acc.sum())}")
     assert ate <= 1e-6 and rot <= 1e-6
     assert lm["solve_failures"] == 0
 
 
-@pytest.mark.parametrize("extra_windows", [0, 300])
-def test_both_solver_forms_vs_oracle(oracle, extra_windows):
-    """The band solver has two forms: two waves per window from both ends (used for <= 256
-    windows) and one wave per window (more windows).  Empty extra windows select the second."""
+@pytest.mark.parametrize("extra_windows,chunks", [(0, 1), (300, 1), (300, 0), (0, 0)])
+def test_both_solver_forms_vs_oracle(oracle, extra_windows, chunks):
+    """The whole-window band solver has two forms: two waves per window from both ends (used for
+    <= 256 windows) and one wave per window (more windows); empty extra windows select the second.
+    chunks=0 lets the engine choose: partitioned solve for the single window, sweeps for 301."""
     from vil_sensor_fusion_amd import Engine, EngineOpts
     n = 333                                   # not a multiple of 4: pads on the reverse sweep
     seq = synth.make_sequence(seed=9, n_kf=n)
     prob = helpers.build_problem(oracle, seq, perturb=0.01)
-    eng = Engine(EngineOpts(windows=1 + extra_windows, capacity=n + 3))
+    eng = Engine(EngineOpts(windows=1 + extra_windows, capacity=n + 3, chunks=chunks))
     helpers.load_engine(eng, 0, prob)
     eng.linearize(0); eng.assemble(); eng.solve()
     H, g = eng.read_normal(0, 0, n)
@@ -180,7 +182,7 @@ def test_both_solver_forms_vs_oracle(oracle, extra_windows):
     Hl, gl = H.astype(np.longdouble), g.astype(np.longdouble)
     bg = float(np.abs(band_matvec(Hl, np.longdouble(1e-5), d.astype(np.longdouble)) + gl).max() / np.abs(gl).max())
     bo = float(np.abs(band_matvec(Hl, np.longdouble(1e-5), do.astype(np.longdouble)) + gl).max() / np.abs(gl).max())
-    print(f"extra={extra_windows}: backward error gpu {bg:.3e} oracle {bo:.3e} forward diff {relerr(d, do):.3e}")
+    print(f"extra={extra_windows} chunks={chunks}: backward error gpu {bg:.3e} oracle {bo:.3e} forward diff {relerr(d, do):.3e}")
     assert bg < 1e-9 and bg < 50 * bo + 1e-13 and relerr(d, do) < 1e-3
     eng.iterate(5)
     win = helpers.oracle_window(oracle, prob)

@@ -140,7 +140,11 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.gvec, G * 15);
     AL(v.delta, G * 15);
     AL(v.Lp, G * vf::PANEL);
-    v.P = o->chunks >= 2 ? o->chunks : 0;
+    // K4 form: chunks = 0 picks it from the batch size: up to 32 windows -> partitioned solve with at
+    // most 48 chunks, fewer on short windows (latency form); more windows -> one sweep per window
+    // (throughput form; the partitioned solve does about twice the arithmetic).  1 forces sweeps.
+    v.P = o->chunks >= 2 ? o->chunks : (o->chunks == 0 && o->windows <= 32 ? 48 : 0);
+    v.P_fit = o->chunks == 0 ? 1 : 0;
     if (v.P) {
         const size_t BP = (size_t)v.B * v.P;
         AL(v.Vp, G * vf::VROW);

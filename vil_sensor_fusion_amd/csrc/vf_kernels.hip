@@ -1444,7 +1444,7 @@ __global__ void __launch_bounds__(128) k_chunk_forward(View v) {
     const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
     const int n = v.hi[w] - v.lo[w];
     if (n <= 0) return;
-    const int Pe = chunk_count(n, P);
+    const int Pe = chunk_count(n, P, v.P_fit);
     if (c >= Pe) return;
     __shared__ double S[S_TOTAL_RING];
     const ChunkGeom cg = chunk_geom(n, Pe, c);
@@ -1456,7 +1456,7 @@ __global__ void __launch_bounds__(64) k_chunk_back(View v) {
     const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
     const int n = v.hi[w] - v.lo[w];
     if (n <= 0) return;
-    const int Pe = chunk_count(n, P);
+    const int Pe = chunk_count(n, P, v.P_fit);
     if (c >= Pe) return;
     __shared__ double S[S_TOTAL];
     band_solve_body<SOLVE_CHUNK_BWD>(v, S, nullptr, nullptr, w, threadIdx.x, 0, chunk_geom(n, Pe, c), nullptr);
@@ -1467,7 +1467,7 @@ __global__ void __launch_bounds__(256) k_chunk_rhs(View v) {
     const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
     const int lo = v.lo[w], n = v.hi[w] - lo;
     if (n <= 0) return;
-    const int Pe = chunk_count(n, P);
+    const int Pe = chunk_count(n, P, v.P_fit);
     if (c == 0 || c >= Pe) return;
     const ChunkGeom cg = chunk_geom(n, Pe, c);
     const size_t base = (size_t)w * v.M + lo + cg.i0;
@@ -1503,6 +1503,7 @@ __global__ void __launch_bounds__(256) k_chunk_rhs(View v) {
 constexpr int ZS = 46;                       // LDS row stride of the Z / D blocks (45 columns + rhs)
 constexpr int LXS = 96;                      // HBM: factor of one separator, column-major [45][96]: rows 0..44 L, 45..89 Z, 90 y
 constexpr int FS = 97;                       // LDS row stride of the factor copy (odd: conflict-free row walks)
+constexpr int ZZ = 49;                       // LDS row stride of the Z rows (odd; zero padding = MFMA K and tile remainders)
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for
 // the stager's global loads and the factor stores at every one of the 45 pivot barriers of a step
 #define LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
@@ -1518,10 +1519,10 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches on the role
     const int lo = v.lo[w], n = v.hi[w] - lo;
     if (n <= 0) return;
-    const int Pe = chunk_count(n, P), m = Pe - 1;
+    const int Pe = chunk_count(n, P, v.P_fit), m = Pe - 1;
     if (m <= 0) return;
     __shared__ __attribute__((aligned(16))) double colbuf[3][48];  // column c of the pivot rows (47 = sink of the other rows)
-    __shared__ __attribute__((aligned(16))) double Zs[46 * ZS];    // Z rows 0..44, y = row 45
+    __shared__ double Zs[48 * ZZ];                                 // Z rows 0..44, y = row 45; rows 46, 47 and columns 45..48 stay zero
     __shared__ __attribute__((aligned(16))) double Dn[92 * ZS];    // panel input: D rows 0..44, C rows 45..89, rhs row 90, zero row 91
     __shared__ double Fb[2][SEP * FS];                             // backward sweep: factor of the current / next separator
     __shared__ double dnext[48];
@@ -1531,6 +1532,7 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
     double* __restrict__ Lx = v.sepL + (size_t)w * P * SEPL;
     int failed = 0;
     for (int e = tid; e < 92 * ZS; e += 192) Dn[e] = 0.0;
+    for (int e = tid; e < 48 * ZZ; e += 192) Zs[e] = 0.0;
     __syncthreads();
     // staged element (i, j) of a [45][46] (D | rhs) block / of a [45][45] coupling block -> panel input
     auto dst_d = [](int e) { const int i = e / 46, j = e - i * 46; return e < SEP * 46 ? (j == 45 ? 90 * ZS + i : i * ZS + j) : 91 * ZS + 45; };
@@ -1621,7 +1623,7 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
             }
             if (tid >= 45 && tid <= 90) {
 #pragma unroll
-                for (int c = 0; c < SEP; c++) Zs[(tid - 45) * ZS + c] = p[c];
+                for (int c = 0; c < SEP; c++) Zs[(tid - 45) * ZZ + c] = p[c];
             }
         }
         LDS_BARRIER();
@@ -1633,16 +1635,15 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
 #pragma unroll 1
             for (int t = wave; t < 9; t += 3) {
                 const int I = t / 3, J = t - I * 3;
-                const int ri = 16 * I + li, rj = 16 * J + li;
-                const int oa = ri < 45 ? ri * ZS : 0, ob = rj < 46 ? rj * ZS : 0;   // rows beyond Z: masked below
+                // rows 45 (y), 46, 47 of tile I = 2 produce output rows that are dropped; zero padding does the masking
+                const double* za = Zs + (16 * I + li) * ZZ + lq;
+                const double* zb = Zs + (16 * J + li) * ZZ + lq;
+                double av[12], bv[12];
+#pragma unroll
+                for (int q = 0; q < 12; q++) { av[q] = za[4 * q]; bv[q] = zb[4 * q]; }
                 d4_t acc = {0, 0, 0, 0};
 #pragma unroll
-                for (int q = 0; q < 12; q++) {
-                    const int kc = 4 * q + lq;
-                    const double a = (ri < 45 && kc < 45) ? Zs[oa + kc] : 0.0;
-                    const double bq = (rj < 46 && kc < 45) ? Zs[ob + kc] : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc, 0, 0, 0);
-                }
+                for (int q = 0; q < 12; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int i = 16 * I + lq + 4 * r, j = 16 * J + li;

@@ -29,7 +29,14 @@ __host__ __device__ inline int chunk_len(int n, int P) {
     const int up = ((total + P - 1) / P + 3) & ~3;     // round up: the last chunk gets the (smaller) rest
     return n - (P - 1) * (up + 3) >= 8 ? up : (total / P) & ~3;
 }
-__host__ __device__ inline int chunk_count(int n, int P) {
+// chunks actually used for an n-keyframe window: at most P; with `fit` also at most sqrt(0.22 n), the
+// measured optimum of (chunk sweep time ~ 3.7 us * n / P) + (separator chain ~ 17 us * P)
+__host__ __device__ inline int chunk_count(int n, int P, int fit) {
+    if (fit) {
+        int want = 1;
+        while ((want + 1) * (want + 1) * 100 <= n * 22) want++;
+        if (P > want) P = want;
+    }
     while (P > 1 && chunk_len(n, P) < 8) P--;
     return P < 1 ? 1 : P;
 }
@@ -69,6 +76,7 @@ struct View {
     double* Lp;         // [G][43][16]         Cholesky panels (15 of 16 columns used)
     // partitioned solve (allocated when P >= 2)
     int P;              // chunks per window (0/1 = whole-window sweeps)
+    int P_fit;          // 1: use fewer chunks on short windows (see chunk_count)
     double* Vp;         // [G][15][48]         spikes: L^-1 (coupling of the chunk interior to its left separator)
     double* sepR;       // [B][P][45][46]      separator block + rhs left by the forward sweep of chunk c
     double* sepS;       // [B][P][45][46]      Schur term of chunk c on its LEFT separator (c >= 1)

@@ -38,7 +38,7 @@ class EngineOpts:
     lambda_down: float = 10.0
     lambda_min: float = 1e-12
     lambda_max: float = 1e10
-    chunks: int = 0          # K4 form: 0 = one sweep per window, P >= 2 = partitioned solve (P chunks + separators)
+    chunks: int = 0          # K4 form: 0 = auto (<= 32 windows: partitioned solve), 1 = sweeps, P >= 2 = P chunks
 
 
 class Engine:

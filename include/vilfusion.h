@@ -58,7 +58,7 @@ typedef struct {
     int device;             /* HIP device ordinal */
     double gravity[3];      /* n_gravity; MakeSharedU => (0,0,-9.81) (ImuManagerRos.cpp:16) */
     double lambda0, lambda_up, lambda_down, lambda_min, lambda_max; /* LM damping schedule */
-    int chunks;             /* K4 form.  0 = chosen from the batch size: up to 32 windows -> partitioned
+    int chunks;             /* K4 form.  0 = chosen from the batch size: up to 128 windows -> partitioned
                                solve (chunks joined by 45-dof separators, about sqrt(0.22 n) of them for an
                                n-keyframe window: one-window latency); more windows -> one sweep per window
                                (throughput).  1 = always sweeps.  P >= 2 = partitioned solve with P chunks. */
@@ -111,6 +111,46 @@ int vf_engine_decide(vf_engine* e, int init);
 /* `iterations` LM trials (linearize once, then {assemble, solve, retract, linearize(trial),
  * decide} per trial).  Replaces ISAM2::update + calculateEstimate (GraphManager.cpp:126-127). */
 int vf_engine_iterate(vf_engine* e, int iterations);
+/* ---- time-sharded windows (one window spread over the GPUs of a node; no reference code: the reference
+ * is a single process.  SURVEY.md 8e / BASELINE.json configs[4]) ----
+ * Every rank holds the whole window (states and factors replicated) in an engine created with the same
+ * explicit chunk count (vf_engine_opts.chunks = P, a multiple of the world size).  Rank r owns the chunks
+ * [r P / world, (r+1) P / world) and the keyframes they cover: vf_engine_linearize / _assemble then work on
+ * the owned keyframes only (plus a 3-keyframe halo of factor linearisations), and one LM trial is
+ *     linearize, assemble, solve_local, <all-gather sep_r, sep_s, sep_c>, solve_global, <all-reduce delta>,
+ *     retract, linearize(trial), decide_partial, <all-reduce cost_part>, decide_total
+ * where the bracketed collectives are the caller's (RCCL over xGMI via torch.distributed in
+ * vil_sensor_fusion_amd/distributed.py; the library itself has no communication dependency).  The exchange
+ * is the packed separator system: P * 6165 doubles per window per trial; the increment all-reduce is 15
+ * doubles per keyframe. */
+typedef struct {
+    int rank, world, windows, chunks;
+    void* sep_r;            /* device, [chunks][windows][45*46]: rank r writes chunks [r P/world, (r+1) P/world) */
+    void* sep_s;            /* device, [chunks][windows][45*46] */
+    void* sep_c;            /* device, [chunks][windows][45*45] */
+    long sep_rs_per_chunk;  /* doubles per chunk in sep_r / sep_s */
+    long sep_c_per_chunk;   /* doubles per chunk in sep_c */
+    void* delta;            /* device, increments of all keyframe slots; non-owned entries are zero after solve_global */
+    long delta_count;
+    void* cost_part;        /* device, [2][windows]: this rank's share of the cost, its solve-failure flags */
+    long cost_count;
+} vf_shard_info;
+/* Geometry of the partitioned solve, host only (no device needed): an n-keyframe window is cut into `count`
+ * chunks (<= chunks; fit != 0: also <= sqrt(0.22 n)); chunk c = `interior` keyframes from window-local
+ * keyframe `first`, followed by 3 separator keyframes when has_separator.  vf_shard_range: the chunks
+ * [chunk_lo, chunk_hi) and window-local keyframes [kf_lo, kf_hi) rank `rank` of `world` owns. */
+int vf_chunk_geometry(int n, int chunks, int fit, int c, int* count, int* first, int* interior, int* has_separator);
+int vf_shard_range(int n, int chunks, int fit, int rank, int world, int* chunk_lo, int* chunk_hi, int* kf_lo, int* kf_hi);
+/* run every later stage on the caller's HIP stream (hipStream_t), e.g. the one its collectives use */
+int vf_engine_set_stream(vf_engine* e, void* hip_stream);
+int vf_engine_set_shard(vf_engine* e, int rank, int world);
+int vf_engine_shard_info(vf_engine* e, vf_shard_info* out);
+int vf_engine_solve_local(vf_engine* e);    /* chunk sweeps + spikes of the owned chunks */
+int vf_engine_solve_global(vf_engine* e);   /* separator chain, back substitution of the owned chunks, zero the rest of delta */
+int vf_engine_decide_partial(vf_engine* e, int init);
+int vf_engine_decide_total(vf_engine* e, int init);
+int vf_engine_reset_lambda(vf_engine* e);   /* lambda := lambda0, as vf_engine_iterate does before its first trial */
+
 /* Fixed-lag marginalisation of every window's oldest keyframe (no reference code: the
  * reference's iSAM2 graph is unbounded): Schur complement of all factors touching it, at the
  * current linearisation, into a dense Gaussian prior on [next: 15 dof][next+1: pose][next+2:

@@ -1,0 +1,102 @@
+"""CPU: geometry of the partitioned solve and of time-sharded windows (host-only entry points of the C
+ABI), and the exchange helpers of distributed.ShardedSolver under gloo with world_size 2."""
+import os
+import socket
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.mark.parametrize("fit", [False, True])
+def test_chunks_partition_the_window(fit):
+    from vil_sensor_fusion_amd.distributed import chunk_geometry
+    for n in (1, 5, 11, 35, 64, 200, 333, 1000, 10000):
+        for P in (1, 2, 3, 5, 8, 16, 48, 128):
+            g = chunk_geometry(n, P, fit)
+            assert 1 <= len(g) <= P
+            pos = 0
+            for c, (first, interior, has_sep) in enumerate(g):
+                assert first == pos and interior >= 1
+                assert has_sep == (c < len(g) - 1)
+                if has_sep:
+                    assert interior % 4 == 0 and interior >= 8      # the sweep is unrolled by 4 keyframes
+                pos = first + interior + (3 if has_sep else 0)
+            assert pos == n
+            if len(g) > 1:
+                lens = [b for _, b, _ in g]
+                assert max(lens[:-1]) == min(lens[:-1])
+            if fit and n >= 5:
+                assert len(g) ** 2 * 100 <= n * 22 or len(g) == 1
+
+
+def test_fit_rule_matches_measured_optimum():
+    from vil_sensor_fusion_amd.distributed import chunk_geometry
+    assert len(chunk_geometry(1000, 48, True)) == 14       # sqrt(0.22 * 1000) = 14.8
+    assert len(chunk_geometry(200, 48, True)) == 6
+    assert len(chunk_geometry(10000, 48, True)) == 46
+    assert len(chunk_geometry(40, 48, True)) == 2
+
+
+def test_shard_ranges_partition_chunks_and_keyframes():
+    from vil_sensor_fusion_amd.distributed import chunk_geometry, shard_range
+    for n, P in ((10000, 128), (1000, 16), (1000, 8), (333, 4)):
+        g = chunk_geometry(n, P)
+        for world in (1, 2, 4, 8):
+            spans = [shard_range(n, P, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == len(g)
+            assert spans[0][2] == 0 and spans[-1][3] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0] and a[3] == b[2]
+            for c0, c1, k0, k1 in spans:
+                if c0 < len(g):
+                    assert k0 == g[c0][0]                           # a rank starts at a chunk's first interior keyframe
+                if len(g) % world == 0:
+                    assert c1 - c0 == len(g) // world
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    from vil_sensor_fusion_amd import distributed as D
+    dist = D.init(backend="gloo")
+    per = 6165                                            # one chunk's separator blocks
+    full = torch.zeros(world * per + 7, dtype=torch.float64)    # (+ tail that must stay untouched)
+    full[rank * per:(rank + 1) * per] = torch.arange(per, dtype=torch.float64) + 1000.0 * (rank + 1)
+    full[-7:] = -1.0
+    D.all_gather_slices(dist, full, per, rank, world, "gloo")
+    ok = all(torch.equal(full[r * per:(r + 1) * per], torch.arange(per, dtype=torch.float64) + 1000.0 * (r + 1)) for r in range(world))
+    ok = ok and bool((full[-7:] == -1.0).all())
+    delta = torch.zeros(64, dtype=torch.float64)
+    delta[rank * 32:(rank + 1) * 32] = rank + 1.0         # non-owned entries are zero (k_mask_delta)
+    D.all_reduce_sum(dist, delta, "gloo")
+    ok = ok and bool((delta[:32] == 1.0).all() and (delta[32:] == 2.0).all())
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_exchange_helpers_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

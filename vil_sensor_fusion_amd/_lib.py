@@ -31,6 +31,14 @@ class ImuParamsC(C.Structure):
                 ("bias_acc_omega_int", C.c_double)]
 
 
+class ShardInfoC(C.Structure):
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("windows", C.c_int), ("chunks", C.c_int),
+                ("sep_r", C.c_void_p), ("sep_s", C.c_void_p), ("sep_c", C.c_void_p),
+                ("sep_rs_per_chunk", C.c_long), ("sep_c_per_chunk", C.c_long),
+                ("delta", C.c_void_p), ("delta_count", C.c_long),
+                ("cost_part", C.c_void_p), ("cost_count", C.c_long)]
+
+
 class GraphOptsC(C.Structure):
     _fields_ = [("capacity", C.c_int), ("lag", C.c_int), ("iterations", C.c_int), ("device", C.c_int),
                 ("prior_sigma", C.c_double * 15)]
@@ -55,6 +63,9 @@ SYMBOLS = [
     "vf_engine_time_stage", "vf_engine_time_iterate", "vf_engine_counts",
     "vf_engine_preintegrate", "vf_engine_get_imu",
     "vf_engine_marginalize", "vf_engine_drop_oldest", "vf_engine_read_marginal", "vf_engine_compact",
+    "vf_engine_set_stream", "vf_engine_set_shard", "vf_engine_shard_info", "vf_engine_solve_local",
+    "vf_engine_solve_global", "vf_engine_decide_partial", "vf_engine_decide_total", "vf_engine_reset_lambda",
+    "vf_chunk_geometry", "vf_shard_range",
     "vf_graph_default_opts", "vf_create", "vf_destroy", "vf_add_imu", "vf_reserve_node",
     "vf_add_between", "vf_solve", "vf_get_state", "vf_get_bias", "vf_most_recent_pose_time",
     "vf_set_callback", "vf_graph_staged", "vf_get_trajectory", "vf_get_imu_factor",

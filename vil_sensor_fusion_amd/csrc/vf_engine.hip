@@ -37,6 +37,7 @@ struct vf_engine {
     vf::View v{};
     vf_engine_opts opts{};
     hipStream_t stream = nullptr;
+    bool own_stream = true;   // false once the caller has handed in its own stream (vf_engine_set_stream)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<void*> allocs;
     double* stage = nullptr;  // device staging buffer (AoS)
@@ -140,10 +141,10 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.gvec, G * 15);
     AL(v.delta, G * 15);
     AL(v.Lp, G * vf::PANEL);
-    // K4 form: chunks = 0 picks it from the batch size: up to 32 windows -> partitioned solve with at
+    // K4 form: chunks = 0 picks it from the batch size: up to 128 windows -> partitioned solve with at
     // most 48 chunks, fewer on short windows (latency form); more windows -> one sweep per window
     // (throughput form; the partitioned solve does about twice the arithmetic).  1 forces sweeps.
-    v.P = o->chunks >= 2 ? o->chunks : (o->chunks == 0 && o->windows <= 32 ? 48 : 0);
+    v.P = o->chunks >= 2 ? o->chunks : (o->chunks == 0 && o->windows <= 128 ? 48 : 0);
     v.P_fit = o->chunks == 0 ? 1 : 0;
     if (v.P) {
         const size_t BP = (size_t)v.B * v.P;
@@ -163,6 +164,9 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.n_acc, (size_t)v.B);
     AL(v.n_rej, (size_t)v.B);
     AL(v.n_fail, (size_t)v.B);
+    AL(v.cost_part, 2 * (size_t)v.B);
+    v.sh_r = 0;
+    v.sh_G = 1;
     AL(e->sigma_dev, 16);
     AL(e->status_dev, 4);
 #undef AL
@@ -184,7 +188,7 @@ void vf_engine_destroy(vf_engine* e) {
     if (e->stage) (void)hipFree(e->stage);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->stream && e->own_stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
 
@@ -404,6 +408,110 @@ int vf_engine_iterate(vf_engine* e, int iterations) {
         if ((rc = vf_engine_linearize(e, 1))) return rc;
         if ((rc = vf_engine_decide(e, 0))) return rc;
     }
+    HIPCHK(hipStreamSynchronize(e->stream));  // lam is a host temporary
+    return VF_OK;
+}
+
+// ------------------------------------------------------------------ chunk geometry (host only, no device needed)
+int vf_chunk_geometry(int n, int chunks, int fit, int c, int* count, int* first, int* interior, int* has_separator) {
+    if (n < 0 || chunks < 1) return fail(VF_ERR_INVALID, "bad geometry query");
+    const int Pe = vf::chunk_count(n, chunks, fit ? 1 : 0);
+    if (count) *count = Pe;
+    if (c < 0 || c >= Pe) {
+        if (first || interior || has_separator) return fail(VF_ERR_INVALID, "chunk %d out of range (%d)", c, Pe);
+        return VF_OK;
+    }
+    const vf::ChunkGeom g = vf::chunk_geom(n, Pe, c);
+    if (first) *first = g.i0;
+    if (interior) *interior = g.ni;
+    if (has_separator) *has_separator = g.has_sep;
+    return VF_OK;
+}
+int vf_shard_range(int n, int chunks, int fit, int rank, int world, int* chunk_lo, int* chunk_hi, int* kf_lo, int* kf_hi) {
+    if (n < 0 || chunks < 1 || world < 1 || rank < 0 || rank >= world) return fail(VF_ERR_INVALID, "bad shard query");
+    const int Pe = vf::chunk_count(n, chunks, fit ? 1 : 0);
+    const int c0 = (int)((long)rank * Pe / world), c1 = (int)((long)(rank + 1) * Pe / world);
+    if (chunk_lo) *chunk_lo = c0;
+    if (chunk_hi) *chunk_hi = c1;
+    if (kf_lo) *kf_lo = c0 < Pe ? vf::chunk_geom(n, Pe, c0).i0 : n;
+    if (kf_hi) *kf_hi = c1 < Pe ? vf::chunk_geom(n, Pe, c1).i0 : n;
+    return VF_OK;
+}
+
+// ------------------------------------------------------------------ time-sharded windows (multi-GPU)
+int vf_engine_set_stream(vf_engine* e, void* hip_stream) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->own_stream && e->stream) HIPCHK(hipStreamDestroy(e->stream));
+    e->stream = (hipStream_t)hip_stream;      // nullptr = the device's default stream
+    e->own_stream = false;
+    return VF_OK;
+}
+int vf_engine_set_shard(vf_engine* e, int rank, int world) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (world < 1 || rank < 0 || rank >= world) return fail(VF_ERR_INVALID, "bad shard %d of %d", rank, world);
+    if (world > 1 && (e->v.P < 2 || e->v.P_fit))
+        return fail(VF_ERR_INVALID, "time sharding needs an explicit chunk count (vf_engine_opts.chunks >= 2)");
+    if (world > 1 && e->v.P % world != 0) return fail(VF_ERR_INVALID, "chunks (%d) must be a multiple of the world size (%d)", e->v.P, world);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->v.sh_r = rank;
+    e->v.sh_G = world;
+    return VF_OK;
+}
+int vf_engine_shard_info(vf_engine* e, vf_shard_info* out) {
+    if (!e || !out) return fail(VF_ERR_INVALID, "null argument");
+    if (e->v.P < 2) return fail(VF_ERR_INVALID, "engine was not created with the partitioned solve (chunks >= 2)");
+    memset(out, 0, sizeof(*out));
+    out->rank = e->v.sh_r; out->world = e->v.sh_G; out->windows = e->v.B; out->chunks = e->v.P;
+    out->sep_r = e->v.sepR; out->sep_s = e->v.sepS; out->sep_c = e->v.sepC;
+    out->sep_rs_per_chunk = (long)e->v.B * vf::SEPM;
+    out->sep_c_per_chunk = (long)e->v.B * vf::SEP * vf::SEP;
+    out->delta = e->v.delta; out->delta_count = e->v.G * 15;
+    out->cost_part = e->v.cost_part; out->cost_count = 2L * e->v.B;
+    return VF_OK;
+}
+static int check_sharded(vf_engine* e) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (e->v.P < 2) return fail(VF_ERR_INVALID, "engine was not created with the partitioned solve (chunks >= 2)");
+    if (e->v.sh_G > 1)
+        for (int w = 0; w < e->v.B; w++) {
+            const int n = e->h_hi[w] - e->h_lo[w];
+            if (n > 0 && vf::chunk_count(n, e->v.P, e->v.P_fit) != e->v.P)
+                return fail(VF_ERR_INVALID, "window %d (%d keyframes) is too short for %d chunks", w, n, e->v.P);
+        }
+    return VF_OK;
+}
+int vf_engine_solve_local(vf_engine* e) {
+    int rc = check_sharded(e);
+    if (rc) return rc;
+    vf::launch_partitioned_local(e->v, e->stream);
+    HIPCHK(hipGetLastError());
+    return VF_OK;
+}
+int vf_engine_solve_global(vf_engine* e) {
+    int rc = check_sharded(e);
+    if (rc) return rc;
+    vf::launch_partitioned_global(e->v, e->stream);
+    if (e->v.sh_G > 1) vf::launch_mask_delta(e->v, e->stream);
+    HIPCHK(hipGetLastError());
+    return VF_OK;
+}
+int vf_engine_decide_partial(vf_engine* e, int init) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    vf::launch_decide_mode(e->v, init ? 1 : 0, 1, e->stream);
+    HIPCHK(hipGetLastError());
+    return VF_OK;
+}
+int vf_engine_decide_total(vf_engine* e, int init) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    vf::launch_decide_mode(e->v, init ? 1 : 0, 2, e->stream);
+    HIPCHK(hipGetLastError());
+    return VF_OK;
+}
+int vf_engine_reset_lambda(vf_engine* e) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    std::vector<double> lam((size_t)e->v.B, e->opts.lambda0);
+    HIPCHK(hipMemcpyAsync(e->v.lambda, lam.data(), e->v.B * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));  // lam is a host temporary
     return VF_OK;
 }

@@ -23,6 +23,33 @@ namespace vf {
 
 #define XS(buf, c, gk) v.x[((size_t)(buf) * 16 + (c)) * (size_t)v.G + (size_t)(gk)]
 
+// Time-sharded windows: the window-local keyframe range [klo, khi) and the chunk range [c0, c1) rank sh_r owns.
+// A chunk owns its interior keyframes and the separator that follows it; a factor belongs to its later keyframe.
+VF_DI void own_chunks(const View& v, int Pe, int& c0, int& c1) {
+    if (v.sh_G <= 1) { c0 = 0; c1 = Pe; return; }
+    c0 = (int)((long)v.sh_r * Pe / v.sh_G);
+    c1 = (int)((long)(v.sh_r + 1) * Pe / v.sh_G);
+}
+VF_DI void own_range(const View& v, int w, int& klo, int& khi) {
+    const int n = v.hi[w] - v.lo[w];
+    klo = 0;
+    khi = n;
+    if (v.sh_G <= 1 || n <= 0) return;
+    const int Pe = chunk_count(n, v.P, v.P_fit);
+    int c0, c1;
+    own_chunks(v, Pe, c0, c1);
+    klo = c0 < Pe ? chunk_geom(n, Pe, c0).i0 : n;
+    khi = c1 < Pe ? chunk_geom(n, Pe, c1).i0 : n;
+}
+// linearisation of factor slot k (absolute): needed for the owned rows of H and their 3-keyframe halo
+VF_DI bool shard_skips_factor(const View& v, int w, int k) {
+    if (v.sh_G <= 1) return false;
+    int klo, khi;
+    own_range(v, w, klo, khi);
+    const int kk = k - v.lo[w];
+    return kk < klo || kk >= khi + 3;
+}
+
 struct State {
     Q4 q;
     V3 t, vel, ba, bg;
@@ -208,6 +235,7 @@ __global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_imu(View
     if (gk >= v.G) return;
     const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
     if (k <= v.lo[w] || k >= v.hi[w]) return;
+    if (shard_skips_factor(v, w, k)) return;
     const int b = v.sel[w] ^ which;
 
     const double* __restrict__ in = v.imu_in + (size_t)(gk >> 6) * IMU_IN * TILE + (gk & 63);
@@ -366,6 +394,7 @@ __global__ void __launch_bounds__(256) k_linearize_between(View v, int which) {
     const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
     const int lo = v.lo[w];
     if (k <= lo || k >= v.hi[w]) return;
+    if (shard_skips_factor(v, w, k)) return;
     const int a = v.btw_a[gk];
     if (a < lo || a >= k) return;
     const int b = v.sel[w] ^ which;
@@ -539,7 +568,11 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
     if (gk0 >= v.G) return;
     const int w = (int)(gk0 / v.M), k0 = (int)(gk0 - (long)w * v.M);
     const int lo = v.lo[w], hi = v.hi[w];
-    if (k0 + AT <= lo || k0 >= hi) return;   // no active keyframe in this tile (uniform)
+    int rlo, rhi;                            // rows of H this rank assembles (absolute slots)
+    own_range(v, w, rlo, rhi);
+    rlo += lo;
+    rhi += lo;
+    if (k0 + AT <= rlo || k0 >= rhi) return; // no owned active keyframe in this tile (uniform)
     // a rejected LM trial leaves the current linearisation, hence H and g, unchanged: nothing to do
     // (k_decide clears `fresh` on reject; accept / init / slide set it)
     if (!v.fresh[w]) return;
@@ -655,7 +688,7 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
 #pragma unroll
             for (int q = 0; q < 4; q++) D = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[q], ai[q], D, 0, 0, 0);
             const int kl = lf - 1, k = k0 + kl;
-            if (k >= lo && k < hi) {
+            if (k >= rlo && k < rhi) {
                 const long gk = gk0 + kl;
                 double* Hk = v.H + (size_t)gk * HROW;
                 const bool btw_here = s_a[kl] >= 0;
@@ -702,7 +735,7 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
                 D = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[q], aj[q], D, 0, 0, 0);
             }
             const int kl = lf, k = k0 + kl;
-            if (k >= lo && k < hi) {
+            if (k >= rlo && k < rhi) {
                 double* Hk = v.H + (size_t)(gk0 + kl) * HROW;
                 const int ak = s_a[kl];
                 const int dk = ak >= 0 ? k - ak : 0;   // 1..3 when a between factor ends here
@@ -1311,7 +1344,7 @@ __global__ void __launch_bounds__(128) k_band_solve_tw(View v) {
 // results feed the next product without leaving registers.  Three column tiles cover the 45 separator
 // columns.  The panel of step k is read from the LDS ring slot k & 3 once the sweep has published it.
 __device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int c, ChunkGeom cg, int lane) {
-    const int P = v.P, lo = v.lo[w];
+    const int lo = v.lo[w];
     const int li = lane & 15, lq = lane >> 4;
     const size_t base = (size_t)w * v.M + lo + cg.i0;
     const double* __restrict__ Hb = v.H + base * HROW;
@@ -1410,7 +1443,7 @@ __device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int
         }
     }
     // ---- outputs --------------------------------------------------------------------------------
-    double* Sm = v.sepS + ((size_t)w * P + c) * SEPM;    // -(V^T V), -(V^T y): added to separator c-1
+    double* Sm = v.sepS + ((size_t)c * v.B + w) * SEPM;  // -(V^T V), -(V^T y): added to separator c-1
     auto put = [&](const d4_t& t, int I, int J) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -1424,7 +1457,7 @@ __device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int
     put(acc[0], 0, 0); put(acc[1], 0, 1); put(acc[2], 0, 2); put(acc[3], 1, 1); put(acc[4], 1, 2); put(acc[5], 2, 2);
     if (cg.has_sep) {
         // what is left in W belongs to the right separator: rows i1 (15), i1+1 and i1+2 (pose rows)
-        double* Cm = v.sepC + ((size_t)w * P + c) * SEP * SEP;
+        double* Cm = v.sepC + ((size_t)c * v.B + w) * SEP * SEP;
 #pragma unroll
         for (int J = 0; J < 3; J++)
 #pragma unroll
@@ -1445,11 +1478,13 @@ __global__ void __launch_bounds__(128) k_chunk_forward(View v) {
     const int n = v.hi[w] - v.lo[w];
     if (n <= 0) return;
     const int Pe = chunk_count(n, P, v.P_fit);
-    if (c >= Pe) return;
+    int oc0, oc1;
+    own_chunks(v, Pe, oc0, oc1);
+    if (c >= Pe || c < oc0 || c >= oc1) return;
     __shared__ double S[S_TOTAL_RING];
     const ChunkGeom cg = chunk_geom(n, Pe, c);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave == 0) band_solve_body<SOLVE_CHUNK_FWD>(v, S, nullptr, nullptr, w, lane, 0, cg, v.sepR + ((size_t)w * P + c) * SEPM);
+    if (wave == 0) band_solve_body<SOLVE_CHUNK_FWD>(v, S, nullptr, nullptr, w, lane, 0, cg, v.sepR + ((size_t)c * v.B + w) * SEPM);
     else if (c > 0) chunk_spike(v, S, w, c, cg, lane);
 }
 __global__ void __launch_bounds__(64) k_chunk_back(View v) {
@@ -1457,7 +1492,9 @@ __global__ void __launch_bounds__(64) k_chunk_back(View v) {
     const int n = v.hi[w] - v.lo[w];
     if (n <= 0) return;
     const int Pe = chunk_count(n, P, v.P_fit);
-    if (c >= Pe) return;
+    int oc0, oc1;
+    own_chunks(v, Pe, oc0, oc1);
+    if (c >= Pe || c < oc0 || c >= oc1) return;
     __shared__ double S[S_TOTAL];
     band_solve_body<SOLVE_CHUNK_BWD>(v, S, nullptr, nullptr, w, threadIdx.x, 0, chunk_geom(n, Pe, c), nullptr);
 }
@@ -1468,7 +1505,9 @@ __global__ void __launch_bounds__(256) k_chunk_rhs(View v) {
     const int lo = v.lo[w], n = v.hi[w] - lo;
     if (n <= 0) return;
     const int Pe = chunk_count(n, P, v.P_fit);
-    if (c == 0 || c >= Pe) return;
+    int oc0, oc1;
+    own_chunks(v, Pe, oc0, oc1);
+    if (c == 0 || c >= Pe || c < oc0 || c >= oc1) return;
     const ChunkGeom cg = chunk_geom(n, Pe, c);
     const size_t base = (size_t)w * v.M + lo + cg.i0;
     __shared__ double dl[SEP];
@@ -1526,9 +1565,12 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
     __shared__ __attribute__((aligned(16))) double Dn[92 * ZS];    // panel input: D rows 0..44, C rows 45..89, rhs row 90, zero row 91
     __shared__ double Fb[2][SEP * FS];                             // backward sweep: factor of the current / next separator
     __shared__ double dnext[48];
-    const double* __restrict__ R = v.sepR + (size_t)w * P * SEPM;
-    const double* __restrict__ Sx = v.sepS + (size_t)w * P * SEPM;      // slot 0 is never written: 2070 zeros
-    const double* __restrict__ Cx = v.sepC + (size_t)w * P * SEP * SEP;
+    // separator blocks are stored chunk-major, [P][B][..]: the chunks of one rank of a time-sharded window are
+    // contiguous (all-gather slices); element (c, w) of this window sits c * cs (resp. c * cc) further on
+    const size_t cs = (size_t)v.B * SEPM, cc = (size_t)v.B * SEP * SEP;
+    const double* __restrict__ R = v.sepR + (size_t)w * SEPM;
+    const double* __restrict__ Sx = v.sepS + (size_t)w * SEPM;          // chunk 0 is never written: 2070 zeros
+    const double* __restrict__ Cx = v.sepC + (size_t)w * SEP * SEP;
     double* __restrict__ Lx = v.sepL + (size_t)w * P * SEPL;
     int failed = 0;
     for (int e = tid; e < 92 * ZS; e += 192) Dn[e] = 0.0;
@@ -1537,8 +1579,8 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
     // staged element (i, j) of a [45][46] (D | rhs) block / of a [45][45] coupling block -> panel input
     auto dst_d = [](int e) { const int i = e / 46, j = e - i * 46; return e < SEP * 46 ? (j == 45 ? 90 * ZS + i : i * ZS + j) : 91 * ZS + 45; };
     auto dst_c = [](int e) { const int i = e / SEP, j = e - i * SEP; return e < SEP * SEP ? (45 + i) * ZS + j : 91 * ZS + 45; };
-    for (int e = tid; e < SEP * 46; e += 192) Dn[dst_d(e)] = R[e] + Sx[SEPM + e];
-    if (m > 1) for (int e = tid; e < SEP * SEP; e += 192) Dn[dst_c(e)] = Cx[(size_t)SEP * SEP + e];
+    for (int e = tid; e < SEP * 46; e += 192) Dn[dst_d(e)] = R[e] + Sx[cs + e];
+    if (m > 1) for (int e = tid; e < SEP * SEP; e += 192) Dn[dst_c(e)] = Cx[cc + e];
     __syncthreads();
     const int prow = (tid < 91 ? tid : 91) * ZS;       // this thread's panel row in Dn (91 = zeros)
     double* col_w = &colbuf[0][tid < 45 ? tid : 47];   // one base register + immediates (nothing per-column to hoist)
@@ -1563,9 +1605,9 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
             // loads are unconditional and nothing is computed on them before the pivot barriers are behind us.
             int sz;
             asm volatile("v_mov_b32 %0, 0" : "=v"(sz));      // opaque zero: keeps the element maps inside the loop
-            const double* pa = more ? R + (size_t)(s + 1) * SEPM : Sx;
-            const double* pb = (more && s + 2 <= m) ? Sx + (size_t)(s + 2) * SEPM : Sx;
-            const double* pc = s + 2 < m ? Cx + (size_t)(s + 2) * SEP * SEP : Sx;
+            const double* pa = more ? R + (size_t)(s + 1) * cs : Sx;
+            const double* pb = (more && s + 2 <= m) ? Sx + (size_t)(s + 2) * cs : Sx;
+            const double* pc = s + 2 < m ? Cx + (size_t)(s + 2) * cc : Sx;
             LDS_BARRIER();   // Dn consumed (the stager arrives first: nothing of its work sits in front of the pivots)
             // one slice of the staging work (3 loads + 2 destinations) between two pivot barriers, so that the
             // stager is never the last wave to arrive
@@ -1748,15 +1790,19 @@ __global__ void __launch_bounds__(256) k_retract(View v) {
 
 // cost of buffer (sel ^ !init) per window, then the LM decision. One 256-thread block per window;
 // fixed-shape tree reduction => bitwise reproducible.
-__global__ void __launch_bounds__(256) k_decide(View v, int init) {
+// mode 0: whole cost + accept / reject (one rank).  Sharded windows: mode 1 = this rank's share of the cost
+// -> cost_part (the host side sums it over the ranks), mode 2 = accept / reject with cost_part as the total.
+__global__ void __launch_bounds__(256) k_decide(View v, int init, int mode) {
     const int w = blockIdx.x, tid = threadIdx.x;
     const int lo = v.lo[w], hi = v.hi[w];
+    int klo, khi;
+    own_range(v, w, klo, khi);
     const int b = init ? v.sel[w] : (v.sel[w] ^ 1);
     const size_t tiles = (size_t)(v.G >> 6);
     const double* imu_out = v.imu_out + (size_t)b * tiles * IMU_OUT * TILE;
     const double* btw_out = v.btw_out + (size_t)b * tiles * BTW_OUT * TILE;
     double s = 0.0;
-    for (int k = lo + 1 + tid; k < hi; k += 256) {
+    for (int k = lo + (klo > 1 ? klo : 1) + tid; k < lo + khi && mode != 2; k += 256) {
         const long gk = (long)w * v.M + k;
         const double* f = imu_out + (size_t)(gk >> 6) * IMU_OUT * TILE + (gk & 63);
         double c = 0.0;
@@ -1770,13 +1816,13 @@ __global__ void __launch_bounds__(256) k_decide(View v, int init) {
         }
         s += c;
     }
-    if (tid == 0) {
+    if (tid == 0 && mode != 2) {
         const int pk = v.prior_k[w];
-        if (pk >= lo && pk < hi) {
+        if (pk >= lo + klo && pk < lo + khi) {
             const double* f = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT;
             for (int r = 0; r < 15; r++) s = fma(f[r], f[r], s);
         }
-        if (v.mp_on[w] && hi - lo >= 3) s += 2.0 * v.mp_out[((size_t)b * v.B + w) * 28 + 27];
+        if (v.mp_on[w] && hi - lo >= 3 && klo == 0) s += 2.0 * v.mp_out[((size_t)b * v.B + w) * 28 + 27];
     }
     __shared__ double red[256];
     red[tid] = s;
@@ -1785,8 +1831,13 @@ __global__ void __launch_bounds__(256) k_decide(View v, int init) {
         if (tid < st) red[tid] += red[tid + st];
         __syncthreads();
     }
-    if (tid == 0) {
-        const double c = 0.5 * red[0];
+    if (tid == 0 && mode == 1) {
+        v.cost_part[w] = 0.5 * red[0];
+        v.cost_part[v.B + w] = v.fail[w] ? 1.0 : 0.0;     // a failed elimination on any rank rejects the trial
+    }
+    if (tid == 0 && mode != 1) {
+        const double c = mode == 2 ? v.cost_part[w] : 0.5 * red[0];
+        if (mode == 2) v.fail[w] = v.cost_part[v.B + w] > 0.0 ? 1 : 0;
         if (init) {
             v.cost[w] = c;
             v.fail[w] = 0;
@@ -2048,12 +2099,33 @@ void launch_linearize_prior(const View& v, int which, hipStream_t s) {
 void launch_assemble(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_assemble, dim3(nblk(v.G, AT)), dim3(256), 0, s, v);
 }
-void launch_partitioned_solve(const View& v, hipStream_t s) {
+void launch_partitioned_local(const View& v, hipStream_t s) {
+    hipLaunchKernelGGL(k_chunk_forward, dim3((unsigned)v.B * (unsigned)v.P), dim3(128), 0, s, v);
+}
+void launch_partitioned_global(const View& v, hipStream_t s) {
     const unsigned nb = (unsigned)v.B * (unsigned)v.P;
-    hipLaunchKernelGGL(k_chunk_forward, dim3(nb), dim3(128), 0, s, v);
     hipLaunchKernelGGL(k_sep_solve, dim3(v.B), dim3(192), 0, s, v);
     hipLaunchKernelGGL(k_chunk_rhs, dim3(nb), dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_chunk_back, dim3(nb), dim3(64), 0, s, v);
+}
+void launch_partitioned_solve(const View& v, hipStream_t s) {
+    launch_partitioned_local(v, s);
+    launch_partitioned_global(v, s);
+}
+__global__ void __launch_bounds__(256) k_mask_delta(View v) {
+    const long gk = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gk >= v.G) return;
+    const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
+    const int lo = v.lo[w];
+    if (k < lo || k >= v.hi[w]) return;
+    int klo, khi;
+    own_range(v, w, klo, khi);
+    if (k - lo >= klo && k - lo < khi) return;
+#pragma unroll
+    for (int a = 0; a < 15; a++) v.delta[(size_t)gk * 15 + a] = 0.0;
+}
+void launch_mask_delta(const View& v, hipStream_t s) {
+    hipLaunchKernelGGL(k_mask_delta, dim3(nblk(v.G, 256)), dim3(256), 0, s, v);
 }
 void launch_band_solve(const View& v, hipStream_t s) {
     if (v.P >= 2) { launch_partitioned_solve(v, s); return; }
@@ -2066,7 +2138,10 @@ void launch_retract(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_retract, dim3(nblk(v.G, 256)), dim3(256), 0, s, v);
 }
 void launch_decide(const View& v, int init, hipStream_t s) {
-    hipLaunchKernelGGL(k_decide, dim3(v.B), dim3(256), 0, s, v, init);
+    hipLaunchKernelGGL(k_decide, dim3(v.B), dim3(256), 0, s, v, init, 0);
+}
+void launch_decide_mode(const View& v, int init, int mode, hipStream_t s) {
+    hipLaunchKernelGGL(k_decide, dim3(v.B), dim3(256), 0, s, v, init, mode);
 }
 void launch_predict(const View& v, int window, int k0, int n, hipStream_t s) {
     if (window >= 0) hipLaunchKernelGGL(k_predict, dim3(1), dim3(1), 0, s, v, window, k0, n);

@@ -77,10 +77,15 @@ struct View {
     // partitioned solve (allocated when P >= 2)
     int P;              // chunks per window (0/1 = whole-window sweeps)
     int P_fit;          // 1: use fewer chunks on short windows (see chunk_count)
+    // time-sharded windows (multi-GPU): rank sh_r of sh_G owns the chunks [sh_r Pe / sh_G, (sh_r+1) Pe / sh_G)
+    // of every window; states and factors are replicated, each rank linearises / assembles / eliminates its own
+    // keyframes only.  sh_G <= 1: not sharded.
+    int sh_r, sh_G;
+    double* cost_part;  // [2][B]              this rank's share of the cost, and its solve-failure flag (summed over ranks by the host side)
     double* Vp;         // [G][15][48]         spikes: L^-1 (coupling of the chunk interior to its left separator)
-    double* sepR;       // [B][P][45][46]      separator block + rhs left by the forward sweep of chunk c
-    double* sepS;       // [B][P][45][46]      Schur term of chunk c on its LEFT separator (c >= 1)
-    double* sepC;       // [B][P][45][45]      coupling (right separator of chunk c) x (left separator of chunk c)
+    double* sepR;       // [P][B][45][46]      separator block + rhs left by the forward sweep of chunk c
+    double* sepS;       // [P][B][45][46]      Schur term of chunk c on its LEFT separator (c >= 1)
+    double* sepC;       // [P][B][45][45]      coupling (right separator of chunk c) x (left separator of chunk c)
     double* sepL;       // [B][P][45][96]      factors of the separator chain, column-major (for its back substitution)
     int* lo;            // [B] active range [lo, hi)
     int* hi;
@@ -106,6 +111,11 @@ void launch_assemble(const View& v, hipStream_t s);
 void launch_band_solve(const View& v, hipStream_t s);
 void launch_retract(const View& v, hipStream_t s);
 void launch_decide(const View& v, int init, hipStream_t s);
+// sharded windows: mode 1 = this rank's share of the cost -> cost_part; mode 2 = accept / reject with cost_part as the total
+void launch_decide_mode(const View& v, int init, int mode, hipStream_t s);
+void launch_partitioned_local(const View& v, hipStream_t s);    // chunk sweeps + spikes of the owned chunks
+void launch_partitioned_global(const View& v, hipStream_t s);   // separator chain (all of it) + back substitution of the owned chunks
+void launch_mask_delta(const View& v, hipStream_t s);           // zero the increments of keyframes this rank does not own
 void launch_predict(const View& v, int window, int k0, int n, hipStream_t s);
 void launch_slide(const View& v, const double* sigma15_dev, int reanchor, hipStream_t s);
 void launch_marginalize(const View& v, int* status, hipStream_t s);

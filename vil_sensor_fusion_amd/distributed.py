@@ -3,8 +3,14 @@
 The hot path shards over independent smoothing windows (vehicles / sequences): every rank owns a
 contiguous block of windows and runs the whole K0-K5 pipeline on its own MI355X; there is NO
 data-path collective.  The only communication is control-plane: a barrier around the timed region,
-a MAX-reduce of the elapsed time and an all-gather of per-rank summaries.  (Sharding ONE window in
-time with an RCCL reduce of the separator system is the next multi-GPU row, DESIGN.md section e.)
+a MAX-reduce of the elapsed time and an all-gather of per-rank summaries.
+
+ShardedSolver is the other multi-GPU form (BASELINE.json configs[4]): ONE window spread
+in time over the ranks.  Every rank holds the window, owns a contiguous range of the chunks of the
+partitioned solve (K4p) and the keyframes they cover, and per LM trial the ranks exchange the packed
+separator system (all-gather, 6165 doubles per chunk), the increments (all-reduce, 15 doubles per
+keyframe) and two scalars per window (all-reduce).  RCCL collectives are enqueued on the stream the
+engine's kernels run on, so a trial needs no host synchronisation.
 """
 from __future__ import annotations
 
@@ -74,3 +80,117 @@ def gather_summaries(dist, summary: dict):
 def whole_job_throughput(summaries, seconds: float) -> float:
     """value = units all ranks processed / max-over-ranks time."""
     return sum(s["keyframes"] for s in summaries) / seconds
+
+
+# ------------------------------------------------------------------------------------------------
+# time-sharded windows
+def chunk_geometry(n: int, chunks: int, fit: bool = False):
+    """[(first, interior, has_separator)] of the partitioned solve (libvilfusion's own geometry)."""
+    import ctypes as C
+    from . import _lib
+    l = _lib.lib()
+    cnt = C.c_int()
+    _lib.check(l.vf_chunk_geometry(n, chunks, int(fit), -1, C.byref(cnt), None, None, None))
+    out = []
+    for c in range(cnt.value):
+        a, b, h = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(l.vf_chunk_geometry(n, chunks, int(fit), c, None, C.byref(a), C.byref(b), C.byref(h)))
+        out.append((a.value, b.value, bool(h.value)))
+    return out
+
+
+def shard_range(n: int, chunks: int, rank: int, world: int, fit: bool = False):
+    """(chunk_lo, chunk_hi, kf_lo, kf_hi) owned by `rank`."""
+    import ctypes as C
+    from . import _lib
+    v = [C.c_int() for _ in range(4)]
+    _lib.check(_lib.lib().vf_shard_range(n, chunks, int(fit), rank, world, *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
+
+
+def all_gather_slices(dist, full, per_slice: int, rank: int, world: int, backend: str):
+    """`full` = world equal slices of per_slice elements; rank r holds slice r; afterwards all hold all.
+    nccl (RCCL): in place on the device.  gloo (CPU tests, shared-GPU smoke runs): staged through the host."""
+    if dist is None or world == 1:
+        return
+    own = full[rank * per_slice:(rank + 1) * per_slice]
+    if backend == "nccl":
+        dist.all_gather_into_tensor(full[:world * per_slice], own)
+        return
+    import torch
+    parts = [torch.empty(per_slice, dtype=full.dtype) for _ in range(world)]
+    dist.all_gather(parts, own.detach().cpu().contiguous())
+    full[:world * per_slice].copy_(torch.cat(parts))
+
+
+def all_reduce_sum(dist, t, backend: str):
+    if dist is None:
+        return
+    if backend == "nccl":
+        dist.all_reduce(t)
+        return
+    c = t.detach().cpu()
+    dist.all_reduce(c)
+    t.copy_(c)
+
+
+class _DevicePtr:
+    """Raw device pointer -> torch tensor without a copy (__cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+class ShardedSolver:
+    """LM on windows spread in time over the ranks of `dist` (see the module docstring).
+
+    eng: an Engine created on every rank with the same explicit `chunks` (a multiple of the world size)
+    and loaded with the same window(s).  iterate(K) has the semantics of Engine.iterate(K)."""
+
+    def __init__(self, eng, dist, device, backend: str = "nccl"):
+        import torch
+        self.eng, self.dist, self.backend = eng, dist, backend
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.device = torch.device(device)
+        eng.set_shard(self.rank, self.world)
+        # kernels and collectives share torch's current stream: no host round trip inside a trial
+        eng.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        info = eng.shard_info()
+        wrap = lambda p, n: torch.as_tensor(_DevicePtr(p, n), device=self.device)
+        self.chunks = info.chunks
+        self.per_rank = info.chunks // self.world
+        self.rs_per, self.c_per = info.sep_rs_per_chunk, info.sep_c_per_chunk
+        self.sep_r = wrap(info.sep_r, info.chunks * self.rs_per)
+        self.sep_s = wrap(info.sep_s, info.chunks * self.rs_per)
+        self.sep_c = wrap(info.sep_c, info.chunks * self.c_per)
+        self.delta = wrap(info.delta, info.delta_count)
+        self.cost = wrap(info.cost_part, info.cost_count)
+
+    def _exchange_separators(self):
+        for t, per in ((self.sep_r, self.rs_per), (self.sep_s, self.rs_per), (self.sep_c, self.c_per)):
+            all_gather_slices(self.dist, t, per * self.per_rank, self.rank, self.world, self.backend)
+
+    def _decide(self, init):
+        self.eng.decide_partial(init)
+        all_reduce_sum(self.dist, self.cost, self.backend)
+        self.eng.decide_total(init)
+
+    def trial(self):
+        e = self.eng
+        e.assemble()
+        e.solve_local()
+        self._exchange_separators()
+        e.solve_global()
+        all_reduce_sum(self.dist, self.delta, self.backend)
+        e.retract()
+        e.linearize(1)
+        self._decide(False)
+
+    def iterate(self, iterations: int):
+        e = self.eng
+        e.reset_lambda()
+        e.linearize(0)
+        self._decide(True)
+        for _ in range(iterations):
+            self.trial()

@@ -38,7 +38,7 @@ class EngineOpts:
     lambda_down: float = 10.0
     lambda_min: float = 1e-12
     lambda_max: float = 1e10
-    chunks: int = 0          # K4 form: 0 = auto (<= 32 windows: partitioned solve), 1 = sweeps, P >= 2 = P chunks
+    chunks: int = 0          # K4 form: 0 = auto (<= 128 windows: partitioned solve), 1 = sweeps, P >= 2 = P chunks
 
 
 class Engine:
@@ -158,6 +158,34 @@ class Engine:
 
     def sync(self):
         check(self._l.vf_engine_sync(self._h))
+
+    # ---- time-sharded windows (see include/vilfusion.h; the collectives live in distributed.ShardedSolver)
+    def set_stream(self, hip_stream):
+        """Run every later stage on the caller's HIP stream (an integer hipStream_t, 0 = default stream)."""
+        check(self._l.vf_engine_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_shard(self, rank, world):
+        check(self._l.vf_engine_set_shard(self._h, rank, world))
+
+    def shard_info(self):
+        info = _lib.ShardInfoC()
+        check(self._l.vf_engine_shard_info(self._h, C.byref(info)))
+        return info
+
+    def solve_local(self):
+        check(self._l.vf_engine_solve_local(self._h))
+
+    def solve_global(self):
+        check(self._l.vf_engine_solve_global(self._h))
+
+    def decide_partial(self, init=False):
+        check(self._l.vf_engine_decide_partial(self._h, int(init)))
+
+    def decide_total(self, init=False):
+        check(self._l.vf_engine_decide_total(self._h, int(init)))
+
+    def reset_lambda(self):
+        check(self._l.vf_engine_reset_lambda(self._h))
 
     # ---- read-back
     def read_imu_lin(self, window, k0, n, which=0):

@@ -75,6 +75,46 @@ def cpu_baseline(args):
                        f"built or timed here (no GTSAM/Eigen/Boost/ROS)")
 
 
+def time_sharded_window(args, info, dist, backend, dev):
+    """BASELINE.json configs[4]: ONE 10 000-pose window spread in time over the ranks (every rank owns
+    48 / world chunks of the partitioned solve; separator blocks all-gathered, increments all-reduced
+    over RCCL).  Outside the timed region of the headline metric; every rank takes part."""
+    import torch
+    from vil_sensor_fusion_amd import Engine, EngineOpts, synth, distributed as D
+    from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
+    n, chunks, trials = args.sharded_window, 48, args.iterations
+    seq = synth.make_sequence(seed=4242, n_kf=n)
+    eng = Engine(EngineOpts(windows=1, capacity=n + 8, device=dev.index, chunks=chunks))
+    eng.preintegrate(0, 1, seq.imu_off[1:], seq.imu_steps, np.zeros(6), synth.CARLA_IMU_COV)
+    eng.set_between(0, seq.btw_a, seq.btw_b, synth.between_records(seq))
+    eng.set_states(0, 0, seq.gt_states[:1])
+    eng.set_prior(0, 0, synth.prior_record(seq.gt_states[0], REFERENCE_PRIOR_SIGMAS))
+    eng.set_range(0, 0, 1)
+    eng.predict(0, 1, n - 1)
+    eng.set_range(0, 0, n)
+    eng.sync()
+    solver = D.ShardedSolver(eng, dist, dev, backend=backend)
+    solver.iterate(trials)                       # converge + warm up (not timed)
+    torch.cuda.synchronize(dev)
+    D.barrier(dist)
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        solver.iterate(trials)
+    torch.cuda.synchronize(dev)
+    dt = D.max_over_ranks(dist, time.perf_counter() - t0, device=dev if (dist is not None and backend == "nccl") else "cpu")
+    lm = eng.read_lm(0)
+    per_trial = dt / (reps * (trials + 1e-30))
+    out = {"window_keyframes": n, "ranks": info.world, "chunks": chunks, "chunks_per_rank": chunks // max(info.world, 1),
+           "lm_trials_timed": reps * trials, "ms_per_lm_trial": per_trial * 1e3,
+           "keyframe_relinearisations_per_s": n / per_trial,
+           "exchange_doubles_per_trial": chunks * 6165 + n * 15 + 2,
+           "collectives_per_trial": "3 all-gather (separator blocks) + 2 all-reduce (increments, cost)",
+           "backend": backend if dist is not None else "none", "final_cost": lm["cost"], "solve_failures": lm["solve_failures"]}
+    eng.close()
+    return out
+
+
 def measured_traffic_per_imu_factor():
     """HBM bytes per IMU factor of K1 from the committed PMC profile (separate --pmc passes,
     2*FETCH_SIZE + WRITE_SIZE, KiB units; tools/summarize_prof.py)."""
@@ -97,6 +137,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-window", action="store_true")
     ap.add_argument("--reanchor", action="store_true", help="drop the oldest keyframe by re-anchoring tight priors instead of marginalising it")
+    ap.add_argument("--sharded-window", type=int, default=10000, help="keyframes of the time-sharded window (BASELINE configs[4])")
+    ap.add_argument("--no-sharded", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -134,6 +176,14 @@ def main():
     dt = D.max_over_ranks(dist, time.perf_counter() - t0, device=dev if (dist is not None and backend == "nccl") else "cpu")
     summaries = D.gather_summaries(dist, dict(rank=info.rank, keyframes=args.windows * args.steps))
 
+    sharded = None
+    if not args.no_sharded and 48 % info.world == 0:
+        # every rank reports whether its side is healthy before any collective of this section is entered
+        try:
+            sharded = time_sharded_window(args, info, dist, backend, dev)
+        except Exception as exc:   # noqa: BLE001 -- reported in the JSON line, the headline number stands
+            sharded = {"error": f"{type(exc).__name__}: {exc}"}
+
     if info.rank == 0:
         counts = eng.counts()
         kf_per_s = D.whole_job_throughput(summaries, dt)
@@ -167,6 +217,8 @@ def main():
             "stage_ms": stages,
             "lm_state_window0": eng.read_lm(0),
         }
+        if sharded is not None:
+            out["time_sharded_window"] = sharded
         if not args.no_single_window:
             # latency of the same update on ONE window (what a single vehicle sees)
             one = make_engine(args, 7777, gpu, 1)

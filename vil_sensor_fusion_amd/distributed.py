@@ -111,7 +111,7 @@ def shard_range(n: int, chunks: int, rank: int, world: int, fit: bool = False):
 def all_gather_slices(dist, full, per_slice: int, rank: int, world: int, backend: str):
     """`full` = world equal slices of per_slice elements; rank r holds slice r; afterwards all hold all.
     nccl (RCCL): in place on the device.  gloo (CPU tests, shared-GPU smoke runs): staged through the host."""
-    if dist is None or world == 1:
+    if dist is None or (world == 1 and backend != "nccl"):
         return
     own = full[rank * per_slice:(rank + 1) * per_slice]
     if backend == "nccl":

@@ -126,3 +126,35 @@ def test_partitioned_with_marginal_prior(oracle):
     assert d <= 1e-6
     for e in engines:
         e.close()
+
+
+def test_config3_batch_lm_with_degeneracy_metrics(oracle):
+    """BASELINE.json configs[2]: a 1000-pose batch LM solve with the partitioned Cholesky (16 chunks,
+    MFMA Schur / spike products), degeneracy detection on: K6 over the 1000 per-keyframe 6x6 pose
+    information blocks of the converged window, against the numpy restatement of the reference's
+    metric library."""
+    from oracle import degeneracy_oracle as dor
+    from vil_sensor_fusion_amd import Engine, EngineOpts, degeneracy as dg
+    n = 1000
+    seq = synth.make_sequence(seed=31, n_kf=n)
+    prob = helpers.build_problem(oracle, seq, perturb=0.005)
+    eng = Engine(EngineOpts(windows=1, capacity=n, chunks=16))
+    helpers.load_engine(eng, 0, prob)
+    eng.iterate(8)
+    win = helpers.oracle_window(oracle, prob)
+    win.lm(iterations=8)
+    a, r = helpers.ate(eng.get_states(0, 0, n), win.states)
+    lm = eng.read_lm(0)
+    print(f"config 3: ATE vs oracle {a:.3e} m, cost {lm['cost']:.6e}, accepted {lm['accepted']}")
+    assert a <= 1e-6 and r <= 1e-6 and lm["solve_failures"] == 0
+    eng.linearize(0)
+    eng.assemble()
+    info = eng.pose_information(0, 1, n - 1)                    # keyframe 0 carries the 1e14 prior
+    mats = info.transpose(2, 0, 1)
+    pose = np.zeros((n - 1, 6))
+    for name in ("d_opt", "e_opt", "condition_number", "max_eigen_ratio"):
+        for sub in ("all", "trans", "rot"):
+            y = dg.apply_degen_function(info, pose.T[:, None, :], sub, name)
+            ms, ps = dor.subset(mats, pose, sub)
+            np.testing.assert_allclose(y, dor.evaluate(name, ms, ps), rtol=1e-7, atol=1e-9, err_msg=f"{name}/{sub}")
+    eng.close()

@@ -203,6 +203,13 @@ class Engine:
         check(self._l.vf_engine_read_normal(self._h, window, k0, n, _d(H), _d(g)))
         return H, g
 
+    def pose_information(self, window, k0, n):
+        """(6, 6, n): the pose block of each keyframe's diagonal block of J^T J at the current
+        linearisation (information of pose k given the rest of the window) -- the per-keyframe 6x6
+        blocks the degeneracy metrics (K6) are run on in the batch pipeline (BASELINE configs[2])."""
+        H, _ = self.read_normal(window, k0, n)
+        return np.ascontiguousarray(H[:, 0, :6, :6].transpose(1, 2, 0))
+
     def read_delta(self, window, k0, n):
         d = np.zeros((n, 15))
         check(self._l.vf_engine_read_delta(self._h, window, k0, n, _d(d)))

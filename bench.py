@@ -52,9 +52,10 @@ def make_engine(args, rank, local_rank, windows):
     return eng
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, threads=1):
     """The CPU oracle (a port, not GTSAM: GTSAM cannot be built here) doing the same update on a
-    bounded sample: one window, `cpu_steps` updates of K LM trials each, one host core."""
+    bounded sample: one window, `cpu_steps` updates of K LM trials each, on `threads` host cores
+    (OpenMP over the factors of the linearisation; the banded solve is scalar)."""
     from oracle import oracle
     from tests import helpers
     from vil_sensor_fusion_amd import synth
@@ -65,13 +66,13 @@ def cpu_baseline(args):
     t0 = time.perf_counter()
     for s in range(args.cpu_steps):
         win = helpers.oracle_window(oracle, prob, lo=s, hi=s + n)
-        win.lm(iterations=args.iterations, n_threads=1)
+        win.lm(iterations=args.iterations, n_threads=threads)
         prob["states"][s:s + n] = win.states
     dt = time.perf_counter() - t0
-    return dict(value=args.cpu_steps / dt, unit="keyframes/s", cores=1, kind="port",
+    return dict(value=args.cpu_steps / dt, unit="keyframes/s", cores=threads, kind="port",
                 host_cores_available=os.cpu_count(),
                 sample=f"{args.cpu_steps} fixed-lag updates of one {n}-pose window, {args.iterations} LM trials each, "
-                       f"single-thread C restatement (oracle/vf_oracle.c); the reference's CPU GTSAM path cannot be "
+                       f"C restatement (oracle/vf_oracle.c) on {threads} thread(s); the reference's CPU GTSAM path cannot be "
                        f"built or timed here (no GTSAM/Eigen/Boost/ROS)")
 
 
@@ -236,6 +237,10 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
             out["cpu_baseline"]["gpu_over_cpu"] = kf_per_s / out["cpu_baseline"]["value"]
+            # also with OpenMP over the factors, on a bounded number of the host's cores
+            nthr = max(1, min(16, os.cpu_count() or 1))
+            if nthr > 1:
+                out["cpu_baseline_openmp"] = cpu_baseline(args, threads=nthr)
         print(json.dumps(out), flush=True)
     D.barrier(dist)
     if dist is not None:

@@ -123,4 +123,7 @@ def test_shard_errors():
     eng.set_range(0, 0, 20)
     with pytest.raises(VilFusionError):
         eng.solve_local()                        # 20 keyframes cannot hold 6 chunks
+    for whole_window_call in (lambda: eng.iterate(1), eng.solve, eng.decide, eng.marginalize):
+        with pytest.raises(VilFusionError):
+            whole_window_call()                  # a shard cannot run whole-window stages on its own
     eng.close()

@@ -374,8 +374,15 @@ int vf_engine_assemble(vf_engine* e) {
     HIPCHK(hipGetLastError());
     return VF_OK;
 }
+static int not_sharded(vf_engine* e, const char* what) {
+    if (e->v.sh_G > 1)
+        return fail(VF_ERR_INVALID, "%s works on whole windows; this engine holds shard %d of %d (use the staged calls, "
+                    "include/vilfusion.h \"time-sharded windows\")", what, e->v.sh_r, e->v.sh_G);
+    return VF_OK;
+}
 int vf_engine_solve(vf_engine* e) {
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (int rc = not_sharded(e, "vf_engine_solve")) return rc;
     vf::launch_band_solve(e->v, e->stream);
     HIPCHK(hipGetLastError());
     return VF_OK;
@@ -388,6 +395,7 @@ int vf_engine_retract(vf_engine* e) {
 }
 int vf_engine_decide(vf_engine* e, int init) {
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (int rc = not_sharded(e, "vf_engine_decide")) return rc;
     vf::launch_decide(e->v, init ? 1 : 0, e->stream);
     HIPCHK(hipGetLastError());
     return VF_OK;
@@ -395,6 +403,7 @@ int vf_engine_decide(vf_engine* e, int init) {
 int vf_engine_iterate(vf_engine* e, int iterations) {
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (iterations < 0) return fail(VF_ERR_INVALID, "iterations < 0");
+    if (int rc0 = not_sharded(e, "vf_engine_iterate")) return rc0;
     // every solve starts from lambda0, as a fresh LevenbergMarquardtOptimizer would
     std::vector<double> lam((size_t)e->v.B, e->opts.lambda0);
     HIPCHK(hipMemcpyAsync(e->v.lambda, lam.data(), e->v.B * sizeof(double), hipMemcpyHostToDevice, e->stream));
@@ -527,6 +536,7 @@ int vf_engine_predict(vf_engine* e, int window, int k0, int n) {
 
 int vf_engine_marginalize(vf_engine* e) {
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (int rc = not_sharded(e, "vf_engine_marginalize")) return rc;
     for (int w = 0; w < e->v.B; w++)
         if (e->h_hi[w] - e->h_lo[w] < 4) return fail(VF_ERR_INVALID, "window %d: marginalisation needs >= 4 keyframes", w);
     HIPCHK(hipMemsetAsync(e->status_dev, 0, sizeof(int), e->stream));

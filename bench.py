@@ -44,7 +44,8 @@ def make_engine(args, rank, local_rank, windows):
         eng.set_states(w, 0, gt0.reshape(1, 16))
         eng.set_prior(w, 0, synth.prior_record(gt0, REFERENCE_PRIOR_SIGMAS))
         eng.set_range(w, 0, 1)
-        eng.predict(w, 1, n - 1)
+    eng.predict(-1, 1, n - 1)         # initial values by IMU prediction, all windows in one launch
+    for w in range(windows):
         eng.set_range(w, 0, n)
     eng.sync()
     eng.iterate(args.iterations)      # converge the initial windows (not timed)

@@ -1,3 +1,4 @@
+"""Prints the per-kernel rows of a rocprofv3 --kernel-trace --stats --output-format csv directory."""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)
 for r in csv.DictReader(open(f[0])):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): scratch/profile_round.sh <tag>
+# usage (on the GPU box, from the repo root): tools/profile_round.sh <tag>
 tag=$1
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$tag

@@ -1,3 +1,4 @@
+"""s_memtime stamps of k_sep_solve (diagnostic build: tools/build_stamps.sh): usage tools/sep_stamps_probe.py <chunks>."""
 import sys, ctypes as C, numpy as np, os
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, ROOT)

@@ -1,7 +1,10 @@
+"""Times the K4 forms on synthetic windows: usage tools/solve_forms_probe.py <keyframes> <windows> <chunks,chunks,...>
+(chunks: 0 = the engine's choice, 1 = whole-window sweeps, P >= 2 = partitioned solve with P chunks).
+VF_VARIANT=<path to a diagnostic libvilfusion build> times that build instead."""
 import sys, os, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from vil_sensor_fusion_amd import _lib
-if os.environ.get('VF_VARIANT'): _lib._SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libvf_' + os.environ['VF_VARIANT'] + '.so')
+if os.environ.get('VF_VARIANT'): _lib._SO = os.path.abspath(os.environ['VF_VARIANT'])
 from vil_sensor_fusion_amd import Engine, EngineOpts, synth
 from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000

@@ -154,6 +154,7 @@ class Engine:
         return dict(on=on.value, xbar=x, L=L, eta=eta)
 
     def predict(self, window, k0, n):
+        """Initial values of keyframes [k0, k0+n) by IMU prediction from k0-1; window = -1: every window."""
         check(self._l.vf_engine_predict(self._h, window, k0, n))
 
     def sync(self):

@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--reanchor", action="store_true", help="drop the oldest keyframe by re-anchoring tight priors instead of marginalising it")
     ap.add_argument("--sharded-window", type=int, default=10000, help="keyframes of the time-sharded window (BASELINE configs[4])")
     ap.add_argument("--no-sharded", action="store_true")
+    ap.add_argument("--no-convergence-exit", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -177,6 +178,28 @@ def main():
     fence()
     dt = D.max_over_ranks(dist, time.perf_counter() - t0, device=dev if (dist is not None and backend == "nccl") else "cpu")
     summaries = D.gather_summaries(dist, dict(rank=info.rank, keyframes=args.windows * args.steps))
+
+    # Same update with GTSAM's LM termination rule switched on (vf_engine_set_convergence): a second,
+    # clearly labelled number -- the headline above always runs all K trials on every window.
+    conv = None
+    if not args.no_convergence_exit:
+        before = [eng.read_lm(w) for w in (0, args.windows - 1)]
+        eng.set_convergence(1e-5, 1e-5)
+        for _ in range(args.warmup):
+            one_step(eng)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step(eng)
+        fence()
+        dt_c = D.max_over_ranks(dist, time.perf_counter() - t1, device=dev if (dist is not None and backend == "nccl") else "cpu")
+        after = [eng.read_lm(w) for w in (0, args.windows - 1)]
+        trials = [(a["accepted"] + a["rejected"] - b["accepted"] - b["rejected"]) / (args.steps + args.warmup) for a, b in zip(after, before)]
+        eng.set_convergence(0.0, 0.0)
+        conv = {"value": info.world * args.windows * args.steps / dt_c, "unit": "keyframes/s", "ms_per_step": dt_c / args.steps * 1e3,
+                "rule": "stop a window after an accepted trial with cost decrease <= 1e-5 absolute or relative "
+                        "(gtsam LevenbergMarquardtParams defaults), at most K trials",
+                "trials_per_update_first_last_window": trials}
 
     sharded = None
     if not args.no_sharded and 48 % info.world == 0:
@@ -219,6 +242,8 @@ def main():
             "stage_ms": stages,
             "lm_state_window0": eng.read_lm(0),
         }
+        if conv is not None:
+            out["with_convergence_exit"] = conv
         if sharded is not None:
             out["time_sharded_window"] = sharded
         if not args.no_single_window:

@@ -151,6 +151,13 @@ int vf_engine_decide_partial(vf_engine* e, int init);
 int vf_engine_decide_total(vf_engine* e, int init);
 int vf_engine_reset_lambda(vf_engine* e);   /* lambda := lambda0, as vf_engine_iterate does before its first trial */
 
+/* Optional LM termination (off by default: vf_engine_iterate runs exactly `iterations` trials).  With a
+ * tolerance > 0, a window whose accepted trial lowers the cost by <= abs_tol, or by <= rel_tol * cost, is
+ * converged and takes no part in the remaining trials of that solve: the rule of
+ * gtsam::LevenbergMarquardtOptimizer (checkConvergence; LevenbergMarquardtParams defaults 1e-5 / 1e-5), the
+ * optimiser commented out at GraphManager.cpp:128-129.  (0, 0) switches it off again. */
+int vf_engine_set_convergence(vf_engine* e, double rel_tol, double abs_tol);
+
 /* Fixed-lag marginalisation of every window's oldest keyframe (no reference code: the
  * reference's iSAM2 graph is unbounded): Schur complement of all factors touching it, at the
  * current linearisation, into a dense Gaussian prior on [next: 15 dof][next+1: pose][next+2:

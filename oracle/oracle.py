@@ -63,7 +63,8 @@ class Problem(C.Structure):
 class LmOpts(C.Structure):
     _fields_ = [("lambda0", C.c_double), ("lambda_up", C.c_double), ("lambda_down", C.c_double),
                 ("lambda_min", C.c_double), ("lambda_max", C.c_double),
-                ("iterations", C.c_int), ("n_threads", C.c_int)]
+                ("iterations", C.c_int), ("n_threads", C.c_int),
+                ("rel_tol", C.c_double), ("abs_tol", C.c_double)]
 
 
 _lib = None
@@ -317,8 +318,8 @@ class Window:
         return cost, H, g
 
     def lm(self, iterations=5, lambda0=1e-5, up=10.0, down=10.0, lmin=1e-12, lmax=1e10,
-           n_threads=1):
-        o = LmOpts(lambda0, up, down, lmin, lmax, iterations, n_threads)
+           n_threads=1, rel_tol=0.0, abs_tol=0.0):
+        o = LmOpts(lambda0, up, down, lmin, lmax, iterations, n_threads, rel_tol, abs_tol)
         costs = np.zeros(iterations + 1)
         acc = np.zeros(iterations, dtype=np.int32)
         lam = lib().vfo_lm(C.byref(self.c), C.byref(o), _d(costs),

@@ -1186,7 +1186,13 @@ double vfo_lm(vfo_problem* p, const vfo_lm_opts* o, double* costs_out, int* acce
     double lambda = o->lambda0;
     double cost = vfo_assemble(p, w, H, g, o->n_threads);
     if (costs_out) costs_out[0] = cost;
+    int converged = 0;
     for (int it = 0; it < o->iterations; it++) {
+        if (converged) {
+            if (costs_out) costs_out[it + 1] = cost;
+            if (accepted_out) accepted_out[it] = -1;
+            continue;
+        }
         int ok = vfo_band_solve(n, w, H, g, lambda, d) == 0, acc = 0;
         if (ok) {
             memcpy(xs, p->states, sizeof(double) * (size_t)n * 16);
@@ -1196,6 +1202,8 @@ double vfo_lm(vfo_problem* p, const vfo_lm_opts* o, double* costs_out, int* acce
             double cn = vfo_assemble(p, w, Hn, gn, o->n_threads);
             if (cn < cost) { /* NaN compares false -> reject */
                 acc = 1;
+                if ((o->abs_tol > 0.0 || o->rel_tol > 0.0) &&
+                    (cost - cn <= o->abs_tol || cost - cn <= o->rel_tol * cost)) converged = 1;
                 cost = cn;
                 free(H); free(g);
                 H = Hn; g = gn;

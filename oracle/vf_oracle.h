@@ -129,6 +129,8 @@ typedef struct {
     double lambda0, lambda_up, lambda_down, lambda_min, lambda_max;
     int iterations;              /* fixed trip count (one trial per iteration) */
     int n_threads;               /* >1: OpenMP over factors in linearisation */
+    double rel_tol, abs_tol;     /* > 0: stop after an accepted trial whose cost decrease is <= abs_tol or
+                                    <= rel_tol * cost (gtsam LevenbergMarquardtOptimizer checkConvergence) */
 } vfo_lm_opts;
 
 /* total cost 0.5*sum |r|^2 at the current states */
@@ -142,7 +144,7 @@ double vfo_assemble(const vfo_problem* p, int w, double* Hband, double* g, int n
 int vfo_band_solve(int n_kf, int w, const double* Hband, const double* g, double lambda,
                    double* delta);
 /* Fixed-trip LM; costs_out[iterations+1] (cost after each iteration, [0] = initial),
- * accepted_out[iterations]. Returns final lambda. */
+ * accepted_out[iterations] (-1 = trial not run: converged earlier). Returns final lambda. */
 double vfo_lm(vfo_problem* p, const vfo_lm_opts* o, double* costs_out, int* accepted_out);
 
 /* d (27) of a marginal prior at the current states */

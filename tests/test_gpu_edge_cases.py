@@ -281,3 +281,41 @@ def test_graph_manager_runs_past_its_capacity_with_a_lag():
         (q, t), v, b = gm.getState()
         finals.append(np.concatenate([q, t, v, b]))
     np.testing.assert_array_equal(finals[0], finals[1])
+
+
+def test_lm_convergence_exit_matches_oracle(oracle):
+    """Optional LM termination (vf_engine_set_convergence = GTSAM's LM tolerances): the converged window
+    stops taking trials; same number of trials, same trajectory as the oracle under the same rule.
+    A second, harder window in the same engine keeps iterating (the flag is per window)."""
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    n, iters = 120, 10
+    eng = Engine(EngineOpts(windows=2, capacity=n + 8))
+    probs = []
+    for w, perturb in enumerate((0.001, 0.05)):
+        seq = synth.make_sequence(seed=40 + w, n_kf=n)
+        prob = helpers.build_problem(oracle, seq, perturb=perturb)
+        helpers.load_engine(eng, w, prob)
+        probs.append(prob)
+    eng.set_convergence(1e-5, 1e-5)
+    eng.iterate(iters)
+    trials = []
+    for w in range(2):
+        win = helpers.oracle_window(oracle, probs[w])
+        costs, acc, _ = win.lm(iterations=iters, rel_tol=1e-5, abs_tol=1e-5)
+        ran = int((acc >= 0).sum())
+        lm = eng.read_lm(w)
+        a, r = helpers.ate(eng.get_states(w, 0, n), win.states)
+        print(f"window {w}: trials gpu {lm['accepted'] + lm['rejected']} oracle {ran}; ATE {a:.3e}")
+        assert lm["accepted"] + lm["rejected"] == ran
+        assert lm["accepted"] == int((acc == 1).sum())
+        assert a <= 1e-6 and r <= 1e-6
+        trials.append(ran)
+    assert trials[0] < iters                 # the easy window stopped early
+    # switched off again: exactly `iters` trials
+    eng.set_convergence(0.0, 0.0)
+    before = [eng.read_lm(w) for w in range(2)]
+    eng.iterate(3)
+    for w in range(2):
+        lm = eng.read_lm(w)
+        assert lm["accepted"] + lm["rejected"] - before[w]["accepted"] - before[w]["rejected"] == 3
+    eng.close()

@@ -212,3 +212,21 @@ def test_prior_factor_fd(oracle):
     np.testing.assert_allclose(J * sig[:, None], Jn * sig[:, None], atol=5e-8)
     r1, _ = oracle.prior_factor(rec, mean)
     np.testing.assert_allclose(r1, 0, atol=1e-9)
+
+
+def test_oracle_lm_convergence_rule(oracle):
+    """vfo_lm with GTSAM's termination tolerances: trials after convergence are not run (accepted = -1),
+    the cost stays put, and the result equals the fixed-trip run truncated at the same trial."""
+    from tests import helpers
+    from vil_sensor_fusion_amd import synth
+    seq = synth.make_sequence(seed=3, n_kf=40)
+    prob = helpers.build_problem(oracle, seq, perturb=0.002)
+    a = helpers.oracle_window(oracle, prob)
+    costs, acc, _ = a.lm(iterations=8, rel_tol=1e-5, abs_tol=1e-5)
+    ran = int((acc >= 0).sum())
+    assert 1 <= ran < 8 and (acc[ran:] == -1).all()
+    assert (costs[ran:] == costs[ran]).all()
+    b = helpers.oracle_window(oracle, prob)
+    costs_b, acc_b, _ = b.lm(iterations=ran)
+    np.testing.assert_array_equal(a.states, b.states)
+    np.testing.assert_array_equal(costs[:ran + 1], costs_b)

@@ -65,7 +65,7 @@ SYMBOLS = [
     "vf_engine_marginalize", "vf_engine_drop_oldest", "vf_engine_read_marginal", "vf_engine_compact",
     "vf_engine_set_stream", "vf_engine_set_shard", "vf_engine_shard_info", "vf_engine_solve_local",
     "vf_engine_solve_global", "vf_engine_decide_partial", "vf_engine_decide_total", "vf_engine_reset_lambda",
-    "vf_chunk_geometry", "vf_shard_range",
+    "vf_chunk_geometry", "vf_shard_range", "vf_engine_set_convergence",
     "vf_graph_default_opts", "vf_create", "vf_destroy", "vf_add_imu", "vf_reserve_node",
     "vf_add_between", "vf_solve", "vf_get_state", "vf_get_bias", "vf_most_recent_pose_time",
     "vf_set_callback", "vf_graph_staged", "vf_get_trajectory", "vf_get_imu_factor",

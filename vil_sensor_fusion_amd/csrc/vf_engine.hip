@@ -165,6 +165,9 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.n_rej, (size_t)v.B);
     AL(v.n_fail, (size_t)v.B);
     AL(v.cost_part, 2 * (size_t)v.B);
+    AL(v.done, (size_t)v.B);
+    v.stop_on = 0;
+    v.rel_tol = v.abs_tol = 0.0;
     v.sh_r = 0;
     v.sh_G = 1;
     AL(e->sigma_dev, 16);
@@ -360,8 +363,11 @@ int vf_engine_get_imu(vf_engine* e, int window, int k0, int n, double* rec) {
 int vf_engine_linearize(vf_engine* e, int which) {
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     which = which ? 1 : 0;
-    // a new linearisation of the CURRENT states invalidates H, g
-    if (!which) HIPCHK(hipMemsetAsync(e->v.fresh, 0x01, e->v.B * sizeof(int), e->stream));
+    // a new linearisation of the CURRENT states invalidates H, g and starts a new solve (no window is converged yet)
+    if (!which) {
+        HIPCHK(hipMemsetAsync(e->v.fresh, 0x01, e->v.B * sizeof(int), e->stream));
+        HIPCHK(hipMemsetAsync(e->v.done, 0, e->v.B * sizeof(int), e->stream));
+    }
     vf::launch_linearize_imu(e->v, which, e->stream);
     vf::launch_linearize_between(e->v, which, e->stream);
     vf::launch_linearize_prior(e->v, which, e->stream);
@@ -515,6 +521,16 @@ int vf_engine_decide_total(vf_engine* e, int init) {
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     vf::launch_decide_mode(e->v, init ? 1 : 0, 2, e->stream);
     HIPCHK(hipGetLastError());
+    return VF_OK;
+}
+int vf_engine_set_convergence(vf_engine* e, double rel_tol, double abs_tol) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (!(rel_tol >= 0.0) || !(abs_tol >= 0.0)) return fail(VF_ERR_INVALID, "tolerances must be >= 0");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->v.rel_tol = rel_tol;
+    e->v.abs_tol = abs_tol;
+    e->v.stop_on = (rel_tol > 0.0 || abs_tol > 0.0) ? 1 : 0;
+    HIPCHK(hipMemsetAsync(e->v.done, 0, e->v.B * sizeof(int), e->stream));
     return VF_OK;
 }
 int vf_engine_reset_lambda(vf_engine* e) {
@@ -754,14 +770,16 @@ int vf_engine_read_lm(vf_engine* e, int window, double* cost, double* lambda, in
 // ------------------------------------------------------------------ measurement
 int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms) {
     if (!e || !avg_ms || reps < 1) return fail(VF_ERR_INVALID, "bad argument");
+    vf::View tv = e->v;
+    tv.stop_on = 0;           // stage timings are of the full work, whatever the windows' convergence flags say
     auto run = [&]() {
         switch (stage) {
-            case VF_STAGE_LINEARIZE_IMU: vf::launch_linearize_imu(e->v, 0, e->stream); break;
-            case VF_STAGE_LINEARIZE_BTW: vf::launch_linearize_between(e->v, 0, e->stream); break;
-            case VF_STAGE_ASSEMBLE: vf::launch_assemble(e->v, e->stream); break;
-            case VF_STAGE_SOLVE: vf::launch_band_solve(e->v, e->stream); break;
-            case VF_STAGE_RETRACT: vf::launch_retract(e->v, e->stream); break;
-            case VF_STAGE_DECIDE: vf::launch_decide(e->v, 1, e->stream); break;
+            case VF_STAGE_LINEARIZE_IMU: vf::launch_linearize_imu(tv, 0, e->stream); break;
+            case VF_STAGE_LINEARIZE_BTW: vf::launch_linearize_between(tv, 0, e->stream); break;
+            case VF_STAGE_ASSEMBLE: vf::launch_assemble(tv, e->stream); break;
+            case VF_STAGE_SOLVE: vf::launch_band_solve(tv, e->stream); break;
+            case VF_STAGE_RETRACT: vf::launch_retract(tv, e->stream); break;
+            case VF_STAGE_DECIDE: vf::launch_decide(tv, 1, e->stream); break;
             default: break;
         }
     };

@@ -23,6 +23,9 @@ namespace vf {
 
 #define XS(buf, c, gk) v.x[((size_t)(buf) * 16 + (c)) * (size_t)v.G + (size_t)(gk)]
 
+// optional LM termination: a window that has converged takes no part in the remaining trials of this solve
+VF_DI bool window_done(const View& v, int w) { return v.stop_on && v.done[w]; }
+
 // Time-sharded windows: the window-local keyframe range [klo, khi) and the chunk range [c0, c1) rank sh_r owns.
 // A chunk owns its interior keyframes and the separator that follows it; a factor belongs to its later keyframe.
 VF_DI void own_chunks(const View& v, int Pe, int& c0, int& c1) {
@@ -235,7 +238,7 @@ __global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_imu(View
     if (gk >= v.G) return;
     const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
     if (k <= v.lo[w] || k >= v.hi[w]) return;
-    if (shard_skips_factor(v, w, k)) return;
+    if (shard_skips_factor(v, w, k) || window_done(v, w)) return;
     const int b = v.sel[w] ^ which;
 
     const double* __restrict__ in = v.imu_in + (size_t)(gk >> 6) * IMU_IN * TILE + (gk & 63);
@@ -394,7 +397,7 @@ __global__ void __launch_bounds__(256) k_linearize_between(View v, int which) {
     const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
     const int lo = v.lo[w];
     if (k <= lo || k >= v.hi[w]) return;
-    if (shard_skips_factor(v, w, k)) return;
+    if (shard_skips_factor(v, w, k) || window_done(v, w)) return;
     const int a = v.btw_a[gk];
     if (a < lo || a >= k) return;
     const int b = v.sel[w] ^ which;
@@ -496,7 +499,7 @@ VF_DI void marg_delta(const View& v, int w, int b, double (&d)[27]) {
 
 __global__ void k_linearize_prior(View v, int which) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= v.B) return;
+    if (w >= v.B || window_done(v, w)) return;
     const int b = v.sel[w] ^ which;
     if (v.mp_on[w] && v.hi[w] - v.lo[w] >= 3) {
         // marginal prior: gm = L d + eta, cost = 0.5 d^T L d + eta^T d (fixed linearisation point)
@@ -575,7 +578,7 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
     if (k0 + AT <= rlo || k0 >= rhi) return; // no owned active keyframe in this tile (uniform)
     // a rejected LM trial leaves the current linearisation, hence H and g, unchanged: nothing to do
     // (k_decide clears `fresh` on reject; accept / init / slide set it)
-    if (!v.fresh[w]) return;
+    if (!v.fresh[w] || window_done(v, w)) return;
     const int b = v.sel[w];
     const int tid = threadIdx.x;
     const size_t tiles = (size_t)(v.G >> 6);
@@ -1303,7 +1306,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 
 __global__ void __launch_bounds__(64) k_band_solve(View v) {
     const int w = blockIdx.x;
-    if (v.hi[w] - v.lo[w] <= 0) return;
+    if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w)) return;
     __shared__ double S[S_TOTAL];
     band_solve_body<SOLVE_FULL>(v, S, nullptr, nullptr, w, threadIdx.x, 0);
 }
@@ -1312,7 +1315,7 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
 __global__ void __launch_bounds__(128) k_band_solve_tw(View v) {
     const int w = blockIdx.x;
     const int n = v.hi[w] - v.lo[w];
-    if (n <= 0) return;
+    if (n <= 0 || window_done(v, w)) return;
     __shared__ double S2[2 * S_TOTAL];
     __shared__ double MID[MID_TOTAL];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1476,7 +1479,7 @@ __device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int
 __global__ void __launch_bounds__(128) k_chunk_forward(View v) {
     const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
     const int n = v.hi[w] - v.lo[w];
-    if (n <= 0) return;
+    if (n <= 0 || window_done(v, w)) return;
     const int Pe = chunk_count(n, P, v.P_fit);
     int oc0, oc1;
     own_chunks(v, Pe, oc0, oc1);
@@ -1490,7 +1493,7 @@ __global__ void __launch_bounds__(128) k_chunk_forward(View v) {
 __global__ void __launch_bounds__(64) k_chunk_back(View v) {
     const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
     const int n = v.hi[w] - v.lo[w];
-    if (n <= 0) return;
+    if (n <= 0 || window_done(v, w)) return;
     const int Pe = chunk_count(n, P, v.P_fit);
     int oc0, oc1;
     own_chunks(v, Pe, oc0, oc1);
@@ -1503,7 +1506,7 @@ __global__ void __launch_bounds__(64) k_chunk_back(View v) {
 __global__ void __launch_bounds__(256) k_chunk_rhs(View v) {
     const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
     const int lo = v.lo[w], n = v.hi[w] - lo;
-    if (n <= 0) return;
+    if (n <= 0 || window_done(v, w)) return;
     const int Pe = chunk_count(n, P, v.P_fit);
     int oc0, oc1;
     own_chunks(v, Pe, oc0, oc1);
@@ -1557,7 +1560,7 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
     const int P = v.P, w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches on the role
     const int lo = v.lo[w], n = v.hi[w] - lo;
-    if (n <= 0) return;
+    if (n <= 0 || window_done(v, w)) return;
     const int Pe = chunk_count(n, P, v.P_fit), m = Pe - 1;
     if (m <= 0) return;
     __shared__ __attribute__((aligned(16))) double colbuf[3][48];  // column c of the pivot rows (47 = sink of the other rows)
@@ -1772,7 +1775,7 @@ __global__ void __launch_bounds__(256) k_retract(View v) {
     const long gk = (long)blockIdx.x * 256 + threadIdx.x;
     if (gk >= v.G) return;
     const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
-    if (k < v.lo[w] || k >= v.hi[w]) return;
+    if (k < v.lo[w] || k >= v.hi[w] || window_done(v, w)) return;
     const int b = v.sel[w];
     const State s = load_state(v, b, gk);
     const double* d = v.delta + (size_t)gk * 15;
@@ -1794,6 +1797,7 @@ __global__ void __launch_bounds__(256) k_retract(View v) {
 // -> cost_part (the host side sums it over the ranks), mode 2 = accept / reject with cost_part as the total.
 __global__ void __launch_bounds__(256) k_decide(View v, int init, int mode) {
     const int w = blockIdx.x, tid = threadIdx.x;
+    if (window_done(v, w) && !init) return;
     const int lo = v.lo[w], hi = v.hi[w];
     int klo, khi;
     own_range(v, w, klo, khi);
@@ -1842,11 +1846,16 @@ __global__ void __launch_bounds__(256) k_decide(View v, int init, int mode) {
             v.cost[w] = c;
             v.fail[w] = 0;
             v.fresh[w] = 1;
+            if (v.stop_on) v.done[w] = 0;
         } else {
             const bool ok = (v.fail[w] == 0) && (c < v.cost[w]);
             if (v.fail[w]) v.n_fail[w] += 1;
             v.fresh[w] = ok ? 1 : 0;
             if (ok) {
+                if (v.stop_on) {   // gtsam checkConvergence on the accepted step
+                    const double dec = v.cost[w] - c;
+                    if (dec <= v.abs_tol || dec <= v.rel_tol * v.cost[w]) v.done[w] = 1;
+                }
                 v.sel[w] ^= 1;
                 v.cost[w] = c;
                 v.n_acc[w] += 1;

@@ -98,6 +98,13 @@ struct View {
     int* n_rej;
     int* n_fail;
     double lam_up, lam_down, lam_min, lam_max;
+    // optional LM termination (off by default: every vf_engine_iterate runs its fixed number of trials).  With
+    // stop_on, a window whose accepted trial lowers the cost by <= abs_tol, or by <= rel_tol relative to the cost
+    // (gtsam::LevenbergMarquardtParams relativeErrorTol / absoluteErrorTol, checkConvergence), is done: every
+    // kernel of the remaining trials skips it.
+    int stop_on;
+    double rel_tol, abs_tol;
+    int* done;          // [B]
 };
 
 // isotropic IMU covariances (ImuManagerRos.cpp:20-33)

@@ -188,6 +188,11 @@ class Engine:
     def reset_lambda(self):
         check(self._l.vf_engine_reset_lambda(self._h))
 
+    def set_convergence(self, rel_tol=1e-5, abs_tol=1e-5):
+        """Stop a window's LM trials once an accepted step lowers its cost by <= abs_tol or by <= rel_tol * cost
+        (GTSAM's LM rule; off by default, (0, 0) switches it off)."""
+        check(self._l.vf_engine_set_convergence(self._h, C.c_double(rel_tol), C.c_double(abs_tol)))
+
     # ---- read-back
     def read_imu_lin(self, window, k0, n, which=0):
         r, J = np.zeros((n, 15)), np.zeros((n, 15, 30))

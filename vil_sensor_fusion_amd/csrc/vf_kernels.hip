@@ -7,14 +7,20 @@
 //                           (factor built at GraphManager.cpp:86)
 //   K2b k_linearize_prior   the three priors of GraphManager.cpp:27-35
 //   K3 k_assemble           block-banded J^T J / J^T r, owner-computes per keyframe
-//   K4 k_band_solve         (H + lambda I) delta = -g, block-banded Cholesky, one wave/window
+//   K0 k_preintegrate       combined-IMU preintegration (IMUManager.cpp:42-64 + GTSAM's PIM)
+//   K4 k_band_solve(_tw)    (H + lambda I) delta = -g, block-banded Cholesky, one wave per window
+//                           (_tw: two waves from both ends)
+//   K4p k_chunk_forward, k_sep_solve, k_chunk_rhs, k_chunk_back
+//                           the same solve partitioned into chunks joined by 45-dof separators
+//                           (one-window latency; the per-GPU piece of a time-sharded window)
+//   K-marg k_marginalize    fixed-lag marginalisation of the oldest keyframe into a dense prior
 //   K5 k_retract, k_decide  x (+) delta, cost reduction, LM accept/reject
 //   a2 k_predict, k_slide   PreintegrationBase::predict initial values (GraphManager.cpp:152-160)
 //
 // Mapping: one lane per factor / keyframe for K1-K3,K5 (HBM-bound, coalesced AoSoA tiles of 64:
-// lane l of a wave reads word l of a 512-byte field row), one 64-lane wave per window for K4
-// (latency-bound; panel factorisation in registers with v_readlane broadcasts, trailing
-// window in LDS).
+// lane l of a wave reads word l of a 512-byte field row), one 64-lane wave per window or per
+// chunk for K4 / K4p (latency-bound; panel factorisation in registers with v_readlane broadcasts,
+// trailing window in LDS, Schur / spike products on v_mfma_f64_16x16x4).
 #include "vf_kernels.hpp"
 #include "vf_math.hpp"
 #include <cstdlib>
@@ -1593,9 +1599,6 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
     int zero_v;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
     const double* cb = &colbuf[0][0] + zero_v;
-#ifndef VF_SEP_SKIP
-#define VF_SEP_SKIP 0
-#endif
 #ifdef VF_SOLVE_STAMPS
     unsigned long long sst[16] = {0}, stprev = __builtin_amdgcn_s_memtime();
 #endif
@@ -1618,7 +1621,7 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
             int da[33], dc[33];
 #pragma unroll
             for (int c = 0; c < SEP; c++) {
-                if (c < 33 && !(VF_SEP_SKIP & 4)) {
+                if (c < 33) {
                     const int e = lane + 64 * c + sz, ed = e < SEP * 46 ? e : 0;
                     ba[c] = pa[ed];
                     bb[c] = pb[ed];
@@ -1626,7 +1629,7 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
                     bc[c] = pc[e < SEP * SEP ? e : 0];
                     dc[c] = dst_c(e);
                 }
-                if (!(VF_SEP_SKIP & 4)) LDS_BARRIER();
+                LDS_BARRIER();
             }
 #pragma unroll
             for (int q = 0; q < 33; q++) { Dn[da[q]] = ba[q] + bb[q]; Dn[dc[q]] = bc[q]; }
@@ -1639,7 +1642,7 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
             SSTAMP(1);
             double pc_prev = 0.0;
 #pragma unroll
-            for (int c = 0; c < ((VF_SEP_SKIP & 4) ? 0 : SEP); c++) {
+            for (int c = 0; c < SEP; c++) {
                 col_w[(c % 3) * 48] = p[c];
                 LDS_BARRIER();
                 double piv = cb[(c % 3) * 48 + c];
@@ -1661,7 +1664,7 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
             }
             SSTAMP(2);
             // factor rows -> HBM, column-major: one contiguous 8-byte-per-lane store per column
-            if (tid < 91 && !(VF_SEP_SKIP & 1)) {
+            if (tid < 91) {
                 double* dst = Lx + (size_t)s * SEPL + tid;
 #pragma unroll
                 for (int c = 0; c < SEP; c++) dst[c * LXS] = p[c];
@@ -1673,7 +1676,7 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
         }
         LDS_BARRIER();
         SSTAMP(3);
-        if (more && !(VF_SEP_SKIP & 2)) {
+        if (more) {
             // D_{s+1} -= Z Z^T, rhs_{s+1} -= Z y on the matrix cores: 3 x 3 tiles of 16 x 16, three per wave,
             // K = 45 (12 steps of 4); both operands come from the Z rows in LDS (row 45 = y)
             const int li = lane & 15, lq = lane >> 4;
@@ -1718,7 +1721,7 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
     if (tid < 48) dnext[tid] = 0.0;
     __syncthreads();
 #pragma unroll 1
-    for (int s = (VF_SEP_SKIP & 8) ? -1 : m - 1; s >= 0; s--) {
+    for (int s = m - 1; s >= 0; s--) {
         if (wave != 0) {
             if (s > 0) copy_factor(s - 1, (s - 1) & 1, tid - 64);
         } else {

@@ -84,6 +84,34 @@ def test_assemble_parity(setup, oracle):
         assert abs(eng.read_lm(w)["cost"] - cost) <= 1e-10 * cost
 
 
+def test_assemble_parity_ragged_windows_in_a_large_batch(oracle):
+    """K3 on ragged windows spread over a large batch (2560 tiles): same H, g as the oracle."""
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    n, B = 150, 160
+    eng = Engine(EngineOpts(windows=B, capacity=256))
+    picks = {0: (0, n), 77: (3, 131), 159: (17, n), 80: (0, 40)}
+    probs = {}
+    for w, (lo, hi) in picks.items():
+        seq = synth.make_sequence(seed=100 + w, n_kf=n)
+        probs[w] = helpers.build_problem(oracle, seq, perturb=0.01)
+        helpers.load_engine(eng, w, probs[w], lo=lo, hi=hi)
+    eng.linearize(0)
+    eng.assemble()
+    for w, (lo, hi) in picks.items():
+        H, g = eng.read_normal(w, lo, hi - lo)
+        cost, Ho, go = helpers.oracle_window(oracle, probs[w], lo=lo, hi=hi).assemble(w=3)
+        for k in range(hi - lo):
+            for d in range(min(k, 3) + 1):
+                if np.abs(Ho[k, d]).max() == 0:
+                    assert np.abs(H[k, d][:6, :6]).max() == 0 or d < 2
+                else:
+                    blk = H[k, d] if d < 2 else H[k, d][:6, :6]
+                    ref = Ho[k, d] if d < 2 else Ho[k, d][:6, :6]
+                    assert relerr(blk, ref) < 1e-10, (w, k, d)
+        assert relerr(g, go) < 1e-10
+    eng.close()
+
+
 def band_matvec(H, lam, x):
     """(H + lam I) x for the block-banded storage (block d of row k = H[k][k-d])."""
     n = H.shape[0]

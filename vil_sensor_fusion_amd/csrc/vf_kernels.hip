@@ -778,6 +778,7 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
     }
 }
 
+
 // ------------------------------------------------------------------------------------ K4
 VF_DI double readlane_d(double x, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
@@ -2109,6 +2110,8 @@ void launch_linearize_prior(const View& v, int which, hipStream_t s) {
     hipLaunchKernelGGL(k_linearize_prior, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, which);
 }
 void launch_assemble(const View& v, hipStream_t s) {
+    // (a persistent one-workgroup-per-CU form with the next tile's loads in flight was measured at 5.1 ms against
+    // 2.8 ms for this one: the LDS / MFMA phase of a tile, not its HBM round trip, is what two workgroups per CU hide)
     hipLaunchKernelGGL(k_assemble, dim3(nblk(v.G, AT)), dim3(256), 0, s, v);
 }
 void launch_partitioned_local(const View& v, hipStream_t s) {

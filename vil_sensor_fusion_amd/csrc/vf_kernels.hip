@@ -911,11 +911,8 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     constexpr int RSLOT = RINGM ? RING_SLOT : 0;
     const int pw_off = (lane >= 15 && lane < (RINGM ? 58 : 43)) ? S_P + (lane - 15) * 15
                                                                 : (RINGM ? S_P + 646 : S_DUMP + 16);   // sub-panel -> LDS
-    if constexpr (RINGM) {
-        if (lane < 4) S[S_P + lane * RING_SLOT + 645] = 0.0;
-        if (lane == 4) S[S_PROG] = 0.0;
-        if (lane == 5) S[S_CONS] = 0.0;
-    }
+    // (the ring's zero cells and hand-shake counters are initialised by k_chunk_forward BEFORE the two waves part:
+    // the follower must never poll a counter left over in LDS by an earlier workgroup)
     const int op_zero = RINGM ? S_P + 645 : S_ZERO;
     const bool follower = RINGM && cg.i0 > 0;              // chunk 0 has no left separator, hence no spike
     // Schur write-back targets (MFMA C layout): tile t in {(0,0),(1,0),(1,1)}, register r:
@@ -1494,6 +1491,10 @@ __global__ void __launch_bounds__(128) k_chunk_forward(View v) {
     __shared__ double S[S_TOTAL_RING];
     const ChunkGeom cg = chunk_geom(n, Pe, c);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < 4) S[S_P + threadIdx.x * RING_SLOT + 645] = 0.0;   // zero cell of every ring slot
+    if (threadIdx.x == 4) S[S_PROG] = 0.0;
+    if (threadIdx.x == 5) S[S_CONS] = 0.0;
+    __syncthreads();
     if (wave == 0) band_solve_body<SOLVE_CHUNK_FWD>(v, S, nullptr, nullptr, w, lane, 0, cg, v.sepR + ((size_t)c * v.B + w) * SEPM);
     else if (c > 0) chunk_spike(v, S, w, c, cg, lane);
 }
@@ -1537,22 +1538,30 @@ __global__ void __launch_bounds__(256) k_chunk_rhs(View v) {
     }
 }
 
-// Block-tridiagonal Cholesky of the separator chain, one workgroup (3 waves) per window.
-// Forward: step s factors the 91-row panel of separator s, one row per thread of waves 0-1, 45 columns in
-// registers:     0..44  D_s (pivot block)      45..89  C_s (coupling to separator s+1)      90  rhs
-// Column operations as in the band solver: after 45 pivots the rows hold L_ss, Z = C_s L_ss^-T and y.
+// Block-tridiagonal Cholesky of the separator chain, one workgroup per window: two teams of three waves
+// eliminate the chain from both ends towards the middle separator h = m / 2 (no extra arithmetic: the
+// two-sided order of the same factorisation), then back-substitute outwards from it.
+// Forward, per team: step j factors the 91-row panel of its pivot separator, one row per thread of the
+// team's waves 0-1, 45 columns in registers:
+//     0..44  D (pivot block)      45..89  C (coupling to the next separator of this team's direction)      90  rhs
+// (team 1 walks the chain backwards, so its coupling rows are the stored blocks transposed).
+// Column operations as in the band solver: after 45 pivots the rows hold L, Z = C L^-T and y.
 // Column c of the pivot rows crosses the waves through a triple-buffered LDS column (one LDS-only barrier
 // per pivot); only column c+1 is updated on the critical path, the others after the next barrier in the
-// shadow of its rsqrt.  Wave 2 owns no rows: it stages the inputs of step s+1 (global -> registers at the
-// start of the step, -> LDS after the pivots) so that no global latency sits on the chain.
-// D_{s+1} -= Z Z^T, rhs_{s+1} -= Z y: nine 16x16 MFMA tiles, three per wave, operands from the Z rows in LDS.
-// Backward: wave 0 solves L_ss^T delta_s = y_s - Z_s^T delta_{s+1} (increment broadcast by v_readlane,
-// no barriers inside a separator) while waves 1-2 copy the factor of separator s-1 from HBM into LDS.
-// Measured cost and what bounds it: DESIGN.md "K4p".
-constexpr int ZS = 46;                       // LDS row stride of the Z / D blocks (45 columns + rhs)
+// shadow of its rsqrt.  Wave 2 of a team owns no rows: it stages the inputs of the team's next step
+// (global -> registers during the pivots, one slice between two barriers, -> LDS after them).
+// D_next -= Z Z^T, rhs_next -= Z y: nine 16x16 MFMA tiles, three per wave, operands from the Z rows in LDS.
+// The middle separator receives both teams' Schur terms and is factored by team 0.
+// Backward: wave 0 of a team solves L^T delta = y - Z^T delta(neighbour towards the middle) (increment
+// broadcast by v_readlane, no barriers inside a separator) while its waves 1-2 copy the next factor from
+// HBM into LDS.  Measured cost and what bounds it: DESIGN.md "K4p".
+constexpr int ZS = 46;                       // LDS row stride of the D / C panel input (45 columns + rhs)
 constexpr int LXS = 96;                      // HBM: factor of one separator, column-major [45][96]: rows 0..44 L, 45..89 Z, 90 y
 constexpr int FS = 97;                       // LDS row stride of the factor copy (odd: conflict-free row walks)
 constexpr int ZZ = 49;                       // LDS row stride of the Z rows (odd; zero padding = MFMA K and tile remainders)
+constexpr int SEP_FW = 144 + 48 * ZZ + 92 * ZS;      // forward LDS of one team: column buffers, Z rows, panel input
+constexpr int SEP_BW = 2 * SEP * FS;                  // backward LDS of one team: two factor copies
+constexpr int SEP_LDS = 2 * (SEP_FW > SEP_BW ? SEP_FW : SEP_BW);
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for
 // the stager's global loads and the factor stores at every one of the 45 pivot barriers of a step
 #define LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
@@ -1563,18 +1572,21 @@ __device__ unsigned long long g_sep_stamps[16];
 #define SSTAMP(i) do {} while (0)
 #endif
 static_assert(SEPL >= SEP * LXS, "factor block does not fit its HBM slot");
-__global__ void __launch_bounds__(192) k_sep_solve(View v) {
+__global__ void __launch_bounds__(384) k_sep_solve(View v) {
     const int P = v.P, w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches on the role
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches on the roles
+    const int team = wave >= 3 ? 1 : 0, tw = wave - 3 * team, tt = tid - 192 * team;
     const int lo = v.lo[w], n = v.hi[w] - lo;
     if (n <= 0 || window_done(v, w)) return;
     const int Pe = chunk_count(n, P, v.P_fit), m = Pe - 1;
     if (m <= 0) return;
-    __shared__ __attribute__((aligned(16))) double colbuf[3][48];  // column c of the pivot rows (47 = sink of the other rows)
-    __shared__ double Zs[48 * ZZ];                                 // Z rows 0..44, y = row 45; rows 46, 47 and columns 45..48 stay zero
-    __shared__ __attribute__((aligned(16))) double Dn[92 * ZS];    // panel input: D rows 0..44, C rows 45..89, rhs row 90, zero row 91
-    __shared__ double Fb[2][SEP * FS];                             // backward sweep: factor of the current / next separator
-    __shared__ double dnext[48];
+    const int h = m / 2;                         // middle separator; team 0: 0 .. h-1 then h, team 1: m-1 .. h+1
+    const int nreal = team == 0 ? h : m - 1 - h; // real forward steps of this team (the loop runs h times)
+    __shared__ __attribute__((aligned(16))) double smem[SEP_LDS];
+    __shared__ double dnext_s[2][48];
+    double* colbuf = smem + team * SEP_FW;       // [3][48]: column c of the pivot rows (47 = sink of the other rows)
+    double* Zs = colbuf + 144;                   // [48][ZZ]: Z rows 0..44, y = row 45; rows 46, 47 and columns 45..48 stay zero
+    double* Dn = Zs + 48 * ZZ;                   // [92][ZS]: panel input: D rows 0..44, C rows 45..89, rhs row 90, zero row 91
     // separator blocks are stored chunk-major, [P][B][..]: the chunks of one rank of a time-sharded window are
     // contiguous (all-gather slices); element (c, w) of this window sits c * cs (resp. c * cc) further on
     const size_t cs = (size_t)v.B * SEPM, cc = (size_t)v.B * SEP * SEP;
@@ -1583,41 +1595,73 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
     const double* __restrict__ Cx = v.sepC + (size_t)w * SEP * SEP;
     double* __restrict__ Lx = v.sepL + (size_t)w * P * SEPL;
     int failed = 0;
-    for (int e = tid; e < 92 * ZS; e += 192) Dn[e] = 0.0;
-    for (int e = tid; e < 48 * ZZ; e += 192) Zs[e] = 0.0;
+    // ---- chain geometry of this team: step j eliminates separator piv(j); its panel needs
+    //   D  = R[piv] + S[piv+1]            (the middle's own D is carried by team 0; team 1 adds Schur terms only)
+    //   C  = coupling to the next separator of the walk: sepC[piv+1] (team 0) / sepC[piv]^T (team 1)
+    auto piv = [=](int j) { return team == 0 ? j : m - 1 - j; };
+    auto d_ptrs = [=](int sidx, const double*& pa, const double*& pb) {      // D and rhs of separator sidx, or zeros
+        const bool own = sidx >= 0 && sidx < m && (team == 0 ? sidx <= h : sidx > h);
+        pa = own ? R + (size_t)sidx * cs : Sx;
+        pb = (own && sidx + 1 <= m) ? Sx + (size_t)(sidx + 1) * cs : Sx;
+    };
+    auto c_ptr = [=](int sidx) -> const double* {   // coupling rows of the step whose pivot is sidx, or zeros
+        if (team == 0) return (sidx >= 0 && sidx < h) ? Cx + (size_t)(sidx + 1) * cc : Sx;
+        return (sidx > h && sidx < m) ? Cx + (size_t)sidx * cc : Sx;
+    };
+    for (int e = tt; e < 92 * ZS; e += 192) Dn[e] = 0.0;
+    for (int e = tt; e < 48 * ZZ; e += 192) Zs[e] = 0.0;
     __syncthreads();
     // staged element (i, j) of a [45][46] (D | rhs) block / of a [45][45] coupling block -> panel input
     auto dst_d = [](int e) { const int i = e / 46, j = e - i * 46; return e < SEP * 46 ? (j == 45 ? 90 * ZS + i : i * ZS + j) : 91 * ZS + 45; };
-    auto dst_c = [](int e) { const int i = e / SEP, j = e - i * SEP; return e < SEP * SEP ? (45 + i) * ZS + j : 91 * ZS + 45; };
-    for (int e = tid; e < SEP * 46; e += 192) Dn[dst_d(e)] = R[e] + Sx[cs + e];
-    if (m > 1) for (int e = tid; e < SEP * SEP; e += 192) Dn[dst_c(e)] = Cx[cc + e];
+    auto dst_c = [=](int e) {
+        const int i = e / SEP, j = e - i * SEP;
+        if (e >= SEP * SEP) return 91 * ZS + 45;                             // (row 91, column 45) is never read
+        return team == 0 ? (45 + i) * ZS + j : (45 + j) * ZS + i;            // team 1: the stored block transposed
+    };
+    {
+        const double *pa, *pb;
+        d_ptrs(piv(0), pa, pb);
+        const double* pc = c_ptr(piv(0));
+        const bool any = nreal > 0 || team == 0;          // team 0 also prepares the middle when it has no step of its own
+        if (any) {
+            for (int e = tt; e < SEP * 46; e += 192) Dn[dst_d(e)] = pa[e] + pb[e];
+            for (int e = tt; e < SEP * SEP; e += 192) Dn[dst_c(e)] = pc[e];
+        }
+    }
     __syncthreads();
-    const int prow = (tid < 91 ? tid : 91) * ZS;       // this thread's panel row in Dn (91 = zeros)
-    double* col_w = &colbuf[0][tid < 45 ? tid : 47];   // one base register + immediates (nothing per-column to hoist)
+    const int prow = (tt < 91 ? tt : 91) * ZS;         // this thread's panel row in Dn (91 = zeros)
+    double* col_w = colbuf + (tt < 45 ? tt : 47);      // one base register + immediates (nothing per-column to hoist)
     // LDS reads at compile-time addresses go through ONE opaque base register so that every access is
     // base + immediate (otherwise each constant address is materialised in its own VGPR, hoisted out of
     // the loop, and the register file is gone: the reads then serialise on a single destination register)
     int zero_v;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
-    const double* cb = &colbuf[0][0] + zero_v;
+    const double* cb = colbuf + zero_v;
 #ifdef VF_SOLVE_STAMPS
     unsigned long long sst[16] = {0}, stprev = __builtin_amdgcn_s_memtime();
 #endif
-#pragma unroll 1
-    for (int s = 0; s < m; s++) {
-        const bool more = s + 1 < m;
+    // one elimination step of this team (real = 0: keep in step with the other team's barriers, touch nothing)
+    auto step = [&](int sidx, int snext, bool real, bool more) {
         SSTAMP(0);
-        if (wave == 2) {
-            // ---- stager: D_{s+1} = R_{s+1} + S_{s+2} (+ rhs) and C_{s+1}.  Absent terms read the zero slot, so the
-            // loads are unconditional and nothing is computed on them before the pivot barriers are behind us.
+        if (!real) {
+#pragma unroll 1
+            for (int c = 0; c < SEP + 3; c++) LDS_BARRIER();
+            return;
+        }
+        if (tw == 2) {
+            // ---- stager: D and C of the team's next step.  Absent terms read the zero slot, so the loads are
+            // unconditional and nothing is computed on them before the pivot barriers are behind us.
             int sz;
             asm volatile("v_mov_b32 %0, 0" : "=v"(sz));      // opaque zero: keeps the element maps inside the loop
-            const double* pa = more ? R + (size_t)(s + 1) * cs : Sx;
-            const double* pb = (more && s + 2 <= m) ? Sx + (size_t)(s + 2) * cs : Sx;
-            const double* pc = s + 2 < m ? Cx + (size_t)(s + 2) * cc : Sx;
+            const double *pa, *pb;
+            d_ptrs(more ? snext : -1, pa, pb);
+            const int after = team == 0 ? snext : snext;      // pivot of the step after this one
+            const double* pc = more ? c_ptr(after) : Sx;
             LDS_BARRIER();   // Dn consumed (the stager arrives first: nothing of its work sits in front of the pivots)
-            // one slice of the staging work (3 loads + 2 destinations) between two pivot barriers, so that the
-            // stager is never the last wave to arrive
+            // one slice of the staging work (3 loads, 2 destinations) between two pivot barriers, so that the stager
+            // is never the last wave to arrive; a slice goes to LDS 12 barriers (~2.5 us) after its loads were issued
+            // (the panel input was consumed at the top of the step, so Dn is free; the Schur update comes after)
+            constexpr int LAG = 12;
             double ba[33], bb[33], bc[33];
             int da[33], dc[33];
 #pragma unroll
@@ -1630,10 +1674,9 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
                     bc[c] = pc[e < SEP * SEP ? e : 0];
                     dc[c] = dst_c(e);
                 }
+                if (c >= LAG) { Dn[da[c - LAG]] = ba[c - LAG] + bb[c - LAG]; Dn[dc[c - LAG]] = bc[c - LAG]; }
                 LDS_BARRIER();
             }
-#pragma unroll
-            for (int q = 0; q < 33; q++) { Dn[da[q]] = ba[q] + bb[q]; Dn[dc[q]] = bc[q]; }
         } else {
             // ---- panel rows ----
             double p[SEP];
@@ -1646,15 +1689,15 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
             for (int c = 0; c < SEP; c++) {
                 col_w[(c % 3) * 48] = p[c];
                 LDS_BARRIER();
-                double piv = cb[(c % 3) * 48 + c];
+                double pivv = cb[(c % 3) * 48 + c];
                 double mv[SEP];          // multipliers of the previous pivot: all LDS reads in flight together
                 if (c > 0) {
 #pragma unroll
                     for (int c2 = c + 1; c2 < SEP; c2++) mv[c2] = cb[((c - 1) % 3) * 48 + c2];
                 }
                 __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler serialises read -> wait -> fma pairs)
-                if (!(piv > 0.0)) { failed = 1; piv = 1.0; }
-                const double inv = fast_rsqrt(piv);
+                if (!(pivv > 0.0)) { failed = 1; pivv = 1.0; }
+                const double inv = fast_rsqrt(pivv);
                 if (c > 0) {
 #pragma unroll
                     for (int c2 = c + 1; c2 < SEP; c2++) p[c2] = fma(pc_prev, mv[c2], p[c2]);
@@ -1665,24 +1708,24 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
             }
             SSTAMP(2);
             // factor rows -> HBM, column-major: one contiguous 8-byte-per-lane store per column
-            if (tid < 91) {
-                double* dst = Lx + (size_t)s * SEPL + tid;
+            if (tt < 91) {
+                double* dst = Lx + (size_t)sidx * SEPL + tt;
 #pragma unroll
                 for (int c = 0; c < SEP; c++) dst[c * LXS] = p[c];
             }
-            if (tid >= 45 && tid <= 90) {
+            if (tt >= 45 && tt <= 90) {
 #pragma unroll
-                for (int c = 0; c < SEP; c++) Zs[(tid - 45) * ZZ + c] = p[c];
+                for (int c = 0; c < SEP; c++) Zs[(tt - 45) * ZZ + c] = p[c];
             }
         }
         LDS_BARRIER();
         SSTAMP(3);
         if (more) {
-            // D_{s+1} -= Z Z^T, rhs_{s+1} -= Z y on the matrix cores: 3 x 3 tiles of 16 x 16, three per wave,
+            // D_next -= Z Z^T, rhs_next -= Z y on the matrix cores: 3 x 3 tiles of 16 x 16, three per wave,
             // K = 45 (12 steps of 4); both operands come from the Z rows in LDS (row 45 = y)
             const int li = lane & 15, lq = lane >> 4;
 #pragma unroll 1
-            for (int t = wave; t < 9; t += 3) {
+            for (int t = tw; t < 9; t += 3) {
                 const int I = t / 3, J = t - I * 3;
                 // rows 45 (y), 46, 47 of tile I = 2 produce output rows that are dropped; zero padding does the masking
                 const double* za = Zs + (16 * I + li) * ZZ + lq;
@@ -1701,40 +1744,62 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
             }
         }
         LDS_BARRIER();
+    };
+#pragma unroll 1
+    for (int j = 0; j < h; j++) {
+        const bool real = j < nreal;
+        const int sidx = piv(j), snext = team == 0 ? sidx + 1 : sidx - 1;
+        step(sidx, snext, real, true);
+    }
+    // ---- the middle separator: team 0's panel input (its own D + left Schur terms) + team 1's Schur terms
+    {
+        const double* Dother = smem + SEP_FW + 144 + 48 * ZZ;
+        if (team == 0)
+            for (int e = tt; e < 91 * ZS; e += 192) Dn[e] += (e < 45 * ZS || e >= 90 * ZS) ? Dother[e] : 0.0;
+        LDS_BARRIER();
+        step(h, -1, team == 0, false);
     }
     SSTAMP(4);
     __syncthreads();   // the factor blocks in HBM (written by other threads of the workgroup) are read back below
-    // ---- back substitution along the chain, last separator first --------------------------------
-    // HBM -> LDS copy of one factor block: [45 columns][91 rows], rows contiguous -> Fb[c * FS + r]
+    // ---- back substitution outwards from the middle ------------------------------------------------
+    // HBM -> LDS copy of one factor block: [45 columns][91 rows], rows contiguous -> F[c * FS + r]
     // (all loads of a thread are issued before the first LDS write: 34 independent round trips, not 34 serial ones)
-    auto copy_factor = [&](int s, int buf, int t0) {     // 128 threads: t0 = 0..127
-        const double* Ls = Lx + (size_t)s * SEPL;
+    double* Fb = smem + team * SEP_BW;
+    auto copy_factor = [&](int sidx, int buf, int t0) {     // 128 threads of a team: t0 = 0..127
+        const double* Ls = Lx + (size_t)sidx * SEPL;
         double x[34];
 #pragma unroll
         for (int q = 0; q < 34; q++) { const int e = t0 + 128 * q; x[q] = Ls[e < SEP * LXS ? e : 0]; }
 #pragma unroll
         for (int q = 0; q < 34; q++) {
             const int e = t0 + 128 * q, c = e / LXS, r = e - c * LXS;
-            if (e < SEP * LXS && r < 91) Fb[buf][c * FS + r] = x[q];
+            if (e < SEP * LXS && r < 91) Fb[buf * SEP * FS + c * FS + r] = x[q];
         }
     };
-    if (wave != 0) copy_factor(m - 1, (m - 1) & 1, tid - 64);
-    if (tid < 48) dnext[tid] = 0.0;
+    // iteration i: team 0 solves separator h - i (i = 0: the middle, nothing towards the middle to subtract),
+    // team 1 solves h + i (from i = 1); factor copies live in buffer i & 1
+    auto mine = [=](int i) { return team == 0 ? h - i : h + i; };
+    auto have = [=](int i) { return team == 0 ? i <= h : (i >= 1 && h + i <= m - 1); };
+    if (tw != 0) {
+        if (team == 0) copy_factor(h, 0, tt - 64);
+        else if (have(1)) copy_factor(h + 1, 1, tt - 64);
+    }
+    if (tt < 48) dnext_s[team][tt] = 0.0;
     __syncthreads();
 #pragma unroll 1
-    for (int s = m - 1; s >= 0; s--) {
-        if (wave != 0) {
-            if (s > 0) copy_factor(s - 1, (s - 1) & 1, tid - 64);
-        } else {
-            // thread j < 45 owns column j: F[j * FS + r] = L[r][j] (r >= j), Z[i][j] at row 45 + i, y_j at row 90
-            const double* F = Fb[s & 1] + (lane < 45 ? lane : 0) * FS;
+    for (int i = 0; i <= h; i++) {
+        if (tw != 0) {
+            if (have(i + 1) && !(team == 1 && i == 0)) copy_factor(mine(i + 1), (i + 1) & 1, tt - 64);
+        } else if (have(i)) {
+            // thread j < 45 owns column j: F[j * FS + r] = L[r][j] (r >= j), Z[q][j] at row 45 + q, y_j at row 90
+            const double* F = Fb + (i & 1) * SEP * FS + (lane < 45 ? lane : 0) * FS;
             double t0 = F[90], t1 = 0.0, t2 = 0.0;
-            if (s + 1 < m) {
+            if (i > 0) {
 #pragma unroll
-                for (int i = 0; i < SEP; i += 3) {
-                    t0 = fma(-F[45 + i], dnext[i], t0);
-                    t1 = fma(-F[45 + i + 1], dnext[i + 1], t1);
-                    t2 = fma(-F[45 + i + 2], dnext[i + 2], t2);
+                for (int q = 0; q < SEP; q += 3) {
+                    t0 = fma(-F[45 + q], dnext_s[team][q], t0);
+                    t1 = fma(-F[45 + q + 1], dnext_s[team][q + 1], t1);
+                    t2 = fma(-F[45 + q + 2], dnext_s[team][q + 2], t2);
                 }
             }
             double t = (t0 + t1) + t2;
@@ -1749,8 +1814,9 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
                 t = lane == c ? xc : (lane < c ? fma(-Lc[c], xc, t) : t);
             }
             if (lane < 45) {
-                dnext[lane] = t;
-                const ChunkGeom cg = chunk_geom(n, Pe, s);
+                dnext_s[team][lane] = t;
+                if (i == 0) dnext_s[1][lane] = t;      // the middle's increment starts team 1's walk as well
+                const ChunkGeom cg = chunk_geom(n, Pe, mine(i));
                 v.delta[((size_t)w * v.M + lo + cg.i0 + cg.ni) * 15 + lane] = t;
             }
         }
@@ -1760,7 +1826,7 @@ __global__ void __launch_bounds__(192) k_sep_solve(View v) {
 #ifdef VF_SOLVE_STAMPS
     if (w == 0 && tid == 0) for (int i = 0; i < 16; i++) g_sep_stamps[i] = sst[i];
 #endif
-    if (failed && tid == 0) atomicOr(v.fail + w, 1);
+    if (failed && tt == 0) atomicOr(v.fail + w, 1);
 }
 
 #ifdef VF_SOLVE_STAMPS
@@ -2119,7 +2185,7 @@ void launch_partitioned_local(const View& v, hipStream_t s) {
 }
 void launch_partitioned_global(const View& v, hipStream_t s) {
     const unsigned nb = (unsigned)v.B * (unsigned)v.P;
-    hipLaunchKernelGGL(k_sep_solve, dim3(v.B), dim3(192), 0, s, v);
+    hipLaunchKernelGGL(k_sep_solve, dim3(v.B), dim3(384), 0, s, v);
     hipLaunchKernelGGL(k_chunk_rhs, dim3(nb), dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_chunk_back, dim3(nb), dim3(64), 0, s, v);
 }

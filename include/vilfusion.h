@@ -59,7 +59,7 @@ typedef struct {
     double gravity[3];      /* n_gravity; MakeSharedU => (0,0,-9.81) (ImuManagerRos.cpp:16) */
     double lambda0, lambda_up, lambda_down, lambda_min, lambda_max; /* LM damping schedule */
     int chunks;             /* K4 form.  0 = chosen from the batch size: up to 128 windows -> partitioned
-                               solve (chunks joined by 45-dof separators, about sqrt(0.22 n) of them for an
+                               solve (chunks joined by 45-dof separators, about sqrt(0.32 n) of them for an
                                n-keyframe window: one-window latency); more windows -> one sweep per window
                                (throughput).  1 = always sweeps.  P >= 2 = partitioned solve with P chunks. */
 } vf_engine_opts;
@@ -136,7 +136,7 @@ typedef struct {
     long cost_count;
 } vf_shard_info;
 /* Geometry of the partitioned solve, host only (no device needed): an n-keyframe window is cut into `count`
- * chunks (<= chunks; fit != 0: also <= sqrt(0.22 n)); chunk c = `interior` keyframes from window-local
+ * chunks (<= chunks; fit != 0: also <= sqrt(0.32 n)); chunk c = `interior` keyframes from window-local
  * keyframe `first`, followed by 3 separator keyframes when has_separator.  vf_shard_range: the chunks
  * [chunk_lo, chunk_hi) and window-local keyframes [kf_lo, kf_hi) rank `rank` of `world` owns. */
 int vf_chunk_geometry(int n, int chunks, int fit, int c, int* count, int* first, int* interior, int* has_separator);
@@ -152,8 +152,9 @@ int vf_engine_decide_total(vf_engine* e, int init);
 int vf_engine_reset_lambda(vf_engine* e);   /* lambda := lambda0, as vf_engine_iterate does before its first trial */
 
 /* Optional LM termination (off by default: vf_engine_iterate runs exactly `iterations` trials).  With a
- * tolerance > 0, a window whose accepted trial lowers the cost by <= abs_tol, or by <= rel_tol * cost, is
- * converged and takes no part in the remaining trials of that solve: the rule of
+ * tolerance > 0, a window whose trial changes the cost by <= abs_tol, or by <= rel_tol * cost (an accepted
+ * step that no longer pays, or a rejected one inside the rounding floor), is converged and takes no part in
+ * the remaining trials of that solve: the rule of
  * gtsam::LevenbergMarquardtOptimizer (checkConvergence; LevenbergMarquardtParams defaults 1e-5 / 1e-5), the
  * optimiser commented out at GraphManager.cpp:128-129.  (0, 0) switches it off again. */
 int vf_engine_set_convergence(vf_engine* e, double rel_tol, double abs_tol);

@@ -1200,10 +1200,12 @@ double vfo_lm(vfo_problem* p, const vfo_lm_opts* o, double* costs_out, int* acce
             double* Hn = (double*)malloc(sizeof(double) * (size_t)n * (w + 1) * 225);
             double* gn = (double*)malloc(sizeof(double) * (size_t)n * 15);
             double cn = vfo_assemble(p, w, Hn, gn, o->n_threads);
+            /* termination (gtsam checkConvergence), also on a rejected trial within the tolerance: the
+             * window then sits at its rounding floor */
+            if ((o->abs_tol > 0.0 || o->rel_tol > 0.0) &&
+                (fabs(cost - cn) <= o->abs_tol || fabs(cost - cn) <= o->rel_tol * cost)) converged = 1;
             if (cn < cost) { /* NaN compares false -> reject */
                 acc = 1;
-                if ((o->abs_tol > 0.0 || o->rel_tol > 0.0) &&
-                    (cost - cn <= o->abs_tol || cost - cn <= o->rel_tol * cost)) converged = 1;
                 cost = cn;
                 free(H); free(g);
                 H = Hn; g = gn;

@@ -56,7 +56,7 @@ def test_partitioned_solve_matches_band_system(oracle, chunks):
 
 def test_partitioned_equals_one_sweep_increment(oracle):
     ranges = [(0, N), (3, 171)]
-    ref, _ = make_engine(oracle, 0, ranges)
+    ref, _ = make_engine(oracle, 1, ranges)      # whole-window sweeps
     par, _ = make_engine(oracle, 7, ranges)
     for e in (ref, par):
         e.linearize(0)
@@ -111,7 +111,7 @@ def test_partitioned_with_marginal_prior(oracle):
     from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
     ranges = [(0, 100)]
     engines = []
-    for chunks in (0, 5):
+    for chunks in (1, 5):
         eng, _ = make_engine(oracle, chunks, ranges, perturb=0.0)
         eng.iterate(3)
         engines.append(eng)

@@ -30,15 +30,15 @@ def test_chunks_partition_the_window(fit):
                 lens = [b for _, b, _ in g]
                 assert max(lens[:-1]) == min(lens[:-1])
             if fit and n >= 5:
-                assert len(g) ** 2 * 100 <= n * 22 or len(g) == 1
+                assert len(g) ** 2 * 100 <= n * 32 or len(g) == 1
 
 
 def test_fit_rule_matches_measured_optimum():
     from vil_sensor_fusion_amd.distributed import chunk_geometry
-    assert len(chunk_geometry(1000, 48, True)) == 14       # sqrt(0.22 * 1000) = 14.8
-    assert len(chunk_geometry(200, 48, True)) == 6
-    assert len(chunk_geometry(10000, 48, True)) == 46
-    assert len(chunk_geometry(40, 48, True)) == 2
+    assert len(chunk_geometry(1000, 48, True)) == 17       # sqrt(0.32 * 1000) = 17.9
+    assert len(chunk_geometry(200, 48, True)) == 8
+    assert len(chunk_geometry(10000, 48, True)) == 48
+    assert len(chunk_geometry(40, 48, True)) == 3
 
 
 def test_shard_ranges_partition_chunks_and_keyframes():

@@ -162,6 +162,9 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     // (throughput form; the partitioned solve does about twice the arithmetic).  1 forces sweeps.
     v.P = o->chunks >= 2 ? o->chunks : (o->chunks == 0 && o->windows <= 128 ? 48 : 0);
     v.P_fit = o->chunks == 0 ? 1 : 0;
+    // (the chunk kernels launch windows x P workgroups: no more chunks than a full window could use)
+    if (v.P_fit && v.P) v.P = vf::chunk_count(v.M, v.P, 1);
+    if (v.P < 2) v.P = 0;
     if (v.P) {
         const size_t BP = (size_t)v.B * v.P;
         AL(v.Vp, G * vf::VROW);

@@ -1921,11 +1921,14 @@ __global__ void __launch_bounds__(256) k_decide(View v, int init, int mode) {
             const bool ok = (v.fail[w] == 0) && (c < v.cost[w]);
             if (v.fail[w]) v.n_fail[w] += 1;
             v.fresh[w] = ok ? 1 : 0;
+            if (v.stop_on && v.fail[w] == 0) {
+                // gtsam checkConvergence (absolute / relative decrease of the accepted step), applied to rejected
+                // trials too: a trial that changes the cost by less than the tolerance in either direction means
+                // the window sits at its rounding floor, where accept / reject is decided by the last bit
+                const double dec = fabs(v.cost[w] - c);
+                if (dec <= v.abs_tol || dec <= v.rel_tol * v.cost[w]) v.done[w] = 1;
+            }
             if (ok) {
-                if (v.stop_on) {   // gtsam checkConvergence on the accepted step
-                    const double dec = v.cost[w] - c;
-                    if (dec <= v.abs_tol || dec <= v.rel_tol * v.cost[w]) v.done[w] = 1;
-                }
                 v.sel[w] ^= 1;
                 v.cost[w] = c;
                 v.n_acc[w] += 1;

@@ -29,12 +29,12 @@ __host__ __device__ inline int chunk_len(int n, int P) {
     const int up = ((total + P - 1) / P + 3) & ~3;     // round up: the last chunk gets the (smaller) rest
     return n - (P - 1) * (up + 3) >= 8 ? up : (total / P) & ~3;
 }
-// chunks actually used for an n-keyframe window: at most P; with `fit` also at most sqrt(0.22 n), the
-// measured optimum of (chunk sweep time ~ 3.7 us * n / P) + (separator chain ~ 17 us * P)
+// chunks actually used for an n-keyframe window: at most P; with `fit` also at most sqrt(0.32 n), the
+// measured optimum of (chunk sweeps ~ 3.7 us * n / P) + (two-sided separator chain ~ 17 us * P / 2 + middle)
 __host__ __device__ inline int chunk_count(int n, int P, int fit) {
     if (fit) {
         int want = 1;
-        while ((want + 1) * (want + 1) * 100 <= n * 22) want++;
+        while ((want + 1) * (want + 1) * 100 <= n * 32) want++;
         if (P > want) P = want;
     }
     while (P > 1 && chunk_len(n, P) < 8) P--;
@@ -99,9 +99,9 @@ struct View {
     int* n_fail;
     double lam_up, lam_down, lam_min, lam_max;
     // optional LM termination (off by default: every vf_engine_iterate runs its fixed number of trials).  With
-    // stop_on, a window whose accepted trial lowers the cost by <= abs_tol, or by <= rel_tol relative to the cost
-    // (gtsam::LevenbergMarquardtParams relativeErrorTol / absoluteErrorTol, checkConvergence), is done: every
-    // kernel of the remaining trials skips it.
+    // stop_on, a window whose trial changes the cost by <= abs_tol, or by <= rel_tol relative to the cost
+    // (gtsam::LevenbergMarquardtParams relativeErrorTol / absoluteErrorTol, checkConvergence; applied to
+    // rejected trials as well), is done: every kernel of the remaining trials skips it.
     int stop_on;
     double rel_tol, abs_tol;
     int* done;          // [B]

@@ -117,6 +117,33 @@ def time_sharded_window(args, info, dist, backend, dev):
     return out
 
 
+def degeneracy_section():
+    """K6 (BASELINE.json configs[3]): the degeneracy metrics of the reference's Python library on a batch of
+    6x6 information matrices, float64 and float32, kernel time from HIP events inside the library; beside it the
+    per-matrix numpy/LAPACK calls the reference makes (degeneracy_detection_functions.py:38-83), on a bounded sample."""
+    from vil_sensor_fusion_amd import degeneracy as dg
+    rng = np.random.default_rng(7)
+    T = 200_000
+    A = rng.normal(size=(T, 6, 6))
+    mats = np.ascontiguousarray((A @ A.transpose(0, 2, 1) + 0.5 * np.eye(6)).transpose(1, 2, 0))
+    out = {"matrices": T, "gpu_ns_per_matrix": {}, "algorithmic_bytes_per_matrix": {"f64": 296, "f32": 148}}
+    for name in ("d_opt", "e_opt", "condition_number"):
+        for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
+            _, ms = dg.apply_degen_function(mats, None, "all", name, dtype=dt, reps=5)
+            out["gpu_ns_per_matrix"][f"{name}/{tag}"] = ms * 1e6 / T
+    sample = np.ascontiguousarray(mats[:, :, :2000].transpose(2, 0, 1))
+    t0 = time.perf_counter()
+    for m in sample:                                   # one LAPACK call per matrix, as the reference does
+        np.exp(np.log(np.linalg.det(m)) / 6)
+    t1 = time.perf_counter()
+    for m in sample:
+        np.linalg.eigvals(m).real.min()
+    t2 = time.perf_counter()
+    out["numpy_per_matrix_ns"] = {"d_opt": (t1 - t0) / len(sample) * 1e9, "e_opt": (t2 - t1) / len(sample) * 1e9,
+                                  "sample": len(sample), "cores": 1}
+    return out
+
+
 def measured_traffic_per_imu_factor():
     """HBM bytes per IMU factor of K1 from the committed PMC profile (separate --pmc passes,
     2*FETCH_SIZE + WRITE_SIZE, KiB units; tools/summarize_prof.py)."""
@@ -142,6 +169,7 @@ def main():
     ap.add_argument("--sharded-window", type=int, default=10000, help="keyframes of the time-sharded window (BASELINE configs[4])")
     ap.add_argument("--no-sharded", action="store_true")
     ap.add_argument("--no-convergence-exit", action="store_true")
+    ap.add_argument("--no-degeneracy", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -262,7 +290,9 @@ def main():
             out["single_window"] = {"ms_per_update": lat * 1e3, "keyframes_per_s": 1.0 / lat,
                                     "solve_ms": one.time_stage("solve", reps=5)}
             one.close()
-        if not args.no_cpu_baseline:
+        if not args.no_degeneracy and info.world == 1:
+            out["degeneracy_k6"] = degeneracy_section()
+        if not args.no_cpu_baseline and info.world == 1:       # the CPU legs: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args)
             out["cpu_baseline"]["gpu_over_cpu"] = kf_per_s / out["cpu_baseline"]["value"]
             # also with OpenMP over the factors, on a bounded number of the host's cores

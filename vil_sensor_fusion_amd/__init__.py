@@ -10,3 +10,5 @@ from ._lib import VilFusionError, lib, lib_path  # noqa: F401
 from .engine import Engine, EngineOpts  # noqa: F401
 
 __all__ = ["VilFusionError", "lib", "lib_path", "Engine", "EngineOpts"]
+from .graph_manager import GraphManager  # noqa: F401,E402
+from .sensor_manager import SensorManager  # noqa: F401,E402

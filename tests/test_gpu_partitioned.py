@@ -158,3 +158,22 @@ def test_config3_batch_lm_with_degeneracy_metrics(oracle):
             ms, ps = dor.subset(mats, pose, sub)
             np.testing.assert_allclose(y, dor.evaluate(name, ms, ps), rtol=1e-7, atol=1e-9, err_msg=f"{name}/{sub}")
     eng.close()
+
+
+def test_partitioned_solve_is_deterministic(oracle):
+    """The sweep and spike waves of a chunk, and the two teams of the separator chain, hand data to each
+    other through LDS counters and barriers: 150 repeated solves of the same systems must give the same bits
+    (a stale hand-shake cell once showed up as a last-bit difference in about one run out of 25)."""
+    ranges = [(0, N), (5, 150), (0, 64), (10, 47), (0, 133), (2, 199)]
+    eng, _ = make_engine(oracle, 0, ranges)
+    eng.linearize(0)
+    eng.assemble()
+    eng.solve()
+    first = [eng.read_delta(w, lo, hi - lo).copy() for w, (lo, hi) in enumerate(ranges)]
+    assert all(np.isfinite(d).all() for d in first)
+    for rep in range(150):
+        eng.solve()
+        if rep % 10 == 9:
+            for w, (lo, hi) in enumerate(ranges):
+                np.testing.assert_array_equal(eng.read_delta(w, lo, hi - lo), first[w], err_msg=f"solve {rep} window {w}")
+    eng.close()

@@ -299,10 +299,22 @@ def main():
             nthr = max(1, min(16, os.cpu_count() or 1))
             if nthr > 1:
                 out["cpu_baseline_openmp"] = cpu_baseline(args, threads=nthr)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
     D.barrier(dist)
     if dist is not None:
         dist.destroy_process_group()
+    # the ONE JSON line goes out last, after the communication libraries have said whatever they print on stdout
+    # (RCCL's version banner, gloo's connection notes)
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)        # RCCL prints its banner through C stdio: push it out before the JSON line
+    except OSError:
+        pass
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

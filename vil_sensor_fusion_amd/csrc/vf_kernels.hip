@@ -1865,7 +1865,9 @@ __global__ void __launch_bounds__(256) k_retract(View v) {
 // fixed-shape tree reduction => bitwise reproducible.
 // mode 0: whole cost + accept / reject (one rank).  Sharded windows: mode 1 = this rank's share of the cost
 // -> cost_part (the host side sums it over the ranks), mode 2 = accept / reject with cost_part as the total.
-__global__ void __launch_bounds__(256) k_decide(View v, int init, int mode) {
+// Block = window, 256 threads (1024 when there are few windows: the per-thread loop over a long window's factors
+// is a latency chain); fixed-shape tree reduction, so the cost is bitwise reproducible for a given engine.
+__global__ void __launch_bounds__(1024) k_decide(View v, int init, int mode) {
     const int w = blockIdx.x, tid = threadIdx.x;
     if (window_done(v, w) && !init) return;
     const int lo = v.lo[w], hi = v.hi[w];
@@ -1876,7 +1878,8 @@ __global__ void __launch_bounds__(256) k_decide(View v, int init, int mode) {
     const double* imu_out = v.imu_out + (size_t)b * tiles * IMU_OUT * TILE;
     const double* btw_out = v.btw_out + (size_t)b * tiles * BTW_OUT * TILE;
     double s = 0.0;
-    for (int k = lo + (klo > 1 ? klo : 1) + tid; k < lo + khi && mode != 2; k += 256) {
+    const int nt = (int)blockDim.x;
+    for (int k = lo + (klo > 1 ? klo : 1) + tid; k < lo + khi && mode != 2; k += nt) {
         const long gk = (long)w * v.M + k;
         const double* f = imu_out + (size_t)(gk >> 6) * IMU_OUT * TILE + (gk & 63);
         double c = 0.0;
@@ -1898,10 +1901,10 @@ __global__ void __launch_bounds__(256) k_decide(View v, int init, int mode) {
         }
         if (v.mp_on[w] && hi - lo >= 3 && klo == 0) s += 2.0 * v.mp_out[((size_t)b * v.B + w) * 28 + 27];
     }
-    __shared__ double red[256];
+    __shared__ double red[1024];
     red[tid] = s;
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
+    for (int st = nt >> 1; st > 0; st >>= 1) {
         if (tid < st) red[tid] += red[tid + st];
         __syncthreads();
     }
@@ -2222,10 +2225,10 @@ void launch_retract(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_retract, dim3(nblk(v.G, 256)), dim3(256), 0, s, v);
 }
 void launch_decide(const View& v, int init, hipStream_t s) {
-    hipLaunchKernelGGL(k_decide, dim3(v.B), dim3(256), 0, s, v, init, 0);
+    hipLaunchKernelGGL(k_decide, dim3(v.B), dim3(v.B <= 64 ? 1024 : 256), 0, s, v, init, 0);
 }
 void launch_decide_mode(const View& v, int init, int mode, hipStream_t s) {
-    hipLaunchKernelGGL(k_decide, dim3(v.B), dim3(256), 0, s, v, init, mode);
+    hipLaunchKernelGGL(k_decide, dim3(v.B), dim3(v.B <= 64 ? 1024 : 256), 0, s, v, init, mode);
 }
 void launch_predict(const View& v, int window, int k0, int n, hipStream_t s) {
     if (window >= 0) hipLaunchKernelGGL(k_predict, dim3(1), dim3(1), 0, s, v, window, k0, n);

@@ -24,21 +24,25 @@ def test_chunks_partition_the_window(fit):
                 assert has_sep == (c < len(g) - 1)
                 if has_sep:
                     assert interior % 4 == 0 and interior >= 8      # the sweep is unrolled by 4 keyframes
-                pos = first + interior + (3 if has_sep else 0)
+                # the cut keyframe first + interior belongs to the separator; the next chunk starts right after it
+                # (its first two keyframes contribute their velocity / bias dof only)
+                pos = first + interior + (1 if has_sep else 0)
             assert pos == n
             if len(g) > 1:
                 lens = [b for _, b, _ in g]
-                assert max(lens[:-1]) == min(lens[:-1])
+                assert max(lens[:-1]) - min(lens[:-1]) in (0, 4)       # chunks of L or L + 4 pivots, longer ones first
+                assert lens[:-1] == sorted(lens[:-1], reverse=True)
+                assert lens[-1] <= min(lens[:-1]) + 7 or len(g) * 8 > n  # the last chunk is not the straggler
             if fit and n >= 5:
-                assert len(g) ** 2 * 100 <= n * 32 or len(g) == 1
+                assert len(g) ** 2 * 100 <= n * 75 or len(g) == 1
 
 
 def test_fit_rule_matches_measured_optimum():
     from vil_sensor_fusion_amd.distributed import chunk_geometry
-    assert len(chunk_geometry(1000, 48, True)) == 17       # sqrt(0.32 * 1000) = 17.9
-    assert len(chunk_geometry(200, 48, True)) == 8
-    assert len(chunk_geometry(10000, 48, True)) == 48
-    assert len(chunk_geometry(40, 48, True)) == 3
+    assert len(chunk_geometry(1000, 96, True)) == 27       # sqrt(0.75 * 1000) = 27.4
+    assert len(chunk_geometry(200, 96, True)) == 12
+    assert len(chunk_geometry(10000, 96, True)) == 86
+    assert len(chunk_geometry(40, 96, True)) == 4
 
 
 def test_shard_ranges_partition_chunks_and_keyframes():

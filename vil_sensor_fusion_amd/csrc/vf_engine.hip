@@ -158,9 +158,9 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.delta, G * 15);
     AL(v.Lp, G * vf::PANEL);
     // K4 form: chunks = 0 picks it from the batch size: up to 128 windows -> partitioned solve with at
-    // most 48 chunks, fewer on short windows (latency form); more windows -> one sweep per window
+    // most 96 chunks, fewer on short windows (latency form); more windows -> one sweep per window
     // (throughput form; the partitioned solve does about twice the arithmetic).  1 forces sweeps.
-    v.P = o->chunks >= 2 ? o->chunks : (o->chunks == 0 && o->windows <= 128 ? 48 : 0);
+    v.P = o->chunks >= 2 ? o->chunks : (o->chunks == 0 && o->windows <= 128 ? 96 : 0);
     v.P_fit = o->chunks == 0 ? 1 : 0;
     // (the chunk kernels launch windows x P workgroups: no more chunks than a full window could use)
     if (v.P_fit && v.P) v.P = vf::chunk_count(v.M, v.P, 1);

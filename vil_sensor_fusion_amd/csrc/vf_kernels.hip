@@ -11,7 +11,7 @@
 //   K4 k_band_solve(_tw)    (H + lambda I) delta = -g, block-banded Cholesky, one wave per window
 //                           (_tw: two waves from both ends)
 //   K4p k_chunk_forward, k_sep_solve, k_chunk_rhs, k_chunk_back
-//                           the same solve partitioned into chunks joined by 45-dof separators
+//                           the same solve partitioned into chunks joined by 27-dof separators
 //                           (one-window latency; the per-GPU piece of a time-sharded window)
 //   K-marg k_marginalize    fixed-lag marginalisation of the oldest keyframe into a dense prior
 //   K5 k_retract, k_decide  x (+) delta, cost reduction, LM accept/reject
@@ -50,13 +50,15 @@ VF_DI void own_range(const View& v, int w, int& klo, int& khi) {
     klo = c0 < Pe ? chunk_geom(n, Pe, c0).i0 : n;
     khi = c1 < Pe ? chunk_geom(n, Pe, c1).i0 : n;
 }
-// linearisation of factor slot k (absolute): needed for the owned rows of H and their 3-keyframe halo
+// A rank's last chunk sweeps two rows beyond its own keyframes (the pose rows of the two keyframes after its cut
+// keyframe), so it assembles the rows [klo, khi + 2) of H, and needs the linearisation of the factor slots that
+// feed them: 3 more (a row of H collects factors up to 3 keyframes ahead).
 VF_DI bool shard_skips_factor(const View& v, int w, int k) {
     if (v.sh_G <= 1) return false;
     int klo, khi;
     own_range(v, w, klo, khi);
     const int kk = k - v.lo[w];
-    return kk < klo || kk >= khi + 3;
+    return kk < klo || kk >= khi + 5;
 }
 
 struct State {
@@ -581,6 +583,8 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
     own_range(v, w, rlo, rhi);
     rlo += lo;
     rhi += lo;
+    if (v.sh_G > 1 && rhi + 2 <= hi) rhi += 2;   // tail rows of the rank's last chunk (see shard_skips_factor)
+    else if (v.sh_G > 1) rhi = hi;
     if (k0 + AT <= rlo || k0 >= rhi) return; // no owned active keyframe in this tile (uniform)
     // a rejected LM trial leaves the current linearisation, hence H and g, unchanged: nothing to do
     // (k_decide clears `fresh` on reject; accept / init / slide set it)
@@ -1018,9 +1022,47 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         }
         return r;
     };
-    auto commit_row = [&](auto ph, const HRow r, int kind, int kk) {   // sweep row kk with kk & 3 == PH
+    // Chunk sweeps: rows at a chunk boundary keep only the dof that belong to this chunk (vf_kernels.hpp "SEP").
+    //   head (chunks c >= 1): sweep rows 0, 1 are keyframes whose pose dof sit in the LEFT separator: their pose rows
+    //     and columns are pinned (identity), also in the blocks of rows 1..4 that reach back to them;
+    //   tail (a separator follows): rows ni+1, ni+2 contribute their pose dof only (their velocity / bias dof are the
+    //     head of the next chunk).
+    // Applied when the row is committed -- never on the freshly prefetched values (that would stall on vmcnt).
+    auto mask_boundary_row = [=](HRow r, int kk) {
+        const bool head = CH && cg.i0 > 0 && kk <= 4, tail = CH && cg.has_sep && kk > cg.ni && kk <= cg.ni + 2;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int idx = lane + 64 * j, a = idx / 15, c = idx - a * 15;
+            if (head) {
+                const bool vv = a >= 6 && c >= 6;
+                if (kk <= 1) r.h0[j] = vv ? r.h0[j] : ((a == c && idx < 225) ? 1.0 : 0.0);
+                if (kk == 1) r.h1[j] = vv ? r.h1[j] : 0.0;
+                if (kk == 2) r.h1[j] = c >= 6 ? r.h1[j] : 0.0;
+            }
+            if (tail) {
+                const bool pp = a < 6 && c < 6;
+                r.h0[j] = pp ? r.h0[j] : ((a == c && idx < 225) ? 1.0 : 0.0);
+                r.h1[j] = (kk == cg.ni + 1 ? a < 6 : pp) ? r.h1[j] : 0.0;
+            }
+        }
+        if (head) {
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                if (kk == 2 || kk == 3) r.h2[it] = 0.0;      // pose x pose coupling to a pinned keyframe: carried by the spike
+                if (kk == 3 || kk == 4) r.h3[it] = 0.0;
+            }
+            if (kk <= 1 && lane < 6) r.hg = 0.0;
+        }
+        if (tail && lane >= 6) r.hg = 0.0;
+        return r;
+    };
+    auto commit_row = [&](auto ph, const HRow r_in, int kind, int kk) {   // sweep row kk with kk & 3 == PH
         constexpr int PH = decltype(ph)::value;
         constexpr int s = PH * 15, c1 = ((PH + 3) & 3) * 15, c2 = ((PH + 2) & 3) * 15, c3 = ((PH + 1) & 3) * 15;
+        HRow r = r_in;
+        if constexpr (CH) {
+            if ((cg.i0 > 0 && kk <= 4) || (cg.has_sep && kk > cg.ni && kk <= cg.ni + 2)) r = mask_boundary_row(r_in, kk);
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const bool in = cm_off[j] >= 0;
@@ -1142,19 +1184,20 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     }
     }   // forward sweep
     if constexpr (MODE == SOLVE_CHUNK_FWD) {
-        // the 3 separator keyframes sit in slots 0..2 (cnt is a multiple of 4): their block
-        // (own H + lambda + Schur terms of this chunk's interior) and rhs go to sep_out [45][46]
+        // the cut keyframe and the two after it sit in slots 0..2 (cnt is a multiple of 4): the separator's 27 dof
+        // (15 + pose + pose): own H + lambda + Schur terms of this chunk's interior, and rhs, go to sep_out [27][28]
         if (cg.has_sep) {
-            for (int e = lane; e < SEP * 46; e += 64) {
-                const int i = e / 46, jc = e - i * 46;
-                const int oi = i / 15, ai = i - oi * 15;
-                double val = 0.0;
-                if (jc == 45) {
+            for (int e = lane; e < SEP * 28; e += 64) {
+                const int i = e / 28, jc = e - i * 28;
+                const int oi = i < 15 ? 0 : (i < 21 ? 1 : 2), ai = i < 15 ? i : (i < 21 ? i - 15 : i - 21);
+                double val;
+                if (jc == 27) {
                     val = S[S_GD + oi * 15 + ai];
                 } else {
                     const int hi_i = i >= jc ? i : jc, lo_i = i >= jc ? jc : i;
-                    const int oa = hi_i / 15, a = hi_i - oa * 15, ob = lo_i / 15, bb = lo_i - ob * 15;
-                    if (oa - ob < 2 || a < 6) val = S[S_WD + (oa * 15 + a) * LDW + ob * 15 + bb];
+                    const int oa = hi_i < 15 ? 0 : (hi_i < 21 ? 1 : 2), a = hi_i < 15 ? hi_i : (hi_i < 21 ? hi_i - 15 : hi_i - 21);
+                    const int ob = lo_i < 15 ? 0 : (lo_i < 21 ? 1 : 2), bb = lo_i < 15 ? lo_i : (lo_i < 21 ? lo_i - 15 : lo_i - 21);
+                    val = S[S_WD + (oa * 15 + a) * LDW + ob * 15 + bb];
                 }
                 sep_out[e] = val;
             }
@@ -1170,8 +1213,9 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     S[S_DL + lane] = 0.0;
     if constexpr (MODE == SOLVE_CHUNK_BWD) {
         WSYNC();
-        // increments of the separator keyframes (solved by k_sep_solve) start the recursion
-        if (cg.has_sep && lane < SEP) S[S_DL + lane] = dbase[(size_t)cg.ni * 15 + lane];
+        // increments of the separator dof (solved by k_sep_solve) start the recursion; the velocity / bias dof of the
+        // two keyframes after the cut belong to the next chunk and do not couple to this one
+        if (cg.has_sep && lane < 45) S[S_DL + lane] = (lane < 15 || (lane % 15) < 6) ? dbase[(size_t)cg.ni * 15 + lane] : 0.0;
         WSYNC();
     }
     if constexpr (TW) {
@@ -1287,7 +1331,8 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         STAMP(9);
         WSYNC();
         S[(lane >= 28 && lane < 43) ? S_DL + PH * 15 + lane - 28 : dl_w] = x;
-        if (lane >= 28 && lane < 43 && pivot_real(k)) dbase[(size_t)kf_of(k) * 15 + lane - 28] = x;
+        // (head keyframes of a chunk: only their velocity / bias increments are this sweep's; the pose part is the separator's)
+        if (lane >= 28 && lane < 43 && pivot_real(k) && !(CH && cg.i0 > 0 && k < 2 && lane < 34)) dbase[(size_t)kf_of(k) * 15 + lane - 28] = x;
         WSYNC();
         STAMP(10);
     };
@@ -1345,11 +1390,11 @@ __global__ void __launch_bounds__(128) k_band_solve_tw(View v) {
 //   5. k_chunk_back    : the band back substitution of every chunk, started from delta(S_c).
 // Same arithmetic as one sweep up to the elimination order (a nested-dissection ordering of the same
 // Cholesky factorisation); tests/test_gpu_partitioned.py compares the increments of the two forms.
-// Spike of chunk c >= 1 (second wave of k_chunk_forward).  W = the not yet substituted part of E for the
-// next 4 keyframes, V_k = L_kk^-1 W_k, all kept as 16x16 tiles in the MFMA accumulator layout
-// (row = (lane>>4) + 4r, column = lane & 15), which is also the B-operand layout of v_mfma_f64_16x16x4:
-// results feed the next product without leaving registers.  Three column tiles cover the 45 separator
-// columns.  The panel of step k is read from the LDS ring slot k & 3 once the sweep has published it.
+// Spike of chunk c >= 1 (second wave of k_chunk_forward).  W = the not yet substituted part of E (coupling of the
+// chunk's dof to its LEFT separator, 27 columns) for the next 4 keyframes, V_k = L_kk^-1 W_k, all kept as 16x16
+// tiles in the MFMA accumulator layout (row = (lane>>4) + 4r, column = lane & 15), which is also the B-operand
+// layout of v_mfma_f64_16x16x4: results feed the next product without leaving registers.  Two column tiles cover
+// the 27 separator columns.  The panel of step k is read from the LDS ring slot k & 3 once the sweep has published it.
 __device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int c, ChunkGeom cg, int lane) {
     const int lo = v.lo[w];
     const int li = lane & 15, lq = lane >> 4;
@@ -1357,30 +1402,37 @@ __device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int
     const double* __restrict__ Hb = v.H + base * HROW;
     double* __restrict__ Vb = v.Vp + base * VROW;
 
-    // E rows of interior keyframe kk (0..2): block d = kk + 3 - o of its H row couples it to separator
-    // keyframe o (0..2); d = 1 is a full 15x15 block (IMU factor), d = 2, 3 pose x pose only
+    // E[(kk, a)][j]: dof a of the chunk's keyframe kk (window keyframe i0 + kk) against separator column j:
+    //   j < 15: dof j of the cut keyframe i0 - 1;  15..20: pose of keyframe i0 (kk = 0);  21..26: pose of i0 + 1 (kk = 1).
+    // Rows: all 15 dof for kk >= 2, the velocity / bias dof (a >= 6) for the pinned head keyframes kk = 0, 1.
+    // Entries come from the block rows of H (block d of row k = H[k][k-d]; d = 1 full 15x15, d = 2, 3 pose x pose),
+    // the diagonal block for a keyframe against its own pose, and the transposed d = 1 block of row i0 + 1 for
+    // (kk = 0 velocity/bias) x (pose of i0 + 1).  Nothing beyond kk = 4.
     auto e_val = [&](int kk, int a, int j) -> double {
-        if (j >= SEP || a >= 15 || kk >= cg.ni) return 0.0;
-        const int o = j / 15, cc = j - o * 15, d = kk + 3 - o;
+        if (j >= SEP || a >= 15 || kk >= cg.ni || kk > 4) return 0.0;
+        if (kk <= 1 && a < 6) return 0.0;
+        const int kc = j < 15 ? -1 : (j < 21 ? 0 : 1), cc = j < 15 ? j : (j < 21 ? j - 15 : j - 21);
+        const int d = kk - kc;
         if (d > 3) return 0.0;
-        const double* Hk = Hb + (size_t)kk * HROW;
-        if (d == 1) return Hk[225 + a * 15 + cc];
-        return (a < 6 && cc < 6) ? Hk[225 * d + a * 15 + cc] : 0.0;
+        if (d == 0) return Hb[(size_t)kk * HROW + a * 15 + cc];                      // own diagonal block: (vel/bias) x pose
+        if (d < 0) return Hb[(size_t)kc * HROW + 225 + cc * 15 + a];                 // kk = 0, kc = 1: H[i0+1][i0] transposed
+        if (d == 1) return Hb[(size_t)kk * HROW + 225 + a * 15 + cc];
+        return (a < 6 && cc < 6) ? Hb[(size_t)kk * HROW + 225 * d + a * 15 + cc] : 0.0;
     };
-    d4_t Wa[3], Wb[3], Wcd[3];   // W of keyframes k, k+1 and (pose rows of) k+2 | k+3 stacked at rows 0..7 | 8..15
+    d4_t Wa[2], Wb[2], Wcd[2];   // W of keyframes k, k+1 and rows 0..7 of k+2 | k+3 stacked at tile rows 0..7 | 8..15
 #pragma unroll
-    for (int J = 0; J < 3; J++) {
+    for (int J = 0; J < 2; J++) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int a = lq + 4 * r, j = 16 * J + li;
             Wa[J][r] = e_val(0, a, j);
             Wb[J][r] = e_val(1, a, j);
-            Wcd[J][r] = r < 2 ? e_val(2, a, j) : 0.0;
+            Wcd[J][r] = r < 2 ? e_val(2, a, j) : e_val(3, lq + 4 * (r - 2), j);
         }
     }
-    d4_t acc[6];                 // sum_k V_k^T [V_k | y_k], tiles (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+    d4_t acc[3];                 // sum_k V_k^T [V_k | y_k], tiles (0,0) (0,1) (1,1)
 #pragma unroll
-    for (int t = 0; t < 6; t++) acc[t] = (d4_t){0, 0, 0, 0};
+    for (int t = 0; t < 3; t++) acc[t] = (d4_t){0, 0, 0, 0};
 
     // panel rows: 0..14 L[k+1][k], 15..20 L[k+2 pose][k], 21..26 L[k+3 pose][k], 27 y_k, 28..42 L_kk^-T
     // (LDS ring slot: row stride 15, cell 645 = 0.0 for the masked lanes)
@@ -1393,7 +1445,7 @@ __device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int
         o_linv[q] = (ck && li < 15) ? (28 + cq) * 15 + li : 645;
         o_x1[q] = (ck && li < 15) ? li * 15 + cq : 645;
         o_x23[q] = (ck && r23 >= 0) ? r23 * 15 + cq : 645;
-        o_y[q] = (ck && li == 13) ? 27 * 15 + cq : 645;
+        o_y[q] = (ck && li == 11) ? 27 * 15 + cq : 645;          // column 27 = tile 1, lane & 15 == 11
     }
 #pragma unroll 1
     for (int k = 0; k < cg.ni; k++) {
@@ -1404,48 +1456,50 @@ __device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int
         for (int q = 0; q < 4; q++) { linv[q] = Pk[o_linv[q]]; x1[q] = -Pk[o_x1[q]]; x23[q] = -Pk[o_x23[q]]; yv[q] = Pk[o_y[q]]; }
         WSYNC();
         if (lane == 0) S[S_CONS] = (double)(k + 1);      // slot may be reused
-        d4_t V[3];
+        d4_t V[2];
 #pragma unroll
-        for (int J = 0; J < 3; J++) {
+        for (int J = 0; J < 2; J++) {
             V[J] = (d4_t){0, 0, 0, 0};
 #pragma unroll
             for (int q = 0; q < 4; q++) V[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(linv[q], Wa[J][q], V[J], 0, 0, 0);
         }
 #pragma unroll
-        for (int J = 0; J < 3; J++) {
+        for (int J = 0; J < 2; J++) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 Wb[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[q], V[J][q], Wb[J], 0, 0, 0);
                 Wcd[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(x23[q], V[J][q], Wcd[J], 0, 0, 0);
             }
         }
-        // V^T [V | y]: y_k rides in column 45 (tile 2, lane & 15 == 13), where V is identically zero
+        // V^T [V | y]: y_k rides in column 27 (tile 1, lane & 15 == 11), where V is identically zero
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const double v2y = V[2][q] + yv[q];
+            const double v1y = V[1][q] + yv[q];
             acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[0][q], V[0][q], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[0][q], V[1][q], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[0][q], v2y, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[1][q], V[1][q], acc[3], 0, 0, 0);
-            acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[1][q], v2y, acc[4], 0, 0, 0);
-            acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[2][q], v2y, acc[5], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[0][q], v1y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[1][q], v1y, acc[2], 0, 0, 0);
         }
         // spike rows of keyframe k -> HBM (k_chunk_rhs reads them back)
         double* Vk = Vb + (size_t)k * VROW;
 #pragma unroll
-        for (int J = 0; J < 3; J++)
+        for (int J = 0; J < 2; J++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int a = lq + 4 * r;
-                if (a < 15) Vk[a * 48 + 16 * J + li] = V[J][r];
+                if (a < 15) Vk[a * 32 + 16 * J + li] = V[J][r];
             }
         if (k + 1 < cg.ni) {
-            // advance one keyframe: new E rows only exist for the first three keyframes (already in W)
+            // advance one keyframe.  E rows that only now get a register home: rows 8..14 of keyframe k+2 (it becomes
+            // the "k+1" tile) and rows 0..7 of keyframe k+4 (the new "k+3" half tile); both vanish beyond keyframe 4
 #pragma unroll
-            for (int J = 0; J < 3; J++) {
+            for (int J = 0; J < 2; J++) {
+                const int j = 16 * J + li;
+                double e2 = 0.0, e3 = 0.0, f0 = 0.0, f1 = 0.0;
+                if (k <= 2) { e2 = e_val(k + 2, lq + 8, j); e3 = e_val(k + 2, lq + 12, j); }
+                if (k == 0) { f0 = e_val(4, lq, j); f1 = e_val(4, lq + 4, j); }
                 Wa[J] = Wb[J];
-                Wb[J] = (d4_t){Wcd[J][0], Wcd[J][1], 0.0, 0.0};
-                Wcd[J] = (d4_t){Wcd[J][2], Wcd[J][3], 0.0, 0.0};
+                Wb[J] = (d4_t){Wcd[J][0], Wcd[J][1], e2, e3};
+                Wcd[J] = (d4_t){Wcd[J][2], Wcd[J][3], f0, f1};
             }
         }
     }
@@ -1455,25 +1509,27 @@ __device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int i = 16 * I + lq + 4 * r, j = 16 * J + li;
-            if (i < SEP && j < 46) {
-                Sm[i * 46 + j] = -t[r];
-                if (I != J && j < SEP) Sm[j * 46 + i] = -t[r];
+            if (i < SEP && j < 28) {
+                Sm[i * 28 + j] = -t[r];
+                if (I != J && j < SEP) Sm[j * 28 + i] = -t[r];
             }
         }
     };
-    put(acc[0], 0, 0); put(acc[1], 0, 1); put(acc[2], 0, 2); put(acc[3], 1, 1); put(acc[4], 1, 2); put(acc[5], 2, 2);
+    put(acc[0], 0, 0); put(acc[1], 0, 1); put(acc[2], 1, 1);
     if (cg.has_sep) {
-        // what is left in W belongs to the right separator: rows i1 (15), i1+1 and i1+2 (pose rows)
+        // what is left in W belongs to the right separator: the cut keyframe (15 rows), pose rows of the two after it
         double* Cm = v.sepC + ((size_t)c * v.B + w) * SEP * SEP;
 #pragma unroll
-        for (int J = 0; J < 3; J++)
+        for (int J = 0; J < 2; J++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int a = lq + 4 * r, j = 16 * J + li;
-                if (j < SEP && a < 15) {
-                    Cm[a * SEP + j] = Wb[J][r];
-                    Cm[(15 + a) * SEP + j] = r < 2 ? Wcd[J][r] : 0.0;
-                    Cm[(30 + a) * SEP + j] = r < 2 ? Wcd[J][r + 2] : 0.0;
+                if (j < SEP) {
+                    if (a < 15) Cm[a * SEP + j] = Wb[J][r];
+                    if (r < 2 && a < 6) {
+                        Cm[(15 + a) * SEP + j] = Wcd[J][r];
+                        Cm[(21 + a) * SEP + j] = Wcd[J][r + 2];
+                    }
                 }
             }
     }
@@ -1522,11 +1578,15 @@ __global__ void __launch_bounds__(256) k_chunk_rhs(View v) {
     const ChunkGeom cg = chunk_geom(n, Pe, c);
     const size_t base = (size_t)w * v.M + lo + cg.i0;
     __shared__ double dl[SEP];
-    if (threadIdx.x < SEP) dl[threadIdx.x] = v.delta[(base - 3) * 15 + threadIdx.x];
+    // left separator: the cut keyframe i0 - 1 (15), pose of i0, pose of i0 + 1
+    if (threadIdx.x < SEP) {
+        const int j = threadIdx.x;
+        dl[j] = j < 15 ? v.delta[(base - 1) * 15 + j] : (j < 21 ? v.delta[base * 15 + j - 15] : v.delta[(base + 1) * 15 + j - 21]);
+    }
     __syncthreads();
     for (int e = threadIdx.x; e < cg.ni * 15; e += 256) {
         const int k = e / 15, a = e - k * 15;
-        const double* Vr = v.Vp + (base + k) * VROW + a * 48;
+        const double* Vr = v.Vp + (base + k) * VROW + a * 32;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int j = 0; j < SEP; j += 3) {
@@ -1538,32 +1598,32 @@ __global__ void __launch_bounds__(256) k_chunk_rhs(View v) {
     }
 }
 
-// Block-tridiagonal Cholesky of the separator chain, one workgroup per window: two teams of three waves
-// eliminate the chain from both ends towards the middle separator h = m / 2 (no extra arithmetic: the
+// Block-tridiagonal Cholesky of the separator chain (27-dof blocks), one workgroup per window: two teams of two
+// waves eliminate the chain from both ends towards the middle separator h = m / 2 (no extra arithmetic: the
 // two-sided order of the same factorisation), then back-substitute outwards from it.
-// Forward, per team: step j factors the 91-row panel of its pivot separator, one row per thread of the
-// team's waves 0-1, 45 columns in registers:
-//     0..44  D (pivot block)      45..89  C (coupling to the next separator of this team's direction)      90  rhs
+// Forward, per team: step j factors the 55-row panel of its pivot separator, one row per lane of the team's
+// wave 0, 27 columns in registers:
+//     0..26  D (pivot block)      27..53  C (coupling to the next separator of this team's direction)      54  rhs
 // (team 1 walks the chain backwards, so its coupling rows are the stored blocks transposed).
-// Column operations as in the band solver: after 45 pivots the rows hold L, Z = C L^-T and y.
-// Column c of the pivot rows crosses the waves through a triple-buffered LDS column (one LDS-only barrier
-// per pivot); only column c+1 is updated on the critical path, the others after the next barrier in the
-// shadow of its rsqrt.  Wave 2 of a team owns no rows: it stages the inputs of the team's next step
-// (global -> registers during the pivots, one slice between two barriers, -> LDS after them).
-// D_next -= Z Z^T, rhs_next -= Z y: nine 16x16 MFMA tiles, three per wave, operands from the Z rows in LDS.
+// Column operations as in the band solver: after 27 pivots the rows hold L, Z = C L^-T and y.
+// Column c of the pivot rows goes through a triple-buffered LDS column (one LDS-only barrier per pivot keeps
+// the two teams and their stagers in step); only column c+1 is updated on the critical path, the others after
+// the next barrier in the shadow of its rsqrt.  Wave 1 of a team owns no rows: it stages the inputs of the
+// team's next step (global -> registers during the pivots, one slice between two barriers, -> LDS 12 barriers later).
+// D_next -= Z Z^T, rhs_next -= Z y: four 16x16 MFMA tiles, two per wave, operands from the Z rows in LDS.
 // The middle separator receives both teams' Schur terms and is factored by team 0.
 // Backward: wave 0 of a team solves L^T delta = y - Z^T delta(neighbour towards the middle) (increment
-// broadcast by v_readlane, no barriers inside a separator) while its waves 1-2 copy the next factor from
+// broadcast by v_readlane, no barriers inside a separator) while its wave 1 copies the next factor from
 // HBM into LDS.  Measured cost and what bounds it: DESIGN.md "K4p".
-constexpr int ZS = 46;                       // LDS row stride of the D / C panel input (45 columns + rhs)
-constexpr int LXS = 96;                      // HBM: factor of one separator, column-major [45][96]: rows 0..44 L, 45..89 Z, 90 y
-constexpr int FS = 97;                       // LDS row stride of the factor copy (odd: conflict-free row walks)
-constexpr int ZZ = 49;                       // LDS row stride of the Z rows (odd; zero padding = MFMA K and tile remainders)
-constexpr int SEP_FW = 144 + 48 * ZZ + 92 * ZS;      // forward LDS of one team: column buffers, Z rows, panel input
+constexpr int ZS = 28;                       // LDS row stride of the D / C panel input (27 columns + rhs)
+constexpr int LXS = 64;                      // HBM: factor of one separator, column-major [27][64]: rows 0..26 L, 27..53 Z, 54 y
+constexpr int FS = 57;                       // LDS row stride of the factor copy (odd: conflict-free row walks)
+constexpr int ZZ = 29;                       // LDS row stride of the Z rows (odd; zero padding = MFMA K and tile remainders)
+constexpr int SEP_FW = 96 + 32 * ZZ + 56 * ZS;        // forward LDS of one team: column buffers, Z rows, panel input
 constexpr int SEP_BW = 2 * SEP * FS;                  // backward LDS of one team: two factor copies
 constexpr int SEP_LDS = 2 * (SEP_FW > SEP_BW ? SEP_FW : SEP_BW);
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for
-// the stager's global loads and the factor stores at every one of the 45 pivot barriers of a step
+// the stager's global loads and the factor stores at every one of the 27 pivot barriers of a step
 #define LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #ifdef VF_SOLVE_STAMPS
 __device__ unsigned long long g_sep_stamps[16];
@@ -1572,10 +1632,12 @@ __device__ unsigned long long g_sep_stamps[16];
 #define SSTAMP(i) do {} while (0)
 #endif
 static_assert(SEPL >= SEP * LXS, "factor block does not fit its HBM slot");
-__global__ void __launch_bounds__(384) k_sep_solve(View v) {
+// the three keyframes of separator `s`: element j of its 27-dof increment -> offset in v.delta relative to the cut keyframe
+VF_DI int sep_delta_offset(int j) { return j < 15 ? j : (j < 21 ? 15 + (j - 15) : 30 + (j - 21)); }
+__global__ void __launch_bounds__(256) k_sep_solve(View v) {
     const int P = v.P, w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches on the roles
-    const int team = wave >= 3 ? 1 : 0, tw = wave - 3 * team, tt = tid - 192 * team;
+    const int team = wave >= 2 ? 1 : 0, tw = wave - 2 * team, tt = tid - 128 * team;
     const int lo = v.lo[w], n = v.hi[w] - lo;
     if (n <= 0 || window_done(v, w)) return;
     const int Pe = chunk_count(n, P, v.P_fit), m = Pe - 1;
@@ -1583,15 +1645,15 @@ __global__ void __launch_bounds__(384) k_sep_solve(View v) {
     const int h = m / 2;                         // middle separator; team 0: 0 .. h-1 then h, team 1: m-1 .. h+1
     const int nreal = team == 0 ? h : m - 1 - h; // real forward steps of this team (the loop runs h times)
     __shared__ __attribute__((aligned(16))) double smem[SEP_LDS];
-    __shared__ double dnext_s[2][48];
-    double* colbuf = smem + team * SEP_FW;       // [3][48]: column c of the pivot rows (47 = sink of the other rows)
-    double* Zs = colbuf + 144;                   // [48][ZZ]: Z rows 0..44, y = row 45; rows 46, 47 and columns 45..48 stay zero
-    double* Dn = Zs + 48 * ZZ;                   // [92][ZS]: panel input: D rows 0..44, C rows 45..89, rhs row 90, zero row 91
+    __shared__ double dnext_s[2][32];
+    double* colbuf = smem + team * SEP_FW;       // [3][32]: column c of the pivot rows (31 = sink of the other rows)
+    double* Zs = colbuf + 96;                    // [32][ZZ]: Z rows 0..26, y = row 27; rows 28..31 and columns 27, 28 stay zero
+    double* Dn = Zs + 32 * ZZ;                   // [56][ZS]: panel input: D rows 0..26, C rows 27..53, rhs row 54, zero row 55
     // separator blocks are stored chunk-major, [P][B][..]: the chunks of one rank of a time-sharded window are
     // contiguous (all-gather slices); element (c, w) of this window sits c * cs (resp. c * cc) further on
     const size_t cs = (size_t)v.B * SEPM, cc = (size_t)v.B * SEP * SEP;
     const double* __restrict__ R = v.sepR + (size_t)w * SEPM;
-    const double* __restrict__ Sx = v.sepS + (size_t)w * SEPM;          // chunk 0 is never written: 2070 zeros
+    const double* __restrict__ Sx = v.sepS + (size_t)w * SEPM;          // chunk 0 is never written: 756 zeros
     const double* __restrict__ Cx = v.sepC + (size_t)w * SEP * SEP;
     double* __restrict__ Lx = v.sepL + (size_t)w * P * SEPL;
     int failed = 0;
@@ -1608,15 +1670,15 @@ __global__ void __launch_bounds__(384) k_sep_solve(View v) {
         if (team == 0) return (sidx >= 0 && sidx < h) ? Cx + (size_t)(sidx + 1) * cc : Sx;
         return (sidx > h && sidx < m) ? Cx + (size_t)sidx * cc : Sx;
     };
-    for (int e = tt; e < 92 * ZS; e += 192) Dn[e] = 0.0;
-    for (int e = tt; e < 48 * ZZ; e += 192) Zs[e] = 0.0;
+    for (int e = tt; e < 56 * ZS; e += 128) Dn[e] = 0.0;
+    for (int e = tt; e < 32 * ZZ; e += 128) Zs[e] = 0.0;
     __syncthreads();
-    // staged element (i, j) of a [45][46] (D | rhs) block / of a [45][45] coupling block -> panel input
-    auto dst_d = [](int e) { const int i = e / 46, j = e - i * 46; return e < SEP * 46 ? (j == 45 ? 90 * ZS + i : i * ZS + j) : 91 * ZS + 45; };
+    // staged element (i, j) of a [27][28] (D | rhs) block / of a [27][27] coupling block -> panel input
+    auto dst_d = [](int e) { const int i = e / 28, j = e - i * 28; return e < SEP * 28 ? (j == 27 ? 54 * ZS + i : i * ZS + j) : 55 * ZS + 27; };
     auto dst_c = [=](int e) {
         const int i = e / SEP, j = e - i * SEP;
-        if (e >= SEP * SEP) return 91 * ZS + 45;                             // (row 91, column 45) is never read
-        return team == 0 ? (45 + i) * ZS + j : (45 + j) * ZS + i;            // team 1: the stored block transposed
+        if (e >= SEP * SEP) return 55 * ZS + 27;                             // (row 55, column 27) is never read
+        return team == 0 ? (27 + i) * ZS + j : (27 + j) * ZS + i;            // team 1: the stored block transposed
     };
     {
         const double *pa, *pb;
@@ -1624,13 +1686,13 @@ __global__ void __launch_bounds__(384) k_sep_solve(View v) {
         const double* pc = c_ptr(piv(0));
         const bool any = nreal > 0 || team == 0;          // team 0 also prepares the middle when it has no step of its own
         if (any) {
-            for (int e = tt; e < SEP * 46; e += 192) Dn[dst_d(e)] = pa[e] + pb[e];
-            for (int e = tt; e < SEP * SEP; e += 192) Dn[dst_c(e)] = pc[e];
+            for (int e = tt; e < SEP * 28; e += 128) Dn[dst_d(e)] = pa[e] + pb[e];
+            for (int e = tt; e < SEP * SEP; e += 128) Dn[dst_c(e)] = pc[e];
         }
     }
     __syncthreads();
-    const int prow = (tt < 91 ? tt : 91) * ZS;         // this thread's panel row in Dn (91 = zeros)
-    double* col_w = colbuf + (tt < 45 ? tt : 47);      // one base register + immediates (nothing per-column to hoist)
+    const int prow = (lane < 55 ? lane : 55) * ZS;     // this lane's panel row in Dn (55 = zeros)
+    double* col_w = colbuf + (lane < 27 ? lane : 31);  // one base register + immediates (nothing per-column to hoist)
     // LDS reads at compile-time addresses go through ONE opaque base register so that every access is
     // base + immediate (otherwise each constant address is materialised in its own VGPR, hoisted out of
     // the loop, and the register file is gone: the reads then serialise on a single destination register)
@@ -1648,33 +1710,32 @@ __global__ void __launch_bounds__(384) k_sep_solve(View v) {
             for (int c = 0; c < SEP + 3; c++) LDS_BARRIER();
             return;
         }
-        if (tw == 2) {
+        if (tw == 1) {
             // ---- stager: D and C of the team's next step.  Absent terms read the zero slot, so the loads are
             // unconditional and nothing is computed on them before the pivot barriers are behind us.
             int sz;
             asm volatile("v_mov_b32 %0, 0" : "=v"(sz));      // opaque zero: keeps the element maps inside the loop
             const double *pa, *pb;
             d_ptrs(more ? snext : -1, pa, pb);
-            const int after = team == 0 ? snext : snext;      // pivot of the step after this one
-            const double* pc = more ? c_ptr(after) : Sx;
+            const double* pc = more ? c_ptr(snext) : Sx;
             LDS_BARRIER();   // Dn consumed (the stager arrives first: nothing of its work sits in front of the pivots)
             // one slice of the staging work (3 loads, 2 destinations) between two pivot barriers, so that the stager
-            // is never the last wave to arrive; a slice goes to LDS 12 barriers (~2.5 us) after its loads were issued
+            // is never the last wave to arrive; a slice goes to LDS 12 barriers later
             // (the panel input was consumed at the top of the step, so Dn is free; the Schur update comes after)
-            constexpr int LAG = 12;
-            double ba[33], bb[33], bc[33];
-            int da[33], dc[33];
+            constexpr int NSL = 12, LAG = 12;                 // 12 * 64 = 768 >= 756 elements of (D | rhs)
+            double ba[NSL], bb[NSL], bc[NSL];
+            int da[NSL], dc[NSL];
 #pragma unroll
             for (int c = 0; c < SEP; c++) {
-                if (c < 33) {
-                    const int e = lane + 64 * c + sz, ed = e < SEP * 46 ? e : 0;
+                if (c < NSL) {
+                    const int e = lane + 64 * c + sz, ed = e < SEP * 28 ? e : 0;
                     ba[c] = pa[ed];
                     bb[c] = pb[ed];
                     da[c] = dst_d(e);
                     bc[c] = pc[e < SEP * SEP ? e : 0];
                     dc[c] = dst_c(e);
                 }
-                if (c >= LAG) { Dn[da[c - LAG]] = ba[c - LAG] + bb[c - LAG]; Dn[dc[c - LAG]] = bc[c - LAG]; }
+                if (c >= LAG && c - LAG < NSL) { Dn[da[c - LAG]] = ba[c - LAG] + bb[c - LAG]; Dn[dc[c - LAG]] = bc[c - LAG]; }
                 LDS_BARRIER();
             }
         } else {
@@ -1687,13 +1748,13 @@ __global__ void __launch_bounds__(384) k_sep_solve(View v) {
             double pc_prev = 0.0;
 #pragma unroll
             for (int c = 0; c < SEP; c++) {
-                col_w[(c % 3) * 48] = p[c];
+                col_w[(c % 3) * 32] = p[c];
                 LDS_BARRIER();
-                double pivv = cb[(c % 3) * 48 + c];
+                double pivv = cb[(c % 3) * 32 + c];
                 double mv[SEP];          // multipliers of the previous pivot: all LDS reads in flight together
                 if (c > 0) {
 #pragma unroll
-                    for (int c2 = c + 1; c2 < SEP; c2++) mv[c2] = cb[((c - 1) % 3) * 48 + c2];
+                    for (int c2 = c + 1; c2 < SEP; c2++) mv[c2] = cb[((c - 1) % 3) * 32 + c2];
                 }
                 __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler serialises read -> wait -> fma pairs)
                 if (!(pivv > 0.0)) { failed = 1; pivv = 1.0; }
@@ -1704,42 +1765,42 @@ __global__ void __launch_bounds__(384) k_sep_solve(View v) {
                 }
                 p[c] *= inv;
                 pc_prev = -p[c] * inv;
-                if (c + 1 < SEP) p[c + 1] = fma(pc_prev, cb[(c % 3) * 48 + c + 1], p[c + 1]);
+                if (c + 1 < SEP) p[c + 1] = fma(pc_prev, cb[(c % 3) * 32 + c + 1], p[c + 1]);
             }
             SSTAMP(2);
             // factor rows -> HBM, column-major: one contiguous 8-byte-per-lane store per column
-            if (tt < 91) {
-                double* dst = Lx + (size_t)sidx * SEPL + tt;
+            if (lane < 55) {
+                double* dst = Lx + (size_t)sidx * SEPL + lane;
 #pragma unroll
                 for (int c = 0; c < SEP; c++) dst[c * LXS] = p[c];
             }
-            if (tt >= 45 && tt <= 90) {
+            if (lane >= 27 && lane <= 54) {
 #pragma unroll
-                for (int c = 0; c < SEP; c++) Zs[(tt - 45) * ZZ + c] = p[c];
+                for (int c = 0; c < SEP; c++) Zs[(lane - 27) * ZZ + c] = p[c];
             }
         }
         LDS_BARRIER();
         SSTAMP(3);
         if (more) {
-            // D_next -= Z Z^T, rhs_next -= Z y on the matrix cores: 3 x 3 tiles of 16 x 16, three per wave,
-            // K = 45 (12 steps of 4); both operands come from the Z rows in LDS (row 45 = y)
+            // D_next -= Z Z^T, rhs_next -= Z y on the matrix cores: 2 x 2 tiles of 16 x 16, two per wave,
+            // K = 27 (7 steps of 4); both operands come from the Z rows in LDS (row 27 = y)
             const int li = lane & 15, lq = lane >> 4;
 #pragma unroll 1
-            for (int t = tw; t < 9; t += 3) {
-                const int I = t / 3, J = t - I * 3;
-                // rows 45 (y), 46, 47 of tile I = 2 produce output rows that are dropped; zero padding does the masking
+            for (int t = tw; t < 4; t += 2) {
+                const int I = t >> 1, J = t & 1;
+                // rows 27 (y), 28..31 of tile I = 1 produce output rows that are dropped; zero padding does the masking
                 const double* za = Zs + (16 * I + li) * ZZ + lq;
                 const double* zb = Zs + (16 * J + li) * ZZ + lq;
-                double av[12], bv[12];
+                double av[7], bv[7];
 #pragma unroll
-                for (int q = 0; q < 12; q++) { av[q] = za[4 * q]; bv[q] = zb[4 * q]; }
+                for (int q = 0; q < 7; q++) { av[q] = za[4 * q]; bv[q] = zb[4 * q]; }
                 d4_t acc = {0, 0, 0, 0};
 #pragma unroll
-                for (int q = 0; q < 12; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+                for (int q = 0; q < 7; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int i = 16 * I + lq + 4 * r, j = 16 * J + li;
-                    if (i < 45 && j < 46) Dn[j == 45 ? 90 * ZS + i : i * ZS + j] -= acc[r];
+                    if (i < 27 && j < 28) Dn[j == 27 ? 54 * ZS + i : i * ZS + j] -= acc[r];
                 }
             }
         }
@@ -1753,71 +1814,69 @@ __global__ void __launch_bounds__(384) k_sep_solve(View v) {
     }
     // ---- the middle separator: team 0's panel input (its own D + left Schur terms) + team 1's Schur terms
     {
-        const double* Dother = smem + SEP_FW + 144 + 48 * ZZ;
+        const double* Dother = smem + SEP_FW + 96 + 32 * ZZ;
         if (team == 0)
-            for (int e = tt; e < 91 * ZS; e += 192) Dn[e] += (e < 45 * ZS || e >= 90 * ZS) ? Dother[e] : 0.0;
+            for (int e = tt; e < 55 * ZS; e += 128) Dn[e] += (e < 27 * ZS || e >= 54 * ZS) ? Dother[e] : 0.0;
         LDS_BARRIER();
         step(h, -1, team == 0, false);
     }
     SSTAMP(4);
     __syncthreads();   // the factor blocks in HBM (written by other threads of the workgroup) are read back below
     // ---- back substitution outwards from the middle ------------------------------------------------
-    // HBM -> LDS copy of one factor block: [45 columns][91 rows], rows contiguous -> F[c * FS + r]
-    // (all loads of a thread are issued before the first LDS write: 34 independent round trips, not 34 serial ones)
+    // HBM -> LDS copy of one factor block: [27 columns][55 rows], rows contiguous -> F[c * FS + r]
+    // (all loads of a thread are issued before the first LDS write: 27 independent round trips, not 27 serial ones)
     double* Fb = smem + team * SEP_BW;
-    auto copy_factor = [&](int sidx, int buf, int t0) {     // 128 threads of a team: t0 = 0..127
+    auto copy_factor = [&](int sidx, int buf) {     // the 64 lanes of a team's wave 1
         const double* Ls = Lx + (size_t)sidx * SEPL;
-        double x[34];
+        double x[SEP];
 #pragma unroll
-        for (int q = 0; q < 34; q++) { const int e = t0 + 128 * q; x[q] = Ls[e < SEP * LXS ? e : 0]; }
+        for (int q = 0; q < SEP; q++) x[q] = Ls[q * LXS + lane];
 #pragma unroll
-        for (int q = 0; q < 34; q++) {
-            const int e = t0 + 128 * q, c = e / LXS, r = e - c * LXS;
-            if (e < SEP * LXS && r < 91) Fb[buf * SEP * FS + c * FS + r] = x[q];
-        }
+        for (int q = 0; q < SEP; q++)
+            if (lane < 55) Fb[buf * SEP * FS + q * FS + lane] = x[q];
     };
     // iteration i: team 0 solves separator h - i (i = 0: the middle, nothing towards the middle to subtract),
     // team 1 solves h + i (from i = 1); factor copies live in buffer i & 1
     auto mine = [=](int i) { return team == 0 ? h - i : h + i; };
     auto have = [=](int i) { return team == 0 ? i <= h : (i >= 1 && h + i <= m - 1); };
     if (tw != 0) {
-        if (team == 0) copy_factor(h, 0, tt - 64);
-        else if (have(1)) copy_factor(h + 1, 1, tt - 64);
+        if (team == 0) copy_factor(h, 0);
+        else if (have(1)) copy_factor(h + 1, 1);
     }
-    if (tt < 48) dnext_s[team][tt] = 0.0;
+    if (tt < 32) dnext_s[team][tt] = 0.0;
     __syncthreads();
 #pragma unroll 1
     for (int i = 0; i <= h; i++) {
         if (tw != 0) {
-            if (have(i + 1) && !(team == 1 && i == 0)) copy_factor(mine(i + 1), (i + 1) & 1, tt - 64);
+            if (have(i + 1) && !(team == 1 && i == 0)) copy_factor(mine(i + 1), (i + 1) & 1);
         } else if (have(i)) {
-            // thread j < 45 owns column j: F[j * FS + r] = L[r][j] (r >= j), Z[q][j] at row 45 + q, y_j at row 90
-            const double* F = Fb + (i & 1) * SEP * FS + (lane < 45 ? lane : 0) * FS;
-            double t0 = F[90], t1 = 0.0, t2 = 0.0;
+            // lane j < 27 owns column j: F[j * FS + r] = L[r][j] (r >= j), Z[q][j] at row 27 + q, y_j at row 54
+            const double* F = Fb + (i & 1) * SEP * FS + (lane < 27 ? lane : 0) * FS;
+            double t0 = F[54], t1 = 0.0, t2 = 0.0;
             if (i > 0) {
 #pragma unroll
                 for (int q = 0; q < SEP; q += 3) {
-                    t0 = fma(-F[45 + q], dnext_s[team][q], t0);
-                    t1 = fma(-F[45 + q + 1], dnext_s[team][q + 1], t1);
-                    t2 = fma(-F[45 + q + 2], dnext_s[team][q + 2], t2);
+                    t0 = fma(-F[27 + q], dnext_s[team][q], t0);
+                    t1 = fma(-F[27 + q + 1], dnext_s[team][q + 1], t1);
+                    t2 = fma(-F[27 + q + 2], dnext_s[team][q + 2], t2);
                 }
             }
             double t = (t0 + t1) + t2;
             double Lc[SEP];
 #pragma unroll
             for (int c = 0; c < SEP; c++) Lc[c] = F[c];
-            const double invd = 1.0 / F[lane < 45 ? lane : 0];       // 1 / L_jj
+            const double invd = 1.0 / F[lane < 27 ? lane : 0];       // 1 / L_jj
             // L^T x = t, last unknown first: x_c = t_c / L_cc, then t_j -= L[c][j] x_c for j < c
 #pragma unroll
             for (int c = SEP - 1; c >= 0; c--) {
                 const double xc = readlane_d(t * invd, c);
                 t = lane == c ? xc : (lane < c ? fma(-Lc[c], xc, t) : t);
             }
-            if (lane < 45) {
+            if (lane < 27) {
                 dnext_s[team][lane] = t;
                 if (i == 0) dnext_s[1][lane] = t;      // the middle's increment starts team 1's walk as well
                 const ChunkGeom cg = chunk_geom(n, Pe, mine(i));
-                v.delta[((size_t)w * v.M + lo + cg.i0 + cg.ni) * 15 + lane] = t;
+                v.delta[((size_t)w * v.M + lo + cg.i0 + cg.ni) * 15 + sep_delta_offset(lane)] = t;
             }
         }
         __syncthreads();
@@ -2191,7 +2250,7 @@ void launch_partitioned_local(const View& v, hipStream_t s) {
 }
 void launch_partitioned_global(const View& v, hipStream_t s) {
     const unsigned nb = (unsigned)v.B * (unsigned)v.P;
-    hipLaunchKernelGGL(k_sep_solve, dim3(v.B), dim3(384), 0, s, v);
+    hipLaunchKernelGGL(k_sep_solve, dim3(v.B), dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_chunk_rhs, dim3(nb), dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_chunk_back, dim3(nb), dim3(64), 0, s, v);
 }

@@ -15,38 +15,54 @@ constexpr int PRIOR_OUT = 240;  // r(15), J(15x15)
 constexpr int NBLK = 4;         // band blocks stored per keyframe (bandwidth 3 + diagonal)
 constexpr int HROW = NBLK * 225;
 constexpr int PANEL = 43 * 16;  // Cholesky panel in HBM: 43 rows (27 sub-diagonal, rhs, 15 of L^-T), one 128-B line each
-// partitioned solve (K4p): a window is cut into P chunks separated by 3-keyframe (45-dof) separators
-constexpr int SEP = 45;
-constexpr int SEPM = SEP * 46;  // 45x45 block + right-hand side column
-constexpr int SEPL = 45 * 96;   // factor of one separator elimination, column-major [45][96]: L (45 rows), Z (45), y
-constexpr int VROW = 15 * 48;   // spike rows of one keyframe: 15 dof x 45 separator columns (48 stored)
+// partitioned solve (K4p): a window is cut into P chunks joined by 27-dof separators.  With the profile
+// [k: 15][k+1: 15][k+2: pose 6][k+3: pose 6], everything in front of a cut keyframe b couples to the rest only
+// through  S = { b: 15 dof, pose(b+1): 6, pose(b+2): 6 }  (the 27 sub-diagonal rows of keyframe b-1's panel);
+// the velocity / bias dof of b+1 and b+2 are the first interior dof of the NEXT chunk, which therefore starts
+// at keyframe b+1 with two keyframes whose pose rows are pinned (identity rows).
+constexpr int SEP = 27;
+constexpr int SEPM = SEP * 28;  // 27x27 block + right-hand side column
+constexpr int SEPL = SEP * 64;  // factor of one separator elimination, column-major [27][64]: L (27 rows), Z (27), y
+constexpr int VROW = 15 * 32;   // spike rows of one keyframe: 15 dof x 27 separator columns (32 stored)
 
-// chunk geometry of an n-keyframe window cut into (at most) P chunks: interiors of L keyframes
-// (L a multiple of 4), 3 separator keyframes between consecutive chunks, the last chunk takes the rest
-__host__ __device__ inline int chunk_len(int n, int P) {
-    const int total = n - 3 * (P - 1);                 // interior keyframes
-    if (total < 8 * P) return total > 0 ? (total / P) & ~3 : 0;
-    const int up = ((total + P - 1) / P + 3) & ~3;     // round up: the last chunk gets the (smaller) rest
-    return n - (P - 1) * (up + 3) >= 8 ? up : (total / P) & ~3;
+// chunk geometry of an n-keyframe window cut into (at most) P chunks: the chunks that are followed by a separator
+// have L or L + 4 pivots (multiples of 4: the sweep's unroll), one cut keyframe sits between consecutive chunks,
+// the last chunk takes the rest:  n = sum_{c < P-1} (pivots_c + 1) + last,  with the first `longer` chunks at L + 4
+// so that the last one is no longer than L + 4 either
+struct ChunkPlan { int L, longer; };
+__host__ __device__ inline ChunkPlan chunk_plan(int n, int P) {
+    ChunkPlan p{0, 0};
+    const int total = n - (P - 1);                     // pivots of all chunks
+    if (P < 1 || total < 8 * P) { p.L = total > 0 && P >= 1 ? (total / P) & ~3 : 0; return p; }
+    p.L = (total / P) & ~3;
+    const int last0 = n - (P - 1) * (p.L + 1);         // the last chunk if no chunk were longer
+    int x = (last0 - (p.L + 4) + 3) / 4;
+    if (x < 0) x = 0;
+    if (x > P - 1) x = P - 1;
+    p.longer = x;
+    return p;
 }
-// chunks actually used for an n-keyframe window: at most P; with `fit` also at most sqrt(0.32 n), the
-// measured optimum of (chunk sweeps ~ 3.7 us * n / P) + (two-sided separator chain ~ 17 us * P / 2 + middle)
+__host__ __device__ inline int chunk_len(int n, int P) { return chunk_plan(n, P).L; }
+// chunks actually used for an n-keyframe window: at most P; with `fit` also at most sqrt(0.75 n), the
+// measured optimum of (chunk sweeps ~ 3.7 us * n / P) + (two-sided separator chain, see DESIGN.md "K4p")
 __host__ __device__ inline int chunk_count(int n, int P, int fit) {
     if (fit) {
         int want = 1;
-        while ((want + 1) * (want + 1) * 100 <= n * 32) want++;
+        while ((want + 1) * (want + 1) * 100 <= n * 75) want++;
         if (P > want) P = want;
     }
     while (P > 1 && chunk_len(n, P) < 8) P--;
     return P < 1 ? 1 : P;
 }
-struct ChunkGeom { int i0, ni, has_sep; };   // first interior keyframe (window-local), interior count, separator follows
+// i0 = first pivot keyframe (window-local), ni = pivots, has_sep: the cut keyframe i0 + ni and the pose rows of the
+// two keyframes after it follow as this chunk's tail rows (the next chunk starts at i0 + ni + 1)
+struct ChunkGeom { int i0, ni, has_sep; };
 __host__ __device__ inline ChunkGeom chunk_geom(int n, int Pe, int c) {
-    const int L = chunk_len(n, Pe);
+    const ChunkPlan p = chunk_plan(n, Pe);
     ChunkGeom g;
-    g.i0 = c * (L + 3);
+    g.i0 = c * (p.L + 1) + 4 * (c < p.longer ? c : p.longer);
     g.has_sep = c < Pe - 1;
-    g.ni = g.has_sep ? L : n - g.i0;
+    g.ni = g.has_sep ? p.L + (c < p.longer ? 4 : 0) : n - g.i0;
     return g;
 }
 
@@ -82,11 +98,11 @@ struct View {
     // keyframes only.  sh_G <= 1: not sharded.
     int sh_r, sh_G;
     double* cost_part;  // [2][B]              this rank's share of the cost, and its solve-failure flag (summed over ranks by the host side)
-    double* Vp;         // [G][15][48]         spikes: L^-1 (coupling of the chunk interior to its left separator)
-    double* sepR;       // [P][B][45][46]      separator block + rhs left by the forward sweep of chunk c
-    double* sepS;       // [P][B][45][46]      Schur term of chunk c on its LEFT separator (c >= 1)
-    double* sepC;       // [P][B][45][45]      coupling (right separator of chunk c) x (left separator of chunk c)
-    double* sepL;       // [B][P][45][96]      factors of the separator chain, column-major (for its back substitution)
+    double* Vp;         // [G][15][32]         spikes: L^-1 (coupling of the chunk interior to its left separator)
+    double* sepR;       // [P][B][27][28]      separator block + rhs left by the forward sweep of chunk c
+    double* sepS;       // [P][B][27][28]      Schur term of chunk c on its LEFT separator (c >= 1)
+    double* sepC;       // [P][B][27][27]      coupling (right separator of chunk c) x (left separator of chunk c)
+    double* sepL;       // [B][P][27][64]      factors of the separator chain, column-major (for its back substitution)
     int* lo;            // [B] active range [lo, hi)
     int* hi;
     int* sel;           // [B] which buffer is current

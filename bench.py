@@ -79,12 +79,12 @@ def cpu_baseline(args, threads=1):
 
 def time_sharded_window(args, info, dist, backend, dev):
     """BASELINE.json configs[4]: ONE 10 000-pose window spread in time over the ranks (every rank owns
-    48 / world chunks of the partitioned solve; separator blocks all-gathered, increments all-reduced
+    96 / world chunks of the partitioned solve; separator blocks all-gathered, increments all-reduced
     over RCCL).  Outside the timed region of the headline metric; every rank takes part."""
     import torch
     from vil_sensor_fusion_amd import Engine, EngineOpts, synth, distributed as D
     from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
-    n, chunks, trials = args.sharded_window, 48, args.iterations
+    n, chunks, trials = args.sharded_window, 96, args.iterations
     seq = synth.make_sequence(seed=4242, n_kf=n)
     eng = Engine(EngineOpts(windows=1, capacity=n + 8, device=dev.index, chunks=chunks))
     eng.preintegrate(0, 1, seq.imu_off[1:], seq.imu_steps, np.zeros(6), synth.CARLA_IMU_COV)
@@ -110,7 +110,7 @@ def time_sharded_window(args, info, dist, backend, dev):
     out = {"window_keyframes": n, "ranks": info.world, "chunks": chunks, "chunks_per_rank": chunks // max(info.world, 1),
            "lm_trials_timed": reps * trials, "ms_per_lm_trial": per_trial * 1e3,
            "keyframe_relinearisations_per_s": n / per_trial,
-           "exchange_doubles_per_trial": chunks * 6165 + n * 15 + 2,
+           "exchange_doubles_per_trial": chunks * 2241 + n * 15 + 2,      # (27x28 + 27x28 + 27x27) per chunk, increments, cost
            "collectives_per_trial": "3 all-gather (separator blocks) + 2 all-reduce (increments, cost)",
            "backend": backend if dist is not None else "none", "final_cost": lm["cost"], "solve_failures": lm["solve_failures"]}
     eng.close()
@@ -232,7 +232,7 @@ def main():
                                       "windows_sampled": len(trials)}}
 
     sharded = None
-    if not args.no_sharded and 48 % info.world == 0:
+    if not args.no_sharded and 96 % info.world == 0:
         # every rank reports whether its side is healthy before any collective of this section is entered
         try:
             sharded = time_sharded_window(args, info, dist, backend, dev)

@@ -59,7 +59,7 @@ typedef struct {
     double gravity[3];      /* n_gravity; MakeSharedU => (0,0,-9.81) (ImuManagerRos.cpp:16) */
     double lambda0, lambda_up, lambda_down, lambda_min, lambda_max; /* LM damping schedule */
     int chunks;             /* K4 form.  0 = chosen from the batch size: up to 128 windows -> partitioned
-                               solve (chunks joined by 45-dof separators, about sqrt(0.75 n) of them for an
+                               solve (chunks joined by 27-dof separators, about sqrt(n) of them for an
                                n-keyframe window: one-window latency); more windows -> one sweep per window
                                (throughput).  1 = always sweeps.  P >= 2 = partitioned solve with P chunks. */
 } vf_engine_opts;
@@ -121,7 +121,7 @@ int vf_engine_iterate(vf_engine* e, int iterations);
  *     retract, linearize(trial), decide_partial, <all-reduce cost_part>, decide_total
  * where the bracketed collectives are the caller's (RCCL over xGMI via torch.distributed in
  * vil_sensor_fusion_amd/distributed.py; the library itself has no communication dependency).  The exchange
- * is the packed separator system: P * 6165 doubles per window per trial; the increment all-reduce is 15
+ * is the packed separator system: P * 2241 doubles per window per trial; the increment all-reduce is 15
  * doubles per keyframe. */
 typedef struct {
     int rank, world, windows, chunks;
@@ -136,7 +136,7 @@ typedef struct {
     long cost_count;
 } vf_shard_info;
 /* Geometry of the partitioned solve, host only (no device needed): an n-keyframe window is cut into `count`
- * chunks (<= chunks; fit != 0: also <= sqrt(0.75 n)); chunk c = `interior` keyframes from window-local
+ * chunks (<= chunks; fit != 0: also <= sqrt(n)); chunk c = `interior` keyframes from window-local
  * keyframe `first`, followed by 3 separator keyframes when has_separator.  vf_shard_range: the chunks
  * [chunk_lo, chunk_hi) and window-local keyframes [kf_lo, kf_hi) rank `rank` of `world` owns. */
 int vf_chunk_geometry(int n, int chunks, int fit, int c, int* count, int* first, int* interior, int* has_separator);

@@ -1,4 +1,4 @@
-"""-m gpu: the partitioned solve K4p (P chunks per window joined by 45-dof separators;
+"""-m gpu: the partitioned solve K4p (P chunks per window joined by 27-dof separators;
 vf_engine_opts.chunks) against the one-sweep band solver and the CPU oracle.
 
 Both forms are Cholesky factorisations of the same block-banded system in different elimination

@@ -1377,15 +1377,17 @@ __global__ void __launch_bounds__(128) k_band_solve_tw(View v) {
 
 // ------------------------------------------------------------------------------------ K4p
 // Partitioned solve of one window by P chunks (latency form for few windows, and the per-GPU piece of
-// the time-sharded smoother).  Keyframes:  [I_0][S_0][I_1][S_1] ... [I_{P-1}],  S_c = 3 keyframes = 45 dof.
-//   1. k_chunk_forward : wave 0 of every chunk eliminates its interior I_c with the band sweep above
-//                        (couplings to its left separator dropped); leaves R_c = H[S_c,S_c] + lambda I
-//                        - F^T A^-1 F and the rhs.
-//   2.  (same kernel)    wave 1 follows one step behind with the spike V = L_c^-1 E (E = coupling of I_c to
-//                        S_{c-1}): forward substitution through the panels (LDS ring) on the matrix cores;
+// the time-sharded smoother).  A cut keyframe b_c sits between chunks c and c+1; the separator is
+//     S_c = { b_c: 15 dof, pose of b_c + 1, pose of b_c + 2 }   (27 dof: what the profile couples across a cut),
+// chunk c+1 starts at keyframe b_c + 1, whose pose rows (and those of b_c + 2) are pinned: only their
+// velocity / bias dof are interior to it (vf_kernels.hpp, mask_boundary_row).
+//   1. k_chunk_forward : wave 0 of every chunk eliminates its pivots with the band sweep above (couplings to
+//                        its left separator dropped); leaves R_c = H[S_c,S_c] + lambda I - F^T A^-1 F and the rhs.
+//   2.  (same kernel)    wave 1 follows one step behind with the spike V = L_c^-1 E (E = coupling of the chunk's
+//                        dof to S_{c-1}): forward substitution through the panels (LDS ring) on the matrix cores;
 //                        gives -E^T A^-1 E, -E^T A^-1 g (left separator), -F^T A^-1 E (coupling
 //                        S_c x S_{c-1}) and the spike rows V for step 4.
-//   3. k_sep_solve     : block-tridiagonal system of the P-1 separators (45-dof blocks).
+//   3. k_sep_solve     : block-tridiagonal system of the P-1 separators (27-dof blocks), from both ends.
 //   4. k_chunk_rhs     : y_k -= V_k delta(S_{c-1})  in the stored panels.
 //   5. k_chunk_back    : the band back substitution of every chunk, started from delta(S_c).
 // Same arithmetic as one sweep up to the elimination order (a nested-dissection ordering of the same
@@ -1605,11 +1607,10 @@ __global__ void __launch_bounds__(256) k_chunk_rhs(View v) {
 // wave 0, 27 columns in registers:
 //     0..26  D (pivot block)      27..53  C (coupling to the next separator of this team's direction)      54  rhs
 // (team 1 walks the chain backwards, so its coupling rows are the stored blocks transposed).
-// Column operations as in the band solver: after 27 pivots the rows hold L, Z = C L^-T and y.
-// Column c of the pivot rows goes through a triple-buffered LDS column (one LDS-only barrier per pivot keeps
-// the two teams and their stagers in step); only column c+1 is updated on the critical path, the others after
-// the next barrier in the shadow of its rsqrt.  Wave 1 of a team owns no rows: it stages the inputs of the
-// team's next step (global -> registers during the pivots, one slice between two barriers, -> LDS 12 barriers later).
+// Column operations as in the band solver: after 27 pivots the rows hold L, Z = C L^-T and y; pivots and
+// multipliers are broadcast by v_readlane (the pivot rows are lanes 0..26), so a step has three LDS-only
+// barriers and none inside the pivot loop.  Wave 1 of a team owns no rows: it stages the inputs of the team's
+// next step (global -> registers -> LDS) while wave 0 factors.
 // D_next -= Z Z^T, rhs_next -= Z y: four 16x16 MFMA tiles, two per wave, operands from the Z rows in LDS.
 // The middle separator receives both teams' Schur terms and is factored by team 0.
 // Backward: wave 0 of a team solves L^T delta = y - Z^T delta(neighbour towards the middle) (increment
@@ -1619,7 +1620,7 @@ constexpr int ZS = 28;                       // LDS row stride of the D / C pane
 constexpr int LXS = 64;                      // HBM: factor of one separator, column-major [27][64]: rows 0..26 L, 27..53 Z, 54 y
 constexpr int FS = 57;                       // LDS row stride of the factor copy (odd: conflict-free row walks)
 constexpr int ZZ = 29;                       // LDS row stride of the Z rows (odd; zero padding = MFMA K and tile remainders)
-constexpr int SEP_FW = 96 + 32 * ZZ + 56 * ZS;        // forward LDS of one team: column buffers, Z rows, panel input
+constexpr int SEP_FW = 32 * ZZ + 56 * ZS;             // forward LDS of one team: Z rows, panel input
 constexpr int SEP_BW = 2 * SEP * FS;                  // backward LDS of one team: two factor copies
 constexpr int SEP_LDS = 2 * (SEP_FW > SEP_BW ? SEP_FW : SEP_BW);
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for
@@ -1646,8 +1647,7 @@ __global__ void __launch_bounds__(256) k_sep_solve(View v) {
     const int nreal = team == 0 ? h : m - 1 - h; // real forward steps of this team (the loop runs h times)
     __shared__ __attribute__((aligned(16))) double smem[SEP_LDS];
     __shared__ double dnext_s[2][32];
-    double* colbuf = smem + team * SEP_FW;       // [3][32]: column c of the pivot rows (31 = sink of the other rows)
-    double* Zs = colbuf + 96;                    // [32][ZZ]: Z rows 0..26, y = row 27; rows 28..31 and columns 27, 28 stay zero
+    double* Zs = smem + team * SEP_FW;           // [32][ZZ]: Z rows 0..26, y = row 27; rows 28..31 and columns 27, 28 stay zero
     double* Dn = Zs + 32 * ZZ;                   // [56][ZS]: panel input: D rows 0..26, C rows 27..53, rhs row 54, zero row 55
     // separator blocks are stored chunk-major, [P][B][..]: the chunks of one rank of a time-sharded window are
     // contiguous (all-gather slices); element (c, w) of this window sits c * cs (resp. c * cc) further on
@@ -1692,13 +1692,6 @@ __global__ void __launch_bounds__(256) k_sep_solve(View v) {
     }
     __syncthreads();
     const int prow = (lane < 55 ? lane : 55) * ZS;     // this lane's panel row in Dn (55 = zeros)
-    double* col_w = colbuf + (lane < 27 ? lane : 31);  // one base register + immediates (nothing per-column to hoist)
-    // LDS reads at compile-time addresses go through ONE opaque base register so that every access is
-    // base + immediate (otherwise each constant address is materialised in its own VGPR, hoisted out of
-    // the loop, and the register file is gone: the reads then serialise on a single destination register)
-    int zero_v;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
-    const double* cb = colbuf + zero_v;
 #ifdef VF_SOLVE_STAMPS
     unsigned long long sst[16] = {0}, stprev = __builtin_amdgcn_s_memtime();
 #endif
@@ -1706,8 +1699,9 @@ __global__ void __launch_bounds__(256) k_sep_solve(View v) {
     auto step = [&](int sidx, int snext, bool real, bool more) {
         SSTAMP(0);
         if (!real) {
-#pragma unroll 1
-            for (int c = 0; c < SEP + 3; c++) LDS_BARRIER();
+            LDS_BARRIER();
+            LDS_BARRIER();
+            LDS_BARRIER();
             return;
         }
         if (tw == 1) {
@@ -1718,25 +1712,21 @@ __global__ void __launch_bounds__(256) k_sep_solve(View v) {
             const double *pa, *pb;
             d_ptrs(more ? snext : -1, pa, pb);
             const double* pc = more ? c_ptr(snext) : Sx;
-            LDS_BARRIER();   // Dn consumed (the stager arrives first: nothing of its work sits in front of the pivots)
-            // one slice of the staging work (3 loads, 2 destinations) between two pivot barriers, so that the stager
-            // is never the last wave to arrive; a slice goes to LDS 12 barriers later
-            // (the panel input was consumed at the top of the step, so Dn is free; the Schur update comes after)
-            constexpr int NSL = 12, LAG = 12;                 // 12 * 64 = 768 >= 756 elements of (D | rhs)
+            LDS_BARRIER();   // Dn consumed: from here on the panel input is free until the Schur update
+            constexpr int NSL = 12;                           // 12 * 64 = 768 >= 756 elements of (D | rhs)
             double ba[NSL], bb[NSL], bc[NSL];
-            int da[NSL], dc[NSL];
 #pragma unroll
-            for (int c = 0; c < SEP; c++) {
-                if (c < NSL) {
-                    const int e = lane + 64 * c + sz, ed = e < SEP * 28 ? e : 0;
-                    ba[c] = pa[ed];
-                    bb[c] = pb[ed];
-                    da[c] = dst_d(e);
-                    bc[c] = pc[e < SEP * SEP ? e : 0];
-                    dc[c] = dst_c(e);
-                }
-                if (c >= LAG && c - LAG < NSL) { Dn[da[c - LAG]] = ba[c - LAG] + bb[c - LAG]; Dn[dc[c - LAG]] = bc[c - LAG]; }
-                LDS_BARRIER();
+            for (int q = 0; q < NSL; q++) {
+                const int e = lane + 64 * q + sz, ed = e < SEP * 28 ? e : 0;
+                ba[q] = pa[ed];
+                bb[q] = pb[ed];
+                bc[q] = pc[e < SEP * SEP ? e : 0];
+            }
+#pragma unroll
+            for (int q = 0; q < NSL; q++) {
+                const int e = lane + 64 * q + sz;
+                Dn[dst_d(e)] = ba[q] + bb[q];
+                Dn[dst_c(e)] = bc[q];
             }
         } else {
             // ---- panel rows ----
@@ -1745,27 +1735,26 @@ __global__ void __launch_bounds__(256) k_sep_solve(View v) {
             for (int c = 0; c < SEP; c++) p[c] = Dn[prow + c];
             LDS_BARRIER();   // Dn consumed
             SSTAMP(1);
-            double pc_prev = 0.0;
+            // the 27 pivot rows are lanes 0..26 of this wave: pivots and multipliers by v_readlane, no LDS round trip and no
+            // barrier inside the step; the rsqrt of the next pivot starts as soon as its column is up to date
+            double dv = readlane_d(p[0], 0);
+            if (!(dv > 0.0)) { failed = 1; dv = 1.0; }
+            double inv = fast_rsqrt(dv);
 #pragma unroll
             for (int c = 0; c < SEP; c++) {
-                col_w[(c % 3) * 32] = p[c];
-                LDS_BARRIER();
-                double pivv = cb[(c % 3) * 32 + c];
-                double mv[SEP];          // multipliers of the previous pivot: all LDS reads in flight together
-                if (c > 0) {
-#pragma unroll
-                    for (int c2 = c + 1; c2 < SEP; c2++) mv[c2] = cb[((c - 1) % 3) * 32 + c2];
-                }
-                __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler serialises read -> wait -> fma pairs)
-                if (!(pivv > 0.0)) { failed = 1; pivv = 1.0; }
-                const double inv = fast_rsqrt(pivv);
-                if (c > 0) {
-#pragma unroll
-                    for (int c2 = c + 1; c2 < SEP; c2++) p[c2] = fma(pc_prev, mv[c2], p[c2]);
-                }
                 p[c] *= inv;
-                pc_prev = -p[c] * inv;
-                if (c + 1 < SEP) p[c + 1] = fma(pc_prev, cb[(c % 3) * 32 + c + 1], p[c + 1]);
+                if (c + 1 < SEP) {
+                    const double l1 = readlane_d(p[c], c + 1);
+                    p[c + 1] = fma(-p[c], l1, p[c + 1]);
+                    dv = readlane_d(p[c + 1], c + 1);
+                    if (!(dv > 0.0)) { failed = 1; dv = 1.0; }
+                    inv = fast_rsqrt(dv);
+                }
+#pragma unroll
+                for (int c2 = c + 2; c2 < SEP; c2++) {
+                    const double l = readlane_d(p[c], c2);
+                    p[c2] = fma(-p[c], l, p[c2]);
+                }
             }
             SSTAMP(2);
             // factor rows -> HBM, column-major: one contiguous 8-byte-per-lane store per column
@@ -1814,7 +1803,7 @@ __global__ void __launch_bounds__(256) k_sep_solve(View v) {
     }
     // ---- the middle separator: team 0's panel input (its own D + left Schur terms) + team 1's Schur terms
     {
-        const double* Dother = smem + SEP_FW + 96 + 32 * ZZ;
+        const double* Dother = smem + SEP_FW + 32 * ZZ;
         if (team == 0)
             for (int e = tt; e < 55 * ZS; e += 128) Dn[e] += (e < 27 * ZS || e >= 54 * ZS) ? Dother[e] : 0.0;
         LDS_BARRIER();

@@ -43,12 +43,12 @@ __host__ __device__ inline ChunkPlan chunk_plan(int n, int P) {
     return p;
 }
 __host__ __device__ inline int chunk_len(int n, int P) { return chunk_plan(n, P).L; }
-// chunks actually used for an n-keyframe window: at most P; with `fit` also at most sqrt(0.75 n), the
+// chunks actually used for an n-keyframe window: at most P; with `fit` also at most sqrt(n), the
 // measured optimum of (chunk sweeps ~ 3.7 us * n / P) + (two-sided separator chain, see DESIGN.md "K4p")
 __host__ __device__ inline int chunk_count(int n, int P, int fit) {
     if (fit) {
         int want = 1;
-        while ((want + 1) * (want + 1) * 100 <= n * 75) want++;
+        while ((want + 1) * (want + 1) <= n) want++;
         if (P > want) P = want;
     }
     while (P > 1 && chunk_len(n, P) < 8) P--;

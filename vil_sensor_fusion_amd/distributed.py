@@ -8,7 +8,7 @@ a MAX-reduce of the elapsed time and an all-gather of per-rank summaries.
 ShardedSolver is the other multi-GPU form (BASELINE.json configs[4]): ONE window spread
 in time over the ranks.  Every rank holds the window, owns a contiguous range of the chunks of the
 partitioned solve (K4p) and the keyframes they cover, and per LM trial the ranks exchange the packed
-separator system (all-gather, 6165 doubles per chunk), the increments (all-reduce, 15 doubles per
+separator system (all-gather, 2241 doubles per chunk), the increments (all-reduce, 15 doubles per
 keyframe) and two scalars per window (all-reduce).  RCCL collectives are enqueued on the stream the
 engine's kernels run on, so a trial needs no host synchronisation.
 """

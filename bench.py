@@ -23,7 +23,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-IMU_BYTES = 5496        # 1776 B read + 3720 B written per IMU factor (unfused K1)
+# Algorithmic bytes of K1 per IMU factor: 1776 B read (190-double record + two 16-double states) + the residual and the
+# 291 entries of the whitened 15x30 Jacobian that are not structurally zero, (15 + 291) * 8 = 2448 B written.
+# SURVEY 8(d) quotes 5496 B for the dense block (465 * 8 = 3720 B written); 159 of its 450 entries are structural zeros
+# which k_linearize_imu no longer writes, so the roofline is priced on the smaller figure; the dense one is kept beside it.
+IMU_BYTES = 1776 + 8 * (15 + 450 - 159)
+IMU_BYTES_DENSE = 5496
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -268,7 +273,12 @@ def main():
                          "traffic": None if traffic is None else traffic["k1_bytes_per_imu_factor"] * counts["imu"],
                          "traffic_source": None if traffic is None else traffic["source"],
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,
-                         "frac_of_measured_copy_peak_6290": achieved / 6290.0},
+                         "algorithmic_bytes_per_imu_factor": IMU_BYTES,
+                         "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+                         "priced_on_survey_dense_figure_5496": {
+                             "achieved": counts["imu"] * IMU_BYTES_DENSE / (k1_ms * 1e-3) / 1e9,
+                             "frac": counts["imu"] * IMU_BYTES_DENSE / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "note": "counts the 159 structurally zero Jacobian entries that are no longer written"}},
             "stage_ms": stages,
             "lm_state_window0": eng.read_lm(0),
         }

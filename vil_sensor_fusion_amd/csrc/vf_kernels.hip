@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_imu(View
         for (int r = 0; r < 3; r++) { u[r] = 0; u[3 + r] = col3(Rji, r, c); u[6 + r] = 0; }
         white9<3, 6>(R, u, o);
 #pragma unroll
-        for (int a = 0; a < 9; a++) JOUT(a, 3 + c) = o[a];
+        for (int a = 0; a < 6; a++) JOUT(a, 3 + c) = o[a];       // rows 6..8: structural zeros, never written
         // V_i : rows p = dt R_j^T, rows v = R_j^T
 #pragma unroll
         for (int r = 0; r < 3; r++) { u[r] = 0; u[3 + r] = dt * Rj.a[c * 3 + r]; u[6 + r] = Rj.a[c * 3 + r]; }
@@ -355,7 +355,8 @@ __global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_imu(View
         for (int a = 0; a < 9; a++) JOUT(a, 9 + c) = o[a];
         // X_j.p : rows p = -I  => -R11(:, 3+c)
 #pragma unroll
-        for (int a = 0; a < 9; a++) JOUT(a, 12 + c) = (a <= 3 + c) ? -R[idx9(a < 3 + c ? a : 3 + c, 3 + c)] : 0.0;
+        for (int a = 0; a < 9; a++)
+            if (a <= 3 + c) JOUT(a, 12 + c) = -R[idx9(a < 3 + c ? a : 3 + c, 3 + c)];   // rows below: structural zeros
         // V_j : rows v = -R_j^T
 #pragma unroll
         for (int r = 0; r < 3; r++) { u[r] = 0; u[3 + r] = 0; u[6 + r] = -Rj.a[c * 3 + r]; }
@@ -363,10 +364,10 @@ __global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_imu(View
 #pragma unroll
         for (int a = 0; a < 9; a++) JOUT(a, 15 + c) = o[a];
     }
-#pragma unroll
-    for (int c = 0; c < 18; c++)
-#pragma unroll
-        for (int a = 9; a < 15; a++) JOUT(a, c) = 0.0;
+    // Structural zeros of the whitened Jacobian are NOT written: rows 9..14 of the columns 0..17, rows 6..8 of X_i.p,
+    // the rows below the diagonal of X_j.p and rows >= 10 + c of the bias columns -- 159 of the 450 entries.  The
+    // output buffers are zero-filled when the engine is created and nothing else writes those words, so readers
+    // (K3, the read-backs) see zeros; a third of the J write traffic is gone.
 
     // bias columns: B_i (18..23) and B_j (24..29)
 #pragma unroll
@@ -385,8 +386,10 @@ __global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_imu(View
 #pragma unroll
         for (int a = 0; a < 15; a++) {
             const double bi = (a < 9) ? o[a] + Rc[a] : Rc[a];
-            JOUT(a, 18 + c) = bi;
-            JOUT(a, 24 + c) = -Rc[a];
+            if (a < n_rc) {                       // rows >= 10 + c: structural zeros
+                JOUT(a, 18 + c) = bi;
+                JOUT(a, 24 + c) = -Rc[a];
+            }
             rw[a] = fma(Rc[a], rb, rw[a]);
         }
     }
@@ -570,6 +573,14 @@ __global__ void k_linearize_prior(View v, int which) {
 __host__ __device__ constexpr int imu_col(int side_j, int c) {
     return c < 9 ? c + (side_j ? 9 : 0) : c + 9 + (side_j ? 6 : 0);
 }
+// structural zeros of the whitened 15x30 IMU Jacobian (k_linearize_imu never writes them, the buffers are zero-filled
+// at creation): field f = 15 + 30 r + c of a factor's (r | J) record
+__host__ __device__ constexpr bool imu_field_is_zero(int f) {
+    if (f < 15 || f >= IMU_OUT) return false;
+    const int r = (f - 15) / 30, c = (f - 15) % 30;
+    if (c < 18) return r >= 9 || (c >= 3 && c < 6 && r >= 6) || (c >= 12 && c < 15 && r > 3 + (c - 12));
+    return r >= 10 + (c - 18) % 6;
+}
 constexpr int AT = 16;          // keyframes per block
 constexpr int LJS = 465;        // LDS stride of one factor's (r | J), odd
 constexpr int LBS = 79;         // LDS stride of one between linearisation (78 + pad), odd
@@ -610,7 +621,7 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
 #pragma unroll
         for (int it = 0; it < 30; it++) {
             const int f = it * 16 + fg;
-            tj[it] = (ok && f < IMU_OUT) ? src[(size_t)f * TILE] : 0.0;
+            tj[it] = (ok && f < IMU_OUT && !imu_field_is_zero(f)) ? src[(size_t)f * TILE] : 0.0;   // a third of J is structurally zero
         }
         // factor k0+16 (its i-side feeds H[k0+15][k0+15]); it may live in the next AoSoA tile
         const int k16 = k0 + AT;
@@ -621,7 +632,7 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int f = tid + 256 * j;
-            t16[j] = (ok16 && f < IMU_OUT) ? src16[(size_t)f * TILE] : 0.0;
+            t16[j] = (ok16 && f < IMU_OUT && !imu_field_is_zero(f)) ? src16[(size_t)f * TILE] : 0.0;
         }
         // between linearisations of slots k0 .. k0+18
         double tb[6];

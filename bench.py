@@ -90,16 +90,26 @@ def time_sharded_window(args, info, dist, backend, dev):
     from vil_sensor_fusion_amd import Engine, EngineOpts, synth, distributed as D
     from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
     n, chunks, trials = args.sharded_window, 96, args.iterations
-    seq = synth.make_sequence(seed=4242, n_kf=n)
-    eng = Engine(EngineOpts(windows=1, capacity=n + 8, device=dev.index, chunks=chunks))
-    eng.preintegrate(0, 1, seq.imu_off[1:], seq.imu_steps, np.zeros(6), synth.CARLA_IMU_COV)
-    eng.set_between(0, seq.btw_a, seq.btw_b, synth.between_records(seq))
-    eng.set_states(0, 0, seq.gt_states[:1])
-    eng.set_prior(0, 0, synth.prior_record(seq.gt_states[0], REFERENCE_PRIOR_SIGMAS))
-    eng.set_range(0, 0, 1)
-    eng.predict(0, 1, n - 1)
-    eng.set_range(0, 0, n)
-    eng.sync()
+    eng, problem = None, None
+    try:       # set-up has no collective in it: a rank that fails here must not leave the others waiting in one
+        seq = synth.make_sequence(seed=4242, n_kf=n)
+        eng = Engine(EngineOpts(windows=1, capacity=n + 8, device=dev.index, chunks=chunks))
+        eng.preintegrate(0, 1, seq.imu_off[1:], seq.imu_steps, np.zeros(6), synth.CARLA_IMU_COV)
+        eng.set_between(0, seq.btw_a, seq.btw_b, synth.between_records(seq))
+        eng.set_states(0, 0, seq.gt_states[:1])
+        eng.set_prior(0, 0, synth.prior_record(seq.gt_states[0], REFERENCE_PRIOR_SIGMAS))
+        eng.set_range(0, 0, 1)
+        eng.predict(0, 1, n - 1)
+        eng.set_range(0, 0, n)
+        eng.sync()
+    except Exception as exc:   # noqa: BLE001
+        problem = f"{type(exc).__name__}: {exc}"
+    healthy = D.max_over_ranks(dist, 0.0 if problem is None else 1.0,
+                               device=dev if (dist is not None and backend == "nccl") else "cpu") == 0.0
+    if not healthy:
+        if eng is not None:
+            eng.close()
+        return {"error": problem or "set-up failed on another rank"}
     solver = D.ShardedSolver(eng, dist, dev, backend=backend)
     solver.iterate(trials)                       # converge + warm up (not timed)
     torch.cuda.synchronize(dev)

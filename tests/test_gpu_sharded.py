@@ -113,6 +113,17 @@ def test_shard_errors():
     eng = Engine(EngineOpts(windows=1, capacity=64, chunks=1))
     with pytest.raises(VilFusionError):
         eng.set_shard(0, 2)                      # sweeps cannot be sharded
+    with pytest.raises(VilFusionError):
+        eng.shard_info()                         # no separator buffers without the partitioned solve
+    with pytest.raises(VilFusionError):
+        eng.solve_local()
+    with pytest.raises(VilFusionError):
+        eng.set_convergence(-1.0, 0.0)
+    eng.set_shard(0, 1)                          # a world of one is always fine
+    eng.close()
+    eng = Engine(EngineOpts(windows=1, capacity=64))            # chunks chosen by the engine: not shardable either
+    with pytest.raises(VilFusionError):
+        eng.set_shard(0, 2)
     eng.close()
     eng = Engine(EngineOpts(windows=1, capacity=64, chunks=6))
     with pytest.raises(VilFusionError):

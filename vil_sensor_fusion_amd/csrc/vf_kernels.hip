@@ -1220,7 +1220,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     // ---- back substitution: delta_k = L_kk^-T (y_k - sum_p L[p][k-cols]^T delta(p)) -----------
     // Panel rows in HBM: 0..26 sub-diagonal rows (p = 15..41), 27 = y, 28..42 = L_kk^-T.
     // Lane r < 43 holds row r in registers; rows 0..27 go through LDS for the column sums,
-    // L^-T stays in the registers of lanes 28..42.  Panels are prefetched two steps ahead.
+    // L^-T stays in the registers of lanes 28..42.  Panels are prefetched three steps ahead.
     S[S_DL + lane] = 0.0;
     if constexpr (MODE == SOLVE_CHUNK_BWD) {
         WSYNC();
@@ -1296,7 +1296,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     const int col = lane < 15 ? lane : 0;
     const int dl_w = (lane >= 28 && lane < 43) ? S_DL + lane - 28 : S_DUMP + 32 + lane;
     WSYNC();
-    auto back = [&](auto ph, int k, PRow& cur_p, PRow& nxt_p) {
+    auto back = [&](auto ph, int k, PRow& cur_p, PRow& nxt_p, PRow& nxt2_p) {
         constexpr int PH = decltype(ph)::value;
         constexpr int b1 = S_DL + ((PH + 1) & 3) * 15, b2 = S_DL + ((PH + 2) & 3) * 15, b3 = S_DL + ((PH + 3) & 3) * 15;
         STAMP(6);
@@ -1306,7 +1306,8 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         for (int c = 0; c < 7; c++) { row[2 * c] = keep * cur_p.x[c].x; row[2 * c + 1] = keep * cur_p.x[c].y; }
         row[14] = keep * cur_p.x[7].x;
         cur_p = nxt_p;
-        nxt_p = load_panel(k - 2);   // two steps ahead
+        nxt_p = nxt2_p;
+        nxt2_p = load_panel(k - 3);  // three steps ahead (two were not enough under a full batch: +450 cycles / step waiting)
 #pragma unroll
         for (int c = 0; c < 15; c++) S[bw_off + c] = row[c];
         WSYNC();
@@ -1348,13 +1349,13 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         STAMP(10);
     };
     {
-        PRow cur_p = load_panel(n4 - 1), nxt_p = load_panel(n4 - 2);
+        PRow cur_p = load_panel(n4 - 1), nxt_p = load_panel(n4 - 2), nxt2_p = load_panel(n4 - 3);
 #pragma unroll 1
         for (int k = n4 - 1; k >= 3; k -= 4) {
-            back(IC<3>{}, k, cur_p, nxt_p);
-            back(IC<2>{}, k - 1, cur_p, nxt_p);
-            back(IC<1>{}, k - 2, cur_p, nxt_p);
-            back(IC<0>{}, k - 3, cur_p, nxt_p);
+            back(IC<3>{}, k, cur_p, nxt_p, nxt2_p);
+            back(IC<2>{}, k - 1, cur_p, nxt_p, nxt2_p);
+            back(IC<1>{}, k - 2, cur_p, nxt_p, nxt2_p);
+            back(IC<0>{}, k - 3, cur_p, nxt_p, nxt2_p);
         }
     }
 #ifdef VF_SOLVE_STAMPS

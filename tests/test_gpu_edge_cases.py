@@ -155,15 +155,16 @@ def _oracle_window(oracle, prob, states, lo, hi, marg, with_prior):
     return w
 
 
-def test_marginal_prior_and_fixed_lag_slides_match_oracle(oracle):
+@pytest.mark.parametrize("N,S,chunks", [(40, 5, 0), (160, 25, 0), (160, 25, 1)])
+def test_marginal_prior_and_fixed_lag_slides_match_oracle(oracle, N, S, chunks):
     """bench.py's update path: marginalise the oldest keyframe (Schur complement into a dense
-    prior), slide, K LM trials -- five times -- against the oracle doing the same; the marginal
-    prior itself (27x27 information, gradient, linearisation states) is compared after every slide."""
+    prior), slide, K LM trials -- S times -- against the oracle doing the same; the marginal
+    prior itself (27x27 information, gradient, linearisation states) is compared after every slide.
+    chunks = 0: the partitioned solve (the marginal prior sits in the first chunk), 1: whole-window sweeps."""
     from vil_sensor_fusion_amd import Engine, EngineOpts
-    N, S = 40, 5
     seq = synth.make_sequence(43, N + S)
     prob = helpers.build_problem(oracle, seq)
-    eng = Engine(EngineOpts(windows=2, capacity=64))     # second window: ragged companion
+    eng = Engine(EngineOpts(windows=2, capacity=N + S + 4, chunks=chunks))     # second window: ragged companion
     helpers.load_engine(eng, 0, prob, lo=0, hi=N)
     helpers.load_engine(eng, 1, prob, lo=0, hi=N - 7)
     eng.iterate(4)
@@ -181,8 +182,11 @@ def test_marginal_prior_and_fixed_lag_slides_match_oracle(oracle):
         assert got["on"] == 1
         scale = np.abs(exp["L"]).max()
         np.testing.assert_allclose(got["L"], exp["L"], atol=1e-9 * scale)
-        np.testing.assert_allclose(got["eta"], exp["eta"], atol=1e-9 * max(np.abs(exp["eta"]).max(), 1e-6 * scale))
-        np.testing.assert_allclose(got["xbar"], exp["xbar"], atol=1e-12)
+        if s <= 5:
+            # eta = information x (state differences): once the two LM trajectories have drifted apart by 1e-10 m
+            # (later slides of the long runs) it can only be compared through the trajectories themselves
+            np.testing.assert_allclose(got["eta"], exp["eta"], atol=1e-9 * max(np.abs(exp["eta"]).max(), 1e-6 * scale))
+        np.testing.assert_allclose(got["xbar"], exp["xbar"], atol=1e-12 if s <= 5 else 1e-8)
         eng.iterate(4)
         marg.k0 = 0
         states[N + s - 1] = oracle.predict(prob["imu"][N + s - 1], prob["gravity"], states[N + s - 2])

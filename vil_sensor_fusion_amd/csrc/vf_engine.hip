@@ -71,6 +71,19 @@ struct vf_engine {
         *p = (T*)q;
         return VF_OK;
     }
+    // grow-only scratch of vf_engine_preintegrate (the GraphManager calls it once per solve: no hipMalloc / hipFree there)
+    void* pre_buf = nullptr;
+    size_t pre_bytes = 0;
+    int ensure_pre(size_t bytes) {
+        if (bytes <= pre_bytes) return VF_OK;
+        if (pre_buf) HIPCHK(hipFree(pre_buf));
+        pre_buf = nullptr;
+        pre_bytes = 0;
+        const size_t want = bytes < (1u << 16) ? (1u << 16) : bytes * 2;
+        HIPCHK(hipMalloc(&pre_buf, want));
+        pre_bytes = want;
+        return VF_OK;
+    }
     int ensure_stage(size_t bytes) {
         if (bytes <= stage_bytes) return VF_OK;
         if (stage) HIPCHK(hipFree(stage));
@@ -215,6 +228,7 @@ void vf_engine_destroy(vf_engine* e) {
     e->drop_graph();
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->stage) (void)hipFree(e->stage);
+    if (e->pre_buf) (void)hipFree(e->pre_buf);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream && e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -352,11 +366,14 @@ int vf_engine_preintegrate(vf_engine* e, int window, int k0, int n, const int32_
     if (off[0] < 0 || total < off[0] || (total > 0 && !steps)) return fail(VF_ERR_INVALID, "bad step offsets");
     for (int i = 0; i < n; i++)
         if (off[i + 1] <= off[i]) return fail(VF_ERR_INDETERMINATE, "imu factor for keyframe %d has no IMU steps", k0 + i);
-    int* d_off = nullptr; double* d_steps = nullptr; double* d_bhat = nullptr; int* d_status = nullptr;
-    HIPCHK(hipMalloc((void**)&d_off, (n + 1) * sizeof(int)));
-    HIPCHK(hipMalloc((void**)&d_steps, (size_t)(total > 0 ? total : 1) * 7 * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&d_bhat, (size_t)n * 6 * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&d_status, sizeof(int)));
+    // one scratch block: [steps 7 x total][bias 6 x n][offsets n + 1][status]
+    const size_t steps_b = (size_t)(total > 0 ? total : 1) * 7 * sizeof(double), bias_b = (size_t)n * 6 * sizeof(double);
+    const size_t off_b = ((size_t)(n + 1) * sizeof(int) + 7) & ~(size_t)7;
+    if ((rc = e->ensure_pre(steps_b + bias_b + off_b + 8))) return rc;
+    double* d_steps = (double*)e->pre_buf;
+    double* d_bhat = (double*)((char*)e->pre_buf + steps_b);
+    int* d_off = (int*)((char*)e->pre_buf + steps_b + bias_b);
+    int* d_status = (int*)((char*)e->pre_buf + steps_b + bias_b + off_b);
     HIPCHK(hipMemcpyAsync(d_off, off, (n + 1) * sizeof(int), hipMemcpyHostToDevice, e->stream));
     if (total > 0) HIPCHK(hipMemcpyAsync(d_steps, steps, (size_t)total * 7 * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d_bhat, bhat, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, e->stream));
@@ -367,7 +384,6 @@ int vf_engine_preintegrate(vf_engine* e, int window, int k0, int n, const int32_
     int status = 0;
     HIPCHK(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    (void)hipFree(d_off); (void)hipFree(d_steps); (void)hipFree(d_bhat); (void)hipFree(d_status);
     if (status) return fail(VF_ERR_NOT_SPD, "preintegrated covariance not positive definite");
     return VF_OK;
 }

@@ -11,6 +11,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -268,6 +271,10 @@ int vf_graph_staged(vf_graph* g, int* staged, int* queued) {
 
 int vf_solve(vf_graph* g) {
     if (!g) return gerr(VF_ERR_INVALID, "null argument");
+    static const bool timing = getenv("VF_SOLVE_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_a = now();
+    auto lap = [&](const char* what) { if (timing) { auto t_b = now(); fprintf(stderr, "[vf_solve] %-12s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t_b - t_a).count()); t_a = t_b; } };
     // ---- under _graphMutex: emptyImuQueue + snapshot of the staged factors (GraphManager.cpp:104-114)
     std::deque<PendingImu> imus;
     std::vector<PendingBetween> betweens;
@@ -305,7 +312,9 @@ int vf_solve(vf_graph* g) {
             memcpy(&bias[(size_t)i * 6], imus[i].bias, sizeof(double) * 6);
         }
         if ((rc = vf_engine_preintegrate(g->eng, 0, (int)k0, n, off.data(), steps.data(), bias.data(), &g->imu))) return rc;
+        lap("preintegrate");
         if ((rc = vf_engine_predict(g->eng, 0, (int)k0, n))) return rc;
+        lap("predict");
     }
     if (!betweens.empty()) {
         std::vector<int32_t> a(betweens.size()), b(betweens.size());
@@ -321,6 +330,7 @@ int vf_solve(vf_graph* g) {
             memcpy(&rec[i * VF_BTW_RECORD], betweens[order[i]].rec, sizeof(double) * VF_BTW_RECORD);
         }
         if ((rc = vf_engine_set_between(g->eng, 0, (int)a.size(), a.data(), b.data(), rec.data()))) return rc;
+        lap("set_between");
     }
     // fixed-lag window: marginalise the keyframes that fall out of the lag, one at a time, at the
     // linearisation of the previous solve (their factors have not changed since)
@@ -332,11 +342,16 @@ int vf_solve(vf_graph* g) {
         lo++;
     }
     g->lo = lo;
+    lap("marginalize");
     if ((rc = vf_engine_set_range(g->eng, 0, lo, last_slot + 1))) return rc;
+    lap("set_range");
     if ((rc = vf_engine_iterate(g->eng, g->opts.iterations))) return rc;   // ISAM2::update + calculateEstimate
+    lap("iterate(launch)");
     int fails = 0;
     if ((rc = vf_engine_read_lm(g->eng, 0, nullptr, nullptr, nullptr, nullptr, &fails))) return rc;
+    lap("read_lm(sync)");
     if ((rc = vf_engine_get_states(g->eng, 0, last_slot, 1, g->state))) return rc;  // :131-133
+    lap("get_states");
     g->solved_key = last_key;
     for (auto& cb : g->callbacks)  // :135-138, on the solving thread, inside _stateMutex
         cb.first(cb.second, last_time, g->state, g->state + 4, g->state + 7, g->state + 10);

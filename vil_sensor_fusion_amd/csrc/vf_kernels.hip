@@ -107,23 +107,32 @@ VF_DI void white9(const double (&R)[45], const double (&u)[9], double (&o)[9]) {
 }
 
 // ------------------------------------------------------------------------------------ K0
-// IMU preintegration, one lane per factor: PreintegratedCombinedMeasurements::integrateMeasurement
-// over the factor's steps (mean, bias Jacobians, 15x15 covariance; GTSAM 4.0.x tangent form),
-// then the noise model R = chol_upper(cov^-1) of the CombinedImuFactor built at
-// gtsam_fusion/src/gtsam_fusion/IMUManager.cpp:68-73.  Runs once per factor (not per LM
-// iteration); the 15x15 work uses per-lane local arrays.
-__global__ void __launch_bounds__(64) k_preintegrate(View v, long g0, int n, const int* __restrict__ off,
-                                                    const double* __restrict__ steps,
-                                                    const double* __restrict__ bhat6, ImuCov prm, int* status) {
-    const int f = blockIdx.x * 64 + threadIdx.x;
+// IMU preintegration, one 256-thread workgroup per factor: PreintegratedCombinedMeasurements::
+// integrateMeasurement over the factor's steps (mean, bias Jacobians, 15x15 covariance; GTSAM 4.0.x tangent
+// form), then the noise model R = chol_upper(cov^-1) of the CombinedImuFactor built at
+// gtsam_fusion/src/gtsam_fusion/IMUManager.cpp:68-73.  Runs once per factor (not per LM iteration).
+// F, P and F P live in LDS, thread (i, j) owns entry (i, j) of the 15x15 products; the small 3x3 quantities of a
+// step are computed by every thread.  (The first version ran one LANE per factor with the 15x15 work in per-lane
+// scratch arrays: 2-4 ms whatever the batch, i.e. most of a GraphManager::solve, which preintegrates one factor.)
+// Every entry is accumulated in the same order as a plain triple loop would, so the result does not depend on
+// the mapping.
+__global__ void __launch_bounds__(256) k_preintegrate(View v, long g0, int n, const int* __restrict__ off,
+                                                     const double* __restrict__ steps,
+                                                     const double* __restrict__ bhat6, ImuCov prm, int* status) {
+    const int f = blockIdx.x, tid = threadIdx.x;
     if (f >= n) return;
+    __shared__ double sF[225], sP[225], sT[225], sH[54], sHn[54];
+    __shared__ int s_ok;
+    const int i = tid / 15, j = tid - i * 15;          // entry of the 15x15 matrices (tid < 225)
+    const int hi_ = tid / 6, hj = tid - hi_ * 6;       // entry of the 9x6 bias Jacobian (tid < 54)
     const double* bh = bhat6 + (size_t)f * 6;
     const V3 bacc = v3(bh[0], bh[1], bh[2]), bgyr = v3(bh[3], bh[4], bh[5]);
     V3 th = v3(0, 0, 0), pos = v3(0, 0, 0), vel = v3(0, 0, 0);
     double dtij = 0.0;
-    double Hb[54], P[225], F[225], T[225];
-    for (int i = 0; i < 54; i++) Hb[i] = 0.0;
-    for (int i = 0; i < 225; i++) P[i] = 0.0;
+    if (tid < 225) sP[tid] = 0.0;
+    if (tid < 54) sH[tid] = 0.0;
+    if (tid == 0) s_ok = 1;
+    __syncthreads();
     for (int s = off[f]; s < off[f + 1]; s++) {
         const double* st = steps + (size_t)s * 7;
         const double dt = st[0], dt22 = 0.5 * dt * dt;
@@ -135,102 +144,105 @@ __global__ void __launch_bounds__(64) k_preintegrate(View v, long g0, int n, con
         const M3 wH = mul(invD, so3_jr_apply_dtheta(th, wt));   // -w_tangent_H_theta
         const M3 aH = mul(mulSkew(R, neg(acc)), Jr);            // a_nav_H_theta
         // F = [[A, Fb], [0, I]]
-        for (int i = 0; i < 225; i++) F[i] = 0.0;
-        for (int i = 0; i < 15; i++) F[i * 15 + i] = 1.0;
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) {
-                F[i * 15 + j] -= wH.a[i * 3 + j] * dt;
-                F[(3 + i) * 15 + j] = aH.a[i * 3 + j] * dt22;
-                F[(6 + i) * 15 + j] = aH.a[i * 3 + j] * dt;
-                F[i * 15 + 12 + j] = -invD.a[i * 3 + j] * dt;   // theta_H_biasOmega = -C.top
-                F[(6 + i) * 15 + 9 + j] = -R.a[i * 3 + j] * dt; // vel_H_biasAcc = -B.bottom
-            }
-        for (int i = 0; i < 3; i++) F[(3 + i) * 15 + 6 + i] = dt;
+        if (tid < 225) {
+            double x = i == j ? 1.0 : 0.0;
+            if (i < 3 && j < 3) x -= wH.a[i * 3 + j] * dt;
+            if (i >= 3 && i < 6 && j < 3) x = aH.a[(i - 3) * 3 + j] * dt22;
+            if (i >= 6 && i < 9 && j < 3) x = aH.a[(i - 6) * 3 + j] * dt;
+            if (i < 3 && j >= 12) x = -invD.a[i * 3 + j - 12] * dt;                 // theta_H_biasOmega = -C.top
+            if (i >= 6 && i < 9 && j >= 9 && j < 12) x = -R.a[(i - 6) * 3 + j - 9] * dt;   // vel_H_biasAcc = -B.bottom
+            if (i >= 3 && i < 6 && j == i + 3) x = dt;
+            sF[tid] = x;
+        }
+        __syncthreads();
         // bias Jacobians: H <- A H - [B | C]
-        {
-            double Hn[54];
-            for (int i = 0; i < 9; i++)
-                for (int j = 0; j < 6; j++) {
-                    double a = 0.0;
-                    for (int l = 0; l < 9; l++) a = fma(F[i * 15 + l], Hb[l * 6 + j], a);
-                    Hn[i * 6 + j] = a;
-                }
-            for (int i = 0; i < 3; i++)
-                for (int j = 0; j < 3; j++) {
-                    Hn[(3 + i) * 6 + j] -= R.a[i * 3 + j] * dt22;
-                    Hn[(6 + i) * 6 + j] -= R.a[i * 3 + j] * dt;
-                    Hn[i * 6 + 3 + j] -= invD.a[i * 3 + j] * dt;
-                }
-            for (int i = 0; i < 54; i++) Hb[i] = Hn[i];
+        if (tid < 54) {
+            double a = 0.0;
+            for (int l = 0; l < 9; l++) a = fma(sF[hi_ * 15 + l], sH[l * 6 + hj], a);
+            if (hi_ >= 3 && hi_ < 6 && hj < 3) a -= R.a[(hi_ - 3) * 3 + hj] * dt22;
+            if (hi_ >= 6 && hj < 3) a -= R.a[(hi_ - 6) * 3 + hj] * dt;
+            if (hi_ < 3 && hj >= 3) a -= invD.a[hi_ * 3 + hj - 3] * dt;
+            sHn[tid] = a;
+        }
+        // covariance: P <- F P F^T + G Q G^T
+        if (tid < 225) {
+            double a = 0.0;
+            for (int l = 0; l < 15; l++) a = fma(sF[i * 15 + l], sP[l * 15 + j], a);
+            sT[tid] = a;
+        }
+        __syncthreads();
+        if (tid < 54) sH[tid] = sHn[tid];
+        if (tid < 225) {
+            double a = 0.0;
+            for (int l = 0; l < 15; l++) a = fma(sT[i * 15 + l], sF[j * 15 + l], a);
+            const double sv = (prm.acc + prm.bias_int) * dt, sr = (prm.gyro + prm.bias_int) * dt;
+            if (i >= 6 && i < 9 && j >= 6 && j < 9) {           // (1/dt) vHb (aCov+int) vHb^T
+                const M3 RRt = mulBT(R, R);
+                a += sv * RRt.a[(i - 6) * 3 + j - 6];
+            }
+            if (i < 3 && j < 3) {                               // (1/dt) tHb (wCov+int) tHb^T
+                const M3 DDt = mulBT(invD, invD);
+                a += sr * DDt.a[i * 3 + j];
+            }
+            if (i == j && i >= 3 && i < 6) a += dt * prm.integration;
+            if (i == j && i >= 9 && i < 12) a += dt * prm.bias_acc;
+            if (i == j && i >= 12) a += dt * prm.bias_omega;
+            sP[tid] = a;
         }
         // mean
         th = th + dt * wt;
         pos = pos + dt * vel + dt22 * anav;
         vel = vel + dt * anav;
         dtij += dt;
-        // covariance: P <- F P F^T + G Q G^T
-        for (int i = 0; i < 15; i++)
-            for (int j = 0; j < 15; j++) {
-                double a = 0.0;
-                for (int l = 0; l < 15; l++) a = fma(F[i * 15 + l], P[l * 15 + j], a);
-                T[i * 15 + j] = a;
-            }
-        for (int i = 0; i < 15; i++)
-            for (int j = 0; j < 15; j++) {
-                double a = 0.0;
-                for (int l = 0; l < 15; l++) a = fma(T[i * 15 + l], F[j * 15 + l], a);
-                P[i * 15 + j] = a;
-            }
-        const double sv = (prm.acc + prm.bias_int) * dt, sr = (prm.gyro + prm.bias_int) * dt;
-        const M3 RRt = mulBT(R, R), DDt = mulBT(invD, invD);
-        for (int i = 0; i < 3; i++) {
-            for (int j = 0; j < 3; j++) {
-                P[(6 + i) * 15 + 6 + j] += sv * RRt.a[i * 3 + j];   // (1/dt) vHb (aCov+int) vHb^T
-                P[i * 15 + j] += sr * DDt.a[i * 3 + j];             // (1/dt) tHb (wCov+int) tHb^T
-            }
-            P[(3 + i) * 15 + 3 + i] += dt * prm.integration;
-            P[(9 + i) * 15 + 9 + i] += dt * prm.bias_acc;
-            P[(12 + i) * 15 + 12 + i] += dt * prm.bias_omega;
-        }
+        __syncthreads();
     }
-    // R upper with R^T R = P^-1: reverse Cholesky P = U U^T (U upper), R = U^-1
-    bool ok = true;
-    for (int i = 0; i < 225; i++) F[i] = 0.0;   // F <- U
-    for (int j = 14; j >= 0; j--) {
-        double d = P[j * 15 + j];
-        for (int l = j + 1; l < 15; l++) d = fma(-F[j * 15 + l], F[j * 15 + l], d);
-        if (!(d > 0.0)) { ok = false; d = 1.0; }
-        const double ujj = sqrt(d);
-        F[j * 15 + j] = ujj;
-        for (int i = 0; i < j; i++) {
-            double a = 0.5 * (P[i * 15 + j] + P[j * 15 + i]);
-            for (int l = j + 1; l < 15; l++) a = fma(-F[i * 15 + l], F[j * 15 + l], a);
-            F[i * 15 + j] = a / ujj;
+    // R upper with R^T R = P^-1: reverse Cholesky P = U U^T (U upper, in sF), R = U^-1 (in sT)
+    if (tid < 225) { sF[tid] = 0.0; sT[tid] = 0.0; }
+    __syncthreads();
+    for (int c = 14; c >= 0; c--) {
+        if (tid == 0) {
+            double d = sP[c * 15 + c];
+            for (int l = c + 1; l < 15; l++) d = fma(-sF[c * 15 + l], sF[c * 15 + l], d);
+            if (!(d > 0.0)) { s_ok = 0; d = 1.0; }
+            sF[c * 15 + c] = sqrt(d);
         }
+        __syncthreads();
+        if (tid < c) {                                          // row tid of column c
+            const double ujj = sF[c * 15 + c];
+            double a = 0.5 * (sP[tid * 15 + c] + sP[c * 15 + tid]);
+            for (int l = c + 1; l < 15; l++) a = fma(-sF[tid * 15 + l], sF[c * 15 + l], a);
+            sF[tid * 15 + c] = a / ujj;
+        }
+        __syncthreads();
     }
-    for (int i = 0; i < 225; i++) T[i] = 0.0;   // T <- U^-1 (upper)
-    for (int c = 0; c < 15; c++) {
-        T[c * 15 + c] = 1.0 / F[c * 15 + c];
+    if (tid < 15) {                                             // column tid of U^-1, bottom up
+        const int c = tid;
+        sT[c * 15 + c] = 1.0 / sF[c * 15 + c];
         for (int r = c - 1; r >= 0; r--) {
             double a = 0.0;
-            for (int l = r + 1; l <= c; l++) a = fma(F[r * 15 + l], T[l * 15 + c], a);
-            T[r * 15 + c] = -a / F[r * 15 + r];
+            for (int l = r + 1; l <= c; l++) a = fma(sF[r * 15 + l], sT[l * 15 + c], a);
+            sT[r * 15 + c] = -a / sF[r * 15 + r];
         }
     }
+    __syncthreads();
     const long gk = g0 + f;
     double* out = v.imu_in + (size_t)(gk >> 6) * IMU_IN * TILE + (gk & 63);
-#define OUTF(i) out[(size_t)(i) * TILE]
-    OUTF(0) = dtij;
-    OUTF(1) = th.x; OUTF(2) = th.y; OUTF(3) = th.z;
-    OUTF(4) = pos.x; OUTF(5) = pos.y; OUTF(6) = pos.z;
-    OUTF(7) = vel.x; OUTF(8) = vel.y; OUTF(9) = vel.z;
-    for (int i = 0; i < 6; i++) OUTF(10 + i) = bh[i];
-    for (int i = 0; i < 54; i++) OUTF(16 + i) = Hb[i];
-    int o = 70;
-    for (int r = 0; r < 15; r++)
-        for (int c = r; c < 15; c++) OUTF(o++) = T[r * 15 + c];
-#undef OUTF
-    if (!ok || off[f + 1] == off[f]) atomicOr(status, 1);
+    if (tid < IMU_IN) {
+        double x;
+        if (tid == 0) x = dtij;
+        else if (tid < 4) x = tid == 1 ? th.x : (tid == 2 ? th.y : th.z);
+        else if (tid < 7) x = tid == 4 ? pos.x : (tid == 5 ? pos.y : pos.z);
+        else if (tid < 10) x = tid == 7 ? vel.x : (tid == 8 ? vel.y : vel.z);
+        else if (tid < 16) x = bh[tid - 10];
+        else if (tid < 70) x = sH[tid - 16];
+        else {                                                  // packed upper triangle, row-major
+            int o = tid - 70, r = 0;
+            while (o >= 15 - r) { o -= 15 - r; r++; }
+            x = sT[r * 15 + r + o];
+        }
+        out[(size_t)tid * TILE] = x;
+    }
+    if (tid == 0 && (!s_ok || off[f + 1] == off[f])) atomicOr(status, 1);
 }
 
 // ------------------------------------------------------------------------------------ K1
@@ -2230,7 +2242,7 @@ static inline unsigned nblk(long n, int bs) { return (unsigned)((n + bs - 1) / b
 
 void launch_preintegrate(const View& v, long g0, int n, const int* off, const double* steps, const double* bhat6,
                          const ImuCov& prm, int* status, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_preintegrate, dim3(nblk(n, 64)), dim3(64), 0, s, v, g0, n, off, steps, bhat6, prm, status);
+    if (n > 0) hipLaunchKernelGGL(k_preintegrate, dim3(n), dim3(256), 0, s, v, g0, n, off, steps, bhat6, prm, status);
 }
 void launch_linearize_imu(const View& v, int which, hipStream_t s) {
     hipLaunchKernelGGL(k_linearize_imu, dim3(nblk(v.G, VF_K1_BLOCK)), dim3(VF_K1_BLOCK), 0, s, v, which);

@@ -2067,9 +2067,9 @@ __global__ void k_predict(View v, int window, int k0, int n) {
 // Fixed-lag marginalisation of the oldest keyframe m = lo: the Schur complement of
 // every factor touching m -- its prior or marginal prior, the IMU factor m -> m+1, the between
 // factors starting at m -- taken at the current linearisation (buffer `sel`), onto
-// [m+1: 15][m+2: pose 6][m+3: pose 6].  One wave per window, 42x42 system in LDS, Gaussian
+// [m+1: 15][m+2: pose 6][m+3: pose 6].  One 256-thread workgroup per window, 42x42 system in LDS, Gaussian
 // elimination of the 15 leading columns (no square roots).  Runs once per slide.
-__global__ void __launch_bounds__(64) k_marginalize(View v, int* status) {
+__global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
     const int w = blockIdx.x, lane = threadIdx.x;
     const int lo = v.lo[w], hi = v.hi[w];
     if (hi - lo < 4) { if (lane == 0) atomicOr(status, 2); return; }
@@ -2094,7 +2094,7 @@ __global__ void __launch_bounds__(64) k_marginalize(View v, int* status) {
     // index maps of the 42-vector: [m:15][m+1:15][m+2 pose][m+3 pose]
     auto imu_c = [](int i) { return i < 15 ? imu_col(0, i) : imu_col(1, i - 15); };   // i < 30
     auto mp_i = [](int i) { return i < 15 ? i : (i < 21 ? i : (i >= 30 && i < 36 ? i - 9 : -1)); };   // 42-index -> 27-index
-    for (int e = lane; e < 42 * 42 + 42; e += 64) {
+    for (int e = lane; e < 42 * 42 + 42; e += 256) {
         const bool is_b = e >= 42 * 42;
         const int i = is_b ? e - 42 * 42 : e / 42, j = is_b ? -1 : e - (e / 42) * 42;
         double sum = 0.0;
@@ -2133,7 +2133,7 @@ __global__ void __launch_bounds__(64) k_marginalize(View v, int* status) {
         // rank-1 update of the trailing (41-c)x(41-c) block and of b, entry-parallel; column c and
         // b[c] are only read in this step, so one pass is hazard-free
         const int m = 41 - c;
-        for (int e = lane; e < m * m + m; e += 64) {
+        for (int e = lane; e < m * m + m; e += 256) {
             const bool is_b = e >= m * m;
             const int i = c + 1 + (is_b ? e - m * m : e / m), j = is_b ? -1 : c + 1 + (e - (e / m) * m);
             const double u = A[i * 43 + c] * inv * (is_b ? bv[c] : A[j * 43 + c]);
@@ -2142,7 +2142,7 @@ __global__ void __launch_bounds__(64) k_marginalize(View v, int* status) {
         __syncthreads();
     }
     // new marginal prior on [m+1:15][m+2 pose][m+3 pose] = rows 15..41, relinearised at the current states
-    for (int e = lane; e < 729 + 27; e += 64) {
+    for (int e = lane; e < 729 + 27; e += 256) {
         if (e < 729) { const int i = e / 27, j = e - i * 27; v.mp_L[(size_t)w * 729 + e] = 0.5 * (A[(15 + i) * 43 + 15 + j] + A[(15 + j) * 43 + 15 + i]); }
         else {
             // also the "linearised" form at the new linearisation point (d = 0: gradient eta, cost 0),
@@ -2310,7 +2310,7 @@ void launch_slide(const View& v, const double* sigma15_dev, int reanchor, hipStr
     hipLaunchKernelGGL(k_slide, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, sigma15_dev, reanchor);
 }
 void launch_marginalize(const View& v, int* status, hipStream_t s) {
-    hipLaunchKernelGGL(k_marginalize, dim3(v.B), dim3(64), 0, s, v, status);
+    hipLaunchKernelGGL(k_marginalize, dim3(v.B), dim3(256), 0, s, v, status);
 }
 void launch_shift_copy(const double* src, double* dst, long n, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_shift_copy, dim3(nblk(n, 256)), dim3(256), 0, s, src, dst, n);

@@ -410,9 +410,13 @@ int vf_engine_linearize(vf_engine* e, int which) {
         HIPCHK(hipMemsetAsync(e->v.fresh, 0x01, e->v.B * sizeof(int), e->stream));
         HIPCHK(hipMemsetAsync(e->v.done, 0, e->v.B * sizeof(int), e->stream));
     }
-    vf::launch_linearize_imu(e->v, which, e->stream);
-    vf::launch_linearize_between(e->v, which, e->stream);
-    vf::launch_linearize_prior(e->v, which, e->stream);
+    if (e->v.B <= 128) {
+        vf::launch_linearize_all(e->v, which, e->stream);       // latency form: K1, K2, K2b side by side
+    } else {
+        vf::launch_linearize_imu(e->v, which, e->stream);
+        vf::launch_linearize_between(e->v, which, e->stream);
+        vf::launch_linearize_prior(e->v, which, e->stream);
+    }
     HIPCHK(hipGetLastError());
     return VF_OK;
 }

@@ -253,8 +253,7 @@ __global__ void __launch_bounds__(256) k_preintegrate(View v, long g0, int n, co
 #ifndef VF_K1_WAVES
 #define VF_K1_WAVES 1
 #endif
-__global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_imu(View v, int which) {
-    const long gk = (long)blockIdx.x * VF_K1_BLOCK + threadIdx.x;
+__device__ __forceinline__ void linearize_imu_factor(const View& v, int which, const long gk) {
     if (gk >= v.G) return;
     const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
     if (k <= v.lo[w] || k >= v.hi[w]) return;
@@ -414,8 +413,11 @@ __global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_imu(View
 
 // ------------------------------------------------------------------------------------ K2
 // Algorithmic traffic per factor: 42 doubles in (2 poses x 7, record 28), 78 out.
-__global__ void __launch_bounds__(256) k_linearize_between(View v, int which) {
-    const long gk = (long)blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_imu(View v, int which) {
+    linearize_imu_factor(v, which, (long)blockIdx.x * VF_K1_BLOCK + threadIdx.x);
+}
+
+__device__ __forceinline__ void linearize_between_factor(const View& v, int which, const long gk) {
     if (gk >= v.G) return;
     const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
     const int lo = v.lo[w];
@@ -520,8 +522,11 @@ VF_DI void marg_delta(const View& v, int w, int b, double (&d)[27]) {
     }
 }
 
-__global__ void k_linearize_prior(View v, int which) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_linearize_between(View v, int which) {
+    linearize_between_factor(v, which, (long)blockIdx.x * 256 + threadIdx.x);
+}
+
+__device__ __forceinline__ void linearize_prior_window(const View& v, int which, const int w) {
     if (w >= v.B || window_done(v, w)) return;
     const int b = v.sel[w] ^ which;
     if (v.mp_on[w] && v.hi[w] - v.lo[w] >= 3) {
@@ -569,6 +574,18 @@ __global__ void k_linearize_prior(View v, int which) {
         out[6 + i] = (xs[i] - in[7 + i]) / sig[6 + i];
         out[15 + (6 + i) * 15 + 6 + i] = 1.0 / sig[6 + i];
     }
+}
+__global__ void k_linearize_prior(View v, int which) {
+    linearize_prior_window(v, which, blockIdx.x * blockDim.x + threadIdx.x);
+}
+// K1 + K2 + K2b in ONE launch, for few windows (latency form): with a handful of windows each of the three kernels
+// is a single latency chain (27 / 9 / 13 us), so running them side by side saves two of the three; for large
+// batches they stay separate (K2 would inherit K1's register footprint here).
+__global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_all(View v, int which, int nb_imu, int nb_btw) {
+    const int bx = blockIdx.x;
+    if (bx < nb_imu) linearize_imu_factor(v, which, (long)bx * VF_K1_BLOCK + threadIdx.x);
+    else if (bx < nb_imu + nb_btw) linearize_between_factor(v, which, (long)(bx - nb_imu) * VF_K1_BLOCK + threadIdx.x);
+    else linearize_prior_window(v, which, (bx - nb_imu - nb_btw) * VF_K1_BLOCK + (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------ K3
@@ -2243,6 +2260,10 @@ static inline unsigned nblk(long n, int bs) { return (unsigned)((n + bs - 1) / b
 void launch_preintegrate(const View& v, long g0, int n, const int* off, const double* steps, const double* bhat6,
                          const ImuCov& prm, int* status, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_preintegrate, dim3(n), dim3(256), 0, s, v, g0, n, off, steps, bhat6, prm, status);
+}
+void launch_linearize_all(const View& v, int which, hipStream_t s) {
+    const int nb_imu = (int)nblk(v.G, VF_K1_BLOCK), nb_btw = nb_imu, nb_pri = (int)nblk(v.B, VF_K1_BLOCK);
+    hipLaunchKernelGGL(k_linearize_all, dim3(nb_imu + nb_btw + nb_pri), dim3(VF_K1_BLOCK), 0, s, v, which, nb_imu, nb_btw);
 }
 void launch_linearize_imu(const View& v, int which, hipStream_t s) {
     hipLaunchKernelGGL(k_linearize_imu, dim3(nblk(v.G, VF_K1_BLOCK)), dim3(VF_K1_BLOCK), 0, s, v, which);

@@ -11,6 +11,15 @@ value = (windows on all ranks) * steps / max-over-ranks time: one new keyframe p
 Contract: python bench.py --gpus N --steps K --warmup W ; rank 0 prints ONE JSON line.
 N > 1: launched by torch.distributed.run, one rank per GPU; windows are independent, so ranks
 share nothing on the data path ("scaling": "weak", windows per GPU fixed).
+
+Beside the contract fields the line carries, all measured outside the timed region of `value`:
+  roofline               K1 (the Jacobian kernel) from HIP events on the engine's stream, PMC traffic from profiles/
+  stage_ms               one launch of every hot-path kernel
+  with_convergence_exit  the same update with GTSAM's LM termination rule on (windows stop taking trials)
+  time_sharded_window    ONE 10 000-pose window spread in time over all ranks (BASELINE configs[4])
+  single_window          latency of the update for one window (what one vehicle sees)
+  degeneracy_k6          the 6x6 degeneracy metrics, f64 / f32, beside the reference's per-matrix numpy calls (N = 1)
+  cpu_baseline(_openmp)  the C oracle doing the same update on the host (N = 1)
 """
 import argparse
 import json

@@ -19,6 +19,7 @@ Beside the contract fields the line carries, all measured outside the timed regi
   time_sharded_window    ONE 10 000-pose window spread in time over all ranks (BASELINE configs[4])
   single_window          latency of the update for one window (what one vehicle sees)
   degeneracy_k6          the 6x6 degeneracy metrics, f64 / f32, beside the reference's per-matrix numpy calls (N = 1)
+  graph_manager          latency of GraphManager::solve (the drop-in call) at a 1000-keyframe lag (N = 1)
   cpu_baseline(_openmp)  the C oracle doing the same update on the host (N = 1)
 """
 import argparse
@@ -168,6 +169,29 @@ def degeneracy_section():
     return out
 
 
+def graph_manager_section(lag=1000, extra=120):
+    """Latency of the drop-in surface itself: GraphManager.solve() (= vf_solve) per keyframe in fixed-lag mode, fed like
+    the node (IMU at 200 Hz between keyframes, one reserveNode + solve per keyframe), once the window is full."""
+    from vil_sensor_fusion_amd import GraphManager, synth
+    nkf = lag + extra
+    seq = synth.make_sequence(seed=3, n_kf=nkf + 2)
+    gm = GraphManager(capacity=lag + 192, lag=lag, iterations=5)
+    t, times = 0.0, []
+    for k in range(1, nkf):
+        for s in seq.imu_steps[seq.imu_off[k]:seq.imu_off[k + 1]]:
+            t += s[0]
+            gm.addIMUMeasurement(t, s[1:4], s[4:7])
+        gm.reserveNode(t)
+        t0 = time.perf_counter()
+        gm.solve()
+        times.append(time.perf_counter() - t0)
+    steady = np.array(times[lag + 20:]) * 1e3
+    gm.close()
+    return {"lag_keyframes": lag, "lm_trials_per_solve": 5, "solve_ms_mean": float(steady.mean()),
+            "solve_ms_p99": float(np.percentile(steady, 99)), "solves_timed": int(steady.size),
+            "what": "vf_solve: K0 of the new IMU factor, prediction, marginalisation of the oldest keyframe, 5 LM trials, read-back"}
+
+
 def measured_traffic_per_imu_factor():
     """HBM bytes per IMU factor of K1 from the committed PMC profile (separate --pmc passes,
     2*FETCH_SIZE + WRITE_SIZE, KiB units; tools/summarize_prof.py)."""
@@ -186,7 +210,8 @@ def main():
     ap.add_argument("--windows", type=int, default=1024, help="independent windows per GPU")
     ap.add_argument("--sequences", type=int, default=8, help="distinct synthetic sequences per rank")
     ap.add_argument("--iterations", type=int, default=5, help="LM trials per update")
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=128,
+                    help="fixed-lag updates the CPU baseline is timed on (128 = about 10 s on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-window", action="store_true")
     ap.add_argument("--reanchor", action="store_true", help="drop the oldest keyframe by re-anchoring tight priors instead of marginalising it")
@@ -194,6 +219,7 @@ def main():
     ap.add_argument("--no-sharded", action="store_true")
     ap.add_argument("--no-convergence-exit", action="store_true")
     ap.add_argument("--no-degeneracy", action="store_true")
+    ap.add_argument("--no-graph-manager", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -321,6 +347,8 @@ def main():
             one.close()
         if not args.no_degeneracy and info.world == 1:
             out["degeneracy_k6"] = degeneracy_section()
+        if not args.no_graph_manager and info.world == 1:
+            out["graph_manager"] = graph_manager_section()
         if not args.no_cpu_baseline and info.world == 1:       # the CPU legs: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args)
             out["cpu_baseline"]["gpu_over_cpu"] = kf_per_s / out["cpu_baseline"]["value"]

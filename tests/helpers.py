@@ -60,3 +60,16 @@ def ate(states_a, states_b):
     qa, qb = states_a[:, :4], states_b[:, :4]
     w = np.abs(np.sum(qa * qb, axis=1)).clip(max=1.0)
     return float(np.sqrt(np.mean(np.sum(d * d, axis=1)))), float(np.max(2 * np.arccos(w)))
+
+
+SWEEP_TOLS = (1e-3, 1e-4, 1e-5, 1e-6, 1e-7)
+
+
+def tolerance_sweep(y, ref, mask=None):
+    """Fraction of entries of y within each relative tolerance of ref (entry 0 of a metric series is
+    the reference's y[0] = 0 placeholder and is skipped); mask selects a stretch of the sequence."""
+    y, ref = np.asarray(y, dtype=np.float64)[1:], np.asarray(ref, dtype=np.float64)[1:]
+    if mask is not None:
+        y, ref = y[mask[1:]], ref[mask[1:]]
+    rel = np.abs(y - ref) / np.maximum(np.abs(ref), 1e-300)
+    return [float(np.mean(rel <= t)) for t in SWEEP_TOLS]

@@ -169,15 +169,29 @@ class Sequence:
     btw_q: np.ndarray          # (m,4) measured relative rotation
     btw_t: np.ndarray          # (m,3)
     btw_cov: np.ndarray        # (m,) isotropic covariance (fusion_params.yaml)
+    btw_info: np.ndarray = None        # (m,6) per-dof information multipliers [rot 3, trans 3] (1 = nominal); None = all 1
+    tunnel: np.ndarray = None          # (n,) bool: keyframe lies in the LiDAR-degenerate stretch
+    loam_hessians: np.ndarray = None   # (n_lidar,6,6) float64: scan-matching Hessian per LiDAR keyframe, LOAM order [trans 3, rot 3]
+    loam_kf: np.ndarray = None         # (n_lidar,) keyframe index of each Hessian
 
     @property
     def n(self):
         return self.kf_time.shape[0]
 
 
-def make_sequence(seed: int, n_kf: int, vio: bool = True, lidar: bool = True) -> Sequence:
+TUNNEL_NOMINAL_EIG = 4.0e4     # scan-matching information per direction: log det of a 3x3 block = 31.8 > 28.9
+
+
+def make_sequence(seed: int, n_kf: int, vio: bool = True, lidar: bool = True, tunnel=None) -> Sequence:
     """n_kf keyframes interleaving camera (20 Hz) and LiDAR (10 Hz) stamps; keyframe 0 is the
-    anchor (the reference's prior node X(0), GraphManager.cpp:20-35)."""
+    anchor (the reference's prior node X(0), GraphManager.cpp:20-35).
+
+    tunnel = (f0, f1, scale): BASELINE configs[3].  For keyframes in the fraction [f0, f1) of the sequence the
+    LiDAR odometry is degenerate along the track (body x): the information of its between factors in that
+    direction is `scale` x nominal (the measurement noise there grows accordingly), and the per-scan 6x6
+    scan-matching Hessians (`loam_hessians`, what loam::OptStatus.hessian carries to the degeneracy filter,
+    degerate_odometry_filter.cpp:29-47) lose the same factor in their along-track eigenvalue -- the tunnel stretch
+    of the reference's Carla evaluation (DEGEN_TRANS, make_prettier_graphs.py:81-84)."""
     horizon = n_kf * LIDAR_DT + 1.0      # enough stamps whichever sources are enabled
     cam = np.arange(0, int(horizon / CAM_DT) + 1) * CAM_DT
     lid = np.arange(0, int(horizon / LIDAR_DT) + 1) * LIDAR_DT + LIDAR_PHASE
@@ -204,17 +218,46 @@ def make_sequence(seed: int, n_kf: int, vio: bool = True, lidar: bool = True) ->
         off.append(off[-1] + s.shape[0])
     imu_steps = np.concatenate(steps) if steps else np.zeros((0, 7))
 
-    ba, bb, bq, bt, bc = [], [], [], [], []
+    in_tunnel = np.zeros(n_kf, dtype=bool)
+    if tunnel is not None:
+        f0, f1, t_scale = tunnel
+        in_tunnel[int(f0 * n_kf):int(f1 * n_kf)] = True
+    ba, bb, bq, bt, bc, bi = [], [], [], [], [], []
     for sid, (nr, nt), cov in ((0, VIO_NOISE, VIO_COV), (1, LIDAR_NOISE, LIDAR_COV)):
         idx = np.nonzero(sensor == sid)[0]
         for a, b in zip(idx[:-1], idx[1:]):
+            info = np.ones(6)
+            noise_t = rng.normal(size=3) * nt
+            if sid == 1 and in_tunnel[b]:
+                info[3] = t_scale                        # along-track translation, frame a
+                noise_t[0] /= np.sqrt(t_scale) * 1e2     # the scan matcher slides along the tunnel (10 x the nominal noise at 1e-6)
             Rab = R[a].T @ R[b] @ so3_exp(rng.normal(size=3) * nr)
-            tab = R[a].T @ (gt[b, 4:7] - gt[a, 4:7]) + rng.normal(size=3) * nt
-            ba.append(a); bb.append(b); bq.append(rot_to_quat(Rab)); bt.append(tab); bc.append(cov)
+            tab = R[a].T @ (gt[b, 4:7] - gt[a, 4:7]) + noise_t
+            ba.append(a); bb.append(b); bq.append(rot_to_quat(Rab)); bt.append(tab); bc.append(cov); bi.append(info)
     o = np.argsort(bb, kind="stable")
-    return Sequence(seed, times, sensor, gt, imu_steps, np.array(off),
-                    np.array(ba, dtype=np.int32)[o], np.array(bb, dtype=np.int32)[o],
-                    np.array(bq).reshape(-1, 4)[o], np.array(bt).reshape(-1, 3)[o], np.array(bc)[o])
+    seq = Sequence(seed, times, sensor, gt, imu_steps, np.array(off),
+                   np.array(ba, dtype=np.int32)[o], np.array(bb, dtype=np.int32)[o],
+                   np.array(bq).reshape(-1, 4)[o], np.array(bt).reshape(-1, 3)[o], np.array(bc)[o])
+    if tunnel is not None:
+        seq.btw_info = np.array(bi).reshape(-1, 6)[o]
+        seq.tunnel = in_tunnel
+        hrng = np.random.default_rng([seed, 0x70AA])
+        lk = np.nonzero(sensor == 1)[0]
+        Hs = np.zeros((lk.size, 6, 6))
+        for i, k in enumerate(lk):
+            # J^T J of a scan match: well spread eigenvalues around the nominal, mild rot/trans coupling
+            q, _ = np.linalg.qr(hrng.normal(size=(6, 6)) * 0.05 + np.eye(6))
+            ev = TUNNEL_NOMINAL_EIG * 10 ** hrng.uniform(-0.15, 0.15, size=6)
+            m = (q * ev) @ q.T
+            if in_tunnel[k]:
+                v = np.zeros(6)                                   # along-track translation (LOAM order: translation first),
+                v[:3] = [1.0, 0.1 * hrng.uniform(-1, 1), 0.03 * hrng.uniform(-1, 1)]   # the sensor a few degrees off the tunnel axis
+                v /= np.linalg.norm(v)
+                mv = m @ v
+                m = m - (1 - t_scale) * np.outer(mv, mv) / (v @ mv)   # information along v -> scale x nominal, m stays PSD
+            Hs[i] = 0.5 * (m + m.T)
+        seq.loam_hessians, seq.loam_kf = Hs, lk
+    return seq
 
 
 def between_records(seq: Sequence) -> np.ndarray:
@@ -227,6 +270,8 @@ def between_records(seq: Sequence) -> np.ndarray:
     iu = np.triu_indices(6)
     diag_pos = np.nonzero(iu[0] == iu[1])[0]
     rec[:, 7 + diag_pos] = (1.0 / np.sqrt(seq.btw_cov))[:, None]
+    if seq.btw_info is not None:
+        rec[:, 7 + diag_pos] *= np.sqrt(seq.btw_info)
     return rec
 
 

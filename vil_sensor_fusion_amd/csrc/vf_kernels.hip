@@ -830,18 +830,6 @@ VF_DI double readlane_d(double x, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// v_rsq_f64 is good to 2^29 ulp (rel. 2^-23); two Newton steps reach full double precision.
-VF_DI double fast_rsqrt(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    double t = x * y;
-    double e = fma(-t, y, 1.0);
-    y = fma(0.5 * y, e, y);
-    t = x * y;
-    e = fma(-t, y, 1.0);
-    y = fma(0.5 * y, e, y);
-    return y;
-}
-
 // One wavefront per window.  Right-looking block Cholesky of the block-banded normal matrix,
 // exploiting its profile: IMU factors couple consecutive keyframes in all 15 dof, between
 // factors couple keyframes up to 3 apart in the 6 pose dof only, so the active set while
@@ -881,6 +869,7 @@ constexpr int S_PROG = S_P + 4 * RING_SLOT;   // panels completed by the sweep
 constexpr int S_CONS = S_PROG + 1;            // panels consumed by the follower
 constexpr int S_TOTAL_RING = S_PROG + 8;
 #define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define VF_SB() __builtin_amdgcn_sched_barrier(0)
 #ifdef VF_SOLVE_STAMPS   // diagnostic build only (tools/build_stamps.sh); never in the shipped library
 __device__ unsigned long long g_stamps[16];
 #define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _t; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); if (w == 0) st[i] += _t - tprev; tprev = _t; } while (0)
@@ -1140,27 +1129,11 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #pragma unroll
         for (int c = 0; c < 15; c++) p[c] = S[ri_ph[PH] + c];
         STAMP(1);
-        // panel factorisation, software-pipelined: inv for column c+1 is started right after
-        // column c+1 has received its update from column c
-        double dv = readlane_d(p[0], 0);
-        if (!(dv > 0.0)) { failed = 1; dv = 1.0; }
-        double inv = fast_rsqrt(dv);
-#pragma unroll
-        for (int c = 0; c < 15; c++) {
-            p[c] *= inv;
-            if (c + 1 < 15) {
-                const double l1 = readlane_d(p[c], c + 1);
-                p[c + 1] = fma(-p[c], l1, p[c + 1]);
-                dv = readlane_d(p[c + 1], c + 1);
-                if (!(dv > 0.0)) { failed = 1; dv = 1.0; }
-                inv = fast_rsqrt(dv);
-            }
-#pragma unroll
-            for (int c2 = c + 2; c2 < 15; c2++) {
-                const double l = readlane_d(p[c], c2);
-                p[c2] = fma(-p[c], l, p[c2]);
-            }
-        }
+        // panel factorisation: straight-line code in a fixed issue order (tools/gen_pivot.py); a non-positive
+        // pivot turns the last reciprocal into NaN / inf, tested once per step
+        double pv_inv;
+#include "vf_pivot_15.inc"
+        if (!(pv_inv < 1e300)) failed = 1;
         STAMP(2);
         // sub-panel + rhs -> LDS (MFMA operands); rows 15..57 -> HBM, one 128-B line per lane
         if constexpr (RINGM) {
@@ -1777,26 +1750,10 @@ __global__ void __launch_bounds__(256) k_sep_solve(View v) {
             LDS_BARRIER();   // Dn consumed
             SSTAMP(1);
             // the 27 pivot rows are lanes 0..26 of this wave: pivots and multipliers by v_readlane, no LDS round trip and no
-            // barrier inside the step; the rsqrt of the next pivot starts as soon as its column is up to date
-            double dv = readlane_d(p[0], 0);
-            if (!(dv > 0.0)) { failed = 1; dv = 1.0; }
-            double inv = fast_rsqrt(dv);
-#pragma unroll
-            for (int c = 0; c < SEP; c++) {
-                p[c] *= inv;
-                if (c + 1 < SEP) {
-                    const double l1 = readlane_d(p[c], c + 1);
-                    p[c + 1] = fma(-p[c], l1, p[c + 1]);
-                    dv = readlane_d(p[c + 1], c + 1);
-                    if (!(dv > 0.0)) { failed = 1; dv = 1.0; }
-                    inv = fast_rsqrt(dv);
-                }
-#pragma unroll
-                for (int c2 = c + 2; c2 < SEP; c2++) {
-                    const double l = readlane_d(p[c], c2);
-                    p[c2] = fma(-p[c], l, p[c2]);
-                }
-            }
+            // barrier inside the step; straight-line code in a fixed issue order (tools/gen_pivot.py)
+            double pv_inv;
+#include "vf_pivot_27.inc"
+            if (!(pv_inv < 1e300)) failed = 1;
             SSTAMP(2);
             // factor rows -> HBM, column-major: one contiguous 8-byte-per-lane store per column
             if (lane < 55) {

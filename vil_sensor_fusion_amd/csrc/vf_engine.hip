@@ -414,8 +414,7 @@ int vf_engine_linearize(vf_engine* e, int which) {
         vf::launch_linearize_all(e->v, which, e->stream);       // latency form: K1, K2, K2b side by side
     } else {
         vf::launch_linearize_imu(e->v, which, e->stream);
-        vf::launch_linearize_between(e->v, which, e->stream);
-        vf::launch_linearize_prior(e->v, which, e->stream);
+        vf::launch_linearize_between_prior(e->v, which, e->stream);
     }
     HIPCHK(hipGetLastError());
     return VF_OK;

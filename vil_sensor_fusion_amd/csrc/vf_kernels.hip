@@ -578,6 +578,13 @@ __device__ __forceinline__ void linearize_prior_window(const View& v, int which,
 __global__ void k_linearize_prior(View v, int which) {
     linearize_prior_window(v, which, blockIdx.x * blockDim.x + threadIdx.x);
 }
+// K2 + K2b in one launch (large batches): the prior linearisations are one lane per window, i.e. a handful of waves
+// running an 80 us latency chain; as the first workgroups of K2's grid they hide behind the between factors
+__global__ void __launch_bounds__(256) k_linearize_between_prior(View v, int which, int nb_pri) {
+    const int bx = blockIdx.x;
+    if (bx < nb_pri) linearize_prior_window(v, which, bx * 256 + (int)threadIdx.x);
+    else linearize_between_factor(v, which, (long)(bx - nb_pri) * 256 + threadIdx.x);
+}
 // K1 + K2 + K2b in ONE launch, for few windows (latency form): with a handful of windows each of the three kernels
 // is a single latency chain (27 / 9 / 13 us), so running them side by side saves two of the three; for large
 // batches they stay separate (K2 would inherit K1's register footprint here).
@@ -610,14 +617,34 @@ __host__ __device__ constexpr bool imu_field_is_zero(int f) {
     if (c < 18) return r >= 9 || (c >= 3 && c < 6 && r >= 6) || (c >= 12 && c < 15 && r > 3 + (c - 12));
     return r >= 10 + (c - 18) % 6;
 }
-constexpr int AT = 16;          // keyframes per block
+#ifndef VF_K3_AT
+#define VF_K3_AT 8
+#endif
+#ifndef VF_K3_NT
+#define VF_K3_NT 256
+#endif
+constexpr int AT = VF_K3_AT;    // keyframes per block
+constexpr int K3_NT = VF_K3_NT; // threads per block
+constexpr int K3_KPW = AT / (K3_NT / 64);   // keyframes per wave
+static_assert(K3_KPW * (K3_NT / 64) == AT && K3_NT % AT == 0, "K3 tiling");
 constexpr int LJS = 465;        // LDS stride of one factor's (r | J), odd
 constexpr int LBS = 79;         // LDS stride of one between linearisation (78 + pad), odd
 
-__global__ void __launch_bounds__(256) k_assemble(View v) {
-    const long gk0 = (long)blockIdx.x * AT;
-    if (gk0 >= v.G) return;
-    const int w = (int)(gk0 / v.M), k0 = (int)(gk0 - (long)w * v.M);
+#ifdef VF_K3_WPE
+__attribute__((amdgpu_waves_per_eu(VF_K3_WPE, VF_K3_WPE)))
+#endif
+__global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
+    __shared__ double LJ[(AT + 1) * LJS];
+    __shared__ double LB[(AT + 3) * LBS];
+    __shared__ int s_a[AT + 3];
+    const int tid = threadIdx.x;
+    // grid = (tiles per window, windows).  A rejected LM trial leaves the current linearisation, hence H and g,
+    // unchanged (k_decide clears `fresh` on reject; accept / init / slide set it): such a tile must cost as little
+    // as a launch can -- one flag read, no index arithmetic in front of it (an all-rejected batch used to take 0.73 ms)
+    const int w = blockIdx.y;
+    if (!v.fresh[w] || window_done(v, w)) return;
+    const int k0 = blockIdx.x * AT;
+    const long gk0 = (long)w * v.M + k0;
     const int lo = v.lo[w], hi = v.hi[w];
     int rlo, rhi;                            // rows of H this rank assembles (absolute slots)
     own_range(v, w, rlo, rhi);
@@ -626,30 +653,25 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
     if (v.sh_G > 1 && rhi + 2 <= hi) rhi += 2;   // tail rows of the rank's last chunk (see shard_skips_factor)
     else if (v.sh_G > 1) rhi = hi;
     if (k0 + AT <= rlo || k0 >= rhi) return; // no owned active keyframe in this tile (uniform)
-    // a rejected LM trial leaves the current linearisation, hence H and g, unchanged: nothing to do
-    // (k_decide clears `fresh` on reject; accept / init / slide set it)
-    if (!v.fresh[w] || window_done(v, w)) return;
     const int b = v.sel[w];
-    const int tid = threadIdx.x;
     const size_t tiles = (size_t)(v.G >> 6);
     const double* imu_out = v.imu_out + (size_t)b * tiles * IMU_OUT * TILE;
     const double* btw_out = v.btw_out + (size_t)b * tiles * BTW_OUT * TILE;
-    __shared__ double LJ[(AT + 1) * LJS];
-    __shared__ double LB[(AT + 3) * LBS];
-    __shared__ int s_a[AT + 3];
 
     // ---- stage (r | J) of factors k0 .. k0+15: thread = (field group, factor), 128-B segments.
     // All of a thread's global loads are issued before the first LDS write (38 loads in flight
     // per thread) so that the tile costs one HBM round trip, not one per batch.
     {
-        const int fac = tid & 15, fg = tid >> 4;
+        constexpr int NG = K3_NT / AT, NIT = (IMU_OUT + NG - 1) / NG, N16 = (IMU_OUT + K3_NT - 1) / K3_NT,
+                      NB = ((AT + 3) * BTW_OUT + K3_NT - 1) / K3_NT;
+        const int fac = tid % AT, fg = tid / AT;
         const int k = k0 + fac;
         const bool ok = k > lo && k < hi;
         const double* src = imu_out + (size_t)(gk0 >> 6) * IMU_OUT * TILE + (gk0 & 63) + fac;
-        double tj[30];
+        double tj[NIT];
 #pragma unroll
-        for (int it = 0; it < 30; it++) {
-            const int f = it * 16 + fg;
+        for (int it = 0; it < NIT; it++) {
+            const int f = it * NG + fg;
             tj[it] = (ok && f < IMU_OUT && !imu_field_is_zero(f)) ? src[(size_t)f * TILE] : 0.0;   // a third of J is structurally zero
         }
         // factor k0+16 (its i-side feeds H[k0+15][k0+15]); it may live in the next AoSoA tile
@@ -657,17 +679,17 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
         const bool ok16 = k16 > lo && k16 < hi;
         const long g16 = gk0 + AT;
         const double* src16 = imu_out + (size_t)(g16 >> 6) * IMU_OUT * TILE + (g16 & 63);
-        double t16[2];
+        double t16[N16];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int f = tid + 256 * j;
+        for (int j = 0; j < N16; j++) {
+            const int f = tid + K3_NT * j;
             t16[j] = (ok16 && f < IMU_OUT && !imu_field_is_zero(f)) ? src16[(size_t)f * TILE] : 0.0;
         }
         // between linearisations of slots k0 .. k0+18
-        double tb[6];
+        double tb[NB];
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const int e = tid + 256 * j;
+        for (int j = 0; j < NB; j++) {
+            const int e = tid + K3_NT * j;
             const int sl = e / BTW_OUT, f = e - sl * BTW_OUT;
             const int ks = k0 + sl;
             const long gs = gk0 + sl;
@@ -680,18 +702,18 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
             s_a[tid] = a;
         }
 #pragma unroll
-        for (int it = 0; it < 30; it++) {
-            const int f = it * 16 + fg;
+        for (int it = 0; it < NIT; it++) {
+            const int f = it * NG + fg;
             if (f < IMU_OUT) LJ[fac * LJS + f] = tj[it];
         }
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int f = tid + 256 * j;
+        for (int j = 0; j < N16; j++) {
+            const int f = tid + K3_NT * j;
             if (f < IMU_OUT) LJ[AT * LJS + f] = t16[j];
         }
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const int e = tid + 256 * j;
+        for (int j = 0; j < NB; j++) {
+            const int e = tid + K3_NT * j;
             if (e < (AT + 3) * BTW_OUT) { const int sl = e / BTW_OUT; LB[sl * LBS + (e - sl * BTW_OUT)] = tb[j]; }
         }
     }
@@ -731,9 +753,9 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
     };
 
     d4_t D = {0, 0, 0, 0};
-    const int lf0 = 4 * wv;
+    const int lf0 = K3_KPW * wv;
 #pragma unroll 1
-    for (int lf = lf0; lf <= lf0 + 4; lf++) {
+    for (int lf = lf0; lf <= lf0 + K3_KPW; lf++) {
         double ai[4], aj[4];
         load_ops(lf, ai, aj);
         if (lf > lf0) {
@@ -778,7 +800,7 @@ __global__ void __launch_bounds__(256) k_assemble(View v) {
                 }
             }
         }
-        if (lf < lf0 + 4) {
+        if (lf < lf0 + K3_KPW) {
             // ---- keyframe kf = lf: off-diagonal block Jj^T Ji, pose-only blocks, start D = Jj^T Jj
             d4_t O = {0, 0, 0, 0};
             D = (d4_t){0, 0, 0, 0};
@@ -2228,13 +2250,18 @@ void launch_linearize_imu(const View& v, int which, hipStream_t s) {
 void launch_linearize_between(const View& v, int which, hipStream_t s) {
     hipLaunchKernelGGL(k_linearize_between, dim3(nblk(v.G, 256)), dim3(256), 0, s, v, which);
 }
+void launch_linearize_between_prior(const View& v, int which, hipStream_t s) {
+    const int nb_pri = (int)nblk(v.B, 256);
+    hipLaunchKernelGGL(k_linearize_between_prior, dim3(nblk(v.G, 256) + nb_pri), dim3(256), 0, s, v, which, nb_pri);
+}
 void launch_linearize_prior(const View& v, int which, hipStream_t s) {
     hipLaunchKernelGGL(k_linearize_prior, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, which);
 }
 void launch_assemble(const View& v, hipStream_t s) {
-    // (a persistent one-workgroup-per-CU form with the next tile's loads in flight was measured at 5.1 ms against
-    // 2.8 ms for this one: the LDS / MFMA phase of a tile, not its HBM round trip, is what two workgroups per CU hide)
-    hipLaunchKernelGGL(k_assemble, dim3(nblk(v.G, AT)), dim3(256), 0, s, v);
+    // (persistent forms were measured slower: one workgroup per CU with the next tile's loads in flight 5.1 ms, a plain
+    // tile loop on 1024-2048 workgroups 4.0-4.3 ms, against 2.7 ms for one workgroup per tile -- stores count in vmcnt
+    // on this ISA, so a loop waits for its own H stores before it can use the next tile's loads)
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)(v.M / AT), (unsigned)v.B), dim3(K3_NT), 0, s, v);
 }
 void launch_partitioned_local(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_chunk_forward, dim3((unsigned)v.B * (unsigned)v.P), dim3(128), 0, s, v);

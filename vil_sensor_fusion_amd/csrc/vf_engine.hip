@@ -167,7 +167,8 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.mp_eta, (size_t)v.B * 27);
     AL(v.mp_out, 2 * (size_t)v.B * 28);
     AL(v.H, G * vf::HROW);
-    AL(v.gvec, G * 15);
+    AL(v.gvec, G * 15 + 64);      // + slack: the solver's row fetch reads 64 lanes of a 15-double row (the excess is never used)
+    AL(v.zrow, vf::HROW);         // a block row of zeros: what the solver fetches for rows outside the window
     AL(v.delta, G * 15);
     AL(v.Lp, G * vf::PANEL);
     // K4 form: chunks = 0 picks it from the batch size: up to 128 windows -> partitioned solve with at

@@ -1027,26 +1027,32 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     struct HRow { double h0[4], h1[4], h2[2], h3[2], hg; };
     const double* __restrict__ Hbase = v.H + base * HROW;
     const double* __restrict__ gbase = v.gvec + base * 15;
+    const double* __restrict__ zrow = v.zrow;
     double* __restrict__ Lbase = v.Lp + base * PANEL;
     double* __restrict__ dbase = v.delta + base * 15;
     auto fetch_row = [=](int kk) {
         HRow r;
         const bool real = row_kind(kk) == 0;
         if (!rev) {
-            const double* Hk = Hbase + (size_t)(real ? kk : 0) * HROW;
+            // unconditional loads: a block that is absent (row outside the window, or reaching in front of it) is read
+            // from a row of zeros -- wave-uniform pointer selects instead of per-lane predicates (exec juggling);
+            // lanes beyond a block's extent read neighbouring words that commit_row sends to the write sink
+            const double* H0 = real ? Hbase + (size_t)kk * HROW : zrow;
+            const double* H1 = (real && kk >= 1) ? H0 + 225 : zrow;
+            const double* H2 = (real && kk >= 2) ? H0 + 450 : zrow;
+            const double* H3 = (real && kk >= 3) ? H0 + 675 : zrow;
+            const double* G0 = real ? gbase + (size_t)kk * 15 : zrow;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const bool in = real && lane + 64 * j < 225;
-                r.h0[j] = in ? Hk[lane + 64 * j] : 0.0;
-                r.h1[j] = (in && kk >= 1) ? Hk[225 + lane + 64 * j] : 0.0;
+                r.h0[j] = H0[lane + 64 * j];
+                r.h1[j] = H1[lane + 64 * j];
             }
 #pragma unroll
             for (int it = 0; it < 2; it++) {
-                const bool in = real && cp_off[it] >= 0;
-                r.h2[it] = (in && kk >= 2) ? Hk[450 + cp_src[it]] : 0.0;
-                r.h3[it] = (in && kk >= 3) ? Hk[675 + cp_src[it]] : 0.0;
+                r.h2[it] = H2[cp_src[it]];
+                r.h3[it] = H3[cp_src[it]];
             }
-            r.hg = (real && lane < 15) ? gbase[(size_t)kk * 15 + lane] : 0.0;   // negated at commit (a use here would stall on vmcnt)
+            r.hg = G0[lane];   // negated at commit (a use here would stall on vmcnt)
         } else {
             // reversed sequence: block d of row j couples j with j+d = H[j+d][d]^T (pose x pose for d >= 2).
             // Rows t, t+1, t+2 (kind 2) keep only their couplings to the reverse part (j+d >= t+3):
@@ -1179,25 +1185,24 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         if constexpr (RINGM) { if (lane == 0) S[S_PROG] = (double)(k + 1); }   // panel k is complete in its ring slot
         STAMP(3);
         // Schur update on the matrix cores: acc[t] = P_Ti P_Tj^T for the 3 lower 16x16 tiles
-        d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-        double a0[4], a1[4];
+        // (the trailing entries are the accumulator input and the A operands are negated: T - P P^T leaves the matrix
+        // cores ready to be written back, no accumulator read-out + subtraction pass)
+        double a0[4], a1[4], n0[4], n1[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) { a0[q] = S[op0[q] + PH * RSLOT]; a1[q] = S[op1[q] + PH * RSLOT]; }
-        double cur[12];
+        d4_t acc0, acc1, acc2;
 #pragma unroll
-        for (int q = 0; q < 12; q++) cur[q] = S[tgt_ph[PH][q]];
+        for (int r = 0; r < 4; r++) { acc0[r] = S[tgt_ph[PH][r]]; acc1[r] = S[tgt_ph[PH][4 + r]]; acc2[r] = S[tgt_ph[PH][8 + r]]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { n0[q] = -a0[q]; n1[q] = -a1[q]; }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], a0[q], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], a0[q], acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], a1[q], acc2, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(n0[q], a0[q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(n1[q], a0[q], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(n1[q], a1[q], acc2, 0, 0, 0);
         }
 #pragma unroll
-        for (int q = 0; q < 12; q++) {
-            const int t = q >> 2, r = q & 3;
-            const double val = t == 0 ? acc0[r] : (t == 1 ? acc1[r] : acc2[r]);
-            S[tgt_ph[PH][q]] = cur[q] - val;
-        }
+        for (int r = 0; r < 4; r++) { S[tgt_ph[PH][r]] = acc0[r]; S[tgt_ph[PH][4 + r]] = acc1[r]; S[tgt_ph[PH][8 + r]] = acc2[r]; }
         WSYNC();
         STAMP(4);
         commit_row(ph, pend, row_kind(k + 4), k + 4);  // row k+4 takes the slot the pivot keyframe frees
@@ -1244,7 +1249,9 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     // ---- back substitution: delta_k = L_kk^-T (y_k - sum_p L[p][k-cols]^T delta(p)) -----------
     // Panel rows in HBM: 0..26 sub-diagonal rows (p = 15..41), 27 = y, 28..42 = L_kk^-T.
     // Lane r < 43 holds row r in registers; rows 0..27 go through LDS for the column sums,
-    // L^-T stays in the registers of lanes 28..42.  Panels are prefetched three steps ahead.
+    // L^-T stays in the registers of lanes 28..42.  Panels are prefetched four steps ahead, each into the register
+    // slot (k & 3) it is consumed from (three steps with a rotating triple measured 2.5 % slower under a full batch;
+    // touching the lines further ahead with a dword load does not help: vector loads return in order).
     S[S_DL + lane] = 0.0;
     if constexpr (MODE == SOLVE_CHUNK_BWD) {
         WSYNC();
@@ -1320,7 +1327,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     const int col = lane < 15 ? lane : 0;
     const int dl_w = (lane >= 28 && lane < 43) ? S_DL + lane - 28 : S_DUMP + 32 + lane;
     WSYNC();
-    auto back = [&](auto ph, int k, PRow& cur_p, PRow& nxt_p, PRow& nxt2_p) {
+    auto back = [&](auto ph, int k, PRow& cur_p) {
         constexpr int PH = decltype(ph)::value;
         constexpr int b1 = S_DL + ((PH + 1) & 3) * 15, b2 = S_DL + ((PH + 2) & 3) * 15, b3 = S_DL + ((PH + 3) & 3) * 15;
         STAMP(6);
@@ -1329,9 +1336,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #pragma unroll
         for (int c = 0; c < 7; c++) { row[2 * c] = keep * cur_p.x[c].x; row[2 * c + 1] = keep * cur_p.x[c].y; }
         row[14] = keep * cur_p.x[7].x;
-        cur_p = nxt_p;
-        nxt_p = nxt2_p;
-        nxt2_p = load_panel(k - 3);  // three steps ahead (two were not enough under a full batch: +450 cycles / step waiting)
+        cur_p = load_panel(k - 4);   // four steps ahead, into the slot just consumed (slot = k & 3: no register rotation)
 #pragma unroll
         for (int c = 0; c < 15; c++) S[bw_off + c] = row[c];
         WSYNC();
@@ -1373,13 +1378,13 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         STAMP(10);
     };
     {
-        PRow cur_p = load_panel(n4 - 1), nxt_p = load_panel(n4 - 2), nxt2_p = load_panel(n4 - 3);
+        PRow p3 = load_panel(n4 - 1), p2 = load_panel(n4 - 2), p1 = load_panel(n4 - 3), p0 = load_panel(n4 - 4);
 #pragma unroll 1
         for (int k = n4 - 1; k >= 3; k -= 4) {
-            back(IC<3>{}, k, cur_p, nxt_p, nxt2_p);
-            back(IC<2>{}, k - 1, cur_p, nxt_p, nxt2_p);
-            back(IC<1>{}, k - 2, cur_p, nxt_p, nxt2_p);
-            back(IC<0>{}, k - 3, cur_p, nxt_p, nxt2_p);
+            back(IC<3>{}, k, p3);
+            back(IC<2>{}, k - 1, p2);
+            back(IC<1>{}, k - 2, p1);
+            back(IC<0>{}, k - 3, p0);
         }
     }
 #ifdef VF_SOLVE_STAMPS

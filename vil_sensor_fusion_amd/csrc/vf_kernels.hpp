@@ -88,6 +88,7 @@ struct View {
     double* mp_out;     // [2][B][28]   L d + eta (27) and the cost 0.5 d^T L d + eta^T d
     double* H;          // [G][4][15][15]      block d of row k = H[k][k-d]
     double* gvec;       // [G][15]
+    double* zrow;       // [900] zeros
     double* delta;      // [G][15]
     double* Lp;         // [G][43][16]         Cholesky panels (15 of 16 columns used)
     // partitioned solve (allocated when P >= 2)

@@ -820,7 +820,13 @@ int vf_engine_read_panels(vf_engine* e, int window, int k0, int n, double* panel
     if (rc) return rc;
     if (n == 0 || !panels) return VF_OK;
     HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(panels, e->v.Lp + ((size_t)window * e->v.M + k0) * vf::PANEL, (size_t)n * vf::PANEL * sizeof(double), hipMemcpyDeviceToHost));
+    // device layout [8 column pairs][43 rows][2] -> the documented [43][16]
+    std::vector<double> raw((size_t)n * vf::PANEL);
+    HIPCHK(hipMemcpy(raw.data(), e->v.Lp + ((size_t)window * e->v.M + k0) * vf::PANEL, raw.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int k = 0; k < n; k++)
+        for (int r = 0; r < 43; r++)
+            for (int c = 0; c < 16; c++)
+                panels[(size_t)k * vf::PANEL + r * 16 + c] = raw[(size_t)k * vf::PANEL + ((size_t)(c >> 1) * 43 + r) * 2 + (c & 1)];
     return VF_OK;
 }
 

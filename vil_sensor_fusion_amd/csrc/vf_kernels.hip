@@ -875,7 +875,11 @@ VF_DI double readlane_d(double x, int lane) {
 // stall every step on the in-flight HBM prefetch); a compiler barrier + lgkmcnt(0) is enough.
 // Sequential in k, hence latency-bound; see DESIGN.md "K4" for the measured cycle budget.
 constexpr int LDW = 61;
-constexpr int PSTR = 16;                 // doubles per panel row in HBM (15 used): one 128-B line
+// Panel of one keyframe in HBM: [8 column pairs][43 rows][2] doubles (the 16th column is padding).  Lane = row, so one
+// 16-byte store / load instruction of the sweeps covers 43 x 16 contiguous bytes (6 lines) -- with a row per 128-B line
+// every instruction touched 43 different lines, 16 bytes of each.
+constexpr int PROWS = 43;
+VF_DI size_t panel_idx(int row, int col) { return ((size_t)(col >> 1) * PROWS + row) * 2 + (col & 1); }
 constexpr int S_WD = 0;                  // LDS map (doubles)
 constexpr int S_GD = 60 * LDW;           // 3660: rhs, circular
 constexpr int S_DUMP = S_GD + 64;        // write sink for masked-off lanes (never read)
@@ -1171,14 +1175,14 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #pragma unroll
         for (int c = 0; c < 15; c++) S[pw_off + PH * RSLOT + c] = p[c];
         if (lane >= 15 && lane < 58 && pivot_real(k)) {
-            d2_t* Lk = (d2_t*)(Lbase + (size_t)kf_of(k) * PANEL + (size_t)(lane - 15) * PSTR);
+            d2_t* Lk = (d2_t*)(Lbase + (size_t)kf_of(k) * PANEL) + (lane - 15);   // chunk c of this row: Lk[c * PROWS]
 #pragma unroll
 #ifdef VF_K4_NT
-            for (int c = 0; c < 7; c++) { d2_t t; t.x = p[2 * c]; t.y = p[2 * c + 1]; __builtin_nontemporal_store(t, Lk + c); }
-            d2_t t; t.x = p[14]; t.y = 0.0; __builtin_nontemporal_store(t, Lk + 7);
+            for (int c = 0; c < 7; c++) { d2_t t; t.x = p[2 * c]; t.y = p[2 * c + 1]; __builtin_nontemporal_store(t, Lk + c * PROWS); }
+            d2_t t; t.x = p[14]; t.y = 0.0; __builtin_nontemporal_store(t, Lk + 7 * PROWS);
 #else
-            for (int c = 0; c < 7; c++) { d2_t t; t.x = p[2 * c]; t.y = p[2 * c + 1]; Lk[c] = t; }
-            d2_t t; t.x = p[14]; t.y = 0.0; Lk[7] = t;
+            for (int c = 0; c < 7; c++) { d2_t t; t.x = p[2 * c]; t.y = p[2 * c + 1]; Lk[c * PROWS] = t; }
+            d2_t t; t.x = p[14]; t.y = 0.0; Lk[7 * PROWS] = t;
 #endif
         }
         WSYNC();
@@ -1318,9 +1322,9 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     auto load_panel = [=](int k) {   // not a real pivot: any valid panel is loaded and zeroed at use (no use here: no stall)
         PRow r;
         const bool ok = k >= 0 && k < cnt && pivot_real(k);
-        const d2_t* Lk = (const d2_t*)(Lbase + (size_t)(ok ? kf_of(k) : 0) * PANEL + (size_t)(lane < 43 ? lane : 0) * PSTR);
+        const d2_t* Lk = (const d2_t*)(Lbase + (size_t)(ok ? kf_of(k) : 0) * PANEL) + (lane < 43 ? lane : 0);
 #pragma unroll
-        for (int c = 0; c < 8; c++) r.x[c] = Lk[c];
+        for (int c = 0; c < 8; c++) r.x[c] = Lk[c * PROWS];
         return r;
     };
     const int bw_off = lane < 28 ? S_P + lane * 15 : S_DUMP + 16;
@@ -1637,7 +1641,7 @@ __global__ void __launch_bounds__(256) k_chunk_rhs(View v) {
             s1 = fma(Vr[j + 1], dl[j + 1], s1);
             s2 = fma(Vr[j + 2], dl[j + 2], s2);
         }
-        v.Lp[(base + k) * PANEL + 27 * 16 + a] -= (s0 + s1) + s2;
+        v.Lp[(base + k) * PANEL + panel_idx(27, a)] -= (s0 + s1) + s2;
     }
 }
 

@@ -14,7 +14,7 @@ constexpr int PRIOR_IN = 31;    // mean state (16), sigma (15)
 constexpr int PRIOR_OUT = 240;  // r(15), J(15x15)
 constexpr int NBLK = 4;         // band blocks stored per keyframe (bandwidth 3 + diagonal)
 constexpr int HROW = NBLK * 225;
-constexpr int PANEL = 43 * 16;  // Cholesky panel in HBM: 43 rows (27 sub-diagonal, rhs, 15 of L^-T), one 128-B line each
+constexpr int PANEL = 43 * 16;  // Cholesky panel in HBM: 43 rows (27 sub-diagonal, rhs, 15 of L^-T) x 16 columns, stored [8 column pairs][43][2]
 // partitioned solve (K4p): a window is cut into P chunks joined by 27-dof separators.  With the profile
 // [k: 15][k+1: 15][k+2: pose 6][k+3: pose 6], everything in front of a cut keyframe b couples to the rest only
 // through  S = { b: 15 dof, pose(b+1): 6, pose(b+2): 6 }  (the 27 sub-diagonal rows of keyframe b-1's panel);

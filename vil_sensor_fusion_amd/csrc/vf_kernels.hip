@@ -1331,66 +1331,93 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     const int col = lane < 15 ? lane : 0;
     const int dl_w = (lane >= 28 && lane < 43) ? S_DL + lane - 28 : S_DUMP + 32 + lane;
     WSYNC();
-    auto back = [&](auto ph, int k, PRow& cur_p) {
-        constexpr int PH = decltype(ph)::value;
-        constexpr int b1 = S_DL + ((PH + 1) & 3) * 15, b2 = S_DL + ((PH + 2) & 3) * 15, b3 = S_DL + ((PH + 3) & 3) * 15;
+    // Software-pipelined: the recursion delta_{k+1} -> delta_k runs on registers only --
+    //   s = y - part - sum_a P[a][.] delta_{k+1}[a]   (delta_{k+1} = the previous step's x, broadcast by v_readlane)
+    //   x = L_kk^-T s                                  (s broadcast by v_readlane)
+    // while everything that does not depend on delta_{k+1} is prepared one step ahead (`prep`): the panel rows of the
+    // next keyframe go through LDS into per-column registers, and the couplings to the two keyframes further on
+    // (12 pose columns, increments already in LDS) are summed into `part`.  The step was 3 LDS round trips and an HBM
+    // wait in sequence (about 2 600 cycles for 200 instructions); LDS accesses of one wave execute in issue order, so
+    // the write -> read hand-offs below need a compiler barrier, not a wait.
+#define CBAR() asm volatile("" ::: "memory")
+    struct Col { double row[15], pv[15], y, part; };   // of one keyframe: its L^-T row (lanes 28..42), column data (lanes 0..14)
+    auto prep = [&](auto ph, int k, PRow& slot, Col& o) {
+        constexpr int PH = decltype(ph)::value;          // = k & 3
+        constexpr int b2 = S_DL + ((PH + 2) & 3) * 15, b3 = S_DL + ((PH + 3) & 3) * 15;
         STAMP(6);
-        double row[15];
-        const double keep = pivot_real(k) ? 1.0 : 0.0;   // identity rows: zero panel
+        const double keep = (k >= 0 && pivot_real(k)) ? 1.0 : 0.0;   // identity rows: zero panel
 #pragma unroll
-        for (int c = 0; c < 7; c++) { row[2 * c] = keep * cur_p.x[c].x; row[2 * c + 1] = keep * cur_p.x[c].y; }
-        row[14] = keep * cur_p.x[7].x;
-        cur_p = load_panel(k - 4);   // four steps ahead, into the slot just consumed (slot = k & 3: no register rotation)
+        for (int c = 0; c < 7; c++) { o.row[2 * c] = keep * slot.x[c].x; o.row[2 * c + 1] = keep * slot.x[c].y; }
+        o.row[14] = keep * slot.x[7].x;
+        slot = load_panel(k - 4);    // four steps ahead, into the slot just consumed (slot = k & 3: no register rotation)
 #pragma unroll
-        for (int c = 0; c < 15; c++) S[bw_off + c] = row[c];
-        WSYNC();
+        for (int c = 0; c < 15; c++) S[bw_off + c] = o.row[c];
+        CBAR();
         STAMP(7);
-        double s;
-        {
-            double pv[27], dv[27];
 #pragma unroll
-            for (int a = 0; a < 27; a++) pv[a] = S[S_P + a * 15 + col];
+        for (int a = 0; a < 15; a++) o.pv[a] = S[S_P + a * 15 + col];
+        double q[12], d[12];
 #pragma unroll
-            for (int a = 0; a < 15; a++) dv[a] = S[b1 + a];
+        for (int a = 0; a < 12; a++) q[a] = S[S_P + (15 + a) * 15 + col];
 #pragma unroll
-            for (int a = 0; a < 6; a++) { dv[15 + a] = S[b2 + a]; dv[21 + a] = S[b3 + a]; }
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int a = 0; a < 6; a++) { d[a] = S[b2 + a]; d[6 + a] = S[b3 + a]; }
+        o.y = S[S_P + 27 * 15 + col];
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
 #pragma unroll
-            for (int a = 0; a < 27; a += 3) {
-                s0 = fma(pv[a], dv[a], s0);
-                s1 = fma(pv[a + 1], dv[a + 1], s1);
-                s2 = fma(pv[a + 2], dv[a + 2], s2);
-            }
-            s = S[S_P + 27 * 15 + col] - ((s0 + s1) + s2);
+        for (int a = 0; a < 12; a += 3) {
+            t0 = fma(q[a], d[a], t0);
+            t1 = fma(q[a + 1], d[a + 1], t1);
+            t2 = fma(q[a + 2], d[a + 2], t2);
         }
+        o.part = (t0 + t1) + t2;
+        CBAR();                      // the next prep overwrites these panel rows in LDS
         STAMP(8);
+    };
+    auto solve = [&](auto ph, int k, const Col& c_, double& xprev) {
+        constexpr int PH = decltype(ph)::value;
+        STAMP(9);
+        double s0 = c_.part, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 15; a += 3) {
+            s0 = fma(c_.pv[a], readlane_d(xprev, 28 + a), s0);
+            s1 = fma(c_.pv[a + 1], readlane_d(xprev, 29 + a), s1);
+            s2 = fma(c_.pv[a + 2], readlane_d(xprev, 30 + a), s2);
+        }
+        const double s = c_.y - ((s0 + s1) + s2);
         // x = L^-T s on lanes 28..42 (row c of L^-T in registers), s broadcast by v_readlane
         double x0 = 0.0, x1 = 0.0;
 #pragma unroll
         for (int c = 0; c < 15; c++) {
             const double sc = readlane_d(s, c);
-            if (c & 1) x1 = fma(row[c], sc, x1);
-            else x0 = fma(row[c], sc, x0);
+            if (c & 1) x1 = fma(c_.row[c], sc, x1);
+            else x0 = fma(c_.row[c], sc, x0);
         }
         const double x = x0 + x1;
-        STAMP(9);
-        WSYNC();
         S[(lane >= 28 && lane < 43) ? S_DL + PH * 15 + lane - 28 : dl_w] = x;
         // (head keyframes of a chunk: only their velocity / bias increments are this sweep's; the pose part is the separator's)
         if (lane >= 28 && lane < 43 && pivot_real(k) && !(CH && cg.i0 > 0 && k < 2 && lane < 34)) dbase[(size_t)kf_of(k) * 15 + lane - 28] = x;
-        WSYNC();
+        xprev = x;
         STAMP(10);
     };
     {
         PRow p3 = load_panel(n4 - 1), p2 = load_panel(n4 - 2), p1 = load_panel(n4 - 3), p0 = load_panel(n4 - 4);
+        // increment of the keyframe after the last pivot (slot n4 & 3 = 0): zero, or the separator's / the middle system's
+        double xprev = S[(lane >= 28 && lane < 43) ? S_DL + lane - 28 : S_ZERO];
+        Col ca, cb;
+        prep(IC<3>{}, n4 - 1, p3, ca);
 #pragma unroll 1
         for (int k = n4 - 1; k >= 3; k -= 4) {
-            back(IC<3>{}, k, p3);
-            back(IC<2>{}, k - 1, p2);
-            back(IC<1>{}, k - 2, p1);
-            back(IC<0>{}, k - 3, p0);
+            prep(IC<2>{}, k - 1, p2, cb);
+            solve(IC<3>{}, k, ca, xprev);
+            prep(IC<1>{}, k - 2, p1, ca);
+            solve(IC<2>{}, k - 1, cb, xprev);
+            prep(IC<0>{}, k - 3, p0, cb);
+            solve(IC<1>{}, k - 2, ca, xprev);
+            prep(IC<3>{}, k - 4, p3, ca);
+            solve(IC<0>{}, k - 3, cb, xprev);
         }
     }
+#undef CBAR
 #ifdef VF_SOLVE_STAMPS
     if (w == 0 && lane == 0) for (int i = 0; i < 16; i++) g_stamps[i] = st[i];
 #endif

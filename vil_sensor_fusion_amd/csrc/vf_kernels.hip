@@ -887,13 +887,15 @@ constexpr int S_ZERO = S_DUMP + 96;      // 16 zeros: read source for masked-off
 constexpr int S_ID = S_ZERO + 16;        // 15x15 identity: panel rows of the L^-T lanes
 constexpr int S_P = S_ID + 225;          // panel rows 15..42 at stride 15 (conflict-free column reads)
 constexpr int S_DL = S_P + 43 * 15;      // back-substitution: delta of the 3 following keyframes
-constexpr int S_TOTAL = S_DL + 64;
+constexpr int S_BC = S_DL + 64;          // 16: pivot-block entries of the column just scaled, read back replicated per 16-lane row
+constexpr int S_TOTAL = S_BC + 16;
 // chunk forward sweep with a spike follower (k_chunk_forward): the panel of step k (43 rows x 15, then a
 // zero cell and a write sink) stays in a 4-slot LDS ring for the second wave; two hand-shake cells follow
 constexpr int RING_SLOT = 664;
 constexpr int S_PROG = S_P + 4 * RING_SLOT;   // panels completed by the sweep
 constexpr int S_CONS = S_PROG + 1;            // panels consumed by the follower
-constexpr int S_TOTAL_RING = S_PROG + 8;
+constexpr int S_BC_RING = S_PROG + 8;
+constexpr int S_TOTAL_RING = S_BC_RING + 16;
 #define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define VF_SB() __builtin_amdgcn_sched_barrier(0)
 #ifdef VF_SOLVE_STAMPS   // diagnostic build only (tools/build_stamps.sh); never in the shipped library
@@ -1164,6 +1166,8 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         // panel factorisation: straight-line code in a fixed issue order (tools/gen_pivot.py); a non-positive
         // pivot turns the last reciprocal into NaN / inf, tested once per step
         double pv_inv;
+        const int pv_bcw = lane < 15 ? (RINGM ? S_BC_RING : S_BC) + lane : S_DUMP + 32 + lane;
+        const int pv_bcr = (RINGM ? S_BC_RING : S_BC) + (lane & 15);
 #include "vf_pivot_15.inc"
         if (!(pv_inv < 1e300)) failed = 1;
         STAMP(2);

@@ -43,7 +43,7 @@ struct vf_engine {
     // hipGraph; re-captured when the trial count or any scalar baked into the kernel arguments changes
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
-    int graph_iters = -1;
+    int graph_iters = -1, graph_mode = 0;
     long graph_epoch = -1, epoch = 0;
     bool graph_off = false;
     double* lambda0_dev = nullptr;   // [B] lambda0, the source of the per-solve reset
@@ -61,6 +61,10 @@ struct vf_engine {
     double* sigma_dev = nullptr;
     int* status_dev = nullptr;
     std::vector<int> h_lo, h_hi;  // host mirror of the active ranges
+    // Warm start of vf_engine_iterate: true from the end of a solve until any entry point other than vf_engine_slide
+    // touches the engine; `slid` counts the slides since.  See k_linearize_tail.
+    bool warm = false;
+    int slid = 0;
 
     template <typename T>
     int alloc(T** p, size_t n, bool zero = true) {
@@ -249,6 +253,7 @@ static int check_range(vf_engine* e, int window, int k0, int n) {
 }
 
 int vf_engine_set_range(vf_engine* e, int window, int lo, int hi) {
+    if (e) e->warm = false;
     int rc = check_window(e, window);
     if (rc) return rc;
     if (lo < 0 || hi < lo || hi > e->v.M) return fail(VF_ERR_BAD_KEY, "bad range [%d,%d)", lo, hi);
@@ -261,6 +266,7 @@ int vf_engine_set_range(vf_engine* e, int window, int lo, int hi) {
 }
 
 int vf_engine_set_states(vf_engine* e, int window, int k0, int n, const double* s) {
+    if (e) e->warm = false;
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (!s) return fail(VF_ERR_INVALID, "null states");
@@ -293,6 +299,7 @@ int vf_engine_get_states(vf_engine* e, int window, int k0, int n, double* s) {
 }
 
 int vf_engine_set_imu(vf_engine* e, int window, int k0, int n, const double* rec) {
+    if (e) e->warm = false;
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (!rec) return fail(VF_ERR_INVALID, "null records");
@@ -307,6 +314,7 @@ int vf_engine_set_imu(vf_engine* e, int window, int k0, int n, const double* rec
 }
 
 int vf_engine_set_between(vf_engine* e, int window, int n, const int32_t* a, const int32_t* b, const double* rec) {
+    if (e) e->warm = false;
     int rc = check_window(e, window);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!a || !b || !rec))) return fail(VF_ERR_INVALID, "null argument");
@@ -335,6 +343,7 @@ int vf_engine_set_between(vf_engine* e, int window, int n, const int32_t* a, con
 }
 
 int vf_engine_clear_between(vf_engine* e, int window, int k0, int n) {
+    if (e) e->warm = false;
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (n == 0) return VF_OK;
@@ -344,6 +353,7 @@ int vf_engine_clear_between(vf_engine* e, int window, int k0, int n) {
 }
 
 int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec) {
+    if (e) e->warm = false;
     int rc = check_range(e, window, k, 1);
     if (rc) return rc;
     if (!rec) return fail(VF_ERR_INVALID, "null record");
@@ -358,6 +368,7 @@ int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec) {
 
 int vf_engine_preintegrate(vf_engine* e, int window, int k0, int n, const int32_t* off, const double* steps,
                            const double* bhat, const vf_imu_params* p) {
+    if (e) e->warm = false;
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (!off || !bhat || !p) return fail(VF_ERR_INVALID, "null argument");
@@ -404,6 +415,7 @@ int vf_engine_get_imu(vf_engine* e, int window, int k0, int n, double* rec) {
 
 // ------------------------------------------------------------------ stages
 int vf_engine_linearize(vf_engine* e, int which) {
+    if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     which = which ? 1 : 0;
     // a new linearisation of the CURRENT states invalidates H, g and starts a new solve (no window is converged yet)
@@ -421,6 +433,7 @@ int vf_engine_linearize(vf_engine* e, int which) {
     return VF_OK;
 }
 int vf_engine_assemble(vf_engine* e) {
+    if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     vf::launch_assemble(e->v, e->stream);
     HIPCHK(hipGetLastError());
@@ -433,6 +446,7 @@ static int not_sharded(vf_engine* e, const char* what) {
     return VF_OK;
 }
 int vf_engine_solve(vf_engine* e) {
+    if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (int rc = not_sharded(e, "vf_engine_solve")) return rc;
     vf::launch_band_solve(e->v, e->stream);
@@ -440,12 +454,14 @@ int vf_engine_solve(vf_engine* e) {
     return VF_OK;
 }
 int vf_engine_retract(vf_engine* e) {
+    if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     vf::launch_retract(e->v, e->stream);
     HIPCHK(hipGetLastError());
     return VF_OK;
 }
 int vf_engine_decide(vf_engine* e, int init) {
+    if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (int rc = not_sharded(e, "vf_engine_decide")) return rc;
     vf::launch_decide(e->v, init ? 1 : 0, e->stream);
@@ -456,7 +472,13 @@ static int iterate_sequence(vf_engine* e, int iterations) {
     // every solve starts from lambda0, as a fresh LevenbergMarquardtOptimizer would
     HIPCHK(hipMemcpyAsync(e->v.lambda, e->lambda0_dev, e->v.B * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     int rc;
-    if ((rc = vf_engine_linearize(e, 0))) return rc;
+    const int slid = (e->warm && e->v.sh_G <= 1 && e->slid >= 1 && e->slid <= 8) ? e->slid : 0;
+    if (slid) {
+        // nothing but slides since the last solve: only the appended keyframes' factors and the priors need linearising
+        HIPCHK(hipMemsetAsync(e->v.done, 0, e->v.B * sizeof(int), e->stream));
+        vf::launch_linearize_tail(e->v, slid, e->stream);
+        HIPCHK(hipGetLastError());
+    } else if ((rc = vf_engine_linearize(e, 0))) return rc;
     if ((rc = vf_engine_decide(e, 1))) return rc;
     for (int it = 0; it < iterations; it++) {
         if ((rc = vf_engine_assemble(e))) return rc;
@@ -465,6 +487,8 @@ static int iterate_sequence(vf_engine* e, int iterations) {
         if ((rc = vf_engine_linearize(e, 1))) return rc;
         if ((rc = vf_engine_decide(e, 0))) return rc;
     }
+    e->warm = true;      // (the stage calls above cleared it)
+    e->slid = 0;
     return VF_OK;
 }
 int vf_engine_iterate(vf_engine* e, int iterations) {
@@ -473,7 +497,8 @@ int vf_engine_iterate(vf_engine* e, int iterations) {
     if (int rc0 = not_sharded(e, "vf_engine_iterate")) return rc0;
     // (asynchronous, like the stages: every read-back synchronises the stream)
     if (e->graph_off || !e->own_stream) return iterate_sequence(e, iterations);
-    if (!e->graph_exec || e->graph_iters != iterations || e->graph_epoch != e->epoch) {
+    const int mode = (e->warm && e->v.sh_G <= 1 && e->slid >= 1 && e->slid <= 8) ? e->slid : 0;
+    if (!e->graph_exec || e->graph_iters != iterations || e->graph_epoch != e->epoch || e->graph_mode != mode) {
         e->drop_graph();
         if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             e->graph_off = true;
@@ -490,6 +515,7 @@ int vf_engine_iterate(vf_engine* e, int iterations) {
         }
         e->graph_iters = iterations;
         e->graph_epoch = e->epoch;
+        e->graph_mode = mode;
     }
     HIPCHK(hipGraphLaunch(e->graph_exec, e->stream));
     return VF_OK;
@@ -523,6 +549,7 @@ int vf_shard_range(int n, int chunks, int fit, int rank, int world, int* chunk_l
 
 // ------------------------------------------------------------------ time-sharded windows (multi-GPU)
 int vf_engine_set_stream(vf_engine* e, void* hip_stream) {
+    if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->own_stream && e->stream) HIPCHK(hipStreamDestroy(e->stream));
@@ -532,6 +559,7 @@ int vf_engine_set_stream(vf_engine* e, void* hip_stream) {
     return VF_OK;
 }
 int vf_engine_set_shard(vf_engine* e, int rank, int world) {
+    if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (world < 1 || rank < 0 || rank >= world) return fail(VF_ERR_INVALID, "bad shard %d of %d", rank, world);
     if (world > 1 && (e->v.P < 2 || e->v.P_fit))
@@ -567,6 +595,7 @@ static int check_sharded(vf_engine* e) {
     return VF_OK;
 }
 int vf_engine_solve_local(vf_engine* e) {
+    if (e) e->warm = false;
     int rc = check_sharded(e);
     if (rc) return rc;
     vf::launch_partitioned_local(e->v, e->stream);
@@ -574,6 +603,7 @@ int vf_engine_solve_local(vf_engine* e) {
     return VF_OK;
 }
 int vf_engine_solve_global(vf_engine* e) {
+    if (e) e->warm = false;
     int rc = check_sharded(e);
     if (rc) return rc;
     vf::launch_partitioned_global(e->v, e->stream);
@@ -582,18 +612,21 @@ int vf_engine_solve_global(vf_engine* e) {
     return VF_OK;
 }
 int vf_engine_decide_partial(vf_engine* e, int init) {
+    if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     vf::launch_decide_mode(e->v, init ? 1 : 0, 1, e->stream);
     HIPCHK(hipGetLastError());
     return VF_OK;
 }
 int vf_engine_decide_total(vf_engine* e, int init) {
+    if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     vf::launch_decide_mode(e->v, init ? 1 : 0, 2, e->stream);
     HIPCHK(hipGetLastError());
     return VF_OK;
 }
 int vf_engine_set_convergence(vf_engine* e, double rel_tol, double abs_tol) {
+    if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (!(rel_tol >= 0.0) || !(abs_tol >= 0.0)) return fail(VF_ERR_INVALID, "tolerances must be >= 0");
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -611,6 +644,7 @@ int vf_engine_reset_lambda(vf_engine* e) {
 }
 
 int vf_engine_predict(vf_engine* e, int window, int k0, int n) {
+    if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (window >= e->v.B || k0 < 1 || n < 0 || k0 + n > e->v.M) return fail(VF_ERR_BAD_KEY, "bad predict range");
     if (n == 0) return VF_OK;
@@ -620,6 +654,7 @@ int vf_engine_predict(vf_engine* e, int window, int k0, int n) {
 }
 
 int vf_engine_marginalize(vf_engine* e) {
+    if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (int rc = not_sharded(e, "vf_engine_marginalize")) return rc;
     for (int w = 0; w < e->v.B; w++)
@@ -635,6 +670,7 @@ int vf_engine_marginalize(vf_engine* e) {
 }
 
 int vf_engine_drop_oldest(vf_engine* e) {
+    if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     for (int w = 0; w < e->v.B; w++) {
         if (e->h_hi[w] - e->h_lo[w] < 2) return fail(VF_ERR_INVALID, "window %d too short", w);
@@ -650,10 +686,13 @@ int vf_engine_slide(vf_engine* e, const double* prior_sigma15, int marginalize) 
     if (!e || !prior_sigma15) return fail(VF_ERR_INVALID, "null argument");
     for (int w = 0; w < e->v.B; w++)
         if (e->h_hi[w] >= e->v.M) return fail(VF_ERR_CAPACITY, "window %d has no free keyframe slot", w);
+    const bool was_warm = e->warm;
     if (marginalize) {
         int rc = vf_engine_marginalize(e);
         if (rc) return rc;
     }
+    e->warm = was_warm;       // a slide is the one change a warm start knows how to follow
+    if (e->warm) e->slid++;
     HIPCHK(hipMemcpyAsync(e->sigma_dev, prior_sigma15, 15 * sizeof(double), hipMemcpyHostToDevice, e->stream));
     vf::launch_slide(e->v, e->sigma_dev, marginalize ? 0 : 1, e->stream);
     HIPCHK(hipGetLastError());
@@ -676,6 +715,7 @@ int vf_engine_read_marginal(vf_engine* e, int window, int* on, double* xbar48, d
 // Move the live keyframes [shift, M) of every window to [0, M - shift): frees `shift` slots at the
 // end.  shift must be a multiple of 64 (whole AoSoA tiles) and <= every window's lo.
 int vf_engine_compact(vf_engine* e, int shift) {
+    if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     vf::View& v = e->v;
     if (shift <= 0 || shift % 64 != 0 || shift >= v.M) return fail(VF_ERR_INVALID, "shift must be a positive multiple of 64 below the capacity");
@@ -844,6 +884,7 @@ int vf_engine_read_lm(vf_engine* e, int window, double* cost, double* lambda, in
 
 // ------------------------------------------------------------------ measurement
 int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms) {
+    if (e) e->warm = false;
     if (!e || !avg_ms || reps < 1) return fail(VF_ERR_INVALID, "bad argument");
     vf::View tv = e->v;
     tv.stop_on = 0;           // stage timings are of the full work, whatever the windows' convergence flags say
@@ -875,6 +916,7 @@ int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms) {
 }
 
 int vf_engine_time_iterate(vf_engine* e, int iterations, float* ms) {
+    if (e) e->warm = false;
     if (!e || !ms) return fail(VF_ERR_INVALID, "bad argument");
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipEventRecord(e->ev0, e->stream));

@@ -582,8 +582,9 @@ __global__ void k_linearize_prior(View v, int which) {
 // running an 80 us latency chain; as the first workgroups of K2's grid they hide behind the between factors
 __global__ void __launch_bounds__(256) k_linearize_between_prior(View v, int which, int nb_pri) {
     const int bx = blockIdx.x;
-    if (bx < nb_pri) linearize_prior_window(v, which, bx * 256 + (int)threadIdx.x);
-    else linearize_between_factor(v, which, (long)(bx - nb_pri) * 256 + threadIdx.x);
+    if (bx < nb_pri) {      // one wave of windows per workgroup: four such chains on one CU ran 1.6 x longer
+        if (threadIdx.x < 64) linearize_prior_window(v, which, bx * 64 + (int)threadIdx.x);
+    } else linearize_between_factor(v, which, (long)(bx - nb_pri) * 256 + threadIdx.x);
 }
 // K1 + K2 + K2b in ONE launch, for few windows (latency form): with a handful of windows each of the three kernels
 // is a single latency chain (27 / 9 / 13 us), so running them side by side saves two of the three; for large
@@ -593,6 +594,27 @@ __global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_all(View
     if (bx < nb_imu) linearize_imu_factor(v, which, (long)bx * VF_K1_BLOCK + threadIdx.x);
     else if (bx < nb_imu + nb_btw) linearize_between_factor(v, which, (long)(bx - nb_imu) * VF_K1_BLOCK + threadIdx.x);
     else linearize_prior_window(v, which, (bx - nb_imu - nb_btw) * VF_K1_BLOCK + (int)threadIdx.x);
+}
+
+// Warm start of a fixed-lag update (vf_engine_slide directly after a solve): the linearisation of every factor that was
+// in the window is still the one of the current states (an accepted trial's records became current with its states, a
+// rejected one left both alone), so only the factors of the `nslid` appended keyframes and the priors (the marginal prior
+// has just changed) are linearised.  H and g are then stale only at the two ends of a window whose last trial was
+// rejected: fresh[w] = 1 + nslid tells k_assemble to redo just those tiles (fresh[w] = 1: all of them).
+__global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_tail(View v, int nslid) {
+    const int bx = blockIdx.x, t = threadIdx.x;
+    if (bx < v.B) {
+        if (t < nslid) linearize_imu_factor(v, 0, (long)bx * v.M + v.hi[bx] - 1 - t);
+    } else if (bx < 2 * v.B) {
+        const int w = bx - v.B;
+        if (t < nslid) linearize_between_factor(v, 0, (long)w * v.M + v.hi[w] - 1 - t);
+    } else {
+        const int w = (bx - 2 * v.B) * 64 + t;      // one wave of windows per workgroup
+        if (t < 64) {
+            if (w < v.B) v.fresh[w] = v.fresh[w] ? 1 : 1 + nslid;
+            linearize_prior_window(v, 0, w);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------ K3
@@ -642,10 +664,15 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     // unchanged (k_decide clears `fresh` on reject; accept / init / slide set it): such a tile must cost as little
     // as a launch can -- one flag read, no index arithmetic in front of it (an all-rejected batch used to take 0.73 ms)
     const int w = blockIdx.y;
-    if (!v.fresh[w] || window_done(v, w)) return;
+    const int fr = v.fresh[w];
+    if (!fr || window_done(v, w)) return;
     const int k0 = blockIdx.x * AT;
     const long gk0 = (long)w * v.M + k0;
     const int lo = v.lo[w], hi = v.hi[w];
+    // warm start (k_linearize_tail): fr = 1 + appended keyframes; only rows near the ends of the window changed --
+    // head: the marginal prior / the factors that left with the oldest keyframe reach rows lo .. lo+3;
+    // tail: a new factor at slot b touches rows b-3 .. b
+    if (fr >= 2 && fr < 64 && k0 >= lo + 4 && k0 + AT <= hi - (fr - 1) - 4) return;
     int rlo, rhi;                            // rows of H this rank assembles (absolute slots)
     own_range(v, w, rlo, rhi);
     rlo += lo;
@@ -2026,7 +2053,7 @@ __global__ void __launch_bounds__(1024) k_decide(View v, int init, int mode) {
         if (init) {
             v.cost[w] = c;
             v.fail[w] = 0;
-            v.fresh[w] = 1;
+            if (!(v.fresh[w] >= 2 && v.fresh[w] < 64)) v.fresh[w] = 1;   // (a warm start has marked the window "ends only")
             if (v.stop_on) v.done[w] = 0;
         } else {
             const bool ok = (v.fail[w] == 0) && (c < v.cost[w]);
@@ -2291,8 +2318,11 @@ void launch_linearize_between(const View& v, int which, hipStream_t s) {
     hipLaunchKernelGGL(k_linearize_between, dim3(nblk(v.G, 256)), dim3(256), 0, s, v, which);
 }
 void launch_linearize_between_prior(const View& v, int which, hipStream_t s) {
-    const int nb_pri = (int)nblk(v.B, 256);
+    const int nb_pri = (int)nblk(v.B, 64);
     hipLaunchKernelGGL(k_linearize_between_prior, dim3(nblk(v.G, 256) + nb_pri), dim3(256), 0, s, v, which, nb_pri);
+}
+void launch_linearize_tail(const View& v, int nslid, hipStream_t s) {
+    hipLaunchKernelGGL(k_linearize_tail, dim3(2 * v.B + nblk(v.B, 64)), dim3(VF_K1_BLOCK), 0, s, v, nslid);
 }
 void launch_linearize_prior(const View& v, int which, hipStream_t s) {
     hipLaunchKernelGGL(k_linearize_prior, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, which);

@@ -132,6 +132,7 @@ void launch_linearize_imu(const View& v, int which, hipStream_t s);
 void launch_linearize_between(const View& v, int which, hipStream_t s);
 void launch_linearize_prior(const View& v, int which, hipStream_t s);
 void launch_linearize_between_prior(const View& v, int which, hipStream_t s);   // K2 + K2b in one launch (large batches)
+void launch_linearize_tail(const View& v, int nslid, hipStream_t s);   // warm start: factors of the appended keyframes + priors
 void launch_linearize_all(const View& v, int which, hipStream_t s);   // the three above in one launch (few windows)
 void launch_assemble(const View& v, hipStream_t s);
 void launch_band_solve(const View& v, hipStream_t s);

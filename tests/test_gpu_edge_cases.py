@@ -325,3 +325,29 @@ def test_lm_convergence_exit_matches_oracle(oracle):
         lm = eng.read_lm(w)
         assert lm["accepted"] + lm["rejected"] - before[w]["accepted"] - before[w]["rejected"] == 3
     eng.close()
+
+
+def test_read_panels_layout_known_answer(oracle):
+    """vf_engine_read_panels returns [43][16] per keyframe whatever the packed device layout: for the FIRST keyframe of a
+    window the pivot block is H00 + lambda I itself, so rows 28..42 (L^-T, upper triangular) satisfy
+    U U^T (H00 + lambda I) = I, and row 27 is y = L^-1 (-g0)."""
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    n = 40
+    seq = synth.make_sequence(seed=3, n_kf=n)
+    prob = helpers.build_problem(oracle, seq, perturb=0.01)
+    eng = Engine(EngineOpts(windows=1, capacity=n, chunks=1))
+    helpers.load_engine(eng, 0, prob)
+    eng.linearize(0)
+    eng.decide(init=True)
+    eng.assemble()
+    eng.solve()
+    lam = eng.read_lm(0)["lam"]
+    H, g = eng.read_normal(0, 0, 1)
+    P = eng.read_panels(0, 0, 1)[0]
+    U = P[28:43, :15]
+    assert np.all(np.tril(U, -1) == 0.0)
+    A = H[0, 0] + lam * np.eye(15)
+    A = np.tril(A) + np.tril(A, -1).T
+    np.testing.assert_allclose(U @ U.T @ A, np.eye(15), atol=1e-9)
+    np.testing.assert_allclose(U.T @ (-g[0]), P[27, :15], rtol=1e-9, atol=1e-12)
+    assert np.all(P[:, 15] == 0.0)

@@ -298,7 +298,7 @@ def main():
         alg_bytes = counts["imu"] * IMU_BYTES
         achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
         stages = {s: eng.time_stage(s, reps=5) for s in
-                  ("linearize_imu", "linearize_between", "assemble", "solve", "retract", "decide")}
+                  ("linearize_imu", "linearize_between", "assemble", "assemble_idle", "solve", "retract", "decide")}
         traffic = measured_traffic_per_imu_factor()
         out = {
             "metric": "keyframes/sec fixed-lag update, 1k-pose window; ATE vs GTSAM ref",

@@ -199,6 +199,7 @@ int vf_engine_read_lm(vf_engine* e, int window, double* cost, double* lambda, in
 #define VF_STAGE_SOLVE 4
 #define VF_STAGE_RETRACT 5
 #define VF_STAGE_DECIDE 6
+#define VF_STAGE_ASSEMBLE_IDLE 7   /* K3 when every window's last trial was rejected: nothing to assemble, the cost of its launch */
 int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms);
 /* HIP-event time of a whole vf_engine_iterate(iterations) */
 int vf_engine_time_iterate(vf_engine* e, int iterations, float* ms);

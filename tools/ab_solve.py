@@ -22,5 +22,5 @@ for w in range(B):
     eng.set_range(w, 0, 1); eng.predict(w, 1, N - 1); eng.set_range(w, 0, N)
 eng.linearize(0); eng.decide(init=True); eng.assemble(); eng.sync()
 r = [eng.time_stage('solve', 5) for _ in range(3)]
-a = [eng.time_stage('assemble', 5) for _ in range(3)]
-print(os.path.basename(sys.argv[1]), 'solve ms', ' '.join(f'{x:.3f}' for x in r), ' assemble ms', ' '.join(f'{x:.3f}' for x in a))
+a = [eng.time_stage('assemble', 5) for _ in range(3)] + [eng.time_stage('assemble_idle', 5) for _ in range(2)]
+print(os.path.basename(sys.argv[1]), 'solve ms', ' '.join(f'{x:.3f}' for x in r), ' assemble ms (last two: idle)', ' '.join(f'{x:.3f}' for x in a))

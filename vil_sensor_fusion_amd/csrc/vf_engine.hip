@@ -896,12 +896,14 @@ int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms) {
             case VF_STAGE_SOLVE: vf::launch_band_solve(tv, e->stream); break;
             case VF_STAGE_RETRACT: vf::launch_retract(tv, e->stream); break;
             case VF_STAGE_DECIDE: vf::launch_decide(tv, 1, e->stream); break;
+            case VF_STAGE_ASSEMBLE_IDLE: vf::launch_assemble(tv, e->stream); break;
             default: break;
         }
     };
-    if (stage < VF_STAGE_LINEARIZE_IMU || stage > VF_STAGE_DECIDE) return fail(VF_ERR_INVALID, "unknown stage %d", stage);
+    if (stage < VF_STAGE_LINEARIZE_IMU || stage > VF_STAGE_ASSEMBLE_IDLE) return fail(VF_ERR_INVALID, "unknown stage %d", stage);
     // time the full-work form of K3 (inside iterate() it is skipped for windows whose last trial was rejected)
     if (stage == VF_STAGE_ASSEMBLE) HIPCHK(hipMemsetAsync(e->v.fresh, 0x01, e->v.B * sizeof(int), e->stream));
+    if (stage == VF_STAGE_ASSEMBLE_IDLE) HIPCHK(hipMemsetAsync(e->v.fresh, 0, e->v.B * sizeof(int), e->stream));
     run();  // warm
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipEventRecord(e->ev0, e->stream));
@@ -912,6 +914,7 @@ int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
     *avg_ms = ms / reps;
+    if (stage == VF_STAGE_ASSEMBLE_IDLE) HIPCHK(hipMemsetAsync(e->v.fresh, 0x01, e->v.B * sizeof(int), e->stream));   // H is as it was
     return VF_OK;
 }
 

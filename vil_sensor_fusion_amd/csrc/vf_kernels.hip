@@ -723,6 +723,7 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
             tb[j] = (e < (AT + 3) * BTW_OUT && ks > lo && ks < hi) ? btw_out[((size_t)(gs >> 6) * BTW_OUT + f) * TILE + (gs & 63)] : 0.0;
         }
         if (tid < AT + 3) {
+            LB[tid * LBS + BTW_OUT] = 0.0;       // the pad cell of a slot: the zero the MFMA operand maps point at
             const int ks = k0 + tid;
             int a = -1;
             if (ks > lo && ks < hi) { a = v.btw_a[gk0 + tid]; if (a < lo || a >= ks) a = -1; }
@@ -763,22 +764,19 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
             }
         }
     };
-    // 6-row dot products on a between linearisation in LDS: offsets 6 = Ja, 42 = Jb, 0 = r
-    auto bdot = [&](int sl, int offA, int a, int offB, int bb) {
-        const double* Bq = LB + sl * LBS;
-        double sum = 0.0;
+    // Between-factor terms on the matrix cores as well: a between linearisation in LDS (r: 0, Ja: 6, Jb: 42, 6 rows) is
+    // the 6 x 16 operand X = [J | 0 ... 0 | r] (column 15 = r, like the IMU tiles), rows padded to 8 = two k-steps;
+    // X^T X adds J^T J to the pose block and J^T r to the gradient column of a diagonal tile, Xb^T Xa is the coupling
+    // block.  Per lane: the in-slot offsets of its two operand words (the slot's pad cell = 0 where X has no entry).
+    // (the VALU form, 6-term dot products per entry from LDS, cost 0.5 ms of K3's 2.7; this one about 0.35)
+    int oA[2], oB[2];
 #pragma unroll
-        for (int r6 = 0; r6 < 6; r6++) sum = fma(Bq[offA + r6 * 6 + a], Bq[offB + r6 * 6 + bb], sum);
-        return sum;
-    };
-    auto bdotr = [&](int sl, int offA, int a) {
-        const double* Bq = LB + sl * LBS;
-        double sum = 0.0;
-#pragma unroll
-        for (int r6 = 0; r6 < 6; r6++) sum = fma(Bq[offA + r6 * 6 + a], Bq[r6], sum);
-        return sum;
-    };
-
+    for (int q = 0; q < 2; q++) {
+        const int row = 4 * q + kq;
+        const bool valid = row < 6;
+        oA[q] = !valid ? BTW_OUT : (ci < 6 ? 6 + row * 6 + ci : (ci == 15 ? row : BTW_OUT));
+        oB[q] = !valid ? BTW_OUT : (ci < 6 ? 42 + row * 6 + ci : (ci == 15 ? row : BTW_OUT));
+    }
     d4_t D = {0, 0, 0, 0};
     const int lf0 = K3_KPW * wv;
 #pragma unroll 1
@@ -793,7 +791,19 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
             if (k >= rlo && k < rhi) {
                 const long gk = gk0 + kl;
                 double* Hk = v.H + (size_t)gk * HROW;
-                const bool btw_here = s_a[kl] >= 0;
+                // (accumulated into D itself: separate accumulators added at the end measured 4 % slower)
+                if (s_a[kl] >= 0) {                       // a between factor ends here: Jb^T [Jb | r]
+                    const double x0 = LB[kl * LBS + oB[0]], x1 = LB[kl * LBS + oB[1]];
+                    D = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D, 0, 0, 0);
+                    D = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, D, 0, 0, 0);
+                }
+#pragma unroll
+                for (int d = 1; d <= 3; d++)
+                    if (s_a[kl + d] == k) {               // ... or starts here: Ja^T [Ja | r]
+                        const double x0 = LB[(kl + d) * LBS + oA[0]], x1 = LB[(kl + d) * LBS + oA[1]];
+                        D = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D, 0, 0, 0);
+                        D = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, D, 0, 0, 0);
+                    }
                 const bool is_prior = v.prior_k[w] == k;
                 const double* Pq = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT;
                 const int mo = (v.mp_on[w] && hi - lo >= 3) ? k - lo : 99;   // 0,1,2: rows of the marginal prior
@@ -803,12 +813,6 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
                 for (int r = 0; r < 4; r++) {
                     const int a = kq + 4 * r;
                     double val = D[r];
-                    if (a < 6 && (ci < 6 || ci == 15)) {
-                        if (btw_here) val += ci == 15 ? bdotr(kl, 42, a) : bdot(kl, 42, a, 42, ci);
-#pragma unroll
-                        for (int d = 1; d <= 3; d++)
-                            if (s_a[kl + d] == k) val += ci == 15 ? bdotr(kl + d, 6, a) : bdot(kl + d, 6, a, 6, ci);
-                    }
                     if (is_prior && a < 15) {
                         double sum = 0.0;
                         for (int rr = 0; rr < 15; rr++)
@@ -843,22 +847,33 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
                 const int dk = ak >= 0 ? k - ak : 0;   // 1..3 when a between factor ends here
                 const int mo2 = (v.mp_on[w] && hi - lo >= 3) ? k - lo : 99;
                 const double* ML2 = v.mp_L + (size_t)w * 729;
+                d4_t T = {0, 0, 0, 0};                    // Jb^T Ja of the between factor ending here
+                if (dk >= 1) {
+                    const double b0 = LB[kl * LBS + oB[0]], b1 = LB[kl * LBS + oB[1]];
+                    const double a0 = LB[kl * LBS + oA[0]], a1 = LB[kl * LBS + oA[1]];
+                    T = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, T, 0, 0, 0);
+                    T = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, T, 0, 0, 0);
+                }
                 if (k > lo) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int a = kq + 4 * r;
                         double val = O[r];
-                        if (dk == 1 && a < 6 && ci < 6) val += bdot(kl, 42, a, 6, ci);
+                        if (dk == 1 && a < 6 && ci < 6) val += T[r];
                         if (mo2 == 1 && a < 6 && ci < 15) val += ML2[(15 + a) * 27 + ci];            // (lo+1 pose) x (lo: 15)
                         if (mo2 == 2 && a < 6 && ci < 6) val += ML2[(21 + a) * 27 + 15 + ci];        // (lo+2 pose) x (lo+1 pose)
                         if (a < 15 && ci < 15) __builtin_nontemporal_store(val, Hk + 225 + a * 15 + ci);
                     }
                 }
-                if (lane < 36) {
-                    const int a6 = lane / 6, b6 = lane - a6 * 6;
-                    const double x = (dk >= 2) ? bdot(kl, 42, a6, 6, b6) : 0.0;
-                    Hk[450 + a6 * 15 + b6] = (dk == 2 ? x : 0.0) + (mo2 == 2 ? ML2[(21 + a6) * 27 + b6] : 0.0);
-                    Hk[675 + a6 * 15 + b6] = dk == 3 ? x : 0.0;
+                // pose x pose blocks two and three keyframes back, straight from the MFMA C layout (rows kq + 4 r)
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int a6 = kq + 4 * r;
+                    if (a6 < 6 && ci < 6) {
+                        const double x = T[r];
+                        Hk[450 + a6 * 15 + ci] = (dk == 2 ? x : 0.0) + (mo2 == 2 ? ML2[(21 + a6) * 27 + ci] : 0.0);
+                        Hk[675 + a6 * 15 + ci] = dk == 3 ? x : 0.0;
+                    }
                 }
                 // the marginal prior couples (lo+2 pose) with all 15 dof of lo: columns 6..14 of the
                 // d=2 strip (the solver reads them only for the window's third keyframe)

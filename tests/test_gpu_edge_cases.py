@@ -351,3 +351,31 @@ def test_read_panels_layout_known_answer(oracle):
     np.testing.assert_allclose(U @ U.T @ A, np.eye(15), atol=1e-9)
     np.testing.assert_allclose(U.T @ (-g[0]), P[27, :15], rtol=1e-9, atol=1e-12)
     assert np.all(P[:, 15] == 0.0)
+
+
+@pytest.mark.parametrize("chunks", [1, 0])
+def test_failed_window_does_not_disturb_its_neighbours(oracle, chunks):
+    """A non-positive pivot is no longer replaced inside the pivot chain: the window's factorisation runs on with NaN
+    and is flagged once per step.  The NaN must stay inside that window: its neighbours in the batch give bit for bit
+    what they give in a clean batch, and the failed window keeps its states (every trial rejected)."""
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    n = 48
+    probs = [helpers.build_problem(oracle, synth.make_sequence(60 + w, n), perturb=0.01) for w in range(3)]
+    clean = Engine(EngineOpts(windows=3, capacity=n, chunks=chunks))
+    dirty = Engine(EngineOpts(windows=3, capacity=n, chunks=chunks))
+    for w in range(3):
+        helpers.load_engine(clean, w, probs[w])
+        p = probs[w]
+        if w == 1:
+            p = dict(p); p["states"] = p["states"].copy(); p["states"][7, 5] = np.nan
+        helpers.load_engine(dirty, w, p)
+    before = dirty.get_states(1, 0, n)
+    clean.iterate(4)
+    dirty.iterate(4)
+    for w in (0, 2):
+        assert np.array_equal(clean.get_states(w, 0, n), dirty.get_states(w, 0, n))
+        assert clean.read_lm(w) == dirty.read_lm(w)
+    lm = dirty.read_lm(1)
+    assert lm["accepted"] == 0 and lm["rejected"] == 4 and lm["solve_failures"] >= 1
+    after = dirty.get_states(1, 0, n)
+    assert np.array_equal(np.isnan(before), np.isnan(after)) and np.array_equal(before[~np.isnan(before)], after[~np.isnan(after)])

@@ -917,11 +917,14 @@ VF_DI double readlane_d(double x, int lane) {
 // stall every step on the in-flight HBM prefetch); a compiler barrier + lgkmcnt(0) is enough.
 // Sequential in k, hence latency-bound; see DESIGN.md "K4" for the measured cycle budget.
 constexpr int LDW = 61;
-// Panel of one keyframe in HBM: [8 column pairs][43 rows][2] doubles (the 16th column is padding).  Lane = row, so one
-// 16-byte store / load instruction of the sweeps covers 43 x 16 contiguous bytes (6 lines) -- with a row per 128-B line
-// every instruction touched 43 different lines, 16 bytes of each.
+// Panel of one keyframe in HBM: 7 column pairs [pair][43 rows][2] doubles, then column 14 alone [43 rows].  Lane = row,
+// so one 16-byte store / load instruction of the sweeps covers 43 x 16 contiguous bytes (6 lines) -- with a row per
+// 128-B line every instruction touched 43 different lines, 16 bytes of each.  (K4 moves its 17 GB per solve at 5.3 TB/s
+// under a full batch: the padding column a 16-double row carried was 6 % of the panel bytes.)
 constexpr int PROWS = 43;
-VF_DI size_t panel_idx(int row, int col) { return ((size_t)(col >> 1) * PROWS + row) * 2 + (col & 1); }
+constexpr int PLAST = 7 * PROWS * 2;     // offset of column 14
+static_assert(PLAST + PROWS <= PANEL && PANEL % 2 == 0, "panel layout");
+VF_DI size_t panel_idx(int row, int col) { return col < 14 ? ((size_t)(col >> 1) * PROWS + row) * 2 + (col & 1) : (size_t)PLAST + row; }
 constexpr int S_WD = 0;                  // LDS map (doubles)
 constexpr int S_GD = 60 * LDW;           // 3660: rhs, circular
 constexpr int S_DUMP = S_GD + 64;        // write sink for masked-off lanes (never read)
@@ -1225,10 +1228,10 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #pragma unroll
 #ifdef VF_K4_NT
             for (int c = 0; c < 7; c++) { d2_t t; t.x = p[2 * c]; t.y = p[2 * c + 1]; __builtin_nontemporal_store(t, Lk + c * PROWS); }
-            d2_t t; t.x = p[14]; t.y = 0.0; __builtin_nontemporal_store(t, Lk + 7 * PROWS);
+            __builtin_nontemporal_store(p[14], Lbase + (size_t)kf_of(k) * PANEL + PLAST + (lane - 15));
 #else
             for (int c = 0; c < 7; c++) { d2_t t; t.x = p[2 * c]; t.y = p[2 * c + 1]; Lk[c * PROWS] = t; }
-            d2_t t; t.x = p[14]; t.y = 0.0; Lk[7 * PROWS] = t;
+            Lbase[(size_t)kf_of(k) * PANEL + PLAST + (lane - 15)] = p[14];
 #endif
         }
         WSYNC();
@@ -1370,7 +1373,9 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         const bool ok = k >= 0 && k < cnt && pivot_real(k);
         const d2_t* Lk = (const d2_t*)(Lbase + (size_t)(ok ? kf_of(k) : 0) * PANEL) + (lane < 43 ? lane : 0);
 #pragma unroll
-        for (int c = 0; c < 8; c++) r.x[c] = Lk[c * PROWS];
+        for (int c = 0; c < 7; c++) r.x[c] = Lk[c * PROWS];
+        r.x[7].x = Lbase[(size_t)(ok ? kf_of(k) : 0) * PANEL + PLAST + (lane < 43 ? lane : 0)];
+        r.x[7].y = 0.0;
         return r;
     };
     const int bw_off = lane < 28 ? S_P + lane * 15 : S_DUMP + 16;

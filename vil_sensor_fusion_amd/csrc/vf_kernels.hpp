@@ -14,12 +14,7 @@ constexpr int PRIOR_IN = 31;    // mean state (16), sigma (15)
 constexpr int PRIOR_OUT = 240;  // r(15), J(15x15)
 constexpr int NBLK = 4;         // band blocks stored per keyframe (bandwidth 3 + diagonal)
 constexpr int HROW = NBLK * 225;
-constexpr int PANEL = 43 * 16;  // Cholesky panel in HBM: 43 rows (27 sub-diagonal, rhs, 15 of L^-T) x 16 columns, stored [8 column pairs][43][2]
-// partitioned solve (K4p): a window is cut into P chunks joined by 27-dof separators.  With the profile
-// [k: 15][k+1: 15][k+2: pose 6][k+3: pose 6], everything in front of a cut keyframe b couples to the rest only
-// through  S = { b: 15 dof, pose(b+1): 6, pose(b+2): 6 }  (the 27 sub-diagonal rows of keyframe b-1's panel);
-// the velocity / bias dof of b+1 and b+2 are the first interior dof of the NEXT chunk, which therefore starts
-// at keyframe b+1 with two keyframes whose pose rows are pinned (identity rows).
+constexpr int PANEL = 646;      // Cholesky panel in HBM: 43 rows (27 sub-diagonal, rhs, 15 of L^-T) x 15 columns = 645 doubles, stored [7 column pairs][43][2] + [43] (+1: 16-byte alignment)
 constexpr int SEP = 27;
 constexpr int SEPM = SEP * 28;  // 27x27 block + right-hand side column
 constexpr int SEPL = SEP * 64;  // factor of one separator elimination, column-major [27][64]: L (27 rows), Z (27), y

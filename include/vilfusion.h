@@ -109,7 +109,12 @@ int vf_engine_solve(vf_engine* e);
 int vf_engine_retract(vf_engine* e);
 int vf_engine_decide(vf_engine* e, int init);
 /* `iterations` LM trials (linearize once, then {assemble, solve, retract, linearize(trial),
- * decide} per trial).  Replaces ISAM2::update + calculateEstimate (GraphManager.cpp:126-127). */
+ * decide} per trial).  Replaces ISAM2::update + calculateEstimate (GraphManager.cpp:126-127).
+ * Warm start: when nothing but vf_engine_slide has touched the engine since the previous
+ * vf_engine_iterate, the opening linearisation covers only the appended keyframes' factors and
+ * the priors, and the first assembly only the ends of windows whose last trial was rejected --
+ * every other record, H row and g entry is still the one of the current states.  Results are
+ * bit-identical to a cold start (which any other mutating call brings back). */
 int vf_engine_iterate(vf_engine* e, int iterations);
 /* ---- time-sharded windows (one window spread over the GPUs of a node; no reference code: the reference
  * is a single process.  SURVEY.md 8e / BASELINE.json configs[4]) ----

@@ -14,6 +14,7 @@ share nothing on the data path ("scaling": "weak", windows per GPU fixed).
 
 Beside the contract fields the line carries, all measured outside the timed region of `value`:
   roofline               K1 (the Jacobian kernel) from HIP events on the engine's stream, PMC traffic from profiles/
+  roofline_solve         the same for K4, the kernel that takes most of a step
   stage_ms               one launch of every hot-path kernel
   with_convergence_exit  the same update with GTSAM's LM termination rule on (windows stop taking trials)
   time_sharded_window    ONE 10 000-pose window spread in time over all ranks (BASELINE configs[4])
@@ -327,6 +328,19 @@ def main():
             "stage_ms": stages,
             "lm_state_window0": eng.read_lm(0),
         }
+        # the kernel that takes most of a step: K4 (banded Cholesky solve), HBM-bound under a full batch.  Algorithmic
+        # bytes per keyframe: the band of H it needs (630 doubles) + g + the panel written by the forward sweep and
+        # read back by the backward one (645 doubles each way) + the increment.
+        k4_bytes_per_kf = 8 * (630 + 15 + 645 + 645 + 15)
+        n_kf = args.windows * args.window
+        k4_ach = n_kf * k4_bytes_per_kf / (stages["solve"] * 1e-3) / 1e9
+        out["roofline_solve"] = {"kernel": "k_band_solve (K4: damped block-banded Cholesky factorisation + both substitutions)",
+                                 "bound": "hbm", "achieved": k4_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": k4_ach / HBM_PEAK_GBPS, "avg_launch_ms": stages["solve"],
+                                 "algorithmic_bytes_per_keyframe": k4_bytes_per_kf,
+                                 "algorithmic_bytes_per_launch": n_kf * k4_bytes_per_kf,
+                                 "frac_of_measured_copy_peak_6290": k4_ach / 6290.0,
+                                 "traffic_note": "profiles/*_pmc_summary.md: k_band_solve read 2*FETCH_SIZE + WRITE_SIZE per launch"}
         if conv is not None:
             out["with_convergence_exit"] = conv
         if sharded is not None:

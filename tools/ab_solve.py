@@ -23,4 +23,5 @@ for w in range(B):
 eng.linearize(0); eng.decide(init=True); eng.assemble(); eng.sync()
 r = [eng.time_stage('solve', 5) for _ in range(3)]
 a = [eng.time_stage('assemble', 5) for _ in range(3)] + [eng.time_stage('assemble_idle', 5) for _ in range(2)]
-print(os.path.basename(sys.argv[1]), 'solve ms', ' '.join(f'{x:.3f}' for x in r), ' assemble ms (last two: idle)', ' '.join(f'{x:.3f}' for x in a))
+k1 = [eng.time_stage('linearize_imu', 10) for _ in range(3)]
+print(os.path.basename(sys.argv[1]), 'K1 ms', ' '.join(f'{x:.3f}' for x in k1), ' solve ms', ' '.join(f'{x:.3f}' for x in r), ' assemble ms (last two: idle)', ' '.join(f'{x:.3f}' for x in a))

@@ -17,7 +17,8 @@ eng.linearize(0); eng.decide(init=True); eng.assemble(); eng.sync()
 print('B', B, 'solve ms', eng.time_stage('solve', 3))
 st = (C.c_ulonglong * 16)()
 _lib.lib().vf_debug_solve_stamps(st)
-names = ['loop top', 'fetch issue+panel LDS load', 'pivot chain', 'P write + panel store', 'schur mfma+wb', 'commit_row', 'bs: top', 'bs: rows->LDS', 'bs: column sums', 'bs: L^-T matvec', 'bs: store']
+names = ['loop top', 'fetch issue+panel LDS load', 'pivot chain', 'P write + panel store', 'schur mfma+wb', 'commit_row', 'bs: between steps', 'bs prep: rows->LDS (+ panel wait)', 'bs prep: column data + far couplings', 'bs: (prep -> solve)', 'bs solve: register chain + store']
+# (the stamps carry scheduling barriers: the prep of step k-1 and the solve of step k overlap in the shipped build)
 tot = sum(st)
 for i, nme in enumerate(names):
     print(f'{nme:28s} {st[i]/N:9.1f} cycles/step  {100*st[i]/tot:5.1f}%')

@@ -645,6 +645,15 @@ __host__ __device__ constexpr bool imu_field_is_zero(int f) {
 #ifndef VF_K3_NT
 #define VF_K3_NT 256
 #endif
+// bit b of word w: field 32 w + b of a factor's (r | J) record exists and is not a structural zero
+__host__ __device__ constexpr unsigned imu_nz_word(int w) {
+    unsigned m = 0;
+    for (int bit = 0; bit < 32; bit++) {
+        const int f = 32 * w + bit;
+        if (f < IMU_OUT && !imu_field_is_zero(f)) m |= 1u << bit;
+    }
+    return m;
+}
 constexpr int AT = VF_K3_AT;    // keyframes per block
 constexpr int K3_NT = VF_K3_NT; // threads per block
 constexpr int K3_KPW = AT / (K3_NT / 64);   // keyframes per wave
@@ -695,11 +704,20 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
         const int k = k0 + fac;
         const bool ok = k > lo && k < hi;
         const double* src = imu_out + (size_t)(gk0 >> 6) * IMU_OUT * TILE + (gk0 & 63) + fac;
+        // A third of J is structurally zero and is not read.  Which fields a thread skips is a compile-time bit mask
+        // per iteration, tested with the thread's field-group bit (evaluating imu_field_is_zero(f) per load, with its
+        // divisions, was about 50 instructions per load in front of the loads); a skipped or out-of-window load is not
+        // predicated either: it reads the engine's row of zeros (one cached line), so the loads are unconditional.
+        // (2.57 -> 2.45 ms, 176 -> 132 VGPRs; the same treatment of the 2 + 4 other loads per thread measured no gain)
+        static_assert(NG <= 32 && 32 % NG == 0, "field groups per mask word");
         double tj[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const int f = it * NG + fg;
-            tj[it] = (ok && f < IMU_OUT && !imu_field_is_zero(f)) ? src[(size_t)f * TILE] : 0.0;   // a third of J is structurally zero
+            const unsigned wordm = imu_nz_word((it * NG) >> 5);                    // compile-time
+            const bool nz = (wordm >> (((it * NG) & 31) + fg)) & 1u;
+            const double* p = (ok && nz) ? src + (size_t)f * TILE : v.zrow;
+            tj[it] = *p;
         }
         // factor k0+16 (its i-side feeds H[k0+15][k0+15]); it may live in the next AoSoA tile
         const int k16 = k0 + AT;

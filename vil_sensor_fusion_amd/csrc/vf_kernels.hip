@@ -661,6 +661,18 @@ static_assert(K3_KPW * (K3_NT / 64) == AT && K3_NT % AT == 0, "K3 tiling");
 constexpr int LJS = 465;        // LDS stride of one factor's (r | J), odd
 constexpr int LBS = 79;         // LDS stride of one between linearisation (78 + pad), odd
 
+#ifdef VF_SOLVE_STAMPS   // diagnostic build only: phase time stamps of one workgroup of K3 (tools/k3_stamps_probe.py)
+__device__ unsigned long long g_k3_stamps[8];
+#define K3STAMP(i) do { if (blockIdx.x == 40 && blockIdx.y == (gridDim.y >> 1) && threadIdx.x == 0) { unsigned long long _t; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); g_k3_stamps[i] = _t; } } while (0)
+#else
+#define K3STAMP(i) do {} while (0)
+#endif
+#ifdef VF_SOLVE_STAMPS
+__device__ unsigned long long g_k3_loop[8];
+#define K3LOOP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _t; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); k3acc[i] += _t - k3prev; k3prev = _t; } while (0)
+#else
+#define K3LOOP(i) do {} while (0)
+#endif
 #ifdef VF_K3_WPE
 __attribute__((amdgpu_waves_per_eu(VF_K3_WPE, VF_K3_WPE)))
 #endif
@@ -689,6 +701,7 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     if (v.sh_G > 1 && rhi + 2 <= hi) rhi += 2;   // tail rows of the rank's last chunk (see shard_skips_factor)
     else if (v.sh_G > 1) rhi = hi;
     if (k0 + AT <= rlo || k0 >= rhi) return; // no owned active keyframe in this tile (uniform)
+    K3STAMP(0);
     const int b = v.sel[w];
     const size_t tiles = (size_t)(v.G >> 6);
     const double* imu_out = v.imu_out + (size_t)b * tiles * IMU_OUT * TILE;
@@ -740,6 +753,7 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
             const long gs = gk0 + sl;
             tb[j] = (e < (AT + 3) * BTW_OUT && ks > lo && ks < hi) ? btw_out[((size_t)(gs >> 6) * BTW_OUT + f) * TILE + (gs & 63)] : 0.0;
         }
+        K3STAMP(1);   // all loads issued
         if (tid < AT + 3) {
             LB[tid * LBS + BTW_OUT] = 0.0;       // the pad cell of a slot: the zero the MFMA operand maps point at
             const int ks = k0 + tid;
@@ -763,9 +777,11 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
             if (e < (AT + 3) * BTW_OUT) { const int sl = e / BTW_OUT; LB[sl * LBS + (e - sl * BTW_OUT)] = tb[j]; }
         }
     }
+    K3STAMP(2);   // own loads landed, LDS written
     __syncthreads();
+    K3STAMP(3);   // everybody's
 
-    const int wv = tid >> 6, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave-uniform: the keyframe loop and its tests stay scalar
     const int ci = lane & 15, kq = lane >> 4;
     const int colI = ci < 15 ? 15 + imu_col(0, ci) : -1, colJ = ci < 15 ? 15 + imu_col(1, ci) : -1;
     auto load_ops = [&](int lf, double (&ai)[4], double (&aj)[4]) {
@@ -795,29 +811,35 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
         oA[q] = !valid ? BTW_OUT : (ci < 6 ? 6 + row * 6 + ci : (ci == 15 ? row : BTW_OUT));
         oB[q] = !valid ? BTW_OUT : (ci < 6 ? 42 + row * 6 + ci : (ci == 15 ? row : BTW_OUT));
     }
+#ifdef VF_SOLVE_STAMPS
+    unsigned long long k3acc[8] = {0}, k3prev = __builtin_amdgcn_s_memtime();
+#endif
     d4_t D = {0, 0, 0, 0};
     const int lf0 = K3_KPW * wv;
 #pragma unroll 1
     for (int lf = lf0; lf <= lf0 + K3_KPW; lf++) {
+        K3LOOP(0);
         double ai[4], aj[4];
         load_ops(lf, ai, aj);
+        K3LOOP(1);    // operands of factor lf in registers
         if (lf > lf0) {
             // ---- finish keyframe kf = lf-1: D += Ji^T Ji of factor lf, add 6x6 terms, store
 #pragma unroll
             for (int q = 0; q < 4; q++) D = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[q], ai[q], D, 0, 0, 0);
+            K3LOOP(2);    // Ji^T Ji issued
             const int kl = lf - 1, k = k0 + kl;
             if (k >= rlo && k < rhi) {
                 const long gk = gk0 + kl;
                 double* Hk = v.H + (size_t)gk * HROW;
                 // (accumulated into D itself: separate accumulators added at the end measured 4 % slower)
-                if (s_a[kl] >= 0) {                       // a between factor ends here: Jb^T [Jb | r]
+                if (__builtin_amdgcn_readfirstlane(s_a[kl]) >= 0) {   // a between factor ends here: Jb^T [Jb | r]
                     const double x0 = LB[kl * LBS + oB[0]], x1 = LB[kl * LBS + oB[1]];
                     D = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D, 0, 0, 0);
                     D = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, D, 0, 0, 0);
                 }
 #pragma unroll
                 for (int d = 1; d <= 3; d++)
-                    if (s_a[kl + d] == k) {               // ... or starts here: Ja^T [Ja | r]
+                    if (__builtin_amdgcn_readfirstlane(s_a[kl + d]) == k) {   // ... or starts here: Ja^T [Ja | r]
                         const double x0 = LB[(kl + d) * LBS + oA[0]], x1 = LB[(kl + d) * LBS + oA[1]];
                         D = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D, 0, 0, 0);
                         D = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, D, 0, 0, 0);
@@ -849,6 +871,7 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
                 }
             }
         }
+        K3LOOP(3);        // diagonal tile finished and stored
         if (lf < lf0 + K3_KPW) {
             // ---- keyframe kf = lf: off-diagonal block Jj^T Ji, pose-only blocks, start D = Jj^T Jj
             d4_t O = {0, 0, 0, 0};
@@ -861,7 +884,7 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
             const int kl = lf, k = k0 + kl;
             if (k >= rlo && k < rhi) {
                 double* Hk = v.H + (size_t)(gk0 + kl) * HROW;
-                const int ak = s_a[kl];
+                const int ak = __builtin_amdgcn_readfirstlane(s_a[kl]);
                 const int dk = ak >= 0 ? k - ak : 0;   // 1..3 when a between factor ends here
                 const int mo2 = (v.mp_on[w] && hi - lo >= 3) ? k - lo : 99;
                 const double* ML2 = v.mp_L + (size_t)w * 729;
@@ -902,6 +925,15 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
             }
         }
     }
+    K3LOOP(4);        // off-diagonal part
+#ifdef VF_SOLVE_STAMPS
+    if (blockIdx.x == 40 && blockIdx.y == (gridDim.y >> 1) && threadIdx.x == 0) for (int i = 0; i < 8; i++) g_k3_loop[i] = k3acc[i];
+#endif
+    K3STAMP(4);       // wave 0: MFMAs done, stores issued
+#ifdef VF_SOLVE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    K3STAMP(5);       // ... and acknowledged
+#endif
 }
 
 
@@ -2006,6 +2038,14 @@ __global__ void __launch_bounds__(256) k_sep_solve(View v) {
 extern "C" int vf_debug_sep_stamps(unsigned long long* out) {
     (void)hipDeviceSynchronize();
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sep_stamps), 16 * sizeof(unsigned long long));
+}
+extern "C" int vf_debug_k3_stamps(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k3_stamps), 8 * sizeof(unsigned long long));
+}
+extern "C" int vf_debug_k3_loop(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k3_loop), 8 * sizeof(unsigned long long));
 }
 extern "C" int vf_debug_solve_stamps(unsigned long long* out) {
     (void)hipDeviceSynchronize();

@@ -19,7 +19,7 @@
 //
 // Mapping: one lane per factor / keyframe for K1-K3,K5 (HBM-bound, coalesced AoSoA tiles of 64:
 // lane l of a wave reads word l of a 512-byte field row), one 64-lane wave per window or per
-// chunk for K4 / K4p (latency-bound; panel factorisation in registers with v_readlane broadcasts,
+// chunk for K4 / K4p (panel factorisation in registers with v_readlane / DPP broadcasts,
 // trailing window in LDS, Schur / spike products on v_mfma_f64_16x16x4).
 #include "vf_kernels.hpp"
 #include "vf_math.hpp"
@@ -953,19 +953,25 @@ VF_DI double readlane_d(double x, int lane) {
 //    43..57  identity  -> after the column operations these rows hold L_kk^-T
 // (the rhs row makes the forward substitution free, the identity rows turn the back substitution
 // into a mat-vec instead of a 15-step triangular chain).
-//   * panel factorisation in registers: pivots/multipliers broadcast with v_readlane, 1/sqrt by
-//     v_rsq_f64 + 2 Newton steps; the next pivot's rsq chain is started as soon as its column has
-//     been updated, so it overlaps the remaining rank-1 updates of the current column;
+//   * panel factorisation in registers, as generated straight-line code in a fixed issue order (tools/gen_pivot.py,
+//     vf_pivot_15.inc): the chain pivot c -> c+1 (scale, v_readlane the multiplier, update, v_readlane the next pivot,
+//     v_rsq_f64 + one third-order correction) interleaved with the other columns' updates -- the two nearest by
+//     v_readlane broadcasts issued one ahead of their use, the rest by one v_fmac_f64_dpp row_newbcast each; a
+//     non-positive pivot shows as NaN / inf in the last reciprocal, tested once per step;
 //   * Schur update of the trailing 28x27 block (27 active rows + rhs) = C - P P^T on the matrix
-//     cores: 3 lower tiles x 4 k-steps of v_mfma_f64_16x16x4, operands straight from the LDS panel;
+//     cores: 3 lower tiles x 4 k-steps of v_mfma_f64_16x16x4, operands straight from the LDS panel, the trailing
+//     entries as accumulator input (negated A operands), results written back without a read-out pass;
 //   * trailing window: circular 4-keyframe LDS buffer.  The k loop is unrolled by 4 so that the
 //     slot arithmetic ((k+d)&3) is a compile-time constant: every LDS address is a per-lane
-//     constant plus an immediate; the next block row of H is prefetched from HBM one step ahead;
-//   * panel rows 15..57 go to HBM straight from registers, one 128-byte line per lane.
+//     constant plus an immediate; block rows of H are fetched from HBM three steps ahead, unconditionally
+//     (absent blocks come from a row of zeros);
+//   * panel rows 15..57 go to HBM straight from registers, by column pairs (see "Panel" below);
+//   * back substitution software-pipelined: the increment of the previous step stays in registers (v_readlane
+//     broadcasts), everything that does not depend on it is prepared one step ahead.
 // One-wave workgroup: LDS operations of a wave retire in issue order, so cross-lane hand-offs
 // through LDS need no s_barrier and no vmcnt(0) (which __syncthreads() carries and which would
-// stall every step on the in-flight HBM prefetch); a compiler barrier + lgkmcnt(0) is enough.
-// Sequential in k, hence latency-bound; see DESIGN.md "K4" for the measured cycle budget.
+// stall every step on the in-flight HBM prefetch); a compiler barrier (+ lgkmcnt(0) where a value is used) is enough.
+// Sequential in k: latency-bound for one window, HBM-bound (5 TB/s) under a full batch; see DESIGN.md "K4".
 constexpr int LDW = 61;
 // Panel of one keyframe in HBM: 7 column pairs [pair][43 rows][2] doubles, then column 14 alone [43 rows].  Lane = row,
 // so one 16-byte store / load instruction of the sweeps covers 43 x 16 contiguous bytes (6 lines) -- with a row per

@@ -329,9 +329,10 @@ def main():
             "lm_state_window0": eng.read_lm(0),
         }
         # the kernel that takes most of a step: K4 (banded Cholesky solve), HBM-bound under a full batch.  Algorithmic
-        # bytes per keyframe: the band of H it needs (630 doubles) + g + the panel written by the forward sweep and
-        # read back by the backward one (645 doubles each way) + the increment.
-        k4_bytes_per_kf = 8 * (630 + 15 + 645 + 645 + 15)
+        # bytes per keyframe: the band of H it needs (H[k][k-1]: 225, lower triangle of H[k][k]: 120, two 6x6 strips:
+        # 432 doubles) + g + the panel written by the forward sweep and read back by the backward one (645 doubles
+        # each way) + the increment.
+        k4_bytes_per_kf = 8 * (432 + 15 + 645 + 645 + 15)
         n_kf = args.windows * args.window
         k4_ach = n_kf * k4_bytes_per_kf / (stages["solve"] * 1e-3) / 1e9
         out["roofline_solve"] = {"kernel": "k_band_solve (K4: damped block-banded Cholesky factorisation + both substitutions)",

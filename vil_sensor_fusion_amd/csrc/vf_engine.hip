@@ -841,7 +841,28 @@ int vf_engine_read_normal(vf_engine* e, int window, int k0, int n, double* Hband
     if (n == 0) return VF_OK;
     const size_t g0 = (size_t)window * e->v.M + k0;
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (Hband) HIPCHK(hipMemcpy(Hband, e->v.H + g0 * vf::HROW, (size_t)n * vf::HROW * sizeof(double), hipMemcpyDeviceToHost));
+    if (Hband) {
+        // device rows are packed for the solver (vf_kernels.hpp "Block row of H") -> the documented [n][4][15][15]
+        std::vector<double> raw((size_t)n * vf::HROW);
+        HIPCHK(hipMemcpy(raw.data(), e->v.H + g0 * vf::HROW, raw.size() * sizeof(double), hipMemcpyDeviceToHost));
+        std::fill(Hband, Hband + (size_t)n * 900, 0.0);
+        for (int k = 0; k < n; k++) {
+            const double* r = raw.data() + (size_t)k * vf::HROW;
+            double* o = Hband + (size_t)k * 900;
+            for (int a = 0; a < 15; a++)
+                for (int c = 0; c < 15; c++) {
+                    o[a * 15 + c] = r[vf::H_D0 + (a >= c ? vf::h_tri(a, c) : vf::h_tri(c, a))];
+                    o[225 + a * 15 + c] = r[vf::H_D1 + a * 15 + c];
+                }
+            for (int a = 0; a < 6; a++) {
+                for (int c = 0; c < 6; c++) {
+                    o[450 + a * 15 + c] = r[vf::H_D2 + a * 6 + c];
+                    o[675 + a * 15 + c] = r[vf::H_D3 + a * 6 + c];
+                }
+                for (int c = 0; c < 9; c++) o[450 + a * 15 + 6 + c] = r[vf::H_DX + a * 9 + c];
+            }
+        }
+    }
     if (g15) HIPCHK(hipMemcpy(g15, e->v.gvec + g0 * 15, (size_t)n * 15 * sizeof(double), hipMemcpyDeviceToHost));
     return VF_OK;
 }

@@ -865,8 +865,8 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
                         val += ci < 6 ? ML[(ob + a) * 27 + ob + ci] : Mg[ob + a];
                     }
                     if (a < 15) {
-                        if (ci < 15) __builtin_nontemporal_store(val, Hk + a * 15 + ci);
-                        else v.gvec[(size_t)gk * 15 + a] = val;
+                        if (ci <= a) __builtin_nontemporal_store(val, Hk + H_D0 + h_tri(a, ci));   // lower triangle only
+                        else if (ci == 15) v.gvec[(size_t)gk * 15 + a] = val;
                     }
                 }
             }
@@ -903,7 +903,7 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
                         if (dk == 1 && a < 6 && ci < 6) val += T[r];
                         if (mo2 == 1 && a < 6 && ci < 15) val += ML2[(15 + a) * 27 + ci];            // (lo+1 pose) x (lo: 15)
                         if (mo2 == 2 && a < 6 && ci < 6) val += ML2[(21 + a) * 27 + 15 + ci];        // (lo+2 pose) x (lo+1 pose)
-                        if (a < 15 && ci < 15) __builtin_nontemporal_store(val, Hk + 225 + a * 15 + ci);
+                        if (a < 15 && ci < 15) __builtin_nontemporal_store(val, Hk + H_D1 + a * 15 + ci);
                     }
                 }
                 // pose x pose blocks two and three keyframes back, straight from the MFMA C layout (rows kq + 4 r)
@@ -912,15 +912,15 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
                     const int a6 = kq + 4 * r;
                     if (a6 < 6 && ci < 6) {
                         const double x = T[r];
-                        Hk[450 + a6 * 15 + ci] = (dk == 2 ? x : 0.0) + (mo2 == 2 ? ML2[(21 + a6) * 27 + ci] : 0.0);
-                        Hk[675 + a6 * 15 + ci] = dk == 3 ? x : 0.0;
+                        Hk[H_D2 + a6 * 6 + ci] = (dk == 2 ? x : 0.0) + (mo2 == 2 ? ML2[(21 + a6) * 27 + ci] : 0.0);
+                        Hk[H_D3 + a6 * 6 + ci] = dk == 3 ? x : 0.0;
                     }
                 }
                 // the marginal prior couples (lo+2 pose) with all 15 dof of lo: columns 6..14 of the
                 // d=2 strip (the solver reads them only for the window's third keyframe)
                 if (mo2 == 2 && lane < 54) {
                     const int a6 = lane / 9, b9 = 6 + lane - a6 * 9;
-                    Hk[450 + a6 * 15 + b9] = ML2[(21 + a6) * 27 + b9];
+                    Hk[H_DX + a6 * 9 + (b9 - 6)] = ML2[(21 + a6) * 27 + b9];
                 }
             }
         }
@@ -1103,35 +1103,42 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         op0[q] = kc < 15 ? S_P + (lane & 15) * 15 + kc : op_zero;
         op1[q] = (kc < 15 && 31 + (lane & 15) <= 42) ? S_P + (16 + (lane & 15)) * 15 + kc : op_zero;
     }
-    // block-row commit map: idx = lane + 64 j over a 15x15 block -> (a, c); diagonal gets +lambda
+    // block-row commit maps (vf_kernels.hpp "Block row of H"): per lane, where the words it loads go in a slot of the window
+    //   d1: idx = lane + 64 j over the 15x15 block -> (a, c)
     int cm_off[4], cm_srcT[4];
-    double cm_lam[4], cm_one[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int idx = lane + 64 * j, a = idx / 15, c = idx - a * 15;
         const bool in = idx < 225;
         cm_off[j] = in ? a * LDW + c : -1;
-        cm_lam[j] = (in && a == c) ? lam : 0.0;
-        cm_one[j] = (in && a == c) ? 1.0 : 0.0;
         cm_srcT[j] = in ? c * 15 + a : 0;            // transposed read for the reverse sweep
     }
-    int cp_off[2], cp_src[2], cp_srcT[2];            // 6x15 pose-row strips of the d = 2,3 blocks
-    double cp_pose[2], cp_rest[2];
+    //   d0: e = lane + 64 j over the 120 entries of the lower triangle -> (a, c <= a); the diagonal gets +lambda
+    int t0_off[2], t0_a[2], t0_c[2];
+    double t0_lam[2], t0_one[2];
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const int e = lane + 64 * it, a = e / 15, c = e - a * 15;
-        cp_off[it] = e < 90 ? a * LDW + c : -1;
-        cp_src[it] = e < 90 ? a * 15 + c : 0;
-        cp_srcT[it] = (e < 90 && c < 6) ? c * 15 + a : 0;   // reverse sweep: pose x pose block, transposed
-        cp_pose[it] = (e < 90 && c < 6) ? 1.0 : 0.0;    // pose x pose part (between factors)
-        cp_rest[it] = (e < 90 && c >= 6) ? 1.0 : 0.0;   // columns 6..14: only the marginal prior fills them
+    for (int j = 0; j < 2; j++) {
+        const int e = lane + 64 * j;
+        int a = 0;
+        while (h_tri(a + 1, 0) <= e && a < 14) a++;
+        const int c = e - h_tri(a, 0);
+        const bool in = e < 120;
+        t0_a[j] = in ? a : -1;
+        t0_c[j] = in ? c : -2;
+        t0_off[j] = in ? a * LDW + c : -1;
+        t0_lam[j] = (in && a == c) ? lam : 0.0;
+        t0_one[j] = (in && a == c) ? 1.0 : 0.0;
     }
+    //   d2, d3: 6x6 pose x pose (lane < 36); dx: 6x9 (pose) x (velocity / bias), columns 6..14 (lane < 54)
+    const int s6_off = lane < 36 ? (lane / 6) * LDW + lane % 6 : -1;
+    const int s6_srcT = lane < 36 ? (lane % 6) * 6 + lane / 6 : 0;      // reverse sweep: transposed
+    const int x9_off = lane < 54 ? (lane / 9) * LDW + 6 + lane % 9 : -1;
     const double mp_third = (v.mp_on[w] && n >= 3 && !rev && (!CH || cg.i0 == 0)) ? 1.0 : 0.0;
     WSYNC();
 
     // ---- H block row prefetch (HBM -> registers) and commit (registers -> LDS slot) ---------
     // (passed by value: captured-by-reference scalars ended up in scratch memory)
-    struct HRow { double h0[4], h1[4], h2[2], h3[2], hg; };
+    struct HRow { double h0[2], h1[4], h2, h3, hx, hg; };
     const double* __restrict__ Hbase = v.H + base * HROW;
     const double* __restrict__ gbase = v.gvec + base * 15;
     const double* __restrict__ zrow = v.zrow;
@@ -1144,21 +1151,19 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             // unconditional loads: a block that is absent (row outside the window, or reaching in front of it) is read
             // from a row of zeros -- wave-uniform pointer selects instead of per-lane predicates (exec juggling);
             // lanes beyond a block's extent read neighbouring words that commit_row sends to the write sink
-            const double* H0 = real ? Hbase + (size_t)kk * HROW : zrow;
-            const double* H1 = (real && kk >= 1) ? H0 + 225 : zrow;
-            const double* H2 = (real && kk >= 2) ? H0 + 450 : zrow;
-            const double* H3 = (real && kk >= 3) ? H0 + 675 : zrow;
+            const double* Hk = real ? Hbase + (size_t)kk * HROW : zrow;
+            const double* H1 = (real && kk >= 1) ? Hk + H_D1 : zrow;
+            const double* H2 = (real && kk >= 2) ? Hk + H_D2 : zrow;
+            const double* H3 = (real && kk >= 3) ? Hk + H_D3 : zrow;
+            const double* HX = (real && kk == 2 && mp_third > 0.0) ? Hk + H_DX : zrow;   // only the marginal prior fills it
             const double* G0 = real ? gbase + (size_t)kk * 15 : zrow;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                r.h0[j] = H0[lane + 64 * j];
-                r.h1[j] = H1[lane + 64 * j];
-            }
+            for (int j = 0; j < 4; j++) r.h1[j] = H1[lane + 64 * j];
 #pragma unroll
-            for (int it = 0; it < 2; it++) {
-                r.h2[it] = H2[cp_src[it]];
-                r.h3[it] = H3[cp_src[it]];
-            }
+            for (int j = 0; j < 2; j++) r.h0[j] = Hk[H_D0 + lane + 64 * j];
+            r.h2 = H2[lane];
+            r.h3 = H3[lane];
+            r.hx = HX[lane];
             r.hg = G0[lane];   // negated at commit (a use here would stall on vmcnt)
         } else {
             // reversed sequence: block d of row j couples j with j+d = H[j+d][d]^T (pose x pose for d >= 2).
@@ -1171,17 +1176,15 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             const bool l1 = has && back >= 1 && j + 1 >= tsp + 3, l2 = has && back >= 2 && j + 2 >= tsp + 3,
                        l3 = has && back >= 3 && j + 3 >= tsp + 3;
 #pragma unroll
+            for (int jj = 0; jj < 2; jj++) r.h0[jj] = (real && lane + 64 * jj < 120) ? Hj[H_D0 + lane + 64 * jj] : 0.0;   // symmetric: as stored
+#pragma unroll
             for (int jj = 0; jj < 4; jj++) {
                 const bool in = lane + 64 * jj < 225;
-                r.h0[jj] = (in && real) ? Hj[lane + 64 * jj] : 0.0;
-                r.h1[jj] = (in && l1) ? Hj[HROW + 225 + cm_srcT[jj]] : 0.0;
+                r.h1[jj] = (in && l1) ? Hj[HROW + H_D1 + cm_srcT[jj]] : 0.0;
             }
-#pragma unroll
-            for (int it = 0; it < 2; it++) {
-                const bool in = cp_off[it] >= 0 && cp_pose[it] > 0.0;
-                r.h2[it] = (in && l2) ? Hj[2 * HROW + 450 + cp_srcT[it]] : 0.0;
-                r.h3[it] = (in && l3) ? Hj[3 * HROW + 675 + cp_srcT[it]] : 0.0;
-            }
+            r.h2 = (lane < 36 && l2) ? Hj[2 * HROW + H_D2 + s6_srcT] : 0.0;
+            r.h3 = (lane < 36 && l3) ? Hj[3 * HROW + H_D3 + s6_srcT] : 0.0;
+            r.hx = 0.0;
             r.hg = (real && lane < 15) ? gbase[(size_t)j * 15 + lane] : 0.0;
         }
         return r;
@@ -1195,26 +1198,24 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     auto mask_boundary_row = [=](HRow r, int kk) {
         const bool head = CH && cg.i0 > 0 && kk <= 4, tail = CH && cg.has_sep && kk > cg.ni && kk <= cg.ni + 2;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < 2; j++) {            // diagonal block (lower triangle)
+            const int a = t0_a[j], c = t0_c[j];
+            const double ident = a == c ? 1.0 : 0.0;
+            if (head && kk <= 1) r.h0[j] = (a >= 6 && c >= 6) ? r.h0[j] : ident;
+            if (tail) r.h0[j] = (a < 6 && c < 6) ? r.h0[j] : ident;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {            // coupling to the keyframe in front
             const int idx = lane + 64 * j, a = idx / 15, c = idx - a * 15;
             if (head) {
-                const bool vv = a >= 6 && c >= 6;
-                if (kk <= 1) r.h0[j] = vv ? r.h0[j] : ((a == c && idx < 225) ? 1.0 : 0.0);
-                if (kk == 1) r.h1[j] = vv ? r.h1[j] : 0.0;
+                if (kk == 1) r.h1[j] = (a >= 6 && c >= 6) ? r.h1[j] : 0.0;
                 if (kk == 2) r.h1[j] = c >= 6 ? r.h1[j] : 0.0;
             }
-            if (tail) {
-                const bool pp = a < 6 && c < 6;
-                r.h0[j] = pp ? r.h0[j] : ((a == c && idx < 225) ? 1.0 : 0.0);
-                r.h1[j] = (kk == cg.ni + 1 ? a < 6 : pp) ? r.h1[j] : 0.0;
-            }
+            if (tail) r.h1[j] = (kk == cg.ni + 1 ? a < 6 : (a < 6 && c < 6)) ? r.h1[j] : 0.0;
         }
         if (head) {
-#pragma unroll
-            for (int it = 0; it < 2; it++) {
-                if (kk == 2 || kk == 3) r.h2[it] = 0.0;      // pose x pose coupling to a pinned keyframe: carried by the spike
-                if (kk == 3 || kk == 4) r.h3[it] = 0.0;
-            }
+            if (kk == 2 || kk == 3) { r.h2 = 0.0; r.hx = 0.0; }   // pose x pose coupling to a pinned keyframe: carried by the spike
+            if (kk == 3 || kk == 4) r.h3 = 0.0;
             if (kk <= 1 && lane < 6) r.hg = 0.0;
         }
         if (tail && lane >= 6) r.hg = 0.0;
@@ -1228,20 +1229,18 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             if ((cg.i0 > 0 && kk <= 4) || (cg.has_sep && kk > cg.ni && kk <= cg.ni + 2)) r = mask_boundary_row(r_in, kk);
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const bool in = cm_off[j] >= 0;
-            const double d0 = r.h0[j] + (kind == 0 ? cm_lam[j] : (kind == 1 ? cm_one[j] : 0.0));
-            S[in ? S_WD + s * LDW + s + cm_off[j] : S_DUMP + 32 + lane] = d0;
-            S[in ? S_WD + s * LDW + c1 + cm_off[j] : S_DUMP + 32 + lane] = r.h1[j];
+        for (int j = 0; j < 2; j++) {
+            const double d0 = r.h0[j] + (kind == 0 ? t0_lam[j] : (kind == 1 ? t0_one[j] : 0.0));
+            S[t0_off[j] >= 0 ? S_WD + s * LDW + s + t0_off[j] : S_DUMP + 32 + lane] = d0;
         }
-        const double third = kk == 2 ? mp_third : 0.0;
 #pragma unroll
-        for (int it = 0; it < 2; it++) {
-            const double x2 = r.h2[it] * (cp_pose[it] + third * cp_rest[it]), x3 = r.h3[it] * cp_pose[it];
-            const bool in = cp_off[it] >= 0;
-            S[in ? S_WD + s * LDW + c2 + cp_off[it] : S_DUMP + 32 + lane] = x2;
-            S[in ? S_WD + s * LDW + c3 + cp_off[it] : S_DUMP + 32 + lane] = x3;
-        }
+        for (int j = 0; j < 4; j++) S[cm_off[j] >= 0 ? S_WD + s * LDW + c1 + cm_off[j] : S_DUMP + 32 + lane] = r.h1[j];
+        // pose rows against the keyframes two and three back: the 6x6 blocks, and columns 6..14 (zero, but for the
+        // marginal prior's entries in the window's third row): the panel reads whole rows
+        S[s6_off >= 0 ? S_WD + s * LDW + c2 + s6_off : S_DUMP + 32 + lane] = r.h2;
+        S[x9_off >= 0 ? S_WD + s * LDW + c2 + x9_off : S_DUMP + 32 + lane] = r.hx;
+        S[s6_off >= 0 ? S_WD + s * LDW + c3 + s6_off : S_DUMP + 32 + lane] = r.h3;
+        S[x9_off >= 0 ? S_WD + s * LDW + c3 + x9_off : S_DUMP + 32 + lane] = 0.0;
         S[lane < 15 ? S_GD + s + lane : S_DUMP + 32 + lane] = -r.hg;
     };
     const int n4 = cnt;   // pivots of this sweep; identity rows beyond the real ones are eliminated harmlessly
@@ -1595,10 +1594,10 @@ __device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int
         const int kc = j < 15 ? -1 : (j < 21 ? 0 : 1), cc = j < 15 ? j : (j < 21 ? j - 15 : j - 21);
         const int d = kk - kc;
         if (d > 3) return 0.0;
-        if (d == 0) return Hb[(size_t)kk * HROW + a * 15 + cc];                      // own diagonal block: (vel/bias) x pose
-        if (d < 0) return Hb[(size_t)kc * HROW + 225 + cc * 15 + a];                 // kk = 0, kc = 1: H[i0+1][i0] transposed
-        if (d == 1) return Hb[(size_t)kk * HROW + 225 + a * 15 + cc];
-        return (a < 6 && cc < 6) ? Hb[(size_t)kk * HROW + 225 * d + a * 15 + cc] : 0.0;
+        if (d == 0) return Hb[(size_t)kk * HROW + H_D0 + h_tri(a, cc)];              // own diagonal block: (vel/bias) x pose, a > cc
+        if (d < 0) return Hb[(size_t)kc * HROW + H_D1 + cc * 15 + a];                // kk = 0, kc = 1: H[i0+1][i0] transposed
+        if (d == 1) return Hb[(size_t)kk * HROW + H_D1 + a * 15 + cc];
+        return (a < 6 && cc < 6) ? Hb[(size_t)kk * HROW + (d == 2 ? H_D2 : H_D3) + a * 6 + cc] : 0.0;
     };
     d4_t Wa[2], Wb[2], Wcd[2];   // W of keyframes k, k+1 and rows 0..7 of k+2 | k+3 stacked at tile rows 0..7 | 8..15
 #pragma unroll

@@ -12,8 +12,16 @@ constexpr int BTW_IN = 28;      // q(4), t(3), R packed upper (21)
 constexpr int BTW_OUT = 78;     // r(6), Ja(36), Jb(36)
 constexpr int PRIOR_IN = 31;    // mean state (16), sigma (15)
 constexpr int PRIOR_OUT = 240;  // r(15), J(15x15)
-constexpr int NBLK = 4;         // band blocks stored per keyframe (bandwidth 3 + diagonal)
-constexpr int HROW = NBLK * 225;
+// Block row of H of one keyframe k, as the solver reads it (512 doubles, 4 KB):
+//   [H_D1, +225)  H[k][k-1]            15 x 15, row-major
+//   [H_D0, +120)  H[k][k]              LOWER triangle, entry (a, c <= a) at a (a + 1) / 2 + c (the row-per-lane panel of the
+//                                      sweep never uses the upper one)
+//   [H_D2, +36), [H_D3, +36)           H[k][k-2], H[k][k-3]: pose x pose, 6 x 6
+//   [H_DX, +54)   (pose of k) x (velocity / bias of k-2), 6 x 9: filled by the marginal prior for the window's third keyframe
+// (the first layout was four 15 x 15 blocks: the solver fetched 5.2 KB of lines per keyframe for the 3.5 KB it needs)
+constexpr int HROW = 512;
+constexpr int H_D1 = 0, H_D0 = 225, H_D2 = 345, H_D3 = 381, H_DX = 432;
+__host__ __device__ constexpr int h_tri(int a, int c) { return a * (a + 1) / 2 + c; }
 constexpr int PANEL = 646;      // Cholesky panel in HBM: 43 rows (27 sub-diagonal, rhs, 15 of L^-T) x 15 columns = 645 doubles, stored [7 column pairs][43][2] + [43] (+1: 16-byte alignment)
 constexpr int SEP = 27;
 constexpr int SEPM = SEP * 28;  // 27x27 block + right-hand side column

@@ -1309,13 +1309,15 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(n1[q], a0[q], acc1, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(n1[q], a1[q], acc2, 0, 0, 0);
         }
-#pragma unroll
-        for (int r = 0; r < 4; r++) { S[tgt_ph[PH][r]] = acc0[r]; S[tgt_ph[PH][4 + r]] = acc1[r]; S[tgt_ph[PH][8 + r]] = acc2[r]; }
-        WSYNC();
-        STAMP(4);
-        commit_row(ph, pend, row_kind(k + 4), k + 4);  // row k+4 takes the slot the pivot keyframe frees
+        // While the twelve MFMAs run (64 cycles each on this part: the longest stretch of the step that needs no issue
+        // slots), row k+4 is committed to the slot the pivot keyframe frees -- its panel is in registers, the operand and
+        // accumulator reads above are ahead of these writes in the LDS queue, and the write-back below goes to other rows.
+        commit_row(ph, pend, row_kind(k + 4), k + 4);
         pend = pend2;
         pend2 = ahead;
+        STAMP(4);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { S[tgt_ph[PH][r]] = acc0[r]; S[tgt_ph[PH][4 + r]] = acc1[r]; S[tgt_ph[PH][8 + r]] = acc2[r]; }
         WSYNC();
         STAMP(5);
     };

@@ -1254,11 +1254,10 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     commit_row(IC<3>{}, fetch_row(3), row_kind(3), 3);
     WSYNC();
     // ---- one elimination step, phase PH = k & 3 compile-time --------------------------------
-    // `pend`, `pend2` = block rows of keyframes k+4, k+5 (fetched one and two steps ago); this step fetches k+6.
+    // `pend`, `pend2` = block rows of keyframes k+4, k+5 (fetched two steps and one step ago); this step fetches k+6.
     auto step = [&](auto ph, int k, HRow& pend, HRow& pend2) {
         constexpr int PH = decltype(ph)::value;
         STAMP(0);
-        const HRow ahead = fetch_row(k + 6);   // three steps of slack for the HBM round trip
         double p[15];
 #pragma unroll
         for (int c = 0; c < 15; c++) p[c] = S[ri_ph[PH] + c];
@@ -1314,7 +1313,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         // accumulator reads above are ahead of these writes in the LDS queue, and the write-back below goes to other rows.
         commit_row(ph, pend, row_kind(k + 4), k + 4);
         pend = pend2;
-        pend2 = ahead;
+        pend2 = fetch_row(k + 6);              // also in the shadow; two steps of slack for the HBM round trip
         STAMP(4);
 #pragma unroll
         for (int r = 0; r < 4; r++) { S[tgt_ph[PH][r]] = acc0[r]; S[tgt_ph[PH][4 + r]] = acc1[r]; S[tgt_ph[PH][8 + r]] = acc2[r]; }

@@ -379,3 +379,22 @@ def test_failed_window_does_not_disturb_its_neighbours(oracle, chunks):
     assert lm["accepted"] == 0 and lm["rejected"] == 4 and lm["solve_failures"] >= 1
     after = dirty.get_states(1, 0, n)
     assert np.array_equal(np.isnan(before), np.isnan(after)) and np.array_equal(before[~np.isnan(before)], after[~np.isnan(after)])
+
+
+def test_results_do_not_depend_on_the_batch(oracle):
+    """The same window gives bit for bit the same states whether it is alone in an engine or one of several copies
+    in a batch (one sweep per window: chunks=1), and all copies agree with each other."""
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    n = 96
+    prob = helpers.build_problem(oracle, synth.make_sequence(71, n), perturb=0.01)
+    alone = Engine(EngineOpts(windows=1, capacity=n, chunks=1))
+    helpers.load_engine(alone, 0, prob)
+    alone.iterate(4)
+    ref = alone.get_states(0, 0, n)
+    many = Engine(EngineOpts(windows=9, capacity=n, chunks=1))
+    for w in range(9):
+        helpers.load_engine(many, w, prob)
+    many.iterate(4)
+    for w in range(9):
+        assert np.array_equal(many.get_states(w, 0, n), ref), w
+        assert many.read_lm(w) == alone.read_lm(0)

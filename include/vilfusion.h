@@ -120,25 +120,22 @@ int vf_engine_iterate(vf_engine* e, int iterations);
  * is a single process.  SURVEY.md 8e / BASELINE.json configs[4]) ----
  * Every rank holds the whole window (states and factors replicated) in an engine created with the same
  * explicit chunk count (vf_engine_opts.chunks = P, a multiple of the world size).  Rank r owns the chunks
- * [r P / world, (r+1) P / world) and the keyframes they cover: vf_engine_linearize / _assemble then work on
- * the owned keyframes only (plus a 3-keyframe halo of factor linearisations), and one LM trial is
- *     linearize, assemble, solve_local, <all-gather sep_r, sep_s, sep_c>, solve_global, <all-reduce delta>,
- *     retract, linearize(trial), decide_partial, <all-reduce cost_part>, decide_total
- * where the bracketed collectives are the caller's (RCCL over xGMI via torch.distributed in
- * vil_sensor_fusion_amd/distributed.py; the library itself has no communication dependency).  The exchange
- * is the packed separator system: P * 2241 doubles per window per trial; the increment all-reduce is 15
- * doubles per keyframe. */
+ * [r P / world, (r+1) P / world) and the keyframes they cover: vf_engine_linearize then writes the Jacobians
+ * of the owned keyframes' factors only (plus a 5-slot halo) but the residual of EVERY factor, vf_engine_assemble
+ * works on the owned rows, and one LM trial is
+ *     assemble, solve_local, <all-gather sep>, solve_global, <all-reduce delta>, retract, linearize(trial), decide
+ * i.e. TWO collectives, both the caller's (RCCL over xGMI via torch.distributed in
+ * vil_sensor_fusion_amd/distributed.py; the library itself has no communication dependency):
+ *   sep    the packed separator system, one slot of 2248 doubles per (chunk, window) = [27x28 | 27x28 | 27x27] + pad,
+ *          chunk-major, so a rank's chunks are one contiguous slice: an in-place all-gather;
+ *   delta  15 doubles per keyframe slot (non-owned entries zero) followed by one solve-failure flag per window: a sum.
+ * The cost of a trial needs no exchange: every rank has every residual and takes the same accept / reject decision. */
 typedef struct {
     int rank, world, windows, chunks;
-    void* sep_r;            /* device, [chunks][windows][45*46]: rank r writes chunks [r P/world, (r+1) P/world) */
-    void* sep_s;            /* device, [chunks][windows][45*46] */
-    void* sep_c;            /* device, [chunks][windows][45*45] */
-    long sep_rs_per_chunk;  /* doubles per chunk in sep_r / sep_s */
-    long sep_c_per_chunk;   /* doubles per chunk in sep_c */
-    void* delta;            /* device, increments of all keyframe slots; non-owned entries are zero after solve_global */
-    long delta_count;
-    void* cost_part;        /* device, [2][windows]: this rank's share of the cost, its solve-failure flags */
-    long cost_count;
+    void* sep;              /* device, [chunks][windows][2248]: rank r writes chunks [r P/world, (r+1) P/world) */
+    long sep_per_chunk;     /* doubles per chunk in sep (= windows * 2248) */
+    void* delta;            /* device: increments of all keyframe slots (non-owned entries are zero after solve_global), */
+    long delta_count;       /*         then one failure flag per window: capacity * windows * 15 + windows doubles */
 } vf_shard_info;
 /* Geometry of the partitioned solve, host only (no device needed): an n-keyframe window is cut into `count`
  * chunks (<= chunks; fit != 0: also <= sqrt(n)); chunk c = `interior` keyframes from window-local
@@ -152,8 +149,6 @@ int vf_engine_set_shard(vf_engine* e, int rank, int world);
 int vf_engine_shard_info(vf_engine* e, vf_shard_info* out);
 int vf_engine_solve_local(vf_engine* e);    /* chunk sweeps + spikes of the owned chunks */
 int vf_engine_solve_global(vf_engine* e);   /* separator chain, back substitution of the owned chunks, zero the rest of delta */
-int vf_engine_decide_partial(vf_engine* e, int init);
-int vf_engine_decide_total(vf_engine* e, int init);
 int vf_engine_reset_lambda(vf_engine* e);   /* lambda := lambda0, as vf_engine_iterate does before its first trial */
 
 /* Optional LM termination (off by default: vf_engine_iterate runs exactly `iterations` trials).  With a
@@ -282,12 +277,21 @@ int vf_reserve_node(vf_graph* g, double time, uint64_t* key_out);
  * (SensorManagerRos.cpp:99); cov is 6x6 row-major in Pose3 tangent order [rot, trans] */
 int vf_add_between(vf_graph* g, uint64_t prev_key, uint64_t cur_key, const double q_wxyz[4],
                    const double t[3], const double cov36[36]);
+/* GraphManager::addFactor(const CombinedImuFactor&) (GraphManager.cpp:90-94): queue a READY-MADE preintegrated factor
+ * X(key-1),V(key-1),X(key),V(key),B(key-1),B(key) as its 190-double record (layout at the top of this file; e.g. what
+ * vf_get_imu_factor returns) instead of cutting one from the IMU buffer.  key must be the next key (current + 1); the
+ * node time advances by the record's deltaTij. */
+int vf_add_imu_factor(vf_graph* g, uint64_t key, const double* rec190);
 /* GraphManager::solve (GraphManager.cpp:101-141) */
 int vf_solve(vf_graph* g);
 /* GraphManager::getState / getBias / getMostRecentPoseTime (GraphManager.cpp:164-178, 71-75) */
 int vf_get_state(vf_graph* g, double q[4], double t[3], double v[3], double bias[6]);
 int vf_get_bias(vf_graph* g, double bias[6]);
 int vf_most_recent_pose_time(vf_graph* g, double* time, uint64_t* key);
+/* GraphManager::getMostRecentEstimate (GraphManager.cpp:77-81).  The reference never assigns the member it returns
+ * (_mostRecentEstimate, GraphManager.h:109), so this is the default NavState -- identity pose, zero velocity -- always;
+ * use vf_get_state for the estimate. */
+int vf_get_most_recent_estimate(vf_graph* g, double q[4], double t[3], double v[3]);
 /* GraphManager::addOptimizationCallback (GraphManager.cpp:96-99) */
 int vf_set_callback(vf_graph* g, vf_callback cb, void* user);
 /* GraphManager::graph()->size(): factors staged since the last solve (3 priors at start +

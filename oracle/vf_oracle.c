@@ -1120,11 +1120,13 @@ int vfo_marginalize(const vfo_problem* p, int m, vfo_marg* out) {
     return 0;
 }
 
-int vfo_band_solve(int n_kf, int w, const double* Hband, const double* g, double lambda,
-                   double* delta) {
+/* workspace form: L = n_kf*15 x ((w+1)*15) doubles, y = n_kf*15 doubles, owned by the caller (vfo_lm allocates them
+ * once per solve instead of once per trial) */
+static int band_solve_ws(int n_kf, int w, const double* Hband, const double* g, double lambda,
+                         double* delta, double* L, double* y) {
     /* scalar banded Cholesky of (H + lambda I), then delta = -(L L^T)^{-1} g */
     const int n = n_kf * 15, bw = (w + 1) * 15 - 1, ld = bw + 1;
-    double* L = (double*)calloc((size_t)n * ld, sizeof(double));
+    memset(L, 0, sizeof(double) * (size_t)n * ld);
 #define LB(i, j) L[(size_t)(i) * ld + ((j) - (i) + bw)]
     for (int k = 0; k < n_kf; k++)
         for (int d = 0; d <= w && d <= k; d++) {
@@ -1153,7 +1155,6 @@ int vfo_band_solve(int n_kf, int w, const double* Hband, const double* g, double
         }
     }
     if (rc == 0) {
-        double* y = (double*)malloc(sizeof(double) * n);
         for (int i = 0; i < n; i++) {
             int k0 = i - bw > 0 ? i - bw : 0;
             double s = -g[i];
@@ -1166,10 +1167,19 @@ int vfo_band_solve(int n_kf, int w, const double* Hband, const double* g, double
             for (int k = i + 1; k <= k1; k++) s -= LB(k, i) * delta[k];
             delta[i] = s / LB(i, i);
         }
-        free(y);
     }
 #undef LB
+    return rc;
+}
+
+int vfo_band_solve(int n_kf, int w, const double* Hband, const double* g, double lambda,
+                   double* delta) {
+    const size_t n = (size_t)n_kf * 15, ld = (size_t)(w + 1) * 15;
+    double* L = (double*)malloc(sizeof(double) * n * ld);
+    double* y = (double*)malloc(sizeof(double) * n);
+    const int rc = band_solve_ws(n_kf, w, Hband, g, lambda, delta, L, y);
     free(L);
+    free(y);
     return rc;
 }
 
@@ -1183,6 +1193,11 @@ double vfo_lm(vfo_problem* p, const vfo_lm_opts* o, double* costs_out, int* acce
     double* g = (double*)malloc(sizeof(double) * (size_t)n * 15);
     double* d = (double*)malloc(sizeof(double) * (size_t)n * 15);
     double* xs = (double*)malloc(sizeof(double) * (size_t)n * 16);
+    /* buffers of a trial, allocated once per solve: the trial's normal equations and the band solver's workspace */
+    double* Hn = (double*)malloc(sizeof(double) * (size_t)n * (w + 1) * 225);
+    double* gn = (double*)malloc(sizeof(double) * (size_t)n * 15);
+    double* Lws = (double*)malloc(sizeof(double) * (size_t)n * 15 * (size_t)(w + 1) * 15);
+    double* yws = (double*)malloc(sizeof(double) * (size_t)n * 15);
     double lambda = o->lambda0;
     double cost = vfo_assemble(p, w, H, g, o->n_threads);
     if (costs_out) costs_out[0] = cost;
@@ -1193,12 +1208,10 @@ double vfo_lm(vfo_problem* p, const vfo_lm_opts* o, double* costs_out, int* acce
             if (accepted_out) accepted_out[it] = -1;
             continue;
         }
-        int ok = vfo_band_solve(n, w, H, g, lambda, d) == 0, acc = 0;
+        int ok = band_solve_ws(n, w, H, g, lambda, d, Lws, yws) == 0, acc = 0;
         if (ok) {
             memcpy(xs, p->states, sizeof(double) * (size_t)n * 16);
             for (int k = 0; k < n; k++) vfo_retract(xs + 16 * k, d + 15 * k, p->states + 16 * k);
-            double* Hn = (double*)malloc(sizeof(double) * (size_t)n * (w + 1) * 225);
-            double* gn = (double*)malloc(sizeof(double) * (size_t)n * 15);
             double cn = vfo_assemble(p, w, Hn, gn, o->n_threads);
             /* termination (gtsam checkConvergence), also on a rejected trial within the tolerance: the
              * window then sits at its rounding floor */
@@ -1207,11 +1220,10 @@ double vfo_lm(vfo_problem* p, const vfo_lm_opts* o, double* costs_out, int* acce
             if (cn < cost) { /* NaN compares false -> reject */
                 acc = 1;
                 cost = cn;
-                free(H); free(g);
-                H = Hn; g = gn;
+                double* t = H; H = Hn; Hn = t;      /* the trial's normal equations become the current ones */
+                t = g; g = gn; gn = t;
             } else {
                 memcpy(p->states, xs, sizeof(double) * (size_t)n * 16);
-                free(Hn); free(gn);
             }
         }
         if (acc) {
@@ -1225,5 +1237,6 @@ double vfo_lm(vfo_problem* p, const vfo_lm_opts* o, double* costs_out, int* acce
         if (accepted_out) accepted_out[it] = acc;
     }
     free(H); free(g); free(d); free(xs);
+    free(Hn); free(gn); free(Lws); free(yws);
     return lambda;
 }

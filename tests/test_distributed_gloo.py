@@ -67,3 +67,29 @@ def test_shard_windows_properties():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_spawns_one_child_per_gpu(tmp_path):
+    """bench.py --gpus N without WORLD_SIZE starts N fresh ranks with the torch.distributed environment set, forwards the
+    arguments and returns a non-zero status if any rank fails (no GPU needed: the children here are a stub script)."""
+    import argparse
+    import subprocess  # noqa: F401
+    sys.path.insert(0, ROOT)
+    import bench
+    stub = tmp_path / "rank_stub.py"
+    stub.write_text("import os, sys\n"
+                    "open(os.path.join(sys.argv[1], 'rank%s' % os.environ['RANK']), 'w').write(' '.join(\n"
+                    "    [os.environ[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR')] + sys.argv[2:]))\n"
+                    "sys.exit(3 if os.environ['RANK'] == sys.argv[2] else 0)\n")
+    rc = bench.spawn_ranks(argparse.Namespace(gpus=3), script=str(stub), argv=[str(tmp_path), "none", "--steps", "5"])
+    assert rc == 0
+    got = sorted((tmp_path / f"rank{r}").read_text() for r in range(3))
+    assert got == [f"{r} {r} 3 127.0.0.1 none --steps 5" for r in range(3)]
+    assert bench.spawn_ranks(argparse.Namespace(gpus=2), script=str(stub), argv=[str(tmp_path), "1"]) == 3
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and "WORLD_SIZE=1" in res.stderr

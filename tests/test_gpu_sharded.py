@@ -48,6 +48,7 @@ def _worker(rank, world, port, q):
     solver = D.ShardedSolver(eng, dist, "cuda:0", backend="gloo")
     solver.iterate(ITERS)
     torch.cuda.synchronize()
+    assert solver.collectives == 2 * ITERS          # one all-gather + one all-reduce per LM trial, none for the cost
     q.put((rank, eng.get_states(0, 0, N), eng.read_lm(0)))
     D.barrier(dist)
     dist.destroy_process_group()
@@ -107,6 +108,69 @@ def test_single_rank_sharded_solver_equals_engine_iterate():
     assert out[0][1] == out[1][1]
 
 
+def _rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      VF_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    from vil_sensor_fusion_amd import Engine, EngineOpts, distributed as D
+    torch.cuda.set_device(0)
+    dist = D.init(backend="nccl", device_id=torch.device("cuda", 0))
+    assert dist is not None and dist.get_backend() == "nccl"
+    _, prob = _problem()
+    eng = Engine(EngineOpts(windows=1, capacity=N + 8, chunks=CHUNKS))
+    helpers.load_engine(eng, 0, prob)
+    solver = D.ShardedSolver(eng, dist, "cuda:0", backend="nccl")
+    solver.iterate(ITERS)
+    torch.cuda.synchronize()
+    q.put((eng.get_states(0, 0, N), eng.read_lm(0), solver.collectives))
+    D.barrier(dist)
+    dist.destroy_process_group()
+
+
+def test_rccl_code_path_one_rank():
+    """The nccl (= RCCL) branch of the exchange -- in-place all_gather_into_tensor of the packed separator buffer and the
+    all_reduce of [increments | failure flags] on the engine's stream -- on hardware, with a world of one rank
+    (VF_FORCE_DIST=1): same states as vf_engine_iterate, bit for bit, and exactly two collectives per LM trial."""
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    _, prob = _problem()
+    ref = Engine(EngineOpts(windows=1, capacity=N + 8, chunks=CHUNKS))
+    helpers.load_engine(ref, 0, prob)
+    ref.iterate(ITERS)
+    ref_states, ref_lm = ref.get_states(0, 0, N), ref.read_lm(0)
+    ref.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    states, lm, ncoll = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    np.testing.assert_array_equal(states, ref_states)
+    assert lm == ref_lm
+    assert ncoll == 2 * ITERS
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (no WORLD_SIZE): bench.py itself starts two ranks; here they share the box's one GPU and
+    talk over gloo.  The line must say n_gpus 2 and the time-sharded section two collectives per trial."""
+    import json
+    import subprocess
+    env = dict(os.environ, VF_BENCH_BACKEND="gloo", VF_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--windows", "8", "--window", "96", "--steps", "2",
+           "--warmup", "1", "--sharded-window", "1200", "--no-single-window"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    sh = line["time_sharded_window"]
+    assert "error" not in sh, sh
+    assert sh["ranks"] == 2 and sh["collectives_per_trial"] == 2
+    assert sh["collectives_issued"] == 2 * sh["lm_trials_run"] and sh["solve_failures"] == 0
+
+
 def test_shard_errors():
     from vil_sensor_fusion_amd import Engine, EngineOpts
     from vil_sensor_fusion_amd._lib import VilFusionError
@@ -134,7 +198,7 @@ def test_shard_errors():
     eng.set_range(0, 0, 20)
     with pytest.raises(VilFusionError):
         eng.solve_local()                        # 20 keyframes cannot hold 6 chunks
-    for whole_window_call in (lambda: eng.iterate(1), eng.solve, eng.decide, eng.marginalize):
+    for whole_window_call in (lambda: eng.iterate(1), eng.solve, eng.marginalize):
         with pytest.raises(VilFusionError):
             whole_window_call()                  # a shard cannot run whole-window stages on its own
     eng.close()

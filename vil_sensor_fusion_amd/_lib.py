@@ -33,10 +33,8 @@ class ImuParamsC(C.Structure):
 
 class ShardInfoC(C.Structure):
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("windows", C.c_int), ("chunks", C.c_int),
-                ("sep_r", C.c_void_p), ("sep_s", C.c_void_p), ("sep_c", C.c_void_p),
-                ("sep_rs_per_chunk", C.c_long), ("sep_c_per_chunk", C.c_long),
-                ("delta", C.c_void_p), ("delta_count", C.c_long),
-                ("cost_part", C.c_void_p), ("cost_count", C.c_long)]
+                ("sep", C.c_void_p), ("sep_per_chunk", C.c_long),
+                ("delta", C.c_void_p), ("delta_count", C.c_long)]
 
 
 class GraphOptsC(C.Structure):
@@ -64,11 +62,12 @@ SYMBOLS = [
     "vf_engine_preintegrate", "vf_engine_get_imu",
     "vf_engine_marginalize", "vf_engine_drop_oldest", "vf_engine_read_marginal", "vf_engine_compact",
     "vf_engine_set_stream", "vf_engine_set_shard", "vf_engine_shard_info", "vf_engine_solve_local",
-    "vf_engine_solve_global", "vf_engine_decide_partial", "vf_engine_decide_total", "vf_engine_reset_lambda",
+    "vf_engine_solve_global", "vf_engine_reset_lambda",
     "vf_chunk_geometry", "vf_shard_range", "vf_engine_set_convergence",
     "vf_graph_default_opts", "vf_create", "vf_destroy", "vf_add_imu", "vf_reserve_node",
     "vf_add_between", "vf_solve", "vf_get_state", "vf_get_bias", "vf_most_recent_pose_time",
     "vf_set_callback", "vf_graph_staged", "vf_get_trajectory", "vf_get_imu_factor",
+    "vf_add_imu_factor", "vf_get_most_recent_estimate",
     "vf_degeneracy_batch", "vf_dopt_filter_f32",
 ]
 

@@ -34,6 +34,18 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 }  // namespace
 
+struct vf_engine;
+// HIP's current device is per host thread: every entry point that takes an engine makes the engine's device current for
+// the duration of the call (allocations, copies and launches would otherwise go to whatever device the calling thread
+// last used -- e.g. a ROS spinner thread driving a GraphManager on device 1) and restores the caller's on return.
+struct DeviceGuard {
+    int prev = -1, want = -1;
+    explicit DeviceGuard(const vf_engine* e);
+    ~DeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 struct vf_engine {
     vf::View v{};
     vf_engine_opts opts{};
@@ -98,6 +110,13 @@ struct vf_engine {
         return VF_OK;
     }
 };
+
+DeviceGuard::DeviceGuard(const vf_engine* e) {
+    if (!e) return;
+    want = e->opts.device;
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipSetDevice(want); return; }
+    if (prev != want) (void)hipSetDevice(want);
+}
 
 extern "C" {
 
@@ -173,7 +192,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.H, G * vf::HROW);
     AL(v.gvec, G * 15 + 64);      // + slack: the solver's row fetch reads 64 lanes of a 15-double row (the excess is never used)
     AL(v.zrow, vf::HROW);         // a block row of zeros: what the solver fetches for rows outside the window
-    AL(v.delta, G * 15);
+    AL(v.delta, G * 15 + (size_t)v.B);   // + one solve-failure flag per window (time-sharded windows: reduced with the increments)
     AL(v.Lp, G * vf::PANEL);
     // K4 form: chunks = 0 picks it from the batch size: up to 128 windows -> partitioned solve with at
     // most 96 chunks, fewer on short windows (latency form); more windows -> one sweep per window
@@ -186,9 +205,9 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     if (v.P) {
         const size_t BP = (size_t)v.B * v.P;
         AL(v.Vp, G * vf::VROW);
-        AL(v.sepR, BP * vf::SEPM);
-        AL(v.sepS, BP * vf::SEPM);
-        AL(v.sepC, BP * vf::SEP * vf::SEP);
+        AL(v.sepR, BP * vf::SEPK);       // one buffer, slots of [sepR | sepS | sepC] (vf_kernels.hpp "SEPK")
+        v.sepS = v.sepR + vf::SEPM;
+        v.sepC = v.sepR + 2 * vf::SEPM;
         AL(v.sepL, BP * vf::SEPL);
     }
     AL(v.lo, (size_t)v.B);
@@ -201,7 +220,6 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.n_acc, (size_t)v.B);
     AL(v.n_rej, (size_t)v.B);
     AL(v.n_fail, (size_t)v.B);
-    AL(v.cost_part, 2 * (size_t)v.B);
     AL(v.done, (size_t)v.B);
     v.stop_on = 0;
     v.rel_tol = v.abs_tol = 0.0;
@@ -228,6 +246,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
 }
 
 void vf_engine_destroy(vf_engine* e) {
+    DeviceGuard dev_guard_(e);
     if (!e) return;
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     e->drop_graph();
@@ -253,6 +272,7 @@ static int check_range(vf_engine* e, int window, int k0, int n) {
 }
 
 int vf_engine_set_range(vf_engine* e, int window, int lo, int hi) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     int rc = check_window(e, window);
     if (rc) return rc;
@@ -266,6 +286,7 @@ int vf_engine_set_range(vf_engine* e, int window, int lo, int hi) {
 }
 
 int vf_engine_set_states(vf_engine* e, int window, int k0, int n, const double* s) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
@@ -284,6 +305,7 @@ int vf_engine_set_states(vf_engine* e, int window, int k0, int n, const double* 
 }
 
 int vf_engine_get_states(vf_engine* e, int window, int k0, int n, double* s) {
+    DeviceGuard dev_guard_(e);
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (!s) return fail(VF_ERR_INVALID, "null states");
@@ -299,6 +321,7 @@ int vf_engine_get_states(vf_engine* e, int window, int k0, int n, double* s) {
 }
 
 int vf_engine_set_imu(vf_engine* e, int window, int k0, int n, const double* rec) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
@@ -314,6 +337,7 @@ int vf_engine_set_imu(vf_engine* e, int window, int k0, int n, const double* rec
 }
 
 int vf_engine_set_between(vf_engine* e, int window, int n, const int32_t* a, const int32_t* b, const double* rec) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     int rc = check_window(e, window);
     if (rc) return rc;
@@ -343,6 +367,7 @@ int vf_engine_set_between(vf_engine* e, int window, int n, const int32_t* a, con
 }
 
 int vf_engine_clear_between(vf_engine* e, int window, int k0, int n) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
@@ -353,6 +378,7 @@ int vf_engine_clear_between(vf_engine* e, int window, int k0, int n) {
 }
 
 int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     int rc = check_range(e, window, k, 1);
     if (rc) return rc;
@@ -368,6 +394,7 @@ int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec) {
 
 int vf_engine_preintegrate(vf_engine* e, int window, int k0, int n, const int32_t* off, const double* steps,
                            const double* bhat, const vf_imu_params* p) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
@@ -401,6 +428,7 @@ int vf_engine_preintegrate(vf_engine* e, int window, int k0, int n, const int32_
 }
 
 int vf_engine_get_imu(vf_engine* e, int window, int k0, int n, double* rec) {
+    DeviceGuard dev_guard_(e);
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (n == 0 || !rec) return VF_OK;
@@ -415,6 +443,7 @@ int vf_engine_get_imu(vf_engine* e, int window, int k0, int n, double* rec) {
 
 // ------------------------------------------------------------------ stages
 int vf_engine_linearize(vf_engine* e, int which) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     which = which ? 1 : 0;
@@ -423,7 +452,7 @@ int vf_engine_linearize(vf_engine* e, int which) {
         HIPCHK(hipMemsetAsync(e->v.fresh, 0x01, e->v.B * sizeof(int), e->stream));
         HIPCHK(hipMemsetAsync(e->v.done, 0, e->v.B * sizeof(int), e->stream));
     }
-    if (e->v.B <= 128) {
+    if (e->v.B <= 128 || e->v.sh_G > 1) {
         vf::launch_linearize_all(e->v, which, e->stream);       // latency form: K1, K2, K2b side by side
     } else {
         vf::launch_linearize_imu(e->v, which, e->stream);
@@ -433,6 +462,7 @@ int vf_engine_linearize(vf_engine* e, int which) {
     return VF_OK;
 }
 int vf_engine_assemble(vf_engine* e) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     vf::launch_assemble(e->v, e->stream);
@@ -446,6 +476,7 @@ static int not_sharded(vf_engine* e, const char* what) {
     return VF_OK;
 }
 int vf_engine_solve(vf_engine* e) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (int rc = not_sharded(e, "vf_engine_solve")) return rc;
@@ -454,6 +485,7 @@ int vf_engine_solve(vf_engine* e) {
     return VF_OK;
 }
 int vf_engine_retract(vf_engine* e) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     vf::launch_retract(e->v, e->stream);
@@ -461,9 +493,9 @@ int vf_engine_retract(vf_engine* e) {
     return VF_OK;
 }
 int vf_engine_decide(vf_engine* e, int init) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
-    if (int rc = not_sharded(e, "vf_engine_decide")) return rc;
     vf::launch_decide(e->v, init ? 1 : 0, e->stream);
     HIPCHK(hipGetLastError());
     return VF_OK;
@@ -487,22 +519,33 @@ static int iterate_sequence(vf_engine* e, int iterations) {
         if ((rc = vf_engine_linearize(e, 1))) return rc;
         if ((rc = vf_engine_decide(e, 0))) return rc;
     }
-    e->warm = true;      // (the stage calls above cleared it)
-    e->slid = 0;
     return VF_OK;
 }
+// the solve leaves every record, H row and g entry consistent with the current states: the next one may start warm.
+// (set by vf_engine_iterate, not by iterate_sequence: a hipGraph replay never runs the sequence's host code)
+static void mark_solved(vf_engine* e) {
+    e->warm = true;
+    e->slid = 0;
+}
 int vf_engine_iterate(vf_engine* e, int iterations) {
+    DeviceGuard dev_guard_(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (iterations < 0) return fail(VF_ERR_INVALID, "iterations < 0");
     if (int rc0 = not_sharded(e, "vf_engine_iterate")) return rc0;
     // (asynchronous, like the stages: every read-back synchronises the stream)
-    if (e->graph_off || !e->own_stream) return iterate_sequence(e, iterations);
+    if (e->graph_off || !e->own_stream) {
+        const int rc = iterate_sequence(e, iterations);
+        if (!rc) mark_solved(e);
+        return rc;
+    }
     const int mode = (e->warm && e->v.sh_G <= 1 && e->slid >= 1 && e->slid <= 8) ? e->slid : 0;
     if (!e->graph_exec || e->graph_iters != iterations || e->graph_epoch != e->epoch || e->graph_mode != mode) {
         e->drop_graph();
         if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             e->graph_off = true;
-            return iterate_sequence(e, iterations);
+            const int rc = iterate_sequence(e, iterations);
+            if (!rc) mark_solved(e);
+            return rc;
         }
         const int rc = iterate_sequence(e, iterations);
         const hipError_t ce = hipStreamEndCapture(e->stream, &e->graph);
@@ -511,13 +554,16 @@ int vf_engine_iterate(vf_engine* e, int iterations) {
             e->drop_graph();
             e->graph_off = true;          // this runtime cannot capture the sequence: plain launches from now on
             (void)hipGetLastError();
-            return iterate_sequence(e, iterations);
+            const int rc2 = iterate_sequence(e, iterations);
+            if (!rc2) mark_solved(e);
+            return rc2;
         }
         e->graph_iters = iterations;
         e->graph_epoch = e->epoch;
         e->graph_mode = mode;
     }
     HIPCHK(hipGraphLaunch(e->graph_exec, e->stream));
+    mark_solved(e);
     return VF_OK;
 }
 
@@ -549,6 +595,7 @@ int vf_shard_range(int n, int chunks, int fit, int rank, int world, int* chunk_l
 
 // ------------------------------------------------------------------ time-sharded windows (multi-GPU)
 int vf_engine_set_stream(vf_engine* e, void* hip_stream) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -559,6 +606,7 @@ int vf_engine_set_stream(vf_engine* e, void* hip_stream) {
     return VF_OK;
 }
 int vf_engine_set_shard(vf_engine* e, int rank, int world) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (world < 1 || rank < 0 || rank >= world) return fail(VF_ERR_INVALID, "bad shard %d of %d", rank, world);
@@ -572,15 +620,14 @@ int vf_engine_set_shard(vf_engine* e, int rank, int world) {
     return VF_OK;
 }
 int vf_engine_shard_info(vf_engine* e, vf_shard_info* out) {
+    DeviceGuard dev_guard_(e);
     if (!e || !out) return fail(VF_ERR_INVALID, "null argument");
     if (e->v.P < 2) return fail(VF_ERR_INVALID, "engine was not created with the partitioned solve (chunks >= 2)");
     memset(out, 0, sizeof(*out));
     out->rank = e->v.sh_r; out->world = e->v.sh_G; out->windows = e->v.B; out->chunks = e->v.P;
-    out->sep_r = e->v.sepR; out->sep_s = e->v.sepS; out->sep_c = e->v.sepC;
-    out->sep_rs_per_chunk = (long)e->v.B * vf::SEPM;
-    out->sep_c_per_chunk = (long)e->v.B * vf::SEP * vf::SEP;
-    out->delta = e->v.delta; out->delta_count = e->v.G * 15;
-    out->cost_part = e->v.cost_part; out->cost_count = 2L * e->v.B;
+    out->sep = e->v.sepR;
+    out->sep_per_chunk = (long)e->v.B * vf::SEPK;
+    out->delta = e->v.delta; out->delta_count = e->v.G * 15 + e->v.B;
     return VF_OK;
 }
 static int check_sharded(vf_engine* e) {
@@ -595,6 +642,7 @@ static int check_sharded(vf_engine* e) {
     return VF_OK;
 }
 int vf_engine_solve_local(vf_engine* e) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     int rc = check_sharded(e);
     if (rc) return rc;
@@ -603,6 +651,7 @@ int vf_engine_solve_local(vf_engine* e) {
     return VF_OK;
 }
 int vf_engine_solve_global(vf_engine* e) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     int rc = check_sharded(e);
     if (rc) return rc;
@@ -611,21 +660,8 @@ int vf_engine_solve_global(vf_engine* e) {
     HIPCHK(hipGetLastError());
     return VF_OK;
 }
-int vf_engine_decide_partial(vf_engine* e, int init) {
-    if (e) e->warm = false;
-    if (!e) return fail(VF_ERR_INVALID, "engine is null");
-    vf::launch_decide_mode(e->v, init ? 1 : 0, 1, e->stream);
-    HIPCHK(hipGetLastError());
-    return VF_OK;
-}
-int vf_engine_decide_total(vf_engine* e, int init) {
-    if (e) e->warm = false;
-    if (!e) return fail(VF_ERR_INVALID, "engine is null");
-    vf::launch_decide_mode(e->v, init ? 1 : 0, 2, e->stream);
-    HIPCHK(hipGetLastError());
-    return VF_OK;
-}
 int vf_engine_set_convergence(vf_engine* e, double rel_tol, double abs_tol) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (!(rel_tol >= 0.0) || !(abs_tol >= 0.0)) return fail(VF_ERR_INVALID, "tolerances must be >= 0");
@@ -638,12 +674,14 @@ int vf_engine_set_convergence(vf_engine* e, double rel_tol, double abs_tol) {
     return VF_OK;
 }
 int vf_engine_reset_lambda(vf_engine* e) {
+    DeviceGuard dev_guard_(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     HIPCHK(hipMemcpyAsync(e->v.lambda, e->lambda0_dev, e->v.B * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     return VF_OK;
 }
 
 int vf_engine_predict(vf_engine* e, int window, int k0, int n) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (window >= e->v.B || k0 < 1 || n < 0 || k0 + n > e->v.M) return fail(VF_ERR_BAD_KEY, "bad predict range");
@@ -654,6 +692,7 @@ int vf_engine_predict(vf_engine* e, int window, int k0, int n) {
 }
 
 int vf_engine_marginalize(vf_engine* e) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (int rc = not_sharded(e, "vf_engine_marginalize")) return rc;
@@ -670,6 +709,7 @@ int vf_engine_marginalize(vf_engine* e) {
 }
 
 int vf_engine_drop_oldest(vf_engine* e) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     for (int w = 0; w < e->v.B; w++) {
@@ -683,6 +723,7 @@ int vf_engine_drop_oldest(vf_engine* e) {
 }
 
 int vf_engine_slide(vf_engine* e, const double* prior_sigma15, int marginalize) {
+    DeviceGuard dev_guard_(e);
     if (!e || !prior_sigma15) return fail(VF_ERR_INVALID, "null argument");
     for (int w = 0; w < e->v.B; w++)
         if (e->h_hi[w] >= e->v.M) return fail(VF_ERR_CAPACITY, "window %d has no free keyframe slot", w);
@@ -702,6 +743,7 @@ int vf_engine_slide(vf_engine* e, const double* prior_sigma15, int marginalize) 
 }
 
 int vf_engine_read_marginal(vf_engine* e, int window, int* on, double* xbar48, double* L729, double* eta27) {
+    DeviceGuard dev_guard_(e);
     int rc = check_window(e, window);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -715,6 +757,7 @@ int vf_engine_read_marginal(vf_engine* e, int window, int* on, double* xbar48, d
 // Move the live keyframes [shift, M) of every window to [0, M - shift): frees `shift` slots at the
 // end.  shift must be a multiple of 64 (whole AoSoA tiles) and <= every window's lo.
 int vf_engine_compact(vf_engine* e, int shift) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     vf::View& v = e->v;
@@ -777,6 +820,7 @@ int vf_engine_compact(vf_engine* e, int shift) {
 }
 
 int vf_engine_sync(vf_engine* e) {
+    DeviceGuard dev_guard_(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     HIPCHK(hipStreamSynchronize(e->stream));
     return VF_OK;
@@ -790,6 +834,7 @@ static int read_sel(vf_engine* e, int window, int* sel) {
 }
 
 int vf_engine_read_imu_lin(vf_engine* e, int window, int which, int k0, int n, double* r15, double* J450) {
+    DeviceGuard dev_guard_(e);
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (n == 0) return VF_OK;
@@ -812,6 +857,7 @@ int vf_engine_read_imu_lin(vf_engine* e, int window, int which, int k0, int n, d
 }
 
 int vf_engine_read_between_lin(vf_engine* e, int window, int which, int k0, int n, double* r6, double* Ja, double* Jb) {
+    DeviceGuard dev_guard_(e);
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (n == 0) return VF_OK;
@@ -836,6 +882,7 @@ int vf_engine_read_between_lin(vf_engine* e, int window, int which, int k0, int 
 }
 
 int vf_engine_read_normal(vf_engine* e, int window, int k0, int n, double* Hband, double* g15) {
+    DeviceGuard dev_guard_(e);
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (n == 0) return VF_OK;
@@ -868,6 +915,7 @@ int vf_engine_read_normal(vf_engine* e, int window, int k0, int n, double* Hband
 }
 
 int vf_engine_read_delta(vf_engine* e, int window, int k0, int n, double* d) {
+    DeviceGuard dev_guard_(e);
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (n == 0 || !d) return VF_OK;
@@ -877,6 +925,7 @@ int vf_engine_read_delta(vf_engine* e, int window, int k0, int n, double* d) {
 }
 
 int vf_engine_read_panels(vf_engine* e, int window, int k0, int n, double* panels) {
+    DeviceGuard dev_guard_(e);
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (n == 0 || !panels) return VF_OK;
@@ -896,6 +945,7 @@ int vf_engine_read_panels(vf_engine* e, int window, int k0, int n, double* panel
 }
 
 int vf_engine_read_lm(vf_engine* e, int window, double* cost, double* lambda, int* acc, int* rej, int* fails) {
+    DeviceGuard dev_guard_(e);
     int rc = check_window(e, window);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -909,6 +959,7 @@ int vf_engine_read_lm(vf_engine* e, int window, double* cost, double* lambda, in
 
 // ------------------------------------------------------------------ measurement
 int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e || !avg_ms || reps < 1) return fail(VF_ERR_INVALID, "bad argument");
     vf::View tv = e->v;
@@ -944,6 +995,7 @@ int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms) {
 }
 
 int vf_engine_time_iterate(vf_engine* e, int iterations, float* ms) {
+    DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e || !ms) return fail(VF_ERR_INVALID, "bad argument");
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -957,6 +1009,7 @@ int vf_engine_time_iterate(vf_engine* e, int iterations, float* ms) {
 }
 
 int vf_engine_counts(vf_engine* e, int64_t* n_imu, int64_t* n_btw, int64_t* n_kf) {
+    DeviceGuard dev_guard_(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     HIPCHK(hipStreamSynchronize(e->stream));
     std::vector<int> a((size_t)e->v.G);

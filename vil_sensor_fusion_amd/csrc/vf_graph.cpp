@@ -29,6 +29,7 @@ struct PendingImu {            // one queued CombinedImuFactor (GraphManager::_i
     uint64_t key;              // X(key-1) -> X(key)
     std::vector<double> steps; // 7 per step: dt, acc, gyro
     double bias[6];            // getBias() at reserveNode time (GraphManager.cpp:61)
+    std::vector<double> record; // non-empty: a ready-made factor handed in through vf_add_imu_factor (addFactor), 190 doubles
 };
 struct PendingBetween { uint64_t a, b; double rec[VF_BTW_RECORD]; };
 
@@ -218,11 +219,47 @@ int vf_reserve_node(vf_graph* g, double time, uint64_t* key_out) {
         memcpy(p.bias, g->state + 10, sizeof(p.bias));
     }
     cut_imu_segment(g, start, time, p.steps);
+    // a factor without a single IMU step has no covariance: GTSAM would fail at the solve with the factor already in
+    // the graph; here the node is refused and nothing is queued (checked before the key is consumed)
+    if (p.steps.empty()) return gerr(VF_ERR_INDETERMINATE, "reserveNode(%.6f): no IMU measurement in (%.6f, %.6f]", time, start, time);
     g->current_key++;
     g->imu_queue.push_back(std::move(p));
     g->last_pose_time = time;
     g->key_time.push_back(time);
     *key_out = g->current_key;
+    return VF_OK;
+}
+
+int vf_add_imu_factor(vf_graph* g, uint64_t key, const double* rec190) {
+    if (!g || !rec190) return gerr(VF_ERR_INVALID, "null argument");
+    if (!(rec190[0] > 0.0) || !std::isfinite(rec190[0])) return gerr(VF_ERR_INVALID, "imu factor with deltaTij = %g", rec190[0]);
+    for (int i = 0; i < VF_IMU_RECORD; i++)
+        if (!std::isfinite(rec190[i])) return gerr(VF_ERR_INVALID, "imu factor record entry %d is not finite", i);
+    for (int r = 0, o = 70; r < 15; o += 15 - r, r++)          // diagonal of the packed upper-triangular square-root information
+        if (!(rec190[o] > 0.0)) return gerr(VF_ERR_NOT_SPD, "imu factor: square-root information has a non-positive diagonal entry (row %d)", r);
+    std::lock_guard<std::mutex> lk(g->graph_mutex);  // GraphManager.cpp:92
+    if (key != g->current_key + 1)
+        return gerr(VF_ERR_BAD_KEY, "imu factor must end at the next key %llu (got %llu): keys are consecutive", (unsigned long long)(g->current_key + 1), (unsigned long long)key);
+    if (g->opts.lag == 0 && (int)(g->current_key + 1) >= g->opts.capacity) return gerr(VF_ERR_CAPACITY, "keyframe capacity %d exhausted", g->opts.capacity);
+    PendingImu p;
+    p.key = key;
+    memset(p.bias, 0, sizeof(p.bias));
+    p.record.assign(rec190, rec190 + VF_IMU_RECORD);
+    g->current_key++;
+    g->imu_queue.push_back(std::move(p));
+    g->last_pose_time = (g->last_pose_time < 0.0 ? 0.0 : g->last_pose_time) + rec190[0];
+    g->key_time.push_back(g->last_pose_time);
+    return VF_OK;
+}
+
+int vf_get_most_recent_estimate(vf_graph* g, double q[4], double t[3], double v[3]) {
+    if (!g) return gerr(VF_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->graph_mutex);  // GraphManager.cpp:79
+    // The reference never assigns _mostRecentEstimate (GraphManager.h:109; no write in GraphManager.cpp): the member
+    // stays the default NavState -- identity pose, zero velocity -- for the life of the node.  Mirrored as it is.
+    if (q) { q[0] = 1.0; q[1] = q[2] = q[3] = 0.0; }
+    if (t) t[0] = t[1] = t[2] = 0.0;
+    if (v) v[0] = v[1] = v[2] = 0.0;
     return VF_OK;
 }
 
@@ -280,40 +317,81 @@ int vf_solve(vf_graph* g) {
     std::vector<PendingBetween> betweens;
     uint64_t last_key;
     double last_time;
+    int staged_before;
     {
         std::lock_guard<std::mutex> lk(g->graph_mutex);
         imus.swap(g->imu_queue);
         betweens.swap(g->staged_between);
+        staged_before = g->staged_count;
         g->staged_count = 0;  // _graph->resize(0)
         last_key = g->current_key;
         last_time = g->last_pose_time;
     }
     std::lock_guard<std::mutex> sl(g->state_mutex);  // :117
     int rc;
+    // A solve that fails before the optimisation has run must not lose what it took from the queues: every step up to
+    // vf_engine_iterate is idempotent on the device (the same records, predictions and ranges are written again), so
+    // the snapshots go back to the FRONT of the queues and the next vf_solve repeats them.
+    auto give_back = [&](int code) {
+        std::lock_guard<std::mutex> lk(g->graph_mutex);
+        for (auto it = imus.rbegin(); it != imus.rend(); ++it) g->imu_queue.push_front(std::move(*it));
+        g->staged_between.insert(g->staged_between.begin(), betweens.begin(), betweens.end());
+        g->staged_count += staged_before;
+        return code;
+    };
+    // host-side validation first: a between factor whose source keyframe has already left the fixed-lag window (late
+    // odometry) can never be added; it is dropped, the rest is given back, and the caller is told once
+    {
+        const uint64_t oldest = g->key_base + (uint64_t)g->lo;
+        for (size_t i = 0; i < betweens.size(); i++)
+            if (betweens[i].a < oldest) {
+                const unsigned long long a = betweens[i].a, b = betweens[i].b;
+                betweens.erase(betweens.begin() + (long)i);
+                staged_before--;
+                give_back(0);
+                return gerr(VF_ERR_BAD_KEY, "between factor (%llu, %llu) dropped: key %llu left the fixed-lag window (oldest key %llu)",
+                            a, b, a, (unsigned long long)oldest);
+            }
+    }
     // fixed-lag mode: reclaim slots below the window when the new keyframes would not fit
     if (g->opts.lag > 0 && (int)(last_key - g->key_base) + 1 > g->opts.capacity) {
         const int shift = (g->lo / 64) * 64;
-        if (shift <= 0) return gerr(VF_ERR_CAPACITY, "capacity %d too small for lag %d plus the keyframes added per solve", g->opts.capacity, g->opts.lag);
-        if ((rc = vf_engine_compact(g->eng, shift))) return rc;
+        if (shift <= 0) return give_back(gerr(VF_ERR_CAPACITY, "capacity %d too small for lag %d plus the keyframes added per solve", g->opts.capacity, g->opts.lag));
+        if ((rc = vf_engine_compact(g->eng, shift))) return give_back(rc);
         g->lo -= shift;
         g->key_base += shift;
-        if ((int)(last_key - g->key_base) + 1 > g->opts.capacity) return gerr(VF_ERR_CAPACITY, "capacity %d exhausted even after compaction", g->opts.capacity);
+        if ((int)(last_key - g->key_base) + 1 > g->opts.capacity) return give_back(gerr(VF_ERR_CAPACITY, "capacity %d exhausted even after compaction", g->opts.capacity));
     }
     if (!imus.empty()) {
         // K0 on the device for all queued factors, then the initial values by IMU prediction
         // (GraphManager.cpp:150-160).  Keys are consecutive by construction.
         const int n = (int)imus.size();
         const uint64_t k0 = imus.front().key - g->key_base;
-        std::vector<int32_t> off(n + 1, 0);
-        std::vector<double> steps, bias((size_t)n * 6);
-        for (int i = 0; i < n; i++) {
-            off[i + 1] = off[i] + (int)(imus[i].steps.size() / 7);
-            steps.insert(steps.end(), imus[i].steps.begin(), imus[i].steps.end());
-            memcpy(&bias[(size_t)i * 6], imus[i].bias, sizeof(double) * 6);
+        // runs of factors cut from the IMU buffer (reserveNode) are preintegrated on the device in one K0 launch;
+        // ready-made factors (addFactor) are staged as records
+        for (int i = 0; i < n;) {
+            int j = i;
+            const bool ready = !imus[i].record.empty();
+            while (j < n && imus[j].record.empty() == !ready) j++;
+            const int cnt = j - i;
+            if (ready) {
+                std::vector<double> recs((size_t)cnt * VF_IMU_RECORD);
+                for (int l = 0; l < cnt; l++) memcpy(&recs[(size_t)l * VF_IMU_RECORD], imus[i + l].record.data(), sizeof(double) * VF_IMU_RECORD);
+                if ((rc = vf_engine_set_imu(g->eng, 0, (int)k0 + i, cnt, recs.data()))) return give_back(rc);
+            } else {
+                std::vector<int32_t> off(cnt + 1, 0);
+                std::vector<double> steps, bias((size_t)cnt * 6);
+                for (int l = 0; l < cnt; l++) {
+                    off[l + 1] = off[l] + (int)(imus[i + l].steps.size() / 7);
+                    steps.insert(steps.end(), imus[i + l].steps.begin(), imus[i + l].steps.end());
+                    memcpy(&bias[(size_t)l * 6], imus[i + l].bias, sizeof(double) * 6);
+                }
+                if ((rc = vf_engine_preintegrate(g->eng, 0, (int)k0 + i, cnt, off.data(), steps.data(), bias.data(), &g->imu))) return give_back(rc);
+            }
+            i = j;
         }
-        if ((rc = vf_engine_preintegrate(g->eng, 0, (int)k0, n, off.data(), steps.data(), bias.data(), &g->imu))) return rc;
         lap("preintegrate");
-        if ((rc = vf_engine_predict(g->eng, 0, (int)k0, n))) return rc;
+        if ((rc = vf_engine_predict(g->eng, 0, (int)k0, n))) return give_back(rc);
         lap("predict");
     }
     if (!betweens.empty()) {
@@ -329,21 +407,20 @@ int vf_solve(vf_graph* g) {
             b[i] = (int32_t)(betweens[order[i]].b - g->key_base);
             memcpy(&rec[i * VF_BTW_RECORD], betweens[order[i]].rec, sizeof(double) * VF_BTW_RECORD);
         }
-        if ((rc = vf_engine_set_between(g->eng, 0, (int)a.size(), a.data(), b.data(), rec.data()))) return rc;
+        if ((rc = vf_engine_set_between(g->eng, 0, (int)a.size(), a.data(), b.data(), rec.data()))) return give_back(rc);
         lap("set_between");
     }
     // fixed-lag window: marginalise the keyframes that fall out of the lag, one at a time, at the
     // linearisation of the previous solve (their factors have not changed since)
     const int last_slot = (int)(last_key - g->key_base);
-    int lo = g->lo;
-    while (g->opts.lag > 0 && last_slot + 1 - lo > g->opts.lag && (int)(g->solved_key - g->key_base) - lo >= 3) {
-        if ((rc = vf_engine_marginalize(g->eng))) return rc;
-        if ((rc = vf_engine_drop_oldest(g->eng))) return rc;
-        lo++;
+    while (g->opts.lag > 0 && last_slot + 1 - g->lo > g->opts.lag && (int)(g->solved_key - g->key_base) - g->lo >= 3) {
+        if ((rc = vf_engine_marginalize(g->eng))) return give_back(rc);
+        if ((rc = vf_engine_drop_oldest(g->eng))) return give_back(rc);
+        g->lo++;      // (kept in step with the device: a keyframe that has been marginalised stays marginalised)
     }
-    g->lo = lo;
+    const int lo = g->lo;
     lap("marginalize");
-    if ((rc = vf_engine_set_range(g->eng, 0, lo, last_slot + 1))) return rc;
+    if ((rc = vf_engine_set_range(g->eng, 0, lo, last_slot + 1))) return give_back(rc);
     lap("set_range");
     if ((rc = vf_engine_iterate(g->eng, g->opts.iterations))) return rc;   // ISAM2::update + calculateEstimate
     lap("iterate(launch)");

@@ -253,11 +253,15 @@ __global__ void __launch_bounds__(256) k_preintegrate(View v, long g0, int n, co
 #ifndef VF_K1_WAVES
 #define VF_K1_WAVES 1
 #endif
+// SH (time-sharded windows): every rank evaluates the residual of EVERY factor -- the cost of a trial is then known on
+// every rank without an exchange -- but writes the Jacobian only of the factors that feed the rows of H it assembles.
+template <bool SH>
 __device__ __forceinline__ void linearize_imu_factor(const View& v, int which, const long gk) {
     if (gk >= v.G) return;
     const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
     if (k <= v.lo[w] || k >= v.hi[w]) return;
-    if (shard_skips_factor(v, w, k) || window_done(v, w)) return;
+    if (window_done(v, w)) return;
+    const bool jac = !SH || !shard_skips_factor(v, w, k);
     const int b = v.sel[w] ^ which;
 
     const double* __restrict__ in = v.imu_in + (size_t)(gk >> 6) * IMU_IN * TILE + (gk & 63);
@@ -269,8 +273,9 @@ __device__ __forceinline__ void linearize_imu_factor(const View& v, int which, c
 #endif
     // write-once streams (3.7 KB per factor, far beyond L2/MALL): non-temporal stores, +15 % measured
     struct NtRef { double* p; VF_DI void operator=(double x) const { __builtin_nontemporal_store(x, p); } };
+    struct NtJac { double* p; bool on; VF_DI void operator=(double x) const { if (!SH || on) __builtin_nontemporal_store(x, p); } };
 #define OUT(f) (NtRef{out + (size_t)(f) * TILE})
-#define JOUT(r, c) OUT(15 + (r) * 30 + (c))
+#define JOUT(r, c) (NtJac{out + (size_t)(15 + (r) * 30 + (c)) * TILE, jac})
 
     const State si = load_state(v, b, gk - 1), sj = load_state(v, b, gk);
     const double dt = IN(0);
@@ -414,15 +419,17 @@ __device__ __forceinline__ void linearize_imu_factor(const View& v, int which, c
 // ------------------------------------------------------------------------------------ K2
 // Algorithmic traffic per factor: 42 doubles in (2 poses x 7, record 28), 78 out.
 __global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_imu(View v, int which) {
-    linearize_imu_factor(v, which, (long)blockIdx.x * VF_K1_BLOCK + threadIdx.x);
+    linearize_imu_factor<false>(v, which, (long)blockIdx.x * VF_K1_BLOCK + threadIdx.x);
 }
 
+template <bool SH>
 __device__ __forceinline__ void linearize_between_factor(const View& v, int which, const long gk) {
     if (gk >= v.G) return;
     const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
     const int lo = v.lo[w];
     if (k <= lo || k >= v.hi[w]) return;
-    if (shard_skips_factor(v, w, k) || window_done(v, w)) return;
+    if (window_done(v, w)) return;
+    const bool jac = !SH || !shard_skips_factor(v, w, k);
     const int a = v.btw_a[gk];
     if (a < lo || a >= k) return;
     const int b = v.sel[w] ^ which;
@@ -432,7 +439,9 @@ __device__ __forceinline__ void linearize_between_factor(const View& v, int whic
     double* __restrict__ out = v.btw_out + ((size_t)b * (size_t)(v.G >> 6) + (size_t)(gk >> 6)) * BTW_OUT * TILE + (gk & 63);
 #define IN(f) in[(size_t)(f) * TILE]
     struct NtRef { double* p; VF_DI void operator=(double x) const { __builtin_nontemporal_store(x, p); } };
+    struct NtJac { double* p; bool on; VF_DI void operator=(double x) const { if (!SH || on) __builtin_nontemporal_store(x, p); } };
 #define OUT(f) (NtRef{out + (size_t)(f) * TILE})
+#define JOUT(f) (NtJac{out + (size_t)(f) * TILE, jac})
 
     const Q4 qa = q4(XS(b, 0, ga), XS(b, 1, ga), XS(b, 2, ga), XS(b, 3, ga));
     const V3 ta = v3(XS(b, 4, ga), XS(b, 5, ga), XS(b, 6, ga));
@@ -492,12 +501,13 @@ __device__ __forceinline__ void linearize_between_factor(const View& v, int whic
                 sa = fma(Rw[off6(r) + l - r], ua[l], sa);
                 sb = fma(Rw[off6(r) + l - r], ub[l], sb);
             }
-            OUT(6 + r * 6 + c) = sa;
-            OUT(42 + r * 6 + c) = sb;
+            JOUT(6 + r * 6 + c) = sa;
+            JOUT(42 + r * 6 + c) = sb;
         }
     }
 #undef IN
 #undef OUT
+#undef JOUT
 }
 
 // ------------------------------------------------------------------------------------ K2b
@@ -523,7 +533,7 @@ VF_DI void marg_delta(const View& v, int w, int b, double (&d)[27]) {
 }
 
 __global__ void __launch_bounds__(256) k_linearize_between(View v, int which) {
-    linearize_between_factor(v, which, (long)blockIdx.x * 256 + threadIdx.x);
+    linearize_between_factor<false>(v, which, (long)blockIdx.x * 256 + threadIdx.x);
 }
 
 __device__ __forceinline__ void linearize_prior_window(const View& v, int which, const int w) {
@@ -584,15 +594,17 @@ __global__ void __launch_bounds__(256) k_linearize_between_prior(View v, int whi
     const int bx = blockIdx.x;
     if (bx < nb_pri) {      // one wave of windows per workgroup: four such chains on one CU ran 1.6 x longer
         if (threadIdx.x < 64) linearize_prior_window(v, which, bx * 64 + (int)threadIdx.x);
-    } else linearize_between_factor(v, which, (long)(bx - nb_pri) * 256 + threadIdx.x);
+    } else linearize_between_factor<false>(v, which, (long)(bx - nb_pri) * 256 + threadIdx.x);
 }
 // K1 + K2 + K2b in ONE launch, for few windows (latency form): with a handful of windows each of the three kernels
 // is a single latency chain (27 / 9 / 13 us), so running them side by side saves two of the three; for large
 // batches they stay separate (K2 would inherit K1's register footprint here).
+// (SH: the form time-sharded windows use, whatever the batch size)
+template <bool SH>
 __global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_all(View v, int which, int nb_imu, int nb_btw) {
     const int bx = blockIdx.x;
-    if (bx < nb_imu) linearize_imu_factor(v, which, (long)bx * VF_K1_BLOCK + threadIdx.x);
-    else if (bx < nb_imu + nb_btw) linearize_between_factor(v, which, (long)(bx - nb_imu) * VF_K1_BLOCK + threadIdx.x);
+    if (bx < nb_imu) linearize_imu_factor<SH>(v, which, (long)bx * VF_K1_BLOCK + threadIdx.x);
+    else if (bx < nb_imu + nb_btw) linearize_between_factor<SH>(v, which, (long)(bx - nb_imu) * VF_K1_BLOCK + threadIdx.x);
     else linearize_prior_window(v, which, (bx - nb_imu - nb_btw) * VF_K1_BLOCK + (int)threadIdx.x);
 }
 
@@ -604,10 +616,10 @@ __global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_all(View
 __global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_tail(View v, int nslid) {
     const int bx = blockIdx.x, t = threadIdx.x;
     if (bx < v.B) {
-        if (t < nslid) linearize_imu_factor(v, 0, (long)bx * v.M + v.hi[bx] - 1 - t);
+        if (t < nslid) linearize_imu_factor<false>(v, 0, (long)bx * v.M + v.hi[bx] - 1 - t);
     } else if (bx < 2 * v.B) {
         const int w = bx - v.B;
-        if (t < nslid) linearize_between_factor(v, 0, (long)w * v.M + v.hi[w] - 1 - t);
+        if (t < nslid) linearize_between_factor<false>(v, 0, (long)w * v.M + v.hi[w] - 1 - t);
     } else {
         const int w = (bx - 2 * v.B) * 64 + t;      // one wave of windows per workgroup
         if (t < 64) {
@@ -1688,7 +1700,7 @@ __device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int
         }
     }
     // ---- outputs --------------------------------------------------------------------------------
-    double* Sm = v.sepS + ((size_t)c * v.B + w) * SEPM;  // -(V^T V), -(V^T y): added to separator c-1
+    double* Sm = v.sepS + ((size_t)c * v.B + w) * SEPK;  // -(V^T V), -(V^T y): added to separator c-1
     auto put = [&](const d4_t& t, int I, int J) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -1702,7 +1714,7 @@ __device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int
     put(acc[0], 0, 0); put(acc[1], 0, 1); put(acc[2], 1, 1);
     if (cg.has_sep) {
         // what is left in W belongs to the right separator: the cut keyframe (15 rows), pose rows of the two after it
-        double* Cm = v.sepC + ((size_t)c * v.B + w) * SEP * SEP;
+        double* Cm = v.sepC + ((size_t)c * v.B + w) * SEPK;
 #pragma unroll
         for (int J = 0; J < 2; J++)
 #pragma unroll
@@ -1735,7 +1747,7 @@ __global__ void __launch_bounds__(128) k_chunk_forward(View v) {
     if (threadIdx.x == 4) S[S_PROG] = 0.0;
     if (threadIdx.x == 5) S[S_CONS] = 0.0;
     __syncthreads();
-    if (wave == 0) band_solve_body<SOLVE_CHUNK_FWD>(v, S, nullptr, nullptr, w, lane, 0, cg, v.sepR + ((size_t)c * v.B + w) * SEPM);
+    if (wave == 0) band_solve_body<SOLVE_CHUNK_FWD>(v, S, nullptr, nullptr, w, lane, 0, cg, v.sepR + ((size_t)c * v.B + w) * SEPK);
     else if (c > 0) chunk_spike(v, S, w, c, cg, lane);
 }
 __global__ void __launch_bounds__(64) k_chunk_back(View v) {
@@ -1833,10 +1845,10 @@ __global__ void __launch_bounds__(256) k_sep_solve(View v) {
     double* Dn = Zs + 32 * ZZ;                   // [56][ZS]: panel input: D rows 0..26, C rows 27..53, rhs row 54, zero row 55
     // separator blocks are stored chunk-major, [P][B][..]: the chunks of one rank of a time-sharded window are
     // contiguous (all-gather slices); element (c, w) of this window sits c * cs (resp. c * cc) further on
-    const size_t cs = (size_t)v.B * SEPM, cc = (size_t)v.B * SEP * SEP;
-    const double* __restrict__ R = v.sepR + (size_t)w * SEPM;
-    const double* __restrict__ Sx = v.sepS + (size_t)w * SEPM;          // chunk 0 is never written: 756 zeros
-    const double* __restrict__ Cx = v.sepC + (size_t)w * SEP * SEP;
+    const size_t cs = (size_t)v.B * SEPK, cc = cs;
+    const double* __restrict__ R = v.sepR + (size_t)w * SEPK;
+    const double* __restrict__ Sx = v.sepS + (size_t)w * SEPK;          // chunk 0 is never written: 756 zeros
+    const double* __restrict__ Cx = v.sepC + (size_t)w * SEPK;
     double* __restrict__ Lx = v.sepL + (size_t)w * P * SEPL;
     int failed = 0;
     // ---- chain geometry of this team: step j eliminates separator piv(j); its panel needs
@@ -2083,25 +2095,23 @@ __global__ void __launch_bounds__(256) k_retract(View v) {
     store_state(v, b ^ 1, gk, o);
 }
 
-// cost of buffer (sel ^ !init) per window, then the LM decision. One 256-thread block per window;
-// fixed-shape tree reduction => bitwise reproducible.
-// mode 0: whole cost + accept / reject (one rank).  Sharded windows: mode 1 = this rank's share of the cost
-// -> cost_part (the host side sums it over the ranks), mode 2 = accept / reject with cost_part as the total.
-// Block = window, 256 threads (1024 when there are few windows: the per-thread loop over a long window's factors
-// is a latency chain); fixed-shape tree reduction, so the cost is bitwise reproducible for a given engine.
-__global__ void __launch_bounds__(1024) k_decide(View v, int init, int mode) {
+// cost of buffer (sel ^ !init) per window, then the LM decision.  Block = window, 256 threads (1024 when there are few
+// windows: the per-thread loop over a long window's factors is a latency chain); fixed-shape tree reduction, so the
+// cost is bitwise reproducible for a given engine.
+// Time-sharded windows: every rank holds the residual of every factor (k_linearize_all<true>), so every rank forms the
+// whole cost itself and takes the same decision -- no exchange; the solve-failure flags of the other ranks arrive in the
+// tail of the increment buffer, summed by the same all-reduce as the increments (k_mask_delta).
+__global__ void __launch_bounds__(1024) k_decide(View v, int init) {
     const int w = blockIdx.x, tid = threadIdx.x;
     if (window_done(v, w) && !init) return;
     const int lo = v.lo[w], hi = v.hi[w];
-    int klo, khi;
-    own_range(v, w, klo, khi);
     const int b = init ? v.sel[w] : (v.sel[w] ^ 1);
     const size_t tiles = (size_t)(v.G >> 6);
     const double* imu_out = v.imu_out + (size_t)b * tiles * IMU_OUT * TILE;
     const double* btw_out = v.btw_out + (size_t)b * tiles * BTW_OUT * TILE;
     double s = 0.0;
     const int nt = (int)blockDim.x;
-    for (int k = lo + (klo > 1 ? klo : 1) + tid; k < lo + khi && mode != 2; k += nt) {
+    for (int k = lo + 1 + tid; k < hi; k += nt) {
         const long gk = (long)w * v.M + k;
         const double* f = imu_out + (size_t)(gk >> 6) * IMU_OUT * TILE + (gk & 63);
         double c = 0.0;
@@ -2115,13 +2125,13 @@ __global__ void __launch_bounds__(1024) k_decide(View v, int init, int mode) {
         }
         s += c;
     }
-    if (tid == 0 && mode != 2) {
+    if (tid == 0) {
         const int pk = v.prior_k[w];
-        if (pk >= lo + klo && pk < lo + khi) {
+        if (pk >= lo && pk < hi) {
             const double* f = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT;
             for (int r = 0; r < 15; r++) s = fma(f[r], f[r], s);
         }
-        if (v.mp_on[w] && hi - lo >= 3 && klo == 0) s += 2.0 * v.mp_out[((size_t)b * v.B + w) * 28 + 27];
+        if (v.mp_on[w] && hi - lo >= 3) s += 2.0 * v.mp_out[((size_t)b * v.B + w) * 28 + 27];
     }
     __shared__ double red[1024];
     red[tid] = s;
@@ -2130,13 +2140,9 @@ __global__ void __launch_bounds__(1024) k_decide(View v, int init, int mode) {
         if (tid < st) red[tid] += red[tid + st];
         __syncthreads();
     }
-    if (tid == 0 && mode == 1) {
-        v.cost_part[w] = 0.5 * red[0];
-        v.cost_part[v.B + w] = v.fail[w] ? 1.0 : 0.0;     // a failed elimination on any rank rejects the trial
-    }
-    if (tid == 0 && mode != 1) {
-        const double c = mode == 2 ? v.cost_part[w] : 0.5 * red[0];
-        if (mode == 2) v.fail[w] = v.cost_part[v.B + w] > 0.0 ? 1 : 0;
+    if (tid == 0) {
+        const double c = 0.5 * red[0];
+        if (v.sh_G > 1 && !init) v.fail[w] = v.delta[(size_t)v.G * 15 + w] > 0.0 ? 1 : 0;   // a failed elimination on any rank rejects the trial
         if (init) {
             v.cost[w] = c;
             v.fail[w] = 0;
@@ -2396,7 +2402,8 @@ void launch_preintegrate(const View& v, long g0, int n, const int* off, const do
 }
 void launch_linearize_all(const View& v, int which, hipStream_t s) {
     const int nb_imu = (int)nblk(v.G, VF_K1_BLOCK), nb_btw = nb_imu, nb_pri = (int)nblk(v.B, VF_K1_BLOCK);
-    hipLaunchKernelGGL(k_linearize_all, dim3(nb_imu + nb_btw + nb_pri), dim3(VF_K1_BLOCK), 0, s, v, which, nb_imu, nb_btw);
+    if (v.sh_G > 1) hipLaunchKernelGGL(k_linearize_all<true>, dim3(nb_imu + nb_btw + nb_pri), dim3(VF_K1_BLOCK), 0, s, v, which, nb_imu, nb_btw);
+    else hipLaunchKernelGGL(k_linearize_all<false>, dim3(nb_imu + nb_btw + nb_pri), dim3(VF_K1_BLOCK), 0, s, v, which, nb_imu, nb_btw);
 }
 void launch_linearize_imu(const View& v, int which, hipStream_t s) {
     hipLaunchKernelGGL(k_linearize_imu, dim3(nblk(v.G, VF_K1_BLOCK)), dim3(VF_K1_BLOCK), 0, s, v, which);
@@ -2433,8 +2440,12 @@ void launch_partitioned_solve(const View& v, hipStream_t s) {
     launch_partitioned_local(v, s);
     launch_partitioned_global(v, s);
 }
+// time-sharded windows, after the back substitution: zero the increments of the keyframes this rank does not own and put
+// this rank's solve-failure flags behind them, so that ONE all-reduce (sum) leaves every rank with all increments and
+// with the number of ranks whose elimination failed
 __global__ void __launch_bounds__(256) k_mask_delta(View v) {
     const long gk = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gk < v.B) v.delta[(size_t)v.G * 15 + gk] = v.fail[gk] ? 1.0 : 0.0;
     if (gk >= v.G) return;
     const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
     const int lo = v.lo[w];
@@ -2459,10 +2470,7 @@ void launch_retract(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_retract, dim3(nblk(v.G, 256)), dim3(256), 0, s, v);
 }
 void launch_decide(const View& v, int init, hipStream_t s) {
-    hipLaunchKernelGGL(k_decide, dim3(v.B), dim3(v.B <= 64 ? 1024 : 256), 0, s, v, init, 0);
-}
-void launch_decide_mode(const View& v, int init, int mode, hipStream_t s) {
-    hipLaunchKernelGGL(k_decide, dim3(v.B), dim3(v.B <= 64 ? 1024 : 256), 0, s, v, init, mode);
+    hipLaunchKernelGGL(k_decide, dim3(v.B), dim3(v.B <= 64 ? 1024 : 256), 0, s, v, init);
 }
 void launch_predict(const View& v, int window, int k0, int n, hipStream_t s) {
     if (window >= 0) hipLaunchKernelGGL(k_predict, dim3(1), dim3(1), 0, s, v, window, k0, n);

@@ -25,6 +25,10 @@ __host__ __device__ constexpr int h_tri(int a, int c) { return a * (a + 1) / 2 +
 constexpr int PANEL = 646;      // Cholesky panel in HBM: 43 rows (27 sub-diagonal, rhs, 15 of L^-T) x 15 columns = 645 doubles, stored [7 column pairs][43][2] + [43] (+1: 16-byte alignment)
 constexpr int SEP = 27;
 constexpr int SEPM = SEP * 28;  // 27x27 block + right-hand side column
+// separator blocks of one (chunk, window): [sepR 27x28 | sepS 27x28 | sepC 27x27] packed in one slot (2241 doubles, padded
+// to a multiple of 8), chunk-major [P][B][SEPK]: the chunks of one rank of a time-sharded window are ONE contiguous slice
+// of ONE buffer, i.e. one all-gather per LM trial
+constexpr int SEPK = (2 * SEPM + SEP * SEP + 7) / 8 * 8;
 constexpr int SEPL = SEP * 64;  // factor of one separator elimination, column-major [27][64]: L (27 rows), Z (27), y
 constexpr int VROW = 15 * 32;   // spike rows of one keyframe: 15 dof x 27 separator columns (32 stored)
 
@@ -92,7 +96,8 @@ struct View {
     double* H;          // [G][4][15][15]      block d of row k = H[k][k-d]
     double* gvec;       // [G][15]
     double* zrow;       // [900] zeros
-    double* delta;      // [G][15]
+    double* delta;      // [G][15] + [B]       increments; tail: solve-failure flag per window (time-sharded windows: summed
+                        //                     over the ranks together with the increments, one all-reduce)
     double* Lp;         // [G][43][16]         Cholesky panels (15 of 16 columns used)
     // partitioned solve (allocated when P >= 2)
     int P;              // chunks per window (0/1 = whole-window sweeps)
@@ -101,11 +106,12 @@ struct View {
     // of every window; states and factors are replicated, each rank linearises / assembles / eliminates its own
     // keyframes only.  sh_G <= 1: not sharded.
     int sh_r, sh_G;
-    double* cost_part;  // [2][B]              this rank's share of the cost, and its solve-failure flag (summed over ranks by the host side)
     double* Vp;         // [G][15][32]         spikes: L^-1 (coupling of the chunk interior to its left separator)
-    double* sepR;       // [P][B][27][28]      separator block + rhs left by the forward sweep of chunk c
-    double* sepS;       // [P][B][27][28]      Schur term of chunk c on its LEFT separator (c >= 1)
-    double* sepC;       // [P][B][27][27]      coupling (right separator of chunk c) x (left separator of chunk c)
+    // the three below point into ONE buffer [P][B][SEPK] (at offsets 0, SEPM, 2 SEPM of a slot): element (c, w) of each sits
+    // ((size_t)c * B + w) * SEPK further on
+    double* sepR;       // [27][28]            separator block + rhs left by the forward sweep of chunk c
+    double* sepS;       // [27][28]            Schur term of chunk c on its LEFT separator (c >= 1)
+    double* sepC;       // [27][27]            coupling (right separator of chunk c) x (left separator of chunk c)
     double* sepL;       // [B][P][27][64]      factors of the separator chain, column-major (for its back substitution)
     int* lo;            // [B] active range [lo, hi)
     int* hi;
@@ -141,8 +147,6 @@ void launch_assemble(const View& v, hipStream_t s);
 void launch_band_solve(const View& v, hipStream_t s);
 void launch_retract(const View& v, hipStream_t s);
 void launch_decide(const View& v, int init, hipStream_t s);
-// sharded windows: mode 1 = this rank's share of the cost -> cost_part; mode 2 = accept / reject with cost_part as the total
-void launch_decide_mode(const View& v, int init, int mode, hipStream_t s);
 void launch_partitioned_local(const View& v, hipStream_t s);    // chunk sweeps + spikes of the owned chunks
 void launch_partitioned_global(const View& v, hipStream_t s);   // separator chain (all of it) + back substitution of the owned chunks
 void launch_mask_delta(const View& v, hipStream_t s);           // zero the increments of keyframes this rank does not own

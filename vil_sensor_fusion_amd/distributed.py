@@ -7,9 +7,11 @@ a MAX-reduce of the elapsed time and an all-gather of per-rank summaries.
 
 ShardedSolver is the other multi-GPU form (BASELINE.json configs[4]): ONE window spread
 in time over the ranks.  Every rank holds the window, owns a contiguous range of the chunks of the
-partitioned solve (K4p) and the keyframes they cover, and per LM trial the ranks exchange the packed
-separator system (all-gather, 2241 doubles per chunk), the increments (all-reduce, 15 doubles per
-keyframe) and two scalars per window (all-reduce).  RCCL collectives are enqueued on the stream the
+partitioned solve (K4p) and the keyframes they cover, and an LM trial has TWO collectives: an in-place
+all-gather of the packed separator system (one buffer, 2248 doubles per chunk and window) and an
+all-reduce of the increments (15 doubles per keyframe slot) with the solve-failure flags behind them.
+The cost of a trial needs none: every rank evaluates every residual (Jacobians only for its own
+factors) and takes the same accept / reject decision.  RCCL collectives are enqueued on the stream the
 engine's kernels run on, so a trial needs no host synchronisation.
 """
 from __future__ import annotations
@@ -110,16 +112,14 @@ def shard_range(n: int, chunks: int, rank: int, world: int, fit: bool = False):
 
 def all_gather_slices(dist, full, per_slice: int, rank: int, world: int, backend: str):
     """`full` = world equal slices of per_slice elements; rank r holds slice r; afterwards all hold all.
-    nccl (RCCL): on the device.  gloo (CPU tests, shared-GPU smoke runs): staged through the host."""
+    nccl (RCCL): ONE in-place all-gather on the device (the send buffer is the rank's own slice of the
+    receive buffer: no clone, no temporary, no copy back).  gloo (CPU tests, shared-GPU smoke runs):
+    staged through the host."""
     if dist is None or (world == 1 and backend != "nccl"):
         return
     own = full[rank * per_slice:(rank + 1) * per_slice]
     if backend == "nccl":
-        import torch
-        # out of place (0.4 MB for a 10 000-pose window): the source slice is not aliased by the collective's output
-        tmp = torch.empty(world * per_slice, dtype=full.dtype, device=full.device)
-        dist.all_gather_into_tensor(tmp, own.clone())
-        full[:world * per_slice].copy_(tmp)
+        dist.all_gather_into_tensor(full[:world * per_slice], own)
         return
     import torch
     parts = [torch.empty(per_slice, dtype=full.dtype) for _ in range(world)]
@@ -164,37 +164,34 @@ class ShardedSolver:
         wrap = lambda p, n: torch.as_tensor(_DevicePtr(p, n), device=self.device)
         self.chunks = info.chunks
         self.per_rank = info.chunks // self.world
-        self.rs_per, self.c_per = info.sep_rs_per_chunk, info.sep_c_per_chunk
-        self.sep_r = wrap(info.sep_r, info.chunks * self.rs_per)
-        self.sep_s = wrap(info.sep_s, info.chunks * self.rs_per)
-        self.sep_c = wrap(info.sep_c, info.chunks * self.c_per)
-        self.delta = wrap(info.delta, info.delta_count)
-        self.cost = wrap(info.cost_part, info.cost_count)
+        self.sep_per = info.sep_per_chunk
+        self.sep = wrap(info.sep, info.chunks * self.sep_per)
+        self.delta = wrap(info.delta, info.delta_count)       # increments + one solve-failure flag per window
+        self.collectives = 0                                   # issued so far (0 when there is no process group)
 
-    def _exchange_separators(self):
-        for t, per in ((self.sep_r, self.rs_per), (self.sep_s, self.rs_per), (self.sep_c, self.c_per)):
-            all_gather_slices(self.dist, t, per * self.per_rank, self.rank, self.world, self.backend)
+    COLLECTIVES_PER_TRIAL = 2
 
-    def _decide(self, init):
-        self.eng.decide_partial(init)
-        all_reduce_sum(self.dist, self.cost, self.backend)
-        self.eng.decide_total(init)
+    def _count(self):
+        if self.dist is not None:
+            self.collectives += 1
 
     def trial(self):
         e = self.eng
         e.assemble()
         e.solve_local()
-        self._exchange_separators()
+        all_gather_slices(self.dist, self.sep, self.sep_per * self.per_rank, self.rank, self.world, self.backend)
+        self._count()
         e.solve_global()
         all_reduce_sum(self.dist, self.delta, self.backend)
+        self._count()
         e.retract()
         e.linearize(1)
-        self._decide(False)
+        e.decide(False)
 
     def iterate(self, iterations: int):
         e = self.eng
         e.reset_lambda()
         e.linearize(0)
-        self._decide(True)
+        e.decide(True)
         for _ in range(iterations):
             self.trial()

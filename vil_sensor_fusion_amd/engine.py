@@ -179,12 +179,6 @@ class Engine:
     def solve_global(self):
         check(self._l.vf_engine_solve_global(self._h))
 
-    def decide_partial(self, init=False):
-        check(self._l.vf_engine_decide_partial(self._h, int(init)))
-
-    def decide_total(self, init=False):
-        check(self._l.vf_engine_decide_total(self._h, int(init)))
-
     def reset_lambda(self):
         check(self._l.vf_engine_reset_lambda(self._h))
 

@@ -76,6 +76,18 @@ class GraphManager:
         check(self._l.vf_add_between(self._h, C.c_uint64(previousKey), C.c_uint64(currentKey), _d(q),
                                      _d(t), _d(cov)))
 
+    def addFactor(self, key, record190):
+        """GraphManager::addFactor(const CombinedImuFactor&): queue a ready-made preintegrated factor ending at `key`
+        (its 190-double record) instead of cutting one from the IMU buffer."""
+        r = np.ascontiguousarray(record190, dtype=np.float64).reshape(190)
+        check(self._l.vf_add_imu_factor(self._h, C.c_uint64(key), _d(r)))
+
+    def getMostRecentEstimate(self):
+        """GraphManager::getMostRecentEstimate: (q_wxyz, t, v) of a member the reference never assigns (identity, zero)."""
+        q, t, v = np.zeros(4), np.zeros(3), np.zeros(3)
+        check(self._l.vf_get_most_recent_estimate(self._h, _d(q), _d(t), _d(v)))
+        return (q, t), v
+
     def solve(self):
         check(self._l.vf_solve(self._h))
 

@@ -55,10 +55,25 @@ def _make_seq(job):
 
 
 def host_workers():
+    """Host cores this process can really use: the affinity mask, capped by the cgroup CPU quota (a GPU box shows all
+    256 hardware threads in the mask but gives a one-GPU job a share of them)."""
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return max(1, os.cpu_count() or 1)
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = min(n, max(1, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
 
 
 def make_sequences(args, rank, count, n_kf, base_seed=0):

@@ -1,7 +1,8 @@
 """-m gpu: parity of the HIP hot path (through the C ABI) against the CPU oracle on the same
 seeded inputs.  Tolerances (float64, two independent implementations):
-  residuals / Jacobians / normal equations: |err| <= 1e-10 * max|block|   (<=1e-12
-  relative was the aim; the looser figure covers the 1e8 dynamic range of the whitened rows)
+  residuals / Jacobians (K1, K2): |err| <= 1e-12 * max|block|   (SURVEY 7.3's aim; observed 2e-13)
+  normal equations (K3), cost:     |err| <= 1e-12 * max|block|   (sums of 15-30 products of such entries)
+  predicted initial values (a2):   |err| <= 1e-12 * max|state|
   trajectories: ATE <= 1e-6 m (BASELINE.json north_star), observed values are printed."""
 import numpy as np
 import pytest
@@ -12,6 +13,7 @@ from vil_sensor_fusion_amd import synth
 pytestmark = pytest.mark.gpu
 
 N = 200
+TOL = 1e-12
 
 
 @pytest.fixture(scope="module")
@@ -49,7 +51,7 @@ def test_linearize_imu_parity(setup, oracle):
             ro, Jo = oracle.imu_factor(p["imu"][k], p["gravity"], p["states"][k - 1], p["states"][k])
             worst = max(worst, relerr(r[k - 1], ro), relerr(J[k - 1], Jo))
     print("imu linearisation worst relative error", worst)
-    assert worst < 1e-10
+    assert worst < TOL
 
 
 def test_linearize_between_parity(setup, oracle):
@@ -64,24 +66,58 @@ def test_linearize_between_parity(setup, oracle):
             ro, Jao, Jbo = oracle.between_factor(rec, p["states"][a], p["states"][b])
             worst = max(worst, relerr(r[b], ro), relerr(Ja[b], Jao), relerr(Jb[b], Jbo))
     print("between linearisation worst relative error", worst)
-    assert worst < 1e-10
+    assert worst < TOL
 
 
 def test_assemble_parity(setup, oracle):
     eng, probs = setup
     eng.linearize(0)
     eng.assemble()
+    worst = 0.0
     for w in range(2):
         H, g = eng.read_normal(w, 0, N)
         cost, Ho, go = helpers.oracle_window(oracle, probs[w]).assemble(w=3)
         for k in range(N):
             for d in range(min(k, 3) + 1):
-                assert relerr(H[k, d], Ho[k, d]) < 1e-10 or np.abs(Ho[k, d]).max() == 0, (w, k, d)
                 if np.abs(Ho[k, d]).max() == 0:
                     assert np.abs(H[k, d]).max() == 0
-        assert relerr(g, go) < 1e-10
+                else:
+                    worst = max(worst, relerr(H[k, d], Ho[k, d]))
+                    assert relerr(H[k, d], Ho[k, d]) < TOL, (w, k, d)
+        worst = max(worst, relerr(g, go))
+        assert relerr(g, go) < TOL
         eng.decide(init=True)
-        assert abs(eng.read_lm(w)["cost"] - cost) <= 1e-10 * cost
+        assert abs(eng.read_lm(w)["cost"] - cost) <= TOL * cost
+    print("normal equations worst relative error", worst)
+
+
+def test_predict_parity(oracle):
+    """a2 (GraphManager::emptyImuQueue -> pim.predict, GraphManager.cpp:143-162) directly: the chain of initial values
+    k_predict writes from keyframe 0 against the oracle's predict, state by state."""
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    n = 120
+    seq = synth.make_sequence(seed=31, n_kf=n)
+    prob = helpers.build_problem(oracle, seq)            # states = the oracle's prediction chain from gt_states[0]
+    eng = Engine(EngineOpts(windows=2, capacity=n + 8))
+    for w in range(2):
+        eng.set_states(w, 0, prob["states"][:1])
+        eng.set_imu(w, 1, prob["imu"][1:])
+        eng.set_range(w, 0, 1)
+    eng.predict(0, 1, n - 1)                             # one window ...
+    eng.predict(-1, 1, n - 1)                            # ... and the all-windows form
+    for w in range(2):
+        got = eng.get_states(w, 0, n)
+        err = np.abs(got - prob["states"]).max(axis=0) / np.abs(prob["states"]).max(axis=0).clip(min=1.0)
+        print(f"window {w}: predicted-state worst relative error per component {err.max():.2e}")
+        assert err.max() < TOL
+        # single-step form as well: every state from the ORACLE's previous one (no error accumulation)
+    eng.set_states(0, 0, prob["states"])
+    for k in (1, 7, n - 1):
+        eng.predict(0, k, 1)
+        one = eng.get_states(0, k, 1)[0]
+        ref = oracle.predict(prob["imu"][k], prob["gravity"], prob["states"][k - 1])
+        assert np.abs(one - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+    eng.close()
 
 
 def test_assemble_parity_ragged_windows_in_a_large_batch(oracle):
@@ -107,8 +143,8 @@ def test_assemble_parity_ragged_windows_in_a_large_batch(oracle):
                 else:
                     blk = H[k, d] if d < 2 else H[k, d][:6, :6]
                     ref = Ho[k, d] if d < 2 else Ho[k, d][:6, :6]
-                    assert relerr(blk, ref) < 1e-10, (w, k, d)
-        assert relerr(g, go) < 1e-10
+                    assert relerr(blk, ref) < TOL, (w, k, d)
+        assert relerr(g, go) < TOL
     eng.close()
 
 
@@ -268,7 +304,7 @@ def test_dense_noise_models_and_san_rafael_imu(oracle):
         ro, Jao, Jbo = oracle.between_factor(rec, states[a], states[b])
         worst = max(worst, relerr(rb[b], ro), relerr(Ja[b], Jao), relerr(Jb[b], Jbo))
     print("dense-noise linearisation worst relative error", worst)
-    assert worst < 1e-10
+    assert worst < TOL
     eng.iterate(5)
     win = helpers.oracle_window(oracle, prob)
     win.lm(iterations=5)

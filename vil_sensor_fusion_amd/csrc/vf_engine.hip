@@ -189,19 +189,28 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.mp_L, (size_t)v.B * 729);
     AL(v.mp_eta, (size_t)v.B * 27);
     AL(v.mp_out, 2 * (size_t)v.B * 28);
-    AL(v.H, G * vf::HROW);
-    AL(v.gvec, G * 15 + 64);      // + slack: the solver's row fetch reads 64 lanes of a 15-double row (the excess is never used)
-    AL(v.zrow, vf::HROW);         // a block row of zeros: what the solver fetches for rows outside the window
-    AL(v.delta, G * 15 + (size_t)v.B);   // + one solve-failure flag per window (time-sharded windows: reduced with the increments)
-    AL(v.Lp, G * vf::PANEL);
-    // K4 form: chunks = 0 picks it from the batch size: up to 128 windows -> partitioned solve with at
-    // most 96 chunks, fewer on short windows (latency form); more windows -> one sweep per window
-    // (throughput form; the partitioned solve does about twice the arithmetic).  1 forces sweeps.
+    // K4 form first (it decides whether K1 + K3 run fused): chunks = 0 picks it from the batch size: up to 128 windows ->
+    // partitioned solve with at most 96 chunks, fewer on short windows (latency form); more windows -> one sweep per
+    // window (throughput form; the partitioned solve does about twice the arithmetic).  1 forces sweeps.
     v.P = o->chunks >= 2 ? o->chunks : (o->chunks == 0 && o->windows <= 128 ? 96 : 0);
     v.P_fit = o->chunks == 0 ? 1 : 0;
     // (the chunk kernels launch windows x P workgroups: no more chunks than a full window could use)
     if (v.P_fit && v.P) v.P = vf::chunk_count(v.M, v.P, 1);
     if (v.P < 2) v.P = 0;
+    // K1 + K3 fused (k_linearize_assemble: the Jacobians stay in LDS, H and g double-buffered like the states) is built,
+    // bit-identical to the unfused kernels (tests/test_gpu_fused.py) and OFF by default: measured on the bench workload
+    // (1 024 x 1 000) one launch takes 6.1 ms against K1 0.84 + K3 1.93 ms -- a factor's linearisation is a 28 us latency
+    // chain and its 3.7 KB of (r | J) limit an LDS tile to 9 factors, i.e. one wave per SIMD with 9 of 64 lanes busy and
+    // nothing to hide the chain behind (DESIGN.md "K1 + K3 fused").  VF_FUSED=1 switches it on for whole-window-sweep
+    // engines (A/B measurements, tests).
+    v.fused = 0;
+    if (const char* f = getenv("VF_FUSED")) v.fused = (atoi(f) != 0 && v.P == 0) ? 1 : 0;
+    const size_t hb = v.fused ? 2 : 1;
+    AL(v.H, hb * G * vf::HROW);
+    AL(v.gvec, hb * G * 15 + 64); // + slack: the solver's row fetch reads 64 lanes of a 15-double row (the excess is never used)
+    AL(v.zrow, vf::HROW);         // a block row of zeros: what the solver fetches for rows outside the window
+    AL(v.delta, G * 15 + (size_t)v.B);   // + one solve-failure flag per window (time-sharded windows: reduced with the increments)
+    AL(v.Lp, G * vf::PANEL);
     if (v.P) {
         const size_t BP = (size_t)v.B * v.P;
         AL(v.Vp, G * vf::VROW);
@@ -505,6 +514,33 @@ static int iterate_sequence(vf_engine* e, int iterations) {
     HIPCHK(hipMemcpyAsync(e->v.lambda, e->lambda0_dev, e->v.B * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     int rc;
     const int slid = (e->warm && e->v.sh_G <= 1 && e->slid >= 1 && e->slid <= 8) ? e->slid : 0;
+    if (e->v.fused) {
+        // K1 + K3 fused (vf_kernels.hip "k_linearize_assemble"): the trial's normal equations are written beside the current
+        // ones by the kernel that linearises the trial, so a trial is K4, K5a, K2 (+ priors), K1+K3, K5b -- no Jacobian
+        // in HBM, no separate assembly, nothing to redo after a rejected trial.
+        if (slid) {
+            // warm start: H, g of buffer sel are still those of the current states except at the two ends of a window
+            HIPCHK(hipMemsetAsync(e->v.done, 0, e->v.B * sizeof(int), e->stream));
+            vf::launch_linearize_tail(e->v, slid, e->stream);          // appended between factors + priors; fresh = 1 + slid
+            vf::launch_linearize_assemble(e->v, 0, 1, e->stream);
+        } else {
+            HIPCHK(hipMemsetAsync(e->v.fresh, 0x01, e->v.B * sizeof(int), e->stream));
+            HIPCHK(hipMemsetAsync(e->v.done, 0, e->v.B * sizeof(int), e->stream));
+            vf::launch_linearize_between_prior(e->v, 0, e->stream);
+            vf::launch_linearize_assemble(e->v, 0, 0, e->stream);
+        }
+        HIPCHK(hipGetLastError());
+        if ((rc = vf_engine_decide(e, 1))) return rc;
+        for (int it = 0; it < iterations; it++) {
+            if ((rc = vf_engine_solve(e))) return rc;
+            if ((rc = vf_engine_retract(e))) return rc;
+            vf::launch_linearize_between_prior(e->v, 1, e->stream);
+            vf::launch_linearize_assemble(e->v, 1, 0, e->stream);
+            HIPCHK(hipGetLastError());
+            if ((rc = vf_engine_decide(e, 0))) return rc;
+        }
+        return VF_OK;
+    }
     if (slid) {
         // nothing but slides since the last solve: only the appended keyframes' factors and the priors need linearising
         HIPCHK(hipMemsetAsync(e->v.done, 0, e->v.B * sizeof(int), e->stream));
@@ -699,6 +735,7 @@ int vf_engine_marginalize(vf_engine* e) {
     for (int w = 0; w < e->v.B; w++)
         if (e->h_hi[w] - e->h_lo[w] < 4) return fail(VF_ERR_INVALID, "window %d: marginalisation needs >= 4 keyframes", w);
     HIPCHK(hipMemsetAsync(e->status_dev, 0, sizeof(int), e->stream));
+    if (e->v.fused) vf::launch_linearize_head(e->v, e->stream);   // the one Jacobian the marginalisation reads (fused engines keep none)
     vf::launch_marginalize(e->v, e->status_dev, e->stream);
     HIPCHK(hipGetLastError());
     int status = 0;
@@ -886,7 +923,12 @@ int vf_engine_read_normal(vf_engine* e, int window, int k0, int n, double* Hband
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (n == 0) return VF_OK;
-    const size_t g0 = (size_t)window * e->v.M + k0;
+    size_t g0 = (size_t)window * e->v.M + k0;
+    if (e->v.fused) {             // the buffer that holds the current states' normal equations
+        int sel = 0;
+        if ((rc = read_sel(e, window, &sel))) return rc;
+        g0 += (size_t)sel * (size_t)e->v.G;
+    }
     HIPCHK(hipStreamSynchronize(e->stream));
     if (Hband) {
         // device rows are packed for the solver (vf_kernels.hpp "Block row of H") -> the documented [n][4][15][15]
@@ -973,10 +1015,12 @@ int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms) {
             case VF_STAGE_RETRACT: vf::launch_retract(tv, e->stream); break;
             case VF_STAGE_DECIDE: vf::launch_decide(tv, 1, e->stream); break;
             case VF_STAGE_ASSEMBLE_IDLE: vf::launch_assemble(tv, e->stream); break;
+            case VF_STAGE_LINEARIZE_ASSEMBLE: vf::launch_linearize_assemble(tv, 0, 0, e->stream); break;
             default: break;
         }
     };
-    if (stage < VF_STAGE_LINEARIZE_IMU || stage > VF_STAGE_ASSEMBLE_IDLE) return fail(VF_ERR_INVALID, "unknown stage %d", stage);
+    if (stage < VF_STAGE_LINEARIZE_IMU || stage > VF_STAGE_LINEARIZE_ASSEMBLE) return fail(VF_ERR_INVALID, "unknown stage %d", stage);
+    if (stage == VF_STAGE_LINEARIZE_ASSEMBLE && !e->v.fused) return fail(VF_ERR_INVALID, "this engine does not run K1 + K3 fused");
     // time the full-work form of K3 (inside iterate() it is skipped for windows whose last trial was rejected)
     if (stage == VF_STAGE_ASSEMBLE) HIPCHK(hipMemsetAsync(e->v.fresh, 0x01, e->v.B * sizeof(int), e->stream));
     if (stage == VF_STAGE_ASSEMBLE_IDLE) HIPCHK(hipMemsetAsync(e->v.fresh, 0, e->v.B * sizeof(int), e->stream));

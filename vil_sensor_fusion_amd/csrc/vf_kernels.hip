@@ -31,6 +31,9 @@ namespace vf {
 
 // optional LM termination: a window that has converged takes no part in the remaining trials of this solve
 VF_DI bool window_done(const View& v, int w) { return v.stop_on && v.done[w]; }
+// Which of the two H / g buffers holds the normal equations of window w's CURRENT states.  Fused engines (the fused
+// linearise + assemble kernel writes the trial's normal equations beside the current ones): buffer sel[w]; otherwise 0.
+VF_DI int h_buf(const View& v, int w) { return v.fused ? v.sel[w] : 0; }
 
 // Time-sharded windows: the window-local keyframe range [klo, khi) and the chunk range [c0, c1) rank sh_r owns.
 // A chunk owns its interior keyframes and the separator that follows it; a factor belongs to its later keyframe.
@@ -253,29 +256,37 @@ __global__ void __launch_bounds__(256) k_preintegrate(View v, long g0, int n, co
 #ifndef VF_K1_WAVES
 #define VF_K1_WAVES 1
 #endif
-// SH (time-sharded windows): every rank evaluates the residual of EVERY factor -- the cost of a trial is then known on
-// every rank without an exchange -- but writes the Jacobian only of the factors that feed the rows of H it assembles.
-template <bool SH>
-__device__ __forceinline__ void linearize_imu_factor(const View& v, int which, const long gk) {
-    if (gk >= v.G) return;
-    const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
-    if (k <= v.lo[w] || k >= v.hi[w]) return;
-    if (window_done(v, w)) return;
-    const bool jac = !SH || !shard_skips_factor(v, w, k);
-    const int b = v.sel[w] ^ which;
+// Where a factor's (r | J) goes.  K1: the factor's AoSoA record in HBM, non-temporal stores (write-once streams of 2.4 KB
+// per factor, far beyond L2/MALL: +15 % measured).  `jac` = false (time-sharded windows, factors this rank does not
+// assemble): residual only.
+struct HbmSink {
+    double* out;
+    bool jac;
+    VF_DI void r(int a, double x) const { __builtin_nontemporal_store(x, out + (size_t)a * TILE); }
+    VF_DI void j(int row, int col, double x) const { if (jac) __builtin_nontemporal_store(x, out + (size_t)(15 + row * 30 + col) * TILE); }
+};
+// Fused linearise + assemble (k_linearize_assemble): (r | J) of a factor goes to its row of the workgroup's LDS tile and
+// never to HBM; only the residual (the LM cost, k_decide) is also stored, for the tile's own factors (out_r != nullptr).
+struct LdsSink {
+    double* F;
+    double* out_r;
+    VF_DI void r(int a, double x) const { F[a] = x; if (out_r) __builtin_nontemporal_store(x, out_r + (size_t)a * TILE); }
+    VF_DI void j(int row, int col, double x) const { F[15 + row * 30 + col] = x; }
+};
 
+// CombinedImuFactor: residual and whitened 15x30 Jacobian of the factor in slot gk, at the states of buffer b.
+template <class Sink>
+__device__ __forceinline__ void linearize_imu_core(const View& v, const int b, const long gk, const Sink sink) {
     const double* __restrict__ in = v.imu_in + (size_t)(gk >> 6) * IMU_IN * TILE + (gk & 63);
-    double* __restrict__ out = v.imu_out + ((size_t)b * (size_t)(v.G >> 6) + (size_t)(gk >> 6)) * IMU_OUT * TILE + (gk & 63);
 #ifdef VF_K1_NTLOAD
 #define IN(f) __builtin_nontemporal_load(in + (size_t)(f) * TILE)
 #else
 #define IN(f) in[(size_t)(f) * TILE]
 #endif
-    // write-once streams (3.7 KB per factor, far beyond L2/MALL): non-temporal stores, +15 % measured
-    struct NtRef { double* p; VF_DI void operator=(double x) const { __builtin_nontemporal_store(x, p); } };
-    struct NtJac { double* p; bool on; VF_DI void operator=(double x) const { if (!SH || on) __builtin_nontemporal_store(x, p); } };
-#define OUT(f) (NtRef{out + (size_t)(f) * TILE})
-#define JOUT(r, c) (NtJac{out + (size_t)(15 + (r) * 30 + (c)) * TILE, jac})
+    struct RRef { const Sink& s; int a; VF_DI void operator=(double x) const { s.r(a, x); } };
+    struct JRef { const Sink& s; int row, col; VF_DI void operator=(double x) const { s.j(row, col, x); } };
+#define OUT(f) (RRef{sink, (f)})
+#define JOUT(r, c) (JRef{sink, (r), (c)})
 
     const State si = load_state(v, b, gk - 1), sj = load_state(v, b, gk);
     const double dt = IN(0);
@@ -414,6 +425,20 @@ __device__ __forceinline__ void linearize_imu_factor(const View& v, int which, c
 #undef IN
 #undef OUT
 #undef JOUT
+}
+
+// K1 proper.  SH (time-sharded windows): every rank evaluates the residual of EVERY factor -- the cost of a trial is then
+// known on every rank without an exchange -- but writes the Jacobian only of the factors that feed the rows of H it assembles.
+template <bool SH>
+__device__ __forceinline__ void linearize_imu_factor(const View& v, int which, const long gk) {
+    if (gk >= v.G) return;
+    const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
+    if (k <= v.lo[w] || k >= v.hi[w]) return;
+    if (window_done(v, w)) return;
+    const bool jac = !SH || !shard_skips_factor(v, w, k);
+    const int b = v.sel[w] ^ which;
+    double* __restrict__ out = v.imu_out + ((size_t)b * (size_t)(v.G >> 6) + (size_t)(gk >> 6)) * IMU_OUT * TILE + (gk & 63);
+    linearize_imu_core(v, b, gk, HbmSink{out, jac});
 }
 
 // ------------------------------------------------------------------------------------ K2
@@ -613,10 +638,11 @@ __global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_all(View
 // rejected one left both alone), so only the factors of the `nslid` appended keyframes and the priors (the marginal prior
 // has just changed) are linearised.  H and g are then stale only at the two ends of a window whose last trial was
 // rejected: fresh[w] = 1 + nslid tells k_assemble to redo just those tiles (fresh[w] = 1: all of them).
-__global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_tail(View v, int nslid) {
+// (fused engines: with_imu = 0, the IMU factors of the end tiles are linearised by k_linearize_assemble itself)
+__global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_tail(View v, int nslid, int with_imu) {
     const int bx = blockIdx.x, t = threadIdx.x;
     if (bx < v.B) {
-        if (t < nslid) linearize_imu_factor<false>(v, 0, (long)bx * v.M + v.hi[bx] - 1 - t);
+        if (t < nslid && with_imu) linearize_imu_factor<false>(v, 0, (long)bx * v.M + v.hi[bx] - 1 - t);
     } else if (bx < 2 * v.B) {
         const int w = bx - v.B;
         if (t < nslid) linearize_between_factor<false>(v, 0, (long)w * v.M + v.hi[w] - 1 - t);
@@ -685,6 +711,163 @@ __device__ unsigned long long g_k3_loop[8];
 #else
 #define K3LOOP(i) do {} while (0)
 #endif
+// The matrix-core part of K3, shared by k_assemble (records staged from HBM) and k_linearize_assemble (records computed
+// into LDS): wave `wv` of the workgroup forms the block rows of KPW keyframes from the tile's (r | J) rows in LJ and the
+// between linearisations in LB (s_a = their source keyframes), and stores them into buffer `hb` of H, g.
+template <int KPW>
+__device__ __forceinline__ void assemble_tile(const View& v, const double* __restrict__ LJ, const double* __restrict__ LB,
+                                              const int* __restrict__ s_a, const int w, const int b, const int hb, const int k0,
+                                              const long gk0, const int lo, const int hi, const int rlo, const int rhi,
+                                              const int wv, const int lane) {
+    const int ci = lane & 15, kq = lane >> 4;
+    const int colI = ci < 15 ? 15 + imu_col(0, ci) : -1, colJ = ci < 15 ? 15 + imu_col(1, ci) : -1;
+    auto load_ops = [&](int lf, double (&ai)[4], double (&aj)[4]) {
+        const double* F = LJ + lf * LJS;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int row = 4 * q + kq;
+            if (row < 15) {
+                ai[q] = ci < 15 ? F[row * 30 + colI] : F[row];
+                aj[q] = ci < 15 ? F[row * 30 + colJ] : F[row];
+            } else {
+                ai[q] = 0.0;
+                aj[q] = 0.0;
+            }
+        }
+    };
+    // Between-factor terms on the matrix cores as well: a between linearisation in LDS (r: 0, Ja: 6, Jb: 42, 6 rows) is
+    // the 6 x 16 operand X = [J | 0 ... 0 | r] (column 15 = r, like the IMU tiles), rows padded to 8 = two k-steps;
+    // X^T X adds J^T J to the pose block and J^T r to the gradient column of a diagonal tile, Xb^T Xa is the coupling
+    // block.  Per lane: the in-slot offsets of its two operand words (the slot's pad cell = 0 where X has no entry).
+    // (the VALU form, 6-term dot products per entry from LDS, cost 0.5 ms of K3's 2.7; this one about 0.35)
+    int oA[2], oB[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int row = 4 * q + kq;
+        const bool valid = row < 6;
+        oA[q] = !valid ? BTW_OUT : (ci < 6 ? 6 + row * 6 + ci : (ci == 15 ? row : BTW_OUT));
+        oB[q] = !valid ? BTW_OUT : (ci < 6 ? 42 + row * 6 + ci : (ci == 15 ? row : BTW_OUT));
+    }
+#ifdef VF_SOLVE_STAMPS
+    unsigned long long k3acc[8] = {0}, k3prev = __builtin_amdgcn_s_memtime();
+#endif
+    d4_t D = {0, 0, 0, 0};
+    const int lf0 = KPW * wv;
+#pragma unroll 1
+    for (int lf = lf0; lf <= lf0 + KPW; lf++) {
+        K3LOOP(0);
+        double ai[4], aj[4];
+        load_ops(lf, ai, aj);
+        K3LOOP(1);    // operands of factor lf in registers
+        if (lf > lf0) {
+            // ---- finish keyframe kf = lf-1: D += Ji^T Ji of factor lf, add 6x6 terms, store
+#pragma unroll
+            for (int q = 0; q < 4; q++) D = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[q], ai[q], D, 0, 0, 0);
+            K3LOOP(2);    // Ji^T Ji issued
+            const int kl = lf - 1, k = k0 + kl;
+            if (k >= rlo && k < rhi) {
+                const long gk = gk0 + kl;
+                double* Hk = v.H + ((size_t)hb * (size_t)v.G + (size_t)gk) * HROW;
+                // (accumulated into D itself: separate accumulators added at the end measured 4 % slower)
+                if (__builtin_amdgcn_readfirstlane(s_a[kl]) >= 0) {   // a between factor ends here: Jb^T [Jb | r]
+                    const double x0 = LB[kl * LBS + oB[0]], x1 = LB[kl * LBS + oB[1]];
+                    D = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D, 0, 0, 0);
+                    D = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, D, 0, 0, 0);
+                }
+#pragma unroll
+                for (int d = 1; d <= 3; d++)
+                    if (__builtin_amdgcn_readfirstlane(s_a[kl + d]) == k) {   // ... or starts here: Ja^T [Ja | r]
+                        const double x0 = LB[(kl + d) * LBS + oA[0]], x1 = LB[(kl + d) * LBS + oA[1]];
+                        D = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D, 0, 0, 0);
+                        D = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, D, 0, 0, 0);
+                    }
+                const bool is_prior = v.prior_k[w] == k;
+                const double* Pq = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT;
+                const int mo = (v.mp_on[w] && hi - lo >= 3) ? k - lo : 99;   // 0,1,2: rows of the marginal prior
+                const double* ML = v.mp_L + (size_t)w * 729;
+                const double* Mg = v.mp_out + ((size_t)b * v.B + w) * 28;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int a = kq + 4 * r;
+                    double val = D[r];
+                    if (is_prior && a < 15) {
+                        double sum = 0.0;
+                        for (int rr = 0; rr < 15; rr++)
+                            sum = fma(Pq[15 + rr * 15 + a], ci < 15 ? Pq[15 + rr * 15 + ci] : Pq[rr], sum);
+                        val += sum;
+                    }
+                    if (mo == 0 && a < 15) val += ci < 15 ? ML[a * 27 + ci] : Mg[a];
+                    if ((mo == 1 || mo == 2) && a < 6 && (ci < 6 || ci == 15)) {
+                        const int ob = mo == 1 ? 15 : 21;
+                        val += ci < 6 ? ML[(ob + a) * 27 + ob + ci] : Mg[ob + a];
+                    }
+                    if (a < 15) {
+                        if (ci <= a) __builtin_nontemporal_store(val, Hk + H_D0 + h_tri(a, ci));   // lower triangle only
+                        else if (ci == 15) v.gvec[((size_t)hb * (size_t)v.G + (size_t)gk) * 15 + a] = val;
+                    }
+                }
+            }
+        }
+        K3LOOP(3);        // diagonal tile finished and stored
+        if (lf < lf0 + KPW) {
+            // ---- keyframe kf = lf: off-diagonal block Jj^T Ji, pose-only blocks, start D = Jj^T Jj
+            d4_t O = {0, 0, 0, 0};
+            D = (d4_t){0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                O = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[q], ai[q], O, 0, 0, 0);
+                D = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[q], aj[q], D, 0, 0, 0);
+            }
+            const int kl = lf, k = k0 + kl;
+            if (k >= rlo && k < rhi) {
+                double* Hk = v.H + ((size_t)hb * (size_t)v.G + (size_t)(gk0 + kl)) * HROW;
+                const int ak = __builtin_amdgcn_readfirstlane(s_a[kl]);
+                const int dk = ak >= 0 ? k - ak : 0;   // 1..3 when a between factor ends here
+                const int mo2 = (v.mp_on[w] && hi - lo >= 3) ? k - lo : 99;
+                const double* ML2 = v.mp_L + (size_t)w * 729;
+                d4_t T = {0, 0, 0, 0};                    // Jb^T Ja of the between factor ending here
+                if (dk >= 1) {
+                    const double b0 = LB[kl * LBS + oB[0]], b1 = LB[kl * LBS + oB[1]];
+                    const double a0 = LB[kl * LBS + oA[0]], a1 = LB[kl * LBS + oA[1]];
+                    T = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, T, 0, 0, 0);
+                    T = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, T, 0, 0, 0);
+                }
+                if (k > lo) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int a = kq + 4 * r;
+                        double val = O[r];
+                        if (dk == 1 && a < 6 && ci < 6) val += T[r];
+                        if (mo2 == 1 && a < 6 && ci < 15) val += ML2[(15 + a) * 27 + ci];            // (lo+1 pose) x (lo: 15)
+                        if (mo2 == 2 && a < 6 && ci < 6) val += ML2[(21 + a) * 27 + 15 + ci];        // (lo+2 pose) x (lo+1 pose)
+                        if (a < 15 && ci < 15) __builtin_nontemporal_store(val, Hk + H_D1 + a * 15 + ci);
+                    }
+                }
+                // pose x pose blocks two and three keyframes back, straight from the MFMA C layout (rows kq + 4 r)
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int a6 = kq + 4 * r;
+                    if (a6 < 6 && ci < 6) {
+                        const double x = T[r];
+                        Hk[H_D2 + a6 * 6 + ci] = (dk == 2 ? x : 0.0) + (mo2 == 2 ? ML2[(21 + a6) * 27 + ci] : 0.0);
+                        Hk[H_D3 + a6 * 6 + ci] = dk == 3 ? x : 0.0;
+                    }
+                }
+                // the marginal prior couples (lo+2 pose) with all 15 dof of lo: columns 6..14 of the
+                // d=2 strip (the solver reads them only for the window's third keyframe)
+                if (mo2 == 2 && lane < 54) {
+                    const int a6 = lane / 9, b9 = 6 + lane - a6 * 9;
+                    Hk[H_DX + a6 * 9 + (b9 - 6)] = ML2[(21 + a6) * 27 + b9];
+                }
+            }
+        }
+    }
+    K3LOOP(4);        // off-diagonal part
+#ifdef VF_SOLVE_STAMPS
+    if (blockIdx.x == 40 && blockIdx.y == (gridDim.y >> 1) && threadIdx.x == 0) for (int i = 0; i < 8; i++) g_k3_loop[i] = k3acc[i];
+#endif
+}
+
 // Four waves per SIMD (128 VGPRs) = four workgroups per CU, which is also what the 40 KB of LDS allow: 2.23 -> 1.98 ms once
 // the staging code had come down to 132 VGPRs (at 176 it spilled and lost).
 #ifndef VF_K3_WPE
@@ -797,158 +980,97 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     K3STAMP(3);   // everybody's
 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave-uniform: the keyframe loop and its tests stay scalar
-    const int ci = lane & 15, kq = lane >> 4;
-    const int colI = ci < 15 ? 15 + imu_col(0, ci) : -1, colJ = ci < 15 ? 15 + imu_col(1, ci) : -1;
-    auto load_ops = [&](int lf, double (&ai)[4], double (&aj)[4]) {
-        const double* F = LJ + lf * LJS;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int row = 4 * q + kq;
-            if (row < 15) {
-                ai[q] = ci < 15 ? F[row * 30 + colI] : F[row];
-                aj[q] = ci < 15 ? F[row * 30 + colJ] : F[row];
-            } else {
-                ai[q] = 0.0;
-                aj[q] = 0.0;
-            }
-        }
-    };
-    // Between-factor terms on the matrix cores as well: a between linearisation in LDS (r: 0, Ja: 6, Jb: 42, 6 rows) is
-    // the 6 x 16 operand X = [J | 0 ... 0 | r] (column 15 = r, like the IMU tiles), rows padded to 8 = two k-steps;
-    // X^T X adds J^T J to the pose block and J^T r to the gradient column of a diagonal tile, Xb^T Xa is the coupling
-    // block.  Per lane: the in-slot offsets of its two operand words (the slot's pad cell = 0 where X has no entry).
-    // (the VALU form, 6-term dot products per entry from LDS, cost 0.5 ms of K3's 2.7; this one about 0.35)
-    int oA[2], oB[2];
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int row = 4 * q + kq;
-        const bool valid = row < 6;
-        oA[q] = !valid ? BTW_OUT : (ci < 6 ? 6 + row * 6 + ci : (ci == 15 ? row : BTW_OUT));
-        oB[q] = !valid ? BTW_OUT : (ci < 6 ? 42 + row * 6 + ci : (ci == 15 ? row : BTW_OUT));
-    }
-#ifdef VF_SOLVE_STAMPS
-    unsigned long long k3acc[8] = {0}, k3prev = __builtin_amdgcn_s_memtime();
-#endif
-    d4_t D = {0, 0, 0, 0};
-    const int lf0 = K3_KPW * wv;
-#pragma unroll 1
-    for (int lf = lf0; lf <= lf0 + K3_KPW; lf++) {
-        K3LOOP(0);
-        double ai[4], aj[4];
-        load_ops(lf, ai, aj);
-        K3LOOP(1);    // operands of factor lf in registers
-        if (lf > lf0) {
-            // ---- finish keyframe kf = lf-1: D += Ji^T Ji of factor lf, add 6x6 terms, store
-#pragma unroll
-            for (int q = 0; q < 4; q++) D = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[q], ai[q], D, 0, 0, 0);
-            K3LOOP(2);    // Ji^T Ji issued
-            const int kl = lf - 1, k = k0 + kl;
-            if (k >= rlo && k < rhi) {
-                const long gk = gk0 + kl;
-                double* Hk = v.H + (size_t)gk * HROW;
-                // (accumulated into D itself: separate accumulators added at the end measured 4 % slower)
-                if (__builtin_amdgcn_readfirstlane(s_a[kl]) >= 0) {   // a between factor ends here: Jb^T [Jb | r]
-                    const double x0 = LB[kl * LBS + oB[0]], x1 = LB[kl * LBS + oB[1]];
-                    D = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D, 0, 0, 0);
-                    D = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, D, 0, 0, 0);
-                }
-#pragma unroll
-                for (int d = 1; d <= 3; d++)
-                    if (__builtin_amdgcn_readfirstlane(s_a[kl + d]) == k) {   // ... or starts here: Ja^T [Ja | r]
-                        const double x0 = LB[(kl + d) * LBS + oA[0]], x1 = LB[(kl + d) * LBS + oA[1]];
-                        D = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D, 0, 0, 0);
-                        D = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, D, 0, 0, 0);
-                    }
-                const bool is_prior = v.prior_k[w] == k;
-                const double* Pq = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT;
-                const int mo = (v.mp_on[w] && hi - lo >= 3) ? k - lo : 99;   // 0,1,2: rows of the marginal prior
-                const double* ML = v.mp_L + (size_t)w * 729;
-                const double* Mg = v.mp_out + ((size_t)b * v.B + w) * 28;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int a = kq + 4 * r;
-                    double val = D[r];
-                    if (is_prior && a < 15) {
-                        double sum = 0.0;
-                        for (int rr = 0; rr < 15; rr++)
-                            sum = fma(Pq[15 + rr * 15 + a], ci < 15 ? Pq[15 + rr * 15 + ci] : Pq[rr], sum);
-                        val += sum;
-                    }
-                    if (mo == 0 && a < 15) val += ci < 15 ? ML[a * 27 + ci] : Mg[a];
-                    if ((mo == 1 || mo == 2) && a < 6 && (ci < 6 || ci == 15)) {
-                        const int ob = mo == 1 ? 15 : 21;
-                        val += ci < 6 ? ML[(ob + a) * 27 + ob + ci] : Mg[ob + a];
-                    }
-                    if (a < 15) {
-                        if (ci <= a) __builtin_nontemporal_store(val, Hk + H_D0 + h_tri(a, ci));   // lower triangle only
-                        else if (ci == 15) v.gvec[(size_t)gk * 15 + a] = val;
-                    }
-                }
-            }
-        }
-        K3LOOP(3);        // diagonal tile finished and stored
-        if (lf < lf0 + K3_KPW) {
-            // ---- keyframe kf = lf: off-diagonal block Jj^T Ji, pose-only blocks, start D = Jj^T Jj
-            d4_t O = {0, 0, 0, 0};
-            D = (d4_t){0, 0, 0, 0};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                O = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[q], ai[q], O, 0, 0, 0);
-                D = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[q], aj[q], D, 0, 0, 0);
-            }
-            const int kl = lf, k = k0 + kl;
-            if (k >= rlo && k < rhi) {
-                double* Hk = v.H + (size_t)(gk0 + kl) * HROW;
-                const int ak = __builtin_amdgcn_readfirstlane(s_a[kl]);
-                const int dk = ak >= 0 ? k - ak : 0;   // 1..3 when a between factor ends here
-                const int mo2 = (v.mp_on[w] && hi - lo >= 3) ? k - lo : 99;
-                const double* ML2 = v.mp_L + (size_t)w * 729;
-                d4_t T = {0, 0, 0, 0};                    // Jb^T Ja of the between factor ending here
-                if (dk >= 1) {
-                    const double b0 = LB[kl * LBS + oB[0]], b1 = LB[kl * LBS + oB[1]];
-                    const double a0 = LB[kl * LBS + oA[0]], a1 = LB[kl * LBS + oA[1]];
-                    T = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, T, 0, 0, 0);
-                    T = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, T, 0, 0, 0);
-                }
-                if (k > lo) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int a = kq + 4 * r;
-                        double val = O[r];
-                        if (dk == 1 && a < 6 && ci < 6) val += T[r];
-                        if (mo2 == 1 && a < 6 && ci < 15) val += ML2[(15 + a) * 27 + ci];            // (lo+1 pose) x (lo: 15)
-                        if (mo2 == 2 && a < 6 && ci < 6) val += ML2[(21 + a) * 27 + 15 + ci];        // (lo+2 pose) x (lo+1 pose)
-                        if (a < 15 && ci < 15) __builtin_nontemporal_store(val, Hk + H_D1 + a * 15 + ci);
-                    }
-                }
-                // pose x pose blocks two and three keyframes back, straight from the MFMA C layout (rows kq + 4 r)
-#pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    const int a6 = kq + 4 * r;
-                    if (a6 < 6 && ci < 6) {
-                        const double x = T[r];
-                        Hk[H_D2 + a6 * 6 + ci] = (dk == 2 ? x : 0.0) + (mo2 == 2 ? ML2[(21 + a6) * 27 + ci] : 0.0);
-                        Hk[H_D3 + a6 * 6 + ci] = dk == 3 ? x : 0.0;
-                    }
-                }
-                // the marginal prior couples (lo+2 pose) with all 15 dof of lo: columns 6..14 of the
-                // d=2 strip (the solver reads them only for the window's third keyframe)
-                if (mo2 == 2 && lane < 54) {
-                    const int a6 = lane / 9, b9 = 6 + lane - a6 * 9;
-                    Hk[H_DX + a6 * 9 + (b9 - 6)] = ML2[(21 + a6) * 27 + b9];
-                }
-            }
-        }
-    }
-    K3LOOP(4);        // off-diagonal part
-#ifdef VF_SOLVE_STAMPS
-    if (blockIdx.x == 40 && blockIdx.y == (gridDim.y >> 1) && threadIdx.x == 0) for (int i = 0; i < 8; i++) g_k3_loop[i] = k3acc[i];
-#endif
+    assemble_tile<K3_KPW>(v, LJ, LB, s_a, w, b, h_buf(v, w), k0, gk0, lo, hi, rlo, rhi, wv, lane);
     K3STAMP(4);       // wave 0: MFMAs done, stores issued
 #ifdef VF_SOLVE_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     K3STAMP(5);       // ... and acknowledged
 #endif
+}
+
+
+// ------------------------------------------------------------------------------------ K1 + K3 fused
+// k_linearize_assemble: the IMU factors of a tile are linearised INTO LDS and assembled from there -- the whitened
+// Jacobian (2.4 KB per factor written by K1 and read back by K3, about 5 GB per LM trial of the full batch) never touches
+// HBM.  One wave per tile of FA keyframes (one workgroup = one wave, so each of the four SIMDs of a CU works on its own
+// tile with the whole register file, as K1 needs): lanes 0 .. FA run the K1 body for the factors k0 .. k0+FA (the last
+// one is the halo: its i-side feeds H[k0+FA-1]; it is recomputed by the next tile), writing (r | J) to their rows of the
+// LDS tile and r also to HBM for the cost; then the wave forms the FA block rows exactly as k_assemble does
+// (assemble_tile) and stores them into the H / g buffer that goes with the states it linearised (buffer sel ^ which):
+// H is double-buffered like the states, so a rejected trial costs nothing to undo and an accepted one is a flip of sel.
+// The J computation uses FA + 1 of the wave's 64 lanes; that is affordable because the kernel is bound by its HBM
+// stream (1.8 KB factor record + 0.6 KB between linearisation in, 3.6 KB of H out per keyframe), not by the VALU.
+// ends_only (warm start after vf_engine_slide): only the tiles at the two ends of a window (see k_linearize_tail).
+constexpr int FA = 8;
+static_assert((FA + 1) * LJS * 8 + (FA + 3) * LBS * 8 + 64 <= 40960, "four tiles per CU");
+__global__ void __launch_bounds__(64) k_linearize_assemble(View v, int which, int ends_only) {
+    __shared__ double LJ[(FA + 1) * LJS];
+    __shared__ double LB[(FA + 3) * LBS];
+    __shared__ int s_a[FA + 3];
+    const int lane = threadIdx.x;
+    const int w = blockIdx.y;
+    if (window_done(v, w)) return;
+    const int k0 = blockIdx.x * FA;
+    const int lo = v.lo[w], hi = v.hi[w];
+    if (k0 + FA <= lo || k0 >= hi) return;            // no active keyframe in this tile (uniform)
+    if (ends_only) {
+        const int fr = v.fresh[w];                    // 1 + appended keyframes (k_linearize_tail)
+        if (fr >= 2 && fr < 64 && k0 >= lo + 4 && k0 + FA <= hi - (fr - 1) - 4) return;
+    }
+    const long gk0 = (long)w * v.M + k0;
+    const int b = v.sel[w] ^ which;
+    const size_t tiles = (size_t)(v.G >> 6);
+    const double* btw_out = v.btw_out + (size_t)b * tiles * BTW_OUT * TILE;
+    // between linearisations of slots k0 .. k0+FA+2 (K2 ran before this kernel): loads issued now, used after the J phase
+    constexpr int NB = ((FA + 3) * BTW_OUT + 63) / 64;
+    double tb[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        const int e = lane + 64 * j;
+        const int sl = e / BTW_OUT, f = e - sl * BTW_OUT;
+        const int ks = k0 + sl;
+        const long gs = gk0 + sl;
+        tb[j] = (e < (FA + 3) * BTW_OUT && ks > lo && ks < hi) ? btw_out[((size_t)(gs >> 6) * BTW_OUT + f) * TILE + (gs & 63)] : 0.0;
+    }
+    int a_src = -1;
+    if (lane < FA + 3) {
+        const int ks = k0 + lane;
+        if (ks > lo && ks < hi) { a_src = v.btw_a[gk0 + lane]; if (a_src < lo || a_src >= ks) a_src = -1; }
+    }
+    // the structural zeros of J (and the rows of factors outside the window) must read as zeros
+#ifndef VF_FUSED_NO_ZERO
+    for (int e = lane; e < (FA + 1) * LJS; e += 64) LJ[e] = 0.0;
+#endif
+#ifndef VF_FUSED_NO_A       // (probe builds: phases compiled out to see what each costs)
+    if (lane <= FA) {
+        const int k = k0 + lane;
+        if (k > lo && k < hi) {
+            const long gk = gk0 + lane;
+            double* out_r = lane < FA ? v.imu_out + ((size_t)b * tiles + (size_t)(gk >> 6)) * IMU_OUT * TILE + (gk & 63) : nullptr;
+            linearize_imu_core(v, b, gk, LdsSink{LJ + lane * LJS, out_r});
+        }
+    }
+#endif
+    if (lane < FA + 3) {
+        LB[lane * LBS + BTW_OUT] = 0.0;       // the pad cell of a slot: the zero the MFMA operand maps point at
+        s_a[lane] = a_src;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        const int e = lane + 64 * j;
+        if (e < (FA + 3) * BTW_OUT) { const int sl = e / BTW_OUT; LB[sl * LBS + (e - sl * BTW_OUT)] = tb[j]; }
+    }
+    __syncthreads();
+#ifndef VF_FUSED_NO_B
+    assemble_tile<FA>(v, LJ, LB, s_a, w, b, b, k0, gk0, lo, hi, lo, hi, 0, lane);
+#endif
+}
+// the head factor of every window (slot lo + 1), by K1 proper: fused engines keep no Jacobians in HBM, and the
+// marginalisation of the oldest keyframe (k_marginalize) reads this one
+__global__ void __launch_bounds__(64) k_linearize_head(View v) {
+    const int w = blockIdx.x * 64 + threadIdx.x;
+    if (w >= v.B) return;
+    linearize_imu_factor<false>(v, 0, (long)w * v.M + v.lo[w] + 1);
 }
 
 
@@ -1154,8 +1276,9 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     // ---- H block row prefetch (HBM -> registers) and commit (registers -> LDS slot) ---------
     // (passed by value: captured-by-reference scalars ended up in scratch memory)
     struct HRow { double h0[2], h1[4], h2, h3, hx, hg; };
-    const double* __restrict__ Hbase = v.H + base * HROW;
-    const double* __restrict__ gbase = v.gvec + base * 15;
+    const size_t hbase = (size_t)h_buf(v, w) * (size_t)v.G + base;      // the buffer of the window's current normal equations
+    const double* __restrict__ Hbase = v.H + hbase * HROW;
+    const double* __restrict__ gbase = v.gvec + hbase * 15;
     const double* __restrict__ zrow = v.zrow;
     double* __restrict__ Lbase = v.Lp + base * PANEL;
     double* __restrict__ dbase = v.delta + base * 15;
@@ -1595,7 +1718,7 @@ __device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int
     const int lo = v.lo[w];
     const int li = lane & 15, lq = lane >> 4;
     const size_t base = (size_t)w * v.M + lo + cg.i0;
-    const double* __restrict__ Hb = v.H + base * HROW;
+    const double* __restrict__ Hb = v.H + ((size_t)h_buf(v, w) * (size_t)v.G + base) * HROW;
     double* __restrict__ Vb = v.Vp + base * VROW;
 
     // E[(kk, a)][j]: dof a of the chunk's keyframe kk (window keyframe i0 + kk) against separator column j:
@@ -2416,10 +2539,16 @@ void launch_linearize_between_prior(const View& v, int which, hipStream_t s) {
     hipLaunchKernelGGL(k_linearize_between_prior, dim3(nblk(v.G, 256) + nb_pri), dim3(256), 0, s, v, which, nb_pri);
 }
 void launch_linearize_tail(const View& v, int nslid, hipStream_t s) {
-    hipLaunchKernelGGL(k_linearize_tail, dim3(2 * v.B + nblk(v.B, 64)), dim3(VF_K1_BLOCK), 0, s, v, nslid);
+    hipLaunchKernelGGL(k_linearize_tail, dim3(2 * v.B + nblk(v.B, 64)), dim3(VF_K1_BLOCK), 0, s, v, nslid, v.fused ? 0 : 1);
 }
 void launch_linearize_prior(const View& v, int which, hipStream_t s) {
     hipLaunchKernelGGL(k_linearize_prior, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, which);
+}
+void launch_linearize_assemble(const View& v, int which, int ends_only, hipStream_t s) {
+    hipLaunchKernelGGL(k_linearize_assemble, dim3((unsigned)(v.M / FA), (unsigned)v.B), dim3(64), 0, s, v, which, ends_only);
+}
+void launch_linearize_head(const View& v, hipStream_t s) {
+    hipLaunchKernelGGL(k_linearize_head, dim3(nblk(v.B, 64)), dim3(64), 0, s, v);
 }
 void launch_assemble(const View& v, hipStream_t s) {
     // (persistent forms were measured slower: one workgroup per CU with the next tile's loads in flight 5.1 ms, a plain

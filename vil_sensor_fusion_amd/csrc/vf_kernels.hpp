@@ -93,8 +93,10 @@ struct View {
     double* mp_L;       // [B][27][27]  information
     double* mp_eta;     // [B][27]      gradient at the linearisation point
     double* mp_out;     // [2][B][28]   L d + eta (27) and the cost 0.5 d^T L d + eta^T d
-    double* H;          // [G][4][15][15]      block d of row k = H[k][k-d]
-    double* gvec;       // [G][15]
+    int fused;          // 1: K1 + K3 fused (k_linearize_assemble); H and g are then double-buffered like the states, the
+                        // normal equations of window w's current states live in buffer sel[w] (h_buf)
+    double* H;          // [1 or 2][G][512]    block row of keyframe k ("Block row of H" above)
+    double* gvec;       // [1 or 2][G][15]
     double* zrow;       // [900] zeros
     double* delta;      // [G][15] + [B]       increments; tail: solve-failure flag per window (time-sharded windows: summed
                         //                     over the ranks together with the increments, one all-reduce)
@@ -144,6 +146,9 @@ void launch_linearize_between_prior(const View& v, int which, hipStream_t s);   
 void launch_linearize_tail(const View& v, int nslid, hipStream_t s);   // warm start: factors of the appended keyframes + priors
 void launch_linearize_all(const View& v, int which, hipStream_t s);   // the three above in one launch (few windows)
 void launch_assemble(const View& v, hipStream_t s);
+// K1 + K3 fused: linearise the IMU factors at buffer sel ^ which and write that buffer's H, g (fused engines)
+void launch_linearize_assemble(const View& v, int which, int ends_only, hipStream_t s);
+void launch_linearize_head(const View& v, hipStream_t s);   // K1 proper for the first factor of every window (for k_marginalize)
 void launch_band_solve(const View& v, hipStream_t s);
 void launch_retract(const View& v, hipStream_t s);
 void launch_decide(const View& v, int init, hipStream_t s);

@@ -13,7 +13,7 @@ from ._lib import check
 
 IMU_RECORD, BTW_RECORD, PRIOR_RECORD = 190, 28, 31
 STAGES = {"linearize_imu": 1, "linearize_between": 2, "assemble": 3, "solve": 4, "retract": 5,
-          "decide": 6, "assemble_idle": 7}
+          "decide": 6, "assemble_idle": 7, "linearize_assemble": 8}
 # GraphManager.cpp:27-31: pose (rad x3, m x3), velocity, bias prior sigmas
 REFERENCE_PRIOR_SIGMAS = np.array([1e-6] * 3 + [5e-5] * 3 + [1e-5] * 3 + [1e-7] * 6)
 

@@ -5,7 +5,7 @@ if len(sys.argv) > 2 or (len(sys.argv) == 2 and not sys.argv[1].endswith('.so'))
     for so in sys.argv[1:]:
         subprocess.run([sys.executable, __file__, os.path.abspath(so)])
     sys.exit(0)
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from vil_sensor_fusion_amd import _lib
 _lib._SO = sys.argv[1]

@@ -177,7 +177,8 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
 #define AL(p, n) if ((rc = e->alloc(&(p), (n))) != VF_OK) { vf_engine_destroy(e); return rc; }
     AL(v.x, 2 * 16 * G);
     AL(v.imu_in, tiles * vf::IMU_IN * 64);
-    AL(v.imu_out, 2 * tiles * vf::IMU_OUT * 64);
+    AL(v.imu_r, 2 * tiles * vf::IMU_R * 64);
+    AL(v.imu_j, 2 * (G / vf::JT) * vf::JT_STRIDE);
     AL(v.btw_a, G);
     AL(v.btw_in, tiles * vf::BTW_IN * 64);
     AL(v.btw_out, 2 * tiles * vf::BTW_OUT * 64);
@@ -803,7 +804,9 @@ int vf_engine_compact(vf_engine* e, int shift) {
         if (e->h_lo[w] < shift) return fail(VF_ERR_BAD_KEY, "window %d: lo %d < shift %d (live keyframes would be lost)", w, e->h_lo[w], shift);
     const size_t keepk = (size_t)(v.M - shift);              // slots kept per window
     // staging buffer: the largest per-window segment moved at once (imu_out tiles)
-    const size_t seg_max = (keepk / 64) * vf::IMU_OUT * 64;
+    constexpr int JNF = vf::JT_STRIDE * (64 / vf::JT) / 64;      // the J stream of 64 slots, counted in "fields" of 64 doubles (292)
+    static_assert(JNF * 64 == vf::JT_STRIDE * (64 / vf::JT), "J stream tiles per 64 slots");
+    const size_t seg_max = (keepk / 64) * (size_t)(JNF > vf::IMU_IN ? JNF : vf::IMU_IN) * 64;
     int rc = e->ensure_stage(seg_max * sizeof(double));
     if (rc) return rc;
     auto move = [&](double* base, size_t per_slot_window_stride, size_t src_off, size_t n) -> int {
@@ -821,7 +824,7 @@ int vf_engine_compact(vf_engine* e, int shift) {
     for (int bc = 0; bc < 32; bc++)
         if ((rc = move(v.x + (size_t)bc * G, (size_t)v.M, (size_t)shift, keepk))) return rc;
     // AoSoA arrays: per window tilesM tiles of nf*64 doubles
-    struct { double* p; int nf; int bufs; } arrs[] = {{v.imu_in, vf::IMU_IN, 1}, {v.imu_out, vf::IMU_OUT, 2},
+    struct { double* p; int nf; int bufs; } arrs[] = {{v.imu_in, vf::IMU_IN, 1}, {v.imu_r, vf::IMU_R, 2}, {v.imu_j, JNF, 2},
                                                        {v.btw_in, vf::BTW_IN, 1}, {v.btw_out, vf::BTW_OUT, 2}};
     for (auto& a : arrs)
         for (int bf = 0; bf < a.bufs; bf++) {
@@ -880,8 +883,7 @@ int vf_engine_read_imu_lin(vf_engine* e, int window, int which, int k0, int n, d
     const int b = sel ^ (which ? 1 : 0);
     const size_t bytes = (size_t)n * vf::IMU_OUT * sizeof(double);
     if ((rc = e->ensure_stage(bytes))) return rc;
-    const double* src = e->v.imu_out + (size_t)b * (size_t)(e->v.G / 64) * vf::IMU_OUT * 64;
-    vf::launch_gather(src, e->stage, (long)window * e->v.M + k0, n, vf::IMU_OUT, e->stream);
+    vf::launch_gather_imu_lin(e->v, b, (long)window * e->v.M + k0, n, e->stage, e->stream);
     HIPCHK(hipGetLastError());
     std::vector<double> h((size_t)n * vf::IMU_OUT);
     HIPCHK(hipMemcpyAsync(h.data(), e->stage, bytes, hipMemcpyDeviceToHost, e->stream));

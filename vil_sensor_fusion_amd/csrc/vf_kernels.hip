@@ -256,35 +256,100 @@ __global__ void __launch_bounds__(256) k_preintegrate(View v, long g0, int n, co
 #ifndef VF_K1_WAVES
 #define VF_K1_WAVES 1
 #endif
-// Where a factor's (r | J) goes.  K1: the factor's AoSoA record in HBM, non-temporal stores (write-once streams of 2.4 KB
-// per factor, far beyond L2/MALL: +15 % measured).  `jac` = false (time-sharded windows, factors this rank does not
-// assemble): residual only.
-struct HbmSink {
-    double* out;
-    bool jac;
-    VF_DI void r(int a, double x) const { __builtin_nontemporal_store(x, out + (size_t)a * TILE); }
-    VF_DI void j(int row, int col, double x) const { if (jac) __builtin_nontemporal_store(x, out + (size_t)(15 + row * 30 + col) * TILE); }
+// Order in which K1 produces the non-zero entries of the whitened 15x30 Jacobian (column index = GTSAM key order
+// X_i(6) V_i(3) X_j(6) V_j(3) B_i(6) B_j(6)), split by the keyframe the column belongs to: this IS the order of the J
+// stream in HBM (vf_kernels.hpp "imu_j"), so K1 stores pairs of consecutive entries of a side as it goes.
+struct JMap {
+    short idx[450];          // entry (row * 30 + col) -> position in its side's stream, -1 = structural zero
+    short fld[2 * JS_PAIRS]; // stream word (2 * pair + half, i-side pairs first) -> row * 30 + col, -1 = padding
+    int n[2];
 };
+__host__ __device__ constexpr bool jcol_is_j(int col) { return (col >= 9 && col < 18) || col >= 24; }
+constexpr JMap make_jmap() {
+    JMap m{};
+    for (int i = 0; i < 450; i++) m.idx[i] = -1;
+    for (int i = 0; i < 2 * JS_PAIRS; i++) m.fld[i] = -1;
+    m.n[0] = m.n[1] = 0;
+    auto emit = [&m](int row, int col) {
+        const int side = jcol_is_j(col) ? 1 : 0;
+        const int e = m.n[side]++;
+        m.idx[row * 30 + col] = (short)e;
+        m.fld[(side ? 2 * JS_PI : 0) + e] = (short)(row * 30 + col);
+    };
+    for (int c = 0; c < 3; c++) {               // (the loop nest of linearize_imu_core)
+        for (int a = 0; a < 9; a++) emit(a, c);
+        for (int a = 0; a < 6; a++) emit(a, 3 + c);
+        for (int a = 0; a < 9; a++) emit(a, 6 + c);
+        for (int a = 0; a < 9; a++) emit(a, 9 + c);
+        for (int a = 0; a <= 3 + c; a++) emit(a, 12 + c);
+        for (int a = 0; a < 9; a++) emit(a, 15 + c);
+    }
+    for (int c = 0; c < 6; c++)
+        for (int a = 0; a < 10 + c; a++) { emit(a, 18 + c); emit(a, 24 + c); }
+    return m;
+}
+constexpr JMap JM = make_jmap();
+static_assert(JM.n[0] == JS_NI && JM.n[1] == JS_NJ, "J stream sizes");
+__device__ constexpr JMap JMD = make_jmap();             // the same tables in device memory, for run-time indexed reads
+VF_DI const double* jtile_ptr(const double* base, long gk) { return base + (size_t)(gk >> 3) * JT_STRIDE; }
+// entry (row, col) of the Jacobian of the factor in slot gk of a J stream buffer (0 for a structural zero)
+VF_DI double jstream_entry(const double* jbuf, long gk, int row, int col) {
+    const int e = JMD.idx[row * 30 + col];
+    if (e < 0) return 0.0;
+    const int pair = (jcol_is_j(col) ? JS_PI : 0) + (e >> 1);
+    return jbuf[(size_t)(gk >> 3) * JT_STRIDE + ((size_t)pair * JT + (gk & 7)) * 2 + (e & 1)];
+}
+
+// Where a factor's (r | J) goes.  K1: r into the AoSoA residual array, J into the factor's slot of its J-stream tile as
+// 16-byte non-temporal stores of two consecutive entries (write-once streams far beyond L2 / MALL: +15 % measured for
+// non-temporal).  (A copy of the i-side pairs of a tile's first factor into the tile in front of it, so that K3 would
+// find its halo factor in its own block, cost K1 0.48 ms: 16-byte partial-line writes.  K3 reads the halo where it is.)
+// `jac` = false (time-sharded windows, factors this rank does not assemble): residual only.
+struct HbmSink {
+    double* out_r;      // imu_r row of this factor (+ a * TILE)
+    double* slot;       // imu_j: tile base + 2 * slot
+    bool jac;
+    double pend[2];
+    VF_DI void r(int a, double x) { __builtin_nontemporal_store(x, out_r + (size_t)a * TILE); }
+    VF_DI void pair(int side, int p, double x0, double x1) {
+        if (!jac) return;
+        d2_t t;
+        t.x = x0;
+        t.y = x1;
+        __builtin_nontemporal_store(t, (d2_t*)(slot + (size_t)((side ? JS_PI : 0) + p) * (JT * 2)));
+    }
+    VF_DI void j(int row, int col, double x) {
+        const int e = JM.idx[row * 30 + col];          // compile-time constants once the core's loops are unrolled
+        const int side = jcol_is_j(col) ? 1 : 0;
+        if (e & 1) pair(side, e >> 1, pend[side], x);
+        else if (e == JM.n[side] - 1) pair(side, e >> 1, x, 0.0);   // odd count: the last entry goes with a zero
+        else pend[side] = x;
+    }
+};
+// LDS image of one IMU linearisation = its words of the J stream as they are ([0, 2 JS_PAIRS): i-side pairs then j-side
+// pairs), then r (15) and a zero cell the MFMA operand maps point at for structural zeros and padding
+constexpr int LJ_R = 2 * JS_PAIRS, LJ_ZERO = LJ_R + 15;
+constexpr int LJS = 310;        // LDS stride of one factor (even: the staging writes are 16-byte; 620 dwords = 12 mod 32 banks: the 8 slots of a pair hit 8 different bank groups)
 // Fused linearise + assemble (k_linearize_assemble): (r | J) of a factor goes to its row of the workgroup's LDS tile and
 // never to HBM; only the residual (the LM cost, k_decide) is also stored, for the tile's own factors (out_r != nullptr).
 struct LdsSink {
     double* F;
     double* out_r;
-    VF_DI void r(int a, double x) const { F[a] = x; if (out_r) __builtin_nontemporal_store(x, out_r + (size_t)a * TILE); }
-    VF_DI void j(int row, int col, double x) const { F[15 + row * 30 + col] = x; }
+    VF_DI void r(int a, double x) { F[LJ_R + a] = x; if (out_r) __builtin_nontemporal_store(x, out_r + (size_t)a * TILE); }
+    VF_DI void j(int row, int col, double x) { F[(jcol_is_j(col) ? 2 * JS_PI : 0) + JM.idx[row * 30 + col]] = x; }
 };
 
 // CombinedImuFactor: residual and whitened 15x30 Jacobian of the factor in slot gk, at the states of buffer b.
 template <class Sink>
-__device__ __forceinline__ void linearize_imu_core(const View& v, const int b, const long gk, const Sink sink) {
+__device__ __forceinline__ void linearize_imu_core(const View& v, const int b, const long gk, Sink& sink) {
     const double* __restrict__ in = v.imu_in + (size_t)(gk >> 6) * IMU_IN * TILE + (gk & 63);
 #ifdef VF_K1_NTLOAD
 #define IN(f) __builtin_nontemporal_load(in + (size_t)(f) * TILE)
 #else
 #define IN(f) in[(size_t)(f) * TILE]
 #endif
-    struct RRef { const Sink& s; int a; VF_DI void operator=(double x) const { s.r(a, x); } };
-    struct JRef { const Sink& s; int row, col; VF_DI void operator=(double x) const { s.j(row, col, x); } };
+    struct RRef { Sink& s; int a; VF_DI void operator=(double x) const { s.r(a, x); } };
+    struct JRef { Sink& s; int row, col; VF_DI void operator=(double x) const { s.j(row, col, x); } };
 #define OUT(f) (RRef{sink, (f)})
 #define JOUT(r, c) (JRef{sink, (r), (c)})
 
@@ -437,8 +502,12 @@ __device__ __forceinline__ void linearize_imu_factor(const View& v, int which, c
     if (window_done(v, w)) return;
     const bool jac = !SH || !shard_skips_factor(v, w, k);
     const int b = v.sel[w] ^ which;
-    double* __restrict__ out = v.imu_out + ((size_t)b * (size_t)(v.G >> 6) + (size_t)(gk >> 6)) * IMU_OUT * TILE + (gk & 63);
-    linearize_imu_core(v, b, gk, HbmSink{out, jac});
+    double* jbuf = v.imu_j + (size_t)b * (size_t)(v.G >> 3) * JT_STRIDE;
+    HbmSink sink;
+    sink.out_r = v.imu_r + ((size_t)b * (size_t)(v.G >> 6) + (size_t)(gk >> 6)) * IMU_R * TILE + (gk & 63);
+    sink.slot = jbuf + (size_t)(gk >> 3) * JT_STRIDE + (gk & 7) * 2;
+    sink.jac = jac;
+    linearize_imu_core(v, b, gk, sink);
 }
 
 // ------------------------------------------------------------------------------------ K2
@@ -696,7 +765,6 @@ constexpr int AT = VF_K3_AT;    // keyframes per block
 constexpr int K3_NT = VF_K3_NT; // threads per block
 constexpr int K3_KPW = AT / (K3_NT / 64);   // keyframes per wave
 static_assert(K3_KPW * (K3_NT / 64) == AT && K3_NT % AT == 0, "K3 tiling");
-constexpr int LJS = 465;        // LDS stride of one factor's (r | J), odd
 constexpr int LBS = 79;         // LDS stride of one between linearisation (78 + pad), odd
 
 #ifdef VF_SOLVE_STAMPS   // diagnostic build only: phase time stamps of one workgroup of K3 (tools/k3_stamps_probe.py)
@@ -720,20 +788,25 @@ __device__ __forceinline__ void assemble_tile(const View& v, const double* __res
                                               const long gk0, const int lo, const int hi, const int rlo, const int rhi,
                                               const int wv, const int lane) {
     const int ci = lane & 15, kq = lane >> 4;
-    const int colI = ci < 15 ? 15 + imu_col(0, ci) : -1, colJ = ci < 15 ? 15 + imu_col(1, ci) : -1;
+    // MFMA operand words of this lane in a factor's LDS image: J[4 q + kq][column ci of the i / j side], column 15 = r;
+    // structural zeros and the padding row 15 read the zero cell
+    int offI[4], offJ[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int row = 4 * q + kq;
+        offI[q] = offJ[q] = LJ_ZERO;
+        if (row < 15) {
+            if (ci < 15) {
+                const int eI = JMD.idx[row * 30 + imu_col(0, ci)], eJ = JMD.idx[row * 30 + imu_col(1, ci)];
+                if (eI >= 0) offI[q] = eI;
+                if (eJ >= 0) offJ[q] = 2 * JS_PI + eJ;
+            } else offI[q] = offJ[q] = LJ_R + row;
+        }
+    }
     auto load_ops = [&](int lf, double (&ai)[4], double (&aj)[4]) {
         const double* F = LJ + lf * LJS;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int row = 4 * q + kq;
-            if (row < 15) {
-                ai[q] = ci < 15 ? F[row * 30 + colI] : F[row];
-                aj[q] = ci < 15 ? F[row * 30 + colJ] : F[row];
-            } else {
-                ai[q] = 0.0;
-                aj[q] = 0.0;
-            }
-        }
+        for (int q = 0; q < 4; q++) { ai[q] = F[offI[q]]; aj[q] = F[offJ[q]]; }
     };
     // Between-factor terms on the matrix cores as well: a between linearisation in LDS (r: 0, Ja: 6, Jb: 42, 6 rows) is
     // the 6 x 16 operand X = [J | 0 ... 0 | r] (column 15 = r, like the IMU tiles), rows padded to 8 = two k-steps;
@@ -875,7 +948,7 @@ __device__ __forceinline__ void assemble_tile(const View& v, const double* __res
 #endif
 __attribute__((amdgpu_waves_per_eu(VF_K3_WPE, VF_K3_WPE)))
 __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
-    __shared__ double LJ[(AT + 1) * LJS];
+    __shared__ __attribute__((aligned(16))) double LJ[(AT + 1) * LJS];
     __shared__ double LB[(AT + 3) * LBS];
     __shared__ int s_a[AT + 3];
     const int tid = threadIdx.x;
@@ -899,49 +972,46 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     if (v.sh_G > 1 && rhi + 2 <= hi) rhi += 2;   // tail rows of the rank's last chunk (see shard_skips_factor)
     else if (v.sh_G > 1) rhi = hi;
     if (k0 + AT <= rlo || k0 >= rhi) return; // no owned active keyframe in this tile (uniform)
+#ifdef VF_K3_STAGGER
+    // the four workgroups a CU starts with (linear ids c, c + 256, c + 512, c + 768: round robin over 8 XCDs x 32 CUs)
+    // begin a quarter of a tile time apart, so that the load phase of one overlaps the MFMA phase of another
+    {
+        const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+        if (lin < 1024u)
+            for (unsigned i = 0; i < ((lin >> 8) & 3u) * VF_K3_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     K3STAMP(0);
     const int b = v.sel[w];
     const size_t tiles = (size_t)(v.G >> 6);
-    const double* imu_out = v.imu_out + (size_t)b * tiles * IMU_OUT * TILE;
     const double* btw_out = v.btw_out + (size_t)b * tiles * BTW_OUT * TILE;
 
-    // ---- stage (r | J) of factors k0 .. k0+15: thread = (field group, factor), 128-B segments.
-    // All of a thread's global loads are issued before the first LDS write (38 loads in flight
-    // per thread) so that the tile costs one HBM round trip, not one per batch.
+    // ---- stage the tile's 9 IMU linearisations from the J stream: the tile's own block is copied into LDS as it is
+    // (146 pairs x 8 slots, 16 bytes per lane and load, every 128-B line used whole, one ds_write_b128 each), the i-side
+    // pairs of the halo factor come from slot 0 of the next tile.  All of a thread's global loads are issued before the
+    // first LDS write.
     {
-        constexpr int NG = K3_NT / AT, NIT = (IMU_OUT + NG - 1) / NG, N16 = (IMU_OUT + K3_NT - 1) / K3_NT,
+        constexpr int NOWN = JS_PAIRS * JT, NALL = NOWN + JS_PI, NJ = (NALL + K3_NT - 1) / K3_NT,
                       NB = ((AT + 3) * BTW_OUT + K3_NT - 1) / K3_NT;
-        const int fac = tid % AT, fg = tid / AT;
-        const int k = k0 + fac;
-        const bool ok = k > lo && k < hi;
-        const double* src = imu_out + (size_t)(gk0 >> 6) * IMU_OUT * TILE + (gk0 & 63) + fac;
-        // A third of J is structurally zero and is not read.  Which fields a thread skips is a compile-time bit mask
-        // per iteration, tested with the thread's field-group bit (evaluating imu_field_is_zero(f) per load, with its
-        // divisions, was about 50 instructions per load in front of the loads); a skipped or out-of-window load is not
-        // predicated either: it reads the engine's row of zeros (one cached line), so the loads are unconditional.
-        // (2.57 -> 2.45 ms, 176 -> 132 VGPRs; the same treatment of the 2 + 4 other loads per thread measured no gain)
-        static_assert(NG <= 32 && 32 % NG == 0, "field groups per mask word");
-        double tj[NIT];
+        static_assert(AT == JT, "K3 tiles are the tiles of the J stream");
+        const d2_t* jt = (const d2_t*)(v.imu_j + ((size_t)b * (size_t)(v.G >> 3) + (size_t)(gk0 >> 3)) * JT_STRIDE);
+        const bool halo_ok = k0 + AT > lo && k0 + AT < hi;          // (then the next tile exists: k0 + AT < M)
+        d2_t tj[NJ];
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int f = it * NG + fg;
-            const unsigned wordm = imu_nz_word((it * NG) >> 5);                    // compile-time
-            const bool nz = (wordm >> (((it * NG) & 31) + fg)) & 1u;
-            const double* p = (ok && nz) ? src + (size_t)f * TILE : v.zrow;
-            tj[it] = *p;
+        for (int it = 0; it < NJ; it++) {
+            const int e = it * K3_NT + tid;
+            const int src = e < NOWN ? e : (e < NALL && halo_ok ? NOWN + (e - NOWN) * JT : 0);   // halo: pair p of slot 0 of the next tile
+            tj[it] = jt[src];
         }
-        // factor k0+16 (its i-side feeds H[k0+15][k0+15]); it may live in the next AoSoA tile
-        const int k16 = k0 + AT;
-        const bool ok16 = k16 > lo && k16 < hi;
-        const long g16 = gk0 + AT;
-        const double* src16 = imu_out + (size_t)(g16 >> 6) * IMU_OUT * TILE + (g16 & 63);
-        double t16[N16];
-#pragma unroll
-        for (int j = 0; j < N16; j++) {
-            const int f = tid + K3_NT * j;
-            t16[j] = (ok16 && f < IMU_OUT && !imu_field_is_zero(f)) ? src16[(size_t)f * TILE] : 0.0;
+        // residuals of the 9 factors: 135 words
+        double tr = 0.0;
+        if (tid < (AT + 1) * IMU_R) {
+            const int fac = tid / IMU_R, a = tid - fac * IMU_R;
+            const long gf = gk0 + fac;
+            const int kf = k0 + fac;
+            if (kf > lo && kf < hi) tr = v.imu_r[((size_t)b * tiles + (size_t)(gf >> 6)) * IMU_R * TILE + (size_t)a * TILE + (gf & 63)];
         }
-        // between linearisations of slots k0 .. k0+18
+        // between linearisations of slots k0 .. k0+10
         double tb[NB];
 #pragma unroll
         for (int j = 0; j < NB; j++) {
@@ -959,15 +1029,20 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
             if (ks > lo && ks < hi) { a = v.btw_a[gk0 + tid]; if (a < lo || a >= ks) a = -1; }
             s_a[tid] = a;
         }
+        if (tid <= AT) LJ[tid * LJS + LJ_ZERO] = 0.0;
+        if (tid < (AT + 1) * IMU_R) LJ[(tid / IMU_R) * LJS + LJ_R + tid % IMU_R] = tr;
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int f = it * NG + fg;
-            if (f < IMU_OUT) LJ[fac * LJS + f] = tj[it];
-        }
-#pragma unroll
-        for (int j = 0; j < N16; j++) {
-            const int f = tid + K3_NT * j;
-            if (f < IMU_OUT) LJ[AT * LJS + f] = t16[j];
+        for (int it = 0; it < NJ; it++) {
+            const int e = it * K3_NT + tid;
+            if (e < NALL) {
+                const int own = e < NOWN;
+                const int pr = own ? e >> 3 : e - NOWN;
+                const int fac = own ? e & 7 : AT;
+                const int kf = k0 + fac;
+                d2_t x = tj[it];
+                if (!(kf > lo && kf < hi)) { x.x = 0.0; x.y = 0.0; }        // factor outside the window: zeros
+                *(d2_t*)(LJ + fac * LJS + 2 * pr) = x;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NB; j++) {
@@ -979,6 +1054,10 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     __syncthreads();
     K3STAMP(3);   // everybody's
 
+#ifdef VF_K3_STAGE_ONLY      // probe build: what the staging alone costs (one word out so that it is not optimised away)
+    if (LJ[tid] + LB[tid] == 1.2345e300) v.gvec[gk0] = 1.0;
+    return;
+#endif
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave-uniform: the keyframe loop and its tests stay scalar
     assemble_tile<K3_KPW>(v, LJ, LB, s_a, w, b, h_buf(v, w), k0, gk0, lo, hi, rlo, rhi, wv, lane);
     K3STAMP(4);       // wave 0: MFMAs done, stores issued
@@ -1046,8 +1125,9 @@ __global__ void __launch_bounds__(64) k_linearize_assemble(View v, int which, in
         const int k = k0 + lane;
         if (k > lo && k < hi) {
             const long gk = gk0 + lane;
-            double* out_r = lane < FA ? v.imu_out + ((size_t)b * tiles + (size_t)(gk >> 6)) * IMU_OUT * TILE + (gk & 63) : nullptr;
-            linearize_imu_core(v, b, gk, LdsSink{LJ + lane * LJS, out_r});
+            double* out_r = lane < FA ? v.imu_r + ((size_t)b * tiles + (size_t)(gk >> 6)) * IMU_R * TILE + (gk & 63) : nullptr;
+            LdsSink sink{LJ + lane * LJS, out_r};
+            linearize_imu_core(v, b, gk, sink);
         }
     }
 #endif
@@ -2230,13 +2310,13 @@ __global__ void __launch_bounds__(1024) k_decide(View v, int init) {
     const int lo = v.lo[w], hi = v.hi[w];
     const int b = init ? v.sel[w] : (v.sel[w] ^ 1);
     const size_t tiles = (size_t)(v.G >> 6);
-    const double* imu_out = v.imu_out + (size_t)b * tiles * IMU_OUT * TILE;
+    const double* imu_r = v.imu_r + (size_t)b * tiles * IMU_R * TILE;
     const double* btw_out = v.btw_out + (size_t)b * tiles * BTW_OUT * TILE;
     double s = 0.0;
     const int nt = (int)blockDim.x;
     for (int k = lo + 1 + tid; k < hi; k += nt) {
         const long gk = (long)w * v.M + k;
-        const double* f = imu_out + (size_t)(gk >> 6) * IMU_OUT * TILE + (gk & 63);
+        const double* f = imu_r + (size_t)(gk >> 6) * IMU_R * TILE + (gk & 63);
         double c = 0.0;
 #pragma unroll
         for (int r = 0; r < 15; r++) { const double x = f[(size_t)r * TILE]; c = fma(x, x, c); }
@@ -2357,8 +2437,9 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
     const long g0 = (long)w * v.M + lo;
     __shared__ double A[42 * 43];
     __shared__ double bv[42];
-    const double* imu = v.imu_out + (size_t)b * tiles * IMU_OUT * TILE + (size_t)((g0 + 1) >> 6) * IMU_OUT * TILE + ((g0 + 1) & 63);
-    auto JI = [&](int r, int c30) { return imu[(size_t)(15 + r * 30 + c30) * TILE]; };
+    const double* imu = v.imu_r + (size_t)b * tiles * IMU_R * TILE + (size_t)((g0 + 1) >> 6) * IMU_R * TILE + ((g0 + 1) & 63);   // residual
+    const double* jbuf = v.imu_j + (size_t)b * (size_t)(v.G >> 3) * JT_STRIDE;
+    auto JI = [&](int r, int c30) { return jstream_entry(jbuf, g0 + 1, r, c30); };
     const bool has_prior = v.prior_k[w] == lo;
     const bool has_mp = v.mp_on[w] != 0;
     const double* Pq = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT;
@@ -2499,6 +2580,15 @@ __global__ void k_gather(const double* aosoa, double* aos, long g0, long n, int 
     const long g = g0 + rec;
     aos[i] = aosoa[((size_t)(g >> 6) * nf + f) * TILE + (g & 63)];
 }
+__global__ void k_gather_imu_lin(View v, int b, long g0, long n, double* aos) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * IMU_OUT) return;
+    const long rec = i / IMU_OUT;
+    const int f = (int)(i - rec * IMU_OUT);
+    const long g = g0 + rec;
+    if (f < IMU_R) aos[i] = v.imu_r[((size_t)b * (size_t)(v.G >> 6) + (size_t)(g >> 6)) * IMU_R * TILE + (size_t)f * TILE + (g & 63)];
+    else aos[i] = jstream_entry(v.imu_j + (size_t)b * (size_t)(v.G >> 3) * JT_STRIDE, g, (f - 15) / 30, (f - 15) % 30);
+}
 __global__ void k_scatter_states(const double* aos, double* x, long G, int buf, long g0, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * 16) return;
@@ -2622,6 +2712,9 @@ void launch_scatter(const double* aos, double* aosoa, long g0, long n, int nf, h
 }
 void launch_gather(const double* aosoa, double* aos, long g0, long n, int nf, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_gather, dim3(nblk(n * nf, 256)), dim3(256), 0, s, aosoa, aos, g0, n, nf);
+}
+void launch_gather_imu_lin(const View& v, int b, long g0, long n, double* aos, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_gather_imu_lin, dim3(nblk(n * IMU_OUT, 256)), dim3(256), 0, s, v, b, g0, n, aos);
 }
 void launch_scatter_states(const double* aos, double* x, long G, int buf, long g0, long n, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_scatter_states, dim3(nblk(n * 16, 256)), dim3(256), 0, s, aos, x, G, buf, g0, n);

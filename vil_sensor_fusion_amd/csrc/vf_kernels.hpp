@@ -7,7 +7,19 @@ namespace vf {
 
 constexpr int TILE = 64;        // AoSoA tile = one wavefront of factors
 constexpr int IMU_IN = 190;     // dt, delta(9), bhat(6), H(54), R packed upper (120)
-constexpr int IMU_OUT = 465;    // r(15), J(15x30 row-major)
+constexpr int IMU_OUT = 465;    // r(15), J(15x30 row-major): the documented (host-side / LDS) form of an IMU linearisation
+// In HBM the whitened residual and the Jacobian of an IMU factor live apart:
+//   imu_r  [2][G/64][15][64]   residuals, AoSoA like the inputs (the cost kernel reads nothing else)
+//   imu_j  [2][G/8][JT_STRIDE] "J stream": per tile of 8 consecutive keyframe slots, the 291 entries of J that are not
+//          structurally zero, in the order K1 produces them, i-side columns (147, padded to 74 pairs) then j-side columns
+//          (144 = 72 pairs), stored as [pair][8 slots][2 doubles].  A K1 store instruction is 16 bytes per lane = 8 full
+//          128-B lines (146 of them per factor instead of 291 8-byte ones); a K3 workgroup copies ONE contiguous 18.7 KB
+//          block into LDS as it is, plus the i-side pairs of its halo factor (slot 0 of the next tile).
+constexpr int IMU_R = 15;
+constexpr int JT = 8;                               // keyframe slots per J tile (= K3's tile)
+constexpr int JS_NI = 147, JS_NJ = 144;             // non-zero entries of the i-side / j-side columns
+constexpr int JS_PI = (JS_NI + 1) / 2, JS_PJ = (JS_NJ + 1) / 2, JS_PAIRS = JS_PI + JS_PJ;   // 74 + 72 pairs
+constexpr int JT_STRIDE = JS_PAIRS * JT * 2;        // 2336 doubles = 146 lines per tile
 constexpr int BTW_IN = 28;      // q(4), t(3), R packed upper (21)
 constexpr int BTW_OUT = 78;     // r(6), Ja(36), Jb(36)
 constexpr int PRIOR_IN = 31;    // mean state (16), sigma (15)
@@ -80,7 +92,8 @@ struct View {
     double grav[3];
     double* x;          // [2][16][G]          states, SoA, double-buffered (current / trial)
     double* imu_in;     // [G/64][190][64]     AoSoA
-    double* imu_out;    // [2][G/64][465][64]  AoSoA, double-buffered
+    double* imu_r;      // [2][G/64][15][64]   whitened residuals, AoSoA, double-buffered (current / LM trial)
+    double* imu_j;      // [2][G/8][2496]      J stream (see IMU_OUT above), double-buffered
     int* btw_a;         // [G]                 local index of key a (b = slot), -1 = empty
     double* btw_in;     // [G/64][28][64]
     double* btw_out;    // [2][G/64][78][64]
@@ -164,6 +177,8 @@ void launch_shift_btw_a(int* a, long G, int M, int shift, hipStream_t s);
 void launch_scatter(const double* aos, double* aosoa, long g0, long n, int nf, hipStream_t s);
 void launch_gather(const double* aosoa, double* aos, long g0, long n, int nf, hipStream_t s);
 void launch_scatter_states(const double* aos, double* x, long G, int buf, long g0, long n, hipStream_t s);
+// the documented (r | J) records of IMU factors [g0, g0 + n) of buffer b, AoS [n][465], from imu_r / imu_j
+void launch_gather_imu_lin(const View& v, int b, long g0, long n, double* aos, hipStream_t s);
 void launch_gather_states(const double* x, double* aos, long G, const int* sel, int M, int which, long g0, long n, hipStream_t s);
 
 }  // namespace vf

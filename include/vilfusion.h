@@ -259,9 +259,13 @@ typedef struct vf_graph vf_graph;
 typedef struct {
     int capacity;    /* keyframe slots on the device (keys 0..capacity-1) */
     int lag;         /* fixed-lag window length in keyframes; 0 = smooth the whole history */
-    int iterations;  /* LM trials per vf_solve */
+    int iterations;  /* LM trials per vf_solve, at most (see rel_tol / abs_tol) */
     int device;
     double prior_sigma[15]; /* X0/V0/B0 prior sigmas; default GraphManager.cpp:27-31 */
+    /* LM termination inside a vf_solve (vf_engine_set_convergence): the solve stops taking trials once one changes the
+     * cost by <= abs_tol or <= rel_tol * cost.  Defaults 1e-5 / 1e-5 = gtsam::LevenbergMarquardtParams (the optimiser at
+     * GraphManager.cpp:128-129); 0 / 0 = always `iterations` trials. */
+    double rel_tol, abs_tol;
 } vf_graph_opts;
 
 /* (time, pose q_wxyz, position, velocity, bias[acc,gyro]) -- GraphManager::OptimizationCallback
@@ -274,6 +278,10 @@ void vf_graph_default_opts(vf_graph_opts* o);
  * (GraphManager.cpp:15-44, IMUManager.cpp:13-17, ImuManagerRos.cpp:14-36) */
 int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** out);
 void vf_destroy(vf_graph* g);
+/* extra (no reference twin): the reference anchors X(0) = identity, V(0) = 0, B(0) = 0 with the priors of
+ * GraphManager.cpp:20-35, which suits a vehicle that starts level and at rest; to replay a log that starts in motion, put the
+ * anchor (state16: q t v bias) and the means of the three priors somewhere else.  Only before the first vf_reserve_node. */
+int vf_set_initial_state(vf_graph* g, const double state16[16]);
 /* IMUManager::addIMUMeasurement (IMUManager.cpp:19-25) */
 int vf_add_imu(vf_graph* g, double time, const double acc[3], const double gyro[3]);
 /* GraphManager::reserveNode (GraphManager.cpp:51-69): 1-based key, key 0 is the prior node */
@@ -302,6 +310,9 @@ int vf_set_callback(vf_graph* g, vf_callback cb, void* user);
 /* GraphManager::graph()->size(): factors staged since the last solve (3 priors at start +
  * between factors; IMU factors wait in the queue, GraphManager.cpp:66,150) and the queue length */
 int vf_graph_staged(vf_graph* g, int* staged_factors, int* queued_imu_factors);
+/* diagnostics (extra): cost after the last solve and the LM trials accepted / rejected / failed (normal equations not
+ * positive definite) over the life of the handle */
+int vf_graph_lm_stats(vf_graph* g, double* cost, int* accepted, int* rejected, int* solve_failures);
 /* smoothed states of keys [key0, key0+n) after the last solve (extra; iSAM2 calculateEstimate) */
 int vf_get_trajectory(vf_graph* g, uint64_t key0, int n, double* state16);
 /* preintegrated record of the factor ending at `key` (extra; firstFactor->preintegratedMeasurements()) */

@@ -73,7 +73,7 @@ def test_graph_manager_end_to_end_vs_oracle(oracle):
     from vil_sensor_fusion_amd.graph_manager import GraphManager
     n = 80
     seq = synth.make_sequence(5, n)
-    gm = GraphManager(capacity=128, iterations=6)
+    gm = GraphManager(capacity=128, iterations=6, rel_tol=0, abs_tol=0)     # exactly 6 trials, like the oracle below
     calls = []
     gm.addOptimizationCallback(lambda t, q, p, v, b: calls.append(t))
     # raw IMU stream re-created from the per-factor steps is not possible (steps are already cut),
@@ -318,3 +318,93 @@ def test_failed_solve_gives_its_factors_back():
     assert gm.graphSize() == 0
     (q, tt), v, b = gm.getState()
     assert np.all(np.isfinite(np.concatenate([q, tt, v, b])))
+
+
+def _stream(seq):
+    traj_t = synth.IMU_PHASE + np.arange(0, int((seq.kf_time[-1] + 0.5) * synth.IMU_RATE)) / synth.IMU_RATE
+    traj = synth.Trajectory(seq.seed, seq.kf_time[-1] + 1.0)
+    rng = np.random.default_rng([seq.seed, 0xBEEF])
+    acc = traj.specific_force(traj_t) + rng.normal(size=(traj_t.size, 3)) * synth.IMU_NOISE
+    gyr = traj.body_rate(traj_t) + rng.normal(size=(traj_t.size, 3)) * synth.IMU_NOISE
+    return traj_t, acc, gyr
+
+
+@pytest.mark.parametrize("lag", [0, 30])
+def test_graph_manager_warm_start_equals_cold_start(lag, monkeypatch):
+    """vf_solve's call sequence (K0 + prediction + between factors for the NEW keyframes, marginalisation of the ones
+    that leave, set_range) keeps the engine warm: the solve linearises only the appended tail.  Fed like the node --
+    one solve per camera keyframe, LiDAR odometry arriving one keyframe late (a between factor INSIDE the window the
+    previous solve covered) -- it must give, solve for solve, bit for bit, what the cold path gives (VF_NO_WARM=1)."""
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    n = 90
+    seq = synth.make_sequence(61, n)
+    traj_t, acc, gyr = _stream(seq)
+
+    def run(cold):
+        if cold:
+            monkeypatch.setenv("VF_NO_WARM", "1")
+        else:
+            monkeypatch.delenv("VF_NO_WARM", raising=False)
+        gm = GraphManager(capacity=128, iterations=4, lag=lag)
+        monkeypatch.delenv("VF_NO_WARM", raising=False)
+        out, late, i_imu = [], [], 0
+        for k in range(1, n):
+            while i_imu < traj_t.size and traj_t[i_imu] <= seq.kf_time[k] + 0.01:
+                gm.addIMUMeasurement(traj_t[i_imu], acc[i_imu], gyr[i_imu]); i_imu += 1
+            gm.reserveNode(seq.kf_time[k])
+            for f in late:                                   # last keyframe's LiDAR odometry arrives only now
+                gm.addBetweenFactor(*f)
+            late = []
+            for a, b, q, t, c in zip(seq.btw_a, seq.btw_b, seq.btw_q, seq.btw_t, seq.btw_cov):
+                if b == k and a >= 1:
+                    f = (int(a), int(b), (q, t), np.eye(6) * c)
+                    if c == synth.LIDAR_COV:
+                        late.append(f)
+                    else:
+                        gm.addBetweenFactor(*f)
+            if k >= 4:
+                gm.solve()
+                (q, t), v, b = gm.getState()
+                out.append(np.concatenate([q, t, v, b]))
+        gm.close()
+        return np.array(out)
+    warm, cold = run(False), run(True)
+    assert warm.shape == cold.shape and np.isfinite(warm).all()
+    np.testing.assert_array_equal(warm, cold)
+
+
+def test_graph_manager_default_termination_matches_oracle(oracle):
+    """Default vf_graph_opts: a solve stops taking LM trials by GTSAM's rule (1e-5 / 1e-5).  Same number of trials and the
+    same trajectory as the oracle's LM under that rule, on a graph built through the API."""
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    n = 60
+    seq = synth.make_sequence(9, n)
+    a = GraphManager(capacity=64, iterations=12)
+    a.setInitialState(seq.gt_states[0])          # the synthetic vehicle is already moving at t = 0
+    with pytest.raises(Exception):
+        a.setInitialState(np.zeros(16))          # not a rotation
+    a.addIMUMeasurement(0.0, seq.imu_steps[0, 1:4], seq.imu_steps[0, 4:7])
+    _feed(a, seq, n)
+    with pytest.raises(Exception):
+        a.setInitialState(seq.gt_states[0])      # only before the first node
+    a.solve()
+    xs = a.trajectory(0, n)
+    recs = np.zeros((n, 190))
+    for k in range(1, n):
+        recs[k] = a.imuFactor(k)
+    g = np.array([0, 0, -9.81])
+    states = np.zeros((n, 16)); states[0] = seq.gt_states[0]
+    for k in range(1, n):
+        states[k] = oracle.predict(recs[k], g, states[k - 1])
+    m = seq.btw_a >= 1
+    from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
+    prob = dict(n=n, states=states, imu=recs, btw_a=seq.btw_a[m], btw_b=seq.btw_b[m], btw=synth.between_records(seq)[m],
+                prior=synth.prior_record(states[0], REFERENCE_PRIOR_SIGMAS), gravity=g)
+    win = helpers.oracle_window(oracle, prob)
+    costs, acc_flags, _ = win.lm(iterations=12, rel_tol=1e-5, abs_tol=1e-5)
+    trials = int(np.sum(np.array(acc_flags) >= 0))
+    lm = a.lmStats()
+    assert 1 <= trials < 12 and lm["accepted"] + lm["rejected"] == trials and lm["solve_failures"] == 0
+    ate, rot = helpers.ate(xs, win.states)
+    print(f"default termination: oracle took {trials} of 12 trials; ATE {ate:.3e} m, rot {rot:.3e} rad")
+    assert ate <= 1e-6 and rot <= 1e-6

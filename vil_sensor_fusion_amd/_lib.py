@@ -39,7 +39,7 @@ class ShardInfoC(C.Structure):
 
 class GraphOptsC(C.Structure):
     _fields_ = [("capacity", C.c_int), ("lag", C.c_int), ("iterations", C.c_int), ("device", C.c_int),
-                ("prior_sigma", C.c_double * 15)]
+                ("prior_sigma", C.c_double * 15), ("rel_tol", C.c_double), ("abs_tol", C.c_double)]
 
 
 CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -67,7 +67,7 @@ SYMBOLS = [
     "vf_graph_default_opts", "vf_create", "vf_destroy", "vf_add_imu", "vf_reserve_node",
     "vf_add_between", "vf_solve", "vf_get_state", "vf_get_bias", "vf_most_recent_pose_time",
     "vf_set_callback", "vf_graph_staged", "vf_get_trajectory", "vf_get_imu_factor",
-    "vf_add_imu_factor", "vf_get_most_recent_estimate",
+    "vf_add_imu_factor", "vf_get_most_recent_estimate", "vf_graph_lm_stats", "vf_set_initial_state",
     "vf_degeneracy_batch", "vf_dopt_filter_f32",
 ]
 

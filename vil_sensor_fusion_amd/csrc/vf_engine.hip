@@ -76,7 +76,9 @@ struct vf_engine {
     // Warm start of vf_engine_iterate: true from the end of a solve until any entry point other than vf_engine_slide
     // touches the engine; `slid` counts the slides since.  See k_linearize_tail.
     bool warm = false;
-    int slid = 0;
+    int slid = 0;             // keyframes appended since the last solve
+    int redo = 0;             // slots in front of the old window end whose factors changed since (see touch())
+    bool no_warm = false;     // VF_NO_WARM=1 at creation: every solve starts cold (tests compare the two)
 
     template <typename T>
     int alloc(T** p, size_t n, bool zero = true) {
@@ -248,6 +250,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     // with plain asynchronous launches -- the queue is never empty, so there is no launch gap to remove.
     // Hence opt-in only.
     e->graph_off = getenv("VF_USE_GRAPH") == nullptr;
+    e->no_warm = getenv("VF_NO_WARM") != nullptr;
     HIPCHK(hipStreamSynchronize(e->stream));
     e->h_lo.assign(v.B, 0);
     e->h_hi.assign(v.B, 0);
@@ -269,6 +272,22 @@ void vf_engine_destroy(vf_engine* e) {
     delete e;
 }
 
+// Warm start across the GraphManager's call sequence (vf_solve: preintegrate / predict / set_between for the NEW keyframes,
+// marginalize + drop_oldest for the ones that leave, set_range): a call that only touches keyframe slots at or beyond the
+// window's current end leaves every existing record, H row and g entry those of the current states, exactly as
+// vf_engine_slide does -- the next vf_engine_iterate then linearises only what was appended (k_linearize_tail).  Engines
+// with one window only (`slid` is one count for the whole engine); anything else makes the next solve a cold start.
+// A factor record written a few slots INSIDE the window's end (late odometry for a keyframe an earlier solve already
+// covered) lengthens the tail that is linearised again (`redo`), up to the 8 keyframes k_linearize_tail handles.
+static void touch(vf_engine* e, int window, int first_slot) {
+    if (!e) return;
+    if (e->warm && e->v.B == 1 && window == 0 && first_slot > e->h_lo[0]) {
+        const int inside = e->h_hi[0] - first_slot;          // <= 0: beyond the current end
+        if (inside > e->redo) e->redo = inside;
+        if (e->redo <= 8) return;
+    }
+    e->warm = false;
+}
 static int check_window(vf_engine* e, int window) {
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (window < 0 || window >= e->v.B) return fail(VF_ERR_INVALID, "window %d out of range", window);
@@ -283,10 +302,13 @@ static int check_range(vf_engine* e, int window, int k0, int n) {
 
 int vf_engine_set_range(vf_engine* e, int window, int lo, int hi) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
     int rc = check_window(e, window);
-    if (rc) return rc;
-    if (lo < 0 || hi < lo || hi > e->v.M) return fail(VF_ERR_BAD_KEY, "bad range [%d,%d)", lo, hi);
+    if (rc) { e->warm = false; return rc; }
+    if (lo < 0 || hi < lo || hi > e->v.M) { e->warm = false; return fail(VF_ERR_BAD_KEY, "bad range [%d,%d)", lo, hi); }
+    // growing the end of the one window of a warm engine = appending keyframes (see touch()); its start is moved by
+    // vf_engine_drop_oldest only
+    if (e->warm && e->v.B == 1 && lo == e->h_lo[0] && hi >= e->h_hi[0] && e->h_hi[0] > e->h_lo[0]) e->slid += hi - e->h_hi[0];
+    else e->warm = false;
     HIPCHK(hipMemcpyAsync(e->v.lo + window, &lo, sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->v.hi + window, &hi, sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -332,7 +354,7 @@ int vf_engine_get_states(vf_engine* e, int window, int k0, int n, double* s) {
 
 int vf_engine_set_imu(vf_engine* e, int window, int k0, int n, const double* rec) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    touch(e, window, k0);
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (!rec) return fail(VF_ERR_INVALID, "null records");
@@ -348,7 +370,11 @@ int vf_engine_set_imu(vf_engine* e, int window, int k0, int n, const double* rec
 
 int vf_engine_set_between(vf_engine* e, int window, int n, const int32_t* a, const int32_t* b, const double* rec) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    {
+        int first = 1 << 30;
+        for (int i = 0; i < n && b; i++) first = b[i] < first ? b[i] : first;
+        touch(e, window, n > 0 ? first : 0);
+    }
     int rc = check_window(e, window);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!a || !b || !rec))) return fail(VF_ERR_INVALID, "null argument");
@@ -405,7 +431,7 @@ int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec) {
 int vf_engine_preintegrate(vf_engine* e, int window, int k0, int n, const int32_t* off, const double* steps,
                            const double* bhat, const vf_imu_params* p) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    touch(e, window, k0);
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (!off || !bhat || !p) return fail(VF_ERR_INVALID, "null argument");
@@ -514,7 +540,8 @@ static int iterate_sequence(vf_engine* e, int iterations) {
     // every solve starts from lambda0, as a fresh LevenbergMarquardtOptimizer would
     HIPCHK(hipMemcpyAsync(e->v.lambda, e->lambda0_dev, e->v.B * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     int rc;
-    const int slid = (e->warm && e->v.sh_G <= 1 && e->slid >= 1 && e->slid <= 8) ? e->slid : 0;
+    const int tail = e->slid + e->redo;
+    const int slid = (e->warm && e->v.sh_G <= 1 && tail >= 1 && tail <= 8) ? tail : 0;
     if (e->v.fused) {
         // K1 + K3 fused (vf_kernels.hip "k_linearize_assemble"): the trial's normal equations are written beside the current
         // ones by the kernel that linearises the trial, so a trial is K4, K5a, K2 (+ priors), K1+K3, K5b -- no Jacobian
@@ -561,8 +588,9 @@ static int iterate_sequence(vf_engine* e, int iterations) {
 // the solve leaves every record, H row and g entry consistent with the current states: the next one may start warm.
 // (set by vf_engine_iterate, not by iterate_sequence: a hipGraph replay never runs the sequence's host code)
 static void mark_solved(vf_engine* e) {
-    e->warm = true;
+    e->warm = !e->no_warm;
     e->slid = 0;
+    e->redo = 0;
 }
 int vf_engine_iterate(vf_engine* e, int iterations) {
     DeviceGuard dev_guard_(e);
@@ -575,7 +603,7 @@ int vf_engine_iterate(vf_engine* e, int iterations) {
         if (!rc) mark_solved(e);
         return rc;
     }
-    const int mode = (e->warm && e->v.sh_G <= 1 && e->slid >= 1 && e->slid <= 8) ? e->slid : 0;
+    const int mode = (e->warm && e->v.sh_G <= 1 && e->slid + e->redo >= 1 && e->slid + e->redo <= 8) ? e->slid + e->redo : 0;
     if (!e->graph_exec || e->graph_iters != iterations || e->graph_epoch != e->epoch || e->graph_mode != mode) {
         e->drop_graph();
         if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
@@ -719,7 +747,7 @@ int vf_engine_reset_lambda(vf_engine* e) {
 
 int vf_engine_predict(vf_engine* e, int window, int k0, int n) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    touch(e, window, k0);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (window >= e->v.B || k0 < 1 || n < 0 || k0 + n > e->v.M) return fail(VF_ERR_BAD_KEY, "bad predict range");
     if (n == 0) return VF_OK;
@@ -730,7 +758,7 @@ int vf_engine_predict(vf_engine* e, int window, int k0, int n) {
 
 int vf_engine_marginalize(vf_engine* e) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    // (reads the current linearisation, writes the marginal prior: what a warm start expects to have changed)
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (int rc = not_sharded(e, "vf_engine_marginalize")) return rc;
     for (int w = 0; w < e->v.B; w++)
@@ -748,7 +776,6 @@ int vf_engine_marginalize(vf_engine* e) {
 
 int vf_engine_drop_oldest(vf_engine* e) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     for (int w = 0; w < e->v.B; w++) {
         if (e->h_hi[w] - e->h_lo[w] < 2) return fail(VF_ERR_INVALID, "window %d too short", w);
@@ -765,13 +792,11 @@ int vf_engine_slide(vf_engine* e, const double* prior_sigma15, int marginalize) 
     if (!e || !prior_sigma15) return fail(VF_ERR_INVALID, "null argument");
     for (int w = 0; w < e->v.B; w++)
         if (e->h_hi[w] >= e->v.M) return fail(VF_ERR_CAPACITY, "window %d has no free keyframe slot", w);
-    const bool was_warm = e->warm;
     if (marginalize) {
         int rc = vf_engine_marginalize(e);
         if (rc) return rc;
     }
-    e->warm = was_warm;       // a slide is the one change a warm start knows how to follow
-    if (e->warm) e->slid++;
+    if (e->warm) e->slid++;   // a slide is a change a warm start knows how to follow
     HIPCHK(hipMemcpyAsync(e->sigma_dev, prior_sigma15, 15 * sizeof(double), hipMemcpyHostToDevice, e->stream));
     vf::launch_slide(e->v, e->sigma_dev, marginalize ? 0 : 1, e->stream);
     HIPCHK(hipGetLastError());

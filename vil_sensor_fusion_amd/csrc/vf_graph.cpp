@@ -114,6 +114,8 @@ void vf_graph_default_opts(vf_graph_opts* o) {
     // GraphManager.cpp:27-31: rad,rad,rad,m,m,m ; m/s ; bias
     const double s[15] = {1e-6, 1e-6, 1e-6, 5e-5, 5e-5, 5e-5, 1e-5, 1e-5, 1e-5, 1e-7, 1e-7, 1e-7, 1e-7, 1e-7, 1e-7};
     memcpy(o->prior_sigma, s, sizeof(s));
+    o->rel_tol = 1e-5;   // gtsam::LevenbergMarquardtParams relativeErrorTol / absoluteErrorTol
+    o->abs_tol = 1e-5;
 }
 
 int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** out) {
@@ -122,6 +124,7 @@ int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** ou
     if (opts) o = *opts; else vf_graph_default_opts(&o);
     if (o.capacity < 8 || o.iterations < 0 || o.lag < 0) return gerr(VF_ERR_INVALID, "bad graph options");
     if (o.lag != 0 && o.lag < 4) return gerr(VF_ERR_INVALID, "lag must be 0 or >= 4 keyframes");
+    if (!(o.rel_tol >= 0.0) || !(o.abs_tol >= 0.0)) return gerr(VF_ERR_INVALID, "tolerances must be >= 0");
     const double covs[6] = {imu->acc_cov, imu->gyro_cov, imu->integration_cov, imu->bias_acc_cov, imu->bias_omega_cov, imu->bias_acc_omega_int};
     for (double c : covs)
         if (!(c > 0.0) || !std::isfinite(c)) return gerr(VF_ERR_NOT_SPD, "IMU covariances must be finite and > 0");
@@ -143,7 +146,7 @@ int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** ou
     rec[0] = 1.0;
     memcpy(rec + 16, o.prior_sigma, sizeof(double) * 15);
     if ((rc = vf_engine_set_states(eng, 0, 0, 1, g->state)) || (rc = vf_engine_set_prior(eng, 0, 0, rec)) ||
-        (rc = vf_engine_set_range(eng, 0, 0, 1))) {
+        (rc = vf_engine_set_range(eng, 0, 0, 1)) || (rc = vf_engine_set_convergence(eng, o.rel_tol, o.abs_tol))) {
         vf_engine_destroy(eng);
         delete g;
         return rc;
@@ -156,6 +159,28 @@ void vf_destroy(vf_graph* g) {
     if (!g) return;
     vf_engine_destroy(g->eng);
     delete g;
+}
+
+int vf_set_initial_state(vf_graph* g, const double state16[16]) {
+    if (!g || !state16) return gerr(VF_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->graph_mutex);
+    std::lock_guard<std::mutex> sl(g->state_mutex);
+    if (g->current_key != 0 || g->solved_key != 0) return gerr(VF_ERR_INVALID, "the initial state can only be set before the first node is reserved");
+    double n = 0.0;
+    for (int i = 0; i < 4; i++) n += state16[i] * state16[i];
+    for (int i = 0; i < 16; i++)
+        if (!std::isfinite(state16[i])) return gerr(VF_ERR_INVALID, "initial state entry %d is not finite", i);
+    if (!(n > 0.0)) return gerr(VF_ERR_INVALID, "initial rotation is not a quaternion");
+    double st[16];
+    memcpy(st, state16, sizeof(st));
+    for (int i = 0; i < 4; i++) st[i] /= std::sqrt(n);
+    double rec[VF_PRIOR_RECORD];
+    memcpy(rec, st, sizeof(double) * 16);
+    memcpy(rec + 16, g->opts.prior_sigma, sizeof(double) * 15);
+    int rc;
+    if ((rc = vf_engine_set_states(g->eng, 0, 0, 1, st)) || (rc = vf_engine_set_prior(g->eng, 0, 0, rec))) return rc;
+    memcpy(g->state, st, sizeof(st));
+    return VF_OK;
 }
 
 int vf_add_imu(vf_graph* g, double time, const double acc[3], const double gyro[3]) {
@@ -448,6 +473,12 @@ int vf_get_state(vf_graph* g, double q[4], double t[3], double v[3], double bias
 }
 
 int vf_get_bias(vf_graph* g, double bias[6]) { return vf_get_state(g, nullptr, nullptr, nullptr, bias); }
+
+int vf_graph_lm_stats(vf_graph* g, double* cost, int* accepted, int* rejected, int* solve_failures) {
+    if (!g) return gerr(VF_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->state_mutex);
+    return vf_engine_read_lm(g->eng, 0, cost, nullptr, accepted, rejected, solve_failures);
+}
 
 int vf_get_trajectory(vf_graph* g, uint64_t key0, int n, double* state16) {
     if (!g || !state16) return gerr(VF_ERR_INVALID, "null argument");

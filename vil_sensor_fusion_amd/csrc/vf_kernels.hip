@@ -824,6 +824,11 @@ __device__ __forceinline__ void assemble_tile(const View& v, const double* __res
 #ifdef VF_SOLVE_STAMPS
     unsigned long long k3acc[8] = {0}, k3prev = __builtin_amdgcn_s_memtime();
 #endif
+    // Window-level scalars are read ONCE, in front of the loop: a global load inside it would have to wait for its result with
+    // s_waitcnt vmcnt(0), and stores count in vmcnt on this ISA -- every keyframe would wait for the H rows of the one before
+    // it to be acknowledged by memory before it could go on.
+    const int prior_key = v.prior_k[w];
+    const bool marg_on = v.mp_on[w] != 0 && hi - lo >= 3;
     d4_t D = {0, 0, 0, 0};
     const int lf0 = KPW * wv;
 #pragma unroll 1
@@ -854,9 +859,9 @@ __device__ __forceinline__ void assemble_tile(const View& v, const double* __res
                         D = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D, 0, 0, 0);
                         D = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, D, 0, 0, 0);
                     }
-                const bool is_prior = v.prior_k[w] == k;
+                const bool is_prior = prior_key == k;
                 const double* Pq = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT;
-                const int mo = (v.mp_on[w] && hi - lo >= 3) ? k - lo : 99;   // 0,1,2: rows of the marginal prior
+                const int mo = marg_on ? k - lo : 99;   // 0,1,2: rows of the marginal prior
                 const double* ML = v.mp_L + (size_t)w * 729;
                 const double* Mg = v.mp_out + ((size_t)b * v.B + w) * 28;
 #pragma unroll
@@ -896,7 +901,7 @@ __device__ __forceinline__ void assemble_tile(const View& v, const double* __res
                 double* Hk = v.H + ((size_t)hb * (size_t)v.G + (size_t)(gk0 + kl)) * HROW;
                 const int ak = __builtin_amdgcn_readfirstlane(s_a[kl]);
                 const int dk = ak >= 0 ? k - ak : 0;   // 1..3 when a between factor ends here
-                const int mo2 = (v.mp_on[w] && hi - lo >= 3) ? k - lo : 99;
+                const int mo2 = marg_on ? k - lo : 99;
                 const double* ML2 = v.mp_L + (size_t)w * 729;
                 d4_t T = {0, 0, 0, 0};                    // Jb^T Ja of the between factor ending here
                 if (dk >= 1) {

@@ -28,7 +28,9 @@ class GraphManager:
     """GraphManager(imuManager): the IMU manager is folded in (addIMUMeasurement)."""
 
     def __init__(self, imu_params=CARLA_IMU, capacity=4096, lag=0, iterations=5, device=0,
-                 prior_sigma=None):
+                 prior_sigma=None, rel_tol=None, abs_tol=None):
+        """iterations: LM trials per solve at most; a solve stops earlier once a trial changes the cost by <= abs_tol or
+        <= rel_tol * cost (defaults 1e-5 / 1e-5, gtsam::LevenbergMarquardtParams; 0 / 0: always `iterations` trials)."""
         self._l = _lib.lib()
         p = _lib.ImuParamsC(imu_params["acc"], imu_params["gyro"], imu_params["integration"],
                             imu_params["bias_acc"], imu_params["bias_omega"],
@@ -38,6 +40,10 @@ class GraphManager:
         o.capacity, o.lag, o.iterations, o.device = capacity, lag, iterations, device
         if prior_sigma is not None:
             o.prior_sigma[:] = list(prior_sigma)
+        if rel_tol is not None:
+            o.rel_tol = rel_tol
+        if abs_tol is not None:
+            o.abs_tol = abs_tol
         self._h = C.c_void_p()
         check(self._l.vf_create(C.byref(p), C.byref(o), C.byref(self._h)))
         self._cbs = []
@@ -52,6 +58,12 @@ class GraphManager:
             self.close()
         except Exception:
             pass
+
+    def setInitialState(self, state16):
+        """extra: anchor X(0), V(0), B(0) (and the means of their priors) at state16 = q t v bias instead of
+        identity / zero; only before the first reserveNode (for logs that do not start level and at rest)."""
+        s = np.ascontiguousarray(state16, dtype=np.float64).reshape(16)
+        check(self._l.vf_set_initial_state(self._h, _d(s)))
 
     # IMUManager::addIMUMeasurement
     def addIMUMeasurement(self, time, accel, gyro):
@@ -119,6 +131,13 @@ class GraphManager:
         s, q = C.c_int(), C.c_int()
         check(self._l.vf_graph_staged(self._h, C.byref(s), C.byref(q)))
         return q.value
+
+    def lmStats(self):
+        """cost after the last solve; LM trials accepted / rejected / failed since creation (diagnostics)."""
+        c = C.c_double()
+        a, r, f = C.c_int(), C.c_int(), C.c_int()
+        check(self._l.vf_graph_lm_stats(self._h, C.byref(c), C.byref(a), C.byref(r), C.byref(f)))
+        return dict(cost=c.value, accepted=a.value, rejected=r.value, solve_failures=f.value)
 
     def trajectory(self, key0, n):
         s = np.zeros((n, 16))

@@ -1,0 +1,212 @@
+"""CPU: the ROS-free diagnostics (every field of gtsam_fusion/msg/DiagnosticMessage.msg on hand-computable cases:
+identity, pure translation, 180-degree rotation, a turning and drifting estimate) and the wiring of the rospy node adapters
+(gtsam_fusion_node.cpp:17-104, degerate_odometry_filter.cpp:13-51), driven with stub ROS objects -- there is no ROS in
+this image, so the adapters take their ROS modules as arguments."""
+import math
+import types
+
+import numpy as np
+
+from vil_sensor_fusion_amd.diagnostics import DiagnosticMessage, DiagnosticTrack, relative_transform
+
+I4 = np.array([1.0, 0, 0, 0])
+
+
+def qz(a):
+    return np.array([math.cos(a / 2), 0, 0, math.sin(a / 2)])
+
+
+def test_identity_and_first_stamp():
+    tr = DiagnosticTrack("vio")
+    assert tr.update(0.0, I4, [0, 0, 0], I4, [0, 0, 0]) is None          # first stamp only initialises (diagnostics.py:67)
+    m = tr.update(0.1, I4, [0, 0, 0], I4, [0, 0, 0])
+    assert isinstance(m, DiagnosticMessage) and m.name == "vio" and m.stamp == 0.1
+    assert m.gt_distance == 0 and m.abs_dist_err == 0 and m.abs_rot_err == 0
+    assert m.relative_dist_err == math.inf and m.rel_linear_vel_err == math.inf and m.rel_rot_vel_err == math.inf   # :124,128-129
+    assert m.abs_linear_vel_err == 0 and m.abs_rot_vel_err == 0
+
+
+def test_pure_translation():
+    tr = DiagnosticTrack("x")
+    tr.update(0.0, I4, [0, 0, 0], I4, [0, 0, 0])
+    m = tr.update(1.0, I4, [3, 4, 0], I4, [3, 4, 0.5])                   # gt moved 5 m, estimate is 0.5 m high
+    assert abs(m.gt_distance - 5.0) < 1e-15 and abs(m.abs_dist_err - 0.5) < 1e-15
+    assert abs(m.relative_dist_err - 0.1) < 1e-15
+    assert abs(m.abs_linear_vel_err - 0.5) < 1e-15 and abs(m.rel_linear_vel_err - 0.1) < 1e-15
+    assert m.abs_rot_err == 0 and m.abs_rot_vel_err == 0 and m.rel_rot_vel_err == math.inf
+    np.testing.assert_allclose(m.err_position, [0, 0, 0.5], atol=1e-15)
+    m = tr.update(2.0, I4, [3, 4, 0], I4, [3, 4, 0.5])                   # standing still: distance accumulates, step ratios are inf
+    assert abs(m.gt_distance - 5.0) < 1e-15 and m.rel_linear_vel_err == math.inf and m.abs_linear_vel_err < 1e-15
+
+
+def test_half_turn_and_frames():
+    tr = DiagnosticTrack("r")
+    tr.update(0.0, I4, [0, 0, 0], I4, [0, 0, 0])
+    m = tr.update(1.0, qz(math.pi / 2), [1, 0, 0], qz(-math.pi / 2), [1, 0, 0])     # estimate turned the other way: 180 deg apart
+    assert abs(m.abs_rot_err - math.pi) < 1e-12
+    assert abs(m.abs_rot_vel_err - math.pi) < 1e-12 and abs(m.rel_rot_vel_err - 2.0) < 1e-12   # pi over the gt's pi/2
+    # the translation error is expressed in the ground-truth frame (lookupTransform(target=gt, source=est), :108-112)
+    m = tr.update(2.0, qz(math.pi / 2), [1, 0, 0], qz(math.pi / 2), [1, 1, 0])
+    np.testing.assert_allclose(m.err_position, [1, 0, 0], atol=1e-12)    # +y in the world = +x of a frame yawed by 90 deg
+    assert abs(m.abs_rot_err) < 1e-7
+    # lookupTransformFull semantics: the later pose in the earlier frame
+    q, t = relative_transform(qz(math.pi / 2), [1, 0, 0], qz(math.pi), [1, 2, 0])
+    np.testing.assert_allclose(t, [2, 0, 0], atol=1e-12)
+    np.testing.assert_allclose(q, qz(math.pi / 2), atol=1e-12)
+
+
+# ---------------------------------------------------------------- node adapters with stub ROS objects
+class _Stamp:
+    def __init__(self, t):
+        self.t = t
+
+    def to_sec(self):
+        return self.t
+
+
+def _ns(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+class _Msg:
+    """attribute bag that grows nested attributes on demand (stands in for any ROS message class)"""
+
+    def __getattr__(self, k):
+        v = _Msg()
+        object.__setattr__(self, k, v)
+        return v
+
+
+class _Rospy:
+    def __init__(self, params):
+        self.params, self.subs, self.pubs, self.warned = params, {}, {}, []
+        self.Time = _ns(from_sec=lambda t: _Stamp(t))
+
+    def get_param(self, name, default=None):
+        node = self.params
+        for part in name.lstrip("~").split("/"):
+            if not isinstance(node, dict) or part not in node:
+                if default is None:
+                    raise KeyError(name)
+                return default
+            node = node[part]
+        return node
+
+    def Subscriber(self, topic, cls, queue_size, callback):
+        self.subs[topic] = (cls, queue_size, callback)
+        return topic
+
+    def Publisher(self, topic, cls, queue_size):
+        sent = []
+        self.pubs[topic] = sent
+        return _ns(publish=sent.append)
+
+    def logwarn(self, m):
+        self.warned.append(m)
+
+    loginfo = logwarn
+
+
+CARLA = {   # gtsam_fusion/config/carla/fusion_params.yaml
+    "sensors": {"lidar": dict(sensor_topic="/lidar", sensor_type="PointCloud2", odom_topic="/gtsam_fusion_filter/laser_odom_output",
+                              optimize_after_odom=False, use_odom_covariance=False, covariance_linear=0.2, covariance_angular=0.2,
+                              max_time_skip=0.1),
+                "vio": dict(sensor_topic="/cam0/image_mono", sensor_type="Image", odom_topic="/rovio/odometry", optimize_after_odom=True,
+                            use_odom_covariance=False, covariance_linear=0.1, covariance_angular=0.1, max_time_skip=0.1),
+                "bogus": dict(sensor_type="Sonar")},
+    "imu": dict(topic="/imu/fusion", cov_bias_acc=1e-4, cov_bias_omega=1e-6, cov_accel=1e-6, cov_gyro=1e-6, cov_integration=1e-8,
+                cov_bias_acc_omega_int=1e-4),
+    "tf": dict(static_frame="/rovio_world", odom_frame="/gtsam_odom"),
+    "filter": dict(rot_degen_threshold=11.5, trans_degen_threshold=28.9)}
+
+
+def _odom_msg(t, p, q):
+    return _ns(header=_ns(stamp=_Stamp(t)), pose=_ns(pose=_ns(position=_ns(x=p[0], y=p[1], z=p[2]),
+                                                                orientation=_ns(w=q[0], x=q[1], y=q[2], z=q[3]))),
+               twist=_ns(covariance=[0.0] * 36))
+
+
+def test_fusion_node_wiring():
+    from tests.test_sensor_manager import FakeGraphManager
+    from vil_sensor_fusion_amd.ros.gtsam_fusion_node import FusionNode
+
+    class GM(FakeGraphManager):
+        def __init__(self):
+            super().__init__()
+            self.imu, self.cb = [], None
+
+        def addIMUMeasurement(self, t, a, w):
+            self.imu.append((t, list(a), list(w)))
+
+        def addOptimizationCallback(self, cb):
+            self.cb = cb
+
+    rospy, sent_tf = _Rospy(CARLA), []
+    gm = GM()
+    node = FusionNode(rospy, _ns(TransformBroadcaster=lambda: _ns(sendTransform=sent_tf.append)),
+                      _ns(Imu="Imu", Image="Image", PointCloud2="PointCloud2", Odometry=_Msg, TransformStamped=_Msg), graph_manager=gm)
+    # subscriptions and queue sizes of the reference (ImuManagerRos.cpp:11, SensorManagerRos.h:59-60); the bad entry is skipped (:52-55)
+    assert rospy.subs["/imu/fusion"][:2] == ("Imu", 100)
+    assert rospy.subs["/lidar"][:2] == ("PointCloud2", 1) and rospy.subs["/cam0/image_mono"][:2] == ("Image", 1)
+    assert rospy.subs["/rovio/odometry"][1] == 1 and rospy.subs["/gtsam_fusion_filter/laser_odom_output"][1] == 1
+    assert sorted(node.sensor_managers) == ["lidar", "vio"] and len(rospy.warned) == 1 and "~odometry" in rospy.pubs
+    assert node.sensor_managers["vio"].optimize_after_odom and not node.sensor_managers["lidar"].optimize_after_odom
+    # IMU message -> addIMUMeasurement (ImuManagerRos.cpp:38-52)
+    rospy.subs["/imu/fusion"][2](_ns(header=_ns(stamp=_Stamp(0.5)), linear_acceleration=_ns(x=1, y=2, z=3), angular_velocity=_ns(x=4, y=5, z=6)))
+    assert gm.imu == [(0.5, [1, 2, 3], [4, 5, 6])]
+    # camera frames + Rovio odometry: first odometry only arms the source, then one between factor and one solve per odometry
+    img, odo = rospy.subs["/cam0/image_mono"][2], rospy.subs["/rovio/odometry"][2]
+    img(_ns(header=_ns(stamp=_Stamp(0.00))))
+    odo(_odom_msg(0.00, [0, 0, 0], I4))
+    for t, x in ((0.05, 0.0), (0.10, 0.5)):
+        img(_ns(header=_ns(stamp=_Stamp(t))))
+        odo(_odom_msg(t, [x, 0, 0], I4))
+    assert gm.key == 2 and gm.solves == 1 and [(a, b) for a, b, _, _ in gm.between] == [(1, 2)]
+    np.testing.assert_allclose(gm.between[0][2][1], [0.5, 0, 0])
+    np.testing.assert_allclose(np.diag(gm.between[0][3]), [0.1] * 6)
+    # the optimisation callback publishes Odometry + TF (gtsam_fusion_node.cpp:64-98)
+    gm.cb(0.1, np.array([0.5, 0.5, 0.5, 0.5]), np.array([1.0, 2.0, 3.0]), np.array([4.0, 5.0, 6.0]), np.zeros(6))
+    o = rospy.pubs["~odometry"][0]
+    assert (o.header.frame_id, o.child_frame_id, o.header.stamp.to_sec()) == ("/rovio_world", "/gtsam_odom", 0.1)
+    assert (o.pose.pose.position.x, o.pose.pose.position.z, o.pose.pose.orientation.w, o.twist.twist.linear.y) == (1.0, 3.0, 0.5, 5.0)
+    t = sent_tf[0]
+    assert (t.header.frame_id, t.child_frame_id, t.transform.translation.y, t.transform.rotation.z) == ("/rovio_world", "/gtsam_odom", 2.0, 0.5)
+
+
+def test_filter_node_wiring():
+    from vil_sensor_fusion_amd.ros.odometry_filter_node import FilterNode
+    rospy = _Rospy(CARLA)
+    calls = []
+
+    class MF:
+        class Subscriber:
+            def __init__(self, topic, cls, queue_size):
+                calls.append((topic, queue_size))
+
+        class TimeSynchronizer:
+            def __init__(self, subs, queue):
+                calls.append(("sync", len(subs), queue))
+
+            def registerCallback(self, cb):
+                self.cb = cb
+
+    seen = []
+    gate = lambda h: (seen.append(len(h)) or h[0] > 0)          # stands in for DegeneracyGate (GPU): keep iff first entry > 0
+    node = FilterNode(rospy, MF, "Odometry", "OptStatus", gate=gate)
+    assert calls == [("~laser_odom_input", 1), ("~laser_opt_status", 1), ("sync", 2, 10)] and "~laser_odom_output" in rospy.pubs
+    keep, drop = _ns(header=_ns(stamp=1)), _ns(header=_ns(stamp=2))
+    node.sync.cb(keep, _ns(hessian=[1.0] * 36))
+    node.sync.cb(drop, _ns(hessian=[-1.0] * 36))
+    assert rospy.pubs["~laser_odom_output"] == [keep] and seen == [36, 36] and len(rospy.warned) == 1
+
+
+def test_diagnostics_message_filling():
+    from vil_sensor_fusion_amd.ros.diagnostics_node import fill_message
+    tr = DiagnosticTrack("lidar")
+    tr.update(0.0, I4, [0, 0, 0], I4, [0, 0, 0])
+    d = tr.update(1.0, I4, [3, 4, 0], qz(0.2), [3, 4, 0.5])
+    m = fill_message(_Msg(), d, "stamp")
+    assert m.header.stamp == "stamp" and m.name == "lidar" and abs(m.gt_distance - 5.0) < 1e-15
+    assert abs(m.abs_rot_err - 0.2) < 1e-12 and abs(m.err.position.z - 0.5) < 1e-15 and abs(m.err.orientation.w - math.cos(0.1)) < 1e-15
+    for k in ("relative_dist_err", "abs_linear_vel_err", "abs_rot_vel_err", "rel_linear_vel_err", "rel_rot_vel_err"):
+        assert isinstance(getattr(m, k), float)

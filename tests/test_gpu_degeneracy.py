@@ -84,3 +84,18 @@ def test_dopt_filter_matches_reference_rule():
     clear = (np.abs(ro - 11.5) > 1e-4) & (np.abs(to - 28.9) > 1e-4)
     np.testing.assert_array_equal(keep[clear], ko[clear])
     assert 0 < keep.sum() < keep.size
+
+
+def test_degeneracy_gate_object():
+    """vil_sensor_fusion_amd.degeneracy_gate.DegeneracyGate = the callback of degerate_odometry_filter.cpp:29-47: keep unless the
+    float32 log det of the rotation (3,3) or translation (0,0) block is below its threshold."""
+    from vil_sensor_fusion_amd.degeneracy_gate import DegeneracyGate
+    gate = DegeneracyGate(11.5, 28.9)
+    good = np.diag([2e4, 3e4, 2.5e4, 60.0, 70.0, 50.0]).astype(np.float32)       # log det: trans 30.3, rot 12.3
+    bad_t = good.copy(); bad_t[0, 0] = 2.0                                        # along-track information gone: trans 21.1
+    bad_r = good.copy(); bad_r[5, 5] = 5.0                                        # rot 9.95
+    keep, rot, trans = gate.evaluate(np.stack([good, bad_t, bad_r]).reshape(3, 36))
+    assert keep.tolist() == [True, False, False]
+    np.testing.assert_allclose(trans[0], np.log(2e4 * 3e4 * 2.5e4), rtol=1e-5)
+    np.testing.assert_allclose(rot[2], np.log(60.0 * 70.0 * 5.0), rtol=1e-5)
+    assert gate(good.reshape(36)) and not gate(bad_t.reshape(36)) and gate.dropped == 1

@@ -1,0 +1,91 @@
+"""The independent numpy twin (oracle/twin.py: generic matrix exponentials, series, finite differences) against the C
+oracle: a disagreement here is a CONVENTION error (tangent order, retraction, residual definition, preintegration
+recursion) that the closed-form Jacobian tests could not see, because oracle and kernels share one reading of GTSAM.
+Neither side pins GTSAM itself (it is not available); this removes common-mode risk between restatements."""
+import numpy as np
+
+from oracle import twin
+from vil_sensor_fusion_amd import synth
+
+
+def _rand_state(rng, scale=1.0):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    if q[0] < 0:
+        q = -q
+    return np.concatenate([q, rng.normal(size=3) * 5 * scale, rng.normal(size=3) * 3 * scale, rng.normal(size=6) * 0.02])
+
+
+def test_lie_group_primitives(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        w = rng.normal(size=3) * rng.choice([1e-4, 0.3, 1.2])
+        if np.linalg.norm(w) > 3.0:                     # keep inside the injectivity radius of the logarithm
+            w *= 3.0 / np.linalg.norm(w)
+        np.testing.assert_allclose(oracle.so3_exp(w), twin.so3_exp(w), atol=1e-13)
+        np.testing.assert_allclose(oracle.so3_log(twin.so3_exp(w)), w, atol=1e-12)
+        np.testing.assert_allclose(oracle.so3_jr(w), twin.so3_jr(w), atol=1e-12)
+        np.testing.assert_allclose(oracle.so3_jr_inv(w) @ twin.so3_jr(w), np.eye(3), atol=1e-11)
+        xi = np.concatenate([w, rng.normal(size=3)])
+        R, t = oracle.se3_exp(xi)
+        Rt, tt = twin.se3_exp(xi)                       # tangent order [omega, v], full exponential map
+        np.testing.assert_allclose(R, Rt, atol=1e-13)
+        np.testing.assert_allclose(t, tt, atol=1e-12)
+        np.testing.assert_allclose(oracle.se3_log(Rt, tt), xi, atol=1e-11)
+        q = oracle.rot_to_quat(Rt)
+        np.testing.assert_allclose(twin.quat_to_rot(q), Rt, atol=1e-13)
+
+
+def _factor(oracle, seed, n_steps=9, bhat=None):
+    rng = np.random.default_rng(seed)
+    bhat = np.zeros(6) if bhat is None else bhat
+    steps = np.column_stack([np.full(n_steps, 0.005) * rng.uniform(0.5, 1.5, n_steps),
+                             rng.normal(size=(n_steps, 3)) * 0.5 + [0.3, -0.2, 9.81], rng.normal(size=(n_steps, 3)) * 0.3])
+    prm = oracle.carla_imu_params()
+    p = oracle.pim_new(bhat)
+    for s in steps:
+        oracle.pim_integrate(p, prm, s[1:4], s[4:7], s[0])
+    return steps, p, oracle.pim_to_record(p)
+
+
+def test_preintegration_mean_and_bias_jacobians(oracle):
+    for seed in range(4):
+        bhat = np.random.default_rng(100 + seed).normal(size=6) * 0.01
+        steps, p, rec = _factor(oracle, seed, bhat=bhat)
+        T, d = twin.preintegrate(steps, bhat)
+        np.testing.assert_allclose(rec[0], T, rtol=1e-14)
+        np.testing.assert_allclose(rec[1:10], d, rtol=1e-11, atol=1e-14)
+        np.testing.assert_allclose(rec[16:70].reshape(9, 6), twin.bias_jacobian_fd(steps, bhat), rtol=2e-6, atol=1e-9)
+
+
+def test_predict_and_imu_factor(oracle):
+    g = np.array([0.0, 0.0, -9.81])
+    for seed in range(4):
+        rng = np.random.default_rng(seed)
+        steps, p, rec = _factor(oracle, 10 + seed)
+        xi = _rand_state(rng)
+        pred = oracle.predict(rec, g, xi)
+        Rp, tp, vp = twin.predict(rec, g, xi)
+        np.testing.assert_allclose(twin.quat_to_rot(pred[:4]), Rp, atol=1e-12)
+        np.testing.assert_allclose(pred[4:7], tp, atol=1e-11)
+        np.testing.assert_allclose(pred[7:10], vp, atol=1e-11)
+        # a state near the prediction, as in a smoother (the residual's Log is then well inside its domain)
+        xj = oracle.retract(pred, rng.normal(size=15) * 0.02)
+        r, J = oracle.imu_factor(rec, g, xi, xj, whiten=False)
+        np.testing.assert_allclose(r, twin.imu_residual(rec, g, xi, xj), atol=1e-11)
+        Jt = twin.imu_jacobian_fd(rec, g, xi, xj)
+        assert np.abs(J - Jt).max() <= 2e-6 * max(1.0, np.abs(J).max()), np.abs(J - Jt).max()
+
+
+def test_between_factor(oracle):
+    seq = synth.make_sequence(seed=2, n_kf=12)
+    recs = synth.between_records(seq)
+    rng = np.random.default_rng(5)
+    for a, b, rec in list(zip(seq.btw_a, seq.btw_b, recs))[:6]:
+        xa = oracle.retract(seq.gt_states[a], rng.normal(size=15) * 0.02)
+        xb = oracle.retract(seq.gt_states[b], rng.normal(size=15) * 0.02)
+        r, Ja, Jb = oracle.between_factor(rec, xa, xb, whiten=False)
+        np.testing.assert_allclose(r, twin.between_residual(rec, xa, xb), atol=1e-11)
+        Jat, Jbt = twin.between_jacobian_fd(rec, xa, xb)
+        assert np.abs(Ja - Jat).max() <= 2e-6 * max(1.0, np.abs(Ja).max())
+        assert np.abs(Jb - Jbt).max() <= 2e-6 * max(1.0, np.abs(Jb).max())

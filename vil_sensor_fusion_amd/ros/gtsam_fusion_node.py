@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Drop-in for the `gtsam_fusion` node (gtsam_fusion/src/gtsam_fusion_node.cpp:17-104): same private parameters
+(config/carla/fusion_params.yaml: sensors/<name>/{sensor_topic, sensor_type, odom_topic, optimize_after_odom,
+use_odom_covariance, covariance_linear, covariance_angular, max_time_skip}, imu/{topic, cov_*}, tf/{static_frame,
+odom_frame}), same subscriptions and queue sizes, same publications (~odometry nav_msgs/Odometry + TF static_frame ->
+odom_frame from the optimisation callback), behind Rovio / LOAM exactly like the reference -- the pose-graph arithmetic
+runs in libvilfusion.so on the MI355X.
+
+Extra private parameters (defaults keep the reference's behaviour): solver/lag (0 = unbounded history, like iSAM2),
+solver/capacity, solver/iterations, solver/device, reference_compat (poseDiff quirk).
+
+    rosrun: python3 -m vil_sensor_fusion_amd.ros.gtsam_fusion_node   (with the node's YAML loaded in its namespace,
+    launch/fusion.launch:58-73)
+"""
+from __future__ import annotations
+
+from ..graph_manager import GraphManager
+from ..sensor_manager import Odometry, SensorManager
+
+
+def odometry_from_msg(m) -> Odometry:
+    """nav_msgs/Odometry -> the fields the reference reads (SensorManagerRos.cpp:122-158)"""
+    p, q = m.pose.pose.position, m.pose.pose.orientation
+    return Odometry(m.header.stamp.to_sec(), [p.x, p.y, p.z], [q.w, q.x, q.y, q.z], list(m.twist.covariance))
+
+
+class FusionNode:
+    """Everything of main() that is not ros::init / ros::spin, so that it can be driven by a test with stub messages."""
+
+    def __init__(self, rospy, tf2_ros, msgs, graph_manager=None):
+        """msgs: namespace with Imu, Image, PointCloud2, Odometry, TransformStamped message classes"""
+        self.rospy, self.msgs = rospy, msgs
+        P = lambda k, d=None: rospy.get_param("~" + k, d) if d is not None else rospy.get_param("~" + k)
+        imu = {k: P("imu/cov_" + n) for k, n in (("acc", "accel"), ("gyro", "gyro"), ("integration", "integration"),
+                                                   ("bias_acc", "bias_acc"), ("bias_omega", "bias_omega"),
+                                                   ("bias_acc_omega_int", "bias_acc_omega_int"))}   # ImuManagerRos.cpp:20-33
+        self.graph = graph_manager or GraphManager(imu_params=imu, capacity=int(P("solver/capacity", 4096)),
+                                                   lag=int(P("solver/lag", 0)), iterations=int(P("solver/iterations", 5)),
+                                                   device=int(P("solver/device", 0)))
+        self.subs = [rospy.Subscriber(P("imu/topic"), msgs.Imu, queue_size=100, callback=self.imu_callback)]   # ImuManagerRos.cpp:11
+        self.sensor_managers = {}
+        compat = bool(P("reference_compat", True))
+        for name, cfg in sorted(P("sensors").items()):                                   # gtsam_fusion_node.cpp:32-56
+            kind = cfg.get("sensor_type")
+            if kind not in ("PointCloud2", "Image"):
+                rospy.logwarn("Sensor %s has invalid type %s" % (name, kind))            # :52-55
+                continue
+            use_cov = bool(cfg["use_odom_covariance"])
+            sm = SensorManager(self.graph, bool(cfg["optimize_after_odom"]), use_cov,
+                               0.0 if use_cov else float(cfg["covariance_linear"]),      # SensorManagerRos.h:50-54
+                               0.0 if use_cov else float(cfg["covariance_angular"]),
+                               float(cfg["max_time_skip"]), reference_compat=compat)
+            self.sensor_managers[name] = sm
+            msg_type = msgs.PointCloud2 if kind == "PointCloud2" else msgs.Image
+            self.subs.append(rospy.Subscriber(cfg["sensor_topic"], msg_type, queue_size=1,                    # SensorManagerRos.h:59
+                                              callback=lambda m, sm=sm: sm.sensorCallback(m.header.stamp.to_sec())))
+            self.subs.append(rospy.Subscriber(cfg["odom_topic"], msgs.Odometry, queue_size=1,                 # :60
+                                              callback=lambda m, sm=sm: sm.odometryCallback(odometry_from_msg(m))))
+        self.pub = rospy.Publisher("~odometry", msgs.Odometry, queue_size=1)             # gtsam_fusion_node.cpp:58
+        self.broadcaster = tf2_ros.TransformBroadcaster()
+        self.static_frame, self.odom_frame = P("tf/static_frame"), P("tf/odom_frame")    # :61-62
+        self.graph.addOptimizationCallback(self.publish)                                 # :64
+
+    def imu_callback(self, m):                                                           # ImuManagerRos.cpp:38-52
+        a, w = m.linear_acceleration, m.angular_velocity
+        self.graph.addIMUMeasurement(m.header.stamp.to_sec(), [a.x, a.y, a.z], [w.x, w.y, w.z])
+
+    def publish(self, time, q, p, v, bias):                                              # gtsam_fusion_node.cpp:64-98
+        stamp = self.rospy.Time.from_sec(time)
+        o = self.msgs.Odometry()
+        o.header.stamp, o.header.frame_id, o.child_frame_id = stamp, self.static_frame, self.odom_frame
+        o.pose.pose.position.x, o.pose.pose.position.y, o.pose.pose.position.z = (float(x) for x in p)
+        (o.pose.pose.orientation.w, o.pose.pose.orientation.x, o.pose.pose.orientation.y,
+         o.pose.pose.orientation.z) = (float(x) for x in q)
+        o.twist.twist.linear.x, o.twist.twist.linear.y, o.twist.twist.linear.z = (float(x) for x in v)
+        self.pub.publish(o)
+        t = self.msgs.TransformStamped()
+        t.header.stamp, t.header.frame_id, t.child_frame_id = stamp, self.static_frame, self.odom_frame
+        t.transform.translation.x, t.transform.translation.y, t.transform.translation.z = (float(x) for x in p)
+        (t.transform.rotation.w, t.transform.rotation.x, t.transform.rotation.y,
+         t.transform.rotation.z) = (float(x) for x in q)
+        self.broadcaster.sendTransform(t)
+
+
+def main():
+    import types
+
+    import rospy
+    import tf2_ros
+    from geometry_msgs.msg import TransformStamped
+    from nav_msgs.msg import Odometry as OdometryMsg
+    from sensor_msgs.msg import Image, Imu, PointCloud2
+    rospy.init_node("gtsam_fusion")
+    FusionNode(rospy, tf2_ros, types.SimpleNamespace(Imu=Imu, Image=Image, PointCloud2=PointCloud2, Odometry=OdometryMsg,
+                                                      TransformStamped=TransformStamped))
+    rospy.spin()          # one spinner thread: callbacks are serialised, as in the reference (gtsam_fusion_node.cpp:101)
+
+
+if __name__ == "__main__":
+    main()

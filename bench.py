@@ -80,7 +80,7 @@ def make_sequences(args, rank, count, n_kf, base_seed=0):
     """`count` synthetic sequences with distinct seeds (one seed per window), generated on the host
     cores by forked workers -- called BEFORE the process touches the GPU."""
     jobs = [(base_seed + 100003 * rank + s, n_kf) for s in range(count)]
-    nproc = min(len(jobs), host_workers(), 32)
+    nproc = min(len(jobs), args.host_workers or host_workers(), 32)
     if nproc <= 1:
         return [_make_seq(j) for j in jobs]
     with multiprocessing.get_context("fork").Pool(nproc) as pool:
@@ -333,6 +333,9 @@ def main():
     ap.add_argument("--iterations", type=int, default=5, help="LM trials per update")
     ap.add_argument("--cpu-steps", type=int, default=64,
                     help="fixed-lag updates the one-core CPU baseline is timed on (64 = about 5 s)")
+    ap.add_argument("--host-workers", type=int, default=0,
+                    help="processes that generate the synthetic sequences (0 = the host cores this job may use; 1 = no worker "
+                         "processes, e.g. under a profiler)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-window", action="store_true")
     ap.add_argument("--reanchor", action="store_true", help="drop the oldest keyframe by re-anchoring tight priors instead of marginalising it")

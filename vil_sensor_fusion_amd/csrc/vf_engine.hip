@@ -79,6 +79,22 @@ struct vf_engine {
     int slid = 0;             // keyframes appended since the last solve
     int redo = 0;             // slots in front of the old window end whose factors changed since (see touch())
     bool no_warm = false;     // VF_NO_WARM=1 at creation: every solve starts cold (tests compare the two)
+    // hybrid K4 (vf_kernels.hpp "View::gate"): buffers and chunk count of the partitioned form for a sweep engine, allocated
+    // when the termination rule is first switched on
+    bool hybrid = false;
+    int hybrid_P = 0;
+    double *h_Vp = nullptr, *h_sep = nullptr, *h_sepL = nullptr;
+    vf::View partitioned_view() const {
+        vf::View p = v;
+        p.P = hybrid_P;
+        p.P_fit = 1;
+        p.Vp = h_Vp;
+        p.sepR = h_sep;
+        p.sepS = h_sep + vf::SEPM;
+        p.sepC = h_sep + 2 * vf::SEPM;
+        p.sepL = h_sepL;
+        return p;
+    }
 
     template <typename T>
     int alloc(T** p, size_t n, bool zero = true) {
@@ -233,6 +249,10 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.n_rej, (size_t)v.B);
     AL(v.n_fail, (size_t)v.B);
     AL(v.done, (size_t)v.B);
+    AL(v.n_active, 4);
+    v.gate = 0;
+    v.gate_T = 256;           // partitioned form: 0.0095 ms per window; the sweep: 3.1 ms whatever their number
+    if (const char* t = getenv("VF_HYBRID_T")) v.gate_T = atoi(t);
     v.stop_on = 0;
     v.rel_tol = v.abs_tol = 0.0;
     v.sh_r = 0;
@@ -516,7 +536,8 @@ int vf_engine_solve(vf_engine* e) {
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (int rc = not_sharded(e, "vf_engine_solve")) return rc;
-    vf::launch_band_solve(e->v, e->stream);
+    if (e->hybrid && e->v.stop_on) vf::launch_band_solve_hybrid(e->v, e->partitioned_view(), e->stream);
+    else vf::launch_band_solve(e->v, e->stream);
     HIPCHK(hipGetLastError());
     return VF_OK;
 }
@@ -533,6 +554,7 @@ int vf_engine_decide(vf_engine* e, int init) {
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     vf::launch_decide(e->v, init ? 1 : 0, e->stream);
+    if (e->hybrid && e->v.stop_on) vf::launch_count_active(e->v, e->stream);   // what the next K4 launch gates on
     HIPCHK(hipGetLastError());
     return VF_OK;
 }
@@ -735,6 +757,18 @@ int vf_engine_set_convergence(vf_engine* e, double rel_tol, double abs_tol) {
     e->v.abs_tol = abs_tol;
     e->v.stop_on = (rel_tol > 0.0 || abs_tol > 0.0) ? 1 : 0;
     e->epoch++;
+    // sweep engines (large batches): once few windows are left taking trials, K4 switches to the partitioned form
+    if (e->v.stop_on && e->v.P == 0 && e->v.B > 128 && !e->hybrid && !getenv("VF_NO_HYBRID")) {
+        vf::View& v = e->v;
+        e->hybrid_P = vf::chunk_count(v.M, 96, 1);
+        if (e->hybrid_P >= 2) {
+            const size_t BP = (size_t)v.B * e->hybrid_P;
+            int rc;
+            if ((rc = e->alloc(&e->h_Vp, (size_t)v.G * vf::VROW)) || (rc = e->alloc(&e->h_sep, BP * vf::SEPK)) ||
+                (rc = e->alloc(&e->h_sepL, BP * vf::SEPL))) return rc;
+            e->hybrid = true;
+        }
+    }
     HIPCHK(hipMemsetAsync(e->v.done, 0, e->v.B * sizeof(int), e->stream));
     return VF_OK;
 }

@@ -31,6 +31,12 @@ namespace vf {
 
 // optional LM termination: a window that has converged takes no part in the remaining trials of this solve
 VF_DI bool window_done(const View& v, int w) { return v.stop_on && v.done[w]; }
+// hybrid K4: which of the two forms of this launch does the work (see View::gate)
+VF_DI bool gated_off(const View& v) {
+    if (!v.gate) return false;
+    const int na = *v.n_active;
+    return v.gate == 1 ? na <= v.gate_T : na > v.gate_T;
+}
 // Which of the two H / g buffers holds the normal equations of window w's CURRENT states.  Fused engines (the fused
 // linearise + assemble kernel writes the trial's normal equations beside the current ones): buffer sel[w]; otherwise 0.
 VF_DI int h_buf(const View& v, int w) { return v.fused ? v.sel[w] : 0; }
@@ -1757,7 +1763,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 
 __global__ void __launch_bounds__(64) k_band_solve(View v) {
     const int w = blockIdx.x;
-    if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w)) return;
+    if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
     __shared__ double S[S_TOTAL];
     band_solve_body<SOLVE_FULL>(v, S, nullptr, nullptr, w, threadIdx.x, 0);
 }
@@ -1943,7 +1949,7 @@ __device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int
 __global__ void __launch_bounds__(128) k_chunk_forward(View v) {
     const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
     const int n = v.hi[w] - v.lo[w];
-    if (n <= 0 || window_done(v, w)) return;
+    if (n <= 0 || window_done(v, w) || gated_off(v)) return;
     const int Pe = chunk_count(n, P, v.P_fit);
     int oc0, oc1;
     own_chunks(v, Pe, oc0, oc1);
@@ -1961,7 +1967,7 @@ __global__ void __launch_bounds__(128) k_chunk_forward(View v) {
 __global__ void __launch_bounds__(64) k_chunk_back(View v) {
     const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
     const int n = v.hi[w] - v.lo[w];
-    if (n <= 0 || window_done(v, w)) return;
+    if (n <= 0 || window_done(v, w) || gated_off(v)) return;
     const int Pe = chunk_count(n, P, v.P_fit);
     int oc0, oc1;
     own_chunks(v, Pe, oc0, oc1);
@@ -1974,7 +1980,7 @@ __global__ void __launch_bounds__(64) k_chunk_back(View v) {
 __global__ void __launch_bounds__(256) k_chunk_rhs(View v) {
     const int P = v.P, w = blockIdx.x / P, c = blockIdx.x - w * P;
     const int lo = v.lo[w], n = v.hi[w] - lo;
-    if (n <= 0 || window_done(v, w)) return;
+    if (n <= 0 || window_done(v, w) || gated_off(v)) return;
     const int Pe = chunk_count(n, P, v.P_fit);
     int oc0, oc1;
     own_chunks(v, Pe, oc0, oc1);
@@ -2042,7 +2048,7 @@ __global__ void __launch_bounds__(256) k_sep_solve(View v) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches on the roles
     const int team = wave >= 2 ? 1 : 0, tw = wave - 2 * team, tt = tid - 128 * team;
     const int lo = v.lo[w], n = v.hi[w] - lo;
-    if (n <= 0 || window_done(v, w)) return;
+    if (n <= 0 || window_done(v, w) || gated_off(v)) return;
     const int Pe = chunk_count(n, P, v.P_fit), m = Pe - 1;
     if (m <= 0) return;
     const int h = m / 2;                         // middle separator; team 0: 0 .. h-1 then h, team 1: m-1 .. h+1
@@ -2689,6 +2695,27 @@ void launch_band_solve(const View& v, hipStream_t s) {
     static const int tw_max = getenv("VF_TWISTED_MAX_WINDOWS") ? atoi(getenv("VF_TWISTED_MAX_WINDOWS")) : 256;
     if (v.B <= tw_max) hipLaunchKernelGGL(k_band_solve_tw, dim3(v.B), dim3(128), 0, s, v);
     else hipLaunchKernelGGL(k_band_solve, dim3(v.B), dim3(64), 0, s, v);
+}
+// windows of the running solve that still take LM trials (termination rule on)
+__global__ void __launch_bounds__(1024) k_count_active(View v) {
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int w = threadIdx.x; w < v.B; w += blockDim.x) mine += (v.hi[w] > v.lo[w] && !v.done[w]) ? 1 : 0;
+    if (mine) atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) *v.n_active = cnt;
+}
+void launch_count_active(const View& v, hipStream_t s) {
+    hipLaunchKernelGGL(k_count_active, dim3(1), dim3(1024), 0, s, v);
+}
+void launch_band_solve_hybrid(const View& v, const View& vp, hipStream_t s) {
+    View a = v, b = vp;
+    a.gate = 1;
+    b.gate = 2;
+    hipLaunchKernelGGL(k_band_solve, dim3(a.B), dim3(64), 0, s, a);
+    launch_partitioned_solve(b, s);
 }
 void launch_retract(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_retract, dim3(nblk(v.G, 256)), dim3(256), 0, s, v);

@@ -155,6 +155,18 @@ int vf_engine_solve_local(vf_engine* e);    /* chunk sweeps + spikes of the owne
 int vf_engine_solve_global(vf_engine* e);   /* separator chain, back substitution of the owned chunks, zero the rest of delta */
 int vf_engine_reset_lambda(vf_engine* e);   /* lambda := lambda0, as vf_engine_iterate does before its first trial */
 
+/* Reference-compat solve: what the reference computes per GraphManager::solve (GraphManager.cpp:38-43,126-127) -- ONE
+ * iSAM2-like update: keyframes whose pending increment reaches relin_threshold in any component (ISAM2Params::
+ * relinearizeThreshold, 1e-4 in the reference) move their linearisation point there, every factor is linearised at the
+ * linearisation points, ONE undamped Gauss-Newton system is solved for the increments of all keyframes, and the
+ * estimate is theta (+) delta.  vf_engine_get_states then returns the linearisation points, vf_engine_get_estimate the
+ * estimate; vf_engine_predict_from_estimate starts the IMU prediction of new keyframes from the estimate of keyframe
+ * k0 - 1 (GraphManager.cpp:152-153).  Exact where iSAM2 is approximate (its partial back-substitution stops below the
+ * wildfire threshold).  Not for sharded engines; fixed-lag marginalisation is not part of this mode. */
+int vf_engine_isam_step(vf_engine* e, double relin_threshold);
+int vf_engine_predict_from_estimate(vf_engine* e, int window, int k0, int n);
+int vf_engine_get_estimate(vf_engine* e, int window, int k0, int n, double* state16);
+
 /* Optional LM termination (off by default: vf_engine_iterate runs exactly `iterations` trials).  With a
  * tolerance > 0, a window whose trial changes the cost by <= abs_tol, or by <= rel_tol * cost (an accepted
  * step that no longer pays, or a rejected one inside the rounding floor), is converged and takes no part in
@@ -266,6 +278,11 @@ typedef struct {
      * cost by <= abs_tol or <= rel_tol * cost.  Defaults 1e-5 / 1e-5 = gtsam::LevenbergMarquardtParams (the optimiser at
      * GraphManager.cpp:128-129); 0 / 0 = always `iterations` trials. */
     double rel_tol, abs_tol;
+    /* reference_compat != 0: vf_solve does what the reference's solve() does -- one iSAM2-like update
+     * (vf_engine_isam_step with relin_threshold, default 1e-4 = GraphManager.cpp:40) instead of LM to convergence; needs
+     * lag == 0 (the reference's graph is unbounded).  Default 0. */
+    int reference_compat;
+    double relin_threshold;
 } vf_graph_opts;
 
 /* (time, pose q_wxyz, position, velocity, bias[acc,gyro]) -- GraphManager::OptimizationCallback

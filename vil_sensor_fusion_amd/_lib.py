@@ -39,7 +39,8 @@ class ShardInfoC(C.Structure):
 
 class GraphOptsC(C.Structure):
     _fields_ = [("capacity", C.c_int), ("lag", C.c_int), ("iterations", C.c_int), ("device", C.c_int),
-                ("prior_sigma", C.c_double * 15), ("rel_tol", C.c_double), ("abs_tol", C.c_double)]
+                ("prior_sigma", C.c_double * 15), ("rel_tol", C.c_double), ("abs_tol", C.c_double),
+                ("reference_compat", C.c_int), ("relin_threshold", C.c_double)]
 
 
 CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -64,6 +65,7 @@ SYMBOLS = [
     "vf_engine_set_stream", "vf_engine_set_shard", "vf_engine_shard_info", "vf_engine_solve_local",
     "vf_engine_solve_global", "vf_engine_reset_lambda",
     "vf_chunk_geometry", "vf_shard_range", "vf_engine_set_convergence",
+    "vf_engine_isam_step", "vf_engine_predict_from_estimate", "vf_engine_get_estimate",
     "vf_graph_default_opts", "vf_create", "vf_destroy", "vf_add_imu", "vf_reserve_node",
     "vf_add_between", "vf_solve", "vf_get_state", "vf_get_bias", "vf_most_recent_pose_time",
     "vf_set_callback", "vf_graph_staged", "vf_get_trajectory", "vf_get_imu_factor",

@@ -785,8 +785,59 @@ int vf_engine_predict(vf_engine* e, int window, int k0, int n) {
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (window >= e->v.B || k0 < 1 || n < 0 || k0 + n > e->v.M) return fail(VF_ERR_BAD_KEY, "bad predict range");
     if (n == 0) return VF_OK;
-    vf::launch_predict(e->v, window, k0, n, e->stream);
+    vf::launch_predict(e->v, window, k0, n, 0, e->stream);
     HIPCHK(hipGetLastError());
+    return VF_OK;
+}
+
+// ------------------------------------------------------------------ reference-compat solve
+// What the reference does per GraphManager::solve (GraphManager.cpp:38-43,126-127): ONE iSAM2 update -- Gauss-Newton
+// (QR, no damping) about per-variable linearisation points theta, relinearising only the variables whose pending
+// increment reaches relinearizeThreshold (1e-4) -- and calculateEstimate() = theta (+) delta.  Here: buffer sel = theta,
+// v.delta = delta, the trial buffer = the estimate.  iSAM2 re-eliminates only the cliques a new factor touches; solving the
+// whole banded system with every factor linearised at theta gives the same increment (its partial back-substitution
+// stops below wildfireThreshold 1e-3 * ... of change; that approximation is NOT reproduced -- the full solve is exact).
+int vf_engine_isam_step(vf_engine* e, double relin_threshold) {
+    DeviceGuard dev_guard_(e);
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (!(relin_threshold >= 0.0)) return fail(VF_ERR_INVALID, "relinearisation threshold must be >= 0");
+    if (int rc0 = not_sharded(e, "vf_engine_isam_step")) return rc0;
+    e->warm = false;
+    int rc;
+    vf::launch_relinearize(e->v, relin_threshold, e->stream);
+    HIPCHK(hipMemsetAsync(e->v.lambda, 0, e->v.B * sizeof(double), e->stream));     // Gauss-Newton: no damping
+    if ((rc = vf_engine_linearize(e, 0)) || (rc = vf_engine_decide(e, 1)) || (rc = vf_engine_assemble(e)) ||
+        (rc = vf_engine_solve(e)) || (rc = vf_engine_retract(e))) return rc;
+    std::vector<int> failed((size_t)e->v.B);
+    HIPCHK(hipMemcpyAsync(failed.data(), e->v.fail, failed.size() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int w = 0; w < e->v.B; w++)
+        if (failed[w]) return fail(VF_ERR_INDETERMINATE, "window %d: normal equations not positive definite (underdetermined graph)", w);
+    e->warm = false;
+    return VF_OK;
+}
+int vf_engine_predict_from_estimate(vf_engine* e, int window, int k0, int n) {
+    DeviceGuard dev_guard_(e);
+    if (e) e->warm = false;
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (window >= e->v.B || k0 < 1 || n < 0 || k0 + n > e->v.M) return fail(VF_ERR_BAD_KEY, "bad predict range");
+    if (n == 0) return VF_OK;
+    vf::launch_predict(e->v, window, k0, n, 1, e->stream);
+    HIPCHK(hipGetLastError());
+    return VF_OK;
+}
+int vf_engine_get_estimate(vf_engine* e, int window, int k0, int n, double* s) {
+    DeviceGuard dev_guard_(e);
+    int rc = check_range(e, window, k0, n);
+    if (rc) return rc;
+    if (!s) return fail(VF_ERR_INVALID, "null states");
+    if (n == 0) return VF_OK;
+    const size_t bytes = (size_t)n * 16 * sizeof(double);
+    if ((rc = e->ensure_stage(bytes))) return rc;
+    vf::launch_gather_states(e->v.x, e->stage, e->v.G, e->v.sel, e->v.M, 1, (long)window * e->v.M + k0, n, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(s, e->stage, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return VF_OK;
 }
 

@@ -116,6 +116,8 @@ void vf_graph_default_opts(vf_graph_opts* o) {
     memcpy(o->prior_sigma, s, sizeof(s));
     o->rel_tol = 1e-5;   // gtsam::LevenbergMarquardtParams relativeErrorTol / absoluteErrorTol
     o->abs_tol = 1e-5;
+    o->reference_compat = 0;
+    o->relin_threshold = 1e-4;   // GraphManager.cpp:40
 }
 
 int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** out) {
@@ -125,6 +127,8 @@ int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** ou
     if (o.capacity < 8 || o.iterations < 0 || o.lag < 0) return gerr(VF_ERR_INVALID, "bad graph options");
     if (o.lag != 0 && o.lag < 4) return gerr(VF_ERR_INVALID, "lag must be 0 or >= 4 keyframes");
     if (!(o.rel_tol >= 0.0) || !(o.abs_tol >= 0.0)) return gerr(VF_ERR_INVALID, "tolerances must be >= 0");
+    if (o.reference_compat && o.lag != 0) return gerr(VF_ERR_INVALID, "reference_compat needs lag == 0 (the reference's graph is unbounded)");
+    if (o.reference_compat && !(o.relin_threshold >= 0.0)) return gerr(VF_ERR_INVALID, "relin_threshold must be >= 0");
     const double covs[6] = {imu->acc_cov, imu->gyro_cov, imu->integration_cov, imu->bias_acc_cov, imu->bias_omega_cov, imu->bias_acc_omega_int};
     for (double c : covs)
         if (!(c > 0.0) || !std::isfinite(c)) return gerr(VF_ERR_NOT_SPD, "IMU covariances must be finite and > 0");
@@ -416,7 +420,9 @@ int vf_solve(vf_graph* g) {
             i = j;
         }
         lap("preintegrate");
-        if ((rc = vf_engine_predict(g->eng, 0, (int)k0, n))) return give_back(rc);
+        // reference_compat: from the ESTIMATE of the last keyframe (_currentState, GraphManager.cpp:152), not its linearisation point
+        if ((rc = (g->opts.reference_compat && g->solved_key > 0) ? vf_engine_predict_from_estimate(g->eng, 0, (int)k0, n)
+                                                                    : vf_engine_predict(g->eng, 0, (int)k0, n))) return give_back(rc);
         lap("predict");
     }
     if (!betweens.empty()) {
@@ -447,12 +453,18 @@ int vf_solve(vf_graph* g) {
     lap("marginalize");
     if ((rc = vf_engine_set_range(g->eng, 0, lo, last_slot + 1))) return give_back(rc);
     lap("set_range");
-    if ((rc = vf_engine_iterate(g->eng, g->opts.iterations))) return rc;   // ISAM2::update + calculateEstimate
-    lap("iterate(launch)");
     int fails = 0;
-    if ((rc = vf_engine_read_lm(g->eng, 0, nullptr, nullptr, nullptr, nullptr, &fails))) return rc;
-    lap("read_lm(sync)");
-    if ((rc = vf_engine_get_states(g->eng, 0, last_slot, 1, g->state))) return rc;  // :131-133
+    if (g->opts.reference_compat) {
+        if ((rc = vf_engine_isam_step(g->eng, g->opts.relin_threshold))) return rc;  // one ISAM2::update
+        lap("isam_step");
+        if ((rc = vf_engine_get_estimate(g->eng, 0, last_slot, 1, g->state))) return rc;   // calculateEstimate, :127,131-133
+    } else {
+        if ((rc = vf_engine_iterate(g->eng, g->opts.iterations))) return rc;   // (ISAM2::update + calculateEstimate: LM to convergence)
+        lap("iterate(launch)");
+        if ((rc = vf_engine_read_lm(g->eng, 0, nullptr, nullptr, nullptr, nullptr, &fails))) return rc;
+        lap("read_lm(sync)");
+        if ((rc = vf_engine_get_states(g->eng, 0, last_slot, 1, g->state))) return rc;  // :131-133
+    }
     lap("get_states");
     g->solved_key = last_key;
     for (auto& cb : g->callbacks)  // :135-138, on the solving thread, inside _stateMutex
@@ -485,6 +497,7 @@ int vf_get_trajectory(vf_graph* g, uint64_t key0, int n, double* state16) {
     std::lock_guard<std::mutex> lk(g->state_mutex);
     if (n < 0 || key0 + (uint64_t)n > g->solved_key + 1) return gerr(VF_ERR_BAD_KEY, "keys [%llu, %llu) not solved yet", (unsigned long long)key0, (unsigned long long)(key0 + n));
     if (key0 < g->key_base) return gerr(VF_ERR_BAD_KEY, "key %llu has been compacted away (oldest retained key %llu)", (unsigned long long)key0, (unsigned long long)g->key_base);
+    if (g->opts.reference_compat) return vf_engine_get_estimate(g->eng, 0, (int)(key0 - g->key_base), n, state16);
     return vf_engine_get_states(g->eng, 0, (int)(key0 - g->key_base), n, state16);
 }
 

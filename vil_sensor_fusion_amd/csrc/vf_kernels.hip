@@ -2423,15 +2423,49 @@ VF_DI State predict_state(const View& v, const State& si, long gk_factor) {
 }
 
 // window < 0: all windows (one lane each)
-__global__ void k_predict(View v, int window, int k0, int n) {
+// from_trial: the first prediction starts from the TRIAL buffer's state of keyframe k0 - 1 (reference-compat solves: the
+// trial buffer holds the estimate theta (+) delta the reference predicts from, GraphManager.cpp:152-153)
+__global__ void k_predict(View v, int window, int k0, int n, int from_trial) {
     const int w = window >= 0 ? window : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (w >= v.B || (window >= 0 && (blockIdx.x | threadIdx.x))) return;
     const int b = v.sel[w];
     for (int k = k0; k < k0 + n; k++) {
         const long gk = (long)w * v.M + k;
-        const State si = load_state(v, b, gk - 1);
-        store_state(v, b, gk, predict_state(v, si, gk));
+        const State si = load_state(v, (from_trial && k == k0) ? b ^ 1 : b, gk - 1);
+        const State sn = predict_state(v, si, gk);
+        store_state(v, b, gk, sn);
+        if (from_trial) store_state(v, b ^ 1, gk, sn);      // the estimate of a keyframe that has no increment yet
     }
+}
+
+// Reference-compat solves (one iSAM2-like update per vf_solve, GraphManager.cpp:38-43,126-127): fluid relinearisation --
+// a keyframe whose pending increment reaches the threshold in any component (ISAM2Params::relinearizeThreshold, a scalar:
+// max |delta| >= threshold) moves its linearisation point there, theta <- theta (+) delta, delta <- 0; the others keep
+// theirs.  Lane = keyframe.
+__global__ void __launch_bounds__(256) k_relinearize(View v, double threshold) {
+    const long gk = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gk >= v.G) return;
+    const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
+    if (k < v.lo[w] || k >= v.hi[w]) return;
+    double* d = v.delta + (size_t)gk * 15;
+    double m = 0.0;
+#pragma unroll
+    for (int a = 0; a < 15; a++) m = fmax(m, fabs(d[a]));
+    if (!(m >= threshold)) return;
+    const int b = v.sel[w];
+    const State s = load_state(v, b, gk);
+    State o;
+    Q4 dq;
+    V3 dtv;
+    se3_exp(v3(d[0], d[1], d[2]), v3(d[3], d[4], d[5]), &dq, &dtv);
+    o.q = qnormalize(qmul(s.q, dq));
+    o.t = s.t + mul(qrot(s.q), dtv);
+    o.vel = s.vel + v3(d[6], d[7], d[8]);
+    o.ba = s.ba + v3(d[9], d[10], d[11]);
+    o.bg = s.bg + v3(d[12], d[13], d[14]);
+    store_state(v, b, gk, o);
+#pragma unroll
+    for (int a = 0; a < 15; a++) d[a] = 0.0;
 }
 
 // Fixed-lag marginalisation of the oldest keyframe m = lo: the Schur complement of
@@ -2723,9 +2757,12 @@ void launch_retract(const View& v, hipStream_t s) {
 void launch_decide(const View& v, int init, hipStream_t s) {
     hipLaunchKernelGGL(k_decide, dim3(v.B), dim3(v.B <= 64 ? 1024 : 256), 0, s, v, init);
 }
-void launch_predict(const View& v, int window, int k0, int n, hipStream_t s) {
-    if (window >= 0) hipLaunchKernelGGL(k_predict, dim3(1), dim3(1), 0, s, v, window, k0, n);
-    else hipLaunchKernelGGL(k_predict, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, window, k0, n);
+void launch_predict(const View& v, int window, int k0, int n, int from_trial, hipStream_t s) {
+    if (window >= 0) hipLaunchKernelGGL(k_predict, dim3(1), dim3(1), 0, s, v, window, k0, n, from_trial);
+    else hipLaunchKernelGGL(k_predict, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, window, k0, n, from_trial);
+}
+void launch_relinearize(const View& v, double threshold, hipStream_t s) {
+    hipLaunchKernelGGL(k_relinearize, dim3(nblk(v.G, 256)), dim3(256), 0, s, v, threshold);
 }
 void launch_slide(const View& v, const double* sigma15_dev, int reanchor, hipStream_t s) {
     hipLaunchKernelGGL(k_slide, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, sigma15_dev, reanchor);

@@ -178,7 +178,8 @@ void launch_decide(const View& v, int init, hipStream_t s);
 void launch_partitioned_local(const View& v, hipStream_t s);    // chunk sweeps + spikes of the owned chunks
 void launch_partitioned_global(const View& v, hipStream_t s);   // separator chain (all of it) + back substitution of the owned chunks
 void launch_mask_delta(const View& v, hipStream_t s);           // zero the increments of keyframes this rank does not own
-void launch_predict(const View& v, int window, int k0, int n, hipStream_t s);
+void launch_predict(const View& v, int window, int k0, int n, int from_trial, hipStream_t s);
+void launch_relinearize(const View& v, double threshold, hipStream_t s);   // reference-compat solves: theta <- theta (+) delta where |delta| >= threshold
 void launch_slide(const View& v, const double* sigma15_dev, int reanchor, hipStream_t s);
 void launch_marginalize(const View& v, int* status, hipStream_t s);
 void launch_shift_copy(const double* src, double* dst, long n, hipStream_t s);

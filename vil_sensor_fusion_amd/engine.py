@@ -157,6 +157,18 @@ class Engine:
         """Initial values of keyframes [k0, k0+n) by IMU prediction from k0-1; window = -1: every window."""
         check(self._l.vf_engine_predict(self._h, window, k0, n))
 
+    def isam_step(self, relin_threshold=1e-4):
+        """One reference-compat update (vf_engine_isam_step): get_states = linearisation points, get_estimate = estimate."""
+        check(self._l.vf_engine_isam_step(self._h, C.c_double(relin_threshold)))
+
+    def predict_from_estimate(self, window, k0, n):
+        check(self._l.vf_engine_predict_from_estimate(self._h, window, k0, n))
+
+    def get_estimate(self, window, k0, n):
+        s = np.zeros((n, 16))
+        check(self._l.vf_engine_get_estimate(self._h, window, k0, n, _d(s)))
+        return s
+
     def sync(self):
         check(self._l.vf_engine_sync(self._h))
 

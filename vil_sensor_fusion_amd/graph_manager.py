@@ -28,7 +28,7 @@ class GraphManager:
     """GraphManager(imuManager): the IMU manager is folded in (addIMUMeasurement)."""
 
     def __init__(self, imu_params=CARLA_IMU, capacity=4096, lag=0, iterations=5, device=0,
-                 prior_sigma=None, rel_tol=None, abs_tol=None):
+                 prior_sigma=None, rel_tol=None, abs_tol=None, reference_compat=False, relin_threshold=None):
         """iterations: LM trials per solve at most; a solve stops earlier once a trial changes the cost by <= abs_tol or
         <= rel_tol * cost (defaults 1e-5 / 1e-5, gtsam::LevenbergMarquardtParams; 0 / 0: always `iterations` trials)."""
         self._l = _lib.lib()
@@ -44,6 +44,10 @@ class GraphManager:
             o.rel_tol = rel_tol
         if abs_tol is not None:
             o.abs_tol = abs_tol
+        # reference_compat: solve() = ONE iSAM2-like update (relinearizeThreshold 1e-4, GraphManager.cpp:38-43), lag must be 0
+        o.reference_compat = int(bool(reference_compat))
+        if relin_threshold is not None:
+            o.relin_threshold = relin_threshold
         self._h = C.c_void_p()
         check(self._l.vf_create(C.byref(p), C.byref(o), C.byref(self._h)))
         self._cbs = []

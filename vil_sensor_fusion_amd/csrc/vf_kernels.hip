@@ -312,6 +312,11 @@ VF_DI double jstream_entry(const double* jbuf, long gk, int row, int col) {
 // find its halo factor in its own block, cost K1 0.48 ms: 16-byte partial-line writes.  K3 reads the halo where it is.)
 // `jac` = false (time-sharded windows, factors this rank does not assemble): residual only.
 struct HbmSink {
+    // The 9x6 bias Jacobians of the record are used twice (bias-corrected delta, bias columns of J) and the second read
+    // misses L2 (18 % excess fetch traffic in the PMC counters).  Keeping them in registers (keep_h = true: 352 -> 406)
+    // removes that traffic (2.15 -> 1.71 GB read per launch) and makes K1 SLOWER, 0.80 -> 0.855 ms: with one wave per SIMD
+    // the kernel is paced by how early its first compute can start, not by its byte count.  Measured, left off.
+    static constexpr bool keep_h = false;
     double* out_r;      // imu_r row of this factor (+ a * TILE)
     double* slot;       // imu_j: tile base + 2 * slot
     bool jac;
@@ -339,6 +344,7 @@ constexpr int LJS = 310;        // LDS stride of one factor (even: the staging w
 // Fused linearise + assemble (k_linearize_assemble): (r | J) of a factor goes to its row of the workgroup's LDS tile and
 // never to HBM; only the residual (the LM cost, k_decide) is also stored, for the tile's own factors (out_r != nullptr).
 struct LdsSink {
+    static constexpr bool keep_h = false;   // (the fused kernel has no registers to spare)
     double* F;
     double* out_r;
     VF_DI void r(int a, double x) { F[LJ_R + a] = x; if (out_r) __builtin_nontemporal_store(x, out_r + (size_t)a * TILE); }
@@ -363,17 +369,23 @@ __device__ __forceinline__ void linearize_imu_core(const View& v, const int b, c
     const double dt = IN(0);
     const V3 dba = si.ba - v3(IN(10), IN(11), IN(12));
     const V3 dbg = si.bg - v3(IN(13), IN(14), IN(15));
+    double Hb[54];
+    if constexpr (Sink::keep_h) {
+#pragma unroll
+        for (int i = 0; i < 54; i++) Hb[i] = IN(16 + i);
+    }
+#define HB(i) (Sink::keep_h ? Hb[i] : IN(16 + (i)))
     // bias-corrected preintegrated delta: d + H (b_i - bhat)   (biasCorrectedDelta)
     double xt[9];
 #pragma unroll
     for (int r = 0; r < 9; r++) {
         double s = IN(1 + r);
-        s = fma(IN(16 + r * 6 + 0), dba.x, s);
-        s = fma(IN(16 + r * 6 + 1), dba.y, s);
-        s = fma(IN(16 + r * 6 + 2), dba.z, s);
-        s = fma(IN(16 + r * 6 + 3), dbg.x, s);
-        s = fma(IN(16 + r * 6 + 4), dbg.y, s);
-        s = fma(IN(16 + r * 6 + 5), dbg.z, s);
+        s = fma(HB(r * 6 + 0), dba.x, s);
+        s = fma(HB(r * 6 + 1), dba.y, s);
+        s = fma(HB(r * 6 + 2), dba.z, s);
+        s = fma(HB(r * 6 + 3), dbg.x, s);
+        s = fma(HB(r * 6 + 4), dbg.y, s);
+        s = fma(HB(r * 6 + 5), dbg.z, s);
         xt[r] = s;
     }
     const V3 tht = v3(xt[0], xt[1], xt[2]), pt = v3(xt[3], xt[4], xt[5]), vt = v3(xt[6], xt[7], xt[8]);
@@ -474,9 +486,9 @@ __device__ __forceinline__ void linearize_imu_core(const View& v, const int b, c
         double Rc[15];
 #pragma unroll
         for (int a = 0; a < 15; a++) Rc[a] = (a < n_rc) ? IN(70 + off15(a) + (9 + c - a)) : 0.0;
-        const V3 hth = v3(IN(16 + 0 * 6 + c), IN(16 + 1 * 6 + c), IN(16 + 2 * 6 + c));
-        const V3 hp = v3(IN(16 + 3 * 6 + c), IN(16 + 4 * 6 + c), IN(16 + 5 * 6 + c));
-        const V3 hv = v3(IN(16 + 6 * 6 + c), IN(16 + 7 * 6 + c), IN(16 + 8 * 6 + c));
+        const V3 hth = v3(HB(0 * 6 + c), HB(1 * 6 + c), HB(2 * 6 + c));
+        const V3 hp = v3(HB(3 * 6 + c), HB(4 * 6 + c), HB(5 * 6 + c));
+        const V3 hv = v3(HB(6 * 6 + c), HB(7 * 6 + c), HB(8 * 6 + c));
         const V3 u0 = mul(M5, hth), u1 = mul(Rji, hp), u2 = mul(Rji, hv);
         u[0] = u0.x; u[1] = u0.y; u[2] = u0.z; u[3] = u1.x; u[4] = u1.y; u[5] = u1.z; u[6] = u2.x; u[7] = u2.y; u[8] = u2.z;
         white9<0, 9>(R, u, o);
@@ -494,6 +506,7 @@ __device__ __forceinline__ void linearize_imu_core(const View& v, const int b, c
 #pragma unroll
     for (int a = 0; a < 15; a++) OUT(a) = rw[a];
 #undef IN
+#undef HB
 #undef OUT
 #undef JOUT
 }

@@ -90,8 +90,11 @@ def test_graph_manager_reproduces_the_integration_timeline():
     assert list(gm.getMostRecentPoseTime()) == gold["most_recent_pose_time"]
     gm.solve()
     assert gm.graphSize() == 0 and gm.imuQueueSize() == 0          # UnitTests.cpp:385
-    # the four factors integrate between the node times of the fixture (the first one from the first IMU stamp, 0.1 s)
+    # Each factor starts at the previous node's time (the first one at the first IMU stamp, 0.1 s, IMUManager.cpp:76-79) and
+    # ends at the LAST IMU sample that had arrived when its node was reserved: the sample that would be interpolated to the
+    # node time (IMUManager.cpp:57-66) is not in the buffer yet (IMU every 0.05 s, nodes at 0.47 / 0.87 / 1.07 / 1.27).
     t_nodes = [0.1] + [t for _, t in gold["nodes"]]
     for k in range(1, 5):
-        np.testing.assert_allclose(gm.imuFactor(k)[0], t_nodes[k] - t_nodes[k - 1], rtol=1e-12)
+        last_sample = np.floor(t_nodes[k] / 0.05 + 1e-9) * 0.05
+        np.testing.assert_allclose(gm.imuFactor(k)[0], last_sample - t_nodes[k - 1], rtol=1e-9)
     gm.close()

@@ -56,6 +56,21 @@ def test_single_odometry_source(oracle, vio, lidar):
     assert ate <= 1e-6 and rot <= 1e-6
 
 
+def test_config1_900_keyframe_clip_lidar_only(oracle):
+    """BASELINE configs[0] at the size SURVEY 8(d) names: the 30 s Carla-like clip (900 keyframes), IMU + LiDAR between
+    factors only -- the HIP path against the CPU oracle (which is this config's own 'CPU fixed-lag, plumbing' leg)."""
+    n = 900
+    seq = synth.make_sequence(25, n, vio=False, lidar=True)
+    prob = helpers.build_problem(oracle, seq, perturb=0.01)
+    assert prob["btw_a"].size > 250
+    eng, xs, win, costs = _solve_both(oracle, prob, 0, n, iters=10)      # (from 1 cm / 0.01 rad off: both must have converged)
+    ate, rot = helpers.ate(xs, win.states)
+    gt_ate = helpers.ate(xs, seq.gt_states)[0]
+    print(f"C1, 900 keyframes, IMU + LiDAR only: ATE vs oracle {ate:.3e} m, rot {rot:.3e} rad; vs ground truth {gt_ate:.3e} m; "
+          f"oracle cost {costs[0]:.3e} -> {costs[-1]:.3e}")
+    assert ate <= 1e-6 and rot <= 1e-6 and costs[-1] < costs[0]
+
+
 def test_imu_only_and_dropped_between_factors(oracle):
     """No between factor at all (IMU chain + priors), then every third factor dropped
     (what the degeneracy filter does to LOAM odometry)."""

@@ -1,9 +1,9 @@
 """Phase time stamps (s_memtime, shader clock) of ONE workgroup of K3 in the middle of a full batch.
 Needs the diagnostic library of tools/build_stamps.sh.  usage: python tools/k3_stamps_probe.py"""
-import sys, ctypes as C, numpy as np, os
-sys.path.insert(0, '.')
+import sys, os, ctypes as C, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vil_sensor_fusion_amd import _lib
-_lib._SO = os.path.abspath('tools/libvilfusion_stamps.so')
+_lib._SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libvilfusion_stamps.so')
 from vil_sensor_fusion_amd import Engine, EngineOpts, synth
 from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
 B, N = 1024, 1000

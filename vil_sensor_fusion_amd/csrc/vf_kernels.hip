@@ -997,12 +997,15 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     else if (v.sh_G > 1) rhi = hi;
     if (k0 + AT <= rlo || k0 >= rhi) return; // no owned active keyframe in this tile (uniform)
 #ifdef VF_K3_STAGGER
-    // the four workgroups a CU starts with (linear ids c, c + 256, c + 512, c + 768: round robin over 8 XCDs x 32 CUs)
-    // begin a quarter of a tile time apart, so that the load phase of one overlaps the MFMA phase of another
+    // probe: the workgroups a CU starts with begin a fraction of a tile time apart (keyed by the hardware wave slot of the
+    // SIMD they landed on), so that the load phase of one overlaps the MFMA phase of another
     {
         const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
-        if (lin < 1024u)
-            for (unsigned i = 0; i < ((lin >> 8) & 3u) * VF_K3_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+        if (lin < 1024u) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw));      // WAVE_ID within the SIMD
+            for (unsigned i = 0; i < (hw & 3u) * VF_K3_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+        }
     }
 #endif
     K3STAMP(0);

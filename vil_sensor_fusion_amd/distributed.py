@@ -119,7 +119,12 @@ def all_gather_slices(dist, full, per_slice: int, rank: int, world: int, backend
         return
     own = full[rank * per_slice:(rank + 1) * per_slice]
     if backend == "nccl":
-        dist.all_gather_into_tensor(full[:world * per_slice], own)
+        try:
+            dist.all_gather_into_tensor(full[:world * per_slice], own)       # in place (NCCL: sendbuff = recvbuff + rank * count)
+        except (RuntimeError, ValueError):
+            # a torch build that refuses aliased buffers says so while checking its arguments, before anything is
+            # communicated and on every rank alike: fall back to a copy of the rank's own slice
+            dist.all_gather_into_tensor(full[:world * per_slice], own.clone())
         return
     import torch
     parts = [torch.empty(per_slice, dtype=full.dtype) for _ in range(world)]

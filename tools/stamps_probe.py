@@ -1,7 +1,7 @@
 import sys, ctypes as C, numpy as np, os
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vil_sensor_fusion_amd import _lib
-_lib._SO = os.path.abspath('tools/libvilfusion_stamps.so')
+_lib._SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libvilfusion_stamps.so')
 from vil_sensor_fusion_amd import Engine, EngineOpts, synth
 from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
 B = int(sys.argv[1]); N = 1000

@@ -517,10 +517,12 @@ template <bool SH>
 __device__ __forceinline__ void linearize_imu_factor(const View& v, int which, const long gk) {
     if (gk >= v.G) return;
     const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
-    if (k <= v.lo[w] || k >= v.hi[w]) return;
-    if (window_done(v, w)) return;
+    // (the window's scalars are requested together, in front of the first branch: one memory round trip instead of one
+    // per test -- with one wave per SIMD nothing else hides them)
+    const int w_lo = v.lo[w], w_hi = v.hi[w], w_sel = v.sel[w], w_done = v.stop_on ? v.done[w] : 0;
+    if (k <= w_lo || k >= w_hi || w_done) return;
     const bool jac = !SH || !shard_skips_factor(v, w, k);
-    const int b = v.sel[w] ^ which;
+    const int b = w_sel ^ which;
     double* jbuf = v.imu_j + (size_t)b * (size_t)(v.G >> 3) * JT_STRIDE;
     HbmSink sink;
     sink.out_r = v.imu_r + ((size_t)b * (size_t)(v.G >> 6) + (size_t)(gk >> 6)) * IMU_R * TILE + (gk & 63);
@@ -539,13 +541,12 @@ template <bool SH>
 __device__ __forceinline__ void linearize_between_factor(const View& v, int which, const long gk) {
     if (gk >= v.G) return;
     const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
-    const int lo = v.lo[w];
-    if (k <= lo || k >= v.hi[w]) return;
-    if (window_done(v, w)) return;
+    const int lo = v.lo[w], w_hi = v.hi[w], w_sel = v.sel[w], w_done = v.stop_on ? v.done[w] : 0;
+    const int a = v.btw_a[gk];                 // (all five requested together: one round trip)
+    if (k <= lo || k >= w_hi || w_done) return;
     const bool jac = !SH || !shard_skips_factor(v, w, k);
-    const int a = v.btw_a[gk];
     if (a < lo || a >= k) return;
-    const int b = v.sel[w] ^ which;
+    const int b = w_sel ^ which;
     const long ga = (long)w * v.M + a;
 
     const double* __restrict__ in = v.btw_in + (size_t)(gk >> 6) * BTW_IN * TILE + (gk & 63);
@@ -980,11 +981,11 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     // unchanged (k_decide clears `fresh` on reject; accept / init / slide set it): such a tile must cost as little
     // as a launch can -- one flag read, no index arithmetic in front of it (an all-rejected batch used to take 0.73 ms)
     const int w = blockIdx.y;
-    const int fr = v.fresh[w];
-    if (!fr || window_done(v, w)) return;
+    // (the window's scalars requested together, in front of the first test: one memory round trip, not three)
+    const int fr = v.fresh[w], lo = v.lo[w], hi = v.hi[w], w_sel = v.sel[w], w_done = v.stop_on ? v.done[w] : 0;
+    if (!fr || w_done) return;
     const int k0 = blockIdx.x * AT;
     const long gk0 = (long)w * v.M + k0;
-    const int lo = v.lo[w], hi = v.hi[w];
     // warm start (k_linearize_tail): fr = 1 + appended keyframes; only rows near the ends of the window changed --
     // head: the marginal prior / the factors that left with the oldest keyframe reach rows lo .. lo+3;
     // tail: a new factor at slot b touches rows b-3 .. b
@@ -1009,7 +1010,7 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     }
 #endif
     K3STAMP(0);
-    const int b = v.sel[w];
+    const int b = w_sel;
     const size_t tiles = (size_t)(v.G >> 6);
     const double* btw_out = v.btw_out + (size_t)b * tiles * BTW_OUT * TILE;
 

@@ -1500,8 +1500,15 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     commit_row(IC<3>{}, fetch_row(3), row_kind(3), 3);
     WSYNC();
     // ---- one elimination step, phase PH = k & 3 compile-time --------------------------------
+#ifndef VF_K4_PF4
     // `pend`, `pend2` = block rows of keyframes k+4, k+5 (fetched two steps and one step ago); this step fetches k+6.
     auto step = [&](auto ph, int k, HRow& pend, HRow& pend2) {
+#else
+    // `slot` = the block row of keyframe k+4, fetched four steps ago into the register stage of this phase; this step
+    // fetches k+8 into it (four rows in flight, no register rotation: the phase is compile-time)
+    auto step = [&](auto ph, int k, HRow& slot) {
+        HRow& pend = slot;
+#endif
         constexpr int PH = decltype(ph)::value;
         STAMP(0);
         double p[15];
@@ -1558,8 +1565,12 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         // slots), row k+4 is committed to the slot the pivot keyframe frees -- its panel is in registers, the operand and
         // accumulator reads above are ahead of these writes in the LDS queue, and the write-back below goes to other rows.
         commit_row(ph, pend, row_kind(k + 4), k + 4);
+#ifndef VF_K4_PF4
         pend = pend2;
         pend2 = fetch_row(k + 6);              // also in the shadow; two steps of slack for the HBM round trip
+#else
+        slot = fetch_row(k + 8);               // also in the shadow; four steps of slack for the HBM round trip
+#endif
         STAMP(4);
 #pragma unroll
         for (int r = 0; r < 4; r++) { S[tgt_ph[PH][r]] = acc0[r]; S[tgt_ph[PH][4 + r]] = acc1[r]; S[tgt_ph[PH][8 + r]] = acc2[r]; }
@@ -1567,6 +1578,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         STAMP(5);
     };
     {
+#ifndef VF_K4_PF4
         HRow pend = fetch_row(4);
         HRow pend2 = fetch_row(5);
 #pragma unroll 1
@@ -1576,6 +1588,16 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             step(IC<2>{}, k + 2, pend, pend2);
             step(IC<3>{}, k + 3, pend, pend2);
         }
+#else
+        HRow f0 = fetch_row(4), f1 = fetch_row(5), f2 = fetch_row(6), f3 = fetch_row(7);
+#pragma unroll 1
+        for (int k = 0; k < n4; k += 4) {
+            step(IC<0>{}, k, f0);
+            step(IC<1>{}, k + 1, f1);
+            step(IC<2>{}, k + 2, f2);
+            step(IC<3>{}, k + 3, f3);
+        }
+#endif
     }
     }   // forward sweep
     if constexpr (MODE == SOLVE_CHUNK_FWD) {

@@ -1702,6 +1702,114 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         r.x[7].y = 0.0;
         return r;
     };
+#ifdef VF_K4_BSMFMA
+    // Back substitution with ONE matrix-vector product on the critical path.  x = L^-T (y - part - P^T xprev) is rewritten
+    //     x = c - M xprev,   M = L^-T P^T (15 x 15),  c = L^-T (y - part),
+    // and [M | c] = L^-T [P^T | y - part] is formed one step ahead on the matrix cores (four v_mfma_f64_16x16x4, operands from
+    // the panel rows in LDS), so that the recursion delta_{k+1} -> delta_k is 15 v_readlane + fma in three chains instead of
+    // two dependent matrix-vector products (30 broadcasts, two reductions).
+    constexpr int S_M = S_WD;                 // [16][17]: rows of [M | c] (the trailing window is free during this sweep)
+    constexpr int S_YM = S_WD + 16 * 17;      // [16]: y - part, cell 15 = 0
+    const int bw_off = lane < 43 ? S_P + lane * 15 : S_DUMP + 16;
+    const int col = lane < 15 ? lane : 0;
+    const int dl_w = (lane >= 28 && lane < 43) ? S_DL + lane - 28 : S_DUMP + 32 + lane;
+    int oa[4], ob[4];
+    {
+        const int li = lane & 15, lq = lane >> 4;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int kk = 4 * q + lq;
+            oa[q] = (li < 15 && kk < 15) ? S_P + (28 + li) * 15 + kk : S_ZERO;                       // L^-T[li][kk]
+            ob[q] = kk < 15 ? (li < 15 ? S_P + li * 15 + kk : S_YM + kk) : S_ZERO;                     // P[li][kk] | (y - part)[kk]
+        }
+    }
+    const int sm_w = S_M + (lane >> 4) * 17 + (lane & 15);                    // D[r] -> row (lane >> 4) + 4 r, column lane & 15
+    const int sm_r = (lane >= 28 && lane < 43) ? S_M + (lane - 28) * 17 : S_ZERO;   // (16 zeros there)
+    const int ym_w = lane < 15 ? S_YM + lane : S_DUMP + 32 + lane;
+    if (lane == 0) S[S_YM + 15] = 0.0;
+    WSYNC();
+#define CBAR() asm volatile("" ::: "memory")
+    struct Col { double M[15], c; };                 // lanes 28..42: a row of M and of c
+    auto prep = [&](auto ph, int k, PRow& slot, Col& o) {
+        constexpr int PH = decltype(ph)::value;          // = k & 3
+        constexpr int b2 = S_DL + ((PH + 2) & 3) * 15, b3 = S_DL + ((PH + 3) & 3) * 15;
+        STAMP(6);
+        const double keep = (k >= 0 && pivot_real(k)) ? 1.0 : 0.0;   // identity rows: zero panel
+        double row[15];
+#pragma unroll
+        for (int c = 0; c < 7; c++) { row[2 * c] = keep * slot.x[c].x; row[2 * c + 1] = keep * slot.x[c].y; }
+        row[14] = keep * slot.x[7].x;
+        slot = load_panel(k - 4);    // four steps ahead, into the slot just consumed (slot = k & 3: no register rotation)
+#pragma unroll
+        for (int c = 0; c < 15; c++) S[bw_off + c] = row[c];           // all 43 rows: sub-diagonal, y, L^-T
+        CBAR();
+        STAMP(7);
+        double q[12], d[12];
+#pragma unroll
+        for (int a = 0; a < 12; a++) q[a] = S[S_P + (15 + a) * 15 + col];
+#pragma unroll
+        for (int a = 0; a < 6; a++) { d[a] = S[b2 + a]; d[6 + a] = S[b3 + a]; }
+        const double y = S[S_P + 27 * 15 + col];
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 12; a += 3) {
+            t0 = fma(q[a], d[a], t0);
+            t1 = fma(q[a + 1], d[a + 1], t1);
+            t2 = fma(q[a + 2], d[a + 2], t2);
+        }
+        S[ym_w] = y - ((t0 + t1) + t2);
+        CBAR();
+        double av[4], bv[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) { av[qq] = S[oa[qq]]; bv[qq] = S[ob[qq]]; }
+        d4_t D = {0, 0, 0, 0};
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) D = __builtin_amdgcn_mfma_f64_16x16x4f64(av[qq], bv[qq], D, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) S[sm_w + 68 * r] = D[r];
+        CBAR();
+#pragma unroll
+        for (int a = 0; a < 15; a++) o.M[a] = S[sm_r + a];
+        o.c = S[sm_r + 15];
+        CBAR();                      // the next prep overwrites the panel rows and [M | c] in LDS
+        STAMP(8);
+    };
+    auto solve = [&](auto ph, int k, const Col& c_, double& xprev) {
+        constexpr int PH = decltype(ph)::value;
+        STAMP(9);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 15; a += 3) {
+            s0 = fma(c_.M[a], readlane_d(xprev, 28 + a), s0);
+            s1 = fma(c_.M[a + 1], readlane_d(xprev, 29 + a), s1);
+            s2 = fma(c_.M[a + 2], readlane_d(xprev, 30 + a), s2);
+        }
+        const double x = c_.c - ((s0 + s1) + s2);
+        S[(lane >= 28 && lane < 43) ? S_DL + PH * 15 + lane - 28 : dl_w] = x;
+        // (head keyframes of a chunk: only their velocity / bias increments are this sweep's; the pose part is the separator's)
+        if (lane >= 28 && lane < 43 && pivot_real(k) && !(CH && cg.i0 > 0 && k < 2 && lane < 34)) dbase[(size_t)kf_of(k) * 15 + lane - 28] = x;
+        xprev = x;
+        STAMP(10);
+    };
+    {
+        PRow p3 = load_panel(n4 - 1), p2 = load_panel(n4 - 2), p1 = load_panel(n4 - 3), p0 = load_panel(n4 - 4);
+        // increment of the keyframe after the last pivot (slot n4 & 3 = 0): zero, or the separator's / the middle system's
+        double xprev = S[(lane >= 28 && lane < 43) ? S_DL + lane - 28 : S_ZERO];
+        Col ca, cb;
+        prep(IC<3>{}, n4 - 1, p3, ca);
+#pragma unroll 1
+        for (int k = n4 - 1; k >= 3; k -= 4) {
+            prep(IC<2>{}, k - 1, p2, cb);
+            solve(IC<3>{}, k, ca, xprev);
+            prep(IC<1>{}, k - 2, p1, ca);
+            solve(IC<2>{}, k - 1, cb, xprev);
+            prep(IC<0>{}, k - 3, p0, cb);
+            solve(IC<1>{}, k - 2, ca, xprev);
+            prep(IC<3>{}, k - 4, p3, ca);
+            solve(IC<0>{}, k - 3, cb, xprev);
+        }
+    }
+#else
     const int bw_off = lane < 28 ? S_P + lane * 15 : S_DUMP + 16;
     const int col = lane < 15 ? lane : 0;
     const int dl_w = (lane >= 28 && lane < 43) ? S_DL + lane - 28 : S_DUMP + 32 + lane;
@@ -1792,6 +1900,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             solve(IC<0>{}, k - 3, cb, xprev);
         }
     }
+#endif
 #undef CBAR
 #ifdef VF_SOLVE_STAMPS
     if (w == 0 && lane == 0) for (int i = 0; i < 16; i++) g_stamps[i] = st[i];

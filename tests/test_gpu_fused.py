@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 @contextlib.contextmanager
 def fused(on):
     old = os.environ.get("VF_FUSED")
-    os.environ["VF_FUSED"] = "1" if on else "0"
+    os.environ["VF_FUSED"] = str(int(on))          # 0: K1 -> K3; 1: K1 into LDS + MFMA tiles; 2: lane per factor (k_lin_asm_v)
     try:
         yield
     finally:
@@ -87,13 +87,14 @@ def _same_normal(a, b, ranges, what, refresh_b=True):
                     assert np.array_equal(Ha[k, d], Hb[k, d]), (what, w, k, d)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("marginalize", [True, False])
-def test_fused_equals_unfused(marginalize):
+def test_fused_equals_unfused(marginalize, mode):
     """Cold solve, then fixed-lag updates (slide + warm solve), on ragged windows whose ends fall on every position of
     the 8-keyframe tiles: bit-identical states, LM bookkeeping, H and g."""
     n_total = 128
     ranges = [(0, 90), (3, 77), (8, 96), (13, 64), (0, 21)]
-    f, u = _engine(n_total, ranges, True), _engine(n_total, ranges, False)
+    f, u = _engine(n_total, ranges, mode), _engine(n_total, ranges, False)
     for e in (f, u):
         e.iterate(5)
     _same(f, u, ranges, "cold")
@@ -115,10 +116,11 @@ def test_fused_equals_unfused(marginalize):
     f.close(); u.close()
 
 
-def test_fused_warm_start_equals_cold_start():
+@pytest.mark.parametrize("mode", [1, 2])
+def test_fused_warm_start_equals_cold_start(mode):
     n_total = 100
     ranges = [(0, 70), (5, 61)]
-    warm, cold = _engine(n_total, ranges, True), _engine(n_total, ranges, True)
+    warm, cold = _engine(n_total, ranges, mode), _engine(n_total, ranges, mode)
     for e in (warm, cold):
         e.iterate(4)
     for s in range(9):
@@ -156,12 +158,13 @@ def test_fused_convergence_exit_and_stage_calls():
     f.close(); u.close()
 
 
-def test_large_batch_runs_fused_and_matches_the_oracle(oracle):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_large_batch_runs_fused_and_matches_the_oracle(oracle, mode):
     """160 windows, fused: LM trajectories of a few of them against the oracle, and the fused stage timer exists only
     on fused engines."""
     from vil_sensor_fusion_amd._lib import VilFusionError
     n, B = 150, 160
-    with fused(True):
+    with fused(mode):
         eng = Engine(EngineOpts(windows=B, capacity=n + 10))
     picks = {0: (0, n), 77: (3, 131), 159: (17, n), 80: (0, 40)}
     probs = {}

@@ -223,7 +223,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     // nothing to hide the chain behind (DESIGN.md "K1 + K3 fused").  VF_FUSED=1 switches it on for whole-window-sweep
     // engines (A/B measurements, tests).
     v.fused = 0;
-    if (const char* f = getenv("VF_FUSED")) v.fused = (atoi(f) != 0 && v.P == 0) ? 1 : 0;
+    if (const char* f = getenv("VF_FUSED")) v.fused = (atoi(f) != 0 && v.P == 0) ? (atoi(f) == 2 ? 2 : 1) : 0;   // 2: lane per factor (k_lin_asm_v)
     const size_t hb = v.fused ? 2 : 1;
     AL(v.H, hb * G * vf::HROW);
     AL(v.gvec, hb * G * 15 + 64); // + slack: the solver's row fetch reads 64 lanes of a 15-double row (the excess is never used)

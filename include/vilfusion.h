@@ -112,8 +112,8 @@ int vf_engine_decide(vf_engine* e, int init);
  * decide} per trial).  Replaces ISAM2::update + calculateEstimate (GraphManager.cpp:126-127).
  * With VF_FUSED=1 in the environment at vf_engine_create, whole-window-sweep engines run the IMU linearisation and the
  * assembly as ONE kernel here (the whitened Jacobians stay in LDS, the trial's normal equations are written beside the
- * current ones; bit-identical results, measured slower: DESIGN.md "K1 + K3 fused"); the stage calls above keep their
- * unfused meaning on every engine.
+ * current ones; results equal to rounding, measured slower: DESIGN.md "K1 + K3 fused"); VF_FUSED=2 selects the lane-per-factor
+ * form of that kernel (no Jacobian at all; also slower).  The stage calls above keep their unfused meaning on every engine.
  * Warm start: when nothing but vf_engine_slide has touched the engine since the previous
  * vf_engine_iterate, the opening linearisation covers only the appended keyframes' factors and
  * the priors, and the first assembly only the ends of windows whose last trial was rejected --
@@ -216,7 +216,7 @@ int vf_engine_read_lm(vf_engine* e, int window, double* cost, double* lambda, in
 #define VF_STAGE_RETRACT 5
 #define VF_STAGE_DECIDE 6
 #define VF_STAGE_ASSEMBLE_IDLE 7   /* K3 when every window's last trial was rejected: nothing to assemble, the cost of its launch */
-#define VF_STAGE_LINEARIZE_ASSEMBLE 8 /* K1 + K3 fused (engines created with VF_FUSED=1 in the environment; off by default: slower) */
+#define VF_STAGE_LINEARIZE_ASSEMBLE 8 /* K1 + K3 fused (engines created with VF_FUSED=1 or 2 in the environment; off by default: slower) */
 int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms);
 /* HIP-event time of a whole vf_engine_iterate(iterations) */
 int vf_engine_time_iterate(vf_engine* e, int iterations, float* ms);

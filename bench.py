@@ -80,7 +80,9 @@ def make_sequences(args, rank, count, n_kf, base_seed=0):
     """`count` synthetic sequences with distinct seeds (one seed per window), generated on the host
     cores by forked workers -- called BEFORE the process touches the GPU."""
     jobs = [(base_seed + 100003 * rank + s, n_kf) for s in range(count)]
-    nproc = min(len(jobs), args.host_workers or host_workers(), 32)
+    # (the ranks of one node share its cores: each takes its share, so that N ranks do not fork N x all-cores workers)
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    nproc = min(len(jobs), args.host_workers or max(1, host_workers() // local_world), 32)
     if nproc <= 1:
         return [_make_seq(j) for j in jobs]
     with multiprocessing.get_context("fork").Pool(nproc) as pool:

@@ -1084,15 +1084,14 @@ int vf_engine_read_panels(vf_engine* e, int window, int k0, int n, double* panel
     if (rc) return rc;
     if (n == 0 || !panels) return VF_OK;
     HIPCHK(hipStreamSynchronize(e->stream));
-    // device layout [7 column pairs][43 rows][2] + column 14 [43] -> the documented [43][16] (column 15 = 0)
+    // packed device layout (vf_kernels.hpp "Cholesky panel") -> the documented [43][16] (column 15 = 0)
     std::vector<double> raw((size_t)n * vf::PANEL);
     HIPCHK(hipMemcpy(raw.data(), e->v.Lp + ((size_t)window * e->v.M + k0) * vf::PANEL, raw.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int k = 0; k < n; k++)
         for (int r = 0; r < 43; r++)
             for (int c = 0; c < 16; c++) {
                 double x = 0.0;
-                if (c < 14) x = raw[(size_t)k * vf::PANEL + ((size_t)(c >> 1) * 43 + r) * 2 + (c & 1)];
-                else if (c == 14) x = raw[(size_t)k * vf::PANEL + 7 * 43 * 2 + r];
+                if (c < 15) { const int i = vf::panel_idx(r, c); x = i == vf::PANEL_DUMP ? 0.0 : raw[(size_t)k * vf::PANEL + i]; }
                 panels[(size_t)k * 688 + r * 16 + c] = x;
             }
     return VF_OK;

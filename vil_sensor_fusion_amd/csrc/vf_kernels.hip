@@ -1680,14 +1680,18 @@ VF_DI double readlane_d(double x, int lane) {
 // stall every step on the in-flight HBM prefetch); a compiler barrier (+ lgkmcnt(0) where a value is used) is enough.
 // Sequential in k: latency-bound for one window, HBM-bound (5 TB/s) under a full batch; see DESIGN.md "K4".
 constexpr int LDW = 61;
-// Panel of one keyframe in HBM: 7 column pairs [pair][43 rows][2] doubles, then column 14 alone [43 rows].  Lane = row,
-// so one 16-byte store / load instruction of the sweeps covers 43 x 16 contiguous bytes (6 lines) -- with a row per
-// 128-B line every instruction touched 43 different lines, 16 bytes of each.  (K4 moves its 17 GB per solve at 5.3 TB/s
-// under a full batch: the padding column a 16-double row carried was 6 % of the panel bytes.)
-constexpr int PROWS = 43;
-constexpr int PLAST = 7 * PROWS * 2;     // offset of column 14
-static_assert(PLAST + PROWS <= PANEL && PANEL % 2 == 0, "panel layout");
-VF_DI size_t panel_idx(int row, int col) { return col < 14 ? ((size_t)(col >> 1) * PROWS + row) * 2 + (col & 1) : (size_t)PLAST + row; }
+// Panel of one keyframe in HBM (vf_kernels.hpp "Cholesky panel"): column pairs, lane = row, so one 16-byte store / load
+// instruction of the sweeps covers up to 43 x 16 contiguous bytes -- with a row per 128-B line every instruction touched 43
+// different lines, 16 bytes of each.  The offset of a lane's entry of pair c is a per-lane constant (its place in the pair,
+// or the keyframe's zero cell where the entry is a structural zero of L^-T): no predicate in either sweep.
+// a wave-uniform pointer into global memory, told to the compiler as such (SGPR base + per-lane 32-bit offset addressing)
+#define VF_GLOBAL __attribute__((address_space(1)))
+template <class T> VF_DI VF_GLOBAL char* uniform_gptr(T* p) {
+    const unsigned long long x = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
+    return (VF_GLOBAL char*)(((unsigned long long)hi << 32) | lo);
+}
+VF_DI int panel_pair_off(int row, int c) { return (row < panel_rows(c) ? panel_off(c) + 2 * row : PANEL_DUMP) * (int)sizeof(double); }
 constexpr int S_WD = 0;                  // LDS map (doubles)
 constexpr int S_GD = 60 * LDW;           // 3660: rhs, circular
 constexpr int S_DUMP = S_GD + 64;        // write sink for masked-off lanes (never read)
@@ -1951,6 +1955,11 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         S[lane < 15 ? S_GD + s + lane : S_DUMP + 32 + lane] = -r.hg;
     };
     const int n4 = cnt;   // pivots of this sweep; identity rows beyond the real ones are eliminated harmlessly
+    // byte offsets of this lane's panel entries within a keyframe's panel (forward sweep: lane 15 + r holds row r)
+    unsigned pp_off[8];
+#pragma unroll
+    for (int c = 0; c < 7; c++) pp_off[c] = (unsigned)panel_pair_off(lane >= 15 && lane < 58 ? lane - 15 : 0, c);
+    pp_off[7] = (unsigned)((PANEL_LAST + (lane >= 15 && lane < 58 ? lane - 15 : 0)) * sizeof(double));
 #ifdef VF_SOLVE_STAMPS
     unsigned long long st[16] = {0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
@@ -1992,15 +2001,10 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #pragma unroll
         for (int c = 0; c < 15; c++) S[pw_off + PH * RSLOT + c] = p[c];
         if (lane >= 15 && lane < 58 && pivot_real(k)) {
-            d2_t* Lk = (d2_t*)(Lbase + (size_t)kf_of(k) * PANEL) + (lane - 15);   // chunk c of this row: Lk[c * PROWS]
+            VF_GLOBAL char* Lk = uniform_gptr(Lbase + (size_t)kf_of(k) * PANEL);     // (the lane's place in each pair: pp_off)
 #pragma unroll
-#ifdef VF_K4_NT
-            for (int c = 0; c < 7; c++) { d2_t t; t.x = p[2 * c]; t.y = p[2 * c + 1]; __builtin_nontemporal_store(t, Lk + c * PROWS); }
-            __builtin_nontemporal_store(p[14], Lbase + (size_t)kf_of(k) * PANEL + PLAST + (lane - 15));
-#else
-            for (int c = 0; c < 7; c++) { d2_t t; t.x = p[2 * c]; t.y = p[2 * c + 1]; Lk[c * PROWS] = t; }
-            Lbase[(size_t)kf_of(k) * PANEL + PLAST + (lane - 15)] = p[14];
-#endif
+            for (int c = 0; c < 7; c++) { d2_t t; t.x = p[2 * c]; t.y = p[2 * c + 1]; *(VF_GLOBAL d2_t*)(Lk + pp_off[c]) = t; }
+            *(VF_GLOBAL double*)(Lk + pp_off[7]) = p[14];
         }
         WSYNC();
         if constexpr (RINGM) { if (lane == 0) S[S_PROG] = (double)(k + 1); }   // panel k is complete in its ring slot
@@ -2153,13 +2157,18 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         WSYNC();
     }
     struct PRow { d2_t x[8]; };
+    // (backward sweep: lane r < 43 holds row r)
+    unsigned pb_off[8];
+#pragma unroll
+    for (int c = 0; c < 7; c++) pb_off[c] = (unsigned)panel_pair_off(lane < 43 ? lane : 0, c);
+    pb_off[7] = (unsigned)((PANEL_LAST + (lane < 43 ? lane : 0)) * sizeof(double));
     auto load_panel = [=](int k) {   // not a real pivot: any valid panel is loaded and zeroed at use (no use here: no stall)
         PRow r;
         const bool ok = k >= 0 && k < cnt && pivot_real(k);
-        const d2_t* Lk = (const d2_t*)(Lbase + (size_t)(ok ? kf_of(k) : 0) * PANEL) + (lane < 43 ? lane : 0);
+        const VF_GLOBAL char* Lk = uniform_gptr(Lbase + (size_t)(ok ? kf_of(k) : 0) * PANEL);
 #pragma unroll
-        for (int c = 0; c < 7; c++) r.x[c] = Lk[c * PROWS];
-        r.x[7].x = Lbase[(size_t)(ok ? kf_of(k) : 0) * PANEL + PLAST + (lane < 43 ? lane : 0)];
+        for (int c = 0; c < 7; c++) r.x[c] = *(const VF_GLOBAL d2_t*)(Lk + pb_off[c]);
+        r.x[7].x = *(const VF_GLOBAL double*)(Lk + pb_off[7]);
         r.x[7].y = 0.0;
         return r;
     };

@@ -34,7 +34,21 @@ constexpr int PRIOR_OUT = 240;  // r(15), J(15x15)
 constexpr int HROW = 512;
 constexpr int H_D1 = 0, H_D0 = 225, H_D2 = 345, H_D3 = 381, H_DX = 432;
 __host__ __device__ constexpr int h_tri(int a, int c) { return a * (a + 1) / 2 + c; }
-constexpr int PANEL = 646;      // Cholesky panel in HBM: 43 rows (27 sub-diagonal, rhs, 15 of L^-T) x 15 columns = 645 doubles, stored [7 column pairs][43][2] + [43] (+1: 16-byte alignment)
+// Cholesky panel of one keyframe in HBM: 43 rows (27 sub-diagonal rows, the rhs row, 15 rows of L^-T) x 15 columns, stored
+// by column PAIRS [pair c][rows_c][2] + column 14 alone [43].  Row r' of L^-T (panel row 28 + r') is zero in front of its
+// diagonal, so pair c (columns 2c, 2c+1) keeps only the rows 0 .. 29 + 2c: 547 doubles instead of 645.  A lane whose entry of
+// a pair is such a structural zero stores it to / loads it from the 16-byte cell PANEL_DUMP of the same keyframe (only
+// zeros are ever written there), so neither sweep needs a predicate.
+__host__ __device__ constexpr int panel_rows(int c) { return 30 + 2 * c; }              // rows kept by column pair c < 7
+__host__ __device__ constexpr int panel_off(int c) { return 58 * c + 2 * c * c; }       // its first double; c = 7: column 14
+constexpr int PANEL_LAST = panel_off(7);     // 504: column 14, [43]
+constexpr int PANEL_DUMP = 548;              // the zero cell (2 doubles)
+constexpr int PANEL = 550;
+static_assert(PANEL_LAST + 43 <= PANEL_DUMP && PANEL_DUMP % 2 == 0 && PANEL % 2 == 0, "panel layout");
+// index of entry (row, col) of a keyframe's panel; structural zeros map to the zero cell
+__host__ __device__ constexpr int panel_idx(int row, int col) {
+    return col >= 14 ? PANEL_LAST + row : (row < panel_rows(col >> 1) ? panel_off(col >> 1) + 2 * row + (col & 1) : PANEL_DUMP);
+}
 constexpr int SEP = 27;
 constexpr int SEPM = SEP * 28;  // 27x27 block + right-hand side column
 // separator blocks of one (chunk, window): [sepR 27x28 | sepS 27x28 | sepC 27x27] packed in one slot (2241 doubles, padded

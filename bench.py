@@ -499,9 +499,10 @@ def main():
                                            "frac": alg_bytes / (pk["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         # the kernel that takes most of a step: K4 (banded Cholesky solve), HBM-bound under a full batch.  Algorithmic
         # bytes per keyframe: the band of H it needs (H[k][k-1]: 225, lower triangle of H[k][k]: 120, two 6x6 strips:
-        # 432 doubles) + g + the panel written by the forward sweep and read back by the backward one (645 doubles
-        # each way) + the increment.
-        k4_bytes_per_kf = 8 * (432 + 15 + 645 + 645 + 15)
+        # 432 doubles) + g + the panel written by the forward sweep and read back by the backward one (547 doubles
+        # each way: 27 sub-diagonal rows + the rhs row x 15, and the 120 + 7 entries of L^-T its column pairs keep) + the
+        # increment.
+        k4_bytes_per_kf = 8 * (432 + 15 + 547 + 547 + 15)
         n_kf = args.windows * args.window
         k4_ach = n_kf * k4_bytes_per_kf / (stages["solve"] * 1e-3) / 1e9
         out["roofline_solve"] = {"kernel": "k_band_solve (K4: damped block-banded Cholesky factorisation + both substitutions)",
@@ -511,8 +512,8 @@ def main():
                                  "irreducible_io_bytes_per_keyframe": 8 * (432 + 15 + 15),
                                  "algorithmic_bytes_per_launch": n_kf * k4_bytes_per_kf,
                                  "frac_of_measured_copy_peak_6290": k4_ach / 6290.0,
-                                 "note": "10.3 of the 14.0 KB per keyframe are the Cholesky panel written by the forward sweep and "
-                                         "read back by the backward one; against H + g + delta alone (3.7 KB) the kernel moves 3.8x",
+                                 "note": "8.8 of the 12.4 KB per keyframe are the Cholesky panel written by the forward sweep and "
+                                         "read back by the backward one; against H + g + delta alone (3.7 KB) the kernel moves 3.4x",
                                  "traffic_note": "profiles/*_pmc_summary.md: k_band_solve read 2*FETCH_SIZE + WRITE_SIZE per launch"}
         if prof is not None:
             out["profiled_kernels"] = prof

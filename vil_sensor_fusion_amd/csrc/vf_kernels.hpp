@@ -44,7 +44,7 @@ __host__ __device__ constexpr int panel_off(int c) { return 58 * c + 2 * c * c; 
 constexpr int PANEL_LAST = panel_off(7);     // 504: column 14, [43]
 constexpr int PANEL_DUMP = 548;              // the zero cell (2 doubles)
 constexpr int PANEL = 550;
-static_assert(PANEL_LAST + 43 <= PANEL_DUMP && PANEL_DUMP % 2 == 0 && PANEL % 2 == 0, "panel layout");
+static_assert(PANEL_LAST + 43 <= PANEL_DUMP && PANEL_DUMP % 2 == 0 && PANEL_DUMP + 2 <= PANEL && PANEL % 2 == 0, "panel layout");
 // index of entry (row, col) of a keyframe's panel; structural zeros map to the zero cell
 __host__ __device__ constexpr int panel_idx(int row, int col) {
     return col >= 14 ? PANEL_LAST + row : (row < panel_rows(col >> 1) ? panel_off(col >> 1) + 2 * row + (col & 1) : PANEL_DUMP);

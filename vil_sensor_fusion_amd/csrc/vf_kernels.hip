@@ -998,18 +998,6 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     if (v.sh_G > 1 && rhi + 2 <= hi) rhi += 2;   // tail rows of the rank's last chunk (see shard_skips_factor)
     else if (v.sh_G > 1) rhi = hi;
     if (k0 + AT <= rlo || k0 >= rhi) return; // no owned active keyframe in this tile (uniform)
-#ifdef VF_K3_STAGGER
-    // probe: the workgroups a CU starts with begin a fraction of a tile time apart (keyed by the hardware wave slot of the
-    // SIMD they landed on), so that the load phase of one overlaps the MFMA phase of another
-    {
-        const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
-        if (lin < 1024u) {
-            unsigned hw;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw));      // WAVE_ID within the SIMD
-            for (unsigned i = 0; i < (hw & 3u) * VF_K3_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
-        }
-    }
-#endif
     K3STAMP(0);
     const int b = w_sel;
     const size_t tiles = (size_t)(v.G >> 6);
@@ -1083,10 +1071,6 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     __syncthreads();
     K3STAMP(3);   // everybody's
 
-#ifdef VF_K3_STAGE_ONLY      // probe build: what the staging alone costs (one word out so that it is not optimised away)
-    if (LJ[tid] + LB[tid] == 1.2345e300) v.gvec[gk0] = 1.0;
-    return;
-#endif
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave-uniform: the keyframe loop and its tests stay scalar
     assemble_tile<K3_KPW>(v, LJ, LB, s_a, w, b, h_buf(v, w), k0, gk0, lo, hi, rlo, rhi, wv, lane);
     K3STAMP(4);       // wave 0: MFMAs done, stores issued
@@ -1146,10 +1130,7 @@ __global__ void __launch_bounds__(64) k_linearize_assemble(View v, int which, in
         if (ks > lo && ks < hi) { a_src = v.btw_a[gk0 + lane]; if (a_src < lo || a_src >= ks) a_src = -1; }
     }
     // the structural zeros of J (and the rows of factors outside the window) must read as zeros
-#ifndef VF_FUSED_NO_ZERO
     for (int e = lane; e < (FA + 1) * LJS; e += 64) LJ[e] = 0.0;
-#endif
-#ifndef VF_FUSED_NO_A       // (probe builds: phases compiled out to see what each costs)
     if (lane <= FA) {
         const int k = k0 + lane;
         if (k > lo && k < hi) {
@@ -1159,7 +1140,6 @@ __global__ void __launch_bounds__(64) k_linearize_assemble(View v, int which, in
             linearize_imu_core(v, b, gk, sink);
         }
     }
-#endif
     if (lane < FA + 3) {
         LB[lane * LBS + BTW_OUT] = 0.0;       // the pad cell of a slot: the zero the MFMA operand maps point at
         s_a[lane] = a_src;
@@ -1170,9 +1150,7 @@ __global__ void __launch_bounds__(64) k_linearize_assemble(View v, int which, in
         if (e < (FA + 3) * BTW_OUT) { const int sl = e / BTW_OUT; LB[sl * LBS + (e - sl * BTW_OUT)] = tb[j]; }
     }
     __syncthreads();
-#ifndef VF_FUSED_NO_B
     assemble_tile<FA>(v, LJ, LB, s_a, w, b, b, k0, gk0, lo, hi, lo, hi, 0, lane);
-#endif
 }
 // ------------------------------------------------------------------------------------ K1 + K3 fused, lane per factor
 // k_lin_asm_v (opt-in, VF_FUSED=2): no Jacobian anywhere.  Lane = IMU factor k (keyframes i = k-1, j = k); with A the
@@ -1970,15 +1948,8 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     commit_row(IC<3>{}, fetch_row(3), row_kind(3), 3);
     WSYNC();
     // ---- one elimination step, phase PH = k & 3 compile-time --------------------------------
-#ifndef VF_K4_PF4
     // `pend`, `pend2` = block rows of keyframes k+4, k+5 (fetched two steps and one step ago); this step fetches k+6.
     auto step = [&](auto ph, int k, HRow& pend, HRow& pend2) {
-#else
-    // `slot` = the block row of keyframe k+4, fetched four steps ago into the register stage of this phase; this step
-    // fetches k+8 into it (four rows in flight, no register rotation: the phase is compile-time)
-    auto step = [&](auto ph, int k, HRow& slot) {
-        HRow& pend = slot;
-#endif
         constexpr int PH = decltype(ph)::value;
         STAMP(0);
         double p[15];
@@ -2030,12 +2001,8 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         // slots), row k+4 is committed to the slot the pivot keyframe frees -- its panel is in registers, the operand and
         // accumulator reads above are ahead of these writes in the LDS queue, and the write-back below goes to other rows.
         commit_row(ph, pend, row_kind(k + 4), k + 4);
-#ifndef VF_K4_PF4
         pend = pend2;
         pend2 = fetch_row(k + 6);              // also in the shadow; two steps of slack for the HBM round trip
-#else
-        slot = fetch_row(k + 8);               // also in the shadow; four steps of slack for the HBM round trip
-#endif
         STAMP(4);
 #pragma unroll
         for (int r = 0; r < 4; r++) { S[tgt_ph[PH][r]] = acc0[r]; S[tgt_ph[PH][4 + r]] = acc1[r]; S[tgt_ph[PH][8 + r]] = acc2[r]; }
@@ -2043,7 +2010,6 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         STAMP(5);
     };
     {
-#ifndef VF_K4_PF4
         HRow pend = fetch_row(4);
         HRow pend2 = fetch_row(5);
 #pragma unroll 1
@@ -2053,16 +2019,6 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             step(IC<2>{}, k + 2, pend, pend2);
             step(IC<3>{}, k + 3, pend, pend2);
         }
-#else
-        HRow f0 = fetch_row(4), f1 = fetch_row(5), f2 = fetch_row(6), f3 = fetch_row(7);
-#pragma unroll 1
-        for (int k = 0; k < n4; k += 4) {
-            step(IC<0>{}, k, f0);
-            step(IC<1>{}, k + 1, f1);
-            step(IC<2>{}, k + 2, f2);
-            step(IC<3>{}, k + 3, f3);
-        }
-#endif
     }
     }   // forward sweep
     if constexpr (MODE == SOLVE_CHUNK_FWD) {
@@ -2172,114 +2128,6 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         r.x[7].y = 0.0;
         return r;
     };
-#ifdef VF_K4_BSMFMA
-    // Back substitution with ONE matrix-vector product on the critical path.  x = L^-T (y - part - P^T xprev) is rewritten
-    //     x = c - M xprev,   M = L^-T P^T (15 x 15),  c = L^-T (y - part),
-    // and [M | c] = L^-T [P^T | y - part] is formed one step ahead on the matrix cores (four v_mfma_f64_16x16x4, operands from
-    // the panel rows in LDS), so that the recursion delta_{k+1} -> delta_k is 15 v_readlane + fma in three chains instead of
-    // two dependent matrix-vector products (30 broadcasts, two reductions).
-    constexpr int S_M = S_WD;                 // [16][17]: rows of [M | c] (the trailing window is free during this sweep)
-    constexpr int S_YM = S_WD + 16 * 17;      // [16]: y - part, cell 15 = 0
-    const int bw_off = lane < 43 ? S_P + lane * 15 : S_DUMP + 16;
-    const int col = lane < 15 ? lane : 0;
-    const int dl_w = (lane >= 28 && lane < 43) ? S_DL + lane - 28 : S_DUMP + 32 + lane;
-    int oa[4], ob[4];
-    {
-        const int li = lane & 15, lq = lane >> 4;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int kk = 4 * q + lq;
-            oa[q] = (li < 15 && kk < 15) ? S_P + (28 + li) * 15 + kk : S_ZERO;                       // L^-T[li][kk]
-            ob[q] = kk < 15 ? (li < 15 ? S_P + li * 15 + kk : S_YM + kk) : S_ZERO;                     // P[li][kk] | (y - part)[kk]
-        }
-    }
-    const int sm_w = S_M + (lane >> 4) * 17 + (lane & 15);                    // D[r] -> row (lane >> 4) + 4 r, column lane & 15
-    const int sm_r = (lane >= 28 && lane < 43) ? S_M + (lane - 28) * 17 : S_ZERO;   // (16 zeros there)
-    const int ym_w = lane < 15 ? S_YM + lane : S_DUMP + 32 + lane;
-    if (lane == 0) S[S_YM + 15] = 0.0;
-    WSYNC();
-#define CBAR() asm volatile("" ::: "memory")
-    struct Col { double M[15], c; };                 // lanes 28..42: a row of M and of c
-    auto prep = [&](auto ph, int k, PRow& slot, Col& o) {
-        constexpr int PH = decltype(ph)::value;          // = k & 3
-        constexpr int b2 = S_DL + ((PH + 2) & 3) * 15, b3 = S_DL + ((PH + 3) & 3) * 15;
-        STAMP(6);
-        const double keep = (k >= 0 && pivot_real(k)) ? 1.0 : 0.0;   // identity rows: zero panel
-        double row[15];
-#pragma unroll
-        for (int c = 0; c < 7; c++) { row[2 * c] = keep * slot.x[c].x; row[2 * c + 1] = keep * slot.x[c].y; }
-        row[14] = keep * slot.x[7].x;
-        slot = load_panel(k - 4);    // four steps ahead, into the slot just consumed (slot = k & 3: no register rotation)
-#pragma unroll
-        for (int c = 0; c < 15; c++) S[bw_off + c] = row[c];           // all 43 rows: sub-diagonal, y, L^-T
-        CBAR();
-        STAMP(7);
-        double q[12], d[12];
-#pragma unroll
-        for (int a = 0; a < 12; a++) q[a] = S[S_P + (15 + a) * 15 + col];
-#pragma unroll
-        for (int a = 0; a < 6; a++) { d[a] = S[b2 + a]; d[6 + a] = S[b3 + a]; }
-        const double y = S[S_P + 27 * 15 + col];
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-#pragma unroll
-        for (int a = 0; a < 12; a += 3) {
-            t0 = fma(q[a], d[a], t0);
-            t1 = fma(q[a + 1], d[a + 1], t1);
-            t2 = fma(q[a + 2], d[a + 2], t2);
-        }
-        S[ym_w] = y - ((t0 + t1) + t2);
-        CBAR();
-        double av[4], bv[4];
-#pragma unroll
-        for (int qq = 0; qq < 4; qq++) { av[qq] = S[oa[qq]]; bv[qq] = S[ob[qq]]; }
-        d4_t D = {0, 0, 0, 0};
-#pragma unroll
-        for (int qq = 0; qq < 4; qq++) D = __builtin_amdgcn_mfma_f64_16x16x4f64(av[qq], bv[qq], D, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; r++) S[sm_w + 68 * r] = D[r];
-        CBAR();
-#pragma unroll
-        for (int a = 0; a < 15; a++) o.M[a] = S[sm_r + a];
-        o.c = S[sm_r + 15];
-        CBAR();                      // the next prep overwrites the panel rows and [M | c] in LDS
-        STAMP(8);
-    };
-    auto solve = [&](auto ph, int k, const Col& c_, double& xprev) {
-        constexpr int PH = decltype(ph)::value;
-        STAMP(9);
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int a = 0; a < 15; a += 3) {
-            s0 = fma(c_.M[a], readlane_d(xprev, 28 + a), s0);
-            s1 = fma(c_.M[a + 1], readlane_d(xprev, 29 + a), s1);
-            s2 = fma(c_.M[a + 2], readlane_d(xprev, 30 + a), s2);
-        }
-        const double x = c_.c - ((s0 + s1) + s2);
-        S[(lane >= 28 && lane < 43) ? S_DL + PH * 15 + lane - 28 : dl_w] = x;
-        // (head keyframes of a chunk: only their velocity / bias increments are this sweep's; the pose part is the separator's)
-        if (lane >= 28 && lane < 43 && pivot_real(k) && !(CH && cg.i0 > 0 && k < 2 && lane < 34)) dbase[(size_t)kf_of(k) * 15 + lane - 28] = x;
-        xprev = x;
-        STAMP(10);
-    };
-    {
-        PRow p3 = load_panel(n4 - 1), p2 = load_panel(n4 - 2), p1 = load_panel(n4 - 3), p0 = load_panel(n4 - 4);
-        // increment of the keyframe after the last pivot (slot n4 & 3 = 0): zero, or the separator's / the middle system's
-        double xprev = S[(lane >= 28 && lane < 43) ? S_DL + lane - 28 : S_ZERO];
-        Col ca, cb;
-        prep(IC<3>{}, n4 - 1, p3, ca);
-#pragma unroll 1
-        for (int k = n4 - 1; k >= 3; k -= 4) {
-            prep(IC<2>{}, k - 1, p2, cb);
-            solve(IC<3>{}, k, ca, xprev);
-            prep(IC<1>{}, k - 2, p1, ca);
-            solve(IC<2>{}, k - 1, cb, xprev);
-            prep(IC<0>{}, k - 3, p0, cb);
-            solve(IC<1>{}, k - 2, ca, xprev);
-            prep(IC<3>{}, k - 4, p3, ca);
-            solve(IC<0>{}, k - 3, cb, xprev);
-        }
-    }
-#else
     const int bw_off = lane < 28 ? S_P + lane * 15 : S_DUMP + 16;
     const int col = lane < 15 ? lane : 0;
     const int dl_w = (lane >= 28 && lane < 43) ? S_DL + lane - 28 : S_DUMP + 32 + lane;
@@ -2370,7 +2218,6 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             solve(IC<0>{}, k - 3, cb, xprev);
         }
     }
-#endif
 #undef CBAR
 #ifdef VF_SOLVE_STAMPS
     if (w == 0 && lane == 0) for (int i = 0; i < 16; i++) g_stamps[i] = st[i];

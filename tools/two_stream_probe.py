@@ -1,33 +1,46 @@
-"""Does splitting the batch over G engines (one HIP stream each) help?  K4 is latency-bound per window and leaves HBM
-bandwidth idle, K1 / K3 are bandwidth-bound: kernels of different engines can overlap.  usage: two_stream_probe.py <groups>"""
-import sys, os, time, numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-from vil_sensor_fusion_amd import Engine, EngineOpts, synth
+"""Does the update step run faster as TWO half-batches on two HIP streams, out of phase (one half in the latency-bound
+banded solve while the other is in the bandwidth-bound linearisation / assembly), than as one full batch?
+usage: python tools/two_stream_probe.py [windows] [steps]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
-G = int(sys.argv[1]); B = 1024 // G; N = 1000; STEPS = 6
-seqs = [synth.make_sequence(seed=s, n_kf=N + STEPS + 4) for s in range(8)]
-recs = [synth.between_records(s) for s in seqs]
-engs = []
-for g in range(G):
-    eng = Engine(EngineOpts(windows=B, capacity=N + STEPS + 4, chunks=1))
-    for w in range(B):
-        q = (g * B + w) % 8
-        seq = seqs[q]
-        eng.preintegrate(w, 1, seq.imu_off[1:], seq.imu_steps, np.zeros(6), synth.CARLA_IMU_COV)
-        eng.set_between(w, seq.btw_a, seq.btw_b, recs[q])
-        eng.set_states(w, 0, seq.gt_states[:1]); eng.set_prior(w, 0, synth.prior_record(seq.gt_states[0], REFERENCE_PRIOR_SIGMAS))
-        eng.set_range(w, 0, 1)
-    eng.predict(-1, 1, N - 1)
-    for w in range(B): eng.set_range(w, 0, N)
-    eng.iterate(5); eng.sync()
-    engs.append(eng)
-def step():
-    for e in engs: e.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)
-    for e in engs: e.iterate(5)
-for _ in range(2): step()
-for e in engs: e.sync()
-t0 = time.perf_counter()
-for _ in range(STEPS - 2): step()
-for e in engs: e.sync()
-dt = (time.perf_counter() - t0) / (STEPS - 2)
-print('groups', G, 'windows each', B, 'ms per step', round(dt * 1e3, 2), 'keyframes/s', round(1024 / dt))
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+args = argparse.Namespace(window=1000, windows=W, steps=steps, warmup=2, iterations=5, host_workers=0, no_convergence_exit=True, sequences=0)
+updates = 3 * (steps + 2) + 2
+seqs = bench.make_sequences(args, 0, 64, args.window + updates + 1)     # 64 distinct sequences are enough for a timing probe
+
+
+def step(e):
+    e.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)
+    e.iterate(5)
+
+
+def timed(engines, lag):
+    for _ in range(2):
+        for e in engines: step(e)
+    for e in engines: e.sync()
+    if lag and len(engines) > 1:
+        engines[1].solve()              # one banded solve ahead of the loop: the second stream starts ~one K4 late
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for e in engines: step(e)
+    for e in engines: e.sync()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+one = bench.make_engine(args, 0, W, seqs, updates)
+t1 = timed([one], False)
+print(f"one engine, {W} windows: {t1:.3f} ms per step", flush=True)
+del one
+halves = [bench.make_engine(args, 0, W // 2, seqs[i::2], updates) for i in range(2)]
+t2 = timed(halves, False)
+print(f"two engines x {W // 2} windows, streams in step: {t2:.3f} ms per step", flush=True)
+t3 = timed(halves, True)
+print(f"two engines x {W // 2} windows, second stream one solve late: {t3:.3f} ms per step", flush=True)
+del halves
+quarters = [bench.make_engine(args, 0, W // 4, seqs[i::4], updates) for i in range(4)]
+t4 = timed(quarters, False)
+print(f"four engines x {W // 4} windows: {t4:.3f} ms per step", flush=True)

@@ -2113,11 +2113,19 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         WSYNC();
     }
     struct PRow { d2_t x[8]; };
-    // (backward sweep: lane r < 43 holds row r)
+    // Backward sweep: lane r < 28 holds panel row r (sub-diagonal rows and the rhs row: they go through LDS); the rows of
+    // L^-T sit in lanes XL .. XL+14 of ONE 16-lane row, where s and x are formed as well, so that both matrix-vector
+    // products of the recursion broadcast their vector with DPP row_newbcast inside v_fmac_f64 (one instruction per term
+    // instead of v_readlane x2, s_nop, v_fma); every other lane points at the keyframe's zero cell.
+    constexpr int XL = 32;
+    const bool xl_lane = lane >= XL && lane < XL + 15;
     unsigned pb_off[8];
+    {
+        const int brow = lane < 28 ? lane : (xl_lane ? 28 + (lane - XL) : -1);
 #pragma unroll
-    for (int c = 0; c < 7; c++) pb_off[c] = (unsigned)panel_pair_off(lane < 43 ? lane : 0, c);
-    pb_off[7] = (unsigned)((PANEL_LAST + (lane < 43 ? lane : 0)) * sizeof(double));
+        for (int c = 0; c < 7; c++) pb_off[c] = brow >= 0 ? (unsigned)panel_pair_off(brow, c) : (unsigned)(PANEL_DUMP * sizeof(double));
+        pb_off[7] = (unsigned)((brow >= 0 ? PANEL_LAST + brow : PANEL_DUMP) * sizeof(double));
+    }
     auto load_panel = [=](int k) {   // not a real pivot: any valid panel is loaded and zeroed at use (no use here: no stall)
         PRow r;
         const bool ok = k >= 0 && k < cnt && pivot_real(k);
@@ -2129,19 +2137,19 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         return r;
     };
     const int bw_off = lane < 28 ? S_P + lane * 15 : S_DUMP + 16;
-    const int col = lane < 15 ? lane : 0;
-    const int dl_w = (lane >= 28 && lane < 43) ? S_DL + lane - 28 : S_DUMP + 32 + lane;
+    const int col = xl_lane ? lane - XL : 0;
+    const int dl_w = xl_lane ? S_DL + lane - XL : S_DUMP + 32 + lane;
     WSYNC();
     // Software-pipelined: the recursion delta_{k+1} -> delta_k runs on registers only --
-    //   s = y - part - sum_a P[a][.] delta_{k+1}[a]   (delta_{k+1} = the previous step's x, broadcast by v_readlane)
-    //   x = L_kk^-T s                                  (s broadcast by v_readlane)
+    //   s = y - part - sum_a P[a][.] delta_{k+1}[a]   (delta_{k+1} = the previous step's x, broadcast by DPP)
+    //   x = L_kk^-T s                                  (s broadcast by DPP)
     // while everything that does not depend on delta_{k+1} is prepared one step ahead (`prep`): the panel rows of the
     // next keyframe go through LDS into per-column registers, and the couplings to the two keyframes further on
     // (12 pose columns, increments already in LDS) are summed into `part`.  The step was 3 LDS round trips and an HBM
     // wait in sequence (about 2 600 cycles for 200 instructions); LDS accesses of one wave execute in issue order, so
     // the write -> read hand-offs below need a compiler barrier, not a wait.
 #define CBAR() asm volatile("" ::: "memory")
-    struct Col { double row[15], pv[15], y, part; };   // of one keyframe: its L^-T row (lanes 28..42), column data (lanes 0..14)
+    struct Col { double row[15], pv[15], y, part; };   // of one keyframe, in lanes XL .. XL+14: its L^-T row, its column data
     auto prep = [&](auto ph, int k, PRow& slot, Col& o) {
         constexpr int PH = decltype(ph)::value;          // = k & 3
         constexpr int b2 = S_DL + ((PH + 2) & 3) * 15, b3 = S_DL + ((PH + 3) & 3) * 15;
@@ -2177,33 +2185,38 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     auto solve = [&](auto ph, int k, const Col& c_, double& xprev) {
         constexpr int PH = decltype(ph)::value;
         STAMP(9);
+        // acc += (lane XL + N of xsrc) * other, on the lanes of that 16-lane row (the DPP operand must have been written
+        // at least two wait states earlier: s_nop in front of the first use of a fresh vector)
+        auto bfma = [](auto n_, double& acc, const double bsrc, const double other) {
+            constexpr int N = decltype(n_)::value;
+            asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(other), "n"(N));
+        };
         double s0 = c_.part, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int a = 0; a < 15; a += 3) {
-            s0 = fma(c_.pv[a], readlane_d(xprev, 28 + a), s0);
-            s1 = fma(c_.pv[a + 1], readlane_d(xprev, 29 + a), s1);
-            s2 = fma(c_.pv[a + 2], readlane_d(xprev, 30 + a), s2);
-        }
+        asm volatile("s_nop 1" :: "v"(xprev));
+        bfma(IC<0>{}, s0, xprev, c_.pv[0]);   bfma(IC<1>{}, s1, xprev, c_.pv[1]);   bfma(IC<2>{}, s2, xprev, c_.pv[2]);
+        bfma(IC<3>{}, s0, xprev, c_.pv[3]);   bfma(IC<4>{}, s1, xprev, c_.pv[4]);   bfma(IC<5>{}, s2, xprev, c_.pv[5]);
+        bfma(IC<6>{}, s0, xprev, c_.pv[6]);   bfma(IC<7>{}, s1, xprev, c_.pv[7]);   bfma(IC<8>{}, s2, xprev, c_.pv[8]);
+        bfma(IC<9>{}, s0, xprev, c_.pv[9]);   bfma(IC<10>{}, s1, xprev, c_.pv[10]); bfma(IC<11>{}, s2, xprev, c_.pv[11]);
+        bfma(IC<12>{}, s0, xprev, c_.pv[12]); bfma(IC<13>{}, s1, xprev, c_.pv[13]); bfma(IC<14>{}, s2, xprev, c_.pv[14]);
         const double s = c_.y - ((s0 + s1) + s2);
-        // x = L^-T s on lanes 28..42 (row c of L^-T in registers), s broadcast by v_readlane
+        // x = L^-T s on lanes XL .. XL+14 (row c of L^-T in registers)
         double x0 = 0.0, x1 = 0.0;
-#pragma unroll
-        for (int c = 0; c < 15; c++) {
-            const double sc = readlane_d(s, c);
-            if (c & 1) x1 = fma(c_.row[c], sc, x1);
-            else x0 = fma(c_.row[c], sc, x0);
-        }
+        asm volatile("s_nop 1" :: "v"(s));
+        bfma(IC<0>{}, x0, s, c_.row[0]);   bfma(IC<1>{}, x1, s, c_.row[1]);   bfma(IC<2>{}, x0, s, c_.row[2]);   bfma(IC<3>{}, x1, s, c_.row[3]);
+        bfma(IC<4>{}, x0, s, c_.row[4]);   bfma(IC<5>{}, x1, s, c_.row[5]);   bfma(IC<6>{}, x0, s, c_.row[6]);   bfma(IC<7>{}, x1, s, c_.row[7]);
+        bfma(IC<8>{}, x0, s, c_.row[8]);   bfma(IC<9>{}, x1, s, c_.row[9]);   bfma(IC<10>{}, x0, s, c_.row[10]); bfma(IC<11>{}, x1, s, c_.row[11]);
+        bfma(IC<12>{}, x0, s, c_.row[12]); bfma(IC<13>{}, x1, s, c_.row[13]); bfma(IC<14>{}, x0, s, c_.row[14]);
         const double x = x0 + x1;
-        S[(lane >= 28 && lane < 43) ? S_DL + PH * 15 + lane - 28 : dl_w] = x;
+        S[xl_lane ? S_DL + PH * 15 + lane - XL : dl_w] = x;
         // (head keyframes of a chunk: only their velocity / bias increments are this sweep's; the pose part is the separator's)
-        if (lane >= 28 && lane < 43 && pivot_real(k) && !(CH && cg.i0 > 0 && k < 2 && lane < 34)) dbase[(size_t)kf_of(k) * 15 + lane - 28] = x;
+        if (xl_lane && pivot_real(k) && !(CH && cg.i0 > 0 && k < 2 && lane < XL + 6)) dbase[(size_t)kf_of(k) * 15 + lane - XL] = x;
         xprev = x;
         STAMP(10);
     };
     {
         PRow p3 = load_panel(n4 - 1), p2 = load_panel(n4 - 2), p1 = load_panel(n4 - 3), p0 = load_panel(n4 - 4);
         // increment of the keyframe after the last pivot (slot n4 & 3 = 0): zero, or the separator's / the middle system's
-        double xprev = S[(lane >= 28 && lane < 43) ? S_DL + lane - 28 : S_ZERO];
+        double xprev = S[xl_lane ? S_DL + lane - XL : S_ZERO];
         Col ca, cb;
         prep(IC<3>{}, n4 - 1, p3, ca);
 #pragma unroll 1

@@ -1831,7 +1831,10 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     const double* __restrict__ Hbase = v.H + hbase * HROW;
     const double* __restrict__ gbase = v.gvec + hbase * 15;
     const double* __restrict__ zrow = v.zrow;
-    double* __restrict__ Lbase = v.Lp + base * PANEL;
+    // panels are stored keyframe-major, [slot][window]: the waves of a batch sweep their windows in step, so what they
+    // write / read at any moment is one contiguous stretch of memory instead of B streams a window apart
+    double* __restrict__ Lbase = v.Lp + ((size_t)(base - (size_t)w * v.M) * v.B + w) * PANEL;
+    const size_t Lstride = (size_t)v.B * PANEL;      // doubles between consecutive keyframes of a window
     double* __restrict__ dbase = v.delta + base * 15;
     auto fetch_row = [=](int kk) {
         HRow r;
@@ -1972,7 +1975,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #pragma unroll
         for (int c = 0; c < 15; c++) S[pw_off + PH * RSLOT + c] = p[c];
         if (lane >= 15 && lane < 58 && pivot_real(k)) {
-            VF_GLOBAL char* Lk = uniform_gptr(Lbase + (size_t)kf_of(k) * PANEL);     // (the lane's place in each pair: pp_off)
+            VF_GLOBAL char* Lk = uniform_gptr(Lbase + (size_t)kf_of(k) * Lstride);     // (the lane's place in each pair: pp_off)
 #pragma unroll
             for (int c = 0; c < 7; c++) { d2_t t; t.x = p[2 * c]; t.y = p[2 * c + 1]; *(VF_GLOBAL d2_t*)(Lk + pp_off[c]) = t; }
             *(VF_GLOBAL double*)(Lk + pp_off[7]) = p[14];
@@ -2129,7 +2132,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     auto load_panel = [=](int k) {   // not a real pivot: any valid panel is loaded and zeroed at use (no use here: no stall)
         PRow r;
         const bool ok = k >= 0 && k < cnt && pivot_real(k);
-        const VF_GLOBAL char* Lk = uniform_gptr(Lbase + (size_t)(ok ? kf_of(k) : 0) * PANEL);
+        const VF_GLOBAL char* Lk = uniform_gptr(Lbase + (size_t)(ok ? kf_of(k) : 0) * Lstride);
 #pragma unroll
         for (int c = 0; c < 7; c++) r.x[c] = *(const VF_GLOBAL d2_t*)(Lk + pb_off[c]);
         r.x[7].x = *(const VF_GLOBAL double*)(Lk + pb_off[7]);
@@ -2482,7 +2485,7 @@ __global__ void __launch_bounds__(256) k_chunk_rhs(View v) {
             s1 = fma(Vr[j + 1], dl[j + 1], s1);
             s2 = fma(Vr[j + 2], dl[j + 2], s2);
         }
-        v.Lp[(base + k) * PANEL + panel_idx(27, a)] -= (s0 + s1) + s2;
+        v.Lp[((size_t)(lo + cg.i0 + k) * v.B + w) * PANEL + panel_idx(27, a)] -= (s0 + s1) + s2;      // (panels: [slot][window])
     }
 }
 

@@ -171,6 +171,25 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     assert sh["collectives_issued"] == 2 * sh["lm_trials_run"] and sh["solve_failures"] == 0
 
 
+def test_bench_abandons_a_stalled_sharded_section():
+    """A multi-rank run whose time-sharded section gives no result in time (here: a limit of zero seconds) must still hand
+    the driver the headline: every rank leaves, rank 0 prints the line it has, exit status 0."""
+    import json
+    import subprocess
+    env = dict(os.environ, VF_BENCH_BACKEND="gloo", VF_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--windows", "8", "--window", "96", "--steps", "2",
+           "--warmup", "1", "--sharded-window", "1200", "--no-single-window", "--sharded-timeout", "0"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["ms_per_step"] > 0
+    assert "error" in line["time_sharded_window"]
+
+
 def test_shard_errors():
     from vil_sensor_fusion_amd import Engine, EngineOpts
     from vil_sensor_fusion_amd._lib import VilFusionError

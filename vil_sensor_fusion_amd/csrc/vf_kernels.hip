@@ -2965,7 +2965,6 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
     __shared__ double bv[42];
     const double* imu = v.imu_r + (size_t)b * tiles * IMU_R * TILE + (size_t)((g0 + 1) >> 6) * IMU_R * TILE + ((g0 + 1) & 63);   // residual
     const double* jbuf = v.imu_j + (size_t)b * (size_t)(v.G >> 3) * JT_STRIDE;
-    auto JI = [&](int r, int c30) { return jstream_entry(jbuf, g0 + 1, r, c30); };
     const bool has_prior = v.prior_k[w] == lo;
     const bool has_mp = v.mp_on[w] != 0;
     const double* Pq = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT;
@@ -2973,10 +2972,23 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
     const double* Mg = v.mp_out + ((size_t)b * v.B + w) * 28;
     int bd[3];   // between factor m -> m+d present?
     for (int d = 1; d <= 3; d++) bd[d - 1] = (v.btw_a[g0 + d] == lo);
-    auto BT = [&](int d, int f) {
+    // The linearisations of the factors that touch m are staged into LDS once (the whitened Jacobian of the IMU factor
+    // m -> m+1 as a dense 15 x 30 block + its residual, the three between linearisations that may start at m); every
+    // entry of the 42 x 42 system then costs LDS reads.  (Read where they lie -- J-stream entries through the index
+    // table, AoSoA fields -- the 54 000 dependent global loads of this phase were most of the kernel's 95 us, i.e. an
+    // eighth of a GraphManager solve.)
+    __shared__ double LJ[15 * 30 + 15];
+    __shared__ double LBt[3 * BTW_OUT];
+    for (int e = lane; e < 15 * 30 + 15; e += 256)
+        LJ[e] = e < 450 ? jstream_entry(jbuf, g0 + 1, e / 30, e % 30) : imu[(size_t)(e - 450) * TILE];
+    for (int e = lane; e < 3 * BTW_OUT; e += 256) {
+        const int d = e / BTW_OUT + 1, f = e - (d - 1) * BTW_OUT;
         const long gs = g0 + d;
-        return v.btw_out[(size_t)b * tiles * BTW_OUT * TILE + ((size_t)(gs >> 6) * BTW_OUT + f) * TILE + (gs & 63)];
-    };
+        LBt[e] = bd[d - 1] ? v.btw_out[(size_t)b * tiles * BTW_OUT * TILE + ((size_t)(gs >> 6) * BTW_OUT + f) * TILE + (gs & 63)] : 0.0;
+    }
+    __syncthreads();
+    auto JI = [&](int r, int c30) { return LJ[r * 30 + c30]; };
+    auto BT = [&](int d, int f) { return LBt[(d - 1) * BTW_OUT + f]; };
     // index maps of the 42-vector: [m:15][m+1:15][m+2 pose][m+3 pose]
     auto imu_c = [](int i) { return i < 15 ? imu_col(0, i) : imu_col(1, i - 15); };   // i < 30
     auto mp_i = [](int i) { return i < 15 ? i : (i < 21 ? i : (i >= 30 && i < 36 ? i - 9 : -1)); };   // 42-index -> 27-index
@@ -2986,7 +2998,7 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
         double sum = 0.0;
         if (i < 30 && (is_b || j < 30)) {   // IMU factor m -> m+1
             const int ci = imu_c(i);
-            for (int r = 0; r < 15; r++) sum = fma(JI(r, ci), is_b ? imu[(size_t)r * TILE] : JI(r, imu_c(j)), sum);
+            for (int r = 0; r < 15; r++) sum = fma(JI(r, ci), is_b ? LJ[450 + r] : JI(r, imu_c(j)), sum);
         }
         for (int d = 1; d <= 3; d++) {      // between factors m -> m+d: Ja on m pose, Jb on (m+d) pose
             if (!bd[d - 1]) continue;

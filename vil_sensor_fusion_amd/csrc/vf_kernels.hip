@@ -800,18 +800,16 @@ __device__ unsigned long long g_k3_loop[8];
 #else
 #define K3LOOP(i) do {} while (0)
 #endif
-// The matrix-core part of K3, shared by k_assemble (records staged from HBM) and k_linearize_assemble (records computed
-// into LDS): wave `wv` of the workgroup forms the block rows of KPW keyframes from the tile's (r | J) rows in LJ and the
-// between linearisations in LB (s_a = their source keyframes), and stores them into buffer `hb` of H, g.
-template <int KPW>
-__device__ __forceinline__ void assemble_tile(const View& v, const double* __restrict__ LJ, const double* __restrict__ LB,
-                                              const int* __restrict__ s_a, const int w, const int b, const int hb, const int k0,
-                                              const long gk0, const int lo, const int hi, const int rlo, const int rhi,
-                                              const int wv, const int lane) {
+// Per-lane operand maps of assemble_tile and the window scalars it needs.  They come from memory (the index table of the J
+// stream, per-window flags): the caller builds them while its staging loads are in flight, not behind the barrier that
+// follows them -- two dependent round trips (about 3 k cycles per tile) taken off the matrix-core phase.
+struct AsmMaps { int offI[4], offJ[4], oA[2], oB[2], prior_key; bool marg_on; };
+__device__ __forceinline__ AsmMaps make_asm_maps(const View& v, const int w, const int lo, const int hi, const int lane) {
+    AsmMaps m;
     const int ci = lane & 15, kq = lane >> 4;
+    int (&offI)[4] = m.offI, (&offJ)[4] = m.offJ, (&oA)[2] = m.oA, (&oB)[2] = m.oB;
     // MFMA operand words of this lane in a factor's LDS image: J[4 q + kq][column ci of the i / j side], column 15 = r;
     // structural zeros and the padding row 15 read the zero cell
-    int offI[4], offJ[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int row = 4 * q + kq;
@@ -824,17 +822,11 @@ __device__ __forceinline__ void assemble_tile(const View& v, const double* __res
             } else offI[q] = offJ[q] = LJ_R + row;
         }
     }
-    auto load_ops = [&](int lf, double (&ai)[4], double (&aj)[4]) {
-        const double* F = LJ + lf * LJS;
-#pragma unroll
-        for (int q = 0; q < 4; q++) { ai[q] = F[offI[q]]; aj[q] = F[offJ[q]]; }
-    };
     // Between-factor terms on the matrix cores as well: a between linearisation in LDS (r: 0, Ja: 6, Jb: 42, 6 rows) is
     // the 6 x 16 operand X = [J | 0 ... 0 | r] (column 15 = r, like the IMU tiles), rows padded to 8 = two k-steps;
     // X^T X adds J^T J to the pose block and J^T r to the gradient column of a diagonal tile, Xb^T Xa is the coupling
     // block.  Per lane: the in-slot offsets of its two operand words (the slot's pad cell = 0 where X has no entry).
     // (the VALU form, 6-term dot products per entry from LDS, cost 0.5 ms of K3's 2.7; this one about 0.35)
-    int oA[2], oB[2];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int row = 4 * q + kq;
@@ -842,14 +834,32 @@ __device__ __forceinline__ void assemble_tile(const View& v, const double* __res
         oA[q] = !valid ? BTW_OUT : (ci < 6 ? 6 + row * 6 + ci : (ci == 15 ? row : BTW_OUT));
         oB[q] = !valid ? BTW_OUT : (ci < 6 ? 42 + row * 6 + ci : (ci == 15 ? row : BTW_OUT));
     }
+    m.prior_key = v.prior_k[w];
+    m.marg_on = v.mp_on[w] != 0 && hi - lo >= 3;
+    return m;
+}
+// The matrix-core part of K3, shared by k_assemble (records staged from HBM) and k_linearize_assemble (records computed
+// into LDS): wave `wv` of the workgroup forms the block rows of KPW keyframes from the tile's (r | J) rows in LJ and the
+// between linearisations in LB (s_a = their source keyframes), and stores them into buffer `hb` of H, g.
+template <int KPW>
+__device__ __forceinline__ void assemble_tile(const View& v, const double* __restrict__ LJ, const double* __restrict__ LB,
+                                              const int* __restrict__ s_a, const int w, const int b, const int hb, const int k0,
+                                              const long gk0, const int lo, const int hi, const int rlo, const int rhi,
+                                              const int wv, const int lane, const AsmMaps& maps) {
+    const int ci = lane & 15, kq = lane >> 4;
+    const int (&offI)[4] = maps.offI, (&offJ)[4] = maps.offJ, (&oA)[2] = maps.oA, (&oB)[2] = maps.oB;
+    auto load_ops = [&](int lf, double (&ai)[4], double (&aj)[4]) {
+        const double* F = LJ + lf * LJS;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { ai[q] = F[offI[q]]; aj[q] = F[offJ[q]]; }
+    };
 #ifdef VF_SOLVE_STAMPS
     unsigned long long k3acc[8] = {0}, k3prev = __builtin_amdgcn_s_memtime();
 #endif
-    // Window-level scalars are read ONCE, in front of the loop: a global load inside it would have to wait for its result with
-    // s_waitcnt vmcnt(0), and stores count in vmcnt on this ISA -- every keyframe would wait for the H rows of the one before
-    // it to be acknowledged by memory before it could go on.
-    const int prior_key = v.prior_k[w];
-    const bool marg_on = v.mp_on[w] != 0 && hi - lo >= 3;
+    // (window-level scalars: read by the caller in front of its staging barrier -- a global load inside the loop would have
+    // to wait for its result with s_waitcnt vmcnt(0), and stores count in vmcnt on this ISA)
+    const int prior_key = maps.prior_key;
+    const bool marg_on = maps.marg_on;
     d4_t D = {0, 0, 0, 0};
     const int lf0 = KPW * wv;
 #pragma unroll 1
@@ -1003,6 +1013,7 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     const size_t tiles = (size_t)(v.G >> 6);
     const double* btw_out = v.btw_out + (size_t)b * tiles * BTW_OUT * TILE;
 
+    AsmMaps maps;
     // ---- stage the tile's 9 IMU linearisations from the J stream: the tile's own block is copied into LDS as it is
     // (146 pairs x 8 slots, 16 bytes per lane and load, every 128-B line used whole, one ds_write_b128 each), the i-side
     // pairs of the halo factor come from slot 0 of the next tile.  All of a thread's global loads are issued before the
@@ -1039,6 +1050,7 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
             tb[j] = (e < (AT + 3) * BTW_OUT && ks > lo && ks < hi) ? btw_out[((size_t)(gs >> 6) * BTW_OUT + f) * TILE + (gs & 63)] : 0.0;
         }
         K3STAMP(1);   // all loads issued
+        maps = make_asm_maps(v, w, lo, hi, tid & 63);      // (their table / flag reads fly with the staging loads)
         if (tid < AT + 3) {
             LB[tid * LBS + BTW_OUT] = 0.0;       // the pad cell of a slot: the zero the MFMA operand maps point at
             const int ks = k0 + tid;
@@ -1072,7 +1084,7 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     K3STAMP(3);   // everybody's
 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave-uniform: the keyframe loop and its tests stay scalar
-    assemble_tile<K3_KPW>(v, LJ, LB, s_a, w, b, h_buf(v, w), k0, gk0, lo, hi, rlo, rhi, wv, lane);
+    assemble_tile<K3_KPW>(v, LJ, LB, s_a, w, b, h_buf(v, w), k0, gk0, lo, hi, rlo, rhi, wv, lane, maps);
     K3STAMP(4);       // wave 0: MFMAs done, stores issued
 #ifdef VF_SOLVE_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1150,7 +1162,7 @@ __global__ void __launch_bounds__(64) k_linearize_assemble(View v, int which, in
         if (e < (FA + 3) * BTW_OUT) { const int sl = e / BTW_OUT; LB[sl * LBS + (e - sl * BTW_OUT)] = tb[j]; }
     }
     __syncthreads();
-    assemble_tile<FA>(v, LJ, LB, s_a, w, b, b, k0, gk0, lo, hi, lo, hi, 0, lane);
+    assemble_tile<FA>(v, LJ, LB, s_a, w, b, b, k0, gk0, lo, hi, lo, hi, 0, lane, make_asm_maps(v, w, lo, hi, lane));
 }
 // ------------------------------------------------------------------------------------ K1 + K3 fused, lane per factor
 // k_lin_asm_v (opt-in, VF_FUSED=2): no Jacobian anywhere.  Lane = IMU factor k (keyframes i = k-1, j = k); with A the

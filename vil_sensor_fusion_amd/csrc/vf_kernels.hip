@@ -361,6 +361,9 @@ __device__ __forceinline__ void linearize_imu_core(const View& v, const int b, c
 #else
 #define IN(f) in[(size_t)(f) * TILE]
 #endif
+    // the square-root information (120 of the 222 input words, read once) non-temporal: more of the bias Jacobians, which
+    // are read twice, survive in L2 until their second use (PMC: 2.15 -> 2.00 GB read per launch; time unchanged)
+#define INR(f) __builtin_nontemporal_load(in + (size_t)(f) * TILE)
     struct RRef { Sink& s; int a; VF_DI void operator=(double x) const { s.r(a, x); } };
     struct JRef { Sink& s; int row, col; VF_DI void operator=(double x) const { s.j(row, col, x); } };
 #define OUT(f) (RRef{sink, (f)})
@@ -421,7 +424,7 @@ __device__ __forceinline__ void linearize_imu_core(const View& v, const int b, c
 #pragma unroll
     for (int a = 0; a < 9; a++)
 #pragma unroll
-        for (int c = a; c < 9; c++) R[idx9(a, c)] = IN(70 + off15(a) + (c - a));
+        for (int c = a; c < 9; c++) R[idx9(a, c)] = INR(70 + off15(a) + (c - a));
 
     double u[9], o[9], rw[15];
     {
@@ -486,7 +489,7 @@ __device__ __forceinline__ void linearize_imu_core(const View& v, const int b, c
         const int n_rc = 10 + c;  // rows 0..9+c of R(:, 9+c) are nonzero
         double Rc[15];
 #pragma unroll
-        for (int a = 0; a < 15; a++) Rc[a] = (a < n_rc) ? IN(70 + off15(a) + (9 + c - a)) : 0.0;
+        for (int a = 0; a < 15; a++) Rc[a] = (a < n_rc) ? INR(70 + off15(a) + (9 + c - a)) : 0.0;
         const V3 hth = v3(HB(0 * 6 + c), HB(1 * 6 + c), HB(2 * 6 + c));
         const V3 hp = v3(HB(3 * 6 + c), HB(4 * 6 + c), HB(5 * 6 + c));
         const V3 hv = v3(HB(6 * 6 + c), HB(7 * 6 + c), HB(8 * 6 + c));
@@ -507,6 +510,7 @@ __device__ __forceinline__ void linearize_imu_core(const View& v, const int b, c
 #pragma unroll
     for (int a = 0; a < 15; a++) OUT(a) = rw[a];
 #undef IN
+#undef INR
 #undef HB
 #undef OUT
 #undef JOUT

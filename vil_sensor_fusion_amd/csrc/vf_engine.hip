@@ -1086,9 +1086,7 @@ int vf_engine_read_panels(vf_engine* e, int window, int k0, int n, double* panel
     HIPCHK(hipStreamSynchronize(e->stream));
     // packed device layout (vf_kernels.hpp "Cholesky panel") -> the documented [43][16] (column 15 = 0)
     std::vector<double> raw((size_t)n * vf::PANEL);
-    for (int k = 0; k < n; k++)      // panels are stored keyframe-major, [slot][window]
-        HIPCHK(hipMemcpy(raw.data() + (size_t)k * vf::PANEL, e->v.Lp + ((size_t)(k0 + k) * e->v.B + window) * vf::PANEL,
-                         vf::PANEL * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(raw.data(), e->v.Lp + ((size_t)window * e->v.M + k0) * vf::PANEL, raw.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int k = 0; k < n; k++)
         for (int r = 0; r < 43; r++)
             for (int c = 0; c < 16; c++) {

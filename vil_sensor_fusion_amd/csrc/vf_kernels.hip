@@ -1847,10 +1847,8 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     const double* __restrict__ Hbase = v.H + hbase * HROW;
     const double* __restrict__ gbase = v.gvec + hbase * 15;
     const double* __restrict__ zrow = v.zrow;
-    // panels are stored keyframe-major, [slot][window]: the waves of a batch sweep their windows in step, so what they
-    // write / read at any moment is one contiguous stretch of memory instead of B streams a window apart
-    double* __restrict__ Lbase = v.Lp + ((size_t)(base - (size_t)w * v.M) * v.B + w) * PANEL;
-    const size_t Lstride = (size_t)v.B * PANEL;      // doubles between consecutive keyframes of a window
+    double* __restrict__ Lbase = v.Lp + base * PANEL;
+    constexpr size_t Lstride = PANEL;                 // doubles between consecutive keyframes of a window
     double* __restrict__ dbase = v.delta + base * 15;
     auto fetch_row = [=](int kk) {
         HRow r;
@@ -2501,7 +2499,7 @@ __global__ void __launch_bounds__(256) k_chunk_rhs(View v) {
             s1 = fma(Vr[j + 1], dl[j + 1], s1);
             s2 = fma(Vr[j + 2], dl[j + 2], s2);
         }
-        v.Lp[((size_t)(lo + cg.i0 + k) * v.B + w) * PANEL + panel_idx(27, a)] -= (s0 + s1) + s2;      // (panels: [slot][window])
+        v.Lp[(base + k) * PANEL + panel_idx(27, a)] -= (s0 + s1) + s2;
     }
 }
 

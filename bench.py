@@ -46,6 +46,7 @@ sys.path.insert(0, ROOT)
 # which k_linearize_imu no longer writes, so the roofline is priced on the smaller figure; the dense one is kept beside it.
 IMU_BYTES = 1776 + 8 * (15 + 450 - 159)
 IMU_BYTES_DENSE = 5496
+EXIT_SHARDED_SECTION_HUNG = 75   # the headline line was printed, the time-sharded (collective) section did not finish
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -466,7 +467,9 @@ def main():
                         "with_convergence_exit": conv,
                         "time_sharded_window": {"error": f"no result within {args.sharded_timeout} s: section abandoned, "
                                                          "the ranks left without tearing the process group down"}}), flush=True)
-                os._exit(0)
+                # a stalled collective is a failure of the run, not a success: the headline line is out, the status says
+                # which part hung (every rank leaves with the same code; spawn_ranks hands it on)
+                os._exit(EXIT_SHARDED_SECTION_HUNG)
             guard = threading.Timer(args.sharded_timeout, bail)
             guard.daemon = True
             guard.start()

@@ -1,0 +1,47 @@
+// Host-logic test double for the engine half of libvilfusion (tests only; never shipped): every vf_engine_* entry point
+// vf_graph.cpp calls, with no device behind it, so that the GraphManager bookkeeping (queues, give-back, the two-lock
+// discipline of GraphManager.h:103-104) can be driven on a CPU and under ThreadSanitizer.
+#include <atomic>
+#include <cstring>
+#include <string>
+
+#include "../../include/vilfusion.h"
+
+struct vf_engine { int dummy; };
+static thread_local std::string g_err;
+std::atomic<int> fake_fail_preintegrate{0};   // != 0: vf_engine_preintegrate fails (the solve gives its queues back)
+std::atomic<long> fake_iterates{0};
+
+extern "C" {
+const char* vf_last_error(void) { return g_err.c_str(); }
+void vf_set_last_error_(const char* m) { g_err = m ? m : ""; }
+void vf_engine_default_opts(vf_engine_opts* o) { memset(o, 0, sizeof(*o)); o->windows = 1; o->capacity = 1088; o->bandwidth = 3; }
+int vf_engine_create(const vf_engine_opts*, vf_engine** out) { *out = new vf_engine(); return VF_OK; }
+void vf_engine_destroy(vf_engine* e) { delete e; }
+int vf_engine_set_states(vf_engine*, int, int, int, const double*) { return VF_OK; }
+int vf_engine_set_prior(vf_engine*, int, int, const double*) { return VF_OK; }
+int vf_engine_set_range(vf_engine*, int, int, int) { return VF_OK; }
+int vf_engine_set_convergence(vf_engine*, double, double) { return VF_OK; }
+int vf_engine_set_imu(vf_engine*, int, int, int, const double*) { return VF_OK; }
+int vf_engine_preintegrate(vf_engine*, int, int, int, const int32_t*, const double*, const double*, const vf_imu_params*) {
+    if (fake_fail_preintegrate.load()) { g_err = "fake: preintegration refused"; return VF_ERR_DEVICE; }
+    return VF_OK;
+}
+int vf_engine_predict(vf_engine*, int, int, int) { return VF_OK; }
+int vf_engine_predict_from_estimate(vf_engine*, int, int, int) { return VF_OK; }
+int vf_engine_set_between(vf_engine*, int, int, const int32_t*, const int32_t*, const double*) { return VF_OK; }
+int vf_engine_set_wide_between(vf_engine*, int, int, const int32_t*, const int32_t*, const double*) { return VF_OK; }
+int vf_engine_marginalize(vf_engine*) { return VF_OK; }
+int vf_engine_drop_oldest(vf_engine*) { return VF_OK; }
+int vf_engine_compact(vf_engine*, int) { return VF_OK; }
+int vf_engine_isam_step(vf_engine*, double) { return VF_OK; }
+int vf_engine_iterate(vf_engine*, int) { fake_iterates++; return VF_OK; }
+int vf_engine_read_lm(vf_engine*, int, double* c, double* l, int* a, int* r, int* f) {
+    if (c) *c = 0; if (l) *l = 0; if (a) *a = 0; if (r) *r = 0; if (f) *f = 0;
+    return VF_OK;
+}
+static int fill_state(int n, double* s) { for (int i = 0; i < n; i++) { memset(s + 16 * i, 0, 16 * sizeof(double)); s[16 * i] = 1.0; } return VF_OK; }
+int vf_engine_get_states(vf_engine*, int, int, int n, double* s) { return fill_state(n, s); }
+int vf_engine_get_estimate(vf_engine*, int, int, int n, double* s) { return fill_state(n, s); }
+int vf_engine_get_imu(vf_engine*, int, int, int n, double* r) { memset(r, 0, sizeof(double) * VF_IMU_RECORD * n); return VF_OK; }
+}

@@ -210,3 +210,129 @@ def test_diagnostics_message_filling():
     assert abs(m.abs_rot_err - 0.2) < 1e-12 and abs(m.err.position.z - 0.5) < 1e-15 and abs(m.err.orientation.w - math.cos(0.1)) < 1e-15
     for k in ("relative_dist_err", "abs_linear_vel_err", "abs_rot_vel_err", "rel_linear_vel_err", "rel_rot_vel_err"):
         assert isinstance(getattr(m, k), float)
+
+
+def test_fusion_node_serialises_callbacks_from_many_threads():
+    """rospy delivers every subscription on its own thread (roscpp's ros::spin() does not, gtsam_fusion_node.cpp:101):
+    sensor, odometry and IMU callbacks fired concurrently must reach the GraphManager / SensorManager one at a time,
+    and the stamp<->key bookkeeping must stay consistent (no 'no corresponding key', every odometry matched)."""
+    import threading
+    import time as _time
+    from tests.test_sensor_manager import FakeGraphManager
+    from vil_sensor_fusion_amd._lib import VilFusionError
+    from vil_sensor_fusion_amd.ros.gtsam_fusion_node import FusionNode
+
+    class GM(FakeGraphManager):
+        def __init__(self):
+            super().__init__()
+            self.inside, self.overlaps, self.imu_n, self.cb = 0, 0, 0, None
+            self.cap = 10 ** 9
+
+        def _enter(self):
+            self.inside += 1
+            if self.inside > 1:
+                self.overlaps += 1
+            _time.sleep(0)                  # give another thread the chance to barge in
+            _time.sleep(1e-5)
+
+        def reserveNode(self, t):
+            self._enter()
+            try:
+                if self.key + 1 >= self.cap:
+                    raise VilFusionError(-6, "keyframe capacity exhausted")
+                return super().reserveNode(t)
+            finally:
+                self.inside -= 1
+
+        def addBetweenFactor(self, a, b, pose, cov):
+            self._enter()
+            try:
+                super().addBetweenFactor(a, b, pose, cov)
+            finally:
+                self.inside -= 1
+
+        def solve(self):
+            self._enter()
+            try:
+                super().solve()
+                if self.cb:
+                    self.cb(0.0, np.array([1.0, 0, 0, 0]), np.zeros(3), np.zeros(3), np.zeros(6))   # publish() inside solve()
+            finally:
+                self.inside -= 1
+
+        def addIMUMeasurement(self, t, a, w):
+            self._enter()
+            self.imu_n += 1
+            self.inside -= 1
+
+        def addOptimizationCallback(self, cb):
+            self.cb = cb
+
+    rospy, sent_tf = _Rospy(CARLA), []
+    gm = GM()
+    node = FusionNode(rospy, _ns(TransformBroadcaster=lambda: _ns(sendTransform=sent_tf.append)),
+                      _ns(Imu="Imu", Image="Image", PointCloud2="PointCloud2", Odometry=_Msg, TransformStamped=_Msg), graph_manager=gm)
+    img, odo = rospy.subs["/cam0/image_mono"][2], rospy.subs["/rovio/odometry"][2]
+    cloud, lodo = rospy.subs["/lidar"][2], rospy.subs["/gtsam_fusion_filter/laser_odom_output"][2]
+    imu = rospy.subs["/imu/fusion"][2]
+    img(_ns(header=_ns(stamp=_Stamp(0.0)))); odo(_odom_msg(0.0, [0, 0, 0], I4))
+    cloud(_ns(header=_ns(stamp=_Stamp(0.02)))); lodo(_odom_msg(0.02, [0, 0, 0], I4))
+    n = 300
+
+    def camera():       # one thread = one sensor pipeline: frame, then its odometry (Rovio publishes after the image)
+        for k in range(1, n):
+            img(_ns(header=_ns(stamp=_Stamp(0.05 * k))))
+            odo(_odom_msg(0.05 * k, [0.5 * k, 0, 0], I4))
+
+    def lidar():
+        for k in range(1, n // 2):
+            cloud(_ns(header=_ns(stamp=_Stamp(0.09 * k + 0.02))))      # (0.09 s apart: under the 0.1 s max_time_skip)
+            lodo(_odom_msg(0.09 * k + 0.02, [1.0 * k, 0, 0], I4))
+
+    def inertial():
+        for k in range(4 * n):
+            imu(_ns(header=_ns(stamp=_Stamp(0.005 * k)), linear_acceleration=_ns(x=0, y=0, z=9.81), angular_velocity=_ns(x=0, y=0, z=0)))
+
+    threads = [threading.Thread(target=f) for f in (camera, lidar, inertial)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert gm.overlaps == 0, "two callbacks were inside the GraphManager at once"
+    assert gm.imu_n == 4 * n and gm.key == (n - 1) + (n // 2 - 1)
+    assert all(not sm.warnings for sm in node.sensor_managers.values())
+    assert len(gm.between) == (n - 2) + (n // 2 - 2) and gm.solves == n - 2 and len(sent_tf) == gm.solves
+    # a keyframe-capacity error (unbounded history on a long bag) is logged once and does not kill the callback thread
+    gm.cap = gm.key + 1
+    before = len(rospy.warned)
+    for k in range(n, n + 3):
+        img(_ns(header=_ns(stamp=_Stamp(0.05 * k))))
+    assert len(rospy.warned) == before + 1 and "solver/lag" in rospy.warned[-1]
+
+
+def test_node_defaults_to_a_fixed_lag_and_tolerates_a_missing_max_time_skip():
+    """with lag = 0 the device's capacity ends the run after minutes; the node's default is a fixed lag.  San
+    Rafael's YAML has no max_time_skip (the reference reads an uninitialised double, SensorManagerRos.h:49,85)."""
+    import copy
+    from tests.test_sensor_manager import FakeGraphManager
+    from vil_sensor_fusion_amd.ros import gtsam_fusion_node as N
+    made = {}
+
+    class GM(FakeGraphManager):
+        def __init__(self, **kw):
+            super().__init__()
+            made.update(kw)
+
+        def addOptimizationCallback(self, cb):
+            pass
+
+    params = copy.deepcopy(CARLA)
+    del params["sensors"]["lidar"]["max_time_skip"]
+    rospy = _Rospy(params)
+    orig, N.GraphManager = N.GraphManager, GM
+    try:
+        node = N.FusionNode(rospy, _ns(TransformBroadcaster=lambda: _ns(sendTransform=lambda t: None)),
+                            _ns(Imu="Imu", Image="Image", PointCloud2="PointCloud2", Odometry=_Msg, TransformStamped=_Msg))
+    finally:
+        N.GraphManager = orig
+    assert made["lag"] == 1000 and made["capacity"] == 1192
+    assert node.sensor_managers["lidar"].max_time_skip == float("inf") and node.sensor_managers["vio"].max_time_skip == 0.1
+    assert any("max_time_skip" in w for w in rospy.warned)

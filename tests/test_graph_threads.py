@@ -1,0 +1,24 @@
+"""Host logic of the GraphManager surface under ThreadSanitizer: vf_graph.cpp against a device-free engine double
+(tests/native/fake_engine.cpp).  Checks the two-lock discipline of GraphManager.h:103-104 / GraphManager.cpp:104-117 --
+in particular that a failing vf_solve, which gives its snapshot back to the queues, never takes the graph lock while it
+holds the state lock (lock-order inversion against vf_reserve_node)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_failing_solve_against_reserve_node_under_tsan(tmp_path):
+    exe = tmp_path / "graph_threads"
+    srcs = [os.path.join(ROOT, "tests", "native", "graph_threads.cpp"), os.path.join(ROOT, "tests", "native", "fake_engine.cpp"),
+            os.path.join(ROOT, "vil_sensor_fusion_amd", "csrc", "vf_graph.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-o", str(exe)] + srcs)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 second_deadlock_stack=1 exitcode=66")
+    p = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=300)
+    print(p.stdout, p.stderr[-3000:])
+    assert "ThreadSanitizer" not in p.stderr, "data race or lock-order inversion reported"
+    assert p.returncode == 0

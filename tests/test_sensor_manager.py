@@ -123,3 +123,31 @@ def test_integration_timeline_structure():
     kw["max_time_skip"] = 0.1
     _integration_timeline(gm2, SensorManager(gm2, **kw), SensorManager(gm2, **kw))
     assert gm2.key == 4 and gm2.between == []
+
+
+def test_wide_between_factor_fails_soft():
+    """The device takes between factors of span <= 3 keyframes, one per end key (include/vilfusion.h); iSAM2 takes any
+    (GraphManager.cpp:83-88).  A factor the C ABI refuses with VF_ERR_CAPACITY is dropped like a missed odometry
+    (SensorManagerRos.cpp:41-45 warns and carries on) instead of raising out of the ROS callback."""
+    from vil_sensor_fusion_amd._lib import VilFusionError
+
+    class Narrow(FakeGraphManager):
+        def addBetweenFactor(self, a, b, pose, cov):
+            if b - a > 3:
+                raise VilFusionError(-6, f"between factor spans {b - a} keyframes (max 3)")
+            super().addBetweenFactor(a, b, pose, cov)
+
+    gm = Narrow()
+    sm = SensorManager(gm, optimize_after_odom=True, max_time_skip=float("inf"))
+    other = SensorManager(gm, optimize_after_odom=False, max_time_skip=float("inf"))
+    sm.odometryCallback(Odometry(0.0, [0, 0, 0], [1, 0, 0, 0]))
+    other.odometryCallback(Odometry(0.0, [0, 0, 0], [1, 0, 0, 0]))
+    sm.sensorCallback(0.1); sm.odometryCallback(Odometry(0.1, [0, 0, 0], [1, 0, 0, 0]))
+    for i in range(5):                       # five keyframes of the other sensor in between: the next factor spans 6 keys
+        other.sensorCallback(0.11 + 0.01 * i)
+    sm.sensorCallback(0.2)
+    assert sm.odometryCallback(Odometry(0.2, [1, 0, 0], [1, 0, 0, 0])) is False
+    assert gm.between == [] and gm.solves == 0 and len(sm.warnings) == 1 and "not added" in sm.warnings[0]
+    sm.sensorCallback(0.3)                   # the chain carries on from the key of the dropped factor
+    assert sm.odometryCallback(Odometry(0.3, [2, 0, 0], [1, 0, 0, 0])) is True
+    assert [(a, b) for a, b, _, _ in gm.between] == [(7, 8)] and gm.solves == 1

@@ -323,7 +323,7 @@ static int check_range(vf_engine* e, int window, int k0, int n) {
 int vf_engine_set_range(vf_engine* e, int window, int lo, int hi) {
     DeviceGuard dev_guard_(e);
     int rc = check_window(e, window);
-    if (rc) { e->warm = false; return rc; }
+    if (rc) { if (e) e->warm = false; return rc; }
     if (lo < 0 || hi < lo || hi > e->v.M) { e->warm = false; return fail(VF_ERR_BAD_KEY, "bad range [%d,%d)", lo, hi); }
     // growing the end of the one window of a warm engine = appending keyframes (see touch()); its start is moved by
     // vf_engine_drop_oldest only

@@ -73,6 +73,7 @@ struct vf_graph {
     vf_imu_params imu{};
     // guarded by graph_mutex (GraphManager::_graphMutex + IMUManager::_bufferMutex)
     std::mutex graph_mutex, buffer_mutex;
+    std::mutex solve_mutex;        // one vf_solve at a time (order: solve -> graph -> state; nothing else takes it)
     std::deque<ImuSample> buffer;
     std::deque<PendingImu> imu_queue;
     std::vector<PendingBetween> staged_between;
@@ -347,6 +348,7 @@ int vf_solve(vf_graph* g) {
     uint64_t last_key;
     double last_time;
     int staged_before;
+    std::lock_guard<std::mutex> solve_lk(g->solve_mutex);
     {
         std::lock_guard<std::mutex> lk(g->graph_mutex);
         imus.swap(g->imu_queue);
@@ -356,18 +358,18 @@ int vf_solve(vf_graph* g) {
         last_key = g->current_key;
         last_time = g->last_pose_time;
     }
+    // Lock order is graph -> state everywhere (vf_reserve_node, vf_set_initial_state; GraphManager.cpp:54,60 -> 176), and the
+    // reference's solve() has released _graphMutex before it takes _stateMutex (:104-117).  A solve that fails before the
+    // optimisation has run must not lose what it took from the queues: every step up to vf_engine_iterate is idempotent
+    // on the device (the same records, predictions and ranges are written again), so the snapshots go back to the FRONT
+    // of the queues and the next vf_solve repeats them -- AFTER the state lock is released (requeue below), never
+    // while it is held.  solve_mutex (taken first, by vf_solve only) keeps a second solver from snapshotting newer
+    // entries between the failure and the give-back.
+    bool requeue = false;
+    auto give_back = [&](int code) { requeue = true; return code; };
+    auto locked = [&]() -> int {
     std::lock_guard<std::mutex> sl(g->state_mutex);  // :117
     int rc;
-    // A solve that fails before the optimisation has run must not lose what it took from the queues: every step up to
-    // vf_engine_iterate is idempotent on the device (the same records, predictions and ranges are written again), so
-    // the snapshots go back to the FRONT of the queues and the next vf_solve repeats them.
-    auto give_back = [&](int code) {
-        std::lock_guard<std::mutex> lk(g->graph_mutex);
-        for (auto it = imus.rbegin(); it != imus.rend(); ++it) g->imu_queue.push_front(std::move(*it));
-        g->staged_between.insert(g->staged_between.begin(), betweens.begin(), betweens.end());
-        g->staged_count += staged_before;
-        return code;
-    };
     // host-side validation first: a between factor whose source keyframe has already left the fixed-lag window (late
     // odometry) can never be added; it is dropped, the rest is given back, and the caller is told once
     {
@@ -377,9 +379,8 @@ int vf_solve(vf_graph* g) {
                 const unsigned long long a = betweens[i].a, b = betweens[i].b;
                 betweens.erase(betweens.begin() + (long)i);
                 staged_before--;
-                give_back(0);
-                return gerr(VF_ERR_BAD_KEY, "between factor (%llu, %llu) dropped: key %llu left the fixed-lag window (oldest key %llu)",
-                            a, b, a, (unsigned long long)oldest);
+                return give_back(gerr(VF_ERR_BAD_KEY, "between factor (%llu, %llu) dropped: key %llu left the fixed-lag window (oldest key %llu)",
+                            a, b, a, (unsigned long long)oldest));
             }
     }
     // fixed-lag mode: reclaim slots below the window when the new keyframes would not fit
@@ -472,6 +473,15 @@ int vf_solve(vf_graph* g) {
     if (fails > 0 && fails >= g->opts.iterations && g->opts.iterations > 0)
         return gerr(VF_ERR_INDETERMINATE, "normal equations not positive definite in every LM trial (underdetermined graph?)");
     return VF_OK;
+    };
+    const int rc = locked();
+    if (requeue) {
+        std::lock_guard<std::mutex> lk(g->graph_mutex);
+        for (auto it = imus.rbegin(); it != imus.rend(); ++it) g->imu_queue.push_front(std::move(*it));
+        g->staged_between.insert(g->staged_between.begin(), betweens.begin(), betweens.end());
+        g->staged_count += staged_before;
+    }
+    return rc;
 }
 
 int vf_get_state(vf_graph* g, double q[4], double t[3], double v[3], double bias[6]) {

@@ -121,9 +121,13 @@ def all_gather_slices(dist, full, per_slice: int, rank: int, world: int, backend
     if backend == "nccl":
         try:
             dist.all_gather_into_tensor(full[:world * per_slice], own)       # in place (NCCL: sendbuff = recvbuff + rank * count)
-        except (RuntimeError, ValueError):
+        except (RuntimeError, ValueError) as exc:
             # a torch build that refuses aliased buffers says so while checking its arguments, before anything is
-            # communicated and on every rank alike: fall back to a copy of the rank's own slice
+            # communicated and on every rank alike: only THAT error falls back to a copy of the rank's own slice; any
+            # other failure (a communicator error, a device fault) is not retried -- a second collective issued by one
+            # rank alone would hang the others
+            if not any(w in str(exc).lower() for w in ("alias", "overlap", "in-place", "inplace", "same memory")):
+                raise
             dist.all_gather_into_tensor(full[:world * per_slice], own.clone())
         return
     import torch
@@ -180,23 +184,103 @@ class ShardedSolver:
         if self.dist is not None:
             self.collectives += 1
 
-    def trial(self):
-        e = self.eng
-        e.assemble()
-        e.solve_local()
+    # one LM trial = three device phases with a collective between them (LockstepGroup drives the same phases for
+    # several shards held by ONE process)
+    def phase_local(self):
+        self.eng.assemble()
+        self.eng.solve_local()
+
+    def exchange_sep(self):
         all_gather_slices(self.dist, self.sep, self.sep_per * self.per_rank, self.rank, self.world, self.backend)
         self._count()
-        e.solve_global()
+
+    def phase_global(self):
+        self.eng.solve_global()
+
+    def exchange_delta(self):
         all_reduce_sum(self.dist, self.delta, self.backend)
         self._count()
+
+    def phase_finish(self):
+        e = self.eng
         e.retract()
         e.linearize(1)
         e.decide(False)
 
-    def iterate(self, iterations: int):
+    def begin(self):
         e = self.eng
         e.reset_lambda()
         e.linearize(0)
         e.decide(True)
+
+    def trial(self):
+        self.phase_local()
+        self.exchange_sep()
+        self.phase_global()
+        self.exchange_delta()
+        self.phase_finish()
+
+    def iterate(self, iterations: int):
+        self.begin()
         for _ in range(iterations):
             self.trial()
+
+
+class _LocalRank:
+    """The two methods of torch.distributed ShardedSolver's constructor asks for, for a shard that lives in this process."""
+
+    def __init__(self, rank, world):
+        self._r, self._w = rank, world
+
+    def get_rank(self):
+        return self._r
+
+    def get_world_size(self):
+        return self._w
+
+
+class LockstepGroup:
+    """`world` shards of ONE time-sharded window held by one process on one GPU: the geometry of an N-GPU run (BASELINE
+    configs[4]: 8 ranks x 12 chunks of a 10 000-pose window) where only one GPU -- and at most six GPU processes -- is to
+    be had.  Every shard is a real engine with vf_engine_set_shard(r, world) running ShardedSolver's own phases; the two
+    collectives of a trial are carried out on the device between the engines' buffers (slice copies for the all-gather,
+    a sum for the all-reduce), in the places the RCCL calls take in a multi-process run.  A test harness for the shard
+    arithmetic, not a way to go faster."""
+
+    def __init__(self, engines, device):
+        import torch
+        self.world = len(engines)
+        self.solvers = []
+        for r, e in enumerate(engines):
+            s = ShardedSolver(e, _LocalRank(r, self.world), device, backend="local")
+            s.dist = None                       # its own exchange_* calls do nothing: the group exchanges for it
+            self.solvers.append(s)
+        self.torch = torch
+        self.collectives = 0
+
+    def _all_gather_sep(self):
+        per = self.solvers[0].sep_per * self.solvers[0].per_rank
+        for r, src in enumerate(self.solvers):
+            for dst in self.solvers:
+                if dst is not src:
+                    dst.sep[r * per:(r + 1) * per].copy_(src.sep[r * per:(r + 1) * per])
+        self.collectives += 1
+
+    def _all_reduce_delta(self):
+        total = self.torch.stack([s.delta for s in self.solvers]).sum(dim=0)
+        for s in self.solvers:
+            s.delta.copy_(total)
+        self.collectives += 1
+
+    def iterate(self, iterations: int):
+        for s in self.solvers:
+            s.begin()
+        for _ in range(iterations):
+            for s in self.solvers:
+                s.phase_local()
+            self._all_gather_sep()
+            for s in self.solvers:
+                s.phase_global()
+            self._all_reduce_delta()
+            for s in self.solvers:
+                s.phase_finish()

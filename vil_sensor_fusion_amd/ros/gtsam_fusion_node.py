@@ -6,13 +6,24 @@ odom_frame}), same subscriptions and queue sizes, same publications (~odometry n
 odom_frame from the optimisation callback), behind Rovio / LOAM exactly like the reference -- the pose-graph arithmetic
 runs in libvilfusion.so on the MI355X.
 
-Extra private parameters (defaults keep the reference's behaviour): solver/lag (0 = unbounded history, like iSAM2),
-solver/capacity, solver/iterations, solver/device, reference_compat (poseDiff quirk).
+Extra private parameters: solver/lag (fixed-lag window in keyframes, default 1000; 0 = smooth the whole history the way the
+reference's unbounded iSAM2 graph does -- but the device holds solver/capacity keyframes, about 2-3 minutes at Carla rates
+with the default 4096, after which reserveNode fails: a node meant to run on bags of normal length keeps a lag),
+solver/capacity (default lag + 192, or 4096 when lag = 0), solver/iterations, solver/device, reference_compat (poseDiff
+quirk).
+
+Threading: roscpp's ros::spin() runs every callback of the reference node on ONE thread (gtsam_fusion_node.cpp:101).
+rospy does not: each subscription delivers on its own receive thread, and ctypes releases the GIL inside the vf_* calls.
+SensorManager's bookkeeping (keys_and_times, last_valid_*) has no lock of its own -- the reference relies on that one
+spinner thread -- so the node serialises its callbacks with one re-entrant lock (publish() runs inside solve(), on the
+thread that holds it).
 
     rosrun: python3 -m vil_sensor_fusion_amd.ros.gtsam_fusion_node   (with the node's YAML loaded in its namespace,
     launch/fusion.launch:58-73)
 """
 from __future__ import annotations
+
+import threading
 
 from ..graph_manager import GraphManager
 from ..sensor_manager import Odometry, SensorManager
@@ -30,14 +41,17 @@ class FusionNode:
     def __init__(self, rospy, tf2_ros, msgs, graph_manager=None):
         """msgs: namespace with Imu, Image, PointCloud2, Odometry, TransformStamped message classes"""
         self.rospy, self.msgs = rospy, msgs
+        self._lock = threading.RLock()          # one callback at a time, as under ros::spin() (gtsam_fusion_node.cpp:101)
+        self._capacity_reported = False
         P = lambda k, d=None: rospy.get_param("~" + k, d) if d is not None else rospy.get_param("~" + k)
         imu = {k: P("imu/cov_" + n) for k, n in (("acc", "accel"), ("gyro", "gyro"), ("integration", "integration"),
                                                    ("bias_acc", "bias_acc"), ("bias_omega", "bias_omega"),
                                                    ("bias_acc_omega_int", "bias_acc_omega_int"))}   # ImuManagerRos.cpp:20-33
-        self.graph = graph_manager or GraphManager(imu_params=imu, capacity=int(P("solver/capacity", 4096)),
-                                                   lag=int(P("solver/lag", 0)), iterations=int(P("solver/iterations", 5)),
-                                                   device=int(P("solver/device", 0)))
-        self.subs = [rospy.Subscriber(P("imu/topic"), msgs.Imu, queue_size=100, callback=self.imu_callback)]   # ImuManagerRos.cpp:11
+        lag = int(P("solver/lag", 1000))
+        capacity = int(P("solver/capacity", lag + 192 if lag > 0 else 4096))
+        self.graph = graph_manager or GraphManager(imu_params=imu, capacity=capacity, lag=lag,
+                                                   iterations=int(P("solver/iterations", 5)), device=int(P("solver/device", 0)))
+        self.subs = [rospy.Subscriber(P("imu/topic"), msgs.Imu, queue_size=100, callback=self._serialised(self.imu_callback))]   # ImuManagerRos.cpp:11
         self.sensor_managers = {}
         compat = bool(P("reference_compat", True))
         for name, cfg in sorted(P("sensors").items()):                                   # gtsam_fusion_node.cpp:32-56
@@ -46,20 +60,44 @@ class FusionNode:
                 rospy.logwarn("Sensor %s has invalid type %s" % (name, kind))            # :52-55
                 continue
             use_cov = bool(cfg["use_odom_covariance"])
+            if "max_time_skip" not in cfg:
+                # the reference reads it with an unchecked getParam into an uninitialised double (SensorManagerRos.h:49,85;
+                # config/san_rafael/fusion_params.yaml has none): here "no limit", and a factor that an odometry gap makes
+                # wider than the device's band is dropped by SensorManager._add_between
+                rospy.logwarn("Sensor %s has no max_time_skip: odometry gaps are not filtered by time" % name)
             sm = SensorManager(self.graph, bool(cfg["optimize_after_odom"]), use_cov,
                                0.0 if use_cov else float(cfg["covariance_linear"]),      # SensorManagerRos.h:50-54
                                0.0 if use_cov else float(cfg["covariance_angular"]),
-                               float(cfg["max_time_skip"]), reference_compat=compat)
+                               float(cfg.get("max_time_skip", float("inf"))), reference_compat=compat)
             self.sensor_managers[name] = sm
             msg_type = msgs.PointCloud2 if kind == "PointCloud2" else msgs.Image
             self.subs.append(rospy.Subscriber(cfg["sensor_topic"], msg_type, queue_size=1,                    # SensorManagerRos.h:59
-                                              callback=lambda m, sm=sm: sm.sensorCallback(m.header.stamp.to_sec())))
+                                              callback=self._serialised(lambda m, sm=sm: sm.sensorCallback(m.header.stamp.to_sec()))))
             self.subs.append(rospy.Subscriber(cfg["odom_topic"], msgs.Odometry, queue_size=1,                 # :60
-                                              callback=lambda m, sm=sm: sm.odometryCallback(odometry_from_msg(m))))
+                                              callback=self._serialised(lambda m, sm=sm: sm.odometryCallback(odometry_from_msg(m)))))
         self.pub = rospy.Publisher("~odometry", msgs.Odometry, queue_size=1)             # gtsam_fusion_node.cpp:58
         self.broadcaster = tf2_ros.TransformBroadcaster()
         self.static_frame, self.odom_frame = P("tf/static_frame"), P("tf/odom_frame")    # :61-62
         self.graph.addOptimizationCallback(self.publish)                                 # :64
+
+    def _serialised(self, fn):
+        """fn under the node's lock; a keyframe-capacity error (lag = 0 on a long bag) is reported once, not raised per message"""
+        from .._lib import VilFusionError
+
+        def call(m):
+            with self._lock:
+                try:
+                    return fn(m)
+                except VilFusionError as exc:
+                    if exc.code != -6:                      # VF_ERR_CAPACITY
+                        raise
+                    if not self._capacity_reported:
+                        self._capacity_reported = True
+                        log = getattr(self.rospy, "logerr", None) or self.rospy.logwarn
+                        log("gtsam_fusion: %s -- no further nodes are added; run with ~solver/lag > 0 (fixed-lag smoothing) "
+                            "or a larger ~solver/capacity" % exc)
+                    return None
+        return call
 
     def imu_callback(self, m):                                                           # ImuManagerRos.cpp:38-52
         a, w = m.linear_acceleration, m.angular_velocity
@@ -93,7 +131,7 @@ def main():
     rospy.init_node("gtsam_fusion")
     FusionNode(rospy, tf2_ros, types.SimpleNamespace(Imu=Imu, Image=Image, PointCloud2=PointCloud2, Odometry=OdometryMsg,
                                                       TransformStamped=TransformStamped))
-    rospy.spin()          # one spinner thread: callbacks are serialised, as in the reference (gtsam_fusion_node.cpp:101)
+    rospy.spin()          # rospy delivers each subscription on its own thread: FusionNode serialises them (see the module docstring)
 
 
 if __name__ == "__main__":

@@ -72,6 +72,22 @@ class SensorManager:
             qr = _qmul(_qinv(before.orientation), after.orientation)
         return qr, dxr, after.twist_covariance
 
+    def _add_between(self, a, b, pose, cov):
+        """addBetweenFactor, failing soft where the device's band is narrower than iSAM2's arbitrary topology
+        (GraphManager.cpp:83-88 takes any pair of keys; libvilfusion takes |b - a| <= 3 keyframes and one factor per end
+        key -- INTEGRATION.md "Topology limits").  With Carla's max_time_skip = 0.1 s (20 Hz camera + 10 Hz LiDAR keyframes)
+        no factor the reference would add is wider; without it (config/san_rafael has no max_time_skip) an odometry gap
+        produces one, which is dropped here like a missed odometry message (:41-45 warns and carries on the same way)."""
+        from ._lib import VilFusionError
+        try:
+            self.gm.addBetweenFactor(a, b, pose, cov)
+            return True
+        except VilFusionError as exc:
+            if exc.code != -6:                  # VF_ERR_CAPACITY: span / second factor on a key
+                raise
+            self.warnings.append(f"between factor ({a}, {b}) not added: {exc}")
+            return False
+
     # SensorManagerRos.cpp:11-120
     def odometryCallback(self, msg: Odometry):
         if not self.has_received_odometry:
@@ -95,9 +111,8 @@ class SensorManager:
                 cov_ros = tw.T.copy()       # std::copy into a column-major Matrix66 (:87)
             else:                           # :91-97, filled [lin,lin,lin,ang,ang,ang] as the reference does
                 cov_ros = np.diag([self.covariance_linear] * 3 + [self.covariance_angular] * 3)
-            self.gm.addBetweenFactor(self.last_valid_key, found[1], (q, t), cov_ros)
-            added = True
-            if self.optimize_after_odom:
+            added = self._add_between(self.last_valid_key, found[1], (q, t), cov_ros)
+            if added and self.optimize_after_odom:
                 self.gm.solve()
         self.last_valid_odom = msg
         self.last_valid_key = found[1]

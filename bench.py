@@ -120,55 +120,85 @@ def make_engine(args, local_rank, windows, seqs, updates):
     for w in range(windows):
         eng.set_range(w, 0, n)
     eng.sync()
-    eng.iterate(args.iterations)      # converge the initial windows (not timed)
+    eng.iterate(args.init_iterations)      # converge the initial windows (not timed)
     eng.sync()
     return eng
 
 
 def _cpu_updates(job):
-    """`steps` fixed-lag updates of one n-pose window by the CPU oracle; returns the seconds the updates took
-    (problem construction -- preintegration, initial values -- is outside, as it is outside the GPU's timed region)."""
-    seed, n, steps, iterations, threads = job
+    """`steps` fixed-lag updates of one n-pose window by the CPU oracle, the SAME update the GPU's timed step does
+    (tests/helpers.FixedLagOracle: marginalise the leaving keyframe into the dense 27-dof prior and carry it, predict the
+    appended keyframe from its IMU factor, K LM trials).  Returns the seconds the updates took (problem construction --
+    preintegration, initial values, the initial converging solve -- is outside, as it is outside the GPU's timed region)
+    and the window's states after update number `snapshot_at` (what the accuracy figure compares with)."""
+    seed, n, n_kf, steps, iterations, threads, snapshot_at, init_iterations = job
     from oracle import oracle
     from tests import helpers
     from vil_sensor_fusion_amd import synth
-    seq = synth.make_sequence(seed=seed, n_kf=n + steps)
+    seq = synth.make_sequence(seed=seed, n_kf=n_kf)
+    assert n_kf >= n + steps + 1
     prob = helpers.build_problem(oracle, seq)
+    ref = helpers.FixedLagOracle(oracle, prob, n, iterations, threads, init_iterations=init_iterations)
+    snap = ref.window_states.copy() if snapshot_at == 0 else None
     t0 = time.perf_counter()
     for s in range(steps):
-        win = helpers.oracle_window(oracle, prob, lo=s, hi=s + n)
-        win.lm(iterations=iterations, n_threads=threads)
-        prob["states"][s:s + n] = win.states
-    return time.perf_counter() - t0
+        ref.update()
+        if s + 1 == snapshot_at:
+            snap = ref.window_states.copy()
+    return time.perf_counter() - t0, snap, (seq.gt_states[snapshot_at:snapshot_at + n] if snap is not None else None)
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, seq_len):
     """The CPU oracle (a port, not GTSAM: GTSAM cannot be built here) doing the same update on a bounded sample,
-    (a) one window on one host core, (b) one window per host core on ALL the cores this process may use (independent
-    windows are how this workload parallelises on a CPU too; the node-level figure is the honest one to hold the GPU
-    number against).  Runs before the process touches the GPU (forked workers)."""
+    (a) one window on one host core -- the window of seed 0, i.e. GPU window 0 of rank 0, so that its states after
+    warmup + steps updates are also the reference of the bench line's `accuracy` -- and (b) one window per host core on ALL
+    the cores this process may use (independent windows are how this workload parallelises on a CPU too; the node-level
+    figure is the honest one to hold the GPU number against).  Runs before the process touches the GPU (forked workers).
+    --no-cpu-baseline keeps only the updates the accuracy check needs and reports no timing."""
     from oracle import oracle
     oracle.build()
     n, cores = args.window, host_workers()
     note = ("C restatement (oracle/vf_oracle.c, gcc -O3 -march=x86-64-v3); the reference's CPU GTSAM path cannot be "
             "built or timed here (no GTSAM/Eigen/Boost/ROS)")
-    dt1 = _cpu_updates((0, n, args.cpu_steps, args.iterations, 1))
-    one = dict(value=args.cpu_steps / dt1, unit="keyframes/s", cores=1, kind="port", host_cores_available=cores,
-               sample=f"{args.cpu_steps} fixed-lag updates of one {n}-pose window, {args.iterations} LM trials each, "
-                      f"on 1 core; " + note)
+    done = args.steps + args.warmup
+    steps1 = done if args.no_cpu_baseline else max(args.cpu_steps, done)
+    dt1, snap, gt = _cpu_updates((0, n, seq_len, steps1, args.iterations, 1, done, args.init_iterations))
+    reference = dict(states=snap, gt=gt, updates=done)
+    if args.no_cpu_baseline:
+        return None, None, reference
+    one = dict(value=steps1 / dt1, unit="keyframes/s", cores=1, kind="port", host_cores_available=cores,
+               sample=f"{steps1} fixed-lag updates of one {n}-pose window (marginalise the oldest keyframe into the dense "
+                      f"prior, append + predict one, {args.iterations} LM trials: the update of the GPU's timed step, same "
+                      f"sequence as GPU window 0), on 1 core; " + note)
     allc = None
     if cores > 1:
         per = max(4, args.cpu_steps // 4)
         t0 = time.perf_counter()
         with multiprocessing.get_context("fork").Pool(cores) as pool:
-            busy = pool.map(_cpu_updates, [(1000 + c, n, per, args.iterations, 1) for c in range(cores)], chunksize=1)
+            res = pool.map(_cpu_updates, [(1000 + c, n, n + per + 1, per, args.iterations, 1, -1, args.init_iterations) for c in range(cores)], chunksize=1)
         wall = time.perf_counter() - t0
+        busy = [r[0] for r in res]
         # rate = updates / the slowest worker's update time (set-up of the problems excluded, as on the GPU side)
         allc = dict(value=cores * per / max(busy), unit="keyframes/s", cores=cores, kind="port",
                     host_cores_available=cores, wall_s_including_setup=wall,
-                    sample=f"{cores} independent {n}-pose windows, one per core, {per} fixed-lag updates each, "
-                           f"{args.iterations} LM trials per update; " + note)
-    return one, allc
+                    sample=f"{cores} independent {n}-pose windows, one per core, {per} fixed-lag updates each (the same "
+                           f"marginalised update), {args.iterations} LM trials per update; " + note)
+    return one, allc, reference
+
+
+def accuracy_vs_oracle(gpu_states, reference):
+    """ATE = sqrt(mean |t_est - t_ref|^2) over the window's keyframes, no alignment (gauge fixed by the priors),
+    and the largest rotation error 2 acos|q_w| of q_est^-1 q_ref (gtsam_fusion/python/diagnostics.py:114,122) -- GPU window 0
+    after the timed region against the CPU oracle after the same updates of the same sequence; and both against the
+    synthetic ground truth."""
+    from tests import helpers
+    ate, rot = helpers.ate(gpu_states, reference["states"])
+    gt_gpu, _ = helpers.ate(gpu_states, reference["gt"])
+    gt_cpu, _ = helpers.ate(reference["states"], reference["gt"])
+    return {"ate_m": ate, "rot_rad": rot, "updates": reference["updates"], "window": 0, "keyframes": int(gpu_states.shape[0]),
+            "vs": "CPU oracle (oracle/vf_oracle.c) after the same marginalised fixed-lag updates of the same sequence; "
+                  "GTSAM itself cannot be run here", "bar_m": 1e-6, "within_bar": bool(ate <= 1e-6 and rot <= 1e-6),
+            "ate_vs_ground_truth_m": {"gpu": gt_gpu, "cpu_oracle": gt_cpu}}
 
 
 def time_sharded_window(args, info, dist, backend, dev):
@@ -335,12 +365,18 @@ def main():
     ap.add_argument("--sequences", type=int, default=0,
                     help="distinct synthetic sequences (seeds) per rank; 0 = one per window (SURVEY 8d)")
     ap.add_argument("--iterations", type=int, default=5, help="LM trials per update")
+    ap.add_argument("--init-iterations", type=int, default=200,
+                    help="LM trials of the untimed solve that converges every window before the first update (GPU and CPU "
+                         "legs alike).  A 1000-pose window started from IMU dead reckoning needs 50-150 to converge; slid "
+                         "while it is still far from its optimum, the soft global yaw / position mode of the marginal prior "
+                         "keeps two float64 implementations 1e-5 m apart (DESIGN.md, Converged start)")
     ap.add_argument("--cpu-steps", type=int, default=64,
                     help="fixed-lag updates the one-core CPU baseline is timed on (64 = about 5 s)")
     ap.add_argument("--host-workers", type=int, default=0,
                     help="processes that generate the synthetic sequences (0 = the host cores this job may use; 1 = no worker "
                          "processes, e.g. under a profiler)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the CPU oracle altogether (no accuracy object, no cpu_baseline)")
     ap.add_argument("--no-single-window", action="store_true")
     ap.add_argument("--reanchor", action="store_true", help="drop the oldest keyframe by re-anchoring tight priors instead of marginalising it")
     ap.add_argument("--sharded-window", type=int, default=10000, help="keyframes of the time-sharded window (BASELINE configs[4])")
@@ -364,12 +400,17 @@ def main():
     rank_env = int(os.environ.get("RANK", "0"))
 
     # ---- host-only phase: everything that forks worker processes happens before the first GPU call
-    cpu_one = cpu_all = None
-    if rank_env == 0 and world_env == 1 and not args.no_cpu_baseline:      # the CPU legs: rank 0 at N = 1 only
-        cpu_one, cpu_all = cpu_baseline(args)
+    cpu_one = cpu_all = reference = None
     updates = updates_per_engine(args)
+    # every sequence is generated at ONE length (make_sequence is not prefix-stable in its length): what the engine's
+    # updates need, and what the one-core CPU leg needs to run its sample on the sequence of GPU window 0
+    if world_env > 1:
+        args.no_cpu_baseline = True      # the CPU legs are timed at N = 1 only; at N > 1 just the updates the accuracy figure needs
+    seq_len = args.window + max(updates, 0 if (args.no_cpu_baseline or args.no_accuracy) else args.cpu_steps) + 1
+    if rank_env == 0 and not args.no_accuracy:
+        cpu_one, cpu_all, reference = cpu_baseline(args, seq_len)
     nseq = args.sequences if args.sequences > 0 else args.windows
-    seqs = make_sequences(args, rank_env, max(1, min(nseq, args.windows)), args.window + updates + 1)
+    seqs = make_sequences(args, rank_env, max(1, min(nseq, args.windows)), seq_len)
     one_updates = 7
     one_seq = make_sequences(args, rank_env, 1, args.window + one_updates + 1, base_seed=7777)
 
@@ -409,6 +450,9 @@ def main():
     dt = D.max_over_ranks(dist, time.perf_counter() - t0, device=dev if (dist is not None and backend == "nccl") else "cpu")
     summaries = D.gather_summaries(dist, dict(rank=info.rank, keyframes=args.windows * args.steps))
     lm_after_timed = eng.read_lm(0)
+    accuracy = None
+    if reference is not None and reference["states"] is not None:
+        accuracy = accuracy_vs_oracle(eng.get_states(0, args.steps + args.warmup, args.window), reference)
 
     # Same update with GTSAM's LM termination rule switched on (vf_engine_set_convergence): a second,
     # clearly labelled number -- the headline above always runs all K trials on every window.  It continues on the
@@ -518,6 +562,7 @@ def main():
                              "achieved": counts["imu"] * IMU_BYTES_DENSE / (k1_ms * 1e-3) / 1e9,
                              "frac": counts["imu"] * IMU_BYTES_DENSE / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                              "note": "counts the 159 structurally zero Jacobian entries that are no longer written"}},
+            "accuracy": accuracy,
             "stage_ms": stages,
             "lm_state_window0": lm_after_timed,
         }

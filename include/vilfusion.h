@@ -62,6 +62,16 @@ typedef struct {
                                solve (chunks joined by 27-dof separators, about sqrt(n) of them for an
                                n-keyframe window: one-window latency); more windows -> one sweep per window
                                (throughput).  1 = always sweeps.  P >= 2 = partitioned solve with P chunks. */
+    /* Solver-form switches.  vf_engine_default_opts sets the measured optimum; they are fields, not environment variables,
+     * so that the library's behaviour never depends on the caller's environment (tests and tools set them to reach one
+     * form on purpose). */
+    int sweep_two_sided_max; /* whole-window sweeps: up to this many windows, two waves per window eliminate from both ends
+                                (latency); above, one wave per window (throughput).  Default 256; 0 = always one wave. */
+    int hybrid_threshold;    /* with vf_engine_set_convergence on a sweep engine of > 128 windows: once at most this many
+                                windows still take trials, K4 runs as the partitioned form.  Default 256; < 0 = never. */
+    int cold_start;          /* != 0: every vf_engine_iterate linearises all factors (no warm start); default 0 */
+    int use_hip_graph;       /* != 0: vf_engine_iterate replays its launch sequence from a captured hipGraph (measured no
+                                faster: the stream never runs empty); default 0 */
 } vf_engine_opts;
 
 void vf_engine_default_opts(vf_engine_opts* o);
@@ -110,10 +120,6 @@ int vf_engine_retract(vf_engine* e);
 int vf_engine_decide(vf_engine* e, int init);
 /* `iterations` LM trials (linearize once, then {assemble, solve, retract, linearize(trial),
  * decide} per trial).  Replaces ISAM2::update + calculateEstimate (GraphManager.cpp:126-127).
- * With VF_FUSED=1 in the environment at vf_engine_create, whole-window-sweep engines run the IMU linearisation and the
- * assembly as ONE kernel here (the whitened Jacobians stay in LDS, the trial's normal equations are written beside the
- * current ones; results equal to rounding, measured slower: DESIGN.md "K1 + K3 fused"); VF_FUSED=2 selects the lane-per-factor
- * form of that kernel (no Jacobian at all; also slower).  The stage calls above keep their unfused meaning on every engine.
  * Warm start: when nothing but vf_engine_slide has touched the engine since the previous
  * vf_engine_iterate, the opening linearisation covers only the appended keyframes' factors and
  * the priors, and the first assembly only the ends of windows whose last trial was rejected --
@@ -216,7 +222,6 @@ int vf_engine_read_lm(vf_engine* e, int window, double* cost, double* lambda, in
 #define VF_STAGE_RETRACT 5
 #define VF_STAGE_DECIDE 6
 #define VF_STAGE_ASSEMBLE_IDLE 7   /* K3 when every window's last trial was rejected: nothing to assemble, the cost of its launch */
-#define VF_STAGE_LINEARIZE_ASSEMBLE 8 /* K1 + K3 fused (engines created with VF_FUSED=1 or 2 in the environment; off by default: slower) */
 int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms);
 /* HIP-event time of a whole vf_engine_iterate(iterations) */
 int vf_engine_time_iterate(vf_engine* e, int iterations, float* ms);
@@ -278,6 +283,7 @@ typedef struct {
      * cost by <= abs_tol or <= rel_tol * cost.  Defaults 1e-5 / 1e-5 = gtsam::LevenbergMarquardtParams (the optimiser at
      * GraphManager.cpp:128-129); 0 / 0 = always `iterations` trials. */
     double rel_tol, abs_tol;
+    int cold_start;  /* != 0: the handle's engine never warm-starts a solve (vf_engine_opts.cold_start); default 0 */
     /* reference_compat != 0: vf_solve does what the reference's solve() does -- one iSAM2-like update
      * (vf_engine_isam_step with relin_threshold, default 1e-4 = GraphManager.cpp:40) instead of LM to convergence; needs
      * lag == 0 (the reference's graph is unbounded).  Default 0. */

@@ -73,3 +73,62 @@ def tolerance_sweep(y, ref, mask=None):
         y, ref = y[mask[1:]], ref[mask[1:]]
     rel = np.abs(y - ref) / np.maximum(np.abs(ref), 1e-300)
     return [float(np.mean(rel <= t)) for t in SWEEP_TOLS]
+
+
+class FixedLagOracle:
+    """The CPU oracle doing bench.py's fixed-lag update (Engine.slide(marginalize=True) + iterate(K)) on one window:
+
+        init:    window [0, n) with the anchor prior of keyframe 0, K LM trials
+        update:  marginalise the oldest keyframe at the current linearisation (vfo_marginalize: Schur complement of its
+                 prior / previous marginal prior, its IMU factor and the between factors that start at it, onto
+                 [next: 15][next+1: pose][next+2: pose]); append one keyframe, initial value by IMU prediction
+                 (GraphManager.cpp:152-160); K LM trials on [s, s+n) with the marginal prior
+
+    prob: helpers.build_problem(...) of a sequence with at least n + updates keyframes (its `states` beyond the first
+    window are ignored: appended keyframes are predicted from the running estimate, as the engine does)."""
+
+    def __init__(self, oracle, prob, n, iterations, threads=1, init_iterations=None):
+        """init_iterations: LM trials of the initial solve (default: `iterations`).  A 1000-pose window started from
+        IMU dead reckoning needs 50-150 trials to converge; slid while still far from its optimum it stays in a regime
+        where two float64 implementations drift apart by 1e-5 m (DESIGN.md "Converged start")."""
+        self.o, self.prob, self.n, self.K, self.threads = oracle, prob, n, iterations, threads
+        self.rel_tol = self.abs_tol = 0.0            # > 0: GTSAM's LM termination rule in the updates that follow
+        self.states = prob["states"].copy()
+        self.s, self.marg = 0, None
+        self.win = self._window(0, None, True)
+        self.costs, self.acc, _ = self.win.lm(iterations=iterations if init_iterations is None else init_iterations, n_threads=threads)
+        self.states[:n] = self.win.states
+
+    def _window(self, lo, marg, with_prior):
+        p, hi = self.prob, lo + self.n
+        m = (p["btw_a"] >= lo) & (p["btw_b"] < hi)
+        ks = np.arange(lo + 1, hi)
+        pk = np.array([0], dtype=np.int32) if with_prior else np.zeros(0, dtype=np.int32)
+        pd = p["prior"].reshape(1, -1) if with_prior else np.zeros((0, 31))
+        w = self.o.Window(self.states[lo:hi], ks - 1 - lo, ks - lo, p["imu"][lo + 1:hi], p["btw_a"][m] - lo,
+                          p["btw_b"][m] - lo, p["btw"][m], pk, pd, p["gravity"])
+        if marg is not None:
+            w.set_marg(marg)
+        return w
+
+    def update(self):
+        """one fixed-lag update; returns the window's states afterwards (keyframes [s, s + n))"""
+        p, n = self.prob, self.n
+        self.marg = self.win.marginalize(0)          # (self.win still holds the previous window, its prior / marginal prior attached)
+        self.marg.k0 = 0
+        self.s += 1
+        s = self.s
+        self.states[s + n - 1] = self.o.predict(p["imu"][s + n - 1], p["gravity"], self.states[s + n - 2])
+        self.win = self._window(s, self.marg, False)
+        self.costs, self.acc, _ = self.win.lm(iterations=self.K, n_threads=self.threads, rel_tol=self.rel_tol, abs_tol=self.abs_tol)
+        self.states[s:s + n] = self.win.states
+        return self.win.states
+
+    @property
+    def trials(self):
+        """LM trials the last update took (acc = -1 marks the ones a termination rule left out)"""
+        return int(np.sum(np.asarray(self.acc) >= 0))
+
+    @property
+    def window_states(self):
+        return self.states[self.s:self.s + self.n]

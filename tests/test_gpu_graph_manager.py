@@ -330,23 +330,18 @@ def _stream(seq):
 
 
 @pytest.mark.parametrize("lag", [0, 30])
-def test_graph_manager_warm_start_equals_cold_start(lag, monkeypatch):
+def test_graph_manager_warm_start_equals_cold_start(lag):
     """vf_solve's call sequence (K0 + prediction + between factors for the NEW keyframes, marginalisation of the ones
     that leave, set_range) keeps the engine warm: the solve linearises only the appended tail.  Fed like the node --
     one solve per camera keyframe, LiDAR odometry arriving one keyframe late (a between factor INSIDE the window the
-    previous solve covered) -- it must give, solve for solve, bit for bit, what the cold path gives (VF_NO_WARM=1)."""
+    previous solve covered) -- it must give, solve for solve, bit for bit, what the cold path gives (vf_graph_opts.cold_start)."""
     from vil_sensor_fusion_amd.graph_manager import GraphManager
     n = 90
     seq = synth.make_sequence(61, n)
     traj_t, acc, gyr = _stream(seq)
 
     def run(cold):
-        if cold:
-            monkeypatch.setenv("VF_NO_WARM", "1")
-        else:
-            monkeypatch.delenv("VF_NO_WARM", raising=False)
-        gm = GraphManager(capacity=128, iterations=4, lag=lag)
-        monkeypatch.delenv("VF_NO_WARM", raising=False)
+        gm = GraphManager(capacity=128, iterations=4, lag=lag, cold_start=cold)
         out, late, i_imu = [], [], 0
         for k in range(1, n):
             while i_imu < traj_t.size and traj_t[i_imu] <= seq.kf_time[k] + 0.01:

@@ -1,0 +1,158 @@
+"""-m gpu: the EXACT path bench.py's headline number runs, against the oracle doing the same updates.
+
+bench.py: B = 1024 windows x 1000 poses -> launch_band_solve picks k_band_solve (one wave per window, the throughput form,
+B > vf_engine_opts.sweep_two_sided_max = 256), every update = vf_engine_slide(marginalize = 1) (K-marg: dense 27-dof prior,
+6x15 strip on the window's third keyframe) + warm-started vf_engine_iterate(5).  Earlier marginalised-slide tests ran 2-3
+windows, i.e. the two-sided sweep or the partitioned form.  Here: > 256 windows of 1000 poses
+(distinct sequences in the sampled windows, factors preintegrated on the device as bench.py's make_engine does), >= 10
+marginalised warm-started slides, the sampled windows compared update by update with helpers.FixedLagOracle; and the
+same with the LM termination rule on, where K4 runs as the hybrid of the sweep and the partitioned form."""
+import numpy as np
+import pytest
+
+from tests import helpers
+from vil_sensor_fusion_amd import Engine, EngineOpts, synth
+from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
+
+pytestmark = pytest.mark.gpu
+
+N, SLIDES, ITERS = 1000, 10, 5
+INIT = 200        # LM trials of the initial solve: bench.py's --init-iterations (a converged start)
+
+
+def _bench_like_engine(oracle, windows, sampled, slides, **opts):
+    """make_engine of bench.py: K0 on the device, predicted initial values, one converging solve.  The sampled windows
+    get sequences of their own; their oracle problems use the DEVICE's preintegrated records, so both sides hold
+    identical factors (K0 has its own parity test)."""
+    total = N + slides + 1
+    eng = Engine(EngineOpts(windows=windows, capacity=total, **opts))
+    filler = synth.make_sequence(seed=900, n_kf=total)
+    seqs = {w: synth.make_sequence(seed=901 + i, n_kf=total) for i, w in enumerate(sampled)}
+    frec = synth.between_records(filler)
+    for w in range(windows):
+        seq = seqs.get(w, filler)
+        rec = synth.between_records(seq) if w in seqs else frec
+        eng.preintegrate(w, 1, seq.imu_off[1:total + 1], seq.imu_steps, np.zeros(6), synth.CARLA_IMU_COV)
+        eng.set_between(w, seq.btw_a, seq.btw_b, rec)
+        eng.set_states(w, 0, seq.gt_states[0].reshape(1, 16))
+        eng.set_prior(w, 0, synth.prior_record(seq.gt_states[0], REFERENCE_PRIOR_SIGMAS))
+        eng.set_range(w, 0, 1)
+    eng.predict(-1, 1, N - 1)
+    for w in range(windows):
+        eng.set_range(w, 0, N)
+    probs = {}
+    g = np.array([0.0, 0.0, -9.81])
+    for w, seq in seqs.items():
+        imu = np.zeros((total, 190))
+        imu[1:] = eng.get_imu(w, 1, total - 1)
+        states = np.zeros((total, 16))
+        states[:N] = eng.get_states(w, 0, N)                 # the device's IMU-predicted initial values
+        probs[w] = dict(n=total, states=states, imu=imu, btw_a=seq.btw_a, btw_b=seq.btw_b, btw=synth.between_records(seq),
+                        prior=synth.prior_record(seq.gt_states[0], REFERENCE_PRIOR_SIGMAS), gravity=g)
+    return eng, probs
+
+
+def test_one_wave_sweep_marginalised_warm_slides_vs_oracle(oracle):
+    B, sampled = 260, (0, 129, 259)
+    eng, probs = _bench_like_engine(oracle, B, sampled, SLIDES)
+    eng.iterate(INIT)
+    refs = {w: helpers.FixedLagOracle(oracle, probs[w], N, ITERS, init_iterations=INIT) for w in sampled}
+    for w in sampled:
+        a, r = helpers.ate(eng.get_states(w, 0, N), refs[w].window_states)
+        assert a <= 1e-6 and r <= 1e-6, ("initial solve", w, a, r)
+    worst = 0.0
+    for s in range(1, SLIDES + 1):
+        eng.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)     # K-marg + predicted new keyframe; the engine stays warm
+        eng.iterate(ITERS)
+        for w in sampled:
+            ref = refs[w].update()
+            a, r = helpers.ate(eng.get_states(w, s, N), ref)
+            lm = eng.read_lm(w)
+            worst = max(worst, a)
+            assert a <= 1e-6 and r <= 1e-6, (s, w, a, r)
+            assert lm["solve_failures"] == 0
+            assert abs(lm["cost"] - refs[w].costs[-1]) <= 1e-6 * abs(refs[w].costs[-1]), (s, w, lm["cost"], refs[w].costs[-1])
+            if s in (1, SLIDES):
+                got, exp = eng.read_marginal(w), refs[w].marg.arrays()
+                assert got["on"] == 1
+                np.testing.assert_allclose(got["L"], exp["L"], atol=1e-9 * np.abs(exp["L"]).max())
+    print(f"k_band_solve (one wave per window), {B} windows x {N} poses, {SLIDES} marginalised warm slides: worst ATE {worst:.3e} m")
+    # the same engine with warm start switched off gives the same bits (the headline's warm path against the cold one)
+    cold, _ = _bench_like_engine(oracle, B, sampled, SLIDES, cold_start=True)
+    cold.iterate(INIT)
+    for s in range(1, SLIDES + 1):
+        cold.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)
+        cold.iterate(ITERS)
+    for w in sampled:
+        np.testing.assert_array_equal(cold.get_states(w, SLIDES, N), eng.get_states(w, SLIDES, N))
+    cold.close()
+    eng.close()
+
+
+def test_two_sided_threshold_zero_forces_the_one_wave_form(oracle):
+    """vf_engine_opts.sweep_two_sided_max = 0: k_band_solve even for a handful of windows (what tools and this test use to
+    reach the throughput form cheaply): marginalised slides of ragged windows against the oracle."""
+    n, slides = 120, 6
+    seq = synth.make_sequence(seed=77, n_kf=n + slides + 1)
+    prob = helpers.build_problem(oracle, seq)
+    eng = Engine(EngineOpts(windows=3, capacity=n + slides + 1, chunks=1, sweep_two_sided_max=0))
+    for w in range(3):
+        helpers.load_engine(eng, w, prob, lo=0, hi=n)
+    eng.iterate(4)
+    ref = helpers.FixedLagOracle(oracle, prob, n, 4)
+    for s in range(1, slides + 1):
+        eng.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)
+        eng.iterate(4)
+        st = ref.update()
+        for w in range(3):
+            a, r = helpers.ate(eng.get_states(w, s, n), st)
+            assert a <= 1e-6 and r <= 1e-6
+    eng.close()
+
+
+def test_hybrid_solve_with_termination_rule_marginalised_slides_vs_oracle(oracle):
+    """bench.py's `with_convergence_exit` path: the same updates with GTSAM's LM rule on (1e-5 / 1e-5).  K4 launches both
+    forms per trial; with 260 windows and the default threshold of 256 the sweep runs while more than 256 windows take
+    trials and the partitioned form afterwards.  The oracle applies the same rule (vfo_lm rel_tol / abs_tol).
+
+    Tolerances.  The rule ends an update once a trial changes the cost by <= 1e-5, i.e. after one or two trials here; that
+    leaves the soft mode of a fixed-lag window (global yaw / position, held only by the marginal prior: information 1e-2
+    against 1e9 in the stiff IMU directions) wherever the last step put it, and a step's component in that mode is
+    accurate to cond * eps ~ 2e-5 of its length in ANY float64 normal-equation solver (the far end of the window moves
+    by centimetres per update -> a few 1e-6 m between two implementations, growing linearly along the window).  So
+    under the rule the trajectories are compared at 1e-5 m, the costs at 1e-8 and the trial counts exactly +-1; then
+    the rule is switched off and ONE update with all K trials must bring the two back within the 1e-6 m bar."""
+    B, sampled = 260, (3, 200)
+    eng, probs = _bench_like_engine(oracle, B, sampled, SLIDES + 1)
+    eng.iterate(INIT)
+    eng.set_convergence(1e-5, 1e-5)
+    refs = {w: helpers.FixedLagOracle(oracle, probs[w], N, ITERS, init_iterations=INIT) for w in sampled}
+    for r in refs.values():
+        r.rel_tol = r.abs_tol = 1e-5
+    trials_saved, worst = 0, 0.0
+    for s in range(1, SLIDES + 1):
+        eng.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)
+        before = {w: eng.read_lm(w) for w in sampled}
+        eng.iterate(ITERS)
+        for w in sampled:
+            st = refs[w].update()
+            lm = eng.read_lm(w)
+            got_trials = lm["accepted"] + lm["rejected"] - before[w]["accepted"] - before[w]["rejected"]
+            a, rot = helpers.ate(eng.get_states(w, s, N), st)
+            worst = max(worst, a)
+            assert a <= 1e-5 and rot <= 1e-6, (s, w, a, rot)
+            assert abs(lm["cost"] - refs[w].costs[-1]) <= 1e-8 * abs(refs[w].costs[-1]), (s, w, lm["cost"], refs[w].costs[-1])
+            assert abs(got_trials - refs[w].trials) <= 1, (s, w, got_trials, refs[w].trials)
+            assert lm["solve_failures"] == 0
+            trials_saved += ITERS - got_trials
+    assert trials_saved > 0              # the rule did end some solves early, i.e. the gated forms were exercised
+    eng.set_convergence(0.0, 0.0)
+    eng.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)
+    eng.iterate(ITERS)
+    for w in sampled:
+        refs[w].rel_tol = refs[w].abs_tol = 0.0
+        st = refs[w].update()
+        a, rot = helpers.ate(eng.get_states(w, SLIDES + 1, N), st)
+        print(f"window {w}: worst ATE under the rule {worst:.3e} m; after one full update without it {a:.3e} m")
+        assert a <= 1e-6 and rot <= 1e-6, (w, a, rot)
+    eng.close()

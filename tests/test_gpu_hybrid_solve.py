@@ -12,34 +12,28 @@ from vil_sensor_fusion_amd import Engine, EngineOpts, synth
 pytestmark = pytest.mark.gpu
 
 
-def _run(monkeypatch, threshold, probs, picks, n, B, iters):
-    if threshold is None:
-        monkeypatch.setenv("VF_NO_HYBRID", "1")
-    else:
-        monkeypatch.delenv("VF_NO_HYBRID", raising=False)
-        monkeypatch.setenv("VF_HYBRID_T", str(threshold))
-    eng = Engine(EngineOpts(windows=B, capacity=n + 10))
+def _run(threshold, probs, picks, n, B, iters):
+    """threshold = vf_engine_opts.hybrid_threshold (None: never the partitioned form)"""
+    eng = Engine(EngineOpts(windows=B, capacity=n + 10, hybrid_threshold=-1 if threshold is None else threshold))
     for w, (lo, hi) in picks.items():
         helpers.load_engine(eng, w, probs[w], lo=lo, hi=hi)
     eng.set_convergence(1e-5, 1e-5)
     eng.iterate(iters)
     out = {w: (eng.get_states(w, lo, hi - lo), eng.read_lm(w)) for w, (lo, hi) in picks.items()}
     eng.close()
-    monkeypatch.delenv("VF_HYBRID_T", raising=False)
-    monkeypatch.delenv("VF_NO_HYBRID", raising=False)
     return out
 
 
-def test_hybrid_solve_matches_sweeps_and_oracle(oracle, monkeypatch):
+def test_hybrid_solve_matches_sweeps_and_oracle(oracle):
     n, B, iters = 150, 160, 8
     picks = {0: (0, n), 77: (3, 131), 159: (17, n), 80: (0, 40), 5: (0, 96)}
     probs = {}
     for w in picks:
         seq = synth.make_sequence(seed=500 + w, n_kf=n)
         probs[w] = helpers.build_problem(oracle, seq, perturb=0.003 if w % 2 else 0.03)
-    sweep = _run(monkeypatch, None, probs, picks, n, B, iters)          # sweeps only
-    always = _run(monkeypatch, 100000, probs, picks, n, B, iters)       # the partitioned form from the first trial on
-    mixed = _run(monkeypatch, 3, probs, picks, n, B, iters)             # sweeps until <= 3 of the 5 windows are left
+    sweep = _run(None, probs, picks, n, B, iters)          # sweeps only
+    always = _run(100000, probs, picks, n, B, iters)       # the partitioned form from the first trial on
+    mixed = _run(3, probs, picks, n, B, iters)             # sweeps until <= 3 of the 5 windows are left
     for w, (lo, hi) in picks.items():
         win = helpers.oracle_window(oracle, probs[w], lo=lo, hi=hi)
         costs, acc, _ = win.lm(iterations=iters, rel_tol=1e-5, abs_tol=1e-5)

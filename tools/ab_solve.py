@@ -24,9 +24,4 @@ eng.linearize(0); eng.decide(init=True); eng.assemble(); eng.sync()
 r = [eng.time_stage('solve', 5) for _ in range(3)]
 a = [eng.time_stage('assemble', 5) for _ in range(3)] + [eng.time_stage('assemble_idle', 5) for _ in range(2)]
 k1 = [eng.time_stage('linearize_imu', 10) for _ in range(3)]
-try:
-    fu = [eng.time_stage('linearize_assemble', 5) for _ in range(3)]
-    print(os.path.basename(sys.argv[1]), 'K1+K3 fused ms', ' '.join(f'{x:.3f}' for x in fu))
-except Exception as exc:
-    print('no fused stage:', exc)
 print(os.path.basename(sys.argv[1]), 'K1 ms', ' '.join(f'{x:.3f}' for x in k1), ' solve ms', ' '.join(f'{x:.3f}' for x in r), ' assemble ms (last two: idle)', ' '.join(f'{x:.3f}' for x in a))

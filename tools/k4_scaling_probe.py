@@ -1,5 +1,5 @@
 """K4 (one-wave-per-window sweep) launch time against the number of windows per CU: 256 / 512 / 768 / 1024 windows = 1 / 2 / 3 / 4
-waves per CU.  usage: VF_TWISTED_MAX_WINDOWS=0 python tools/k4_scaling_probe.py"""
+waves per CU.  usage: python tools/k4_scaling_probe.py"""
 import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vil_sensor_fusion_amd import Engine, EngineOpts, synth
@@ -8,7 +8,7 @@ N = 1000
 seq = synth.make_sequence(0, N)
 rec = synth.between_records(seq)
 for B in (256, 512, 768, 1024):
-    eng = Engine(EngineOpts(windows=B, capacity=N, chunks=1))
+    eng = Engine(EngineOpts(windows=B, capacity=N, chunks=1, sweep_two_sided_max=0))
     for w in range(B):
         eng.preintegrate(w, 1, seq.imu_off[1:], seq.imu_steps, np.zeros(6), synth.CARLA_IMU_COV)
         eng.set_between(w, seq.btw_a, seq.btw_b, rec)

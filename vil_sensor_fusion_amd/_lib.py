@@ -22,7 +22,9 @@ class EngineOptsC(C.Structure):
     _fields_ = [("windows", C.c_int), ("capacity", C.c_int), ("bandwidth", C.c_int),
                 ("device", C.c_int), ("gravity", C.c_double * 3),
                 ("lambda0", C.c_double), ("lambda_up", C.c_double), ("lambda_down", C.c_double),
-                ("lambda_min", C.c_double), ("lambda_max", C.c_double), ("chunks", C.c_int)]
+                ("lambda_min", C.c_double), ("lambda_max", C.c_double), ("chunks", C.c_int),
+                ("sweep_two_sided_max", C.c_int), ("hybrid_threshold", C.c_int), ("cold_start", C.c_int),
+                ("use_hip_graph", C.c_int)]
 
 
 class ImuParamsC(C.Structure):
@@ -40,7 +42,7 @@ class ShardInfoC(C.Structure):
 class GraphOptsC(C.Structure):
     _fields_ = [("capacity", C.c_int), ("lag", C.c_int), ("iterations", C.c_int), ("device", C.c_int),
                 ("prior_sigma", C.c_double * 15), ("rel_tol", C.c_double), ("abs_tol", C.c_double),
-                ("reference_compat", C.c_int), ("relin_threshold", C.c_double)]
+                ("cold_start", C.c_int), ("reference_compat", C.c_int), ("relin_threshold", C.c_double)]
 
 
 CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),

@@ -51,7 +51,7 @@ struct vf_engine {
     vf_engine_opts opts{};
     hipStream_t stream = nullptr;
     bool own_stream = true;   // false once the caller has handed in its own stream (vf_engine_set_stream)
-    // VF_USE_GRAPH=1: vf_engine_iterate replays its launch sequence (6 + 9 K kernels / memsets) from a captured
+    // vf_engine_opts.use_hip_graph: vf_engine_iterate replays its launch sequence (6 + 9 K kernels / memsets) from a captured
     // hipGraph; re-captured when the trial count or any scalar baked into the kernel arguments changes
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -78,7 +78,7 @@ struct vf_engine {
     bool warm = false;
     int slid = 0;             // keyframes appended since the last solve
     int redo = 0;             // slots in front of the old window end whose factors changed since (see touch())
-    bool no_warm = false;     // VF_NO_WARM=1 at creation: every solve starts cold (tests compare the two)
+    bool no_warm = false;     // vf_engine_opts.cold_start: every solve starts cold (tests compare the two)
     // hybrid K4 (vf_kernels.hpp "View::gate"): buffers and chunk count of the partitioned form for a sweep engine, allocated
     // when the termination rule is first switched on
     bool hybrid = false;
@@ -166,6 +166,10 @@ void vf_engine_default_opts(vf_engine_opts* o) {
     // GraphManager.cpp:128-129): lambdaInitial 1e-5, lambdaFactor 10
     o->lambda0 = 1e-5; o->lambda_up = 10.0; o->lambda_down = 10.0;
     o->lambda_min = 1e-12; o->lambda_max = 1e10;
+    o->sweep_two_sided_max = 256;
+    o->hybrid_threshold = 256;   // partitioned form: 0.0095 ms per window; the sweep: 2.9 ms whatever their number
+    o->cold_start = 0;
+    o->use_hip_graph = 0;
 }
 
 int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
@@ -208,25 +212,16 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.mp_L, (size_t)v.B * 729);
     AL(v.mp_eta, (size_t)v.B * 27);
     AL(v.mp_out, 2 * (size_t)v.B * 28);
-    // K4 form first (it decides whether K1 + K3 run fused): chunks = 0 picks it from the batch size: up to 128 windows ->
-    // partitioned solve with at most 96 chunks, fewer on short windows (latency form); more windows -> one sweep per
-    // window (throughput form; the partitioned solve does about twice the arithmetic).  1 forces sweeps.
+    // K4 form: chunks = 0 picks it from the batch size: up to 128 windows -> partitioned solve with at most 96 chunks,
+    // fewer on short windows (latency form); more windows -> one sweep per window (throughput form; the partitioned
+    // solve does about twice the arithmetic).  1 forces sweeps.
     v.P = o->chunks >= 2 ? o->chunks : (o->chunks == 0 && o->windows <= 128 ? 96 : 0);
     v.P_fit = o->chunks == 0 ? 1 : 0;
     // (the chunk kernels launch windows x P workgroups: no more chunks than a full window could use)
     if (v.P_fit && v.P) v.P = vf::chunk_count(v.M, v.P, 1);
     if (v.P < 2) v.P = 0;
-    // K1 + K3 fused (k_linearize_assemble: the Jacobians stay in LDS, H and g double-buffered like the states) is built,
-    // bit-identical to the unfused kernels (tests/test_gpu_fused.py) and OFF by default: measured on the bench workload
-    // (1 024 x 1 000) one launch takes 6.1 ms against K1 0.84 + K3 1.93 ms -- a factor's linearisation is a 28 us latency
-    // chain and its 3.7 KB of (r | J) limit an LDS tile to 9 factors, i.e. one wave per SIMD with 9 of 64 lanes busy and
-    // nothing to hide the chain behind (DESIGN.md "K1 + K3 fused").  VF_FUSED=1 switches it on for whole-window-sweep
-    // engines (A/B measurements, tests).
-    v.fused = 0;
-    if (const char* f = getenv("VF_FUSED")) v.fused = (atoi(f) != 0 && v.P == 0) ? (atoi(f) == 2 ? 2 : 1) : 0;   // 2: lane per factor (k_lin_asm_v)
-    const size_t hb = v.fused ? 2 : 1;
-    AL(v.H, hb * G * vf::HROW);
-    AL(v.gvec, hb * G * 15 + 64); // + slack: the solver's row fetch reads 64 lanes of a 15-double row (the excess is never used)
+    AL(v.H, G * vf::HROW);
+    AL(v.gvec, G * 15 + 64); // + slack: the solver's row fetch reads 64 lanes of a 15-double row (the excess is never used)
     AL(v.zrow, vf::HROW);         // a block row of zeros: what the solver fetches for rows outside the window
     AL(v.delta, G * 15 + (size_t)v.B);   // + one solve-failure flag per window (time-sharded windows: reduced with the increments)
     AL(v.Lp, G * vf::PANEL);
@@ -251,8 +246,8 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.done, (size_t)v.B);
     AL(v.n_active, 4);
     v.gate = 0;
-    v.gate_T = 256;           // partitioned form: 0.0095 ms per window; the sweep: 3.1 ms whatever their number
-    if (const char* t = getenv("VF_HYBRID_T")) v.gate_T = atoi(t);
+    v.gate_T = o->hybrid_threshold;
+    v.tw_max = o->sweep_two_sided_max;
     v.stop_on = 0;
     v.rel_tol = v.abs_tol = 0.0;
     v.sh_r = 0;
@@ -269,8 +264,8 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     // measured on MI355X (ROCm 7.0, one 1000-pose window, K = 5): 2.99 ms replayed from the graph vs 2.91 ms
     // with plain asynchronous launches -- the queue is never empty, so there is no launch gap to remove.
     // Hence opt-in only.
-    e->graph_off = getenv("VF_USE_GRAPH") == nullptr;
-    e->no_warm = getenv("VF_NO_WARM") != nullptr;
+    e->graph_off = o->use_hip_graph == 0;
+    e->no_warm = o->cold_start != 0;
     HIPCHK(hipStreamSynchronize(e->stream));
     e->h_lo.assign(v.B, 0);
     e->h_hi.assign(v.B, 0);
@@ -564,33 +559,6 @@ static int iterate_sequence(vf_engine* e, int iterations) {
     int rc;
     const int tail = e->slid + e->redo;
     const int slid = (e->warm && e->v.sh_G <= 1 && tail >= 1 && tail <= 8) ? tail : 0;
-    if (e->v.fused) {
-        // K1 + K3 fused (vf_kernels.hip "k_linearize_assemble"): the trial's normal equations are written beside the current
-        // ones by the kernel that linearises the trial, so a trial is K4, K5a, K2 (+ priors), K1+K3, K5b -- no Jacobian
-        // in HBM, no separate assembly, nothing to redo after a rejected trial.
-        if (slid) {
-            // warm start: H, g of buffer sel are still those of the current states except at the two ends of a window
-            HIPCHK(hipMemsetAsync(e->v.done, 0, e->v.B * sizeof(int), e->stream));
-            vf::launch_linearize_tail(e->v, slid, e->stream);          // appended between factors + priors; fresh = 1 + slid
-            vf::launch_linearize_assemble(e->v, 0, 1, e->stream);
-        } else {
-            HIPCHK(hipMemsetAsync(e->v.fresh, 0x01, e->v.B * sizeof(int), e->stream));
-            HIPCHK(hipMemsetAsync(e->v.done, 0, e->v.B * sizeof(int), e->stream));
-            vf::launch_linearize_between_prior(e->v, 0, e->stream);
-            vf::launch_linearize_assemble(e->v, 0, 0, e->stream);
-        }
-        HIPCHK(hipGetLastError());
-        if ((rc = vf_engine_decide(e, 1))) return rc;
-        for (int it = 0; it < iterations; it++) {
-            if ((rc = vf_engine_solve(e))) return rc;
-            if ((rc = vf_engine_retract(e))) return rc;
-            vf::launch_linearize_between_prior(e->v, 1, e->stream);
-            vf::launch_linearize_assemble(e->v, 1, 0, e->stream);
-            HIPCHK(hipGetLastError());
-            if ((rc = vf_engine_decide(e, 0))) return rc;
-        }
-        return VF_OK;
-    }
     if (slid) {
         // nothing but slides since the last solve: only the appended keyframes' factors and the priors need linearising
         HIPCHK(hipMemsetAsync(e->v.done, 0, e->v.B * sizeof(int), e->stream));
@@ -758,7 +726,7 @@ int vf_engine_set_convergence(vf_engine* e, double rel_tol, double abs_tol) {
     e->v.stop_on = (rel_tol > 0.0 || abs_tol > 0.0) ? 1 : 0;
     e->epoch++;
     // sweep engines (large batches): once few windows are left taking trials, K4 switches to the partitioned form
-    if (e->v.stop_on && e->v.P == 0 && e->v.B > 128 && !e->hybrid && !getenv("VF_NO_HYBRID")) {
+    if (e->v.stop_on && e->v.P == 0 && e->v.B > 128 && !e->hybrid && e->opts.hybrid_threshold >= 0) {
         vf::View& v = e->v;
         e->hybrid_P = vf::chunk_count(v.M, 96, 1);
         if (e->hybrid_P >= 2) {
@@ -849,7 +817,6 @@ int vf_engine_marginalize(vf_engine* e) {
     for (int w = 0; w < e->v.B; w++)
         if (e->h_hi[w] - e->h_lo[w] < 4) return fail(VF_ERR_INVALID, "window %d: marginalisation needs >= 4 keyframes", w);
     HIPCHK(hipMemsetAsync(e->status_dev, 0, sizeof(int), e->stream));
-    if (e->v.fused) vf::launch_linearize_head(e->v, e->stream);   // the one Jacobian the marginalisation reads (fused engines keep none)
     vf::launch_marginalize(e->v, e->status_dev, e->stream);
     HIPCHK(hipGetLastError());
     int status = 0;
@@ -1035,12 +1002,7 @@ int vf_engine_read_normal(vf_engine* e, int window, int k0, int n, double* Hband
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (n == 0) return VF_OK;
-    size_t g0 = (size_t)window * e->v.M + k0;
-    if (e->v.fused) {             // the buffer that holds the current states' normal equations
-        int sel = 0;
-        if ((rc = read_sel(e, window, &sel))) return rc;
-        g0 += (size_t)sel * (size_t)e->v.G;
-    }
+    const size_t g0 = (size_t)window * e->v.M + k0;
     HIPCHK(hipStreamSynchronize(e->stream));
     if (Hband) {
         // device rows are packed for the solver (vf_kernels.hpp "Block row of H") -> the documented [n][4][15][15]
@@ -1126,12 +1088,10 @@ int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms) {
             case VF_STAGE_RETRACT: vf::launch_retract(tv, e->stream); break;
             case VF_STAGE_DECIDE: vf::launch_decide(tv, 1, e->stream); break;
             case VF_STAGE_ASSEMBLE_IDLE: vf::launch_assemble(tv, e->stream); break;
-            case VF_STAGE_LINEARIZE_ASSEMBLE: vf::launch_linearize_assemble(tv, 0, 0, e->stream); break;
             default: break;
         }
     };
-    if (stage < VF_STAGE_LINEARIZE_IMU || stage > VF_STAGE_LINEARIZE_ASSEMBLE) return fail(VF_ERR_INVALID, "unknown stage %d", stage);
-    if (stage == VF_STAGE_LINEARIZE_ASSEMBLE && !e->v.fused) return fail(VF_ERR_INVALID, "this engine does not run K1 + K3 fused");
+    if (stage < VF_STAGE_LINEARIZE_IMU || stage > VF_STAGE_ASSEMBLE_IDLE) return fail(VF_ERR_INVALID, "unknown stage %d", stage);
     // time the full-work form of K3 (inside iterate() it is skipped for windows whose last trial was rejected)
     if (stage == VF_STAGE_ASSEMBLE) HIPCHK(hipMemsetAsync(e->v.fresh, 0x01, e->v.B * sizeof(int), e->stream));
     if (stage == VF_STAGE_ASSEMBLE_IDLE) HIPCHK(hipMemsetAsync(e->v.fresh, 0, e->v.B * sizeof(int), e->stream));

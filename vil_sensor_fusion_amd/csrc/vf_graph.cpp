@@ -117,6 +117,7 @@ void vf_graph_default_opts(vf_graph_opts* o) {
     memcpy(o->prior_sigma, s, sizeof(s));
     o->rel_tol = 1e-5;   // gtsam::LevenbergMarquardtParams relativeErrorTol / absoluteErrorTol
     o->abs_tol = 1e-5;
+    o->cold_start = 0;
     o->reference_compat = 0;
     o->relin_threshold = 1e-4;   // GraphManager.cpp:40
 }
@@ -138,6 +139,7 @@ int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** ou
     eo.windows = 1;
     eo.capacity = o.capacity;
     eo.device = o.device;
+    eo.cold_start = o.cold_start;
     vf_engine* eng = nullptr;
     int rc = vf_engine_create(&eo, &eng);
     if (rc) return rc;

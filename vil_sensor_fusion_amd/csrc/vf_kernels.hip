@@ -37,9 +37,6 @@ VF_DI bool gated_off(const View& v) {
     const int na = *v.n_active;
     return v.gate == 1 ? na <= v.gate_T : na > v.gate_T;
 }
-// Which of the two H / g buffers holds the normal equations of window w's CURRENT states.  Fused engines (the fused
-// linearise + assemble kernel writes the trial's normal equations beside the current ones): buffer sel[w]; otherwise 0.
-VF_DI int h_buf(const View& v, int w) { return v.fused ? v.sel[w] : 0; }
 
 // Time-sharded windows: the window-local keyframe range [klo, khi) and the chunk range [c0, c1) rank sh_r owns.
 // A chunk owns its interior keyframes and the separator that follows it; a factor belongs to its later keyframe.
@@ -342,16 +339,6 @@ struct HbmSink {
 // pairs), then r (15) and a zero cell the MFMA operand maps point at for structural zeros and padding
 constexpr int LJ_R = 2 * JS_PAIRS, LJ_ZERO = LJ_R + 15;
 constexpr int LJS = 310;        // LDS stride of one factor (even: the staging writes are 16-byte; 620 dwords = 12 mod 32 banks: the 8 slots of a pair hit 8 different bank groups)
-// Fused linearise + assemble (k_linearize_assemble): (r | J) of a factor goes to its row of the workgroup's LDS tile and
-// never to HBM; only the residual (the LM cost, k_decide) is also stored, for the tile's own factors (out_r != nullptr).
-struct LdsSink {
-    static constexpr bool keep_h = false;   // (the fused kernel has no registers to spare)
-    double* F;
-    double* out_r;
-    VF_DI void r(int a, double x) { F[LJ_R + a] = x; if (out_r) __builtin_nontemporal_store(x, out_r + (size_t)a * TILE); }
-    VF_DI void j(int row, int col, double x) { F[(jcol_is_j(col) ? 2 * JS_PI : 0) + JM.idx[row * 30 + col]] = x; }
-};
-
 // CombinedImuFactor: residual and whitened 15x30 Jacobian of the factor in slot gk, at the states of buffer b.
 template <class Sink>
 __device__ __forceinline__ void linearize_imu_core(const View& v, const int b, const long gk, Sink& sink) {
@@ -732,11 +719,10 @@ __global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_all(View
 // rejected one left both alone), so only the factors of the `nslid` appended keyframes and the priors (the marginal prior
 // has just changed) are linearised.  H and g are then stale only at the two ends of a window whose last trial was
 // rejected: fresh[w] = 1 + nslid tells k_assemble to redo just those tiles (fresh[w] = 1: all of them).
-// (fused engines: with_imu = 0, the IMU factors of the end tiles are linearised by k_linearize_assemble itself)
-__global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_tail(View v, int nslid, int with_imu) {
+__global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_tail(View v, int nslid) {
     const int bx = blockIdx.x, t = threadIdx.x;
     if (bx < v.B) {
-        if (t < nslid && with_imu) linearize_imu_factor<false>(v, 0, (long)bx * v.M + v.hi[bx] - 1 - t);
+        if (t < nslid) linearize_imu_factor<false>(v, 0, (long)bx * v.M + v.hi[bx] - 1 - t);
     } else if (bx < 2 * v.B) {
         const int w = bx - v.B;
         if (t < nslid) linearize_between_factor<false>(v, 0, (long)w * v.M + v.hi[w] - 1 - t);
@@ -842,12 +828,11 @@ __device__ __forceinline__ AsmMaps make_asm_maps(const View& v, const int w, con
     m.marg_on = v.mp_on[w] != 0 && hi - lo >= 3;
     return m;
 }
-// The matrix-core part of K3, shared by k_assemble (records staged from HBM) and k_linearize_assemble (records computed
-// into LDS): wave `wv` of the workgroup forms the block rows of KPW keyframes from the tile's (r | J) rows in LJ and the
-// between linearisations in LB (s_a = their source keyframes), and stores them into buffer `hb` of H, g.
+// The matrix-core part of K3: wave `wv` of the workgroup forms the block rows of KPW keyframes from the tile's (r | J) rows in LJ and the
+// between linearisations in LB (s_a = their source keyframes), and stores them into H, g.
 template <int KPW>
 __device__ __forceinline__ void assemble_tile(const View& v, const double* __restrict__ LJ, const double* __restrict__ LB,
-                                              const int* __restrict__ s_a, const int w, const int b, const int hb, const int k0,
+                                              const int* __restrict__ s_a, const int w, const int b, const int k0,
                                               const long gk0, const int lo, const int hi, const int rlo, const int rhi,
                                               const int wv, const int lane, const AsmMaps& maps) {
     const int ci = lane & 15, kq = lane >> 4;
@@ -880,7 +865,7 @@ __device__ __forceinline__ void assemble_tile(const View& v, const double* __res
             const int kl = lf - 1, k = k0 + kl;
             if (k >= rlo && k < rhi) {
                 const long gk = gk0 + kl;
-                double* Hk = v.H + ((size_t)hb * (size_t)v.G + (size_t)gk) * HROW;
+                double* Hk = v.H + (size_t)gk * HROW;
                 // (accumulated into D itself: separate accumulators added at the end measured 4 % slower)
                 if (__builtin_amdgcn_readfirstlane(s_a[kl]) >= 0) {   // a between factor ends here: Jb^T [Jb | r]
                     const double x0 = LB[kl * LBS + oB[0]], x1 = LB[kl * LBS + oB[1]];
@@ -916,7 +901,7 @@ __device__ __forceinline__ void assemble_tile(const View& v, const double* __res
                     }
                     if (a < 15) {
                         if (ci <= a) __builtin_nontemporal_store(val, Hk + H_D0 + h_tri(a, ci));   // lower triangle only
-                        else if (ci == 15) v.gvec[((size_t)hb * (size_t)v.G + (size_t)gk) * 15 + a] = val;
+                        else if (ci == 15) v.gvec[(size_t)gk * 15 + a] = val;
                     }
                 }
             }
@@ -933,7 +918,7 @@ __device__ __forceinline__ void assemble_tile(const View& v, const double* __res
             }
             const int kl = lf, k = k0 + kl;
             if (k >= rlo && k < rhi) {
-                double* Hk = v.H + ((size_t)hb * (size_t)v.G + (size_t)(gk0 + kl)) * HROW;
+                double* Hk = v.H + (size_t)(gk0 + kl) * HROW;
                 const int ak = __builtin_amdgcn_readfirstlane(s_a[kl]);
                 const int dk = ak >= 0 ? k - ak : 0;   // 1..3 when a between factor ends here
                 const int mo2 = marg_on ? k - lo : 99;
@@ -1088,553 +1073,12 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     K3STAMP(3);   // everybody's
 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave-uniform: the keyframe loop and its tests stay scalar
-    assemble_tile<K3_KPW>(v, LJ, LB, s_a, w, b, h_buf(v, w), k0, gk0, lo, hi, rlo, rhi, wv, lane, maps);
+    assemble_tile<K3_KPW>(v, LJ, LB, s_a, w, b, k0, gk0, lo, hi, rlo, rhi, wv, lane, maps);
     K3STAMP(4);       // wave 0: MFMAs done, stores issued
 #ifdef VF_SOLVE_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     K3STAMP(5);       // ... and acknowledged
 #endif
-}
-
-
-// ------------------------------------------------------------------------------------ K1 + K3 fused
-// k_linearize_assemble: the IMU factors of a tile are linearised INTO LDS and assembled from there -- the whitened
-// Jacobian (2.4 KB per factor written by K1 and read back by K3, about 5 GB per LM trial of the full batch) never touches
-// HBM.  One wave per tile of FA keyframes (one workgroup = one wave, so each of the four SIMDs of a CU works on its own
-// tile with the whole register file, as K1 needs): lanes 0 .. FA run the K1 body for the factors k0 .. k0+FA (the last
-// one is the halo: its i-side feeds H[k0+FA-1]; it is recomputed by the next tile), writing (r | J) to their rows of the
-// LDS tile and r also to HBM for the cost; then the wave forms the FA block rows exactly as k_assemble does
-// (assemble_tile) and stores them into the H / g buffer that goes with the states it linearised (buffer sel ^ which):
-// H is double-buffered like the states, so a rejected trial costs nothing to undo and an accepted one is a flip of sel.
-// The J computation uses FA + 1 of the wave's 64 lanes; that is affordable because the kernel is bound by its HBM
-// stream (1.8 KB factor record + 0.6 KB between linearisation in, 3.6 KB of H out per keyframe), not by the VALU.
-// ends_only (warm start after vf_engine_slide): only the tiles at the two ends of a window (see k_linearize_tail).
-constexpr int FA = 8;
-static_assert((FA + 1) * LJS * 8 + (FA + 3) * LBS * 8 + 64 <= 40960, "four tiles per CU");
-__global__ void __launch_bounds__(64) k_linearize_assemble(View v, int which, int ends_only) {
-    __shared__ double LJ[(FA + 1) * LJS];
-    __shared__ double LB[(FA + 3) * LBS];
-    __shared__ int s_a[FA + 3];
-    const int lane = threadIdx.x;
-    const int w = blockIdx.y;
-    if (window_done(v, w)) return;
-    const int k0 = blockIdx.x * FA;
-    const int lo = v.lo[w], hi = v.hi[w];
-    if (k0 + FA <= lo || k0 >= hi) return;            // no active keyframe in this tile (uniform)
-    if (ends_only) {
-        const int fr = v.fresh[w];                    // 1 + appended keyframes (k_linearize_tail)
-        if (fr >= 2 && fr < 64 && k0 >= lo + 4 && k0 + FA <= hi - (fr - 1) - 4) return;
-    }
-    const long gk0 = (long)w * v.M + k0;
-    const int b = v.sel[w] ^ which;
-    const size_t tiles = (size_t)(v.G >> 6);
-    const double* btw_out = v.btw_out + (size_t)b * tiles * BTW_OUT * TILE;
-    // between linearisations of slots k0 .. k0+FA+2 (K2 ran before this kernel): loads issued now, used after the J phase
-    constexpr int NB = ((FA + 3) * BTW_OUT + 63) / 64;
-    double tb[NB];
-#pragma unroll
-    for (int j = 0; j < NB; j++) {
-        const int e = lane + 64 * j;
-        const int sl = e / BTW_OUT, f = e - sl * BTW_OUT;
-        const int ks = k0 + sl;
-        const long gs = gk0 + sl;
-        tb[j] = (e < (FA + 3) * BTW_OUT && ks > lo && ks < hi) ? btw_out[((size_t)(gs >> 6) * BTW_OUT + f) * TILE + (gs & 63)] : 0.0;
-    }
-    int a_src = -1;
-    if (lane < FA + 3) {
-        const int ks = k0 + lane;
-        if (ks > lo && ks < hi) { a_src = v.btw_a[gk0 + lane]; if (a_src < lo || a_src >= ks) a_src = -1; }
-    }
-    // the structural zeros of J (and the rows of factors outside the window) must read as zeros
-    for (int e = lane; e < (FA + 1) * LJS; e += 64) LJ[e] = 0.0;
-    if (lane <= FA) {
-        const int k = k0 + lane;
-        if (k > lo && k < hi) {
-            const long gk = gk0 + lane;
-            double* out_r = lane < FA ? v.imu_r + ((size_t)b * tiles + (size_t)(gk >> 6)) * IMU_R * TILE + (gk & 63) : nullptr;
-            LdsSink sink{LJ + lane * LJS, out_r};
-            linearize_imu_core(v, b, gk, sink);
-        }
-    }
-    if (lane < FA + 3) {
-        LB[lane * LBS + BTW_OUT] = 0.0;       // the pad cell of a slot: the zero the MFMA operand maps point at
-        s_a[lane] = a_src;
-    }
-#pragma unroll
-    for (int j = 0; j < NB; j++) {
-        const int e = lane + 64 * j;
-        if (e < (FA + 3) * BTW_OUT) { const int sl = e / BTW_OUT; LB[sl * LBS + (e - sl * BTW_OUT)] = tb[j]; }
-    }
-    __syncthreads();
-    assemble_tile<FA>(v, LJ, LB, s_a, w, b, b, k0, gk0, lo, hi, lo, hi, 0, lane, make_asm_maps(v, w, lo, hi, lane));
-}
-// ------------------------------------------------------------------------------------ K1 + K3 fused, lane per factor
-// k_lin_asm_v (opt-in, VF_FUSED=2): no Jacobian anywhere.  Lane = IMU factor k (keyframes i = k-1, j = k); with A the
-// unwhitened 15x30 Jacobian (closed-form 3x3 blocks, as K1) and R the factor's upper-triangular square-root information,
-//     H = A^T (R^T R) A,   g = A^T R^T (R r),   cost from R r (written to imu_r as K1 does),
-// formed column by column: for a column a of A,  T = R^T (R a)  (two triangular products with R11 resident; the bias
-// columns and the navigation x bias entries bring in columns of R12 / R22 from L1), and every entry H[c][a] = a_c . T is a
-// short dot product with the resident blocks of A.  A wave covers 63 keyframes (+ one halo factor): lane l owns block row
-// k0 + l -- D1 = H[j][i] and the jj part of D0 come from its own factor, the ii part of D0 from the factor of lane l + 1,
-// which adds it into row l of the LDS staging buffer (two writers in program order: deterministic).  The rows are produced
-// two (dof) rows at a time and flushed through that buffer into the AoS H rows the solver reads (63 stores of 64 words
-// per phase), so H keeps its layout.  Between-factor terms are added by the row's lane from the between linearisations
-// (its own slot and, as source keyframe, the three following ones); the prior / marginal-prior terms of a window's first
-// three rows by k_assemble_fixup afterwards.  H / g double-buffered like the states (fused engines).
-constexpr int VT = 63;          // block rows per wave
-constexpr int VLD = 65;         // LDS stride of a staging row (64 words + pad)
-
-struct V15 { V3 t, p, v; double b[6]; };   // a 15-vector by row blocks: theta, p, v, bias(6)
-
-__global__ void __launch_bounds__(64) k_lin_asm_v(View v, int which, int ends_only) {
-    __shared__ double LBUF[(VT + 1) * VLD];      // (row VT: sink for the halo lane's own-row terms)
-    const int lane = threadIdx.x, w = blockIdx.y;
-    const int k0 = blockIdx.x * VT;
-    const int lo = v.lo[w], hi = v.hi[w], w_sel = v.sel[w], w_done = v.stop_on ? v.done[w] : 0, fr = v.fresh[w];
-    if (w_done || k0 >= hi || k0 + VT <= lo) return;
-    if (ends_only && fr >= 2 && fr < 64 && k0 >= lo + 4 && k0 + VT <= hi - (fr - 1) - 4) return;
-    const int b = w_sel ^ which;
-    const int k = k0 + lane;                               // factor slot of this lane; its block row when lane < VT
-    const long gk = (long)w * v.M + k;
-    const bool fa = k > lo && k < hi;                      // the factor exists
-    const double fz = fa ? 1.0 : 0.0;                      // (the unit entries of A vanish with the factor, like everything else)
-    const bool ra = lane < VT && k >= lo && k < hi;        // the row exists
-    const size_t tiles = (size_t)(v.G >> 6);
-    const double* __restrict__ in = v.imu_in + (size_t)((fa ? gk : 0) >> 6) * IMU_IN * TILE + ((fa ? gk : 0) & 63);
-#define IN(f) in[(size_t)(f) * TILE]
-#define R12(a, c) IN(70 + off15(a) + (9 + (c) - (a)))             // R(a, 9 + c), a < 9
-#define R22(a, c) IN(70 + off15(9 + (a)) + ((c) - (a)))           // R(9 + a, 9 + c), a <= c
-
-    // ---- geometry of the factor (as linearize_imu_core); a lane without a factor carries zeros throughout
-    M3 M1, P1, V1, Rji, Rj, L;
-    V3 rp = v3(0, 0, 0), rv = v3(0, 0, 0);
-    double dt = 0.0, R11[45], Bm[54], rw[15], u[15];
-#pragma unroll
-    for (int i = 0; i < 9; i++) { M1.a[i] = 0; P1.a[i] = 0; V1.a[i] = 0; Rji.a[i] = 0; Rj.a[i] = 0; L.a[i] = 0; }
-#pragma unroll
-    for (int i = 0; i < 45; i++) R11[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 54; i++) Bm[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 15; i++) { rw[i] = 0.0; u[i] = 0.0; }
-    if (fa) {
-        const State si = load_state(v, b, gk - 1), sj = load_state(v, b, gk);
-        dt = IN(0);
-        const V3 dba = si.ba - v3(IN(10), IN(11), IN(12));
-        const V3 dbg = si.bg - v3(IN(13), IN(14), IN(15));
-        double xt[9];
-#pragma unroll
-        for (int r = 0; r < 9; r++) {
-            double s = IN(1 + r);
-            s = fma(IN(16 + r * 6 + 0), dba.x, s);
-            s = fma(IN(16 + r * 6 + 1), dba.y, s);
-            s = fma(IN(16 + r * 6 + 2), dba.z, s);
-            s = fma(IN(16 + r * 6 + 3), dbg.x, s);
-            s = fma(IN(16 + r * 6 + 4), dbg.y, s);
-            s = fma(IN(16 + r * 6 + 5), dbg.z, s);
-            xt[r] = s;
-        }
-        const V3 tht = v3(xt[0], xt[1], xt[2]), pt = v3(xt[3], xt[4], xt[5]), vt = v3(xt[6], xt[7], xt[8]);
-        const M3 Ri = qrot(si.q);
-        Rj = qrot(sj.q);
-        const V3 grav = v3(v.grav[0], v.grav[1], v.grav[2]);
-        const V3 gib = mulT(Ri, grav), vib = mulT(Ri, si.vel);
-        const V3 xp = pt + dt * vib + (0.5 * dt * dt) * gib;
-        const V3 xv = vt + dt * gib;
-        const Q4 eq = qexp(tht);
-        const Q4 qp = qmul(si.q, eq);
-        const V3 pp = si.t + mul(Ri, xp);
-        const V3 vp = si.vel + mul(Ri, xv);
-        const V3 rth = qlog(qmul(qconj(sj.q), qp));
-        rp = mulT(Rj, pp - sj.t);
-        rv = mulT(Rj, vp - sj.vel);
-        const V3 rba = si.ba - sj.ba, rbg = si.bg - sj.bg;
-        L = so3_jr_inv(rth);
-        const M3 Em = qrot(eq);
-        M1 = mulBT(L, Em);
-        Rji = mulTA(Rj, Ri);
-        P1 = mulSkew(Rji, neg(pt));
-        V1 = mulSkew(Rji, neg(vt));
-        const M3 M5 = mul(L, so3_jr(tht));
-#pragma unroll
-        for (int a = 0; a < 9; a++)
-#pragma unroll
-            for (int c = a; c < 9; c++) R11[idx9(a, c)] = IN(70 + off15(a) + (c - a));
-        // bias blocks of A: [M5 H_theta; R_ji H_p; R_ji H_v], column bb at Bm[r * 6 + bb]
-#pragma unroll
-        for (int bb = 0; bb < 6; bb++) {
-            const V3 u0 = mul(M5, v3(IN(16 + 0 * 6 + bb), IN(16 + 1 * 6 + bb), IN(16 + 2 * 6 + bb)));
-            const V3 u1 = mul(Rji, v3(IN(16 + 3 * 6 + bb), IN(16 + 4 * 6 + bb), IN(16 + 5 * 6 + bb)));
-            const V3 u2 = mul(Rji, v3(IN(16 + 6 * 6 + bb), IN(16 + 7 * 6 + bb), IN(16 + 8 * 6 + bb)));
-            Bm[0 * 6 + bb] = u0.x; Bm[1 * 6 + bb] = u0.y; Bm[2 * 6 + bb] = u0.z;
-            Bm[3 * 6 + bb] = u1.x; Bm[4 * 6 + bb] = u1.y; Bm[5 * 6 + bb] = u1.z;
-            Bm[6 * 6 + bb] = u2.x; Bm[7 * 6 + bb] = u2.y; Bm[8 * 6 + bb] = u2.z;
-        }
-        // whitened residual rw = R r and u = R^T rw
-        {
-            const double r9[9] = {rth.x, rth.y, rth.z, rp.x, rp.y, rp.z, rv.x, rv.y, rv.z};
-            const double rb6[6] = {rba.x, rba.y, rba.z, rbg.x, rbg.y, rbg.z};
-            double t9[9];
-            white9<0, 9>(R11, r9, t9);
-#pragma unroll
-            for (int a = 0; a < 9; a++) rw[a] = t9[a];
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-#pragma unroll
-                for (int a = 0; a < 9; a++) rw[a] = fma(R12(a, c), rb6[c], rw[a]);
-#pragma unroll
-                for (int a = 0; a <= c; a++) rw[9 + a] = fma(R22(a, c), rb6[c], rw[9 + a]);
-            }
-#pragma unroll
-            for (int c = 0; c < 9; c++) {
-                double s = 0.0;
-#pragma unroll
-                for (int a = 0; a <= c; a++) s = fma(R11[idx9(a, c)], rw[a], s);
-                u[c] = s;
-            }
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                double s = 0.0;
-#pragma unroll
-                for (int a = 0; a < 9; a++) s = fma(R12(a, c), rw[a], s);
-#pragma unroll
-                for (int a = 0; a <= c; a++) s = fma(R22(a, c), rw[9 + a], s);
-                u[9 + c] = s;
-            }
-        }
-        if (lane < VT) {        // (the halo factor's residual is written by the wave that owns its row)
-            double* out_r = v.imu_r + ((size_t)b * tiles + (size_t)(gk >> 6)) * IMU_R * TILE + (gk & 63);
-#pragma unroll
-            for (int a = 0; a < 15; a++) __builtin_nontemporal_store(rw[a], out_r + (size_t)a * TILE);
-        }
-    }
-    const M3 Sp = skew(rp), Sv = skew(rv);
-
-    // column a of A for the i side (SJ = 0) / the j side (SJ = 1) as a V15 (unit entries in the bias rows included)
-    auto acol = [&](auto sj_, auto a_) {
-        constexpr int SJ = decltype(sj_)::value, a = decltype(a_)::value;
-        V15 c;
-        c.t = c.p = c.v = v3(0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 6; i++) c.b[i] = 0.0;
-        if constexpr (SJ == 0) {
-            if constexpr (a < 3) { c.t = v3(col3(M1, 0, a), col3(M1, 1, a), col3(M1, 2, a)); c.p = v3(col3(P1, 0, a), col3(P1, 1, a), col3(P1, 2, a)); c.v = v3(col3(V1, 0, a), col3(V1, 1, a), col3(V1, 2, a)); }
-            else if constexpr (a < 6) { c.p = v3(col3(Rji, 0, a - 3), col3(Rji, 1, a - 3), col3(Rji, 2, a - 3)); }
-            else if constexpr (a < 9) { c.v = v3(Rj.a[(a - 6) * 3], Rj.a[(a - 6) * 3 + 1], Rj.a[(a - 6) * 3 + 2]); c.p = dt * c.v; }
-            else { constexpr int bb = a - 9; c.t = v3(Bm[bb], Bm[6 + bb], Bm[12 + bb]); c.p = v3(Bm[18 + bb], Bm[24 + bb], Bm[30 + bb]); c.v = v3(Bm[36 + bb], Bm[42 + bb], Bm[48 + bb]); c.b[bb] = fz; }
-        } else {
-            if constexpr (a < 3) { c.t = v3(-L.a[a * 3], -L.a[a * 3 + 1], -L.a[a * 3 + 2]); c.p = v3(col3(Sp, 0, a), col3(Sp, 1, a), col3(Sp, 2, a)); c.v = v3(col3(Sv, 0, a), col3(Sv, 1, a), col3(Sv, 2, a)); }
-            else if constexpr (a < 6) { c.p = v3(a == 3 ? -fz : 0.0, a == 4 ? -fz : 0.0, a == 5 ? -fz : 0.0); }
-            else if constexpr (a < 9) { c.v = v3(-Rj.a[(a - 6) * 3], -Rj.a[(a - 6) * 3 + 1], -Rj.a[(a - 6) * 3 + 2]); }
-            else { c.b[a - 9] = -fz; }
-        }
-        return c;
-    };
-    // a_c . T for column c of side SJ (only the structurally non-zero blocks of the column are touched)
-    auto dotcol = [&](auto sj_, auto c_, const V15& T) -> double {
-        constexpr int SJ = decltype(sj_)::value, c = decltype(c_)::value;
-        if constexpr (SJ == 0) {
-            if constexpr (c < 3) return fma(col3(M1, 0, c), T.t.x, fma(col3(M1, 1, c), T.t.y, fma(col3(M1, 2, c), T.t.z,
-                                        fma(col3(P1, 0, c), T.p.x, fma(col3(P1, 1, c), T.p.y, fma(col3(P1, 2, c), T.p.z,
-                                        fma(col3(V1, 0, c), T.v.x, fma(col3(V1, 1, c), T.v.y, col3(V1, 2, c) * T.v.z))))))));
-            else if constexpr (c < 6) return fma(col3(Rji, 0, c - 3), T.p.x, fma(col3(Rji, 1, c - 3), T.p.y, col3(Rji, 2, c - 3) * T.p.z));
-            else if constexpr (c < 9) {
-                const V3 q = v3(fma(dt, T.p.x, T.v.x), fma(dt, T.p.y, T.v.y), fma(dt, T.p.z, T.v.z));
-                return fma(Rj.a[(c - 6) * 3], q.x, fma(Rj.a[(c - 6) * 3 + 1], q.y, Rj.a[(c - 6) * 3 + 2] * q.z));
-            } else {
-                constexpr int bb = c - 9;
-                return fma(Bm[bb], T.t.x, fma(Bm[6 + bb], T.t.y, fma(Bm[12 + bb], T.t.z,
-                       fma(Bm[18 + bb], T.p.x, fma(Bm[24 + bb], T.p.y, fma(Bm[30 + bb], T.p.z,
-                       fma(Bm[36 + bb], T.v.x, fma(Bm[42 + bb], T.v.y, fma(Bm[48 + bb], T.v.z, T.b[bb])))))))));
-            }
-        } else {
-            if constexpr (c < 3) return -fma(L.a[c * 3], T.t.x, fma(L.a[c * 3 + 1], T.t.y, L.a[c * 3 + 2] * T.t.z)) +
-                                        fma(col3(Sp, 0, c), T.p.x, fma(col3(Sp, 1, c), T.p.y, col3(Sp, 2, c) * T.p.z)) +
-                                        fma(col3(Sv, 0, c), T.v.x, fma(col3(Sv, 1, c), T.v.y, col3(Sv, 2, c) * T.v.z));
-            else if constexpr (c < 6) return -(c == 3 ? T.p.x : (c == 4 ? T.p.y : T.p.z));
-            else if constexpr (c < 9) return -fma(Rj.a[(c - 6) * 3], T.v.x, fma(Rj.a[(c - 6) * 3 + 1], T.v.y, Rj.a[(c - 6) * 3 + 2] * T.v.z));
-            else return -T.b[c - 9];
-        }
-    };
-    // T = R^T (R a) for a column; NEED_B: also its bias rows (rows 9..14 of R^T R a), which cost columns of R12 / R22
-    auto info_col = [&](const V15& a, auto has_bias_, auto bias_index_, auto need_b_) {
-        constexpr bool HB = decltype(has_bias_)::value, NEED_B = decltype(need_b_)::value;
-        constexpr int bb = decltype(bias_index_)::value;
-        // (the columns of R12 / R22 are re-read from L1 for every column of A: left to itself the compiler keeps all 75
-        // of them in registers across the kernel, on top of the ~350 that are resident by design, and spills)
-        int z_ = 0;
-        asm volatile("" : "+s"(z_));          // (an opaque zero: the address space of the pointer stays known)
-        const double* __restrict__ in_ = in + z_;
-#define INL(f) in_[(size_t)(f) * TILE]
-#define R12L(a_, c_) INL(70 + off15(a_) + (9 + (c_) - (a_)))
-#define R22L(a_, c_) INL(70 + off15(9 + (a_)) + ((c_) - (a_)))
-        const double a9[9] = {a.t.x, a.t.y, a.t.z, a.p.x, a.p.y, a.p.z, a.v.x, a.v.y, a.v.z};
-        double w9[9];
-        white9<0, 9>(R11, a9, w9);
-        double wb[6] = {0, 0, 0, 0, 0, 0};
-        if constexpr (HB) {       // the column has a unit (+-1) entry in bias row bb
-            const double sgn = a.b[bb];
-#pragma unroll
-            for (int r = 0; r < 9; r++) w9[r] = fma(R12L(r, bb), sgn, w9[r]);
-#pragma unroll
-            for (int r = 0; r <= bb; r++) wb[r] = R22L(r, bb) * sgn;
-        }
-        V15 T;
-        double t9[9];
-#pragma unroll
-        for (int c = 0; c < 9; c++) {
-            double s = 0.0;
-#pragma unroll
-            for (int r = 0; r <= c; r++) s = fma(R11[idx9(r, c)], w9[r], s);
-            t9[c] = s;
-        }
-        T.t = v3(t9[0], t9[1], t9[2]); T.p = v3(t9[3], t9[4], t9[5]); T.v = v3(t9[6], t9[7], t9[8]);
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-            double s = 0.0;
-            if constexpr (NEED_B) {
-#pragma unroll
-                for (int r = 0; r < 9; r++) s = fma(R12L(r, c), w9[r], s);
-                if constexpr (HB) {
-#pragma unroll
-                    for (int r = 0; r <= (c < bb ? c : bb); r++) s = fma(R22L(r, c), wb[r], s);
-                }
-            }
-            T.b[c] = s;
-        }
-        return T;
-#undef INL
-#undef R12L
-#undef R22L
-    };
-    const V15 U = [&] { V15 x; x.t = v3(u[0], u[1], u[2]); x.p = v3(u[3], u[4], u[5]); x.v = v3(u[6], u[7], u[8]);
-                        for (int i = 0; i < 6; i++) x.b[i] = u[9 + i]; return x; }();
-
-    // ---- between-factor data of this row: source keyframes of the factor ending here and of the three slots after it
-    const size_t bt = (size_t)b * tiles * BTW_OUT * TILE;
-    int a_here = -1, a_next[3] = {-1, -1, -1};
-    if (ra) {
-        if (k > lo) { a_here = v.btw_a[gk]; if (a_here < lo || a_here >= k) a_here = -1; }
-#pragma unroll
-        for (int d = 1; d <= 3; d++)
-            if (k + d < hi) a_next[d - 1] = v.btw_a[gk + d] == k ? k : -1;
-    }
-    const int dk = a_here >= 0 ? k - a_here : 0;
-    auto BT = [&](long gs, int f) { return v.btw_out[bt + ((size_t)(gs >> 6) * BTW_OUT + f) * TILE + (gs & 63)]; };
-
-    double* myrow = LBUF + lane * VLD;
-    double* uprow = LBUF + (lane >= 1 ? lane - 1 : 0) * VLD;                  // the row of keyframe i = k - 1
-    const bool up = fa && lane >= 1;
-    double* Hw = v.H + (size_t)b * (size_t)v.G * HROW;
-    double* gw = v.gvec + (size_t)b * (size_t)v.G * 15;
-    const long grow0 = (long)w * v.M + k0;
-
-    // one phase = dof rows a0, a0 + 1 of every block row of the wave
-    auto phase = [&](auto p_) {
-        constexpr int p = decltype(p_)::value, a0 = 2 * p;
-        // staging row: [0, 30) D1 rows a0, a0 + 1; [30, 62) D0 rows a0 (a0 + 1 entries), a0 + 1 (a0 + 2 entries); 62, 63: g
-        auto row = [&](auto a_) {
-            constexpr int a = decltype(a_)::value, s = a - a0;
-            constexpr int d0off = 30 + (s ? a0 + 1 : 0);
-            // j side: T of j-dof a -> D1 row a (all i dofs), D0 row a (j dofs c <= a), g_j[a]
-            {
-                const V15 col = acol(IC<1>{}, IC<a>{});
-                const V15 T = info_col(col, IC<(a >= 9)>{}, IC<(a >= 9 ? a - 9 : 0)>{}, IC<true>{});
-                auto d1 = [&](auto c_) { constexpr int c = decltype(c_)::value; myrow[s * 15 + c] = dotcol(IC<0>{}, IC<c>{}, T); };
-                d1(IC<0>{}); d1(IC<1>{}); d1(IC<2>{}); d1(IC<3>{}); d1(IC<4>{}); d1(IC<5>{}); d1(IC<6>{}); d1(IC<7>{});
-                d1(IC<8>{}); d1(IC<9>{}); d1(IC<10>{}); d1(IC<11>{}); d1(IC<12>{}); d1(IC<13>{}); d1(IC<14>{});
-                auto d0 = [&](auto c_) { constexpr int c = decltype(c_)::value; if constexpr (c <= a) myrow[d0off + c] = dotcol(IC<1>{}, IC<c>{}, T); };
-                d0(IC<0>{}); d0(IC<1>{}); d0(IC<2>{}); d0(IC<3>{}); d0(IC<4>{}); d0(IC<5>{}); d0(IC<6>{}); d0(IC<7>{});
-                d0(IC<8>{}); d0(IC<9>{}); d0(IC<10>{}); d0(IC<11>{}); d0(IC<12>{}); d0(IC<13>{}); d0(IC<14>{});
-                myrow[62 + s] = dotcol(IC<1>{}, IC<a>{}, U);
-            }
-        };
-        auto row_up = [&](auto a_) {
-            constexpr int a = decltype(a_)::value, s = a - a0;
-            constexpr int d0off = 30 + (s ? a0 + 1 : 0);
-            // i side: T of i-dof a -> D0 row a of keyframe i (i dofs c <= a), g_i[a]: added into the row above
-            const V15 col = acol(IC<0>{}, IC<a>{});
-            const V15 T = info_col(col, IC<(a >= 9)>{}, IC<(a >= 9 ? a - 9 : 0)>{}, IC<(a >= 9)>{});
-            auto d0 = [&](auto c_) { constexpr int c = decltype(c_)::value; if constexpr (c <= a) { const double x = dotcol(IC<0>{}, IC<c>{}, T); if (up) uprow[d0off + c] += x; } };
-            d0(IC<0>{}); d0(IC<1>{}); d0(IC<2>{}); d0(IC<3>{}); d0(IC<4>{}); d0(IC<5>{}); d0(IC<6>{}); d0(IC<7>{});
-            d0(IC<8>{}); d0(IC<9>{}); d0(IC<10>{}); d0(IC<11>{}); d0(IC<12>{}); d0(IC<13>{}); d0(IC<14>{});
-            const double gi = dotcol(IC<0>{}, IC<a>{}, U);
-            if (up) uprow[62 + s] += gi;
-        };
-        row(IC<a0>{});
-        if constexpr (a0 + 1 < 15) row(IC<a0 + 1>{});
-        asm volatile("" ::: "memory");
-        row_up(IC<a0>{});
-        if constexpr (a0 + 1 < 15) row_up(IC<a0 + 1>{});
-        asm volatile("" ::: "memory");
-        // between-factor terms of the pose rows (a < 6)
-        if constexpr (a0 < 6) {
-            if (ra) {
-#pragma unroll
-                for (int s = 0; s < 2; s++) {
-                    const int a = a0 + s;
-                    const int d0off = 30 + (s ? a0 + 1 : 0);
-                    if (dk >= 1) {        // the factor ending here: Jb^T [Jb | r], and Jb^T Ja into the coupling block
-                        double jb[6];
-#pragma unroll
-                        for (int r = 0; r < 6; r++) jb[r] = BT(gk, 42 + r * 6 + a);
-                        for (int c = 0; c <= a; c++) {
-                            double sum = 0.0;
-#pragma unroll
-                            for (int r = 0; r < 6; r++) sum = fma(jb[r], BT(gk, 42 + r * 6 + c), sum);
-                            myrow[d0off + c] += sum;
-                        }
-                        double sg = 0.0;
-#pragma unroll
-                        for (int r = 0; r < 6; r++) sg = fma(jb[r], BT(gk, r), sg);
-                        myrow[62 + s] += sg;
-                        if (dk == 1)
-                            for (int c = 0; c < 6; c++) {
-                                double sum = 0.0;
-#pragma unroll
-                                for (int r = 0; r < 6; r++) sum = fma(jb[r], BT(gk, 6 + r * 6 + c), sum);
-                                myrow[s * 15 + c] += sum;
-                            }
-                    }
-#pragma unroll
-                    for (int d = 1; d <= 3; d++)
-                        if (a_next[d - 1] >= 0) {      // a factor starting here: Ja^T [Ja | r]
-                            const long gs = gk + d;
-                            double ja[6];
-#pragma unroll
-                            for (int r = 0; r < 6; r++) ja[r] = BT(gs, 6 + r * 6 + a);
-                            for (int c = 0; c <= a; c++) {
-                                double sum = 0.0;
-#pragma unroll
-                                for (int r = 0; r < 6; r++) sum = fma(ja[r], BT(gs, 6 + r * 6 + c), sum);
-                                myrow[d0off + c] += sum;
-                            }
-                            double sg = 0.0;
-#pragma unroll
-                            for (int r = 0; r < 6; r++) sg = fma(ja[r], BT(gs, r), sg);
-                            myrow[62 + s] += sg;
-                        }
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // flush: word `lane` of every staging row -> its place in the H row / g of that keyframe
-        {
-            constexpr int nd1 = (a0 + 1 < 15) ? 30 : 15, nd0 = (a0 + 1 < 15) ? 2 * a0 + 3 : a0 + 1, ng = (a0 + 1 < 15) ? 2 : 1;
-            const bool is_d1 = lane < nd1, is_d0 = lane >= 30 && lane < 30 + nd0, is_g = lane >= 62 && lane < 62 + ng;
-            const int hoff = is_d1 ? H_D1 + a0 * 15 + lane : H_D0 + h_tri(a0, 0) + (lane - 30);
-#pragma unroll 1
-            for (int r0 = 0; r0 < VT; r0 += 9) {
-                double x[9];
-#pragma unroll
-                for (int j = 0; j < 9; j++) x[j] = LBUF[(r0 + j) * VLD + lane];
-#pragma unroll
-                for (int j = 0; j < 9; j++) {
-                    const int r = r0 + j, kr = k0 + r;
-                    if (kr < lo || kr >= hi) continue;                   // (uniform)
-                    if (is_d1 || is_d0) __builtin_nontemporal_store(x[j], Hw + (size_t)(grow0 + r) * HROW + hoff);
-                    else if (is_g) gw[(size_t)(grow0 + r) * 15 + a0 + (lane - 62)] = x[j];
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    phase(IC<0>{}); phase(IC<1>{}); phase(IC<2>{}); phase(IC<3>{}); phase(IC<4>{}); phase(IC<5>{}); phase(IC<6>{}); phase(IC<7>{});
-
-    // ---- pose x pose blocks two and three keyframes back (between factors only): staged as [D2 36 | D3 36] in two halves
-    {
-        if (lane < VT) {
-            for (int e = 0; e < 36; e++) {
-                const int aa = e / 6, c = e - aa * 6;
-                double sum = 0.0;
-                if (ra && dk >= 2) {
-#pragma unroll
-                    for (int r = 0; r < 6; r++) sum = fma(BT(gk, 42 + r * 6 + aa), BT(gk, 6 + r * 6 + c), sum);
-                }
-                myrow[e < 32 ? e : e] = 0.0;      // (cells [0, 36) hold the block of this row's d = 2 or d = 3 factor)
-                myrow[e] = sum;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // every row stores 72 words: its block into D2 or D3 (by dk of the ROW, which lives in the lane that owns it), zeros into the other
-        const int dk_mine = dk;
-#pragma unroll 1
-        for (int r = 0; r < VT; r++) {
-            const int kr = k0 + r;
-            if (kr < lo || kr >= hi) continue;
-            const int dkr = __builtin_amdgcn_readlane(dk_mine, r);
-            const double x = lane < 36 ? LBUF[r * VLD + lane] : 0.0;
-            if (lane < 36) {
-                Hw[(size_t)(grow0 + r) * HROW + H_D2 + lane] = dkr == 2 ? x : 0.0;
-                Hw[(size_t)(grow0 + r) * HROW + H_D3 + lane] = dkr == 3 ? x : 0.0;
-            }
-        }
-    }
-#undef IN
-#undef R12
-#undef R22
-}
-
-// Prior and marginal-prior terms of a window's first rows, added onto what k_lin_asm_v wrote (K3 adds them in its epilogue;
-// the lane-per-factor kernel leaves them to this one-workgroup-per-window pass: three H rows per window)
-__global__ void __launch_bounds__(256) k_assemble_fixup(View v, int which) {
-    const int w = blockIdx.x, tid = threadIdx.x;
-    if (window_done(v, w)) return;
-    const int lo = v.lo[w], hi = v.hi[w];
-    if (hi <= lo) return;
-    const int b = v.sel[w] ^ which;
-    double* Hw = v.H + (size_t)b * (size_t)v.G * HROW;
-    double* gw = v.gvec + (size_t)b * (size_t)v.G * 15;
-    const int pk = v.prior_k[w];
-    if (pk >= lo && pk < hi) {
-        const double* Pq = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT;
-        const long gk = (long)w * v.M + pk;
-        for (int e = tid; e < 120 + 15; e += 256) {
-            if (e < 120) {
-                int a = 0;
-                while (h_tri(a + 1, 0) <= e) a++;
-                const int c = e - h_tri(a, 0);
-                double sum = 0.0;
-                for (int rr = 0; rr < 15; rr++) sum = fma(Pq[15 + rr * 15 + a], Pq[15 + rr * 15 + c], sum);
-                Hw[(size_t)gk * HROW + H_D0 + e] += sum;
-            } else {
-                const int a = e - 120;
-                double sum = 0.0;
-                for (int rr = 0; rr < 15; rr++) sum = fma(Pq[15 + rr * 15 + a], Pq[rr], sum);
-                gw[(size_t)gk * 15 + a] += sum;
-            }
-        }
-    }
-    if (v.mp_on[w] && hi - lo >= 3) {
-        const double* ML = v.mp_L + (size_t)w * 729;
-        const double* Mg = v.mp_out + ((size_t)b * v.B + w) * 28;
-        const long g0 = (long)w * v.M + lo;
-        for (int e = tid; e < 512; e += 256) {
-            // row lo: all 15 dof
-            if (e < 120) { int a = 0; while (h_tri(a + 1, 0) <= e) a++; const int c = e - h_tri(a, 0); Hw[(size_t)g0 * HROW + H_D0 + e] += ML[a * 27 + c]; }
-            else if (e < 135) gw[(size_t)g0 * 15 + (e - 120)] += Mg[e - 120];
-            // row lo + 1: pose x pose on the diagonal, pose x (lo: 15) in D1
-            else if (e < 135 + 21) { const int t = e - 135; int a = 0; while (h_tri(a + 1, 0) <= t) a++; const int c = t - h_tri(a, 0);
-                                     Hw[(size_t)(g0 + 1) * HROW + H_D0 + h_tri(a, c)] += ML[(15 + a) * 27 + 15 + c]; }
-            else if (e < 156 + 6) gw[(size_t)(g0 + 1) * 15 + (e - 156)] += Mg[15 + (e - 156)];
-            else if (e < 162 + 90) { const int t = e - 162, a = t / 15, c = t - a * 15; Hw[(size_t)(g0 + 1) * HROW + H_D1 + a * 15 + c] += ML[(15 + a) * 27 + c]; }
-            // row lo + 2: pose x pose diagonal, pose x (lo + 1 pose) in D1, pose x (lo pose) in D2, pose x (lo: velocity / bias) in DX
-            else if (e < 252 + 21) { const int t = e - 252; int a = 0; while (h_tri(a + 1, 0) <= t) a++; const int c = t - h_tri(a, 0);
-                                     Hw[(size_t)(g0 + 2) * HROW + H_D0 + h_tri(a, c)] += ML[(21 + a) * 27 + 21 + c]; }
-            else if (e < 273 + 6) gw[(size_t)(g0 + 2) * 15 + (e - 273)] += Mg[21 + (e - 273)];
-            else if (e < 279 + 36) { const int t = e - 279, a = t / 6, c = t - a * 6; Hw[(size_t)(g0 + 2) * HROW + H_D1 + a * 15 + c] += ML[(21 + a) * 27 + 15 + c]; }
-            else if (e < 315 + 36) { const int t = e - 315, a = t / 6, c = t - a * 6; Hw[(size_t)(g0 + 2) * HROW + H_D2 + a * 6 + c] += ML[(21 + a) * 27 + c]; }
-            else if (e < 351 + 54) { const int t = e - 351, a = t / 9, c = t - a * 9; Hw[(size_t)(g0 + 2) * HROW + H_DX + a * 9 + c] = ML[(21 + a) * 27 + 6 + c]; }
-        }
-    }
-}
-
-// the head factor of every window (slot lo + 1), by K1 proper: fused engines keep no Jacobians in HBM, and the
-// marginalisation of the oldest keyframe (k_marginalize) reads this one
-__global__ void __launch_bounds__(64) k_linearize_head(View v) {
-    const int w = blockIdx.x * 64 + threadIdx.x;
-    if (w >= v.B) return;
-    linearize_imu_factor<false>(v, 0, (long)w * v.M + v.lo[w] + 1);
 }
 
 
@@ -1843,7 +1287,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     // ---- H block row prefetch (HBM -> registers) and commit (registers -> LDS slot) ---------
     // (passed by value: captured-by-reference scalars ended up in scratch memory)
     struct HRow { double h0[2], h1[4], h2, h3, hx, hg; };
-    const size_t hbase = (size_t)h_buf(v, w) * (size_t)v.G + base;      // the buffer of the window's current normal equations
+    const size_t hbase = base;      // the buffer of the window's current normal equations
     const double* __restrict__ Hbase = v.H + hbase * HROW;
     const double* __restrict__ gbase = v.gvec + hbase * 15;
     const double* __restrict__ zrow = v.zrow;
@@ -2304,7 +1748,7 @@ __device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int
     const int lo = v.lo[w];
     const int li = lane & 15, lq = lane >> 4;
     const size_t base = (size_t)w * v.M + lo + cg.i0;
-    const double* __restrict__ Hb = v.H + ((size_t)h_buf(v, w) * (size_t)v.G + base) * HROW;
+    const double* __restrict__ Hb = v.H + (base) * HROW;
     double* __restrict__ Vb = v.Vp + base * VROW;
 
     // E[(kk, a)][j]: dof a of the chunk's keyframe kk (window keyframe i0 + kk) against separator column j:
@@ -3181,21 +2625,10 @@ void launch_linearize_between_prior(const View& v, int which, hipStream_t s) {
     hipLaunchKernelGGL(k_linearize_between_prior, dim3(nblk(v.G, 256) + nb_pri), dim3(256), 0, s, v, which, nb_pri);
 }
 void launch_linearize_tail(const View& v, int nslid, hipStream_t s) {
-    hipLaunchKernelGGL(k_linearize_tail, dim3(2 * v.B + nblk(v.B, 64)), dim3(VF_K1_BLOCK), 0, s, v, nslid, v.fused ? 0 : 1);
+    hipLaunchKernelGGL(k_linearize_tail, dim3(2 * v.B + nblk(v.B, 64)), dim3(VF_K1_BLOCK), 0, s, v, nslid);
 }
 void launch_linearize_prior(const View& v, int which, hipStream_t s) {
     hipLaunchKernelGGL(k_linearize_prior, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, which);
-}
-void launch_linearize_assemble(const View& v, int which, int ends_only, hipStream_t s) {
-    if (v.fused == 2) {       // lane per factor, no Jacobian anywhere (k_lin_asm_v) + the prior terms
-        hipLaunchKernelGGL(k_lin_asm_v, dim3((unsigned)((v.M + VT - 1) / VT), (unsigned)v.B), dim3(64), 0, s, v, which, ends_only);
-        hipLaunchKernelGGL(k_assemble_fixup, dim3((unsigned)v.B), dim3(256), 0, s, v, which);
-        return;
-    }
-    hipLaunchKernelGGL(k_linearize_assemble, dim3((unsigned)(v.M / FA), (unsigned)v.B), dim3(64), 0, s, v, which, ends_only);
-}
-void launch_linearize_head(const View& v, hipStream_t s) {
-    hipLaunchKernelGGL(k_linearize_head, dim3(nblk(v.B, 64)), dim3(64), 0, s, v);
 }
 void launch_assemble(const View& v, hipStream_t s) {
     // (persistent forms were measured slower: one workgroup per CU with the next tile's loads in flight 5.1 ms, a plain
@@ -3238,8 +2671,7 @@ void launch_mask_delta(const View& v, hipStream_t s) {
 void launch_band_solve(const View& v, hipStream_t s) {
     if (v.P >= 2) { launch_partitioned_solve(v, s); return; }
     // few windows: two waves per window from both ends (latency); many: one wave per window (throughput)
-    static const int tw_max = getenv("VF_TWISTED_MAX_WINDOWS") ? atoi(getenv("VF_TWISTED_MAX_WINDOWS")) : 256;
-    if (v.B <= tw_max) hipLaunchKernelGGL(k_band_solve_tw, dim3(v.B), dim3(128), 0, s, v);
+    if (v.B <= v.tw_max) hipLaunchKernelGGL(k_band_solve_tw, dim3(v.B), dim3(128), 0, s, v);
     else hipLaunchKernelGGL(k_band_solve, dim3(v.B), dim3(64), 0, s, v);
 }
 // windows of the running solve that still take LM trials (termination rule on)

@@ -120,10 +120,8 @@ struct View {
     double* mp_L;       // [B][27][27]  information
     double* mp_eta;     // [B][27]      gradient at the linearisation point
     double* mp_out;     // [2][B][28]   L d + eta (27) and the cost 0.5 d^T L d + eta^T d
-    int fused;          // 1: K1 + K3 fused (k_linearize_assemble); H and g are then double-buffered like the states, the
-                        // normal equations of window w's current states live in buffer sel[w] (h_buf)
-    double* H;          // [1 or 2][G][512]    block row of keyframe k ("Block row of H" above)
-    double* gvec;       // [1 or 2][G][15]
+    double* H;          // [G][512]            block row of keyframe k ("Block row of H" above)
+    double* gvec;       // [G][15]
     double* zrow;       // [900] zeros
     double* delta;      // [G][15] + [B]       increments; tail: solve-failure flag per window (time-sharded windows: summed
                         //                     over the ranks together with the increments, one all-reduce)
@@ -167,6 +165,7 @@ struct View {
     // than gate_T windows are active), 2 = this is the partitioned form (runs otherwise).
     int* n_active;      // [1]  windows of the current solve that still take trials (k_count_active)
     int gate, gate_T;
+    int tw_max;         // whole-window sweeps: up to this many windows two waves per window from both ends, above one wave per window
 };
 
 // isotropic IMU covariances (ImuManagerRos.cpp:20-33)
@@ -180,9 +179,6 @@ void launch_linearize_between_prior(const View& v, int which, hipStream_t s);   
 void launch_linearize_tail(const View& v, int nslid, hipStream_t s);   // warm start: factors of the appended keyframes + priors
 void launch_linearize_all(const View& v, int which, hipStream_t s);   // the three above in one launch (few windows)
 void launch_assemble(const View& v, hipStream_t s);
-// K1 + K3 fused: linearise the IMU factors at buffer sel ^ which and write that buffer's H, g (fused engines)
-void launch_linearize_assemble(const View& v, int which, int ends_only, hipStream_t s);
-void launch_linearize_head(const View& v, hipStream_t s);   // K1 proper for the first factor of every window (for k_marginalize)
 void launch_band_solve(const View& v, hipStream_t s);
 void launch_count_active(const View& v, hipStream_t s);
 // hybrid K4 (see View::gate): vp = the same engine viewed with the partitioned form's chunk count

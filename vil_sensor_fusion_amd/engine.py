@@ -13,7 +13,7 @@ from ._lib import check
 
 IMU_RECORD, BTW_RECORD, PRIOR_RECORD = 190, 28, 31
 STAGES = {"linearize_imu": 1, "linearize_between": 2, "assemble": 3, "solve": 4, "retract": 5,
-          "decide": 6, "assemble_idle": 7, "linearize_assemble": 8}
+          "decide": 6, "assemble_idle": 7}
 # GraphManager.cpp:27-31: pose (rad x3, m x3), velocity, bias prior sigmas
 REFERENCE_PRIOR_SIGMAS = np.array([1e-6] * 3 + [5e-5] * 3 + [1e-5] * 3 + [1e-7] * 6)
 
@@ -39,6 +39,11 @@ class EngineOpts:
     lambda_min: float = 1e-12
     lambda_max: float = 1e10
     chunks: int = 0          # K4 form: 0 = auto (<= 128 windows: partitioned solve), 1 = sweeps, P >= 2 = P chunks
+    # solver-form switches (None = the library's default, vf_engine_default_opts; see include/vilfusion.h)
+    sweep_two_sided_max: int | None = None
+    hybrid_threshold: int | None = None
+    cold_start: bool = False
+    use_hip_graph: bool = False
 
 
 class Engine:
@@ -51,6 +56,11 @@ class Engine:
         o.lambda0, o.lambda_up, o.lambda_down = opts.lambda0, opts.lambda_up, opts.lambda_down
         o.lambda_min, o.lambda_max = opts.lambda_min, opts.lambda_max
         o.chunks = opts.chunks
+        if opts.sweep_two_sided_max is not None:
+            o.sweep_two_sided_max = opts.sweep_two_sided_max
+        if opts.hybrid_threshold is not None:
+            o.hybrid_threshold = opts.hybrid_threshold
+        o.cold_start, o.use_hip_graph = int(opts.cold_start), int(opts.use_hip_graph)
         self._h = C.c_void_p()
         check(self._l.vf_engine_create(C.byref(o), C.byref(self._h)))
         self.opts = opts

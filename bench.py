@@ -29,6 +29,7 @@ import argparse
 import json
 import multiprocessing
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -278,6 +279,20 @@ def degeneracy_section():
     t2 = time.perf_counter()
     out["numpy_per_matrix_ns"] = {"d_opt": (t1 - t0) / len(sample) * 1e9, "e_opt": (t2 - t1) / len(sample) * 1e9,
                                   "sample": len(sample), "cores": 1}
+    # roofline of K6 on a launch big enough to be bandwidth- rather than launch-bound (>= 2^20 units per launch;
+    # here 2^22 matrices = 1.2 GB of float64 input): algorithmic bytes = 288 B read + 8 B written per 6x6 (144 + 4 in float32)
+    T2 = 1 << 22
+    big = np.ascontiguousarray(np.tile(mats[:, :, :1 << 16], (1, 1, T2 >> 16)))
+    roof = {"matrices": T2, "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "kernels": {}}
+    for name in ("d_opt", "e_opt"):
+        for dt, tag, nbytes in ((np.float64, "f64", 296), (np.float32, "f32", 148)):
+            _, ms = dg.apply_degen_function(big, None, "all", name, dtype=dt, reps=5)
+            ach = T2 * nbytes / (ms * 1e-3) / 1e9
+            roof["kernels"][f"{name}/{tag}"] = {"avg_launch_ms": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBPS,
+                                                "algorithmic_bytes_per_matrix": nbytes, "ns_per_matrix": ms * 1e6 / T2}
+    roof["note"] = ("d_opt (pivoted LU in registers) is the metric the shipped gate uses; e_opt (cyclic Jacobi, ~10 sweeps) is "
+                    "compute-bound, its fraction is quoted for completeness")
+    out["roofline_k6"] = roof
     return out
 
 
@@ -320,9 +335,16 @@ def measured_traffic_per_imu_factor():
     """HBM bytes per IMU factor of K1 from the committed PMC profile (separate --pmc passes,
     2*FETCH_SIZE + WRITE_SIZE, KiB units; tools/summarize_prof.py)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(path):
-        return json.load(open(path))
-    return None
+    if not os.path.exists(path):
+        return None
+    tr = json.load(open(path))
+    # the PMC passes and the kernel trace must come from ONE profiling round (tools/profile_round.sh writes both): a
+    # traffic file left over from an older round than kernel_durations.json is refused, not silently quoted
+    prof = profiled_kernels()
+    tag = lambda d: (re.search(r"profiles/(r\d+\w*?)_", d.get("source", "")) or [None, None])[1]
+    if prof is not None and tag(prof) != tag(tr):
+        return {"stale": f"profiles/traffic.json is of round-tag {tag(tr)}, kernel_durations.json of {tag(prof)}: not used"}
+    return tr
 
 
 def spawn_ranks(args, script=None, argv=None):
@@ -552,8 +574,8 @@ def main():
             "roofline": {"kernel": "k_linearize_imu (K1: CombinedImuFactor residual + whitened 15x30 Jacobian)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None if traffic is None else traffic["k1_bytes_per_imu_factor"] * counts["imu"],
-                         "traffic_source": None if traffic is None else traffic["source"],
+                         "traffic": None if (traffic is None or "stale" in traffic) else traffic["k1_bytes_per_imu_factor"] * counts["imu"],
+                         "traffic_source": None if traffic is None else traffic.get("source", traffic.get("stale")),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,
                          "avg_launch_ms_source": "HIP events on the engine's stream, 20 back-to-back launches (vf_engine_time_stage)",
                          "algorithmic_bytes_per_imu_factor": IMU_BYTES,

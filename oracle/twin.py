@@ -4,7 +4,9 @@ Written from the mathematics, not from oracle/vf_oracle.c: rotations are 3x3 mat
 scipy's generic matrix functions (expm / logm), the SO(3) right Jacobian is its power series, and every factor Jacobian
 is a central difference of the twin's own residual.  What it shares with the C oracle (and the HIP kernels) is therefore
 only the CONVENTIONS under test: tangent orders, retractions, the preintegration recursion, the residual definitions.
-The 15x15 preintegrated covariance is not restated here (its block recursion cannot be derived without GTSAM's source).
+The 15x15 preintegrated covariance is propagated by `preintegrate_cov`: every Jacobian in it is a central difference of
+the twin's own one-sample step (no closed-form A, B, C), composed in numpy; what it takes from GTSAM is the documented
+SELECTION of blocks (which sensitivities enter F and which noises enter G, see the function).
 
 State layout as everywhere: q(w,x,y,z) t(3) v(3) bias_acc(3) bias_gyro(3).
 """
@@ -78,6 +80,66 @@ def preintegrate(steps, bhat):
         w_t = np.linalg.solve(so3_jr(th), w)
         th, p, v, T = th + w_t * dt, p + v * dt + 0.5 * a_nav * dt * dt, v + a_nav * dt, T + dt
     return T, np.concatenate([th, p, v])
+
+
+def step(x, bias, meas, dt):
+    """ONE sample of the recursion above on x = (theta, p, v) with the measurement corrected by `bias` (6)."""
+    th, p, v = x[:3], x[3:6], x[6:9]
+    a, w = meas[:3] - bias[:3], meas[3:] - bias[3:]
+    a_nav = so3_exp(th) @ a
+    w_t = np.linalg.solve(so3_jr(th), w)
+    return np.concatenate([th + w_t * dt, p + v * dt + 0.5 * a_nav * dt * dt, v + a_nav * dt])
+
+
+def _fd(f, x0, h):
+    """central-difference Jacobian of f at x0"""
+    y0 = f(x0)
+    J = np.zeros((y0.size, x0.size))
+    for c in range(x0.size):
+        e = np.zeros(x0.size)
+        e[c] = h
+        J[:, c] = (f(x0 + e) - f(x0 - e)) / (2 * h)
+    return J
+
+
+def preintegrate_cov(steps, bhat, acc_cov, gyro_cov, int_cov, bias_acc_cov, bias_omega_cov, bias_acc_omega_int, h=1e-5):
+    """15 x 15 covariance of (theta, p, v, bias_acc, bias_omega) after the samples in `steps`, by first-order propagation
+    P <- F P F^T + Q per sample, every sensitivity a central difference of `step`:
+
+        N_x = d step / d x      (9 x 9)        N_b = d step / d bias   (9 x 6; = - d step / d measurement)
+
+    and the composition GTSAM 4.0.x documents for PreintegratedCombinedMeasurements::integrateMeasurement
+    (called at IMUManager.cpp:50,64; "we consider the uncertainty of the bias selection and we keep correlation between
+    biases and preintegrated measurements"):
+      F = [[N_x, S], [0, I6]] with S holding ONLY theta/bias_omega (N_b[0:3, 3:6]) and v/bias_acc (N_b[6:9, 0:3]) -- the
+          position/bias_acc sensitivity is left out there ("TODO: should we not also account for bias on position?");
+      Q = blockdiag( Nt (gyro_cov + int_gg) Nt^T / dt,  dt int_cov,  Nv (acc_cov + int_aa) Nv^T / dt,
+                     dt bias_acc_cov,  dt bias_omega_cov )   with Nt = N_b[0:3, 3:6], Nv = N_b[6:9, 0:3],
+          int_aa / int_gg = the diagonal 3x3 blocks of biasAccOmegaInt (ImuManagerRos.cpp:28-33 sets it to c * I6, whose
+          off-diagonal block -- the D_v_R term -- is zero).
+    Discrete white noise of density c sampled at dt has covariance c / dt: hence N c N^T / dt with N proportional to dt."""
+    x, bhat = np.zeros(9), np.asarray(bhat, dtype=float)
+    P = np.zeros((15, 15))
+    I3 = np.eye(3)
+    for s in np.atleast_2d(steps):
+        dt, meas = s[0], np.asarray(s[1:7], dtype=float)
+        Nx = _fd(lambda y: step(y, bhat, meas, dt), x, h)
+        Nb = _fd(lambda b: step(x, b, meas, dt), bhat, h)
+        Nt, Nv = Nb[0:3, 3:6], Nb[6:9, 0:3]
+        F = np.zeros((15, 15))
+        F[:9, :9] = Nx
+        F[0:3, 12:15] = Nt
+        F[6:9, 9:12] = Nv
+        F[9:, 9:] = np.eye(6)
+        Q = np.zeros((15, 15))
+        Q[0:3, 0:3] = Nt @ ((gyro_cov + bias_acc_omega_int) * I3) @ Nt.T / dt
+        Q[3:6, 3:6] = dt * int_cov * I3
+        Q[6:9, 6:9] = Nv @ ((acc_cov + bias_acc_omega_int) * I3) @ Nv.T / dt
+        Q[9:12, 9:12] = dt * bias_acc_cov * I3
+        Q[12:15, 12:15] = dt * bias_omega_cov * I3
+        P = F @ P @ F.T + Q
+        x = step(x, bhat, meas, dt)
+    return P
 
 
 def bias_jacobian_fd(steps, bhat, h=1e-6):

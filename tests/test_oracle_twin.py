@@ -89,3 +89,61 @@ def test_between_factor(oracle):
         Jat, Jbt = twin.between_jacobian_fd(rec, xa, xb)
         assert np.abs(Ja - Jat).max() <= 2e-6 * max(1.0, np.abs(Ja).max())
         assert np.abs(Jb - Jbt).max() <= 2e-6 * max(1.0, np.abs(Jb).max())
+
+
+# ---------------------------------------------------------------- 15 x 15 preintegrated covariance
+SAN_RAFAEL_COV = dict(acc=1e-6, gyro=1e-6, integration=1e-8, bias_acc=1e-3, bias_omega=1e-6, bias_acc_omega_int=1e-5)   # config/san_rafael/fusion_params.yaml:20-25
+
+
+def _oracle_cov(oracle, steps, bhat, c):
+    prm = oracle.make_imu_params(c["acc"], c["gyro"], c["integration"], c["bias_acc"], c["bias_omega"], c["bias_acc_omega_int"])
+    p = oracle.pim_new(bhat)
+    for s in steps:
+        oracle.pim_integrate(p, prm, s[1:4], s[4:7], s[0])
+    return oracle.pim_fields(p)["cov"], oracle.pim_to_record(p)
+
+
+def _twin_cov(steps, bhat, c):
+    return twin.preintegrate_cov(steps, bhat, c["acc"], c["gyro"], c["integration"], c["bias_acc"], c["bias_omega"], c["bias_acc_omega_int"])
+
+
+def covariance_cases():
+    """(name, steps, bias estimate, covariances): the TestTest.cpp:11-29 recipe, a San-Rafael-parameter sequence with a
+    turning vehicle and a non-zero bias estimate, and a long Carla one (40 samples, large rotation)."""
+    from tests.golden.make_oracle_golden import TESTTEST_COV, testtest_steps
+    seq = synth.make_sequence(seed=31, n_kf=6)
+    sr_steps = seq.imu_steps[seq.imu_off[2]:seq.imu_off[4]].copy()
+    sr_steps[:, 4:7] += [0.4, -0.3, 0.8]                        # a vehicle that turns hard: theta reaches ~0.1 rad
+    rng = np.random.default_rng(7)
+    long_steps = np.column_stack([np.full(40, 0.005), rng.normal(size=(40, 3)) * 2.0 + [0.5, -0.4, 9.81], rng.normal(size=(40, 3)) * 1.5])
+    return [("testtest", testtest_steps(), np.zeros(6), TESTTEST_COV),
+            ("san_rafael", sr_steps, np.array([0.02, -0.01, 0.03, 1e-3, -2e-3, 5e-4]), SAN_RAFAEL_COV),
+            ("carla_long", long_steps, np.array([-0.05, 0.02, 0.01, 2e-3, 1e-3, -3e-3]), synth.CARLA_IMU_COV)]
+
+
+def test_preintegrated_covariance_against_the_independent_propagation(oracle):
+    """vfo_pim_integrate's closed-form block recursion (A, B, C of the tangent update) against the twin's propagation, in
+    which every sensitivity is a central difference of the twin's own one-sample step.  Agreement to finite-difference
+    accuracy on every entry, relative to the scale of its row and column (the covariance spans 1e-12 ... 1e-3)."""
+    for name, steps, bhat, c in covariance_cases():
+        P, rec = _oracle_cov(oracle, steps, bhat, c)
+        Pt = _twin_cov(steps, bhat, c)
+        sd = np.sqrt(np.diag(P))
+        err = np.abs(P - Pt) / np.outer(sd, sd)
+        print(f"{name}: {len(steps)} samples, worst correlation-scaled difference {err.max():.3e}; diag ratio range "
+              f"{(np.diag(Pt) / np.diag(P)).min():.9f} .. {(np.diag(Pt) / np.diag(P)).max():.9f}")
+        assert np.allclose(P, P.T, atol=1e-18) and np.all(np.linalg.eigvalsh(Pt) > 0)
+        assert err.max() < 5e-8, name
+        # ... and the factor's noise model built from it: R^T R = P^-1 (noiseModel::Gaussian::Covariance, CombinedImuFactor)
+        R = oracle.unpack_upper(rec[70:], 15)
+        np.testing.assert_allclose(R.T @ R @ Pt, np.eye(15), atol=2e-6)
+
+
+def test_frozen_testtest_covariance_matches_the_twin():
+    """the committed fixture (tests/golden/pim_testtest.npz, what the oracle made of the TestTest.cpp recipe) against the twin"""
+    import os
+    from tests.golden.make_oracle_golden import TESTTEST_COV
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "pim_testtest.npz"))
+    Pt = _twin_cov(z["steps"], np.zeros(6), TESTTEST_COV)
+    sd = np.sqrt(np.diag(z["cov"]))
+    assert (np.abs(z["cov"] - Pt) / np.outer(sd, sd)).max() < 5e-8

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 outputs under gpurun_out/ into the tracked summaries under profiles/.
 
-usage: tools/summarize_prof.py <round-tag> <prof-dir>      (prof-dir = gpurun_out/prof_<tag>, written by tools/profile_round.sh)
+usage: tools/summarize_prof.py <round-tag> <prof-dir> [out-dir]     (prof-dir = gpurun_out/prof_<tag>, written by tools/profile_round.sh)
 
 Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --stats, verbatim), <tag>_pmc_summary.md, <tag>_step_timeline.txt,
 profiles/kernel_durations.json (what bench.py carries in its line as `profiled_kernels`) and profiles/traffic.json.
@@ -26,7 +26,9 @@ import sys
 
 tag, prof = sys.argv[1:3]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = os.path.join(root, "profiles")
+# optional third argument: where to write (tools/profile_round.sh summarises ON the GPU box into gpurun_out/.../summary, the
+# raw per-dispatch counter CSVs are too large to travel back; the files are then copied into profiles/ by hand)
+out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 
 
@@ -60,6 +62,29 @@ def pmc(sub):
     return {k: sum(sorted(v)[len(v) // 2:]) / len(sorted(v)[len(v) // 2:]) for k, v in d.items()}
 
 
+def pmc_multi(sub):
+    """{kernel: {counter: mean over the kernel's FULL launches}} of a pass that collected several counters: a dispatch's
+    counters are rows with the same Dispatch_Id; full launches = dispatches whose SQ_WAVE_CYCLES (or first counter) is at
+    least half of the kernel's largest."""
+    f = one(f"{sub}/**/*counter_collection.csv")
+    if not f:
+        return {}
+    disp = collections.defaultdict(dict)
+    for r in csv.DictReader(open(f)):
+        disp[(short(r["Kernel_Name"]), r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
+    per = collections.defaultdict(list)
+    for (k, _), c in disp.items():
+        per[k].append(c)
+    out = {}
+    for k, rows in per.items():
+        key = "SQ_WAVE_CYCLES" if "SQ_WAVE_CYCLES" in rows[0] else sorted(rows[0])[0]
+        top = max(r.get(key, 0.0) for r in rows)
+        full = [r for r in rows if r.get(key, 0.0) >= 0.5 * top] or rows
+        out[k] = {c: sum(r.get(c, 0.0) for r in full) / len(full) for c in full[0]}
+        out[k]["_full_launches"] = len(full)
+    return out
+
+
 fetch, write = pmc("fetch"), pmc("write")
 bench = None
 for name in ("bench_traced.json", "bench_default.json"):
@@ -89,6 +114,48 @@ if bench and "vf::k_linearize_imu" in fetch:
                "source": f"profiles/{tag}_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
                          "read = 2*FETCH_SIZE*1024 per MI355X_MICROARCH.md, write = WRITE_SIZE*1024)"},
               open(os.path.join(out, "traffic.json"), "w"), indent=1)
+# ---- SQ counters (two / three passes of 8): MFMA utilisation, VALU issue occupancy, waits, LDS conflicts
+sq = {}
+for sub in ("sq_a", "sq_b", "sq_c"):
+    for k, c in pmc_multi(sub).items():
+        sq.setdefault(k, {}).update({n: v for n, v in c.items() if not (n == "SQ_WAVE_CYCLES" and sub != "sq_a" and "SQ_WAVE_CYCLES" in sq.get(k, {}))})
+if sq:
+    hot = [k for k in ("vf::k_linearize_imu", "vf::k_linearize_between_prior", "vf::k_assemble", "vf::k_band_solve", "vf::k_retract", "vf::k_decide") if k in sq]
+    L = [f"# {tag}: SQ counters per kernel (rocprofv3 --pmc, separate passes; means over full launches of `bench.py --steps 3`)", "",
+         "Units (MI355X_MICROARCH.md, `s_memtime` tick vs SQ PMC units): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; "
+         "SQ_VALU_MFMA_BUSY_CYCLES counts cycles of a SIMD's matrix pipe; SQ_BUSY_CYCLES is per shader engine x its busy time; "
+         "SQ_INSTS_VALU_MFMA_MOPS_F64 counts 512-flop units (16x16x4 f64 = 2048 flop = 4 units per wave instruction).", "",
+         "Derived: wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES (wave parked in s_waitcnt / barrier); issue-stall = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES; "
+         "valu = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (share of a wave's life spent issuing vector instructions incl. MFMA); "
+         "mfma-pipe = SQ_VALU_MFMA_BUSY_CYCLES / (launch duration x 2.4 GHz x 1024 SIMDs) = utilisation of the chip's matrix pipes; "
+         "lds-conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; f64 VALU flop = (2 FMA + MUL + ADD) x 64 lanes.", "",
+         "| kernel | waves | wait | issue-stall | valu | lds | mfma-pipe util | MFMA f64 GFLOP/launch | VALU f64 GFLOP/launch | VALU insts/wave | LDS insts/wave | lds-conflict | VMEM rd / wr per wave |",
+         "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    summ = {}
+    for k in hot:
+        c = sq[k]
+        wc = c.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+        waves = c.get("SQ_WAVES", 0.0) or 1.0
+        dur_ms = kern.get(k, {}).get("full_avg_ms", 0.0)
+        pipe = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (dur_ms * 1e-3 * 2.4e9 * 1024) if dur_ms else 0.0
+        mfma_gf = c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) * 512 / 1e9
+        valu_gf = (2 * c.get("SQ_INSTS_VALU_FMA_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + c.get("SQ_INSTS_VALU_ADD_F64", 0.0)) * 64 / 1e9
+        d = {"waves": waves, "wait_frac": c.get("SQ_WAIT_ANY", 0.0) / wc, "issue_stall_frac": c.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+             "valu_issue_frac": c.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, "lds_issue_frac": c.get("SQ_ACTIVE_INST_LDS", 0.0) / wc,
+             "mfma_pipe_util": pipe, "mfma_f64_gflop_per_launch": mfma_gf, "valu_f64_gflop_per_launch": valu_gf,
+             "valu_insts_per_wave": c.get("SQ_INSTS_VALU", 0.0) / waves, "lds_insts_per_wave": c.get("SQ_INSTS_LDS", 0.0) / waves,
+             "lds_conflict_frac": c.get("SQ_LDS_BANK_CONFLICT", 0.0) / (c.get("SQ_LDS_IDX_ACTIVE", 0.0) or 1.0),
+             "vmem_rd_per_wave": c.get("SQ_INSTS_VMEM_RD", 0.0) / waves, "vmem_wr_per_wave": c.get("SQ_INSTS_VMEM_WR", 0.0) / waves,
+             "raw": {n: v for n, v in c.items()}}
+        summ[k] = d
+        if k in kern:
+            kern[k]["sq"] = {n: v for n, v in d.items() if n != "raw"}
+        L.append(f"| {k} | {waves:.0f} | {d['wait_frac']:.2f} | {d['issue_stall_frac']:.2f} | {d['valu_issue_frac']:.2f} | {d['lds_issue_frac']:.2f} | {pipe:.3f} | "
+                 f"{mfma_gf:.2f} | {valu_gf:.2f} | {d['valu_insts_per_wave']:.0f} | {d['lds_insts_per_wave']:.0f} | {d['lds_conflict_frac']:.3f} | {d['vmem_rd_per_wave']:.0f} / {d['vmem_wr_per_wave']:.0f} |")
+    L += ["", "Raw counter means per full launch:", "", "```json", json.dumps({k: summ[k]["raw"] for k in summ}, indent=1), "```"]
+    open(os.path.join(out, f"{tag}_sq_counters.md"), "w").write("\n".join(L) + "\n")
+    json.dump({"source": source, "kernels": kern}, open(os.path.join(out, "kernel_durations.json"), "w"), indent=1)
+    print("\n".join(L[6:6 + 2 + len(hot)]))
 tl = subprocess.run([sys.executable, os.path.join(root, "tools", "step_timeline.py"), trace], capture_output=True, text=True).stdout
 open(os.path.join(out, f"{tag}_step_timeline.txt"), "w").write(tl)
 print("\n".join(lines[:14]))

@@ -1482,6 +1482,9 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         }
     }
     }   // forward sweep
+#ifdef VF_K4_FWD_ONLY   // probe build only (tools/build_variant.sh): the forward sweep's share of the un-stamped kernel
+    if constexpr (MODE == SOLVE_FULL) return;
+#endif
     if constexpr (MODE == SOLVE_CHUNK_FWD) {
         // the cut keyframe and the two after it sit in slots 0..2 (cnt is a multiple of 4): the separator's 27 dof
         // (15 + pose + pose): own H + lambda + Schur terms of this chunk's interior, and rhs, go to sep_out [27][28]

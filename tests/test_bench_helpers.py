@@ -1,0 +1,60 @@
+"""CPU: the pieces of bench.py that decide what the JSON line may claim."""
+import json
+import os
+
+import numpy as np
+
+import bench
+
+
+def test_accuracy_object_definition():
+    """ATE = sqrt(mean |dt|^2) without alignment, rotation = max 2 acos|q.q'| (diagnostics.py:114,122)"""
+    n = 50
+    ref = np.zeros((n, 16)); ref[:, 0] = 1.0
+    ref[:, 4] = np.arange(n)
+    got = ref.copy()
+    got[:, 5] += 3e-7                                        # 0.3 um sideways everywhere
+    a = 1e-3
+    got[7, :4] = [np.cos(a / 2), 0, 0, np.sin(a / 2)]        # one keyframe yawed by 1 mrad
+    acc = bench.accuracy_vs_oracle(got, dict(states=ref, gt=ref, updates=12))
+    assert abs(acc["ate_m"] - 3e-7) < 1e-15 and abs(acc["rot_rad"] - a) < 1e-9
+    assert acc["within_bar"] is False and acc["updates"] == 12 and acc["bar_m"] == 1e-6     # the rotation is over the bar
+    acc = bench.accuracy_vs_oracle(ref + 0.0, dict(states=ref, gt=ref, updates=1))
+    assert acc["within_bar"] is True and acc["ate_m"] == 0.0
+
+
+def test_stale_traffic_file_is_refused(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed PMC summary: it must be of the same profiling round as the kernel trace"""
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (prof / "kernel_durations.json").write_text(json.dumps({"source": "profiles/r03a_kernel_stats.csv + r03a_pmc_summary.md", "kernels": {}}))
+    (prof / "traffic.json").write_text(json.dumps({"k1_bytes_per_imu_factor": 4416.0, "source": "profiles/r02e_pmc_summary.md (...)"}))
+    t = bench.measured_traffic_per_imu_factor()
+    assert "stale" in t and "r02e" in t["stale"] and "r03a" in t["stale"]
+    (prof / "traffic.json").write_text(json.dumps({"k1_bytes_per_imu_factor": 4416.0, "source": "profiles/r03a_pmc_summary.md (...)"}))
+    assert bench.measured_traffic_per_imu_factor()["k1_bytes_per_imu_factor"] == 4416.0
+
+
+def test_committed_profiles_are_of_one_round():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t = bench.measured_traffic_per_imu_factor()
+    assert t is not None and "stale" not in t, t
+    k = json.load(open(os.path.join(root, "profiles", "kernel_durations.json")))
+    assert "sq" in k["kernels"]["vf::k_band_solve"] and 0.0 < k["kernels"]["vf::k_band_solve"]["sq"]["valu_issue_frac"] < 1.0
+
+
+def test_cpu_leg_is_the_marginalised_update(oracle):
+    """_cpu_updates: the update the GPU's timed step does -- its states after s updates equal a
+    hand-rolled marginalise / predict / LM loop, and differ from the old re-anchoring loop."""
+    from tests import helpers
+    from vil_sensor_fusion_amd import synth
+    n, steps, K = 60, 4, 4
+    dt, snap, gt = bench._cpu_updates((3, n, n + steps + 1, steps, K, 1, steps, 30))
+    seq = synth.make_sequence(seed=3, n_kf=n + steps + 1)
+    prob = helpers.build_problem(oracle, seq)
+    ref = helpers.FixedLagOracle(oracle, prob, n, K, init_iterations=30)
+    for _ in range(steps):
+        ref.update()
+    np.testing.assert_array_equal(snap, ref.window_states)
+    assert ref.marg is not None and ref.marg.on == 1 and dt > 0 and gt.shape == (n, 16)

@@ -164,7 +164,14 @@ def cpu_baseline(args, seq_len):
     done = args.steps + args.warmup
     steps1 = done if args.no_cpu_baseline else max(args.cpu_steps, done)
     dt1, snap, gt = _cpu_updates((0, n, seq_len, steps1, args.iterations, 1, done, args.init_iterations))
-    reference = dict(states=snap, gt=gt, updates=done)
+    reference = dict(states=snap, gt=gt, updates=done, more=[])
+    # accuracy is a property of the sequence too (DESIGN.md "Converged start"): a few more windows of the batch (seeds 1, 2,
+    # ... = GPU windows 1, 2, ... of rank 0) get a CPU reference as well, one forked worker each
+    extra = max(0, min(args.accuracy_windows, args.windows) - 1)
+    if extra:
+        with multiprocessing.get_context("fork").Pool(min(extra, cores)) as pool:
+            res = pool.map(_cpu_updates, [(w, n, seq_len, done, args.iterations, 1, done, args.init_iterations) for w in range(1, extra + 1)], chunksize=1)
+        reference["more"] = [dict(window=w + 1, states=r[1], gt=r[2]) for w, r in enumerate(res)]
     if args.no_cpu_baseline:
         return None, None, reference
     one = dict(value=steps1 / dt1, unit="keyframes/s", cores=1, kind="port", host_cores_available=cores,
@@ -398,6 +405,8 @@ def main():
                     help="processes that generate the synthetic sequences (0 = the host cores this job may use; 1 = no worker "
                          "processes, e.g. under a profiler)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--accuracy-windows", type=int, default=4,
+                    help="windows of rank 0 (0 .. n-1) whose final states are compared with the CPU oracle doing the same updates")
     ap.add_argument("--no-accuracy", action="store_true", help="skip the CPU oracle altogether (no accuracy object, no cpu_baseline)")
     ap.add_argument("--no-single-window", action="store_true")
     ap.add_argument("--reanchor", action="store_true", help="drop the oldest keyframe by re-anchoring tight priors instead of marginalising it")
@@ -474,7 +483,20 @@ def main():
     lm_after_timed = eng.read_lm(0)
     accuracy = None
     if reference is not None and reference["states"] is not None:
-        accuracy = accuracy_vs_oracle(eng.get_states(0, args.steps + args.warmup, args.window), reference)
+        done = args.steps + args.warmup
+        accuracy = accuracy_vs_oracle(eng.get_states(0, done, args.window), reference)
+        per = [dict(window=0, ate_m=accuracy["ate_m"], rot_rad=accuracy["rot_rad"])]
+        for m in reference.get("more", []):
+            a = accuracy_vs_oracle(eng.get_states(m["window"], done, args.window), dict(states=m["states"], gt=m["gt"], updates=done))
+            per.append(dict(window=m["window"], ate_m=a["ate_m"], rot_rad=a["rot_rad"]))
+        accuracy["windows"] = per
+        accuracy["ate_m_max"] = max(x["ate_m"] for x in per)
+        accuracy["ate_m_median"] = float(np.median([x["ate_m"] for x in per]))
+        accuracy["within_bar_all"] = bool(all(x["ate_m"] <= 1e-6 and x["rot_rad"] <= 1e-6 for x in per))
+        accuracy["note"] = ("ate_m / rot_rad are window 0; `windows` lists every compared window.  Two float64 normal-equation "
+                            "solvers agree on a 1000-pose fixed-lag window to (cond * eps) x (how far the window's soft modes move "
+                            "per update): 1e-8 ... 1e-6 m depending on the sequence (DESIGN.md, Converged start; "
+                            "tools/accuracy_sweep.py: 16 sequences, median 5e-8, worst 1.4e-6)")
 
     # Same update with GTSAM's LM termination rule switched on (vf_engine_set_convergence): a second,
     # clearly labelled number -- the headline above always runs all K trials on every window.  It continues on the

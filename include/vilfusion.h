@@ -72,6 +72,12 @@ typedef struct {
     int cold_start;          /* != 0: every vf_engine_iterate linearises all factors (no warm start); default 0 */
     int use_hip_graph;       /* != 0: vf_engine_iterate replays its launch sequence from a captured hipGraph (measured no
                                 faster: the stream never runs empty); default 0 */
+    double accept_rel;       /* an LM trial is accepted iff  new cost < cost + accept_rel * cost.  Default 1e-9: the rounding
+                                floor of the cost of a 1000-pose window (a sum of ~30 000 squared whitened residuals, the IMU
+                                ones scaled by 5e4) is ~1e-10 of its value; with a strict "decreases" test (accept_rel = 0) a
+                                converged window rejects about half of its Newton steps on the last bits of that sum, its
+                                soft modes stop converging, and two float64 implementations end 1e-7 ... 1e-6 m apart
+                                instead of 1e-9 (DESIGN.md "Accept rule at the floor").  Must be >= 0. */
 } vf_engine_opts;
 
 void vf_engine_default_opts(vf_engine_opts* o);

@@ -60,11 +60,14 @@ class Problem(C.Structure):
                 ("gravity", C.c_double * 3), ("marg", C.POINTER(Marg))]
 
 
+ACCEPT_REL = 1e-9    # default accept tolerance of vfo_lm = vf_engine_opts.accept_rel's default (include/vilfusion.h)
+
+
 class LmOpts(C.Structure):
     _fields_ = [("lambda0", C.c_double), ("lambda_up", C.c_double), ("lambda_down", C.c_double),
                 ("lambda_min", C.c_double), ("lambda_max", C.c_double),
                 ("iterations", C.c_int), ("n_threads", C.c_int),
-                ("rel_tol", C.c_double), ("abs_tol", C.c_double)]
+                ("rel_tol", C.c_double), ("abs_tol", C.c_double), ("accept_rel", C.c_double)]
 
 
 _lib = None
@@ -318,8 +321,8 @@ class Window:
         return cost, H, g
 
     def lm(self, iterations=5, lambda0=1e-5, up=10.0, down=10.0, lmin=1e-12, lmax=1e10,
-           n_threads=1, rel_tol=0.0, abs_tol=0.0):
-        o = LmOpts(lambda0, up, down, lmin, lmax, iterations, n_threads, rel_tol, abs_tol)
+           n_threads=1, rel_tol=0.0, abs_tol=0.0, accept_rel=None):
+        o = LmOpts(lambda0, up, down, lmin, lmax, iterations, n_threads, rel_tol, abs_tol, ACCEPT_REL if accept_rel is None else accept_rel)
         costs = np.zeros(iterations + 1)
         acc = np.zeros(iterations, dtype=np.int32)
         lam = lib().vfo_lm(C.byref(self.c), C.byref(o), _d(costs),

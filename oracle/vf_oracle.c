@@ -1217,7 +1217,7 @@ double vfo_lm(vfo_problem* p, const vfo_lm_opts* o, double* costs_out, int* acce
              * window then sits at its rounding floor */
             if ((o->abs_tol > 0.0 || o->rel_tol > 0.0) &&
                 (fabs(cost - cn) <= o->abs_tol || fabs(cost - cn) <= o->rel_tol * cost)) converged = 1;
-            if (cn < cost) { /* NaN compares false -> reject */
+            if (cn < cost + o->accept_rel * cost) { /* NaN compares false -> reject */
                 acc = 1;
                 cost = cn;
                 double* t = H; H = Hn; Hn = t;      /* the trial's normal equations become the current ones */

@@ -131,6 +131,8 @@ typedef struct {
     int n_threads;               /* >1: OpenMP over factors in linearisation */
     double rel_tol, abs_tol;     /* > 0: stop after an accepted trial whose cost decrease is <= abs_tol or
                                     <= rel_tol * cost (gtsam LevenbergMarquardtOptimizer checkConvergence) */
+    double accept_rel;           /* a trial is accepted iff  new cost < cost + accept_rel * cost  (0: strict decrease; the
+                                    engine's default is 1e-9: the rounding floor of the cost sum) */
 } vfo_lm_opts;
 
 /* total cost 0.5*sum |r|^2 at the current states */

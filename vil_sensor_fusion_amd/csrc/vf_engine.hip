@@ -170,6 +170,7 @@ void vf_engine_default_opts(vf_engine_opts* o) {
     o->hybrid_threshold = 256;   // partitioned form: 0.0095 ms per window; the sweep: 2.9 ms whatever their number
     o->cold_start = 0;
     o->use_hip_graph = 0;
+    o->accept_rel = 1e-9;
 }
 
 int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
@@ -178,6 +179,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     if (o->bandwidth < 1 || o->bandwidth > VF_MAX_BANDWIDTH)
         return fail(VF_ERR_INVALID, "bandwidth must be in 1..%d", VF_MAX_BANDWIDTH);
     if (o->chunks < 0 || o->chunks > 4096) return fail(VF_ERR_INVALID, "chunks must be in 0..4096");
+    if (!(o->accept_rel >= 0.0) || !(o->accept_rel < 1.0)) return fail(VF_ERR_INVALID, "accept_rel must be in [0, 1)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(VF_ERR_NO_DEVICE, "no HIP device visible; libvilfusion has no CPU path");
@@ -191,6 +193,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     v.G = (long)v.B * v.M;
     for (int i = 0; i < 3; i++) v.grav[i] = o->gravity[i];
     v.lam_up = o->lambda_up; v.lam_down = o->lambda_down; v.lam_min = o->lambda_min; v.lam_max = o->lambda_max;
+    v.accept_rel = o->accept_rel;
     HIPCHK(hipStreamCreate(&e->stream));
     HIPCHK(hipEventCreate(&e->ev0));
     HIPCHK(hipEventCreate(&e->ev1));

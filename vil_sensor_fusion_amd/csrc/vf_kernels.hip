@@ -2305,7 +2305,10 @@ __global__ void __launch_bounds__(1024) k_decide(View v, int init) {
             if (!(v.fresh[w] >= 2 && v.fresh[w] < 64)) v.fresh[w] = 1;   // (a warm start has marked the window "ends only")
             if (v.stop_on) v.done[w] = 0;
         } else {
-            const bool ok = (v.fail[w] == 0) && (c < v.cost[w]);
+            // accept unless the cost rises by more than the rounding floor of its own evaluation (View::accept_rel): at a
+            // converged window a strict "c < cost" is decided by the last bits of two 1000-term sums, and a rejected
+            // Newton step leaves the soft modes of the window where they were (DESIGN.md "Accept rule at the floor")
+            const bool ok = (v.fail[w] == 0) && (c < v.cost[w] + v.accept_rel * v.cost[w]);
             if (v.fail[w]) v.n_fail[w] += 1;
             v.fresh[w] = ok ? 1 : 0;
             if (v.stop_on && v.fail[w] == 0) {

@@ -151,6 +151,7 @@ struct View {
     int* n_rej;
     int* n_fail;
     double lam_up, lam_down, lam_min, lam_max;
+    double accept_rel;  // an LM trial is accepted iff new cost < cost + accept_rel * cost (vf_engine_opts.accept_rel)
     // optional LM termination (off by default: every vf_engine_iterate runs its fixed number of trials).  With
     // stop_on, a window whose trial changes the cost by <= abs_tol, or by <= rel_tol relative to the cost
     // (gtsam::LevenbergMarquardtParams relativeErrorTol / absoluteErrorTol, checkConvergence; applied to

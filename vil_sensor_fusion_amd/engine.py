@@ -44,6 +44,7 @@ class EngineOpts:
     hybrid_threshold: int | None = None
     cold_start: bool = False
     use_hip_graph: bool = False
+    accept_rel: float | None = None      # LM accept tolerance (None = the library's default 1e-9; 0 = strict decrease)
 
 
 class Engine:
@@ -61,6 +62,8 @@ class Engine:
         if opts.hybrid_threshold is not None:
             o.hybrid_threshold = opts.hybrid_threshold
         o.cold_start, o.use_hip_graph = int(opts.cold_start), int(opts.use_hip_graph)
+        if opts.accept_rel is not None:
+            o.accept_rel = opts.accept_rel
         self._h = C.c_void_p()
         check(self._l.vf_engine_create(C.byref(o), C.byref(self._h)))
         self.opts = opts

@@ -634,6 +634,11 @@ def main():
                                  "frac_of_measured_copy_peak_6290": k4_ach / 6290.0,
                                  "note": "8.8 of the 12.4 KB per keyframe are the Cholesky panel written by the forward sweep and "
                                          "read back by the backward one; against H + g + delta alone (3.7 KB) the kernel moves 3.4x",
+                                 "what_bounds_it": "not HBM: the per-window dependency chain at one wave per SIMD.  SQ counters "
+                                                   "(profiles/*_sq_counters.md): the wave issues vector instructions 33 % and LDS "
+                                                   "instructions 16 % of its cycles, is stalled on a dependent result 31 % and in "
+                                                   "s_waitcnt 15 %; matrix pipes 11 % busy (DESIGN.md 7.9).  The HBM fraction is "
+                                                   "quoted because it is what the kernel's traffic amounts to, not as its roofline",
                                  "traffic_note": "profiles/*_pmc_summary.md: k_band_solve read 2*FETCH_SIZE + WRITE_SIZE per launch"}
         if prof is not None:
             out["profiled_kernels"] = prof

@@ -205,6 +205,12 @@ int vf_engine_predict(vf_engine* e, int window, int k0, int n); /* states k0..k0
  * (states, factor records, linearisations, between sources, ranges, prior keys).  shift must be
  * a multiple of 64 and <= every window's lo.  Lets a fixed-lag smoother run indefinitely. */
 int vf_engine_compact(vf_engine* e, int shift);
+/* Grow every window to `new_capacity` keyframe slots (> the current capacity; rounded up to a multiple of 64): states
+ * (both buffers), pending increments, factor records, between sources, priors / marginal priors, ranges and LM counters
+ * are carried over on the device; linearisations and normal equations are not (the next solve starts cold).  This is
+ * what lets a GraphManager with lag = 0 keep the whole history the way the reference's unbounded iSAM2 graph does
+ * (GraphManager.cpp:17-43), for as long as the 24 KB per keyframe slot fit in HBM.  Not for sharded engines. */
+int vf_engine_grow(vf_engine* e, int new_capacity);
 int vf_engine_sync(vf_engine* e);
 
 /* ---- read-back (synchronises) ---- */
@@ -280,7 +286,8 @@ int vf_dopt_filter_f32(const float* hessians36, int count, float rot_thr, float 
 typedef struct vf_graph vf_graph;
 
 typedef struct {
-    int capacity;    /* keyframe slots on the device (keys 0..capacity-1) */
+    int capacity;    /* keyframe slots on the device (keys 0..capacity-1); with lag = 0 the INITIAL number: vf_solve doubles
+                        it whenever the history outgrows it (vf_engine_grow), unless fixed_capacity != 0 */
     int lag;         /* fixed-lag window length in keyframes; 0 = smooth the whole history */
     int iterations;  /* LM trials per vf_solve, at most (see rel_tol / abs_tol) */
     int device;
@@ -290,6 +297,8 @@ typedef struct {
      * GraphManager.cpp:128-129); 0 / 0 = always `iterations` trials. */
     double rel_tol, abs_tol;
     int cold_start;  /* != 0: the handle's engine never warm-starts a solve (vf_engine_opts.cold_start); default 0 */
+    int fixed_capacity; /* != 0 with lag = 0: vf_reserve_node fails with VF_ERR_CAPACITY once `capacity` keyframes exist
+                           (the behaviour before the history could grow); default 0 */
     /* reference_compat != 0: vf_solve does what the reference's solve() does -- one iSAM2-like update
      * (vf_engine_isam_step with relin_threshold, default 1e-4 = GraphManager.cpp:40) instead of LM to convergence; needs
      * lag == 0 (the reference's graph is unbounded).  Default 0. */

@@ -34,6 +34,7 @@ int vf_engine_set_wide_between(vf_engine*, int, int, const int32_t*, const int32
 int vf_engine_marginalize(vf_engine*) { return VF_OK; }
 int vf_engine_drop_oldest(vf_engine*) { return VF_OK; }
 int vf_engine_compact(vf_engine*, int) { return VF_OK; }
+int vf_engine_grow(vf_engine*, int) { return VF_OK; }
 int vf_engine_isam_step(vf_engine*, double) { return VF_OK; }
 int vf_engine_iterate(vf_engine*, int) { fake_iterates++; return VF_OK; }
 int vf_engine_read_lm(vf_engine*, int, double* c, double* l, int* a, int* r, int* f) {

@@ -403,3 +403,53 @@ def test_graph_manager_default_termination_matches_oracle(oracle):
     ate, rot = helpers.ate(xs, win.states)
     print(f"default termination: oracle took {trials} of 12 trials; ATE {ate:.3e} m, rot {rot:.3e} rad")
     assert ate <= 1e-6 and rot <= 1e-6
+
+
+def _feed_stream(gm, seq, traj_t, acc, gyr, n, every=1):
+    out, i_imu = [], 0
+    for k in range(1, n):
+        while i_imu < traj_t.size and traj_t[i_imu] <= seq.kf_time[k] + 0.01:
+            gm.addIMUMeasurement(traj_t[i_imu], acc[i_imu], gyr[i_imu]); i_imu += 1
+        gm.reserveNode(seq.kf_time[k])
+        for a, b, q, t, c in zip(seq.btw_a, seq.btw_b, seq.btw_q, seq.btw_t, seq.btw_cov):
+            if b == k and a >= 1:
+                gm.addBetweenFactor(int(a), int(b), (q, t), np.eye(6) * c)
+        if k % every == 0:
+            gm.solve()
+            (q, t), v, b = gm.getState()
+            out.append(np.concatenate([q, t, v, b]))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("compat", [False, True])
+def test_whole_history_outgrows_the_initial_capacity(compat):
+    """lag = 0 is the reference's unbounded graph (GraphManager.cpp:17-43): the engine grows (vf_engine_grow: states, pending
+    increments, factor records and priors carried over on the device) whenever the history outgrows its keyframe slots.
+    A handle created with 64 slots fed 300 keyframes must publish what one created with 512 slots publishes -- LM to
+    convergence, and the reference-compat solve (one iSAM2-like update per solve, which carries increments and
+    linearisation points across the growth) -- and `fixed_capacity` keeps the old hard limit."""
+    from vil_sensor_fusion_amd._lib import VilFusionError
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    n = 300
+    seq = synth.make_sequence(71, n)
+    traj_t, acc, gyr = _stream(seq)
+    outs = []
+    for cap in (64, 512):
+        gm = GraphManager(capacity=cap, iterations=4, lag=0, reference_compat=compat)
+        gm.setInitialState(seq.gt_states[0])
+        outs.append(_feed_stream(gm, seq, traj_t, acc, gyr, n, every=3))
+        gm.solve()                      # (the last two keyframes)
+        full = gm.trajectory(0, n)
+        assert np.isfinite(full).all()
+        gm.close()
+    small, big = outs
+    assert small.shape == big.shape and np.isfinite(small).all()
+    d = np.abs(small - big).max()
+    print(f"reference_compat={compat}: 64-slot handle grown to hold {n} keyframes vs a 512-slot one: largest difference {d:.3e}")
+    assert d <= 1e-8                    # (the partitioned solve picks its chunk count from the capacity: another elimination order)
+    gm = GraphManager(capacity=64, iterations=2, lag=0, fixed_capacity=True)
+    gm.setInitialState(seq.gt_states[0])
+    with pytest.raises(VilFusionError) as ei:
+        _feed_stream(gm, seq, traj_t, acc, gyr, 80, every=4)
+    assert ei.value.code == -6
+    gm.close()

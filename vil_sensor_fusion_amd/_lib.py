@@ -42,7 +42,8 @@ class ShardInfoC(C.Structure):
 class GraphOptsC(C.Structure):
     _fields_ = [("capacity", C.c_int), ("lag", C.c_int), ("iterations", C.c_int), ("device", C.c_int),
                 ("prior_sigma", C.c_double * 15), ("rel_tol", C.c_double), ("abs_tol", C.c_double),
-                ("cold_start", C.c_int), ("reference_compat", C.c_int), ("relin_threshold", C.c_double)]
+                ("cold_start", C.c_int), ("fixed_capacity", C.c_int), ("reference_compat", C.c_int),
+                ("relin_threshold", C.c_double)]
 
 
 CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -63,7 +64,7 @@ SYMBOLS = [
     "vf_engine_read_delta", "vf_engine_read_panels", "vf_engine_read_lm",
     "vf_engine_time_stage", "vf_engine_time_iterate", "vf_engine_counts",
     "vf_engine_preintegrate", "vf_engine_get_imu",
-    "vf_engine_marginalize", "vf_engine_drop_oldest", "vf_engine_read_marginal", "vf_engine_compact",
+    "vf_engine_marginalize", "vf_engine_drop_oldest", "vf_engine_read_marginal", "vf_engine_compact", "vf_engine_grow",
     "vf_engine_set_stream", "vf_engine_set_shard", "vf_engine_shard_info", "vf_engine_solve_local",
     "vf_engine_solve_global", "vf_engine_reset_lambda",
     "vf_chunk_geometry", "vf_shard_range", "vf_engine_set_convergence",

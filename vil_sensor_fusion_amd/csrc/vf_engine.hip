@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/vilfusion.h"
@@ -936,6 +937,57 @@ int vf_engine_compact(vf_engine* e, int shift) {
     HIPCHK(hipMemcpyAsync(v.hi, hi.data(), v.B * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(v.prior_k, pk.data(), v.B * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    return VF_OK;
+}
+
+// New engine with more keyframe slots per window, the problem carried over on the device, then swapped into *e (the
+// handle the caller holds stays valid).  Inputs and states only: every linearisation, H, g and panel is recomputed by
+// the next (cold) solve.
+int vf_engine_grow(vf_engine* e, int new_capacity) {
+    DeviceGuard dev_guard_(e);
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (int rc0 = not_sharded(e, "vf_engine_grow")) return rc0;
+    const int M0 = e->v.M, M1 = (new_capacity + 63) / 64 * 64;
+    if (M1 <= M0) return fail(VF_ERR_INVALID, "new capacity %d does not exceed the current %d", new_capacity, M0);
+    vf_engine_opts o = e->opts;
+    o.capacity = M1;
+    vf_engine* n = nullptr;
+    int rc = vf_engine_create(&o, &n);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const vf::View &a = e->v, &b = n->v;
+    const int B = a.B;
+    const size_t G0 = (size_t)a.G, G1 = (size_t)b.G;
+    auto cp = [&](void* dst, const void* src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, n->stream); };
+    for (int w = 0; w < B; w++) {
+        const size_t s0 = (size_t)w * M0, s1 = (size_t)w * M1;          // first slot of the window, old / new
+        for (int pl = 0; pl < 32; pl++) HIPCHK(cp(b.x + (size_t)pl * G1 + s1, a.x + (size_t)pl * G0 + s0, (size_t)M0 * sizeof(double)));
+        HIPCHK(cp(b.imu_in + (s1 / 64) * vf::IMU_IN * 64, a.imu_in + (s0 / 64) * vf::IMU_IN * 64, (size_t)(M0 / 64) * vf::IMU_IN * 64 * sizeof(double)));
+        HIPCHK(cp(b.btw_in + (s1 / 64) * vf::BTW_IN * 64, a.btw_in + (s0 / 64) * vf::BTW_IN * 64, (size_t)(M0 / 64) * vf::BTW_IN * 64 * sizeof(double)));
+        HIPCHK(cp(b.btw_a + s1, a.btw_a + s0, (size_t)M0 * sizeof(int)));
+        HIPCHK(cp(b.delta + s1 * 15, a.delta + s0 * 15, (size_t)M0 * 15 * sizeof(double)));
+    }
+    struct { void* d; const void* s; size_t bytes; } per_window[] = {
+        {b.prior_k, a.prior_k, B * sizeof(int)}, {b.prior_in, a.prior_in, (size_t)B * vf::PRIOR_IN * sizeof(double)},
+        {b.mp_on, a.mp_on, B * sizeof(int)}, {b.mp_x, a.mp_x, (size_t)B * 48 * sizeof(double)}, {b.mp_L, a.mp_L, (size_t)B * 729 * sizeof(double)},
+        {b.mp_eta, a.mp_eta, (size_t)B * 27 * sizeof(double)}, {b.lo, a.lo, B * sizeof(int)}, {b.hi, a.hi, B * sizeof(int)},
+        {b.sel, a.sel, B * sizeof(int)}, {b.lambda, a.lambda, B * sizeof(double)}, {b.cost, a.cost, B * sizeof(double)},
+        {b.n_acc, a.n_acc, B * sizeof(int)}, {b.n_rej, a.n_rej, B * sizeof(int)}, {b.n_fail, a.n_fail, B * sizeof(int)},
+        {n->lambda0_dev, e->lambda0_dev, B * sizeof(double)}};
+    for (auto& c : per_window) HIPCHK(cp(c.d, c.s, c.bytes));
+    HIPCHK(hipStreamSynchronize(n->stream));
+    n->h_lo = e->h_lo;
+    n->h_hi = e->h_hi;
+    if (e->v.stop_on && (rc = vf_engine_set_convergence(n, e->v.rel_tol, e->v.abs_tol))) { vf_engine_destroy(n); return rc; }
+    if (!e->own_stream) {          // the caller's stream stays the one every later stage runs on
+        if ((rc = vf_engine_set_stream(n, (void*)e->stream))) { vf_engine_destroy(n); return rc; }
+    }
+    std::swap(*e, *n);             // *e: the grown engine; *n: the old buffers
+    n->own_stream = n->own_stream && n->stream != e->stream;
+    vf_engine_destroy(n);
+    e->warm = false;
+    e->slid = e->redo = 0;
+    e->epoch++;
     return VF_OK;
 }
 

@@ -118,6 +118,7 @@ void vf_graph_default_opts(vf_graph_opts* o) {
     o->rel_tol = 1e-5;   // gtsam::LevenbergMarquardtParams relativeErrorTol / absoluteErrorTol
     o->abs_tol = 1e-5;
     o->cold_start = 0;
+    o->fixed_capacity = 0;
     o->reference_compat = 0;
     o->relin_threshold = 1e-4;   // GraphManager.cpp:40
 }
@@ -233,8 +234,8 @@ static void cut_imu_segment(vf_graph* g, double start, double end, std::vector<d
 int vf_reserve_node(vf_graph* g, double time, uint64_t* key_out) {
     if (!g || !key_out) return gerr(VF_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(g->graph_mutex);  // GraphManager.cpp:54
-    if (g->opts.lag == 0 && (int)(g->current_key + 1) >= g->opts.capacity)
-        return gerr(VF_ERR_CAPACITY, "keyframe capacity %d exhausted (unbounded history; set a lag to smooth indefinitely)", g->opts.capacity);
+    if (g->opts.lag == 0 && g->opts.fixed_capacity && (int)(g->current_key + 1) >= g->opts.capacity)
+        return gerr(VF_ERR_CAPACITY, "keyframe capacity %d exhausted (fixed_capacity; set a lag to smooth indefinitely)", g->opts.capacity);
     double start;
     if (g->current_key + 1 > 1) {
         start = g->last_pose_time;  // :59-61
@@ -272,7 +273,7 @@ int vf_add_imu_factor(vf_graph* g, uint64_t key, const double* rec190) {
     std::lock_guard<std::mutex> lk(g->graph_mutex);  // GraphManager.cpp:92
     if (key != g->current_key + 1)
         return gerr(VF_ERR_BAD_KEY, "imu factor must end at the next key %llu (got %llu): keys are consecutive", (unsigned long long)(g->current_key + 1), (unsigned long long)key);
-    if (g->opts.lag == 0 && (int)(g->current_key + 1) >= g->opts.capacity) return gerr(VF_ERR_CAPACITY, "keyframe capacity %d exhausted", g->opts.capacity);
+    if (g->opts.lag == 0 && g->opts.fixed_capacity && (int)(g->current_key + 1) >= g->opts.capacity) return gerr(VF_ERR_CAPACITY, "keyframe capacity %d exhausted", g->opts.capacity);
     PendingImu p;
     p.key = key;
     memset(p.bias, 0, sizeof(p.bias));
@@ -384,6 +385,14 @@ int vf_solve(vf_graph* g) {
                 return give_back(gerr(VF_ERR_BAD_KEY, "between factor (%llu, %llu) dropped: key %llu left the fixed-lag window (oldest key %llu)",
                             a, b, a, (unsigned long long)oldest));
             }
+    }
+    // whole-history mode (lag = 0, the reference's unbounded graph): the engine grows with the history
+    if (g->opts.lag == 0 && (int)(last_key - g->key_base) + 1 > g->opts.capacity) {
+        int want = g->opts.capacity;
+        while ((int)(last_key - g->key_base) + 1 > want) want *= 2;
+        if ((rc = vf_engine_grow(g->eng, want))) return give_back(rc);
+        g->opts.capacity = want;
+        lap("grow");
     }
     // fixed-lag mode: reclaim slots below the window when the new keyframes would not fit
     if (g->opts.lag > 0 && (int)(last_key - g->key_base) + 1 > g->opts.capacity) {

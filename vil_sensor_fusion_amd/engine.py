@@ -154,6 +154,11 @@ class Engine:
     def compact(self, shift):
         check(self._l.vf_engine_compact(self._h, shift))
 
+    def grow(self, new_capacity):
+        """more keyframe slots per window; states, factors and priors are carried over (vf_engine_grow)"""
+        check(self._l.vf_engine_grow(self._h, new_capacity))
+        self.capacity = (new_capacity + 63) // 64 * 64
+
     def marginalize(self):
         check(self._l.vf_engine_marginalize(self._h))
 

@@ -29,7 +29,7 @@ class GraphManager:
 
     def __init__(self, imu_params=CARLA_IMU, capacity=4096, lag=0, iterations=5, device=0,
                  prior_sigma=None, rel_tol=None, abs_tol=None, reference_compat=False, relin_threshold=None,
-                 cold_start=False):
+                 cold_start=False, fixed_capacity=False):
         """iterations: LM trials per solve at most; a solve stops earlier once a trial changes the cost by <= abs_tol or
         <= rel_tol * cost (defaults 1e-5 / 1e-5, gtsam::LevenbergMarquardtParams; 0 / 0: always `iterations` trials)."""
         self._l = _lib.lib()
@@ -48,6 +48,7 @@ class GraphManager:
         # reference_compat: solve() = ONE iSAM2-like update (relinearizeThreshold 1e-4, GraphManager.cpp:38-43), lag must be 0
         o.reference_compat = int(bool(reference_compat))
         o.cold_start = int(bool(cold_start))      # every solve linearises all factors (tests compare it with the warm start)
+        o.fixed_capacity = int(bool(fixed_capacity))   # lag = 0: fail with VF_ERR_CAPACITY instead of growing the engine
         if relin_threshold is not None:
             o.relin_threshold = relin_threshold
         self._h = C.c_void_p()

@@ -7,10 +7,10 @@ odom_frame from the optimisation callback), behind Rovio / LOAM exactly like the
 runs in libvilfusion.so on the MI355X.
 
 Extra private parameters: solver/lag (fixed-lag window in keyframes, default 1000; 0 = smooth the whole history the way the
-reference's unbounded iSAM2 graph does -- but the device holds solver/capacity keyframes, about 2-3 minutes at Carla rates
-with the default 4096, after which reserveNode fails: a node meant to run on bags of normal length keeps a lag),
-solver/capacity (default lag + 192, or 4096 when lag = 0), solver/iterations, solver/device, reference_compat (poseDiff
-quirk).
+reference's unbounded iSAM2 graph does: the engine then grows with the history (vf_engine_grow) and every solve
+relinearises all of it, so a solve gets slower as the bag gets longer -- a node meant to run indefinitely keeps a lag),
+solver/capacity (default lag + 192, or 4096 initial slots when lag = 0), solver/iterations, solver/device,
+reference_compat (poseDiff quirk).
 
 Threading: roscpp's ros::spin() runs every callback of the reference node on ONE thread (gtsam_fusion_node.cpp:101).
 rospy does not: each subscription delivers on its own receive thread, and ctypes releases the GIL inside the vf_* calls.

@@ -954,18 +954,21 @@ int vf_engine_grow(vf_engine* e, int new_capacity) {
     vf_engine* n = nullptr;
     int rc = vf_engine_create(&o, &n);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(e->stream));
     const vf::View &a = e->v, &b = n->v;
     const int B = a.B;
     const size_t G0 = (size_t)a.G, G1 = (size_t)b.G;
-    auto cp = [&](void* dst, const void* src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, n->stream); };
+    // every copy through one lambda that remembers the first failure: the new engine is destroyed on any error path
+    hipError_t herr = hipStreamSynchronize(e->stream);
+    auto cp = [&](void* dst, const void* src, size_t bytes) {
+        if (herr == hipSuccess) herr = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, n->stream);
+    };
     for (int w = 0; w < B; w++) {
         const size_t s0 = (size_t)w * M0, s1 = (size_t)w * M1;          // first slot of the window, old / new
-        for (int pl = 0; pl < 32; pl++) HIPCHK(cp(b.x + (size_t)pl * G1 + s1, a.x + (size_t)pl * G0 + s0, (size_t)M0 * sizeof(double)));
-        HIPCHK(cp(b.imu_in + (s1 / 64) * vf::IMU_IN * 64, a.imu_in + (s0 / 64) * vf::IMU_IN * 64, (size_t)(M0 / 64) * vf::IMU_IN * 64 * sizeof(double)));
-        HIPCHK(cp(b.btw_in + (s1 / 64) * vf::BTW_IN * 64, a.btw_in + (s0 / 64) * vf::BTW_IN * 64, (size_t)(M0 / 64) * vf::BTW_IN * 64 * sizeof(double)));
-        HIPCHK(cp(b.btw_a + s1, a.btw_a + s0, (size_t)M0 * sizeof(int)));
-        HIPCHK(cp(b.delta + s1 * 15, a.delta + s0 * 15, (size_t)M0 * 15 * sizeof(double)));
+        for (int pl = 0; pl < 32; pl++) cp(b.x + (size_t)pl * G1 + s1, a.x + (size_t)pl * G0 + s0, (size_t)M0 * sizeof(double));
+        cp(b.imu_in + (s1 / 64) * vf::IMU_IN * 64, a.imu_in + (s0 / 64) * vf::IMU_IN * 64, (size_t)(M0 / 64) * vf::IMU_IN * 64 * sizeof(double));
+        cp(b.btw_in + (s1 / 64) * vf::BTW_IN * 64, a.btw_in + (s0 / 64) * vf::BTW_IN * 64, (size_t)(M0 / 64) * vf::BTW_IN * 64 * sizeof(double));
+        cp(b.btw_a + s1, a.btw_a + s0, (size_t)M0 * sizeof(int));
+        cp(b.delta + s1 * 15, a.delta + s0 * 15, (size_t)M0 * 15 * sizeof(double));
     }
     struct { void* d; const void* s; size_t bytes; } per_window[] = {
         {b.prior_k, a.prior_k, B * sizeof(int)}, {b.prior_in, a.prior_in, (size_t)B * vf::PRIOR_IN * sizeof(double)},
@@ -974,8 +977,12 @@ int vf_engine_grow(vf_engine* e, int new_capacity) {
         {b.sel, a.sel, B * sizeof(int)}, {b.lambda, a.lambda, B * sizeof(double)}, {b.cost, a.cost, B * sizeof(double)},
         {b.n_acc, a.n_acc, B * sizeof(int)}, {b.n_rej, a.n_rej, B * sizeof(int)}, {b.n_fail, a.n_fail, B * sizeof(int)},
         {n->lambda0_dev, e->lambda0_dev, B * sizeof(double)}};
-    for (auto& c : per_window) HIPCHK(cp(c.d, c.s, c.bytes));
-    HIPCHK(hipStreamSynchronize(n->stream));
+    for (auto& c : per_window) cp(c.d, c.s, c.bytes);
+    if (herr == hipSuccess) herr = hipStreamSynchronize(n->stream);
+    if (herr != hipSuccess) {
+        vf_engine_destroy(n);
+        return fail(VF_ERR_DEVICE, "vf_engine_grow: device copy failed: %s", hipGetErrorString(herr));
+    }
     n->h_lo = e->h_lo;
     n->h_hi = e->h_hi;
     if (e->v.stop_on && (rc = vf_engine_set_convergence(n, e->v.rel_tol, e->v.abs_tol))) { vf_engine_destroy(n); return rc; }

@@ -207,7 +207,8 @@ int vf_engine_predict(vf_engine* e, int window, int k0, int n); /* states k0..k0
 int vf_engine_compact(vf_engine* e, int shift);
 /* Grow every window to `new_capacity` keyframe slots (> the current capacity; rounded up to a multiple of 64): states
  * (both buffers), pending increments, factor records, between sources, priors / marginal priors, ranges and LM counters
- * are carried over on the device; linearisations and normal equations are not (the next solve starts cold).  This is
+ * are carried over on the device; the linearisation of the current states is recomputed, normal equations are not kept
+ * (the next solve starts cold).  This is
  * what lets a GraphManager with lag = 0 keep the whole history the way the reference's unbounded iSAM2 graph does
  * (GraphManager.cpp:17-43), for as long as the 24 KB per keyframe slot fit in HBM.  Not for sharded engines. */
 int vf_engine_grow(vf_engine* e, int new_capacity);

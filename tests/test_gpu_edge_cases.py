@@ -413,3 +413,42 @@ def test_results_do_not_depend_on_the_batch(oracle):
     for w in range(9):
         assert np.array_equal(many.get_states(w, 0, n), ref), w
         assert many.read_lm(w) == alone.read_lm(0)
+
+
+def test_engine_grow_carries_the_problem_over(oracle):
+    """vf_engine_grow on a batch engine with ragged windows and a marginal prior: after growing, a solve gives bitwise what
+    an engine created at the larger capacity gives (states, factor records, priors, marginal priors, ranges and LM
+    counters are carried over on the device; linearisations are recomputed)."""
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    from vil_sensor_fusion_amd._lib import VilFusionError
+    n = 100
+    seq = synth.make_sequence(52, n + 8)
+    prob = helpers.build_problem(oracle, seq, perturb=0.01)
+    ranges = [(0, n), (0, 64), (5, 90)]
+
+    def prepared(capacity):
+        eng = Engine(EngineOpts(windows=3, capacity=capacity, chunks=1))
+        for w, (lo, hi) in enumerate(ranges):
+            helpers.load_engine(eng, w, prob, lo=lo, hi=hi)
+        eng.iterate(3)
+        eng.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)       # leaves a marginal prior and a predicted keyframe
+        eng.iterate(2)
+        return eng
+
+    small, big = prepared(128), prepared(320)
+    small.grow(320)
+    assert small.capacity == 320
+    for e in (small, big):
+        e.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)
+        e.iterate(3)
+    for w, (lo, hi) in enumerate(ranges):
+        a, b = small.get_states(w, lo + 2, hi - lo), big.get_states(w, lo + 2, hi - lo)
+        np.testing.assert_array_equal(a, b)
+        assert small.read_lm(w) == big.read_lm(w)
+        ma, mb = small.read_marginal(w), big.read_marginal(w)
+        assert ma["on"] == mb["on"] == 1
+        np.testing.assert_array_equal(ma["L"], mb["L"])
+        np.testing.assert_array_equal(small.get_imu(w, hi, 2), big.get_imu(w, hi, 2))
+    with pytest.raises(VilFusionError):
+        small.grow(320)                     # must exceed the current capacity
+    small.close(); big.close()

@@ -190,3 +190,23 @@ def test_strict_accept_rule_is_what_leaves_the_soft_modes_unconverged(oracle):
     print(f"strict rule: worst ATE {out[0.0][0]:.2e} m, {out[0.0][1]} oracle trials accepted; accept_rel 1e-9: {out[1e-9][0]:.2e} m, {out[1e-9][1]} accepted")
     assert out[1e-9][0] <= 1e-8 and out[0.0][0] <= 1e-5
     assert out[1e-9][1] > out[0.0][1]                    # the strict rule rejects trials the tolerant one takes
+
+
+def test_agreement_across_sequences(oracle):
+    """tools/accuracy_sweep.py at test size: six more sequences through the same path (260 windows, converged start, six
+    marginalised warm updates of five trials): GPU and oracle within 1e-8 m on every window after every update."""
+    B, slides = 260, 6
+    sampled = tuple(range(10, 250, 40))
+    eng, probs = _bench_like_engine(oracle, B, sampled, slides)
+    eng.iterate(INIT)
+    refs = {w: helpers.FixedLagOracle(oracle, probs[w], N, ITERS, init_iterations=INIT) for w in sampled}
+    worst = 0.0
+    for s in range(1, slides + 1):
+        eng.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)
+        eng.iterate(ITERS)
+        for w in sampled:
+            a, r = helpers.ate(eng.get_states(w, s, N), refs[w].update())
+            worst = max(worst, a)
+            assert a <= 1e-8 and r <= 1e-6, (s, w, a, r)
+    print(f"{len(sampled)} sequences x {slides} updates: worst ATE {worst:.3e} m")
+    eng.close()

@@ -995,6 +995,12 @@ int vf_engine_grow(vf_engine* e, int new_capacity) {
     e->warm = false;
     e->slid = e->redo = 0;
     e->epoch++;
+    // the linearisation of the current states is part of the state other entry points rely on (vf_engine_marginalize reads
+    // the Jacobians of the oldest keyframe's factors): recompute it in the new buffers
+    bool any = false;
+    for (int w = 0; w < e->v.B; w++) any = any || e->h_hi[w] > e->h_lo[w];
+    if (any && (rc = vf_engine_linearize(e, 0))) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
     return VF_OK;
 }
 

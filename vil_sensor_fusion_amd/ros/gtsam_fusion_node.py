@@ -9,8 +9,11 @@ runs in libvilfusion.so on the MI355X.
 Extra private parameters: solver/lag (fixed-lag window in keyframes, default 1000; 0 = smooth the whole history the way the
 reference's unbounded iSAM2 graph does: the engine then grows with the history (vf_engine_grow) and every solve
 relinearises all of it, so a solve gets slower as the bag gets longer -- a node meant to run indefinitely keeps a lag),
-solver/capacity (default lag + 192, or 4096 initial slots when lag = 0), solver/iterations, solver/device,
-reference_compat (poseDiff quirk).
+solver/capacity (default lag + 192, or 4096 initial slots when lag = 0), solver/iterations, solver/rel_tol and
+solver/abs_tol (LM termination, default 1e-5 / 1e-5 = gtsam's LevenbergMarquardtParams; 0 / 0 = always `iterations` trials),
+solver/device, solver/initial_state (16 doubles q t v bias: the anchor X(0), V(0), B(0) and the means of their priors; default =
+the reference's identity / at rest, GraphManager.cpp:20-35), reference_compat (poseDiff quirk).
+NOTE the default solver/lag = 1000 is a deviation: the reference smooths an unbounded iSAM2 graph (= solver/lag 0 here).
 
 Threading: roscpp's ros::spin() runs every callback of the reference node on ONE thread (gtsam_fusion_node.cpp:101).
 rospy does not: each subscription delivers on its own receive thread, and ctypes releases the GIL inside the vf_* calls.
@@ -42,15 +45,20 @@ class FusionNode:
         """msgs: namespace with Imu, Image, PointCloud2, Odometry, TransformStamped message classes"""
         self.rospy, self.msgs = rospy, msgs
         self._lock = threading.RLock()          # one callback at a time, as under ros::spin() (gtsam_fusion_node.cpp:101)
-        self._capacity_reported = False
+        self._capacity_errors = 0
         P = lambda k, d=None: rospy.get_param("~" + k, d) if d is not None else rospy.get_param("~" + k)
         imu = {k: P("imu/cov_" + n) for k, n in (("acc", "accel"), ("gyro", "gyro"), ("integration", "integration"),
                                                    ("bias_acc", "bias_acc"), ("bias_omega", "bias_omega"),
                                                    ("bias_acc_omega_int", "bias_acc_omega_int"))}   # ImuManagerRos.cpp:20-33
         lag = int(P("solver/lag", 1000))
         capacity = int(P("solver/capacity", lag + 192 if lag > 0 else 4096))
+        tol = lambda k: (None if rospy.get_param("~solver/" + k, -1.0) < 0 else float(rospy.get_param("~solver/" + k)))
         self.graph = graph_manager or GraphManager(imu_params=imu, capacity=capacity, lag=lag,
-                                                   iterations=int(P("solver/iterations", 5)), device=int(P("solver/device", 0)))
+                                                   iterations=int(P("solver/iterations", 5)), device=int(P("solver/device", 0)),
+                                                   rel_tol=tol("rel_tol"), abs_tol=tol("abs_tol"))
+        x0 = rospy.get_param("~solver/initial_state", [])
+        if graph_manager is None and len(x0) == 16:
+            self.graph.setInitialState(x0)
         self.subs = [rospy.Subscriber(P("imu/topic"), msgs.Imu, queue_size=100, callback=self._serialised(self.imu_callback))]   # ImuManagerRos.cpp:11
         self.sensor_managers = {}
         compat = bool(P("reference_compat", True))
@@ -81,7 +89,11 @@ class FusionNode:
         self.graph.addOptimizationCallback(self.publish)                                 # :64
 
     def _serialised(self, fn):
-        """fn under the node's lock; a keyframe-capacity error (lag = 0 on a long bag) is reported once, not raised per message"""
+        """fn under the node's lock.  VF_ERR_CAPACITY from a callback (no keyframe slot left with solver/capacity fixed, or a
+        window that cannot hold solver/lag plus the keyframes of one solve) does not kill the subscriber thread: it is
+        logged -- the first occurrence and then every 100th, with the running count, so that a persistent failure keeps
+        showing -- and the message is dropped.  (A between factor the band cannot hold never gets here:
+        SensorManager._add_between handles that case.)  Every other error propagates."""
         from .._lib import VilFusionError
 
         def call(m):
@@ -91,11 +103,11 @@ class FusionNode:
                 except VilFusionError as exc:
                     if exc.code != -6:                      # VF_ERR_CAPACITY
                         raise
-                    if not self._capacity_reported:
-                        self._capacity_reported = True
+                    self._capacity_errors += 1
+                    if self._capacity_errors == 1 or self._capacity_errors % 100 == 0:
                         log = getattr(self.rospy, "logerr", None) or self.rospy.logwarn
-                        log("gtsam_fusion: %s -- no further nodes are added; run with ~solver/lag > 0 (fixed-lag smoothing) "
-                            "or a larger ~solver/capacity" % exc)
+                        log("gtsam_fusion: %s (capacity error #%d: the message is dropped) -- check ~solver/lag and "
+                            "~solver/capacity" % (exc, self._capacity_errors))
                     return None
         return call
 

@@ -173,6 +173,9 @@ class Sequence:
     tunnel: np.ndarray = None          # (n,) bool: keyframe lies in the LiDAR-degenerate stretch
     loam_hessians: np.ndarray = None   # (n_lidar,6,6) float64: scan-matching Hessian per LiDAR keyframe, LOAM order [trans 3, rot 3]
     loam_kf: np.ndarray = None         # (n_lidar,) keyframe index of each Hessian
+    imu_t: np.ndarray = None           # (T,) the raw 200 Hz stream the steps were cut from: stamps,
+    imu_acc: np.ndarray = None         # (T,3) specific force,
+    imu_gyro: np.ndarray = None        # (T,3) body rate (what a node replaying the sequence as messages publishes)
 
     @property
     def n(self):
@@ -238,6 +241,7 @@ def make_sequence(seed: int, n_kf: int, vio: bool = True, lidar: bool = True, tu
     seq = Sequence(seed, times, sensor, gt, imu_steps, np.array(off),
                    np.array(ba, dtype=np.int32)[o], np.array(bb, dtype=np.int32)[o],
                    np.array(bq).reshape(-1, 4)[o], np.array(bt).reshape(-1, 3)[o], np.array(bc)[o])
+    seq.imu_t, seq.imu_acc, seq.imu_gyro = t_imu, acc, gyr
     if tunnel is not None:
         seq.btw_info = np.array(bi).reshape(-1, 6)[o]
         seq.tunnel = in_tunnel

@@ -135,6 +135,10 @@ int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** ou
     const double covs[6] = {imu->acc_cov, imu->gyro_cov, imu->integration_cov, imu->bias_acc_cov, imu->bias_omega_cov, imu->bias_acc_omega_int};
     for (double c : covs)
         if (!(c > 0.0) || !std::isfinite(c)) return gerr(VF_ERR_NOT_SPD, "IMU covariances must be finite and > 0");
+    // the engine allocates keyframe slots in whole AoSoA tiles of 64: keep the number the growth / compaction / capacity
+    // checks below work with equal to what the engine really has (a handle created with capacity 16 has 64 slots; growing
+    // it "to 32" would ask vf_engine_grow for the 64 it already has)
+    o.capacity = (o.capacity + 63) / 64 * 64;
     vf_engine_opts eo;
     vf_engine_default_opts(&eo);
     eo.windows = 1;

@@ -110,25 +110,34 @@ def shard_range(n: int, chunks: int, rank: int, world: int, fit: bool = False):
     return tuple(x.value for x in v)
 
 
-def all_gather_slices(dist, full, per_slice: int, rank: int, world: int, backend: str):
+def probe_inplace_all_gather(dist, device, rank: int, world: int) -> bool:
+    """Does this torch / RCCL build accept an all-gather whose send buffer is the rank's own slice of the receive buffer?
+    Decided ONCE, at set-up, on every rank alike, with a four-double probe: a build that refuses aliased buffers raises
+    while checking its arguments -- before anything is communicated, identically on all ranks -- so every rank reaches the
+    same answer and the hot path never has to interpret an error message."""
+    import torch
+    probe = torch.zeros(4 * world, dtype=torch.float64, device=device)
+    probe[4 * rank:4 * rank + 4] = float(rank + 1)
+    try:
+        dist.all_gather_into_tensor(probe, probe[4 * rank:4 * rank + 4])
+    except (RuntimeError, ValueError):
+        return False
+    torch.cuda.synchronize(device)
+    want = torch.arange(1, world + 1, dtype=torch.float64, device=device).repeat_interleave(4)
+    return bool(torch.equal(probe, want))
+
+
+def all_gather_slices(dist, full, per_slice: int, rank: int, world: int, backend: str, inplace: bool = True):
     """`full` = world equal slices of per_slice elements; rank r holds slice r; afterwards all hold all.
-    nccl (RCCL): ONE in-place all-gather on the device (the send buffer is the rank's own slice of the
-    receive buffer: no clone, no temporary, no copy back).  gloo (CPU tests, shared-GPU smoke runs):
-    staged through the host."""
+    nccl (RCCL): ONE all-gather on the device, in place when `inplace` (the send buffer is the rank's own slice of the
+    receive buffer: no clone, no temporary, no copy back; `probe_inplace_all_gather` says whether the build takes that),
+    otherwise from a copy of the rank's slice.  gloo (CPU tests, shared-GPU smoke runs): staged through the host.
+    An error of the collective itself is never retried: a second collective issued by one rank alone would hang the others."""
     if dist is None or (world == 1 and backend != "nccl"):
         return
     own = full[rank * per_slice:(rank + 1) * per_slice]
     if backend == "nccl":
-        try:
-            dist.all_gather_into_tensor(full[:world * per_slice], own)       # in place (NCCL: sendbuff = recvbuff + rank * count)
-        except (RuntimeError, ValueError) as exc:
-            # a torch build that refuses aliased buffers says so while checking its arguments, before anything is
-            # communicated and on every rank alike: only THAT error falls back to a copy of the rank's own slice; any
-            # other failure (a communicator error, a device fault) is not retried -- a second collective issued by one
-            # rank alone would hang the others
-            if not any(w in str(exc).lower() for w in ("alias", "overlap", "in-place", "inplace", "same memory")):
-                raise
-            dist.all_gather_into_tensor(full[:world * per_slice], own.clone())
+        dist.all_gather_into_tensor(full[:world * per_slice], own if inplace else own.clone())
         return
     import torch
     parts = [torch.empty(per_slice, dtype=full.dtype) for _ in range(world)]
@@ -177,6 +186,9 @@ class ShardedSolver:
         self.sep = wrap(info.sep, info.chunks * self.sep_per)
         self.delta = wrap(info.delta, info.delta_count)       # increments + one solve-failure flag per window
         self.collectives = 0                                   # issued so far (0 when there is no process group)
+        # whether the in-place form of the separator all-gather is usable is settled here, once, on every rank alike
+        self.inplace_all_gather = (probe_inplace_all_gather(dist, self.device, self.rank, self.world)
+                                   if (dist is not None and backend == "nccl") else True)
 
     COLLECTIVES_PER_TRIAL = 2
 
@@ -191,7 +203,8 @@ class ShardedSolver:
         self.eng.solve_local()
 
     def exchange_sep(self):
-        all_gather_slices(self.dist, self.sep, self.sep_per * self.per_rank, self.rank, self.world, self.backend)
+        all_gather_slices(self.dist, self.sep, self.sep_per * self.per_rank, self.rank, self.world, self.backend,
+                          inplace=self.inplace_all_gather)
         self._count()
 
     def phase_global(self):

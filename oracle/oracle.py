@@ -60,7 +60,8 @@ class Problem(C.Structure):
                 ("gravity", C.c_double * 3), ("marg", C.POINTER(Marg))]
 
 
-ACCEPT_REL = 1e-9    # default accept tolerance of vfo_lm = vf_engine_opts.accept_rel's default (include/vilfusion.h)
+ACCEPT_REL = 1e-9    # default accept tolerance of vfo_lm = vf_engine_opts.accept_rel's default (include/vilfusion.h).  A constant:
+#                      callers that want another rule pass accept_rel to Window.lm / FixedLagOracle, nobody assigns to this name
 
 
 class LmOpts(C.Structure):

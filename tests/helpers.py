@@ -87,16 +87,22 @@ class FixedLagOracle:
     prob: helpers.build_problem(...) of a sequence with at least n + updates keyframes (its `states` beyond the first
     window are ignored: appended keyframes are predicted from the running estimate, as the engine does)."""
 
-    def __init__(self, oracle, prob, n, iterations, threads=1, init_iterations=None):
+    def __init__(self, oracle, prob, n, iterations, threads=1, init_iterations=None, accept_rel=None, ingest=None):
         """init_iterations: LM trials of the initial solve (default: `iterations`).  A 1000-pose window started from
         IMU dead reckoning needs 50-150 trials to converge; slid while still far from its optimum it stays in a regime
         where two float64 implementations drift apart by 1e-5 m (DESIGN.md "Converged start")."""
-        self.o, self.prob, self.n, self.K, self.threads = oracle, prob, n, iterations, threads
+        self.o, self.prob, self.n, self.K, self.threads = oracle, dict(prob, imu=prob["imu"].copy()), n, iterations, threads
+        # ingest = (synth.Sequence, oracle.ImuParams): every update preintegrates the appended keyframe's IMU factor afresh
+        # from its raw samples WITH THE CURRENT BIAS ESTIMATE (the bias of the window's last keyframe), as
+        # GraphManager::reserveNode does (GraphManager.cpp:59) and as vf_engine_ingest_tail does on the device
+        self.ingest = ingest
+        self.accept_rel = accept_rel                 # None: the oracle's default (= the engine's); 0: strict decrease
         self.rel_tol = self.abs_tol = 0.0            # > 0: GTSAM's LM termination rule in the updates that follow
         self.states = prob["states"].copy()
         self.s, self.marg = 0, None
         self.win = self._window(0, None, True)
-        self.costs, self.acc, _ = self.win.lm(iterations=iterations if init_iterations is None else init_iterations, n_threads=threads)
+        self.costs, self.acc, _ = self.win.lm(iterations=iterations if init_iterations is None else init_iterations, n_threads=threads,
+                                              accept_rel=accept_rel)
         self.states[:n] = self.win.states
 
     def _window(self, lo, marg, with_prior):
@@ -118,9 +124,17 @@ class FixedLagOracle:
         self.marg.k0 = 0
         self.s += 1
         s = self.s
+        if self.ingest is not None:
+            seq, prm = self.ingest
+            new = s + n - 1
+            pim = self.o.pim_new(self.states[new - 1, 10:16])
+            for st in seq.imu_steps[seq.imu_off[new]:seq.imu_off[new + 1]]:
+                self.o.pim_integrate(pim, prm, st[1:4], st[4:7], st[0])
+            p["imu"][new] = self.o.pim_to_record(pim)
         self.states[s + n - 1] = self.o.predict(p["imu"][s + n - 1], p["gravity"], self.states[s + n - 2])
         self.win = self._window(s, self.marg, False)
-        self.costs, self.acc, _ = self.win.lm(iterations=self.K, n_threads=self.threads, rel_tol=self.rel_tol, abs_tol=self.abs_tol)
+        self.costs, self.acc, _ = self.win.lm(iterations=self.K, n_threads=self.threads, rel_tol=self.rel_tol, abs_tol=self.abs_tol,
+                                              accept_rel=self.accept_rel)
         self.states[s:s + n] = self.win.states
         return self.win.states
 

@@ -1,0 +1,509 @@
+"""Independent optimiser over the twin's own residuals, solving every step by Householder QR -- test infrastructure only.
+
+Why it exists ("What's missing" 1): the reference solves by QR (GraphManager.cpp:38 `factorization =
+ISAM2Params::QR`); the HIP path and the C oracle both solve NORMAL EQUATIONS by Cholesky (cond ~ 1e11) and share one LM
+accept rule.  This module says where the optimum is without sharing any of that:
+
+  * residuals: the definitions of oracle/twin.py (tangent orders, retractions, the preintegration recursion, the residuals
+    of CombinedImuFactor / BetweenFactor<Pose3> / the priors), evaluated batched in torch float64 with GENERIC matrix
+    functions -- `torch.linalg.matrix_exp` for every exponential, a Gregory series of the matrix logarithm
+    (log M = 2 sum_k C^(2k+1) / (2k+1), C = (M - I)(M + I)^-1) for every logarithm; no Rodrigues formula, no closed-form
+    SO(3) / SE(3) Jacobian anywhere;
+  * Jacobians: forward-mode automatic differentiation of those residuals along the retraction
+    (Pose3: x Exp(d) with the full SE(3) exponential; velocity and bias: x + d) -- exact to rounding, no finite differences;
+  * factor records: `twin_records` preintegrates the raw IMU samples with twin.preintegrate / bias_jacobian_fd /
+    preintegrate_cov and takes R = chol(cov^-1)^T itself (vf_oracle.c is not involved);
+  * linear algebra: sequential variable elimination by dense Householder QR (numpy.linalg.qr = LAPACK geqrf) of the
+    WHITENED JACOBIAN, keyframe by keyframe -- what GTSAM's QR elimination does on its cliques; J^T J is never formed
+    (cond(J) ~ 3e5 against 1e11 for the normal equations); LM damping enters as rows sqrt(lambda) I;
+  * iteration: damped Gauss-Newton accepted on the gain ratio (actual / predicted decrease > 0, gtsam's modelFidelity
+    test), then undamped Gauss-Newton polishing steps with NO accept test: near the optimum the iteration is a
+    contraction towards J^T r = 0 and the last step's size is the convergence evidence that gets stored;
+  * fixed-lag marginalisation in square-root (SRIF) form: the oldest keyframe's 15 columns are eliminated by QR from the
+    rows of the factors touching it, the left-over rows ARE the marginal prior  R d + z,  d = Local(xbar -> x).  The
+    definition of that prior follows DESIGN.md section 4 (fixed linearisation point, dLocal/dx taken as identity): the
+    reference has no marginalisation to follow.
+
+State layout as everywhere: q(w,x,y,z) t(3) v(3) bias_acc(3) bias_gyro(3); tangent per keyframe [theta t v ba bg].
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from scipy.linalg import solve_triangular
+from torch.func import jacfwd, vmap
+
+from . import twin
+
+torch.set_default_dtype(torch.float64)
+DOF = 15
+
+
+# ---------------------------------------------------------------- generic matrix functions (batched, differentiable)
+def hat(w):
+    z = torch.zeros_like(w[..., 0])
+    return torch.stack([torch.stack([z, -w[..., 2], w[..., 1]], -1),
+                        torch.stack([w[..., 2], z, -w[..., 0]], -1),
+                        torch.stack([-w[..., 1], w[..., 0], z], -1)], -2)
+
+
+def vee(W):
+    return torch.stack([W[..., 2, 1], W[..., 0, 2], W[..., 1, 0]], -1)
+
+
+def logm_near_identity(M, terms=14):
+    """log M by the Gregory series 2 sum C^(2k+1)/(2k+1), C = (M + I)^-1 (M - I); |C| ~ |M - I| / 2, so 14 terms reach
+    rounding for |M - I| < 0.5 (every residual transform of these problems is far inside that)."""
+    I = torch.eye(M.shape[-1], dtype=M.dtype)
+    C = torch.linalg.inv(M + I) @ (M - I)     # (linalg.solve's batching rule under vmap(jacfwd) is wrong in torch 2.10)
+    C2 = C @ C
+    P, S = C, C
+    for k in range(1, terms):
+        P = P @ C2
+        S = S + P / (2 * k + 1)
+    return 2 * S
+
+
+def so3_exp(w):
+    return torch.linalg.matrix_exp(hat(w))
+
+
+def so3_log(R):
+    return vee(logm_near_identity(R))
+
+
+def se3_mat(R, t):
+    top = torch.cat([R, t.unsqueeze(-1)], -1)
+    bot = torch.zeros(R.shape[:-2] + (1, 4), dtype=R.dtype)
+    bot[..., 0, 3] = 1.0
+    return torch.cat([top, bot], -2)
+
+
+def se3_exp(xi):
+    """tangent [omega, v] -> (R, t), full exponential of the 4x4 twist matrix"""
+    M = torch.zeros(xi.shape[:-1] + (4, 4), dtype=xi.dtype)
+    M = M + torch.nn.functional.pad(hat(xi[..., :3]), (0, 1, 0, 1))
+    M = M + torch.nn.functional.pad(xi[..., 3:].unsqueeze(-1), (3, 0, 0, 1))
+    E = torch.linalg.matrix_exp(M)
+    return E[..., :3, :3], E[..., :3, 3]
+
+
+def se3_log(R, t):
+    L = logm_near_identity(se3_mat(R, t))
+    return torch.cat([vee(L[..., :3, :3]), L[..., :3, 3]], -1)
+
+
+def quat_to_rot(q):
+    q = q / torch.linalg.norm(q, dim=-1, keepdim=True)
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    return torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], -1),
+                        torch.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], -1),
+                        torch.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1)], -2)
+
+
+def rot_to_quat_np(R):
+    """(n,3,3) -> (n,4), w >= 0; through the symmetric 4x4 eigenproblem (no branch on the trace)."""
+    R = np.asarray(R)
+    out = np.zeros(R.shape[:-2] + (4,))
+    for i, r in enumerate(R.reshape(-1, 3, 3)):
+        K = np.array([[r[0, 0] + r[1, 1] + r[2, 2], r[2, 1] - r[1, 2], r[0, 2] - r[2, 0], r[1, 0] - r[0, 1]],
+                      [r[2, 1] - r[1, 2], r[0, 0] - r[1, 1] - r[2, 2], r[0, 1] + r[1, 0], r[0, 2] + r[2, 0]],
+                      [r[0, 2] - r[2, 0], r[0, 1] + r[1, 0], r[1, 1] - r[0, 0] - r[2, 2], r[1, 2] + r[2, 1]],
+                      [r[1, 0] - r[0, 1], r[0, 2] + r[2, 0], r[1, 2] + r[2, 1], r[2, 2] - r[0, 0] - r[1, 1]]]) / 3.0
+        w, v = np.linalg.eigh(K)
+        q = v[:, -1]
+        out.reshape(-1, 4)[i] = q if q[0] >= 0 else -q
+    return out
+
+
+# ---------------------------------------------------------------- states
+class States:
+    """n keyframes as rotation matrices + vectors (torch float64)"""
+
+    def __init__(self, R, t, v, b):
+        self.R, self.t, self.v, self.b = R, t, v, b
+
+    @classmethod
+    def from_array(cls, x):
+        x = torch.as_tensor(np.asarray(x, dtype=np.float64))
+        return cls(quat_to_rot(x[:, 0:4]), x[:, 4:7].clone(), x[:, 7:10].clone(), x[:, 10:16].clone())
+
+    def to_array(self):
+        out = np.zeros((self.n, 16))
+        out[:, 0:4] = rot_to_quat_np(self.R.numpy())
+        out[:, 4:7], out[:, 7:10], out[:, 10:16] = self.t.numpy(), self.v.numpy(), self.b.numpy()
+        return out
+
+    @property
+    def n(self):
+        return self.R.shape[0]
+
+    def pick(self, idx):
+        idx = torch.as_tensor(np.asarray(idx), dtype=torch.long)
+        return self.R[idx], self.t[idx], self.v[idx], self.b[idx]
+
+    def retract(self, delta):
+        """Values::retract: Pose3 x Exp(d[0:6]) (full exponential), velocity and bias add; rotations re-orthonormalised
+        (polar factor) so that rounding does not accumulate over the iterations"""
+        d = torch.as_tensor(delta).reshape(self.n, DOF)
+        dR, dt = se3_exp(d[:, :6])
+        R = self.R @ dR
+        U, _, Vh = torch.linalg.svd(R)
+        return States(U @ Vh, self.t + (self.R @ dt.unsqueeze(-1)).squeeze(-1), self.v + d[:, 6:9], self.b + d[:, 9:15])
+
+    def slice(self, lo, hi):
+        return States(self.R[lo:hi].clone(), self.t[lo:hi].clone(), self.v[lo:hi].clone(), self.b[lo:hi].clone())
+
+
+def _retract_one(R, t, v, b, d):
+    dR, dt = se3_exp(d[:6])
+    return R @ dR, t + R @ dt, v + d[6:9], b + d[9:15]
+
+
+def unpack_upper_t(Rp, n):
+    iu = np.triu_indices(n)
+    R = torch.zeros(Rp.shape[:-1] + (n, n), dtype=Rp.dtype)
+    R[..., iu[0], iu[1]] = Rp
+    return R
+
+
+# ---------------------------------------------------------------- residuals (one factor; vmapped over the batch)
+def _imu_res(d, Ri, ti, vi, bi, Rj, tj, vj, bj, rec, W, g):
+    """whitened CombinedImuFactor residual at (x_i (+) d[:15], x_j (+) d[15:]); formulas of twin.predict / imu_residual"""
+    Ri, ti, vi, bi = _retract_one(Ri, ti, vi, bi, d[:15])
+    Rj, tj, vj, bj = _retract_one(Rj, tj, vj, bj, d[15:])
+    dt = rec[0]
+    x = rec[1:10] + rec[16:70].reshape(9, 6) @ (bi - rec[10:16])          # biasCorrectedDelta
+    xp = x[3:6] + dt * (Ri.T @ vi) + 0.5 * dt * dt * (Ri.T @ g)
+    xv = x[6:9] + dt * (Ri.T @ g)
+    Rp, tp, vp = Ri @ so3_exp(x[:3]), ti + Ri @ xp, vi + Ri @ xv
+    r = torch.cat([so3_log(Rj.T @ Rp), Rj.T @ (tp - tj), Rj.T @ (vp - vj), bi - bj])
+    return W @ r
+
+
+def _btw_res(d, Ra, ta, Rb, tb, rec, W):
+    """whitened BetweenFactor<Pose3> residual at (x_a Exp(d[:6]), x_b Exp(d[6:])): Logmap(measured^-1 (T_a^-1 T_b))"""
+    dRa, dta = se3_exp(d[:6])
+    dRb, dtb = se3_exp(d[6:])
+    Ra, ta = Ra @ dRa, ta + Ra @ dta
+    Rb, tb = Rb @ dRb, tb + Rb @ dtb
+    Rm, tm = quat_to_rot(rec[0:4]), rec[4:7]
+    Rh, th = Ra.T @ Rb, Ra.T @ (tb - ta)
+    return W @ se3_log(Rm.T @ Rh, Rm.T @ (th - tm))
+
+
+def _prior_res(d, R, t, v, b, rec):
+    """the three priors of GraphManager.cpp:27-35 on one keyframe: Local(prior, x) / sigma"""
+    R, t, v, b = _retract_one(R, t, v, b, d)
+    Rp, tp = quat_to_rot(rec[0:4]), rec[4:7]
+    xi = se3_log(Rp.T @ R, Rp.T @ (t - tp))
+    return torch.cat([xi, v - rec[7:10], b - rec[10:16]]) / rec[16:31]
+
+
+def _local_pose(Rb, tb, R, t):
+    return se3_log(Rb.transpose(-1, -2) @ R, (Rb.transpose(-1, -2) @ (t - tb).unsqueeze(-1)).squeeze(-1))
+
+
+class MargPrior:
+    """square-root marginal prior on [k0: 15][k0+1: pose][k0+2: pose]: residual rows  Rm d + z,  d = Local(xbar -> x),
+    Jacobian Rm (dLocal/dx = I: the fixed-lag definition of DESIGN.md section 4)"""
+
+    def __init__(self, k0, xbar: States, Rm, z):
+        self.k0, self.xbar, self.Rm, self.z = k0, xbar, np.asarray(Rm), np.asarray(z)
+
+    def delta(self, st: States):
+        k = self.k0
+        d = []
+        for j in range(3):
+            xi = _local_pose(self.xbar.R[j], self.xbar.t[j], st.R[k + j], st.t[k + j])
+            d.append(xi)
+            if j == 0:
+                d.append(st.v[k] - self.xbar.v[0])
+                d.append(st.b[k] - self.xbar.b[0])
+        return torch.cat(d).numpy()
+
+    def residual(self, st: States):
+        return self.Rm @ self.delta(st) + self.z
+
+    def information(self):
+        """(Lambda, eta) of the equivalent  1/2 d^T Lambda d + eta^T d  (for comparisons with the normal-equation form)"""
+        return self.Rm.T @ self.Rm, self.Rm.T @ self.z
+
+
+# ---------------------------------------------------------------- problem
+class Problem:
+    """One window: keyframes 0..n-1 (window-local indices), factors as records.  `imu[k]` is the factor k-1 -> k."""
+
+    def __init__(self, states, imu_j, imu_rec, btw_a, btw_b, btw_rec, prior_k=None, prior_rec=None, marg: MargPrior = None,
+                 gravity=(0.0, 0.0, -9.81)):
+        self.st = states if isinstance(states, States) else States.from_array(states)
+        self.imu_j = np.asarray(imu_j, dtype=np.int64)
+        self.imu_rec = torch.as_tensor(np.asarray(imu_rec, dtype=np.float64)).reshape(-1, 190)
+        self.btw_a, self.btw_b = np.asarray(btw_a, dtype=np.int64), np.asarray(btw_b, dtype=np.int64)
+        self.btw_rec = torch.as_tensor(np.asarray(btw_rec, dtype=np.float64)).reshape(-1, 28)
+        self.imu_W = unpack_upper_t(self.imu_rec[:, 70:190], 15)      # whitening matrices R (R^T R = covariance^-1)
+        self.btw_W = unpack_upper_t(self.btw_rec[:, 7:28], 6)
+        self.prior_k = prior_k
+        self.prior_rec = None if prior_rec is None else torch.as_tensor(np.asarray(prior_rec, dtype=np.float64))
+        self.marg = marg
+        self.g = torch.as_tensor(np.asarray(gravity, dtype=np.float64))
+        assert np.all(self.btw_b - self.btw_a >= 1) and np.all(self.btw_b - self.btw_a <= 3)
+
+    @property
+    def n(self):
+        return self.st.n
+
+    # -- linearisation: per-factor residual r and Jacobian J (dense small blocks), by forward-mode AD
+    def linearize(self, st: States = None, jac=True):
+        st = self.st if st is None else st
+        out = {}
+        if self.imu_j.size:
+            a = st.pick(self.imu_j - 1) + st.pick(self.imu_j)
+            z = torch.zeros(self.imu_j.size, 30)
+            f = lambda d, *x: _imu_res(d, *x, self.g)
+            r = vmap(f)(z, *a, self.imu_rec, self.imu_W)
+            J = vmap(jacfwd(f))(z, *a, self.imu_rec, self.imu_W) if jac else None
+            out["imu"] = (r.numpy(), None if J is None else J.numpy())
+        if self.btw_a.size:
+            Ra, ta, _, _ = st.pick(self.btw_a)
+            Rb, tb, _, _ = st.pick(self.btw_b)
+            z = torch.zeros(self.btw_a.size, 12)
+            r = vmap(_btw_res)(z, Ra, ta, Rb, tb, self.btw_rec, self.btw_W)
+            J = vmap(jacfwd(_btw_res))(z, Ra, ta, Rb, tb, self.btw_rec, self.btw_W) if jac else None
+            out["btw"] = (r.numpy(), None if J is None else J.numpy())
+        if self.prior_rec is not None:
+            k = self.prior_k
+            a = (st.R[k], st.t[k], st.v[k], st.b[k])
+            z = torch.zeros(15)
+            r = _prior_res(z, *a, self.prior_rec)
+            J = jacfwd(_prior_res)(z, *a, self.prior_rec) if jac else None
+            out["prior"] = (r.numpy(), None if J is None else J.numpy())
+        if self.marg is not None:
+            out["marg"] = (self.marg.residual(st), self.marg.Rm)
+        return out
+
+    def cost(self, st: States = None):
+        lin = self.linearize(st, jac=False)
+        return 0.5 * sum(float(np.sum(r * r)) for r, _ in lin.values())
+
+    # -- row blocks of the whitened Jacobian: (sorted keyframes, matrix [len(kfs)*15 + 1]) with the rhs (= residual) last
+    def row_blocks(self, lin):
+        blocks = []
+        if "imu" in lin:
+            r, J = lin["imu"]
+            for f, j in enumerate(self.imu_j):
+                blocks.append(([j - 1, j], np.hstack([J[f], r[f][:, None]])))
+        if "btw" in lin:
+            r, J = lin["btw"]
+            for f, (a, b) in enumerate(zip(self.btw_a, self.btw_b)):
+                M = np.zeros((6, 31))
+                M[:, 0:6], M[:, 15:21], M[:, 30] = J[f][:, :6], J[f][:, 6:], r[f]
+                blocks.append(([a, b], M))
+        if "prior" in lin:
+            r, J = lin["prior"]
+            blocks.append(([self.prior_k], np.hstack([J, r[:, None]])))
+        if "marg" in lin:
+            r, Rm = lin["marg"]
+            k = self.marg.k0
+            M = np.zeros((Rm.shape[0], 46))
+            M[:, 0:15], M[:, 15:21], M[:, 30:36], M[:, 45] = Rm[:, 0:15], Rm[:, 15:21], Rm[:, 21:27], r
+            blocks.append(([k, k + 1, k + 2], M))
+        return blocks
+
+    # -- least squares  min |J d + r|^2 + lam |d|^2  by sequential Householder QR elimination of the keyframes
+    def solve_qr(self, lin, lam=0.0):
+        n = self.n
+        at = [[] for _ in range(n)]                 # blocks filed under their FIRST keyframe
+        for kfs, M in self.row_blocks(lin):
+            at[kfs[0]].append((list(kfs), M))
+        if lam > 0.0:
+            D = np.hstack([np.sqrt(lam) * np.eye(DOF), np.zeros((DOF, 1))])
+            for k in range(n):
+                at[k].append(([k], D))
+        cond = [None] * n
+        for k in range(n):
+            S = sorted(set(j for kfs, _ in at[k] for j in kfs))
+            assert S and S[0] == k, f"keyframe {k} has no factor"
+            col = {j: i * DOF for i, j in enumerate(S)}
+            w = len(S) * DOF
+            F = np.vstack([self._embed(kfs, M, col, w) for kfs, M in at[k]])
+            Rf = np.linalg.qr(F, mode="r")             # LAPACK geqrf: Householder reflections, no normal equations
+            if Rf.shape[0] < DOF or np.min(np.abs(np.diag(Rf)[:DOF])) == 0.0:
+                raise np.linalg.LinAlgError(f"keyframe {k} is not determined by its factors")
+            cond[k] = (S, Rf[:DOF].copy())
+            rest = Rf[DOF:min(Rf.shape[0], w), DOF:]   # rows that still involve variables (a row beyond w is pure residual)
+            if len(S) > 1 and rest.shape[0] > 0:
+                at[S[1]].append((S[1:], rest))
+        delta = np.zeros((n, DOF))
+        for k in range(n - 1, -1, -1):
+            S, Rk = cond[k]
+            rhs = -Rk[:, -1]
+            for i, j in enumerate(S[1:], start=1):
+                rhs = rhs - Rk[:, i * DOF:(i + 1) * DOF] @ delta[j]
+            delta[k] = solve_triangular(Rk[:, :DOF], rhs, lower=False)
+        return delta
+
+    @staticmethod
+    def _embed(kfs, M, col, w):
+        out = np.zeros((M.shape[0], w + 1))
+        for i, j in enumerate(kfs):
+            out[:, col[j]:col[j] + DOF] = M[:, i * DOF:(i + 1) * DOF]
+        out[:, w] = M[:, -1]
+        return out
+
+    def model_cost(self, lin, delta):
+        """1/2 |J d + r|^2 of the linearised factors (the damping rows are not part of it)"""
+        c = 0.0
+        for kfs, M in self.row_blocks(lin):
+            v = M[:, -1].copy()
+            for i, j in enumerate(kfs):
+                v += M[:, i * DOF:(i + 1) * DOF] @ delta[j]
+            c += 0.5 * float(v @ v)
+        return c
+
+    # -- optimiser
+    def optimize(self, max_iterations=200, lam0=1e-5, step_tol=1e-9, polish=3, verbose=False):
+        """damped Gauss-Newton on the gain ratio until an accepted step is below step_tol (inf-norm, tangent units), then
+        `polish` undamped Gauss-Newton steps.  Returns a log dict; self.st holds the optimum."""
+        lam, log = lam0, dict(costs=[], steps=[], accepted=[], lam=[])
+        cost = self.cost()
+        log["costs"].append(cost)
+        lin = self.linearize()
+        for it in range(max_iterations):
+            d = self.solve_qr(lin, lam)
+            trial = self.st.retract(d)
+            c_new = self.cost(trial)
+            pred = cost - self.model_cost(lin, d)
+            rho = (cost - c_new) / pred if pred > 0 else -1.0
+            step = float(np.max(np.abs(d)))
+            ok = rho > 0.0
+            if verbose:
+                print(f"  it {it:3d} lam {lam:.1e} cost {cost:.12e} -> {c_new:.12e} rho {rho:+.3f} step {step:.2e} {'acc' if ok else 'REJ'}")
+            log["accepted"].append(bool(ok)); log["steps"].append(step); log["lam"].append(lam)
+            if ok:
+                self.st, cost = trial, c_new
+                lin = self.linearize()
+                lam = max(lam / 10.0, 1e-12)
+            else:
+                lam = min(lam * 10.0, 1e10)
+            log["costs"].append(cost)
+            if step < step_tol and (ok or pred <= 1e-14 * cost):
+                break
+        pol = []
+        for _ in range(polish):
+            d = self.solve_qr(lin, 0.0)
+            self.st = self.st.retract(d)
+            lin = self.linearize()
+            pol.append(float(np.max(np.abs(d))))
+        log["polish_steps"] = pol
+        log["final_cost"] = self.cost()
+        log["iterations"] = len(log["steps"])
+        if verbose:
+            print(f"  polish steps {pol} final cost {log['final_cost']:.12e}")
+        return log
+
+    # -- square-root marginalisation of keyframe m (window-local; the oldest): returns the prior on [m+1, m+2, m+3]
+    def marginalize(self, m=0) -> MargPrior:
+        lin = self.linearize()
+        rows = []
+        off = {m: 0, m + 1: 15, m + 2: 30, m + 3: 36}          # [m:15][m+1:15][m+2 pose:6][m+3 pose:6] + rhs = 43 columns
+        width = {m: 15, m + 1: 15, m + 2: 6, m + 3: 6}
+        for kfs, M in self.row_blocks(lin):
+            if m not in kfs:
+                continue
+            assert kfs[0] == m and all(j in off for j in kfs), "a factor of the oldest keyframe reaches beyond m+3"
+            out = np.zeros((M.shape[0], 43))
+            for i, j in enumerate(kfs):
+                blk = M[:, i * DOF:(i + 1) * DOF]
+                assert np.all(blk[:, width[j]:] == 0.0), "velocity / bias columns beyond m+1 in a factor of the oldest keyframe"
+                out[:, off[j]:off[j] + width[j]] = blk[:, :width[j]]
+            out[:, 42] = M[:, -1]
+            rows.append(out)
+        F = np.vstack(rows)
+        Rf = np.linalg.qr(F, mode="r")
+        rest = Rf[DOF:min(Rf.shape[0], 42)]
+        return MargPrior(m + 1, self.st.slice(m + 1, m + 4), rest[:, 15:42].copy(), rest[:, 42].copy())
+
+
+# ---------------------------------------------------------------- records from raw measurements, by the twin alone
+def twin_imu_record(steps, bhat, cov):
+    bhat = np.asarray(bhat, dtype=float)
+    """190-double record [dt, delta(9), bhat(6), H(9x6), upper(R)(120)] with R^T R = preintMeasCov^-1, from raw IMU samples:
+    mean by twin.preintegrate, bias Jacobians by central differences of it, covariance by twin.preintegrate_cov"""
+    T, d = twin.preintegrate(steps, bhat)
+    H = twin.bias_jacobian_fd(steps, bhat)
+    P = twin.preintegrate_cov(steps, bhat, cov["acc"], cov["gyro"], cov["integration"], cov["bias_acc"], cov["bias_omega"],
+                              cov["bias_acc_omega_int"])
+    P = 0.5 * (P + P.T)
+    R = np.linalg.cholesky(np.linalg.inv(P)).T            # upper, R^T R = P^-1
+    return np.concatenate([[T], d, np.asarray(bhat, dtype=float), H.ravel(), R[np.triu_indices(15)]])
+
+
+def _rec_job(job):
+    steps, cov = job
+    return twin_imu_record(steps, np.zeros(6), cov)
+
+
+def twin_records(seq, cov, count=None, workers=1):
+    """records of the IMU factors 0->1, ..., count-2 -> count-1 of a synth.Sequence (row 0 stays empty), bias estimate 0"""
+    count = seq.n if count is None else count
+    jobs = [(seq.imu_steps[seq.imu_off[k]:seq.imu_off[k + 1]], cov) for k in range(1, count)]
+    if workers > 1:
+        import multiprocessing
+        with multiprocessing.get_context("fork").Pool(workers) as pool:
+            recs = pool.map(_rec_job, jobs, chunksize=8)
+    else:
+        recs = [_rec_job(j) for j in jobs]
+    return np.vstack([np.zeros((1, 190))] + recs)
+
+
+def dead_reckon(x0, imu_rec, gravity=(0.0, 0.0, -9.81)):
+    """initial values by the IMU prediction chain (GraphManager.cpp:152-160) with twin.predict"""
+    n = imu_rec.shape[0]
+    out = np.zeros((n, 16))
+    out[0] = x0
+    for k in range(1, n):
+        R, t, v = twin.predict(imu_rec[k], gravity, out[k - 1])
+        out[k, 0:4], out[k, 4:7], out[k, 7:10], out[k, 10:16] = twin.rot_to_quat(R), t, v, out[k - 1, 10:16]
+    return out
+
+
+class FixedLag:
+    """bench.py's fixed-lag update by this module: window of n keyframes over a longer sequence; update = marginalise the
+    oldest keyframe (square-root form), append one keyframe predicted from its IMU factor, optimise to convergence."""
+
+    def __init__(self, n, imu_rec, btw_a, btw_b, btw_rec, prior_rec, x0, gravity=(0.0, 0.0, -9.81), verbose=False, ingest=None):
+        """ingest = (synth.Sequence, covariance dict): every update preintegrates the appended keyframe's factor afresh from
+        its raw samples with the CURRENT bias estimate (the bias of the window's last keyframe), as
+        GraphManager::reserveNode does (GraphManager.cpp:59); None: the records handed in are used as they are"""
+        self.n, self.imu, self.ba, self.bb, self.brec, self.g, self.verbose = n, np.array(imu_rec), btw_a, btw_b, btw_rec, gravity, verbose
+        self.ingest = ingest
+        self.states = np.zeros((imu_rec.shape[0], 16))
+        self.states[:n] = dead_reckon(x0, imu_rec[:n], gravity)
+        self.s, self.marg = 0, None
+        self.prob = self._problem(prior_rec)
+        self.log = self.prob.optimize(max_iterations=400, verbose=verbose)
+        self.states[:n] = self.prob.st.to_array()
+
+    def _problem(self, prior_rec=None):
+        lo, hi = self.s, self.s + self.n
+        m = (self.ba >= lo) & (self.bb < hi)
+        return Problem(self.states[lo:hi], np.arange(1, self.n), self.imu[lo + 1:hi], self.ba[m] - lo, self.bb[m] - lo,
+                       self.brec[m], prior_k=None if prior_rec is None else 0, prior_rec=prior_rec, marg=self.marg, gravity=self.g)
+
+    def update(self):
+        mp = self.prob.marginalize(0)
+        mp.k0 = 0
+        self.marg = mp
+        self.s += 1
+        new = self.s + self.n - 1
+        if self.ingest is not None:
+            seq, cov = self.ingest
+            self.imu[new] = twin_imu_record(seq.imu_steps[seq.imu_off[new]:seq.imu_off[new + 1]], self.states[new - 1, 10:16], cov)
+        R, t, v = twin.predict(self.imu[new], self.g, self.states[new - 1])
+        self.states[new, 0:4], self.states[new, 4:7], self.states[new, 7:10] = twin.rot_to_quat(R), t, v
+        self.states[new, 10:16] = self.states[new - 1, 10:16]
+        self.prob = self._problem()
+        self.log = self.prob.optimize(max_iterations=60, verbose=self.verbose)
+        self.states[self.s:self.s + self.n] = self.prob.st.to_array()
+        return self.states[self.s:self.s + self.n]

@@ -1,0 +1,86 @@
+"""-m gpu: the HIP path against the INDEPENDENT optimum.
+
+The reference's iSAM2 factorises by QR (GraphManager.cpp:38).  The device solves normal equations by block Cholesky, and so
+does the C oracle it is otherwise compared with.  The fixtures under tests/golden/qr_twin_*.npz are the optima found by
+oracle/twin_qr.py -- the twin's own preintegration of the raw samples, generic matrix exponentials / logarithms,
+automatic-differentiation Jacobians, Householder QR elimination of the whitened Jacobian, gain-ratio acceptance and
+undamped Gauss-Newton polishing (last steps ~1e-12) -- generated in the build container by
+tests/golden/make_qr_twin_golden.py.  Inputs are rebuilt here from the same seeds; the device preintegrates its own
+factors (K0).  Bar: ATE <= 1e-6 m (north star); observed values are printed, and held to 1e-8 m so that a regression of
+two orders of magnitude cannot hide under the bar."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers
+from tests.test_gpu_ingest import _engine, _feed
+from vil_sensor_fusion_amd import Engine, EngineOpts, synth
+from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("form", ["partitioned", "one_wave_sweep"])
+def test_config1_200_pose_window_vs_independent_qr_optimum(form):
+    """BASELINE configs[1]: full VIL (Rovio + LOAM + IMU preintegration), 200-pose window, fp64, batch LM from the IMU
+    dead-reckoning start.  Both accept rules are run and reported."""
+    F = np.load(os.path.join(GOLD, "qr_twin_n200.npz"))
+    n = int(F["n"])
+    seq = synth.make_sequence(seed=int(F["seed"]), n_kf=n)
+    opts = dict(chunks=1, sweep_two_sided_max=0) if form == "one_wave_sweep" else {}
+    out = {}
+    for tol in (None, 0.0):
+        eng = Engine(EngineOpts(windows=1, capacity=n, accept_rel=tol, **opts))
+        eng.preintegrate(0, 1, seq.imu_off[1:n + 1], seq.imu_steps, np.zeros(6), synth.CARLA_IMU_COV)
+        eng.set_between(0, seq.btw_a, seq.btw_b, synth.between_records(seq))
+        eng.set_states(0, 0, seq.gt_states[0].reshape(1, 16))
+        eng.set_prior(0, 0, synth.prior_record(seq.gt_states[0], REFERENCE_PRIOR_SIGMAS))
+        eng.set_range(0, 0, 1)
+        eng.predict(0, 1, n - 1)
+        eng.set_range(0, 0, n)
+        eng.iterate(100)
+        out[tol] = helpers.ate(eng.get_states(0, 0, n), F["states"])
+        assert eng.read_lm(0)["solve_failures"] == 0
+        eng.close()
+    print(f"configs[1], {form}: HIP vs independent QR optimum: ATE {out[None][0]:.3e} m (accept_rel 1e-9), {out[0.0][0]:.3e} m (strict)")
+    assert out[None][0] <= 1e-8 and out[None][1] <= 1e-6
+    assert out[0.0][0] <= 1e-6 and out[0.0][1] <= 1e-6
+
+
+@pytest.mark.parametrize("form", ["partitioned", "one_wave_sweep"])
+def test_fixed_lag_updates_vs_independent_qr_optimum(form):
+    """bench.py's window 0: the 1000-pose batch optimum (BASELINE configs[2]) and 25 marginalised fixed-lag updates, each =
+    vf_engine_ingest_tail (K0 at the current bias estimate) + slide + 5 LM trials, in the partitioned form (what one window
+    runs) and in the one-wave sweep (what the bench's 1024 windows run).  The independent optimiser converges every update."""
+    F = np.load(os.path.join(GOLD, "qr_twin_fixed_lag.npz"))
+    n, updates = int(F["window"]), int(max(F["updates"]))
+    seq = synth.make_sequence(seed=int(F["seed"]), n_kf=int(F["seq_len"]))
+    opts = dict(chunks=1, sweep_two_sided_max=0) if form == "one_wave_sweep" else {}
+    res = {}
+    for tol in (None, 0.0):
+        eng = _engine(None, [seq], n, updates, accept_rel=tol, **opts)
+        eng.iterate(200)
+        worst = batch = helpers.ate(eng.get_states(0, 0, n), F["states_u0"])[0]
+        for u in range(1, updates + 1):
+            eng.ingest_tail(*_feed([seq], n + u - 1))
+            eng.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)
+            eng.iterate(5)
+            if u in F["updates"]:
+                x = np.zeros((n, 16))
+                x[:, :7] = F[f"pose_u{u}"]
+                a, r = helpers.ate(eng.get_states(0, u, n), x)
+                worst = max(worst, a)
+                assert r <= 1e-6, (u, r)
+        eng.ingest_status()
+        assert eng.read_lm(0)["solve_failures"] == 0
+        # the marginal prior the device carries after the last update against the square-root one of the fixture
+        got = eng.read_marginal(0)
+        dL = np.abs(got["L"] - F["marg_L"]).max() / np.abs(F["marg_L"]).max()
+        res[tol] = (batch, worst, dL)
+        eng.close()
+    print(f"fixed lag, {form}: HIP vs independent QR optimum: batch {res[None][0]:.3e} m, worst over {updates} updates "
+          f"{res[None][1]:.3e} m (accept_rel 1e-9); strict rule: {res[0.0][0]:.3e} / {res[0.0][1]:.3e} m; marginal information rel. diff {res[None][2]:.1e}")
+    assert res[None][1] <= 1e-8 and res[0.0][1] <= 1e-6
+    assert res[None][2] <= 1e-6

@@ -1,0 +1,180 @@
+"""CPU: the independent QR optimiser (oracle/twin_qr.py) -- its pieces against the scipy twin, and the C oracle against its
+committed optima (tests/golden/qr_twin_*.npz, made by tests/golden/make_qr_twin_golden.py).
+
+Why: the reference factorises by QR (GraphManager.cpp:38 `factorization = ISAM2Params::QR`); the HIP path and the C oracle
+both solve normal equations by Cholesky and share an accept rule.  twin_qr shares neither (own preintegration, generic
+matrix functions, automatic-differentiation Jacobians, Householder QR of the whitened Jacobian, gain-ratio acceptance +
+undamped polishing).  These tests pin (a) that twin_qr evaluates what the twin defines, (b) where the optimum is."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import twin
+from oracle import twin_qr as tq
+from tests import helpers
+from vil_sensor_fusion_amd import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _random_state(rng, scale=0.3):
+    R = twin.so3_exp(rng.normal(size=3) * scale)
+    return np.concatenate([twin.rot_to_quat(R), rng.normal(size=3), rng.normal(size=3), rng.normal(size=6) * 1e-2])
+
+
+def test_generic_matrix_functions_against_scipy():
+    rng = np.random.default_rng(0)
+    for scale in (1e-9, 1e-3, 0.2):
+        w = rng.normal(size=(20, 3)) * scale
+        R = tq.so3_exp(torch.as_tensor(w)).numpy()
+        for i in range(20):
+            np.testing.assert_allclose(R[i], twin.so3_exp(w[i]), atol=1e-15)
+        np.testing.assert_allclose(tq.so3_log(torch.as_tensor(R)).numpy(), w, rtol=0, atol=1e-15)
+        xi = rng.normal(size=(20, 6)) * scale
+        Rt, tt = tq.se3_exp(torch.as_tensor(xi))
+        for i in range(20):
+            Rs, ts = twin.se3_exp(xi[i])
+            np.testing.assert_allclose(Rt[i].numpy(), Rs, atol=1e-15)
+            np.testing.assert_allclose(tt[i].numpy(), ts, atol=1e-15)
+            np.testing.assert_allclose(tq.se3_log(Rt[i], tt[i]).numpy(), twin.se3_log(Rs, ts), rtol=0, atol=3e-15)
+    q = tq.rot_to_quat_np(np.stack([twin.so3_exp(rng.normal(size=3) * 2.5) for _ in range(50)]))
+    for qi in q:                                        # near-pi rotations included: the eigenvector route has no trace branch
+        assert abs(np.linalg.norm(qi) - 1) < 1e-14 and qi[0] >= 0
+
+
+def test_residuals_and_ad_jacobians_against_the_scipy_twin(oracle):
+    """twin_qr's batched residuals ARE the twin's (imu_residual / between_residual, scipy expm / logm), its forward-mode
+    Jacobians are the derivatives of those residuals (central differences of the TWIN), the vmapped evaluation equals a
+    per-factor loop (torch 2.10's linalg.solve batching rule was wrong under vmap(jacfwd): guarded here)."""
+    n = 12
+    seq = synth.make_sequence(seed=5, n_kf=n)
+    imu = tq.twin_records(seq, synth.CARLA_IMU_COV)
+    rng = np.random.default_rng(1)
+    x = tq.dead_reckon(seq.gt_states[0], imu)
+    for k in range(1, n):                               # off the optimum, non-zero biases: every term of the residual is live
+        x[k] = twin._perturb(twin._perturb(twin._perturb(x[k], "pose", rng.normal(size=6) * 2e-3), "vel", rng.normal(size=3) * 1e-2),
+                             "bias", rng.normal(size=6) * 1e-3)
+    prior = np.concatenate([seq.gt_states[0], [1e-6] * 3 + [5e-5] * 3 + [1e-5] * 3 + [1e-7] * 6])
+    P = tq.Problem(x, np.arange(1, n), imu[1:], seq.btw_a, seq.btw_b, synth.between_records(seq), 0, prior)
+    lin = P.linearize()
+    g = np.array([0.0, 0.0, -9.81])
+    r, J = lin["imu"]
+    for f in range(n - 1):
+        W = P.imu_W[f].numpy()
+        np.testing.assert_allclose(r[f], W @ twin.imu_residual(imu[f + 1], g, x[f], x[f + 1]), rtol=0, atol=1e-9 * np.abs(r[f]).max())
+        Jfd = W @ twin.imu_jacobian_fd(imu[f + 1], g, x[f], x[f + 1])       # GTSAM key order X_i V_i X_j V_j B_i B_j
+        Jfd = np.hstack([Jfd[:, 0:9], Jfd[:, 18:24], Jfd[:, 9:18], Jfd[:, 24:30]])
+        assert np.abs(J[f] - Jfd).max() <= 2e-6 * np.abs(Jfd).max()
+    r, J = lin["btw"]
+    brec = synth.between_records(seq)
+    for f, (a, b) in enumerate(zip(seq.btw_a, seq.btw_b)):
+        W = P.btw_W[f].numpy()
+        np.testing.assert_allclose(r[f], W @ twin.between_residual(brec[f], x[a], x[b]), atol=1e-12)
+        Ja, Jb = twin.between_jacobian_fd(brec[f], x[a], x[b])
+        assert np.abs(J[f] - W @ np.hstack([Ja, Jb])).max() <= 1e-6 * np.abs(J[f]).max()
+    # vmapped == looped (bit for bit is not promised by torch; 1e-13 relative is)
+    st = P.st
+    for f in (0, 3, n - 2):
+        args = [t[P.imu_j[f] - 1] for t in (st.R, st.t, st.v, st.b)] + [t[P.imu_j[f]] for t in (st.R, st.t, st.v, st.b)]
+        Jl = torch.func.jacfwd(lambda d: tq._imu_res(d, *args, P.imu_rec[f], P.imu_W[f], P.g))(torch.zeros(30)).numpy()
+        assert np.abs(Jl - lin["imu"][1][f]).max() <= 1e-13 * np.abs(Jl).max()
+    # and the C oracle's closed forms agree with the AD Jacobians to rounding (no finite-difference floor in between)
+    COLI, COLJ = [0, 1, 2, 3, 4, 5, 6, 7, 8, 18, 19, 20, 21, 22, 23], [9, 10, 11, 12, 13, 14, 15, 16, 17, 24, 25, 26, 27, 28, 29]
+    for f in range(n - 1):
+        ro, Jo = oracle.imu_factor(imu[f + 1], g, x[f], x[f + 1])
+        Jo = np.hstack([Jo[:, COLI], Jo[:, COLJ]])
+        assert np.abs(ro - lin["imu"][0][f]).max() <= 1e-11 * np.abs(ro).max()
+        assert np.abs(Jo - lin["imu"][1][f]).max() <= 1e-12 * np.abs(Jo).max()
+
+
+def test_qr_elimination_is_the_least_squares_solution():
+    """sequential Householder elimination == numpy.linalg.lstsq on the dense whitened Jacobian (with and without damping)"""
+    n = 16
+    seq = synth.make_sequence(seed=6, n_kf=n)
+    imu = tq.twin_records(seq, synth.CARLA_IMU_COV)
+    x = tq.dead_reckon(seq.gt_states[0], imu)
+    prior = np.concatenate([seq.gt_states[0], [1e-6] * 3 + [5e-5] * 3 + [1e-5] * 3 + [1e-7] * 6])
+    P = tq.Problem(x, np.arange(1, n), imu[1:], seq.btw_a, seq.btw_b, synth.between_records(seq), 0, prior)
+    lin = P.linearize()
+    rows = []
+    for kfs, M in P.row_blocks(lin):
+        A = np.zeros((M.shape[0], 15 * n + 1))
+        for i, k in enumerate(kfs):
+            A[:, 15 * k:15 * k + 15] = M[:, 15 * i:15 * i + 15]
+        A[:, -1] = M[:, -1]
+        rows.append(A)
+    A = np.vstack(rows)
+    for lam in (0.0, 1e-3):
+        Ad = np.vstack([A[:, :-1], np.sqrt(lam) * np.eye(15 * n)]) if lam else A[:, :-1]
+        bd = np.concatenate([A[:, -1], np.zeros(15 * n)]) if lam else A[:, -1]
+        ref = np.linalg.lstsq(Ad, -bd, rcond=None)[0].reshape(n, 15)
+        got = P.solve_qr(lin, lam)
+        assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max()
+        assert abs(P.model_cost(lin, got) - 0.5 * np.sum((A[:, :-1] @ got.ravel() + A[:, -1]) ** 2)) < 1e-12
+
+
+def test_square_root_marginalisation_equals_the_information_form(oracle):
+    """the QR-eliminated marginal prior (R, z) carries the information the C oracle's Schur complement carries
+    (Lambda = R^T R, eta = R^T z), on a window whose oldest keyframe holds the anchor prior AND after a second
+    marginalisation that folds the first prior in"""
+    n = 30
+    seq = synth.make_sequence(seed=8, n_kf=n + 3)
+    prob = helpers.build_problem(oracle, seq)
+    ref = helpers.FixedLagOracle(oracle, prob, n, 5, init_iterations=30)
+    fl = tq.FixedLag(n, prob["imu"], prob["btw_a"], prob["btw_b"], prob["btw"], prob["prior"], seq.gt_states[0])
+    for u in range(2):
+        ref.update()
+        fl.update()
+        L, eta = fl.marg.information()
+        exp = ref.marg.arrays()
+        assert np.abs(L - exp["L"]).max() <= 1e-8 * np.abs(exp["L"]).max()
+        # (eta is the gradient at a converged linearisation point: tiny and rounding-dominated; compare what it does to the
+        # optimum instead -- the windows agree)
+        a, r = helpers.ate(fl.prob.st.to_array(), ref.window_states)
+        assert a <= 1e-9, (u, a)
+
+
+def test_c_oracle_reaches_the_independent_optimum_n200(oracle):
+    """BASELINE configs[1] (full VIL, 200 poses): the C oracle's LM optimum (normal equations, its own records) against the
+    independent one (twin records, QR).  Observed 1e-13 m."""
+    F = np.load(os.path.join(GOLD, "qr_twin_n200.npz"))
+    seq = synth.make_sequence(seed=int(F["seed"]), n_kf=int(F["n"]))
+    prob = helpers.build_problem(oracle, seq)
+    win = helpers.oracle_window(oracle, prob)
+    win.lm(iterations=100)
+    a, r = helpers.ate(win.states, F["states"])
+    print(f"n = 200: C oracle vs independent QR optimum: ATE {a:.3e} m, rot {r:.3e} rad (twin's last Gauss-Newton step {F['polish_steps'][-1]:.1e})")
+    assert a <= 1e-9 and r <= 1e-6 and F["polish_steps"][-1] < 1e-11
+    # the records themselves: the twin's preintegration (finite-difference sensitivities) against the oracle's closed forms
+    rec = F["imu_records"]
+    assert np.abs(rec[1:, :16] - prob["imu"][1:, :16]).max() < 1e-13
+    assert np.abs(rec[1:, 70:] - prob["imu"][1:, 70:]).max() <= 1e-8 * np.abs(prob["imu"][1:, 70:]).max()
+
+
+@pytest.mark.parametrize("accept_rel", [None, 0.0])
+def test_c_oracle_fixed_lag_updates_against_the_independent_optimum(oracle, accept_rel):
+    """bench.py's window 0 (seed 0, 1000 poses, sequence length 1065): the batch optimum (BASELINE configs[2]) and 25
+    marginalised fixed-lag updates with the appended factor preintegrated at the current bias estimate; the C oracle
+    takes 5 LM trials per update, the independent optimiser converges each update.  With the tolerant accept rule (the
+    default, = the engine's) observed 1e-11 m throughout; with the strict rule 1e-9 ... 1e-8 m: both far inside 1e-6."""
+    F = np.load(os.path.join(GOLD, "qr_twin_fixed_lag.npz"))
+    n = int(F["window"])
+    seq = synth.make_sequence(seed=int(F["seed"]), n_kf=int(F["seq_len"]))
+    prob = helpers.build_problem(oracle, seq)
+    ref = helpers.FixedLagOracle(oracle, prob, n, 5, init_iterations=200, accept_rel=accept_rel, ingest=(seq, oracle.carla_imu_params()))
+    a0, r0 = helpers.ate(ref.window_states, F["states_u0"])
+    worst = a0
+    assert r0 <= 1e-6
+    for u in range(1, int(max(F["updates"])) + 1):
+        st = ref.update()
+        if u in F["updates"]:
+            x = np.zeros((n, 16))
+            x[:, :7] = F[f"pose_u{u}"]
+            a, r = helpers.ate(st, x)
+            worst = max(worst, a)
+            assert r <= 1e-6, (u, r)
+    print(f"accept_rel {accept_rel}: C oracle vs independent QR optimum over {int(max(F['updates']))} updates: batch {a0:.3e} m, worst {worst:.3e} m")
+    assert worst <= (1e-9 if accept_rel is None else 1e-6)
+    assert float(np.max(F["last_polish_step_per_update"])) < 1e-10       # the fixture itself is converged

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: keyframes/sec of fixed-lag smoother updates on 1000-pose windows.
 
-One *step* = one fixed-lag update of every window in the batch: append one keyframe (its IMU
-factor and between factor are already resident in HBM; its initial value comes from the IMU
-prediction, GraphManager.cpp:152-160), marginalise the oldest one into a dense prior (Schur complement, K-marg), then K
-Levenberg-Marquardt trials, each = linearise ALL factors of the window (K1+K2) -> block-banded
+One *step* = one fixed-lag update of every window in the batch: INGEST the new keyframe (vf_engine_ingest_tail: one
+host->device copy of its raw IMU samples and between record for all windows, K0 preintegration with each window's current
+bias estimate -- GraphManager.cpp:59 -- and staging of the between factor, GraphManager.cpp:83-88), append it (initial
+value by IMU prediction, GraphManager.cpp:152-160), marginalise the oldest one into a dense prior (Schur complement,
+K-marg), then K Levenberg-Marquardt trials, each = linearise ALL factors of the window (K1+K2) -> block-banded
 J^T J (K3) -> banded Cholesky solve (K4) -> retract + cost + accept/reject (K5).
 value = (windows on all ranks) * steps / max-over-ranks time: one new keyframe per window per step.
 
@@ -98,9 +99,12 @@ def updates_per_engine(args):
     return (args.steps + args.warmup) * (1 if args.no_convergence_exit else 2)
 
 
-def make_engine(args, local_rank, windows, seqs, updates):
-    """Synthetic Carla-like factors for `windows` windows, preintegrated ON THE DEVICE (K0).  Capacity and the length
-    of every sequence cover window + updates + 1 keyframes: no update ever appends a slot without its factors."""
+def make_engine(args, local_rank, windows, seqs, updates, all_resident=False):
+    """Synthetic Carla-like factors for `windows` windows.  Only the FIRST window's factors are made resident here (K0 on
+    the device, bias estimate 0: GraphManager's bias before the first solve); the factors of the keyframes the updates
+    append stay on the host as what a driver receives per keyframe -- raw IMU samples + the between record -- and go in
+    through vf_engine_ingest_tail inside the timed step (`feed[u]` = update u's packed arguments for all windows).
+    all_resident (timing probes under tools/ only): every factor preintegrated up front, no feed."""
     from vil_sensor_fusion_amd import Engine, EngineOpts, synth
     from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
     n, total = args.window, args.window + updates + 1
@@ -111,8 +115,8 @@ def make_engine(args, local_rank, windows, seqs, updates):
     for w in range(windows):
         seq = seqs[w % nseq]
         gt0 = seq.gt_states[0]
-        eng.preintegrate(w, 1, seq.imu_off[1:total + 1], seq.imu_steps, np.zeros(6), synth.CARLA_IMU_COV)
-        m = seq.btw_b < total
+        eng.preintegrate(w, 1, seq.imu_off[1:(total if all_resident else n) + 1], seq.imu_steps, np.zeros(6), synth.CARLA_IMU_COV)
+        m = seq.btw_b < (total if all_resident else n)
         eng.set_between(w, seq.btw_a[m], seq.btw_b[m], recs[w % nseq][m])
         eng.set_states(w, 0, gt0.reshape(1, 16))
         eng.set_prior(w, 0, synth.prior_record(gt0, REFERENCE_PRIOR_SIGMAS))
@@ -123,7 +127,30 @@ def make_engine(args, local_rank, windows, seqs, updates):
     eng.sync()
     eng.iterate(args.init_iterations)      # converge the initial windows (not timed)
     eng.sync()
-    return eng
+    if all_resident:
+        return eng, None
+    # per sequence and appended keyframe k: its steps and the between factor that ends at k
+    by_end = []
+    for si, seq in enumerate(seqs):
+        d = {}
+        for i in np.nonzero(seq.btw_b >= n)[0]:
+            d[int(seq.btw_b[i])] = (int(seq.btw_a[i]), recs[si][i])
+        by_end.append(d)
+    feed, none_rec = [], np.zeros(28)
+    for u in range(updates):
+        k = n + u
+        off, steps, a, rec = [0], [], [], []
+        for w in range(windows):
+            seq = seqs[w % nseq]
+            st = seq.imu_steps[seq.imu_off[k]:seq.imu_off[k + 1]]
+            steps.append(st)
+            off.append(off[-1] + st.shape[0])
+            src, r = by_end[w % nseq].get(k, (-1, none_rec))
+            a.append(src)
+            rec.append(r)
+        feed.append((np.array(off, dtype=np.int32), np.ascontiguousarray(np.concatenate(steps)), synth.CARLA_IMU_COV,
+                     np.array(a, dtype=np.int32), np.ascontiguousarray(np.array(rec))))
+    return eng, feed
 
 
 def _cpu_updates(job):
@@ -139,7 +166,10 @@ def _cpu_updates(job):
     seq = synth.make_sequence(seed=seed, n_kf=n_kf)
     assert n_kf >= n + steps + 1
     prob = helpers.build_problem(oracle, seq)
-    ref = helpers.FixedLagOracle(oracle, prob, n, iterations, threads, init_iterations=init_iterations)
+    # (the appended keyframes' factors are preintegrated again at each update with the bias estimate of the moment, as the
+    # GPU's ingest does: GraphManager.cpp:59)
+    ref = helpers.FixedLagOracle(oracle, prob, n, iterations, threads, init_iterations=init_iterations,
+                                 ingest=(seq, oracle.carla_imu_params()))
     snap = ref.window_states.copy() if snapshot_at == 0 else None
     t0 = time.perf_counter()
     for s in range(steps):
@@ -207,6 +237,32 @@ def accuracy_vs_oracle(gpu_states, reference):
             "vs": "CPU oracle (oracle/vf_oracle.c) after the same marginalised fixed-lag updates of the same sequence; "
                   "GTSAM itself cannot be run here", "bar_m": 1e-6, "within_bar": bool(ate <= 1e-6 and rot <= 1e-6),
             "ate_vs_ground_truth_m": {"gpu": gt_gpu, "cpu_oracle": gt_cpu}}
+
+
+def accuracy_vs_independent_qr(gpu_states, reference, args, seq_len, done):
+    """GPU window 0 (and the CPU oracle) against the committed trajectory of the INDEPENDENT optimiser (oracle/twin_qr.py: the
+    twin's own preintegration and residuals, automatic-differentiation Jacobians, Householder QR on the whitened Jacobian
+    as the reference's iSAM2 is configured to factorise -- GraphManager.cpp:38 --, no normal equations, its own accept
+    rule; converged at every update).  The fixture (tests/golden/qr_twin_fixed_lag.npz, made by
+    tests/golden/make_qr_twin_golden.py) is data; it exists for this window length / sequence length at a few update counts."""
+    from tests import helpers
+    path = os.path.join(ROOT, "tests", "golden", "qr_twin_fixed_lag.npz")
+    if not os.path.exists(path):
+        return {"skipped": "fixture missing"}
+    F = np.load(path)
+    if int(F["window"]) != args.window or int(F["seq_len"]) != seq_len or done not in F["updates"]:
+        return {"skipped": f"the fixture holds window {int(F['window'])}, sequence length {int(F['seq_len'])}, updates "
+                           f"{[int(u) for u in F['updates']]}; this run: {args.window}, {seq_len}, {done}"}
+    ref = np.zeros((args.window, 16))
+    ref[:, :7] = F["states_u0"][:, :7] if done == 0 else F[f"pose_u{done}"]
+    ate, rot = helpers.ate(gpu_states, ref)
+    out = {"ate_m": ate, "rot_rad": rot, "updates": done, "window": 0, "bar_m": 1e-6, "within_bar": bool(ate <= 1e-6 and rot <= 1e-6),
+           "vs": "oracle/twin_qr.py: independent residuals + AD Jacobians + Householder QR elimination (no normal equations), "
+                 "converged at every update; fixture tests/golden/qr_twin_fixed_lag.npz",
+           "twin_last_gauss_newton_step": float(F["last_polish_step_per_update"][done - 1]) if done > 0 else float(F["polish_steps_u0"][-1])}
+    if reference is not None and reference.get("states") is not None:
+        out["cpu_oracle_vs_independent_qr_ate_m"] = helpers.ate(reference["states"], ref)[0]
+    return out
 
 
 def time_sharded_window(args, info, dist, backend, dev):
@@ -459,15 +515,20 @@ def main():
         dist = D.init(backend=backend, device_id=torch.device("cuda", gpu) if backend == "nccl" else None)
     dev = torch.device("cuda", gpu)
 
-    eng = make_engine(args, gpu, args.windows, seqs, updates)
+    eng, feed = make_engine(args, gpu, args.windows, seqs, updates)
     del seqs
+    fed = {id(eng): 0}
 
     def fence():
         D.barrier(dist)
         torch.cuda.synchronize(dev)
         eng.sync()
 
-    def one_step(e):
+    def one_step(e, feed_=None):
+        f = feed if feed_ is None else feed_
+        u = fed.setdefault(id(e), 0)
+        fed[id(e)] = u + 1
+        e.ingest_tail(*f[u])               # H2D of the new keyframe's samples + between record, K0 with the current bias, staging
         e.slide(REFERENCE_PRIOR_SIGMAS, marginalize=not args.reanchor)
         e.iterate(args.iterations)
 
@@ -480,6 +541,7 @@ def main():
     fence()
     dt = D.max_over_ranks(dist, time.perf_counter() - t0, device=dev if (dist is not None and backend == "nccl") else "cpu")
     summaries = D.gather_summaries(dist, dict(rank=info.rank, keyframes=args.windows * args.steps))
+    ingest_ms = eng.ingest_status()        # raises if any ingest of the run failed on the device; (h2d, K0 + staging) of the last one
     lm_after_timed = eng.read_lm(0)
     accuracy = None
     if reference is not None and reference["states"] is not None:
@@ -490,6 +552,7 @@ def main():
             a = accuracy_vs_oracle(eng.get_states(m["window"], done, args.window), dict(states=m["states"], gt=m["gt"], updates=done))
             per.append(dict(window=m["window"], ate_m=a["ate_m"], rot_rad=a["rot_rad"]))
         accuracy["windows"] = per
+        accuracy["vs_independent_qr"] = accuracy_vs_independent_qr(eng.get_states(0, done, args.window), reference, args, seq_len, done)
         accuracy["ate_m_max"] = max(x["ate_m"] for x in per)
         accuracy["ate_m_median"] = float(np.median([x["ate_m"] for x in per]))
         accuracy["within_bar_all"] = bool(all(x["ate_m"] <= 1e-6 and x["rot_rad"] <= 1e-6 for x in per))
@@ -607,7 +670,13 @@ def main():
                              "frac": counts["imu"] * IMU_BYTES_DENSE / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                              "note": "counts the 159 structurally zero Jacobian entries that are no longer written"}},
             "accuracy": accuracy,
-            "stage_ms": stages,
+            "stage_ms": dict(stages, h2d=ingest_ms[0], preintegrate_tail=ingest_ms[1]),
+            "ingest": {"in_timed_step": True,
+                       "what": "per update and window: the new keyframe's raw IMU samples (7 doubles each) + its 28-double between "
+                               "record, one pinned host->device copy for all windows (stage_ms.h2d); K0 with each window's current "
+                               "bias estimate (GraphManager.cpp:59) + staging of the between record in one launch "
+                               "(stage_ms.preintegrate_tail); HIP events of the last timed update",
+                       "bytes_per_update": int(feed[0][1].nbytes + feed[0][4].nbytes + feed[0][0].nbytes + feed[0][3].nbytes)},
             "lm_state_window0": lm_after_timed,
         }
         if prof is not None and "vf::k_linearize_imu" in prof.get("kernels", {}):
@@ -649,13 +718,13 @@ def main():
         if not args.no_single_window:
             # latency of the same update on ONE window (what a single vehicle sees)
             sv = argparse.Namespace(**vars(args))
-            one = make_engine(sv, gpu, 1, one_seq, one_updates)
+            one, one_feed = make_engine(sv, gpu, 1, one_seq, one_updates)
             for _ in range(2):
-                one_step(one)
+                one_step(one, one_feed)
             one.sync()
             t1 = time.perf_counter()
             for _ in range(5):
-                one_step(one)
+                one_step(one, one_feed)
             one.sync()
             lat = (time.perf_counter() - t1) / 5
             out["single_window"] = {"ms_per_update": lat * 1e3, "keyframes_per_s": 1.0 / lat,

@@ -70,14 +70,23 @@ typedef struct {
     int hybrid_threshold;    /* with vf_engine_set_convergence on a sweep engine of > 128 windows: once at most this many
                                 windows still take trials, K4 runs as the partitioned form.  Default 256; < 0 = never. */
     int cold_start;          /* != 0: every vf_engine_iterate linearises all factors (no warm start); default 0 */
-    int use_hip_graph;       /* != 0: vf_engine_iterate replays its launch sequence from a captured hipGraph (measured no
-                                faster: the stream never runs empty); default 0 */
+    int use_hip_graph;       /* != 0: vf_engine_iterate replays its launch sequence from a captured hipGraph, re-captured whenever
+                                the trial count, the warm-start tail or a scalar baked into the kernel arguments changes
+                                (vf_engine_graph_info counts captures and replays).  Bit-identical to plain launches
+                                (tests/test_gpu_hip_graph.py); measured no faster, the stream never runs empty (bench.py
+                                `single_window.with_hip_graph`); default 0 */
     double accept_rel;       /* an LM trial is accepted iff  new cost < cost + accept_rel * cost.  Default 1e-9: the rounding
                                 floor of the cost of a 1000-pose window (a sum of ~30 000 squared whitened residuals, the IMU
                                 ones scaled by 5e4) is ~1e-10 of its value; with a strict "decreases" test (accept_rel = 0) a
                                 converged window rejects about half of its Newton steps on the last bits of that sum, its
                                 soft modes stop converging, and two float64 implementations end 1e-7 ... 1e-6 m apart
-                                instead of 1e-9 (DESIGN.md "Accept rule at the floor").  Must be >= 0. */
+                                instead of 1e-9 (DESIGN.md "Accept rule at the floor").  Must be >= 0.
+                                NOTE this accept test is the build's own.  Of gtsam::LevenbergMarquardtParams only lambdaInitial
+                                (1e-5), lambdaFactor (10) and the termination tolerances (vf_engine_set_convergence) are
+                                followed; GTSAM accepts a step on modelFidelity = actual / predicted decrease >
+                                minModelFidelity (1e-3), which this library does not evaluate.  Where the optimum is does not
+                                depend on either rule: tests/test_gpu_vs_qr_twin.py holds the result to an independent QR
+                                optimiser that uses the gain-ratio test. */
 } vf_engine_opts;
 
 void vf_engine_default_opts(vf_engine_opts* o);
@@ -111,6 +120,18 @@ typedef struct {
 int vf_engine_preintegrate(vf_engine* e, int window, int k0, int n, const int32_t* step_off,
                            const double* steps7, const double* bias_hat6, const vf_imu_params* p);
 int vf_engine_get_imu(vf_engine* e, int window, int k0, int n, double* rec190);
+/* The INGEST half of a fixed-lag update, for every window at once -- what GraphManager::reserveNode (GraphManager.cpp:51-69)
+ * and addBetweenFactor (:83-88) do for one vehicle per keyframe: window w's next IMU factor (hi[w]-1 -> hi[w]) is
+ * preintegrated on the device from its raw samples steps7[step_off[w] .. step_off[w+1]) WITH THE WINDOW'S CURRENT BIAS
+ * ESTIMATE (the bias of its last keyframe, read on the device: `getFactor(_lastPoseTime, time, _currentKey, getBias())`,
+ * GraphManager.cpp:59), and the between factor that ends at the same keyframe is staged (btw_a[w] = source keyframe
+ * slot, -1 = none; btw_rec28[w] its record).  One packed host->device copy from a pinned buffer, one kernel launch, no host
+ * synchronisation; vf_engine_slide then appends the keyframe (its initial value predicted from this factor) and
+ * vf_engine_iterate solves, the engine staying warm.  Errors found on the device (no free slot, covariance not SPD) are
+ * reported by vf_engine_ingest_status, which also returns the last call's copy / kernel times from HIP events. */
+int vf_engine_ingest_tail(vf_engine* e, const int32_t* step_off, const double* steps7, const vf_imu_params* p,
+                          const int32_t* btw_a, const double* btw_rec28);
+int vf_engine_ingest_status(vf_engine* e, float* h2d_ms, float* k0_ms);
 
 /* ---- hot-path stages (asynchronous on the engine's HIP stream) ---- */
 /* K1+K2+priors: residual + whitened Jacobian of every factor, at the current (which=0) or
@@ -210,9 +231,15 @@ int vf_engine_compact(vf_engine* e, int shift);
  * are carried over on the device; the linearisation of the current states is recomputed, normal equations are not kept
  * (the next solve starts cold).  This is
  * what lets a GraphManager with lag = 0 keep the whole history the way the reference's unbounded iSAM2 graph does
- * (GraphManager.cpp:17-43), for as long as the 24 KB per keyframe slot fit in HBM.  Not for sharded engines. */
+ * (GraphManager.cpp:17-43), for as long as the 24 KB per keyframe slot fit in HBM.  Not for sharded engines.
+ * Memory: the old and the new buffers are alive together until the copies are done -- a doubling peaks at 3x the old
+ * footprint.  Cost: 36 device-to-device copies per window (32 state planes + 4 arrays); meant for the one-window engine
+ * of a GraphManager handle, not for growing a batch of a thousand windows in a loop. */
 int vf_engine_grow(vf_engine* e, int new_capacity);
 int vf_engine_sync(vf_engine* e);
+/* vf_engine_opts.use_hip_graph: is replay active (0 once a capture failed or a caller's stream was handed in), how often the
+ * launch sequence was captured, how many vf_engine_iterate calls were served by hipGraphLaunch */
+int vf_engine_graph_info(vf_engine* e, int* enabled, int* captures, long* replays);
 
 /* ---- read-back (synchronises) ---- */
 int vf_engine_read_imu_lin(vf_engine* e, int window, int which, int k0, int n, double* r15, double* J450);
@@ -287,8 +314,9 @@ int vf_dopt_filter_f32(const float* hessians36, int count, float rot_thr, float 
 typedef struct vf_graph vf_graph;
 
 typedef struct {
-    int capacity;    /* keyframe slots on the device (keys 0..capacity-1); with lag = 0 the INITIAL number: vf_solve doubles
-                        it whenever the history outgrows it (vf_engine_grow), unless fixed_capacity != 0 */
+    int capacity;    /* keyframe slots on the device (keys 0..capacity-1), rounded up to a multiple of 64 by vf_create (the
+                        engine allocates whole tiles); with lag = 0 the INITIAL number: vf_solve doubles it whenever the
+                        history outgrows it (vf_engine_grow), unless fixed_capacity != 0 */
     int lag;         /* fixed-lag window length in keyframes; 0 = smooth the whole history */
     int iterations;  /* LM trials per vf_solve, at most (see rel_tol / abs_tol) */
     int device;

@@ -53,8 +53,10 @@ def test_cpu_leg_is_the_marginalised_update(oracle):
     dt, snap, gt = bench._cpu_updates((3, n, n + steps + 1, steps, K, 1, steps, 30))
     seq = synth.make_sequence(seed=3, n_kf=n + steps + 1)
     prob = helpers.build_problem(oracle, seq)
-    ref = helpers.FixedLagOracle(oracle, prob, n, K, init_iterations=30)
+    ref = helpers.FixedLagOracle(oracle, prob, n, K, init_iterations=30, ingest=(seq, oracle.carla_imu_params()))
     for _ in range(steps):
         ref.update()
     np.testing.assert_array_equal(snap, ref.window_states)
+    # the appended factors were preintegrated again with the bias estimate of the moment (GraphManager.cpp:59), not with 0
+    assert np.abs(ref.prob["imu"][n + steps - 1][10:16]).max() > 0 and not np.abs(prob["imu"][n + steps - 1][10:16]).any()
     assert ref.marg is not None and ref.marg.on == 1 and dt > 0 and gt.shape == (n, 16)

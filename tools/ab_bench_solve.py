@@ -11,11 +11,13 @@ from vil_sensor_fusion_amd import _lib
 _lib._SO = sys.argv[1]
 import bench
 from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
-args = argparse.Namespace(window=1000, windows=1024, steps=10, warmup=2, iterations=5, host_workers=0, no_convergence_exit=False, sequences=0)
+args = argparse.Namespace(window=1000, windows=1024, steps=10, warmup=2, init_iterations=200, iterations=5, host_workers=0, no_convergence_exit=False, sequences=0)
 updates = bench.updates_per_engine(args)
 seqs = bench.make_sequences(args, 0, 64, args.window + updates + 1)
-eng = bench.make_engine(args, 0, args.windows, seqs, updates)
+eng, feed = bench.make_engine(args, 0, args.windows, seqs, updates)
+fed = [0]
 def step():
+    eng.ingest_tail(*feed[fed[0]]); fed[0] += 1
     eng.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True); eng.iterate(5)
 for _ in range(3): step()
 eng.sync()

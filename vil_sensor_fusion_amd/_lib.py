@@ -59,11 +59,11 @@ SYMBOLS = [
     "vf_engine_set_between", "vf_engine_clear_between", "vf_engine_set_prior",
     "vf_engine_linearize", "vf_engine_assemble", "vf_engine_solve", "vf_engine_retract",
     "vf_engine_decide", "vf_engine_iterate", "vf_engine_slide", "vf_engine_predict",
-    "vf_engine_sync",
+    "vf_engine_sync", "vf_engine_graph_info",
     "vf_engine_read_imu_lin", "vf_engine_read_between_lin", "vf_engine_read_normal",
     "vf_engine_read_delta", "vf_engine_read_panels", "vf_engine_read_lm",
     "vf_engine_time_stage", "vf_engine_time_iterate", "vf_engine_counts",
-    "vf_engine_preintegrate", "vf_engine_get_imu",
+    "vf_engine_preintegrate", "vf_engine_get_imu", "vf_engine_ingest_tail", "vf_engine_ingest_status",
     "vf_engine_marginalize", "vf_engine_drop_oldest", "vf_engine_read_marginal", "vf_engine_compact", "vf_engine_grow",
     "vf_engine_set_stream", "vf_engine_set_shard", "vf_engine_shard_info", "vf_engine_solve_local",
     "vf_engine_solve_global", "vf_engine_reset_lambda",

@@ -32,32 +32,73 @@ template <> struct Lim<float> { static constexpr float eps = 1.1920929e-07f; sta
 template <typename T> DI T t_sqrt(T x) { return sqrt(x); }
 template <typename T> DI T t_abs(T x) { return fabs(x); }
 
-// symmetric eigenvalues, cyclic Jacobi (two-sided rotations on the full matrix)
+// Reciprocal and reciprocal square root for the Jacobi rotations: the hardware approximations (v_rcp / v_rsq: 2^-23
+// relative in float64, 1 ulp in float32) + ONE third-order correction step in float64 (error e^3 ~ 2^-69: full double).
+// No scaling for denormals / huge arguments as the library sqrt() and '/' carry (about 20 instructions each in float64):
+// the arguments here are sums of squares of matrix entries, and the kernels document their range (|entry| in 1e-150 ... 1e150).
+DI double rsq_full(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+DI float rsq_full(float x) { return __builtin_amdgcn_rsqf(x); }
+DI double rcp_full(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, fma(e, e, e), r);
+}
+DI float rcp_full(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// Jacobi rotation that annihilates beta in [[a, beta], [beta, b]], alpha = (b - a) / 2:
+//   t = tan(phi) = sgn(alpha) beta / (|alpha| + sqrt(alpha^2 + beta^2)),  c = 1 / sqrt(1 + t^2),  s = t c
+// (the textbook theta = alpha / beta form costs two divisions and two square roots; this one a reciprocal square root, a
+// reciprocal and a second reciprocal square root).  beta = 0 gives t = 0, c = 1, s = 0 without a branch.
+template <typename T>
+DI void jacobi_cs(T alpha, T beta, T& t, T& c, T& s) {
+    const T h2 = fma(alpha, alpha, beta * beta);
+    const T h = h2 * rsq_full(h2 > T(0) ? h2 : T(1));
+    const T den = copysign(t_abs(alpha) + h, alpha);
+    t = beta != T(0) ? beta * rcp_full(den) : T(0);
+    c = rsq_full(fma(t, t, T(1)));
+    s = t * c;
+}
+
+// symmetric eigenvalues, cyclic Jacobi on the UPPER TRIANGLE (a[p * N + q], p <= q; the strict lower triangle is neither
+// read nor written).  A sweep ends the iteration for the whole wave once every lane's off-diagonal mass has dropped to
+// rounding level, off^2 <= eps^2 * sum diag^2 (eigenvalue error ~ off^2 / gap: far below eps for any spectrum); a 6x6
+// takes 5-7 sweeps, the cap Lim<T>::sweeps is a safety net.  `active`: lanes without a matrix do not hold the wave back.
 template <typename T, int N>
-DI void jacobi_eig(T (&a)[N * N], T (&ev)[N]) {
+DI void jacobi_eig(T (&a)[N * N], T (&ev)[N], bool active) {
 #pragma unroll 1
     for (int sweep = 0; sweep < Lim<T>::sweeps; sweep++) {
+        T off2 = T(0), d2 = T(0);
+#pragma unroll
+        for (int p = 0; p < N; p++) {
+            d2 = fma(a[p * N + p], a[p * N + p], d2);
+#pragma unroll
+            for (int q = p + 1; q < N; q++) off2 = fma(a[p * N + q], a[p * N + q], off2);
+        }
+        const bool done = !active || !(off2 > Lim<T>::eps * Lim<T>::eps * d2);
+        if (__all(done)) break;
 #pragma unroll
         for (int p = 0; p < N - 1; p++)
 #pragma unroll
             for (int q = p + 1; q < N; q++) {
+                T t, c, s;
                 const T apq = a[p * N + q];
-                if (apq != T(0)) {
-                    const T theta = (a[q * N + q] - a[p * N + p]) / (T(2) * apq);
-                    const T t = copysign(T(1), theta) / (t_abs(theta) + t_sqrt(theta * theta + T(1)));
-                    const T c = T(1) / t_sqrt(t * t + T(1)), s = t * c;
+                jacobi_cs<T>(T(0.5) * (a[q * N + q] - a[p * N + p]), apq, t, c, s);
+                a[p * N + p] = fma(-t, apq, a[p * N + p]);
+                a[q * N + q] = fma(t, apq, a[q * N + q]);
+                a[p * N + q] = T(0);
 #pragma unroll
-                    for (int k = 0; k < N; k++) {
-                        const T akp = a[k * N + p], akq = a[k * N + q];
-                        a[k * N + p] = c * akp - s * akq;
-                        a[k * N + q] = s * akp + c * akq;
-                    }
-#pragma unroll
-                    for (int k = 0; k < N; k++) {
-                        const T apk = a[p * N + k], aqk = a[q * N + k];
-                        a[p * N + k] = c * apk - s * aqk;
-                        a[q * N + k] = s * apk + c * aqk;
-                    }
+                for (int k = 0; k < N; k++) {
+                    if (k == p || k == q) continue;
+                    // entry (k, p) and (k, q) of the symmetric matrix, wherever the upper triangle keeps them
+                    T& xp = k < p ? a[k * N + p] : a[p * N + k];
+                    T& xq = k < q ? a[k * N + q] : a[q * N + k];
+                    const T vp = xp, vq = xq;
+                    xp = fma(c, vp, -(s * vq));
+                    xq = fma(s, vp, c * vq);
                 }
             }
     }
@@ -65,11 +106,13 @@ DI void jacobi_eig(T (&a)[N * N], T (&ev)[N]) {
     for (int i = 0; i < N; i++) ev[i] = a[i * N + i];
 }
 
-// singular values of a general matrix, one-sided Jacobi on the columns
+// singular values of a general matrix, one-sided (Hestenes) Jacobi on the columns; a sweep in which no lane of the wave
+// rotated ends the iteration
 template <typename T, int N>
-DI void jacobi_svd(T (&a)[N * N], T (&sv)[N]) {
+DI void jacobi_svd(T (&a)[N * N], T (&sv)[N], bool active) {
 #pragma unroll 1
     for (int sweep = 0; sweep < Lim<T>::sweeps; sweep++) {
+        bool rotated = false;
 #pragma unroll
         for (int p = 0; p < N - 1; p++)
 #pragma unroll
@@ -81,18 +124,19 @@ DI void jacobi_svd(T (&a)[N * N], T (&sv)[N]) {
                     be = fma(a[k * N + q], a[k * N + q], be);
                     ga = fma(a[k * N + p], a[k * N + q], ga);
                 }
-                if (t_abs(ga) > Lim<T>::eps * T(0.01) * t_sqrt(al * be) && ga != T(0)) {
-                    const T zeta = (be - al) / (T(2) * ga);
-                    const T t = copysign(T(1), zeta) / (t_abs(zeta) + t_sqrt(T(1) + zeta * zeta));
-                    const T c = T(1) / t_sqrt(T(1) + t * t), s = c * t;
+                constexpr T tol = Lim<T>::eps * T(0.01);
+                const bool need = ga * ga > tol * tol * al * be;
+                rotated |= need;
+                T t, c, s;
+                jacobi_cs<T>(T(0.5) * (be - al), need ? ga : T(0), t, c, s);
 #pragma unroll
-                    for (int k = 0; k < N; k++) {
-                        const T akp = a[k * N + p], akq = a[k * N + q];
-                        a[k * N + p] = c * akp - s * akq;
-                        a[k * N + q] = s * akp + c * akq;
-                    }
+                for (int k = 0; k < N; k++) {
+                    const T akp = a[k * N + p], akq = a[k * N + q];
+                    a[k * N + p] = fma(c, akp, -(s * akq));
+                    a[k * N + q] = fma(s, akp, c * akq);
                 }
             }
+        if (__all(!active || !rotated)) break;
     }
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -231,7 +275,7 @@ DI void matmul(const T (&a)[N * N], const T (&b)[N * N], T (&c)[N * N]) {
 
 // eigenvalues of now * prev^-1 for SPD prev: similar to L^-1 now L^-T with prev = L L^T
 template <typename T, int N>
-DI void ratio_eig(const T (&now)[N * N], const T (&prev)[N * N], T (&ev)[N], bool& ok) {
+DI void ratio_eig(const T (&now)[N * N], const T (&prev)[N * N], T (&ev)[N], bool& ok, bool active) {
     T L[N * N];
 #pragma unroll
     for (int i = 0; i < N * N; i++) L[i] = T(0);
@@ -276,7 +320,7 @@ DI void ratio_eig(const T (&now)[N * N], const T (&prev)[N * N], T (&ev)[N], boo
     for (int r = 0; r < N; r++)
 #pragma unroll
         for (int c = r + 1; c < N; c++) { const T m = T(0.5) * (S[r * N + c] + S[c * N + r]); S[r * N + c] = m; S[c * N + r] = m; }
-    jacobi_eig<T, N>(S, ev);
+    jacobi_eig<T, N>(S, ev, active);
 }
 
 enum Metric { D_OPT, D_OPT_RATIO, A_OPT, A_OPT_RATIO, E_OPT, E_OPT_RATIO, MAX_EIGEN, MAX_EIGEN_RATIO, JENSEN_BREGMAN,
@@ -303,40 +347,82 @@ DI T normfro(const T (&a)[N * N]) {
     return t_sqrt(s);
 }
 
-// mats: (T,6,6) row-major, pose (T,6) or null; off = 0 (all / trans) or 3 (rot); out[0] = 0
-template <typename T, int N>
+// Which metrics read the previous message's matrix (the ratio / divergence family, make_prettier_graphs.py:565-574)
+__host__ __device__ constexpr bool metric_needs_prev(int m) {
+    return m == D_OPT_RATIO || m == A_OPT_RATIO || m == E_OPT_RATIO || m == MAX_EIGEN_RATIO || m == JENSEN_BREGMAN || m == CORR_DIST ||
+           m == KULLBACK_LEIBLER || m == NORM_FRO_RATIO || m == NORM_NUC_RATIO || m == NORM_1_RATIO || m == NORM_2_RATIO;
+}
+constexpr int MSTRIDE = 37;   // LDS stride of one 6x6 (36 + 1 pad: 64 lanes reading entry e of their own matrix hit 32 / 64 distinct banks)
+
+// mats: (T,6,6) row-major, pose (T,6) or null; off = 0 (all / trans) or 3 (rot); out[0] = 0.
+// One wave per 64 consecutive messages.  The wave's matrices (and the one in front of them, for the metrics that compare
+// with the previous message) are ONE contiguous stretch of HBM: it is copied to LDS with 16-byte loads, fully
+// coalesced, and every lane then picks its own matrix out of LDS (lane = message reads of 288-byte records straight
+// from HBM touch 64 cache lines per load instruction).  METRIC is a template parameter: a metric's kernel contains
+// only its own arithmetic and loads the previous matrix only if it uses it.
+template <typename T, int N, int METRIC>
 __global__ void __launch_bounds__(64) k_degeneracy(const T* __restrict__ mats, const T* __restrict__ pose, int count, int off,
-                                                   int metric, T* __restrict__ out) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= count) return;
-    if (i == 0) { out[0] = T(0); return; }   // make_prettier_graphs.py:562-563
+                                                   T* __restrict__ out) {
+    // staged in two halves of 32 messages (lanes 0-31 pick theirs up after the first, 32-63 after the second): 9.8 KB of LDS
+    // per wave instead of 19.2, i.e. four waves per SIMD instead of two for the Jacobi kernels
+    __shared__ T lds[33 * MSTRIDE];
+    const int lane = threadIdx.x, base = blockIdx.x * 64;
+    const int i = base + lane;
+    constexpr bool PREV = metric_needs_prev(METRIC);
+    const bool active = i > 0 && i < count;
     T now[N * N], prev[N * N];
 #pragma unroll
-    for (int r = 0; r < N; r++)
+    for (int half = 0; half < 2; half++) {
+        const int hb = base + 32 * half;                                  // first message of this half
+        if (half) __syncthreads();
+        if (hb < count) {
+            const int first = (PREV && hb > 0) ? hb - 1 : hb;            // first matrix staged, local index first - hb + 1
+            const int last = hb + 32 < count ? hb + 32 : count;
+            constexpr int V = 16 / (int)sizeof(T);                        // elements per 16-byte load (36 is a multiple of both)
+            const int nvec = (last - first) * 36 / V;
+            using vec_t = T __attribute__((ext_vector_type(V)));
+            const vec_t* src = reinterpret_cast<const vec_t*>(mats + (size_t)first * 36);
+            for (int v = lane; v < nvec; v += 64) {
+                const vec_t x = __builtin_nontemporal_load(src + v);
+                const int e = v * V, m = e / 36, r = e - m * 36;
+                T* dst = lds + (m + first - hb + 1) * MSTRIDE + r;
 #pragma unroll
-        for (int c = 0; c < N; c++) {
-            now[r * N + c] = mats[(size_t)i * 36 + (off + r) * 6 + off + c];
-            prev[r * N + c] = mats[(size_t)(i - 1) * 36 + (off + r) * 6 + off + c];
+                for (int k = 0; k < V; k++) dst[k] = x[k];
+            }
         }
+        __syncthreads();
+        if ((lane >> 5) == half) {
+            const int l = lane & 31;
+            const T* mn = lds + (l + 1) * MSTRIDE + off * 7;
+            const T* mp = lds + l * MSTRIDE + off * 7;
+#pragma unroll
+            for (int r = 0; r < N; r++)
+#pragma unroll
+                for (int c = 0; c < N; c++) {
+                    now[r * N + c] = active ? mn[r * 6 + c] : T(r == c);
+                    prev[r * N + c] = (PREV && active) ? mp[r * 6 + c] : T(r == c);
+                }
+        }
+    }
     const T nan = T(NAN);
     T y = nan;
-    const bool is_ratio = metric == D_OPT_RATIO || metric == A_OPT_RATIO || metric == NORM_FRO_RATIO ||
-                          metric == NORM_NUC_RATIO || metric == NORM_1_RATIO || metric == NORM_2_RATIO;
+    constexpr bool is_ratio = METRIC == D_OPT_RATIO || METRIC == A_OPT_RATIO || METRIC == NORM_FRO_RATIO ||
+                              METRIC == NORM_NUC_RATIO || METRIC == NORM_1_RATIO || METRIC == NORM_2_RATIO;
     T ratio[N * N];
     if (is_ratio) {
         T pinv[N * N];
         gj_inverse<T, N>(prev, pinv);
         matmul<T, N>(now, pinv, ratio);
     }
-    switch (metric) {
+    switch (METRIC) {
         case D_OPT: case D_OPT_RATIO: {
-            const T la = (metric == D_OPT) ? lu_logabsdet<T, N>(now) : lu_logabsdet<T, N>(ratio);
+            const T la = (METRIC == D_OPT) ? lu_logabsdet<T, N>(now) : lu_logabsdet<T, N>(ratio);
             y = exp(la / T(N));
         } break;
         case A_OPT: case A_OPT_RATIO: {
             T s = 0;
 #pragma unroll
-            for (int k = 0; k < N; k++) s += (metric == A_OPT) ? now[k * N + k] : ratio[k * N + k];
+            for (int k = 0; k < N; k++) s += (METRIC == A_OPT) ? now[k * N + k] : ratio[k * N + k];
             y = s;
         } break;
         case E_OPT: case MAX_EIGEN: {
@@ -345,20 +431,20 @@ __global__ void __launch_bounds__(64) k_degeneracy(const T* __restrict__ mats, c
             for (int r = 0; r < N; r++)
 #pragma unroll
                 for (int c = 0; c < N; c++) s[r * N + c] = T(0.5) * (now[r * N + c] + now[c * N + r]);
-            jacobi_eig<T, N>(s, ev);
+            jacobi_eig<T, N>(s, ev, active);
             T lo = ev[0], hi = ev[0];
 #pragma unroll
             for (int k = 1; k < N; k++) { lo = ev[k] < lo ? ev[k] : lo; hi = ev[k] > hi ? ev[k] : hi; }
-            y = metric == E_OPT ? lo : hi;
+            y = METRIC == E_OPT ? lo : hi;
         } break;
         case E_OPT_RATIO: case MAX_EIGEN_RATIO: {
             T ev[N];
             bool ok;
-            ratio_eig<T, N>(now, prev, ev, ok);
+            ratio_eig<T, N>(now, prev, ev, ok, active);
             T lo = ev[0], hi = ev[0];
 #pragma unroll
             for (int k = 1; k < N; k++) { lo = ev[k] < lo ? ev[k] : lo; hi = ev[k] > hi ? ev[k] : hi; }
-            y = ok ? (metric == E_OPT_RATIO ? lo : hi) : nan;
+            y = ok ? (METRIC == E_OPT_RATIO ? lo : hi) : nan;
         } break;
         case JENSEN_BREGMAN: {
             T avg[N * N], prod[N * N];
@@ -390,7 +476,7 @@ __global__ void __launch_bounds__(64) k_degeneracy(const T* __restrict__ mats, c
             for (int k = 0; k < N; k++) a += m[k * N + k] - T(1);
             T du[N], b = 0;
 #pragma unroll
-            for (int k = 0; k < N; k++) du[k] = pose ? pose[(size_t)(i - 1) * 6 + off + k] - pose[(size_t)i * 6 + off + k] : T(0);
+            for (int k = 0; k < N; k++) du[k] = (pose && active) ? pose[(size_t)(i - 1) * 6 + off + k] - pose[(size_t)i * 6 + off + k] : T(0);
 #pragma unroll
             for (int r = 0; r < N; r++) {
                 T s = 0;
@@ -407,14 +493,14 @@ __global__ void __launch_bounds__(64) k_degeneracy(const T* __restrict__ mats, c
         case NORM_1_RATIO: y = norm1<T, N>(ratio); break;
         case NORM_NUC: case NORM_2: case COND_NUMBER: case NORM_NUC_RATIO: case NORM_2_RATIO: {
             T w[N * N], sv[N];
-            const bool r = metric == NORM_NUC_RATIO || metric == NORM_2_RATIO;
+            constexpr bool r = METRIC == NORM_NUC_RATIO || METRIC == NORM_2_RATIO;
 #pragma unroll
             for (int k = 0; k < N * N; k++) w[k] = r ? ratio[k] : now[k];
-            jacobi_svd<T, N>(w, sv);
+            jacobi_svd<T, N>(w, sv, active);
             T lo = sv[0], hi = sv[0], sum = 0;
 #pragma unroll
             for (int k = 0; k < N; k++) { lo = sv[k] < lo ? sv[k] : lo; hi = sv[k] > hi ? sv[k] : hi; sum += sv[k]; }
-            y = (metric == NORM_NUC || metric == NORM_NUC_RATIO) ? sum : ((metric == COND_NUMBER) ? -(hi / lo) : hi);
+            y = (METRIC == NORM_NUC || METRIC == NORM_NUC_RATIO) ? sum : ((METRIC == COND_NUMBER) ? -(hi / lo) : hi);
         } break;
         case DIFF_ENTROPY: {
             const T x = pow(T(2.0 * 3.141592653589793 * 2.718281828459045), T(N));
@@ -423,8 +509,22 @@ __global__ void __launch_bounds__(64) k_degeneracy(const T* __restrict__ mats, c
         } break;
         default: break;
     }
-    out[i] = y;
+    if (i == 0) out[0] = T(0);            // make_prettier_graphs.py:562-563
+    else if (i < count) out[i] = y;
 }
+
+template <typename T, int N>
+void launch_degeneracy(int metric, dim3 grid, const T* m, const T* p, int count, int off, T* o) {
+#define VF_K6_CASE(M) case M: hipLaunchKernelGGL((k_degeneracy<T, N, M>), grid, dim3(64), 0, 0, m, p, count, off, o); break;
+    switch (metric) {
+        VF_K6_CASE(0) VF_K6_CASE(1) VF_K6_CASE(2) VF_K6_CASE(3) VF_K6_CASE(4) VF_K6_CASE(5) VF_K6_CASE(6) VF_K6_CASE(7)
+        VF_K6_CASE(8) VF_K6_CASE(9) VF_K6_CASE(10) VF_K6_CASE(11) VF_K6_CASE(12) VF_K6_CASE(13) VF_K6_CASE(14) VF_K6_CASE(15)
+        VF_K6_CASE(16) VF_K6_CASE(17) VF_K6_CASE(18) VF_K6_CASE(19) VF_K6_CASE(20)
+        default: break;
+    }
+#undef VF_K6_CASE
+}
+static_assert(N_METRICS == 21, "launch_degeneracy lists every metric");
 
 // degerate_odometry_filter.cpp:29-47 (float32): hessian (row-major floats) copied into a
 // column-major Eigen matrix, rotation = block(3,3), translation = block(0,0), log(det)
@@ -471,13 +571,13 @@ int run_batch(const void* mats, const void* pose, int count, int subset, int met
         HIPCHK(hipMemcpy(d_p, pose, pb, hipMemcpyHostToDevice));
     }
     const int off = subset == 2 ? 3 : 0;
-    const dim3 grid((count + 63) / 64), block(64);
+    const dim3 grid((count + 63) / 64);
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     auto launch = [&]() {
-        if (subset == 0) hipLaunchKernelGGL((k_degeneracy<T, 6>), grid, block, 0, 0, d_m, d_p, count, off, metric, d_o);
-        else hipLaunchKernelGGL((k_degeneracy<T, 3>), grid, block, 0, 0, d_m, d_p, count, off, metric, d_o);
+        if (subset == 0) launch_degeneracy<T, 6>(metric, grid, d_m, d_p, count, off, d_o);
+        else launch_degeneracy<T, 3>(metric, grid, d_m, d_p, count, off, d_o);
     };
     launch();
     HIPCHK(hipDeviceSynchronize());

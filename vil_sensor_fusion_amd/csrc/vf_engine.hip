@@ -59,6 +59,8 @@ struct vf_engine {
     int graph_iters = -1, graph_mode = 0;
     long graph_epoch = -1, epoch = 0;
     bool graph_off = false;
+    long graph_replays = 0;          // hipGraphLaunch calls so far; graph_captures: (re-)captures of the sequence
+    int graph_captures = 0;
     double* lambda0_dev = nullptr;   // [B] lambda0, the source of the per-solve reset
     void drop_graph() {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -117,6 +119,33 @@ struct vf_engine {
         const size_t want = bytes < (1u << 16) ? (1u << 16) : bytes * 2;
         HIPCHK(hipMalloc(&pre_buf, want));
         pre_bytes = want;
+        return VF_OK;
+    }
+    // vf_engine_ingest_tail: pinned host staging (so the one host->device copy of an update is asynchronous), its device
+    // twin, the events that time the copy and the kernel, and the sticky status word the kernel reports into
+    void* in_host = nullptr;
+    void* in_dev = nullptr;
+    size_t in_bytes = 0;
+    int* in_status = nullptr;
+    hipEvent_t in_ev[3] = {nullptr, nullptr, nullptr};
+    bool in_pending = false;
+    int ensure_ingest(size_t bytes) {
+        if (!in_ev[0])
+            for (auto& ev : in_ev) HIPCHK(hipEventCreate(&ev));
+        if (!in_status) {
+            HIPCHK(hipMalloc((void**)&in_status, sizeof(int)));
+            HIPCHK(hipMemsetAsync(in_status, 0, sizeof(int), stream));
+        }
+        if (bytes <= in_bytes) return VF_OK;
+        if (in_pending) HIPCHK(hipEventSynchronize(in_ev[1]));
+        if (in_host) HIPCHK(hipHostFree(in_host));
+        if (in_dev) HIPCHK(hipFree(in_dev));
+        in_host = in_dev = nullptr;
+        in_bytes = 0;
+        const size_t want = bytes * 2;
+        HIPCHK(hipHostMalloc(&in_host, want, hipHostMallocDefault));
+        HIPCHK(hipMalloc(&in_dev, want));
+        in_bytes = want;
         return VF_OK;
     }
     int ensure_stage(size_t bytes) {
@@ -285,6 +314,10 @@ void vf_engine_destroy(vf_engine* e) {
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->stage) (void)hipFree(e->stage);
     if (e->pre_buf) (void)hipFree(e->pre_buf);
+    if (e->in_host) (void)hipHostFree(e->in_host);
+    if (e->in_dev) (void)hipFree(e->in_dev);
+    if (e->in_status) (void)hipFree(e->in_status);
+    for (auto ev : e->in_ev) if (ev) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream && e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -482,6 +515,67 @@ int vf_engine_preintegrate(vf_engine* e, int window, int k0, int n, const int32_
     return VF_OK;
 }
 
+int vf_engine_ingest_tail(vf_engine* e, const int32_t* step_off, const double* steps, const vf_imu_params* p,
+                          const int32_t* btw_a, const double* btw_rec) {
+    DeviceGuard dev_guard_(e);
+    if (!e || !step_off || !p || !btw_a || !btw_rec) return fail(VF_ERR_INVALID, "null argument");
+    const int B = e->v.B, M = e->v.M, W = e->opts.bandwidth;
+    const int total = step_off[B];
+    if (step_off[0] != 0 || (total > 0 && !steps)) return fail(VF_ERR_INVALID, "bad step offsets");
+    for (int w = 0; w < B; w++) {
+        if (step_off[w + 1] <= step_off[w]) return fail(VF_ERR_INDETERMINATE, "window %d: the new IMU factor has no IMU steps", w);
+        const int hi = e->h_hi[w], lo = e->h_lo[w];
+        if (hi >= M) return fail(VF_ERR_CAPACITY, "window %d has no free keyframe slot", w);
+        if (hi <= lo) return fail(VF_ERR_BAD_KEY, "window %d is empty", w);
+        if (btw_a[w] >= 0 && (btw_a[w] >= hi || btw_a[w] < lo)) return fail(VF_ERR_BAD_KEY, "window %d: between factor from keyframe %d outside the window [%d, %d)", w, btw_a[w], lo, hi);
+        if (btw_a[w] >= 0 && hi - btw_a[w] > W) return fail(VF_ERR_CAPACITY, "window %d: between factor spans %d keyframes > bandwidth %d", w, hi - btw_a[w], W);
+    }
+    // one packed block: [offsets B + 1][between sources B][between records 28 B][steps 7 x total]
+    const size_t off_b = ((size_t)(B + 1) * sizeof(int) + 7) & ~(size_t)7, a_b = ((size_t)B * sizeof(int) + 7) & ~(size_t)7;
+    const size_t rec_b = (size_t)B * vf::BTW_IN * sizeof(double), st_b = (size_t)total * 7 * sizeof(double);
+    const size_t bytes = off_b + a_b + rec_b + st_b;
+    int rc = e->ensure_ingest(bytes);
+    if (rc) return rc;
+    if (e->in_pending) HIPCHK(hipEventSynchronize(e->in_ev[1]));      // the previous call's copy has left the pinned buffer
+    char* h = (char*)e->in_host;
+    memcpy(h, step_off, (size_t)(B + 1) * sizeof(int));
+    memcpy(h + off_b, btw_a, (size_t)B * sizeof(int));
+    memcpy(h + off_b + a_b, btw_rec, rec_b);
+    memcpy(h + off_b + a_b + rec_b, steps, st_b);
+    char* d = (char*)e->in_dev;
+    HIPCHK(hipEventRecord(e->in_ev[0], e->stream));
+    HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipEventRecord(e->in_ev[1], e->stream));
+    vf::ImuCov c{p->acc_cov, p->gyro_cov, p->integration_cov, p->bias_acc_cov, p->bias_omega_cov, p->bias_acc_omega_int};
+    vf::launch_ingest_tail(e->v, (const int*)d, (const double*)(d + off_b + a_b + rec_b), (const int*)(d + off_b),
+                           (const double*)(d + off_b + a_b), c, e->in_status, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->in_ev[2], e->stream));
+    e->in_pending = true;
+    // Nothing inside any window changed (the records sit in slot hi, beyond every window's end): a warm engine stays warm,
+    // the vf_engine_slide that follows appends the keyframe and the next solve linearises it (k_linearize_tail).
+    return VF_OK;
+}
+
+int vf_engine_ingest_status(vf_engine* e, float* h2d_ms, float* k0_ms) {
+    DeviceGuard dev_guard_(e);
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (h2d_ms) *h2d_ms = 0.f;
+    if (k0_ms) *k0_ms = 0.f;
+    if (!e->in_pending) return VF_OK;
+    HIPCHK(hipEventSynchronize(e->in_ev[2]));
+    if (h2d_ms) HIPCHK(hipEventElapsedTime(h2d_ms, e->in_ev[0], e->in_ev[1]));
+    if (k0_ms) HIPCHK(hipEventElapsedTime(k0_ms, e->in_ev[1], e->in_ev[2]));
+    int status = 0;
+    HIPCHK(hipMemcpy(&status, e->in_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (status) {
+        HIPCHK(hipMemset(e->in_status, 0, sizeof(int)));
+        if (status & 2) return fail(VF_ERR_CAPACITY, "vf_engine_ingest_tail: a window had no free keyframe slot");
+        return fail(VF_ERR_NOT_SPD, "vf_engine_ingest_tail: a preintegrated covariance was not positive definite");
+    }
+    return VF_OK;
+}
+
 int vf_engine_get_imu(vf_engine* e, int window, int k0, int n, double* rec) {
     DeviceGuard dev_guard_(e);
     int rc = check_range(e, window, k0, n);
@@ -620,9 +714,18 @@ int vf_engine_iterate(vf_engine* e, int iterations) {
         e->graph_iters = iterations;
         e->graph_epoch = e->epoch;
         e->graph_mode = mode;
+        e->graph_captures++;
     }
     HIPCHK(hipGraphLaunch(e->graph_exec, e->stream));
+    e->graph_replays++;
     mark_solved(e);
+    return VF_OK;
+}
+int vf_engine_graph_info(vf_engine* e, int* enabled, int* captures, long* replays) {
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (enabled) *enabled = (!e->graph_off && e->own_stream) ? 1 : 0;
+    if (captures) *captures = e->graph_captures;
+    if (replays) *replays = e->graph_replays;
     return VF_OK;
 }
 

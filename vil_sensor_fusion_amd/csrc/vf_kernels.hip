@@ -123,16 +123,38 @@ VF_DI void white9(const double (&R)[45], const double (&u)[9], double (&o)[9]) {
 // scratch arrays: 2-4 ms whatever the batch, i.e. most of a GraphManager::solve, which preintegrates one factor.)
 // Every entry is accumulated in the same order as a plain triple loop would, so the result does not depend on
 // the mapping.
-__global__ void __launch_bounds__(256) k_preintegrate(View v, long g0, int n, const int* __restrict__ off,
-                                                     const double* __restrict__ steps,
-                                                     const double* __restrict__ bhat6, ImuCov prm, int* status) {
+// TAIL = false: factors [g0, g0 + n) of consecutive slots, bias estimates handed in (vf_engine_preintegrate).
+// TAIL = true (vf_engine_ingest_tail, the ingest half of a fixed-lag update for ALL windows in one launch): block w
+// preintegrates the factor that ends at window w's NEXT keyframe, slot hi[w], with the window's CURRENT bias estimate -- the
+// bias of its last keyframe in the current buffer, what GraphManager::reserveNode passes as getBias()
+// (GraphManager.cpp:59) -- and stages the between record that ends at the same keyframe (GraphManager.cpp:83-88).
+template <bool TAIL>
+__global__ void __launch_bounds__(256) k_preintegrate_t(View v, long g0, int n, const int* __restrict__ off,
+                                                       const double* __restrict__ steps,
+                                                       const double* __restrict__ bhat6, const int* __restrict__ tail_a,
+                                                       const double* __restrict__ tail_btw, ImuCov prm, int* status) {
     const int f = blockIdx.x, tid = threadIdx.x;
     if (f >= n) return;
     __shared__ double sF[225], sP[225], sT[225], sH[54], sHn[54];
     __shared__ int s_ok;
     const int i = tid / 15, j = tid - i * 15;          // entry of the 15x15 matrices (tid < 225)
     const int hi_ = tid / 6, hj = tid - hi_ * 6;       // entry of the 9x6 bias Jacobian (tid < 54)
-    const double* bh = bhat6 + (size_t)f * 6;
+    long gk = g0 + f;
+    double bh[6];
+    if (TAIL) {
+        const int hi_w = v.hi[f];
+        if (hi_w >= v.M || hi_w <= v.lo[f]) {          // no free slot / empty window: reported, nothing written
+            if (tid == 0) atomicOr(status, 2);
+            return;
+        }
+        gk = (long)f * v.M + hi_w;
+        const int b = v.sel[f];
+#pragma unroll
+        for (int c = 0; c < 6; c++) bh[c] = XS(b, 10 + c, gk - 1);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 6; c++) bh[c] = bhat6[(size_t)f * 6 + c];
+    }
     const V3 bacc = v3(bh[0], bh[1], bh[2]), bgyr = v3(bh[3], bh[4], bh[5]);
     V3 th = v3(0, 0, 0), pos = v3(0, 0, 0), vel = v3(0, 0, 0);
     double dtij = 0.0;
@@ -232,15 +254,19 @@ __global__ void __launch_bounds__(256) k_preintegrate(View v, long g0, int n, co
         }
     }
     __syncthreads();
-    const long gk = g0 + f;
     double* out = v.imu_in + (size_t)(gk >> 6) * IMU_IN * TILE + (gk & 63);
+    if (TAIL) {
+        if (tid >= 224 && tid < 224 + BTW_IN)
+            v.btw_in[((size_t)(gk >> 6) * BTW_IN + (tid - 224)) * TILE + (gk & 63)] = tail_btw[(size_t)f * BTW_IN + tid - 224];
+        if (tid == 255) v.btw_a[gk] = tail_a[f];
+    }
     if (tid < IMU_IN) {
         double x;
         if (tid == 0) x = dtij;
         else if (tid < 4) x = tid == 1 ? th.x : (tid == 2 ? th.y : th.z);
         else if (tid < 7) x = tid == 4 ? pos.x : (tid == 5 ? pos.y : pos.z);
         else if (tid < 10) x = tid == 7 ? vel.x : (tid == 8 ? vel.y : vel.z);
-        else if (tid < 16) x = bh[tid - 10];
+        else if (tid < 16) x = tid == 10 ? bh[0] : (tid == 11 ? bh[1] : (tid == 12 ? bh[2] : (tid == 13 ? bh[3] : (tid == 14 ? bh[4] : bh[5]))));
         else if (tid < 70) x = sH[tid - 16];
         else {                                                  // packed upper triangle, row-major
             int o = tid - 70, r = 0;
@@ -2613,7 +2639,13 @@ static inline unsigned nblk(long n, int bs) { return (unsigned)((n + bs - 1) / b
 
 void launch_preintegrate(const View& v, long g0, int n, const int* off, const double* steps, const double* bhat6,
                          const ImuCov& prm, int* status, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_preintegrate, dim3(n), dim3(256), 0, s, v, g0, n, off, steps, bhat6, prm, status);
+    if (n > 0) hipLaunchKernelGGL(k_preintegrate_t<false>, dim3(n), dim3(256), 0, s, v, g0, n, off, steps, bhat6,
+                                  (const int*)nullptr, (const double*)nullptr, prm, status);
+}
+void launch_ingest_tail(const View& v, const int* off, const double* steps, const int* tail_a, const double* tail_btw,
+                        const ImuCov& prm, int* status, hipStream_t s) {
+    hipLaunchKernelGGL(k_preintegrate_t<true>, dim3(v.B), dim3(256), 0, s, v, 0L, v.B, off, steps, (const double*)nullptr, tail_a,
+                       tail_btw, prm, status);
 }
 void launch_linearize_all(const View& v, int which, hipStream_t s) {
     const int nb_imu = (int)nblk(v.G, VF_K1_BLOCK), nb_btw = nb_imu, nb_pri = (int)nblk(v.B, VF_K1_BLOCK);

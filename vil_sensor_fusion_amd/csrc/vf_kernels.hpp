@@ -173,6 +173,10 @@ struct View {
 struct ImuCov { double acc, gyro, integration, bias_acc, bias_omega, bias_int; };
 void launch_preintegrate(const View& v, long g0, int n, const int* off, const double* steps, const double* bhat6,
                          const ImuCov& prm, int* status, hipStream_t s);
+// the ingest half of a fixed-lag update, all windows in one launch: K0 of the factor ending at slot hi[w] with the window's
+// current bias estimate + the between record ending there (off: [B + 1] step offsets, tail_a: [B], tail_btw: [B][28])
+void launch_ingest_tail(const View& v, const int* off, const double* steps, const int* tail_a, const double* tail_btw,
+                        const ImuCov& prm, int* status, hipStream_t s);
 void launch_linearize_imu(const View& v, int which, hipStream_t s);
 void launch_linearize_between(const View& v, int which, hipStream_t s);
 void launch_linearize_prior(const View& v, int which, hipStream_t s);

@@ -122,6 +122,25 @@ class Engine:
                             imu_cov["bias_omega"], imu_cov["bias_acc_omega_int"])
         check(self._l.vf_engine_preintegrate(self._h, window, k0, n, _i(off), _d(st), _d(bh), C.byref(p)))
 
+    def ingest_tail(self, step_off, steps, imu_cov, btw_a, btw_rec):
+        """the ingest half of a fixed-lag update for all windows (vf_engine_ingest_tail): window w's next IMU factor from its
+        raw samples steps[step_off[w]:step_off[w+1]], preintegrated with the window's current bias estimate, + the between
+        record ending at the new keyframe (btw_a[w] = source slot or -1).  Asynchronous."""
+        off = np.ascontiguousarray(step_off, dtype=np.int32)
+        st = np.ascontiguousarray(steps, dtype=np.float64).reshape(-1, 7)
+        a = np.ascontiguousarray(btw_a, dtype=np.int32)
+        r = np.ascontiguousarray(btw_rec, dtype=np.float64).reshape(-1, BTW_RECORD)
+        assert off.size == self.windows + 1 and a.size == self.windows and r.shape[0] == self.windows
+        p = _lib.ImuParamsC(imu_cov["acc"], imu_cov["gyro"], imu_cov["integration"], imu_cov["bias_acc"],
+                            imu_cov["bias_omega"], imu_cov["bias_acc_omega_int"])
+        check(self._l.vf_engine_ingest_tail(self._h, _i(off), _d(st), C.byref(p), _i(a), _d(r)))
+
+    def ingest_status(self):
+        """waits for the last ingest_tail, raises what its kernel reported, returns (h2d_ms, k0_ms) of that call"""
+        h, k = C.c_float(), C.c_float()
+        check(self._l.vf_engine_ingest_status(self._h, C.byref(h), C.byref(k)))
+        return h.value, k.value
+
     def get_imu(self, window, k0, n):
         r = np.zeros((n, IMU_RECORD))
         check(self._l.vf_engine_get_imu(self._h, window, k0, n, _d(r)))
@@ -189,6 +208,12 @@ class Engine:
 
     def sync(self):
         check(self._l.vf_engine_sync(self._h))
+
+    def graph_info(self):
+        """use_hip_graph: (replay active, captures of the launch sequence, iterate calls served by hipGraphLaunch)"""
+        en, cap, rep = C.c_int(), C.c_int(), C.c_long()
+        check(self._l.vf_engine_graph_info(self._h, C.byref(en), C.byref(cap), C.byref(rep)))
+        return bool(en.value), cap.value, rep.value
 
     # ---- time-sharded windows (see include/vilfusion.h; the collectives live in distributed.ShardedSolver)
     def set_stream(self, hip_stream):

@@ -99,7 +99,7 @@ def updates_per_engine(args):
     return (args.steps + args.warmup) * (1 if args.no_convergence_exit else 2)
 
 
-def make_engine(args, local_rank, windows, seqs, updates, all_resident=False):
+def make_engine(args, local_rank, windows, seqs, updates, all_resident=False, **engine_opts):
     """Synthetic Carla-like factors for `windows` windows.  Only the FIRST window's factors are made resident here (K0 on
     the device, bias estimate 0: GraphManager's bias before the first solve); the factors of the keyframes the updates
     append stay on the host as what a driver receives per keyframe -- raw IMU samples + the between record -- and go in
@@ -109,7 +109,7 @@ def make_engine(args, local_rank, windows, seqs, updates, all_resident=False):
     from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
     n, total = args.window, args.window + updates + 1
     assert all(s.n >= total for s in seqs), "sequence shorter than the keyframes the run appends"
-    eng = Engine(EngineOpts(windows=windows, capacity=total, device=local_rank))
+    eng = Engine(EngineOpts(windows=windows, capacity=total, device=local_rank, **engine_opts))
     nseq = len(seqs)
     recs = [synth.between_records(s) for s in seqs]
     for w in range(windows):
@@ -347,14 +347,16 @@ def degeneracy_section():
     T2 = 1 << 22
     big = np.ascontiguousarray(np.tile(mats[:, :, :1 << 16], (1, 1, T2 >> 16)))
     roof = {"matrices": T2, "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "kernels": {}}
-    for name in ("d_opt", "e_opt"):
+    for name in ("d_opt", "e_opt", "condition_number"):
         for dt, tag, nbytes in ((np.float64, "f64", 296), (np.float32, "f32", 148)):
             _, ms = dg.apply_degen_function(big, None, "all", name, dtype=dt, reps=5)
             ach = T2 * nbytes / (ms * 1e-3) / 1e9
             roof["kernels"][f"{name}/{tag}"] = {"avg_launch_ms": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBPS,
                                                 "algorithmic_bytes_per_matrix": nbytes, "ns_per_matrix": ms * 1e6 / T2}
-    roof["note"] = ("d_opt (pivoted LU in registers) is the metric the shipped gate uses; e_opt (cyclic Jacobi, ~10 sweeps) is "
-                    "compute-bound, its fraction is quoted for completeness")
+    roof["note"] = ("d_opt (pivoted LU in registers) is the metric the shipped gate uses and is HBM-bound.  e_opt / condition_number "
+                    "(cyclic Jacobi on the upper triangle, rsq / rcp rotations, wave-wide convergence vote: 5-7 sweeps) are bound by "
+                    "float64 VALU issue, not HBM: their HBM fraction is quoted for completeness, the float64 operation counts per "
+                    "launch (SQ_INSTS_VALU_*_F64) and the fraction of the 78.6 TFLOP/s vector peak are in profiles/r04_k6_pmc.md")
     out["roofline_k6"] = roof
     return out
 
@@ -730,6 +732,23 @@ def main():
             out["single_window"] = {"ms_per_update": lat * 1e3, "keyframes_per_s": 1.0 / lat,
                                     "solve_ms": one.time_stage("solve", reps=5)}
             one.close()
+            # the same with vf_engine_opts.use_hip_graph (the launch sequence of iterate replayed from a captured hipGraph;
+            # bit-identical, tests/test_gpu_hip_graph.py): what replay does to the one-window latency
+            try:
+                g1, g1_feed = make_engine(sv, gpu, 1, one_seq, one_updates, use_hip_graph=True)
+                for _ in range(2):
+                    one_step(g1, g1_feed)
+                g1.sync()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    one_step(g1, g1_feed)
+                g1.sync()
+                en, cap, rep = g1.graph_info()
+                out["single_window"]["with_hip_graph"] = {"ms_per_update": (time.perf_counter() - t1) / 5 * 1e3, "replay_active": en,
+                                                          "captures": cap, "replays": rep}
+                g1.close()
+            except Exception as exc:   # noqa: BLE001
+                out["single_window"]["with_hip_graph"] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_degeneracy and info.world == 1:
             out["degeneracy_k6"] = degeneracy_section()
         if not args.no_graph_manager and info.world == 1:

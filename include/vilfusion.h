@@ -87,6 +87,10 @@ typedef struct {
                                 minModelFidelity (1e-3), which this library does not evaluate.  Where the optimum is does not
                                 depend on either rule: tests/test_gpu_vs_qr_twin.py holds the result to an independent QR
                                 optimiser that uses the gain-ratio test. */
+    int solve_split_min;     /* whole-window sweeps (one wave per window): from this many windows on, the forward sweep and the
+                                back substitution run as two kernels (same arithmetic, same bits): the back substitution needs
+                                9 KB of LDS instead of 38 and runs several waves per SIMD.  Pays once the batch is a multiple
+                                of the 1024 SIMDs of the part.  Default 2048; 0 = never. */
 } vf_engine_opts;
 
 void vf_engine_default_opts(vf_engine_opts* o);

@@ -201,6 +201,7 @@ void vf_engine_default_opts(vf_engine_opts* o) {
     o->cold_start = 0;
     o->use_hip_graph = 0;
     o->accept_rel = 1e-9;
+    o->solve_split_min = 2048;
 }
 
 int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
@@ -224,6 +225,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     for (int i = 0; i < 3; i++) v.grav[i] = o->gravity[i];
     v.lam_up = o->lambda_up; v.lam_down = o->lambda_down; v.lam_min = o->lambda_min; v.lam_max = o->lambda_max;
     v.accept_rel = o->accept_rel;
+    v.split_min = o->solve_split_min > 0 ? o->solve_split_min : 0;
     HIPCHK(hipStreamCreate(&e->stream));
     HIPCHK(hipEventCreate(&e->ev0));
     HIPCHK(hipEventCreate(&e->ev1));

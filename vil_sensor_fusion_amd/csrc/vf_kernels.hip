@@ -1115,6 +1115,17 @@ VF_DI double readlane_d(double x, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// lanes 0..15 of x copied into the other three 16-lane rows: two VALU lane swaps per 32-bit half (gfx950's
+// v_permlane16_swap: rows 1, 3 of the first operand <-> rows 0, 2 of the second; v_permlane32_swap: upper half <-> lower half)
+VF_DI double rep_row0(double x) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const auto c = __builtin_amdgcn_permlane32_swap(a[0], a[0], false, false);
+    const auto d = __builtin_amdgcn_permlane32_swap(b[0], b[0], false, false);
+    return __hiloint2double((int)d[0], (int)c[0]);
+}
+
 // One wavefront per window.  Right-looking block Cholesky of the block-banded normal matrix,
 // exploiting its profile: IMU factors couple consecutive keyframes in all 15 dof, between
 // factors couple keyframes up to 3 apart in the 6 pose dof only, so the active set while
@@ -1165,6 +1176,24 @@ constexpr int S_P = S_ID + 225;          // panel rows 15..42 at stride 15 (conf
 constexpr int S_DL = S_P + 43 * 15;      // back-substitution: delta of the 3 following keyframes
 constexpr int S_BC = S_DL + 64;          // 16: pivot-block entries of the column just scaled, read back replicated per 16-lane row
 constexpr int S_TOTAL = S_BC + 16;
+// Compact trailing window of the SPLIT forward sweep (SOLVE_FULL_FWD, k_band_forward): 20.2 KB of LDS per wave instead of 38.3,
+// i.e. EIGHT one-wave workgroups per CU = two resident waves per SIMD (the kernel's 252 registers allow that too).
+// The 60 x 61 window above keeps every (row slot, column slot) pair of its four circular keyframe slots, although only
+// the lower block triangle within the profile [k: 15][k+1: 15][k+2: pose][k+3: pose] is ever live.  Here a block is filed
+// under the slot of its ROW keyframe and its DISTANCE e to the column keyframe -- both stay the same while the sweep
+// moves on (row and column keyframe age together), so nothing is ever copied or promoted:
+//     e = 0: lower triangle, 120      e = 1: 15 x 15      e = 2: 6 x 15 (pose rows; fill-in and the marginal prior's strip)
+//     e = 3: 6 x 6 (pose x pose; a panel row of that block is read 15 wide and its columns 6..14 are masked to zero)
+// the identity rows of the panel come from a 29-cell strip (0 x 14, 1, 0 x 14) read at a per-lane offset.
+constexpr int CW_D0 = 0, CW_D1 = 120, CW_D2 = CW_D1 + 225, CW_D3 = CW_D2 + 90, CW_SLOT = CW_D3 + 36;
+constexpr int CW_GD = 4 * CW_SLOT;           // rhs, circular (4 x 15, padded to 64)
+constexpr int CW_DUMP = CW_GD + 64;
+constexpr int CW_ZERO = CW_DUMP + 96;
+constexpr int CW_ID = CW_ZERO + 16;          // identity strip: cell 14 = 1
+constexpr int CW_P = CW_ID + 30;             // panel rows 15..42 at stride 15 (MFMA operands)
+constexpr int CW_BC = CW_P + 28 * 15;
+constexpr int CW_TOTAL = CW_BC + 16;
+static_assert(CW_TOTAL * 8 <= 20480, "eight compact forward sweeps per CU (160 KB of LDS)");
 // chunk forward sweep with a spike follower (k_chunk_forward): the panel of step k (43 rows x 15, then a
 // zero cell and a write sink) stays in a 4-slot LDS ring for the second wave; two hand-shake cells follow
 constexpr int RING_SLOT = 664;
@@ -1172,6 +1201,9 @@ constexpr int S_PROG = S_P + 4 * RING_SLOT;   // panels completed by the sweep
 constexpr int S_CONS = S_PROG + 1;            // panels consumed by the follower
 constexpr int S_BC_RING = S_PROG + 8;
 constexpr int S_TOTAL_RING = S_BC_RING + 16;
+#ifndef VF_PIVOT_PERMLANE
+#define VF_PIVOT_PERMLANE 0      // 1: the scaled pivot column is replicated over the 16-lane rows by VALU lane swaps instead of through LDS
+#endif
 #define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define VF_SB() __builtin_amdgcn_sched_barrier(0)
 #ifdef VF_SOLVE_STAMPS   // diagnostic build only (tools/build_stamps.sh); never in the shipped library
@@ -1200,13 +1232,20 @@ constexpr int MID_TOTAL = 45 * MID_LD + 48;     // + the 45 solved increments ha
 //   45x45 block (+ rhs) of the 3 separator keyframes that follow in `sep_out`; couplings to
 //   keyframes in front of the chunk (the left separator) are dropped here and carried by the spike
 //   kernel.  The backward sweep starts from the separator increments already in v.delta.
-enum { SOLVE_FULL = 0, SOLVE_TWISTED = 1, SOLVE_CHUNK_FWD = 2, SOLVE_CHUNK_BWD = 3 };
+// MODE 4 / 5 (split sweep, batches of >= View::split_min windows): the forward sweep and the back substitution of SOLVE_FULL
+//   as two kernels.  They hand over through HBM only (the panels and the rhs row the forward sweep stores anyway); the
+//   back substitution needs 9 KB of LDS instead of 38 and so runs two and more waves per SIMD where the fused kernel
+//   is held to one by the forward sweep's trailing window.
+enum { SOLVE_FULL = 0, SOLVE_TWISTED = 1, SOLVE_CHUNK_FWD = 2, SOLVE_CHUNK_BWD = 3, SOLVE_FULL_FWD = 4, SOLVE_FULL_BWD = 5 };
 template <int MODE>
 __device__ __forceinline__ void band_solve_body(const View& v, double* __restrict__ S, double* __restrict__ S_other,
                                                 double* __restrict__ MID, const int w, const int lane, const int wave,
                                                 const ChunkGeom cg = ChunkGeom{0, 0, 0}, double* __restrict__ sep_out = nullptr) {
     constexpr bool TW = MODE == SOLVE_TWISTED;
     constexpr bool CH = MODE == SOLVE_CHUNK_FWD || MODE == SOLVE_CHUNK_BWD;
+    constexpr bool CW = MODE == SOLVE_FULL_FWD;          // compact trailing window ("CW_" map above); the names below shadow the full map
+    constexpr int S_GD = CW ? CW_GD : vf::S_GD, S_DUMP = CW ? CW_DUMP : vf::S_DUMP, S_ZERO = CW ? CW_ZERO : vf::S_ZERO;
+    constexpr int S_ID = CW ? CW_ID : vf::S_ID, S_P = CW ? CW_P : vf::S_P, S_BC = CW ? CW_BC : vf::S_BC;
     const int lo = v.lo[w], hi = v.hi[w];
     const int n = CH ? cg.ni + (cg.has_sep ? 3 : 0) : hi - lo;     // real rows of this sweep
     const double lam = v.lambda[w];
@@ -1232,13 +1271,19 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 
     // ---- per-lane constants.  Every LDS access below is branch-free: masked-off lanes read the
     // zero cells / write the sink, so no exec-mask juggling (and no SGPR spills) in the k loop.
-    for (int e = lane; e < 16 + 225; e += 64) S[S_ZERO + e] = (e >= 16 && (e - 16) % 16 == 0) ? 1.0 : 0.0;
+    if constexpr (CW) { if (lane < 46) S[S_ZERO + lane] = lane == 16 + 14 ? 1.0 : 0.0; }     // 16 zeros, then the identity strip
+    else for (int e = lane; e < 16 + 225; e += 64) S[S_ZERO + e] = (e >= 16 && (e - 16) % 16 == 0) ? 1.0 : 0.0;
     const int pd = lane < 15 ? 0 : (lane < 30 ? 1 : (lane < 36 ? 2 : 3));
     const int pa = lane < 15 ? lane : (lane < 30 ? lane - 15 : (lane < 36 ? lane - 30 : lane - 36));
     int ri_ph[4];   // LDS offset of (this lane's panel row, column 0 of the pivot slot) per phase
 #pragma unroll
     for (int ph = 0; ph < 4; ph++) {
         const int s0 = ph * 15;
+        if constexpr (CW) {
+            const int blk = pd == 0 ? CW_D0 + h_tri(pa, 0) : (pd == 1 ? CW_D1 + pa * 15 : (pd == 2 ? CW_D2 + pa * 15 : CW_D3 + pa * 6));
+            ri_ph[ph] = lane < 42 ? ((ph + pd) & 3) * CW_SLOT + blk
+                      : (lane == 42 ? S_GD + s0 : (lane < 58 ? S_ID + 14 - (lane - 43) : S_ZERO));
+        } else
         ri_ph[ph] = lane < 42 ? S_WD + ((((ph + pd) & 3) * 15) + pa) * LDW + s0
                   : (lane == 42 ? S_GD + s0 : (lane < 58 ? S_ID + (lane - 43) * 15 : S_ZERO));
     }
@@ -1265,6 +1310,11 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #pragma unroll
         for (int ph = 0; ph < 4; ph++) {
             const int cj = (((ph + cs) & 3) * 15) + ca;
+            if constexpr (CW) {
+                const int e = rs - cs;   // 0, 1, 2 (rows k+1 .. k+3 against columns k+1 .. k+3)
+                const int blk = e == 0 ? CW_D0 + h_tri(ra, ca) : (e == 1 ? CW_D1 + ra * 15 + ca : CW_D2 + ra * 15 + ca);
+                tgt_ph[ph][q] = !valid ? S_DUMP + 32 + lane : (i == 27 ? S_GD + cj : ((ph + rs) & 3) * CW_SLOT + blk);
+            } else
             tgt_ph[ph][q] = !valid ? S_DUMP + 32 + lane
                                    : (i == 27 ? S_GD + cj : S_WD + ((((ph + rs) & 3) * 15) + ra) * LDW + cj);
         }
@@ -1404,6 +1454,22 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         if constexpr (CH) {
             if ((cg.i0 > 0 && kk <= 4) || (cg.has_sep && kk > cg.ni && kk <= cg.ni + 2)) r = mask_boundary_row(r_in, kk);
         }
+        if constexpr (CW) {
+            // the words of a block row land in their blocks in the order they were loaded: no per-lane maps
+            constexpr int base = PH * CW_SLOT;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const double d0 = r.h0[j] + (kind == 0 ? t0_lam[j] : (kind == 1 ? t0_one[j] : 0.0));
+                S[lane + 64 * j < 120 ? base + CW_D0 + lane + 64 * j : S_DUMP + 32 + lane] = d0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) S[lane + 64 * j < 225 ? base + CW_D1 + lane + 64 * j : S_DUMP + 32 + lane] = r.h1[j];
+            S[lane < 36 ? base + CW_D2 + (lane / 6) * 15 + lane % 6 : S_DUMP + 32 + lane] = r.h2;
+            S[lane < 54 ? base + CW_D2 + (lane / 9) * 15 + 6 + lane % 9 : S_DUMP + 32 + lane] = r.hx;
+            S[lane < 36 ? base + CW_D3 + lane : S_DUMP + 32 + lane] = r.h3;
+            S[lane < 15 ? S_GD + s + lane : S_DUMP + 32 + lane] = -r.hg;
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const double d0 = r.h0[j] + (kind == 0 ? t0_lam[j] : (kind == 1 ? t0_one[j] : 0.0));
@@ -1428,7 +1494,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #ifdef VF_SOLVE_STAMPS
     unsigned long long st[16] = {0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
-    if constexpr (MODE != SOLVE_CHUNK_BWD) {
+    if constexpr (MODE != SOLVE_CHUNK_BWD && MODE != SOLVE_FULL_BWD) {
     commit_row(IC<0>{}, fetch_row(0), row_kind(0), 0);
     commit_row(IC<1>{}, fetch_row(1), row_kind(1), 1);
     commit_row(IC<2>{}, fetch_row(2), row_kind(2), 2);
@@ -1442,13 +1508,23 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         double p[15];
 #pragma unroll
         for (int c = 0; c < 15; c++) p[c] = S[ri_ph[PH] + c];
+        if constexpr (CW) {     // rows of keyframe k+3 (lanes 36..41) hold pose columns only: the 6 x 6 block has no columns 6..14
+            const bool narrow = lane >= 36 && lane < 42;
+#pragma unroll
+            for (int c = 6; c < 15; c++) p[c] = narrow ? 0.0 : p[c];
+        }
         STAMP(1);
         // panel factorisation: straight-line code in a fixed issue order (tools/gen_pivot.py); a non-positive
         // pivot turns the last reciprocal into NaN / inf, tested once per step
         double pv_inv;
         const int pv_bcw = lane < 15 ? (RINGM ? S_BC_RING : S_BC) + lane : S_DUMP + 32 + lane;
         const int pv_bcr = (RINGM ? S_BC_RING : S_BC) + (lane & 15);
+#if VF_PIVOT_PERMLANE
+#include "vf_pivot_15p.inc"
+        (void)pv_bcw; (void)pv_bcr;
+#else
 #include "vf_pivot_15.inc"
+#endif
         if (!(pv_inv < 1e300)) failed = 1;
         STAMP(2);
         // sub-panel + rhs -> LDS (MFMA operands); rows 15..57 -> HBM, one 128-B line per lane
@@ -1511,6 +1587,10 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #ifdef VF_K4_FWD_ONLY   // probe build only (tools/build_variant.sh): the forward sweep's share of the un-stamped kernel
     if constexpr (MODE == SOLVE_FULL) return;
 #endif
+    if constexpr (MODE == SOLVE_FULL_FWD) {
+        if (lane == 0) v.fail[w] = failed;
+        return;
+    }
     if constexpr (MODE == SOLVE_CHUNK_FWD) {
         // the cut keyframe and the two after it sit in slots 0..2 (cnt is a multiple of 4): the separator's 27 dof
         // (15 + pose + pose): own H + lambda + Schur terms of this chunk's interior, and rhs, go to sep_out [27][28]
@@ -1603,6 +1683,10 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         WSYNC();
     }
     struct PRow { d2_t x[8]; };
+#ifndef VF_BWD_PD
+#define VF_BWD_PD 4
+#endif
+    constexpr int PD = MODE == SOLVE_FULL_BWD ? VF_BWD_PD : 4;      // panels prefetched ahead of the recursion
     // Backward sweep: lane r < 28 holds panel row r (sub-diagonal rows and the rhs row: they go through LDS); the rows of
     // L^-T sit in lanes XL .. XL+14 of ONE 16-lane row, where s and x are formed as well, so that both matrix-vector
     // products of the recursion broadcast their vector with DPP row_newbcast inside v_fmac_f64 (one instruction per term
@@ -1648,7 +1732,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #pragma unroll
         for (int c = 0; c < 7; c++) { o.row[2 * c] = keep * slot.x[c].x; o.row[2 * c + 1] = keep * slot.x[c].y; }
         o.row[14] = keep * slot.x[7].x;
-        slot = load_panel(k - 4);    // four steps ahead, into the slot just consumed (slot = k & 3: no register rotation)
+        slot = load_panel(k - PD);   // PD steps ahead, into the slot just consumed (slot = k & (PD - 1): no register rotation)
 #pragma unroll
         for (int c = 0; c < 15; c++) S[bw_off + c] = o.row[c];
         CBAR();
@@ -1704,10 +1788,30 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         STAMP(10);
     };
     {
-        PRow p3 = load_panel(n4 - 1), p2 = load_panel(n4 - 2), p1 = load_panel(n4 - 3), p0 = load_panel(n4 - 4);
+        // (split back substitution: two waves per SIMD hide the HBM round trip between them; two panels in flight instead
+        // of four keep the kernel inside the 256 registers that takes)
+        PRow p3 = load_panel(n4 - 1), p2 = load_panel(n4 - 2), p1s, p0s;
+        if constexpr (PD == 4) { p1s = load_panel(n4 - 3); p0s = load_panel(n4 - 4); }
+        PRow& p1 = PD == 4 ? p1s : p3;
+        PRow& p0 = PD == 4 ? p0s : p2;
         // increment of the keyframe after the last pivot (slot n4 & 3 = 0): zero, or the separator's / the middle system's
         double xprev = S[xl_lane ? S_DL + lane - XL : S_ZERO];
         Col ca, cb;
+        if constexpr (MODE == SOLVE_FULL_BWD) {
+            // two waves per SIMD: the partner wave covers this one's LDS round trips, so the recursion is not software-
+            // pipelined here -- one set of column registers instead of two keeps the kernel inside 256 registers
+#pragma unroll 1
+            for (int k = n4 - 1; k >= 3; k -= 4) {
+                prep(IC<3>{}, k, p3, ca);
+                solve(IC<3>{}, k, ca, xprev);
+                prep(IC<2>{}, k - 1, p2, ca);
+                solve(IC<2>{}, k - 1, ca, xprev);
+                prep(IC<1>{}, k - 2, p1, ca);
+                solve(IC<1>{}, k - 2, ca, xprev);
+                prep(IC<0>{}, k - 3, p0, ca);
+                solve(IC<0>{}, k - 3, ca, xprev);
+            }
+        } else {
         prep(IC<3>{}, n4 - 1, p3, ca);
 #pragma unroll 1
         for (int k = n4 - 1; k >= 3; k -= 4) {
@@ -1720,13 +1824,14 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             prep(IC<3>{}, k - 4, p3, ca);
             solve(IC<0>{}, k - 3, cb, xprev);
         }
+        }
     }
 #undef CBAR
 #ifdef VF_SOLVE_STAMPS
     if (w == 0 && lane == 0) for (int i = 0; i < 16; i++) g_stamps[i] = st[i];
 #endif
     if constexpr (MODE == SOLVE_FULL) { if (lane == 0) v.fail[w] = failed; }
-    else { if (lane == 0 && failed) atomicOr(v.fail + w, 1); }
+    else if constexpr (MODE != SOLVE_FULL_BWD) { if (lane == 0 && failed) atomicOr(v.fail + w, 1); }
 }
 
 __global__ void __launch_bounds__(64) k_band_solve(View v) {
@@ -1734,6 +1839,23 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
     if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
     __shared__ double S[S_TOTAL];
     band_solve_body<SOLVE_FULL>(v, S, nullptr, nullptr, w, threadIdx.x, 0);
+}
+
+// the split form (see SOLVE_FULL_FWD / SOLVE_FULL_BWD)
+__attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(64) k_band_forward(View v) {
+    const int w = blockIdx.x;
+    if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
+    __shared__ double S[CW_TOTAL];
+    band_solve_body<SOLVE_FULL_FWD>(v, S, nullptr, nullptr, w, threadIdx.x, 0);
+}
+__attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(64) k_band_backward(View v) {
+    const int w = blockIdx.x;
+    if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
+    // the back substitution touches nothing of the trailing window [0, S_GD + 64): its LDS starts at the write sink
+    __shared__ double Sb[S_TOTAL - S_DUMP];
+    band_solve_body<SOLVE_FULL_BWD>(v, Sb - S_DUMP, nullptr, nullptr, w, threadIdx.x, 0);
 }
 
 // two waves per window (see band_solve_body); windows shorter than 32 keyframes are left to wave 0 alone
@@ -2710,7 +2832,10 @@ void launch_band_solve(const View& v, hipStream_t s) {
     if (v.P >= 2) { launch_partitioned_solve(v, s); return; }
     // few windows: two waves per window from both ends (latency); many: one wave per window (throughput)
     if (v.B <= v.tw_max) hipLaunchKernelGGL(k_band_solve_tw, dim3(v.B), dim3(128), 0, s, v);
-    else hipLaunchKernelGGL(k_band_solve, dim3(v.B), dim3(64), 0, s, v);
+    else if (v.split_min > 0 && v.B >= v.split_min) {
+        hipLaunchKernelGGL(k_band_forward, dim3(v.B), dim3(64), 0, s, v);
+        hipLaunchKernelGGL(k_band_backward, dim3(v.B), dim3(64), 0, s, v);
+    } else hipLaunchKernelGGL(k_band_solve, dim3(v.B), dim3(64), 0, s, v);
 }
 // windows of the running solve that still take LM trials (termination rule on)
 __global__ void __launch_bounds__(1024) k_count_active(View v) {
@@ -2730,7 +2855,10 @@ void launch_band_solve_hybrid(const View& v, const View& vp, hipStream_t s) {
     View a = v, b = vp;
     a.gate = 1;
     b.gate = 2;
-    hipLaunchKernelGGL(k_band_solve, dim3(a.B), dim3(64), 0, s, a);
+    if (a.split_min > 0 && a.B >= a.split_min) {
+        hipLaunchKernelGGL(k_band_forward, dim3(a.B), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_band_backward, dim3(a.B), dim3(64), 0, s, a);
+    } else hipLaunchKernelGGL(k_band_solve, dim3(a.B), dim3(64), 0, s, a);
     launch_partitioned_solve(b, s);
 }
 void launch_retract(const View& v, hipStream_t s) {

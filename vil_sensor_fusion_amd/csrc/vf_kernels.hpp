@@ -167,6 +167,7 @@ struct View {
     int* n_active;      // [1]  windows of the current solve that still take trials (k_count_active)
     int gate, gate_T;
     int tw_max;         // whole-window sweeps: up to this many windows two waves per window from both ends, above one wave per window
+    int split_min;      // whole-window sweeps: from this many windows on, forward sweep and back substitution as two kernels (0 = never)
 };
 
 // isotropic IMU covariances (ImuManagerRos.cpp:20-33)

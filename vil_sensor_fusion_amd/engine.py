@@ -45,6 +45,7 @@ class EngineOpts:
     cold_start: bool = False
     use_hip_graph: bool = False
     accept_rel: float | None = None      # LM accept tolerance (None = the library's default 1e-9; 0 = strict decrease)
+    solve_split_min: int | None = None   # one-wave sweeps: from this many windows on, forward sweep / back substitution as two kernels
 
 
 class Engine:
@@ -64,6 +65,8 @@ class Engine:
         o.cold_start, o.use_hip_graph = int(opts.cold_start), int(opts.use_hip_graph)
         if opts.accept_rel is not None:
             o.accept_rel = opts.accept_rel
+        if opts.solve_split_min is not None:
+            o.solve_split_min = opts.solve_split_min
         self._h = C.c_void_p()
         check(self._l.vf_engine_create(C.byref(o), C.byref(self._h)))
         self.opts = opts

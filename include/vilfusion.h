@@ -41,6 +41,7 @@ extern "C" {
 #define VF_BTW_RECORD 28
 #define VF_PRIOR_RECORD 31
 #define VF_MAX_BANDWIDTH 3
+#define VF_MAX_EXTRA 8            /* "far" between factors per window (vf_engine_set_extra_between) */
 
 const char* vf_last_error(void);
 const char* vf_version(void);
@@ -109,6 +110,16 @@ int vf_engine_set_imu(vf_engine* e, int window, int k0, int n, const double* rec
 int vf_engine_set_between(vf_engine* e, int window, int n, const int32_t* a, const int32_t* b,
                           const double* rec28);
 int vf_engine_clear_between(vf_engine* e, int window, int k0, int n);
+/* "Far" between factors: BetweenFactor<Pose3> on ANY pair of keyframes a < b of a window -- wider than the band
+ * (b - a > bandwidth), or a second factor ending at a keyframe that already has one (a loop closure).  iSAM2 takes any
+ * pair of keys (GraphManager.cpp:83-88); the banded device solver keeps such factors out of H and applies them as a
+ * low-rank correction: g gets their J^T r, and every LM trial solves (H_band + lambda I + U U^T) delta = -g by Woodbury
+ * -- the band solver once more per column of U (6 per factor) and one small dense system per window.  A FALLBACK for
+ * the rare window with such factors, several times slower than a band-only window; at most VF_MAX_EXTRA per window.
+ * The call REPLACES the window's list (n = 0 clears it); records as for vf_engine_set_between.  A factor whose older
+ * keyframe leaves the window (slide / drop_oldest / marginalize) stops contributing: its information is dropped, not
+ * marginalised.  Engines holding far factors start every solve cold.  Not for time-sharded engines. */
+int vf_engine_set_extra_between(vf_engine* e, int window, int n, const int32_t* a, const int32_t* b, const double* rec28);
 /* the three priors of GraphManager.cpp:27-35 as one diagonal 15-row factor on keyframe k */
 int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec31);
 

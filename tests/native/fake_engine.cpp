@@ -30,7 +30,7 @@ int vf_engine_preintegrate(vf_engine*, int, int, int, const int32_t*, const doub
 int vf_engine_predict(vf_engine*, int, int, int) { return VF_OK; }
 int vf_engine_predict_from_estimate(vf_engine*, int, int, int) { return VF_OK; }
 int vf_engine_set_between(vf_engine*, int, int, const int32_t*, const int32_t*, const double*) { return VF_OK; }
-int vf_engine_set_wide_between(vf_engine*, int, int, const int32_t*, const int32_t*, const double*) { return VF_OK; }
+int vf_engine_set_extra_between(vf_engine*, int, int, const int32_t*, const int32_t*, const double*) { return VF_OK; }
 int vf_engine_marginalize(vf_engine*) { return VF_OK; }
 int vf_engine_drop_oldest(vf_engine*) { return VF_OK; }
 int vf_engine_compact(vf_engine*, int) { return VF_OK; }

@@ -1,0 +1,137 @@
+"""-m gpu: between factors the band cannot hold.  iSAM2 takes a BetweenFactor<Pose3> on any pair of keys
+(GraphManager.cpp:83-88); the device's banded solver holds spans <= 3 and one factor per end key.  Anything else -- a span-6
+factor, a loop closure between keyframes far apart, a second factor ending at a key -- is a "far" factor
+(vf_engine_set_extra_between, routed there by vf_add_between): its J^T r goes into g, its J^T J is applied as a low-rank
+(Woodbury) correction around the band solver.  Checked against the CPU oracle, which assembles a band as wide as the widest
+factor and so treats these factors like any other."""
+import numpy as np
+import pytest
+
+from tests import helpers
+from vil_sensor_fusion_amd import Engine, EngineOpts, VilFusionError, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _far_record(seq, a, b, rng, cov=0.05, noise=(5e-4, 5e-3)):
+    """relative pose of keyframes a -> b from the ground truth + noise, as a 28-double record (isotropic covariance)"""
+    Ra, Rb = synth.quat_to_rot(seq.gt_states[a, :4]), synth.quat_to_rot(seq.gt_states[b, :4])
+    Rab = Ra.T @ Rb @ synth.so3_exp(rng.normal(size=3) * noise[0])
+    tab = Ra.T @ (seq.gt_states[b, 4:7] - seq.gt_states[a, 4:7]) + rng.normal(size=3) * noise[1]
+    rec = np.zeros(28)
+    rec[0:4], rec[4:7] = synth.rot_to_quat(Rab), tab
+    iu = np.triu_indices(6)
+    rec[7 + np.nonzero(iu[0] == iu[1])[0]] = 1.0 / np.sqrt(cov)
+    return rec
+
+
+FAR = [(40, 46), (20, 170), (21, 171)]       # a span-6 factor whose end key 46 also has its band factor; a loop-closure pair
+
+
+@pytest.mark.parametrize("form", ["partitioned", "one_wave_sweep"])
+def test_far_factors_match_the_oracle(oracle, form):
+    n = 200
+    seq = synth.make_sequence(seed=91, n_kf=n)
+    prob = helpers.build_problem(oracle, seq, perturb=0.003)
+    rng = np.random.default_rng(5)
+    far_rec = np.array([_far_record(seq, a, b, rng) for a, b in FAR])
+    fa, fb = np.array([a for a, _ in FAR], dtype=np.int32), np.array([b for _, b in FAR], dtype=np.int32)
+    opts = dict(chunks=1, sweep_two_sided_max=0) if form == "one_wave_sweep" else {}
+    # three windows on one engine: all three far factors, none, the loop-closure pair only
+    eng = Engine(EngineOpts(windows=3, capacity=n, **opts))
+    for w in range(3):
+        helpers.load_engine(eng, w, prob)
+    eng.set_extra_between(0, fa, fb, far_rec)
+    eng.set_extra_between(2, fa[1:], fb[1:], far_rec[1:])
+    eng.iterate(30)
+    outs = []
+    for w, sel in ((0, [0, 1, 2]), (1, []), (2, [1, 2])):
+        p = dict(prob, btw_a=np.concatenate([prob["btw_a"], fa[sel]]).astype(np.int32),
+                 btw_b=np.concatenate([prob["btw_b"], fb[sel]]).astype(np.int32), btw=np.vstack([prob["btw"], far_rec[sel]]))
+        win = helpers.oracle_window(oracle, p)
+        assert win.bandwidth() == (150 if sel else 3)
+        costs, _, _ = win.lm(iterations=30)
+        got = eng.get_states(w, 0, n)
+        a, r = helpers.ate(got, win.states)
+        lm = eng.read_lm(w)
+        print(f"{form}, window {w} ({len(sel)} far factors): ATE vs oracle {a:.3e} m, rot {r:.3e} rad, cost {lm['cost']:.9e} vs {costs[-1]:.9e}")
+        assert a <= 1e-6 and r <= 1e-6 and lm["solve_failures"] == 0
+        assert abs(lm["cost"] - costs[-1]) <= 1e-8 * abs(costs[-1])
+        outs.append(got)
+    # the far factors do change the answer (a loop closure pulls the far end of the window by millimetres)
+    assert helpers.ate(outs[0], outs[1])[0] > 1e-4 and helpers.ate(outs[2], outs[1])[0] > 1e-4
+    # a far factor whose older keyframe has left the window stops contributing: the window [30, n) knows only (40, 46)
+    ref = Engine(EngineOpts(windows=1, capacity=n, **opts))
+    helpers.load_engine(ref, 0, prob)
+    ref.set_extra_between(0, fa[:1], fb[:1], far_rec[:1])
+    for e, w in ((eng, 0), (ref, 0)):
+        e.set_states(w, 0, prob["states"])
+        e.set_prior(w, 30, synth.prior_record(prob["states"][30], np.array([1e-3] * 15)))
+        e.set_range(w, 30, n)
+        e.iterate(8)
+    np.testing.assert_array_equal(eng.get_states(0, 30, n - 30), ref.get_states(0, 30, n - 30))
+    # clearing the list gives the band-only engine back
+    eng.set_extra_between(0, [], [], np.zeros((0, 28)))
+    eng.set_extra_between(2, [], [], np.zeros((0, 28)))
+    for w in (0, 1):
+        eng.set_states(w, 0, prob["states"])
+        eng.set_prior(w, 0, prob["prior"])
+        eng.set_range(w, 0, n)
+    eng.iterate(10)
+    np.testing.assert_array_equal(eng.get_states(0, 0, n), eng.get_states(1, 0, n))
+    with pytest.raises(VilFusionError) as ei:
+        eng.set_extra_between(0, np.arange(9), np.arange(9) + 10, np.tile(far_rec[0], (9, 1)))
+    assert ei.value.code == -6
+    eng.close()
+    ref.close()
+
+
+@pytest.mark.parametrize("compat", [False, True])
+def test_graph_manager_takes_any_pair_of_keys(oracle, compat):
+    """vf_add_between with a span-6 factor and a loop-closure pair (GraphManager.cpp:83-88): accepted, solved, and the
+    whole trajectory equals the oracle's on the same graph -- LM to convergence and the reference-compat one-update form
+    (which goes through the same stages)."""
+    from tests.test_gpu_graph_manager import _feed
+    from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    n = 120
+    seq = synth.make_sequence(33, n)
+    far = [(30, 36), (10, 100), (11, 101)]
+    rng = np.random.default_rng(6)
+    recs = [_far_record(seq, a, b, rng) for a, b in far]
+    gm = GraphManager(capacity=128, iterations=25, rel_tol=0, abs_tol=0, reference_compat=compat)
+    gm.setInitialState(seq.gt_states[0])
+    gm.addIMUMeasurement(0.0, seq.imu_steps[0, 1:4], seq.imu_steps[0, 4:7])
+    _feed(gm, seq, n)
+    staged = gm.graphSize()
+    for (a, b), r in zip(far, recs):
+        gm.addBetweenFactor(a, b, (r[0:4], r[4:7]), np.eye(6) * 0.05)
+    assert gm.graphSize() == staged + 3                       # they count as staged factors like any other
+    for _ in range(6 if compat else 1):                       # (one iSAM2-like update per solve in compat mode: repeat to converge)
+        gm.solve()
+    assert gm.graphSize() == 0
+    xs = gm.trajectory(0, n)
+    imu = np.zeros((n, 190))
+    for k in range(1, n):
+        imu[k] = gm.imuFactor(k)
+    g = np.array([0, 0, -9.81])
+    states = np.zeros((n, 16)); states[0] = seq.gt_states[0]
+    for k in range(1, n):
+        states[k] = oracle.predict(imu[k], g, states[k - 1])
+    m = seq.btw_a >= 1
+    fa, fb = np.array([a for a, _ in far], dtype=np.int32), np.array([b for _, b in far], dtype=np.int32)
+    prob = dict(n=n, states=states, imu=imu, btw_a=np.concatenate([seq.btw_a[m], fa]).astype(np.int32),
+                btw_b=np.concatenate([seq.btw_b[m], fb]).astype(np.int32), btw=np.vstack([synth.between_records(seq)[m], np.array(recs)]),
+                prior=synth.prior_record(states[0], REFERENCE_PRIOR_SIGMAS), gravity=g)
+    win = helpers.oracle_window(oracle, prob)
+    win.lm(iterations=40)
+    ate, rot = helpers.ate(xs, win.states)
+    print(f"GraphManager with far factors (reference_compat={compat}): ATE vs oracle {ate:.3e} m, rot {rot:.3e} rad")
+    assert ate <= 1e-6 and rot <= 1e-6
+    # the list is bounded: a ninth far factor is refused like the band refused a wide one before
+    for i in range(5):
+        gm.addBetweenFactor(40 + i, 60 + i, (recs[0][0:4], recs[0][4:7]), np.eye(6))
+    with pytest.raises(VilFusionError) as ei:
+        gm.addBetweenFactor(50, 70, (recs[0][0:4], recs[0][4:7]), np.eye(6))
+    assert ei.value.code == -6
+    gm.close()

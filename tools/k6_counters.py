@@ -6,7 +6,7 @@ pmc, trace, out = sys.argv[1:4]
 dur = collections.defaultdict(list)
 for r in csv.DictReader(open(trace)):
     k = r["Kernel_Name"]
-    if "k_degeneracy" in k and int(r["Grid_Size"]) >= (1 << 22):
+    if "k_degeneracy" in k and int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) >= (1 << 22):
         dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(pmc)):

@@ -148,6 +148,15 @@ struct vf_engine {
         in_bytes = want;
         return VF_OK;
     }
+    // far between factors (View::x_*): host mirror of how many slots are in use (the low-rank correction solves 6 right-hand
+    // sides per slot in use), the right-hand-side scratch and the solved columns Z
+    int x_used = 0;
+    std::vector<int> h_xn;
+    std::vector<std::vector<int>> h_xa, h_xb;          // host copies of every window's list (re-sent after compact / grow)
+    std::vector<std::vector<double>> h_xrec;
+    double* x_gtmp = nullptr;
+    double* x_Z = nullptr;
+    size_t x_zstride = 0;
     int ensure_stage(size_t bytes) {
         if (bytes <= stage_bytes) return VF_OK;
         if (stage) HIPCHK(hipFree(stage));
@@ -320,6 +329,8 @@ void vf_engine_destroy(vf_engine* e) {
     if (e->in_dev) (void)hipFree(e->in_dev);
     if (e->in_status) (void)hipFree(e->in_status);
     for (auto ev : e->in_ev) if (ev) (void)hipEventDestroy(ev);
+    if (e->x_gtmp) (void)hipFree(e->x_gtmp);
+    if (e->x_Z) (void)hipFree(e->x_Z);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream && e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -341,6 +352,10 @@ static void touch(vf_engine* e, int window, int first_slot) {
         if (e->redo <= 8) return;
     }
     e->warm = false;
+}
+static int not_sharded_(vf_engine* e, const char* what) {
+    if (e && e->v.sh_G > 1) return fail(VF_ERR_INVALID, "%s: not for time-sharded engines", what);
+    return VF_OK;
 }
 static int check_window(vf_engine* e, int window) {
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
@@ -453,6 +468,60 @@ int vf_engine_set_between(vf_engine* e, int window, int n, const int32_t* a, con
         HIPCHK(hipStreamSynchronize(e->stream));
         i = j;
     }
+    return VF_OK;
+}
+
+int vf_engine_set_extra_between(vf_engine* e, int window, int n, const int32_t* a, const int32_t* b, const double* rec) {
+    DeviceGuard dev_guard_(e);
+    if (e) e->warm = false;
+    int rc = check_window(e, window);
+    if (rc) return rc;
+    if (int rs = not_sharded_(e, "vf_engine_set_extra_between")) return rs;
+    if (n < 0 || n > VF_MAX_EXTRA) return fail(VF_ERR_CAPACITY, "at most %d far between factors per window (got %d)", VF_MAX_EXTRA, n);
+    if (n > 0 && (!a || !b || !rec)) return fail(VF_ERR_INVALID, "null argument");
+    const int M = e->v.M, B = e->v.B, X = VF_MAX_EXTRA;
+    for (int i = 0; i < n; i++) {
+        if (a[i] < 0 || b[i] >= M || a[i] >= b[i]) return fail(VF_ERR_BAD_KEY, "far between factor %d: need 0 <= a < b < capacity (a=%d b=%d)", i, a[i], b[i]);
+        if (!(rec[(size_t)i * vf::BTW_IN + 7] > 0.0)) return fail(VF_ERR_NOT_SPD, "far between factor %d: singular square-root information", i);
+    }
+    if (e->v.x_max == 0) {
+        if (n == 0) return VF_OK;
+        // first use: the per-window lists and the scratch of the low-rank correction (6 X increment-shaped columns)
+        const size_t zs = (size_t)e->v.G * 15 + (size_t)B + 64;
+        int *xa = nullptr, *xb = nullptr;
+        double *xi = nullptr, *xo = nullptr;
+        if ((rc = e->alloc(&xa, (size_t)B * X, false)) || (rc = e->alloc(&xb, (size_t)B * X, false)) ||
+            (rc = e->alloc(&xi, (size_t)B * X * vf::BTW_IN)) || (rc = e->alloc(&xo, 2 * (size_t)B * X * vf::BTW_OUT))) return rc;
+        HIPCHK(hipMemsetAsync(xa, 0xff, (size_t)B * X * sizeof(int), e->stream));
+        HIPCHK(hipMemsetAsync(xb, 0xff, (size_t)B * X * sizeof(int), e->stream));
+        HIPCHK(hipMalloc((void**)&e->x_gtmp, zs * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&e->x_Z, 6 * (size_t)X * zs * sizeof(double)));
+        e->x_zstride = zs;
+        e->v.x_a = xa; e->v.x_b = xb; e->v.x_in = xi; e->v.x_out = xo;
+        e->v.x_max = X;
+        e->h_xn.assign(B, 0);
+        e->h_xa.assign(B, {});
+        e->h_xb.assign(B, {});
+        e->h_xrec.assign(B, {});
+    }
+    e->h_xa[window].assign(a, a + n);
+    e->h_xb[window].assign(b, b + n);
+    e->h_xrec[window].assign(rec, rec + (size_t)n * vf::BTW_IN);
+    std::vector<int> ha(X, -1), hb(X, -1);
+    std::vector<double> hr((size_t)X * vf::BTW_IN, 0.0);
+    for (int i = 0; i < n; i++) { ha[i] = a[i]; hb[i] = b[i]; }
+    if (n) memcpy(hr.data(), rec, (size_t)n * vf::BTW_IN * sizeof(double));
+    HIPCHK(hipMemcpyAsync(e->v.x_a + (size_t)window * X, ha.data(), X * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->v.x_b + (size_t)window * X, hb.data(), X * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->v.x_in + (size_t)window * X * vf::BTW_IN, hr.data(), hr.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    // both linearisation buffers of the window start from zeros (an empty slot must read as "no factor")
+    for (int bf = 0; bf < 2; bf++)
+        HIPCHK(hipMemsetAsync(e->v.x_out + ((size_t)bf * B + window) * X * vf::BTW_OUT, 0, (size_t)X * vf::BTW_OUT * sizeof(double), e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->h_xn[window] = n;
+    e->x_used = 0;
+    for (int w = 0; w < B; w++) e->x_used = e->h_xn[w] > e->x_used ? e->h_xn[w] : e->x_used;
+    e->epoch++;        // (the number of band solves per trial is baked into a captured launch sequence)
     return VF_OK;
 }
 
@@ -609,6 +678,7 @@ int vf_engine_linearize(vf_engine* e, int which) {
         vf::launch_linearize_imu(e->v, which, e->stream);
         vf::launch_linearize_between_prior(e->v, which, e->stream);
     }
+    if (e->x_used > 0) vf::launch_linearize_extra(e->v, which, e->stream);
     HIPCHK(hipGetLastError());
     return VF_OK;
 }
@@ -617,6 +687,7 @@ int vf_engine_assemble(vf_engine* e) {
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     vf::launch_assemble(e->v, e->stream);
+    if (e->x_used > 0) vf::launch_extra_gradient(e->v, e->stream);   // the far factors' J^T r (their J^T J stays out of the band)
     HIPCHK(hipGetLastError());
     return VF_OK;
 }
@@ -631,8 +702,31 @@ int vf_engine_solve(vf_engine* e) {
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (int rc = not_sharded(e, "vf_engine_solve")) return rc;
-    if (e->hybrid && e->v.stop_on) vf::launch_band_solve_hybrid(e->v, e->partitioned_view(), e->stream);
-    else vf::launch_band_solve(e->v, e->stream);
+    auto band_solve = [&](double* gvec, double* delta) {      // the engine's K4 form on another right-hand side / increment buffer
+        vf::View a = e->v;
+        a.gvec = gvec;
+        a.delta = delta;
+        if (e->hybrid && e->v.stop_on) {
+            vf::View p = e->partitioned_view();
+            p.gvec = gvec;
+            p.delta = delta;
+            vf::launch_band_solve_hybrid(a, p, e->stream);
+        } else vf::launch_band_solve(a, e->stream);
+    };
+    band_solve(e->v.gvec, e->v.delta);
+    if (e->x_used > 0) {
+        // Far between factors: (H_band + lambda I + U U^T) delta = -g by Woodbury -- the band solver once more per column of
+        // U (6 per slot in use; it refactorises every time: a fallback for the rare window with such factors, not a fast
+        // path), then one small dense system per window (k_extra_combine).
+        const size_t gbytes = ((size_t)e->v.G * 15 + 64) * sizeof(double);
+        for (int s = 0; s < e->x_used; s++)
+            for (int j = 0; j < 6; j++) {
+                HIPCHK(hipMemsetAsync(e->x_gtmp, 0, gbytes, e->stream));
+                vf::launch_extra_rhs(e->v, s, j, e->x_gtmp, e->stream);
+                band_solve(e->x_gtmp, e->x_Z + (size_t)(6 * s + j) * e->x_zstride);
+            }
+        vf::launch_extra_combine(e->v, e->x_Z, e->x_zstride, e->x_used, e->stream);   // (slots beyond x_used are empty in every window)
+    }
     HIPCHK(hipGetLastError());
     return VF_OK;
 }
@@ -678,7 +772,7 @@ static int iterate_sequence(vf_engine* e, int iterations) {
 // the solve leaves every record, H row and g entry consistent with the current states: the next one may start warm.
 // (set by vf_engine_iterate, not by iterate_sequence: a hipGraph replay never runs the sequence's host code)
 static void mark_solved(vf_engine* e) {
-    e->warm = !e->no_warm;
+    e->warm = !e->no_warm && e->x_used == 0;     // (engines holding far between factors start every solve cold)
     e->slid = 0;
     e->redo = 0;
 }
@@ -1042,6 +1136,19 @@ int vf_engine_compact(vf_engine* e, int shift) {
     HIPCHK(hipMemcpyAsync(v.hi, hi.data(), v.B * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(v.prior_k, pk.data(), v.B * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    // far between factors: slots move down with the keyframes; one whose older keyframe was reclaimed is gone
+    for (int w = 0; w < v.B && v.x_max > 0; w++) {
+        if (e->h_xn[w] == 0) continue;
+        std::vector<int> a, b;
+        std::vector<double> r;
+        for (int i = 0; i < e->h_xn[w]; i++) {
+            if (e->h_xa[w][i] < shift) continue;
+            a.push_back(e->h_xa[w][i] - shift);
+            b.push_back(e->h_xb[w][i] - shift);
+            r.insert(r.end(), e->h_xrec[w].begin() + (size_t)i * vf::BTW_IN, e->h_xrec[w].begin() + (size_t)(i + 1) * vf::BTW_IN);
+        }
+        if (int rc = vf_engine_set_extra_between(e, w, (int)a.size(), a.data(), b.data(), r.data())) return rc;
+    }
     return VF_OK;
 }
 
@@ -1094,6 +1201,11 @@ int vf_engine_grow(vf_engine* e, int new_capacity) {
     if (!e->own_stream) {          // the caller's stream stays the one every later stage runs on
         if ((rc = vf_engine_set_stream(n, (void*)e->stream))) { vf_engine_destroy(n); return rc; }
     }
+    for (int w = 0; w < e->v.B && e->v.x_max > 0; w++)       // far between factors: re-sent from the host copies
+        if (e->h_xn[w] > 0 && (rc = vf_engine_set_extra_between(n, w, e->h_xn[w], e->h_xa[w].data(), e->h_xb[w].data(), e->h_xrec[w].data()))) {
+            vf_engine_destroy(n);
+            return rc;
+        }
     std::swap(*e, *n);             // *e: the grown engine; *n: the old buffers
     n->own_stream = n->own_stream && n->stream != e->stream;
     vf_engine_destroy(n);

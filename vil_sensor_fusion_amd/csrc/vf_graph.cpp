@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -77,6 +78,14 @@ struct vf_graph {
     std::deque<ImuSample> buffer;
     std::deque<PendingImu> imu_queue;
     std::vector<PendingBetween> staged_between;
+    // Between factors the band cannot hold -- wider than VF_MAX_BANDWIDTH keyframes, or a second one ending at a key (loop
+    // closures; iSAM2 takes any pair of keys, GraphManager.cpp:83-88): kept here for as long as both keys are in the window
+    // and handed to the engine as "far" factors (vf_engine_set_extra_between) at every solve.  band_end[k] != 0: key k
+    // already carries a band factor.  far_new counts the ones added since the last solve (they are part of graph()->size()).
+    std::vector<PendingBetween> far_between;
+    std::vector<uint8_t> band_end;
+    int far_new = 0;
+    bool far_on_device = false;    // the engine holds a non-empty far list (written under solve_mutex only)
     int staged_count = 3;  // the three priors (GraphManager.cpp:33-35)
     uint64_t current_key = 0;
     double last_pose_time = -1.0;
@@ -320,10 +329,19 @@ int vf_add_between(vf_graph* g, uint64_t prev, uint64_t cur, const double q[4], 
     if (!sqrt_info_upper6(cov, b.rec + 7)) return gerr(VF_ERR_NOT_SPD, "between covariance is not symmetric positive definite");
     std::lock_guard<std::mutex> lk(g->graph_mutex);  // GraphManager.cpp:85
     if (prev >= cur || cur > g->current_key) return gerr(VF_ERR_BAD_KEY, "between factor keys (%llu, %llu) not reserved in order", (unsigned long long)prev, (unsigned long long)cur);
-    if (cur - prev > VF_MAX_BANDWIDTH) return gerr(VF_ERR_CAPACITY, "between factor spans %llu keyframes (max %d)", (unsigned long long)(cur - prev), VF_MAX_BANDWIDTH);
+    bool band = cur - prev <= VF_MAX_BANDWIDTH && !(cur < g->band_end.size() && g->band_end[cur]);
     for (const auto& s : g->staged_between)
-        if (s.b == cur) return gerr(VF_ERR_CAPACITY, "a between factor already ends at key %llu", (unsigned long long)cur);
-    g->staged_between.push_back(b);
+        if (s.b == cur) band = false;
+    if (band) {
+        g->staged_between.push_back(b);
+    } else {
+        // not a band factor: a far factor, solved as a low-rank correction (slower; include/vilfusion.h).  The list is bounded.
+        if ((int)g->far_between.size() >= VF_MAX_EXTRA)
+            return gerr(VF_ERR_CAPACITY, "between factor (%llu, %llu) spans %llu keyframes or shares its end key, and the window already holds %d such factors",
+                        (unsigned long long)prev, (unsigned long long)cur, (unsigned long long)(cur - prev), VF_MAX_EXTRA);
+        g->far_between.push_back(b);
+        g->far_new++;
+    }
     g->staged_count++;
     return VF_OK;
 }
@@ -351,7 +369,7 @@ int vf_solve(vf_graph* g) {
     auto lap = [&](const char* what) { if (timing) { auto t_b = now(); fprintf(stderr, "[vf_solve] %-12s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t_b - t_a).count()); t_a = t_b; } };
     // ---- under _graphMutex: emptyImuQueue + snapshot of the staged factors (GraphManager.cpp:104-114)
     std::deque<PendingImu> imus;
-    std::vector<PendingBetween> betweens;
+    std::vector<PendingBetween> betweens, fars;
     uint64_t last_key;
     double last_time;
     int staged_before;
@@ -360,6 +378,19 @@ int vf_solve(vf_graph* g) {
         std::lock_guard<std::mutex> lk(g->graph_mutex);
         imus.swap(g->imu_queue);
         betweens.swap(g->staged_between);
+        for (const auto& bt : betweens) {         // these keys now carry their band factor (a second one goes to the far list)
+            if (g->band_end.size() <= bt.b) g->band_end.resize(bt.b + 1, 0);
+            g->band_end[bt.b] = 1;
+        }
+        // far factors whose older key has left the window (as of the previous solve: lo / key_base change under solve_mutex,
+        // which this thread holds) are gone for good: their information is dropped, not marginalised
+        {
+            const uint64_t oldest = g->key_base + (uint64_t)g->lo;
+            auto& fb = g->far_between;
+            fb.erase(std::remove_if(fb.begin(), fb.end(), [&](const PendingBetween& f) { return f.a < oldest; }), fb.end());
+        }
+        fars = g->far_between;
+        g->far_new = 0;
         staged_before = g->staged_count;
         g->staged_count = 0;  // _graph->resize(0)
         last_key = g->current_key;
@@ -467,6 +498,21 @@ int vf_solve(vf_graph* g) {
     }
     const int lo = g->lo;
     lap("marginalize");
+    if (!fars.empty() || g->far_on_device) {
+        // far between factors still inside the window, in window-local slots (the engine ignores one whose older keyframe
+        // is below `lo`; the list is re-sent at every solve, so compaction and growth need no bookkeeping here)
+        std::vector<int32_t> a, b;
+        std::vector<double> rec;
+        for (const auto& f : fars) {
+            if (f.a < g->key_base + (uint64_t)lo || f.b > last_key) continue;
+            a.push_back((int32_t)(f.a - g->key_base));
+            b.push_back((int32_t)(f.b - g->key_base));
+            rec.insert(rec.end(), f.rec, f.rec + VF_BTW_RECORD);
+        }
+        if ((rc = vf_engine_set_extra_between(g->eng, 0, (int)a.size(), a.data(), b.data(), rec.data()))) return give_back(rc);
+        g->far_on_device = !a.empty();
+        lap("set_extra");
+    }
     if ((rc = vf_engine_set_range(g->eng, 0, lo, last_slot + 1))) return give_back(rc);
     lap("set_range");
     int fails = 0;

@@ -555,25 +555,17 @@ __global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_imu(View
     linearize_imu_factor<false>(v, which, (long)blockIdx.x * VF_K1_BLOCK + threadIdx.x);
 }
 
+// BetweenFactor<Pose3> between the keyframes in slots ga -> gk at the states of buffer b: whitened residual (6) and
+// Jacobians (Ja 36, Jb 36) written to out[f * ostride], record read from in[f * istride].  `jac` = false: residual only.
 template <bool SH>
-__device__ __forceinline__ void linearize_between_factor(const View& v, int which, const long gk) {
-    if (gk >= v.G) return;
-    const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
-    const int lo = v.lo[w], w_hi = v.hi[w], w_sel = v.sel[w], w_done = v.stop_on ? v.done[w] : 0;
-    const int a = v.btw_a[gk];                 // (all five requested together: one round trip)
-    if (k <= lo || k >= w_hi || w_done) return;
-    const bool jac = !SH || !shard_skips_factor(v, w, k);
-    if (a < lo || a >= k) return;
-    const int b = w_sel ^ which;
-    const long ga = (long)w * v.M + a;
-
-    const double* __restrict__ in = v.btw_in + (size_t)(gk >> 6) * BTW_IN * TILE + (gk & 63);
-    double* __restrict__ out = v.btw_out + ((size_t)b * (size_t)(v.G >> 6) + (size_t)(gk >> 6)) * BTW_OUT * TILE + (gk & 63);
-#define IN(f) in[(size_t)(f) * TILE]
+__device__ __forceinline__ void between_core(const View& v, const int b, const long ga, const long gk,
+                                             const double* __restrict__ in, const size_t istride,
+                                             double* __restrict__ out, const size_t ostride, const bool jac) {
+#define IN(f) in[(size_t)(f) * istride]
     struct NtRef { double* p; VF_DI void operator=(double x) const { __builtin_nontemporal_store(x, p); } };
     struct NtJac { double* p; bool on; VF_DI void operator=(double x) const { if (!SH || on) __builtin_nontemporal_store(x, p); } };
-#define OUT(f) (NtRef{out + (size_t)(f) * TILE})
-#define JOUT(f) (NtJac{out + (size_t)(f) * TILE, jac})
+#define OUT(f) (NtRef{out + (size_t)(f) * ostride})
+#define JOUT(f) (NtJac{out + (size_t)(f) * ostride, jac})
 
     const Q4 qa = q4(XS(b, 0, ga), XS(b, 1, ga), XS(b, 2, ga), XS(b, 3, ga));
     const V3 ta = v3(XS(b, 4, ga), XS(b, 5, ga), XS(b, 6, ga));
@@ -640,6 +632,127 @@ __device__ __forceinline__ void linearize_between_factor(const View& v, int whic
 #undef IN
 #undef OUT
 #undef JOUT
+}
+
+template <bool SH>
+__device__ __forceinline__ void linearize_between_factor(const View& v, int which, const long gk) {
+    if (gk >= v.G) return;
+    const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
+    const int lo = v.lo[w], w_hi = v.hi[w], w_sel = v.sel[w], w_done = v.stop_on ? v.done[w] : 0;
+    const int a = v.btw_a[gk];                 // (all five requested together: one round trip)
+    if (k <= lo || k >= w_hi || w_done) return;
+    const bool jac = !SH || !shard_skips_factor(v, w, k);
+    if (a < lo || a >= k) return;
+    const int b = w_sel ^ which;
+    const double* __restrict__ in = v.btw_in + (size_t)(gk >> 6) * BTW_IN * TILE + (gk & 63);
+    double* __restrict__ out = v.btw_out + ((size_t)b * (size_t)(v.G >> 6) + (size_t)(gk >> 6)) * BTW_OUT * TILE + (gk & 63);
+    between_core<SH>(v, b, (long)w * v.M + a, gk, in, TILE, out, TILE, jac);
+}
+
+// ---- "far" between factors (View::x_*): BetweenFactor<Pose3> on ANY pair of keyframes of a window -- a span wider than
+// the band, or a second factor on an end key (loop closures; GraphManager.cpp:83-88 takes any pair of keys).  They stay
+// out of the banded H: the solve treats them as a low-rank correction (launch_extra_* below, vf_engine_solve).
+// One lane per (window, slot); a slot that is empty or reaches outside the window writes zeros (no cost, no rows).
+__global__ void __launch_bounds__(64) k_linearize_extra(View v, int which) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= v.B * v.x_max) return;
+    const int w = i / v.x_max;
+    if (window_done(v, w)) return;
+    const int b = v.sel[w] ^ which, lo = v.lo[w], hi = v.hi[w];
+    const int a = v.x_a[i], kb = v.x_b[i];
+    double* out = v.x_out + ((size_t)b * v.B * v.x_max + i) * BTW_OUT;
+    if (a < lo || kb >= hi || a >= kb) {
+        for (int f = 0; f < BTW_OUT; f++) out[f] = 0.0;
+        return;
+    }
+    between_core<false>(v, b, (long)w * v.M + a, (long)w * v.M + kb, v.x_in + (size_t)i * BTW_IN, 1, out, 1, true);
+}
+// g += J^T r of the far factors, for the windows whose rows K3 has just rewritten (same test as k_assemble; engines that
+// hold far factors never warm-start, so "rewritten" means the whole window)
+__global__ void __launch_bounds__(64) k_extra_gradient(View v) {
+    const int w = blockIdx.x, lane = threadIdx.x;
+    if (!v.fresh[w] || window_done(v, w)) return;
+    const int b = v.sel[w];
+    for (int s = 0; s < v.x_max; s++) {              // sequential over the slots: two factors may share a keyframe
+        const int i = w * v.x_max + s;
+        const int a = v.x_a[i], kb = v.x_b[i];
+        if (a < v.lo[w] || kb >= v.hi[w] || a >= kb) continue;
+        const double* f = v.x_out + ((size_t)b * v.B * v.x_max + i) * BTW_OUT;
+        if (lane < 12) {
+            const int c = lane % 6, side = lane / 6;
+            double acc = 0.0;
+            for (int r = 0; r < 6; r++) acc = fma(f[6 + 36 * side + r * 6 + c], f[r], acc);
+            v.gvec[((size_t)w * v.M + (side ? kb : a)) * 15 + c] += acc;
+        }
+        __syncthreads();
+    }
+}
+// right-hand side number (s, j) of the low-rank correction: column j of the far factor in slot s of every window,
+// u = [Ja[j][:] at pose a, Jb[j][:] at pose b], into a zeroed increment-shaped buffer
+__global__ void __launch_bounds__(64) k_extra_rhs(View v, int s, int j, double* __restrict__ gtmp) {
+    const int w = blockIdx.x * 64 + threadIdx.x;
+    if (w >= v.B || window_done(v, w)) return;
+    const int i = w * v.x_max + s;
+    const int a = v.x_a[i], kb = v.x_b[i];
+    if (a < v.lo[w] || kb >= v.hi[w] || a >= kb) return;
+    const double* f = v.x_out + ((size_t)v.sel[w] * v.B * v.x_max + i) * BTW_OUT;
+    for (int c = 0; c < 6; c++) {
+        gtmp[((size_t)w * v.M + a) * 15 + c] = f[6 + j * 6 + c];
+        gtmp[((size_t)w * v.M + kb) * 15 + c] = f[42 + j * 6 + c];
+    }
+}
+// delta = y - Z (I + U^T Z)^-1 U^T y  (Woodbury; A = H_band + lambda I, y = -A^-1 g in v.delta, column q of Zm = -A^-1 u_q as
+// the band solver returned it for the right-hand side u_q): one workgroup per window, the m = 6 x_max square system in LDS.
+__global__ void __launch_bounds__(256) k_extra_combine(View v, const double* __restrict__ Zm, size_t zstride, int slots) {
+    constexpr int MM = 6 * MAX_EXTRA;
+    __shared__ double C[MM][MM + 1];
+    __shared__ double cvec[MM];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w)) return;
+    const int m = 6 * slots, lo = v.lo[w], hi = v.hi[w];      // slots in use (the rest are empty in every window)
+    const double* xo = v.x_out + ((size_t)v.sel[w] * v.B + w) * v.x_max * BTW_OUT;
+    // C[p][q] = delta_pq - u_p . Zm_q  (= delta_pq + u_p^T A^-1 u_q), C[p][m] = u_p . y
+    for (int e = tid; e < m * (m + 1); e += 256) {
+        const int p = e / (m + 1), q = e - p * (m + 1);
+        const int s = p / 6, j = p - 6 * s, i = w * v.x_max + s;
+        const int a = v.x_a[i], kb = v.x_b[i];
+        double acc = 0.0;
+        if (!(a < lo || kb >= hi || a >= kb)) {
+            const double* f = xo + (size_t)s * BTW_OUT;
+            const double* col = q < m ? Zm + (size_t)q * zstride : v.delta;
+            const double* za = col + ((size_t)w * v.M + a) * 15;
+            const double* zb = col + ((size_t)w * v.M + kb) * 15;
+            for (int c = 0; c < 6; c++) acc = fma(f[6 + j * 6 + c], za[c], fma(f[42 + j * 6 + c], zb[c], acc));
+        }
+        C[p][q] = q < m ? (p == q ? 1.0 : 0.0) - acc : acc;
+    }
+    __syncthreads();
+    // Gaussian elimination (C is symmetric positive definite: I + U^T A^-1 U), entry-parallel
+    for (int c = 0; c < m; c++) {
+        const double inv = 1.0 / C[c][c];
+        __syncthreads();
+        const int rem = m - 1 - c;
+        for (int e = tid; e < rem * (rem + 1); e += 256) {
+            const int p = c + 1 + e / (rem + 1), q = c + 1 + (e - (e / (rem + 1)) * (rem + 1));
+            C[p][q] = fma(-C[p][c] * inv, C[c][q], C[p][q]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        for (int p = m - 1; p >= 0; p--) {
+            double t = C[p][m];
+            for (int q = p + 1; q < m; q++) t = fma(-C[p][q], cvec[q], t);
+            cvec[p] = t / C[p][p];
+        }
+    }
+    __syncthreads();
+    // delta = y + sum_q c_q Zm_q over the window's keyframes
+    for (int e = tid; e < (hi - lo) * 15; e += 256) {
+        const size_t o = ((size_t)w * v.M + lo) * 15 + e;
+        double acc = v.delta[o];
+        for (int q = 0; q < m; q++) acc = fma(cvec[q], Zm[(size_t)q * zstride + o], acc);
+        v.delta[o] = acc;
+    }
 }
 
 // ------------------------------------------------------------------------------------ K2b
@@ -2436,6 +2549,10 @@ __global__ void __launch_bounds__(1024) k_decide(View v, int init) {
             for (int r = 0; r < 15; r++) s = fma(f[r], f[r], s);
         }
         if (v.mp_on[w] && hi - lo >= 3) s += 2.0 * v.mp_out[((size_t)b * v.B + w) * 28 + 27];
+        for (int xs = 0; xs < v.x_max; xs++) {           // far between factors (empty slots hold zeros)
+            const double* f = v.x_out + (((size_t)b * v.B + w) * v.x_max + xs) * BTW_OUT;
+            for (int r = 0; r < 6; r++) s = fma(f[r], f[r], s);
+        }
     }
     __shared__ double red[1024];
     red[tid] = s;
@@ -2768,6 +2885,18 @@ void launch_ingest_tail(const View& v, const int* off, const double* steps, cons
                         const ImuCov& prm, int* status, hipStream_t s) {
     hipLaunchKernelGGL(k_preintegrate_t<true>, dim3(v.B), dim3(256), 0, s, v, 0L, v.B, off, steps, (const double*)nullptr, tail_a,
                        tail_btw, prm, status);
+}
+void launch_linearize_extra(const View& v, int which, hipStream_t s) {
+    if (v.x_max > 0) hipLaunchKernelGGL(k_linearize_extra, dim3(nblk((long)v.B * v.x_max, 64)), dim3(64), 0, s, v, which);
+}
+void launch_extra_gradient(const View& v, hipStream_t s) {
+    if (v.x_max > 0) hipLaunchKernelGGL(k_extra_gradient, dim3(v.B), dim3(64), 0, s, v);
+}
+void launch_extra_rhs(const View& v, int slot, int row, double* gtmp, hipStream_t s) {
+    hipLaunchKernelGGL(k_extra_rhs, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, slot, row, gtmp);
+}
+void launch_extra_combine(const View& v, const double* Zm, size_t zstride, int slots, hipStream_t s) {
+    hipLaunchKernelGGL(k_extra_combine, dim3(v.B), dim3(256), 0, s, v, Zm, zstride, slots);
 }
 void launch_linearize_all(const View& v, int which, hipStream_t s) {
     const int nb_imu = (int)nblk(v.G, VF_K1_BLOCK), nb_btw = nb_imu, nb_pri = (int)nblk(v.B, VF_K1_BLOCK);

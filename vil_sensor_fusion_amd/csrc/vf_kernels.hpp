@@ -22,6 +22,7 @@ constexpr int JS_PI = (JS_NI + 1) / 2, JS_PJ = (JS_NJ + 1) / 2, JS_PAIRS = JS_PI
 constexpr int JT_STRIDE = JS_PAIRS * JT * 2;        // 2336 doubles = 146 lines per tile
 constexpr int BTW_IN = 28;      // q(4), t(3), R packed upper (21)
 constexpr int BTW_OUT = 78;     // r(6), Ja(36), Jb(36)
+constexpr int MAX_EXTRA = 8;    // far between factors per window (= VF_MAX_EXTRA of include/vilfusion.h)
 constexpr int PRIOR_IN = 31;    // mean state (16), sigma (15)
 constexpr int PRIOR_OUT = 240;  // r(15), J(15x15)
 // Block row of H of one keyframe k, as the solver reads it (512 doubles, 4 KB):
@@ -168,6 +169,13 @@ struct View {
     int gate, gate_T;
     int tw_max;         // whole-window sweeps: up to this many windows two waves per window from both ends, above one wave per window
     int split_min;      // whole-window sweeps: from this many windows on, forward sweep and back substitution as two kernels (0 = never)
+    // "far" between factors: BetweenFactor<Pose3> on any pair of keyframes of a window (wider than the band, or a second factor
+    // on an end key), at most x_max per window; kept out of the banded H and solved as a low-rank correction
+    int x_max;          // 0 until vf_engine_set_extra_between is first called
+    int* x_a;           // [B][x_max] window-local slots of the two keyframes, -1 = empty
+    int* x_b;
+    double* x_in;       // [B][x_max][28]
+    double* x_out;      // [2][B][x_max][78] linearisations, double-buffered like btw_out
 };
 
 // isotropic IMU covariances (ImuManagerRos.cpp:20-33)
@@ -178,6 +186,10 @@ void launch_preintegrate(const View& v, long g0, int n, const int* off, const do
 // current bias estimate + the between record ending there (off: [B + 1] step offsets, tail_a: [B], tail_btw: [B][28])
 void launch_ingest_tail(const View& v, const int* off, const double* steps, const int* tail_a, const double* tail_btw,
                         const ImuCov& prm, int* status, hipStream_t s);
+void launch_linearize_extra(const View& v, int which, hipStream_t s);       // far between factors (no-op while x_max == 0)
+void launch_extra_gradient(const View& v, hipStream_t s);                    // g += J^T r of the far factors, after K3
+void launch_extra_rhs(const View& v, int slot, int row, double* gtmp, hipStream_t s);
+void launch_extra_combine(const View& v, const double* Zm, size_t zstride, int slots, hipStream_t s);
 void launch_linearize_imu(const View& v, int which, hipStream_t s);
 void launch_linearize_between(const View& v, int which, hipStream_t s);
 void launch_linearize_prior(const View& v, int which, hipStream_t s);

@@ -108,6 +108,14 @@ class Engine:
         assert a.size == b.size == r.shape[0]
         check(self._l.vf_engine_set_between(self._h, window, a.size, _i(a), _i(b), _d(r)))
 
+    def set_extra_between(self, window, a, b, rec):
+        """far between factors of a window (any pair of keyframes; vf_engine_set_extra_between): REPLACES the window's list"""
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        b = np.ascontiguousarray(b, dtype=np.int32)
+        r = np.ascontiguousarray(rec, dtype=np.float64).reshape(-1, BTW_RECORD)
+        assert a.size == b.size == r.shape[0]
+        check(self._l.vf_engine_set_extra_between(self._h, window, a.size, _i(a), _i(b), _d(r)))
+
     def clear_between(self, window, k0, n):
         check(self._l.vf_engine_clear_between(self._h, window, k0, n))
 

@@ -19,6 +19,9 @@ def test_committed_pivot_code_is_what_the_generator_writes():
     for n, kw in ((15, dict(near=3)), (27, dict(near=27))):
         path = os.path.join(ROOT, "vil_sensor_fusion_amd", "csrc", f"vf_pivot_{n}.inc")
         assert open(path).read() == g.gen(n, **kw), path
+    path = os.path.join(ROOT, "vil_sensor_fusion_amd", "csrc", "vf_pivot_15p.inc")        # the lane-swap variant
+    assert open(path).read() == g.gen(15, near=3, rep="permlane")
+    assert "S[pv_bcw]" not in open(path).read() and open(path).read().count("rep_row0(") == 11
 
 
 def test_column_updates_arrive_before_the_column_is_a_pivot():

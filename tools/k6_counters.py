@@ -1,7 +1,7 @@
 """condense the rocprofv3 --pmc CSV of tools/k6_probe.py into a markdown table: per K6 kernel instantiation (largest grid
 only) mean counters per launch, float64 VALU operations and the fraction of the vector float64 peak they amount to at the
 launch duration given in a kernel-trace CSV.  usage: k6_counters.py <counter_collection.csv> <kernel_trace.csv> <out.md>"""
-import csv, sys, collections
+import csv, sys, collections, re
 pmc, trace, out = sys.argv[1:4]
 dur = collections.defaultdict(list)
 for r in csv.DictReader(open(trace)):
@@ -13,15 +13,22 @@ for r in csv.DictReader(open(pmc)):
     k = r["Kernel_Name"]
     if "k_degeneracy" in k and int(r["Grid_Size"]) >= (1 << 22):
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-names = {"Li4E": "e_opt", "Li19E": "condition_number", "Li0E": "d_opt"}
+names = {4: "e_opt", 19: "condition_number", 0: "d_opt"}
+
+
+def parse(k):
+    """('f64' | 'f32', metric id) from a demangled `k_degeneracy<double, 6, 4>(...)` or a mangled `...IdLi6ELi4EE...` name"""
+    m = re.search(r"k_degeneracy<(double|float), (\d+), (\d+)>", k) or re.search(r"k_degeneracyI([df])Li(\d+)ELi(\d+)E", k)
+    return ("f64" if m.group(1) in ("double", "d") else "f32", int(m.group(3))) if m else ("?", -1)
 PEAK_F64, PEAK_F32 = 78.6e12, 157.3e12     # MI355X vector peaks (MI355X_MICROARCH.md), FMA = 2 flop
 L = ["# K6 on 2^22 6x6 matrices: VALU counters per launch (rocprofv3 --pmc, separate pass) and the compute roofline", "",
      "| kernel | dtype | ms per launch (trace) | ns per matrix | VALU insts / wave | f64 FMA | f64 MUL | f64 ADD | f64 TRANS | GFLOP per launch | TFLOP/s | of vector peak | HBM GB/s (296 or 148 B per matrix) |",
      "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 for k in sorted(acc):
     c = {n: sum(v) / len(v) for n, v in acc[k].items()}
-    is64 = "IdLi6E" in k
-    tag = next((v for s, v in names.items() if s + "EEvPK" in k), k[:40])
+    dt, mid = parse(k)
+    is64 = dt == "f64"
+    tag = names.get(mid, k[:40])
     ms = min(dur[k]) if dur.get(k) else float("nan")
     waves = c.get("SQ_WAVES", 0.0)
     fma, mul, add, tr = (c.get("SQ_INSTS_VALU_FMA_F64", 0), c.get("SQ_INSTS_VALU_MUL_F64", 0), c.get("SQ_INSTS_VALU_ADD_F64", 0), c.get("SQ_INSTS_VALU_TRANS_F64", 0))

@@ -11,6 +11,8 @@ struct vf_engine { int dummy; };
 static thread_local std::string g_err;
 std::atomic<int> fake_fail_preintegrate{0};   // != 0: vf_engine_preintegrate fails (the solve gives its queues back)
 std::atomic<long> fake_iterates{0};
+// what the last vf_engine_set_between / vf_engine_set_extra_between calls carried (host-logic tests of the far-factor routing)
+std::atomic<int> fake_band_n{-1}, fake_extra_n{-1}, fake_extra_calls{0}, fake_extra_a0{-1}, fake_extra_b0{-1};
 
 extern "C" {
 const char* vf_last_error(void) { return g_err.c_str(); }
@@ -29,8 +31,14 @@ int vf_engine_preintegrate(vf_engine*, int, int, int, const int32_t*, const doub
 }
 int vf_engine_predict(vf_engine*, int, int, int) { return VF_OK; }
 int vf_engine_predict_from_estimate(vf_engine*, int, int, int) { return VF_OK; }
-int vf_engine_set_between(vf_engine*, int, int, const int32_t*, const int32_t*, const double*) { return VF_OK; }
-int vf_engine_set_extra_between(vf_engine*, int, int, const int32_t*, const int32_t*, const double*) { return VF_OK; }
+int vf_engine_set_between(vf_engine*, int, int n, const int32_t*, const int32_t*, const double*) { fake_band_n = n; return VF_OK; }
+int vf_engine_set_extra_between(vf_engine*, int, int n, const int32_t* a, const int32_t* b, const double*) {
+    fake_extra_n = n;
+    fake_extra_calls++;
+    fake_extra_a0 = n ? a[0] : -1;
+    fake_extra_b0 = n ? b[0] : -1;
+    return VF_OK;
+}
 int vf_engine_marginalize(vf_engine*) { return VF_OK; }
 int vf_engine_drop_oldest(vf_engine*) { return VF_OK; }
 int vf_engine_compact(vf_engine*, int) { return VF_OK; }

@@ -1,0 +1,59 @@
+// Host logic of the far-factor routing in vf_graph.cpp against the device-free engine double (tests/test_graph_threads.py
+// builds and runs this): GraphManager::addBetweenFactor takes any pair of keys (GraphManager.cpp:83-88); a factor the band
+// cannot hold -- wider than VF_MAX_BANDWIDTH, or a second one ending at a key -- goes to the far list, counts as a staged
+// factor, reaches the engine through vf_engine_set_extra_between at every solve while both keys are in the window, and the
+// list is bounded by VF_MAX_EXTRA.
+#include <atomic>
+#include <cstdio>
+
+#include "../../include/vilfusion.h"
+
+extern std::atomic<int> fake_band_n, fake_extra_n, fake_extra_calls, fake_extra_a0, fake_extra_b0;
+
+#define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "line %d: %s failed (%s)\n", __LINE__, #cond, vf_last_error()); return 1; } } while (0)
+
+int main() {
+    vf_imu_params imu{1e-6, 1e-6, 1e-8, 1e-4, 1e-6, 1e-4};
+    vf_graph_opts o;
+    vf_graph_default_opts(&o);
+    o.capacity = 256;
+    o.lag = 16;
+    vf_graph* g = nullptr;
+    CHECK(vf_create(&imu, &o, &g) == VF_OK);
+    const double acc[3] = {0, 0, 9.81}, gyro[3] = {0, 0, 0}, q[4] = {1, 0, 0, 0}, t3[3] = {0.1, 0, 0};
+    double eye[36] = {0};
+    for (int i = 0; i < 6; i++) eye[i * 7] = 1.0;
+    double t = 0.0;
+    auto node = [&]() { for (int s = 0; s < 3; s++) { t += 0.005; vf_add_imu(g, t, acc, gyro); } uint64_t k = 0; vf_reserve_node(g, t, &k); return k; };
+    for (int k = 1; k <= 12; k++) { const uint64_t key = node(); if (key > 1) CHECK(vf_add_between(g, key - 1, key, q, t3, eye) == VF_OK); }
+    int staged = 0, queued = 0;
+    vf_graph_staged(g, &staged, &queued);
+    CHECK(staged == 3 + 11);
+    CHECK(vf_add_between(g, 2, 9, q, t3, eye) == VF_OK);         // span 7: far
+    CHECK(vf_add_between(g, 5, 6, q, t3, eye) == VF_OK);         // key 6 already ends a staged band factor: far
+    vf_graph_staged(g, &staged, &queued);
+    CHECK(staged == 3 + 11 + 2);
+    CHECK(vf_solve(g) == VF_OK);
+    CHECK(fake_band_n.load() == 11 && fake_extra_n.load() == 2 && fake_extra_a0.load() == 2 && fake_extra_b0.load() == 9);
+    vf_graph_staged(g, &staged, &queued);
+    CHECK(staged == 0 && queued == 0);
+    CHECK(vf_add_between(g, 10, 11, q, t3, eye) == VF_OK);       // key 11 got its band factor in the last solve: far
+    CHECK(vf_solve(g) == VF_OK);
+    CHECK(fake_extra_n.load() == 3);                              // the list persists: re-sent at every solve
+    for (int i = 0; i < 5; i++) CHECK(vf_add_between(g, 1 + i, 8 + (uint64_t)i % 4, q, t3, eye) == VF_OK);
+    CHECK(vf_add_between(g, 3, 12, q, t3, eye) == VF_ERR_CAPACITY);   // the ninth
+    CHECK(vf_add_between(g, 12, 3, q, t3, eye) == VF_ERR_BAD_KEY);
+    // keys leave the fixed-lag window (lag 16): far factors whose older key is gone are dropped from the list
+    for (int k = 13; k <= 60; k++) { const uint64_t key = node(); CHECK(vf_add_between(g, key - 1, key, q, t3, eye) == VF_OK); CHECK(vf_solve(g) == VF_OK); }
+    CHECK(fake_extra_n.load() == 0);
+    const int calls = fake_extra_calls.load();
+    node();
+    CHECK(vf_solve(g) == VF_OK);
+    CHECK(fake_extra_calls.load() == calls);                      // nothing far alive and nothing on the device: no call
+    CHECK(vf_add_between(g, 50, 58, q, t3, eye) == VF_OK);        // room again
+    CHECK(vf_solve(g) == VF_OK);
+    CHECK(fake_extra_n.load() == 1);
+    vf_destroy(g);
+    printf("far-factor routing ok\n");
+    return 0;
+}

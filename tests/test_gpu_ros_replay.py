@@ -87,7 +87,7 @@ def test_ros_graph_replay_on_the_device(oracle):
     from vil_sensor_fusion_amd.ros.odometry_filter_node import FilterNode
 
     n = 640                                                     # 30 keyframes / s: 21.3 s
-    seq = synth.make_sequence(seed=21, n_kf=n, tunnel=(0.4, 0.6, 1e-6))
+    seq = synth.make_sequence(seed=21, n_kf=n, tunnel=(0.4, 0.6, 1e-6), keep_raw=True)
     assert seq.kf_time[-1] >= 20.0
     bus = R.Bus()
     msgs = R.ns(Imu="Imu", Image="Image", PointCloud2="PointCloud2", Odometry=R.Msg, TransformStamped=R.Msg)
@@ -236,7 +236,7 @@ def test_node_builds_its_own_graph_manager_from_parameters():
     """the node constructed the way main() does (no graph_manager argument): the solver/* private parameters reach
     vf_create, solver/initial_state moves the anchor, and one camera keyframe goes through to a published estimate"""
     from vil_sensor_fusion_amd.ros.gtsam_fusion_node import FusionNode
-    seq = synth.make_sequence(seed=22, n_kf=12)
+    seq = synth.make_sequence(seed=22, n_kf=12, keep_raw=True)
     bus = R.Bus()
     params = dict(PARAMS, solver=dict(lag=64, capacity=128, iterations=3, rel_tol=0.0, abs_tol=0.0,
                                       initial_state=[float(x) for x in seq.gt_states[0]]))

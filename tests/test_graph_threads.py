@@ -22,3 +22,17 @@ def test_failing_solve_against_reserve_node_under_tsan(tmp_path):
     print(p.stdout, p.stderr[-3000:])
     assert "ThreadSanitizer" not in p.stderr, "data race or lock-order inversion reported"
     assert p.returncode == 0
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_far_factor_routing_host_logic(tmp_path):
+    """vf_add_between takes any pair of keys (GraphManager.cpp:83-88): band factors to vf_engine_set_between, everything else
+    to the bounded far list that is re-sent through vf_engine_set_extra_between at every solve and pruned as keys leave the
+    fixed-lag window (tests/native/graph_far.cpp against the engine double; the arithmetic is tests/test_gpu_far_factors.py)."""
+    exe = tmp_path / "graph_far"
+    srcs = [os.path.join(ROOT, "tests", "native", "graph_far.cpp"), os.path.join(ROOT, "tests", "native", "fake_engine.cpp"),
+            os.path.join(ROOT, "vil_sensor_fusion_amd", "csrc", "vf_graph.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-pthread", "-o", str(exe)] + srcs)
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    print(p.stdout, p.stderr[-2000:])
+    assert p.returncode == 0 and "far-factor routing ok" in p.stdout

@@ -185,7 +185,7 @@ class Sequence:
 TUNNEL_NOMINAL_EIG = 4.0e4     # scan-matching information per direction: log det of a 3x3 block = 31.8 > 28.9
 
 
-def make_sequence(seed: int, n_kf: int, vio: bool = True, lidar: bool = True, tunnel=None) -> Sequence:
+def make_sequence(seed: int, n_kf: int, vio: bool = True, lidar: bool = True, tunnel=None, keep_raw: bool = False) -> Sequence:
     """n_kf keyframes interleaving camera (20 Hz) and LiDAR (10 Hz) stamps; keyframe 0 is the
     anchor (the reference's prior node X(0), GraphManager.cpp:20-35).
 
@@ -241,7 +241,8 @@ def make_sequence(seed: int, n_kf: int, vio: bool = True, lidar: bool = True, tu
     seq = Sequence(seed, times, sensor, gt, imu_steps, np.array(off),
                    np.array(ba, dtype=np.int32)[o], np.array(bb, dtype=np.int32)[o],
                    np.array(bq).reshape(-1, 4)[o], np.array(bt).reshape(-1, 3)[o], np.array(bc)[o])
-    seq.imu_t, seq.imu_acc, seq.imu_gyro = t_imu, acc, gyr
+    if keep_raw:      # the 200 Hz stream itself (a node replay publishes it as messages); off by default: 56 bytes per sample
+        seq.imu_t, seq.imu_acc, seq.imu_gyro = t_imu, acc, gyr
     if tunnel is not None:
         seq.btw_info = np.array(bi).reshape(-1, 6)[o]
         seq.tunnel = in_tunnel

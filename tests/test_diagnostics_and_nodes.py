@@ -336,3 +336,74 @@ def test_node_defaults_to_a_fixed_lag_and_tolerates_a_missing_max_time_skip():
     assert made["lag"] == 1000 and made["capacity"] == 1192
     assert node.sensor_managers["lidar"].max_time_skip == float("inf") and node.sensor_managers["vio"].max_time_skip == 0.1
     assert any("max_time_skip" in w for w in rospy.warned)
+
+
+def test_diagnostic_node_loop_with_a_stub_tf_listener():
+    """DiagnosticNode.transform_loop (gtsam_fusion/python/diagnostics.py:33-141) end to end with a stub TF tree: waits for the
+    two frames, takes the latest common stamp, looks both poses up in the reference frame, publishes one DiagnosticMessage
+    per new stamp with the fields DiagnosticTrack computes (tf quaternions are (x, y, z, w): converted on the way in)."""
+    import threading
+    from vil_sensor_fusion_amd.ros.diagnostics_node import DiagnosticNode
+
+    class Dur:
+        def __init__(self, s):
+            self.s = s
+
+        @staticmethod
+        def from_sec(s):
+            return Dur(s)
+
+    class T:
+        def __init__(self, s=0.0):
+            self.s = s
+
+        def to_sec(self):
+            return self.s
+
+        def __add__(self, d):
+            return T(self.s + d.s)
+
+    class TF:
+        """ground truth drives along x at 2 m/s; the estimate is 0.1 m to the left and yawed by 10 mrad; stamps every 0.1 s"""
+        def __init__(self):
+            self.now, self.calls = 0.0, 0
+
+        def waitForTransform(self, a, b, t, timeout):
+            self.calls += 1
+            if self.calls > 1:
+                self.now = round(self.now + 0.1, 10)
+
+        def getLatestCommonTime(self, a, b):
+            return T(self.now)
+
+        def lookupTransform(self, ref, frame, t):
+            x = 2.0 * t.to_sec()
+            if frame == "gt":
+                return (x, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0)
+            return (x, 0.1, 0.0), (0.0, 0.0, math.sin(0.005), math.cos(0.005))
+
+    class RP(_Rospy):
+        def __init__(self, params, stop_after):
+            super().__init__(params)
+            self.Time, self.Duration, self.left = T, Dur, stop_after
+
+        def is_shutdown(self):
+            return len(self.pubs.get("~fused", [])) >= self.left
+
+        def sleep(self, d):
+            pass
+
+    rospy = RP({"diagnostics": [dict(name="fused", gt="gt", est="est", ref="world", rate=10.0)]}, stop_after=5)
+    node = DiagnosticNode(rospy, TF(), _Msg)
+    for th in node.threads:
+        th.join(timeout=10)
+        assert not th.is_alive()
+    out = rospy.pubs["~fused"]
+    assert len(out) >= 5
+    m = out[-1]
+    assert m.name == "fused" and abs(m.abs_dist_err - 0.1) < 1e-12 and abs(m.abs_rot_err - 0.01) < 1e-12
+    # (each step is expressed in the frame's own previous pose: the estimate's is the ground truth's rotated by its 10 mrad yaw)
+    assert abs(m.abs_linear_vel_err - 0.2 * 2 * math.sin(0.005)) < 1e-12 and abs(m.err.position.y - 0.1) < 1e-12 and abs(m.err.orientation.z - math.sin(0.005)) < 1e-15
+    d = [x.gt_distance for x in out]
+    assert all(abs((b - a) - 0.2) < 1e-9 for a, b in zip(d, d[1:]))          # 2 m/s x 0.1 s per published stamp
+    assert abs(out[-1].relative_dist_err - 0.1 / d[-1]) < 1e-12 and isinstance(threading.current_thread(), threading.Thread)

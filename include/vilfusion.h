@@ -248,8 +248,7 @@ int vf_engine_compact(vf_engine* e, int shift);
  * what lets a GraphManager with lag = 0 keep the whole history the way the reference's unbounded iSAM2 graph does
  * (GraphManager.cpp:17-43), for as long as the 24 KB per keyframe slot fit in HBM.  Not for sharded engines.
  * Memory: the old and the new buffers are alive together until the copies are done -- a doubling peaks at 3x the old
- * footprint.  Cost: 36 device-to-device copies per window (32 state planes + 4 arrays); meant for the one-window engine
- * of a GraphManager handle, not for growing a batch of a thousand windows in a loop. */
+ * footprint.  Cost: 36 pitched device-to-device copies (32 state planes + 4 arrays) whatever the number of windows. */
 int vf_engine_grow(vf_engine* e, int new_capacity);
 int vf_engine_sync(vf_engine* e);
 /* vf_engine_opts.use_hip_graph: is replay active (0 once a capture failed or a caller's stream was handed in), how often the

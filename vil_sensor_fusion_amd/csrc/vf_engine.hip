@@ -1174,14 +1174,17 @@ int vf_engine_grow(vf_engine* e, int new_capacity) {
     auto cp = [&](void* dst, const void* src, size_t bytes) {
         if (herr == hipSuccess) herr = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, n->stream);
     };
-    for (int w = 0; w < B; w++) {
-        const size_t s0 = (size_t)w * M0, s1 = (size_t)w * M1;          // first slot of the window, old / new
-        for (int pl = 0; pl < 32; pl++) cp(b.x + (size_t)pl * G1 + s1, a.x + (size_t)pl * G0 + s0, (size_t)M0 * sizeof(double));
-        cp(b.imu_in + (s1 / 64) * vf::IMU_IN * 64, a.imu_in + (s0 / 64) * vf::IMU_IN * 64, (size_t)(M0 / 64) * vf::IMU_IN * 64 * sizeof(double));
-        cp(b.btw_in + (s1 / 64) * vf::BTW_IN * 64, a.btw_in + (s0 / 64) * vf::BTW_IN * 64, (size_t)(M0 / 64) * vf::BTW_IN * 64 * sizeof(double));
-        cp(b.btw_a + s1, a.btw_a + s0, (size_t)M0 * sizeof(int));
-        cp(b.delta + s1 * 15, a.delta + s0 * 15, (size_t)M0 * 15 * sizeof(double));
-    }
+    // a per-window array with `unit` bytes per keyframe slot is B rows of M0 * unit bytes, pitch M0 -> M1 slots: ONE pitched copy
+    // per array (36 calls whatever the number of windows; the first version issued 36 copies per window)
+    auto cp2 = [&](void* dst, const void* src, size_t unit) {
+        if (herr == hipSuccess)
+            herr = hipMemcpy2DAsync(dst, (size_t)M1 * unit, src, (size_t)M0 * unit, (size_t)M0 * unit, (size_t)B, hipMemcpyDeviceToDevice, n->stream);
+    };
+    for (int pl = 0; pl < 32; pl++) cp2(b.x + (size_t)pl * G1, a.x + (size_t)pl * G0, sizeof(double));     // state planes [2][16][G]
+    cp2(b.imu_in, a.imu_in, vf::IMU_IN * sizeof(double));        // AoSoA tiles of 64 slots: whole tiles move (M0, M1 are multiples of 64)
+    cp2(b.btw_in, a.btw_in, vf::BTW_IN * sizeof(double));
+    cp2(b.btw_a, a.btw_a, sizeof(int));
+    cp2(b.delta, a.delta, 15 * sizeof(double));
     struct { void* d; const void* s; size_t bytes; } per_window[] = {
         {b.prior_k, a.prior_k, B * sizeof(int)}, {b.prior_in, a.prior_in, (size_t)B * vf::PRIOR_IN * sizeof(double)},
         {b.mp_on, a.mp_on, B * sizeof(int)}, {b.mp_x, a.mp_x, (size_t)B * 48 * sizeof(double)}, {b.mp_L, a.mp_L, (size_t)B * 729 * sizeof(double)},

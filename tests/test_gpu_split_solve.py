@@ -47,3 +47,38 @@ def test_split_solve_is_bit_identical_to_the_fused_kernel():
     same(2)
     fused.close()
     split.close()
+
+
+def test_default_threshold_uses_the_split_form_from_2048_windows_on():
+    """vf_engine_opts.solve_split_min defaults to 2048: a 2048-window engine left at its defaults runs k_band_forward +
+    k_band_backward, also behind the termination rule's gate (hybrid K4), and gives the bits of the fused kernel."""
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    n, B = 48, 2048
+    seqs = [synth.make_sequence(seed=720 + i, n_kf=n + 2) for i in range(4)]
+    engines = []
+    for split in (None, 0):                       # library default (2048) / never
+        eng = Engine(EngineOpts(windows=B, capacity=n + 2, solve_split_min=split))
+        recs = [synth.between_records(s) for s in seqs]
+        for w in range(B):
+            s = seqs[w % 4]
+            eng.preintegrate(w, 1, s.imu_off[1:n + 1], s.imu_steps, np.zeros(6), synth.CARLA_IMU_COV)
+            m = s.btw_b < n
+            eng.set_between(w, s.btw_a[m], s.btw_b[m], recs[w % 4][m])
+            eng.set_states(w, 0, s.gt_states[0].reshape(1, 16))
+            eng.set_prior(w, 0, synth.prior_record(s.gt_states[0], REFERENCE_PRIOR_SIGMAS))
+            eng.set_range(w, 0, 1)
+        eng.predict(-1, 1, n - 1)
+        for w in range(B):
+            eng.set_range(w, 0, n - (w % 5))
+        eng.iterate(6)
+        eng.set_convergence(1e-5, 1e-5)
+        eng.iterate(4)
+        engines.append(eng)
+    a, b = engines
+    for w in (0, 1, 517, 1023, 2047):
+        m = n - (w % 5)
+        np.testing.assert_array_equal(a.get_states(w, 0, m), b.get_states(w, 0, m))
+        assert a.read_lm(w) == b.read_lm(w)
+    assert a.time_stage("solve", 2) > 0
+    a.close()
+    b.close()

@@ -8,6 +8,8 @@ every consumer rebuilds the same problem from the seed; nothing of oracle/vf_ora
 
   qr_twin_n200.npz       BASELINE configs[1]: full VIL (IMU + VIO + LiDAR between factors), one 200-pose window, batch
                          optimum from the IMU dead-reckoning start (seed 11)
+  qr_twin_tunnel.npz     BASELINE configs[3]: the LiDAR-degenerate tunnel sequence (seed 41, 400 poses, 20 % of the LiDAR
+                         between factors with 1e-6 x the nominal information along the track): batch optimum
   qr_twin_fixed_lag.npz  the window of bench.py's GPU window 0 (seed 0, sequence length 1065 = what bench.py generates for
                          its defaults and for the driver's --steps 20 --warmup 5): the 1000-pose batch optimum
                          (BASELINE configs[2], update 0) and the window after u = 1..25 marginalised fixed-lag updates
@@ -36,8 +38,8 @@ BENCH_SEED, BENCH_WINDOW, BENCH_SEQ_LEN = 0, 1000, 1065
 WORKERS = min(8, os.cpu_count() or 1)
 
 
-def problem_inputs(seed, n_kf, count):
-    seq = synth.make_sequence(seed=seed, n_kf=n_kf)
+def problem_inputs(seed, n_kf, count, **kw):
+    seq = synth.make_sequence(seed=seed, n_kf=n_kf, **kw)
     t0 = time.time()
     imu = tq.twin_records(seq, synth.CARLA_IMU_COV, count=count, workers=WORKERS)
     print(f"seed {seed}: {count - 1} IMU factors preintegrated by the twin in {time.time() - t0:.1f} s", flush=True)
@@ -55,6 +57,17 @@ def main():
         log = P.optimize(max_iterations=400, verbose=True)
         np.savez(os.path.join(HERE, "qr_twin_n200.npz"), seed=11, n=200, states=P.st.to_array(), final_cost=log["final_cost"],
                  iterations=log["iterations"], polish_steps=np.array(log["polish_steps"]), imu_records=imu)
+
+    # ---- configs[3]: the tunnel sequence, batch
+    if "--skip-tunnel" not in sys.argv:
+        seq, imu, ba, bb, brec, prior = problem_inputs(41, 400, 400, tunnel=(0.4, 0.6, 1e-6))
+        x0 = tq.dead_reckon(seq.gt_states[0], imu)
+        P = tq.Problem(x0, np.arange(1, 400), imu[1:], ba, bb, brec, 0, prior)
+        log = P.optimize(max_iterations=400, verbose=True)
+        np.savez(os.path.join(HERE, "qr_twin_tunnel.npz"), seed=41, n=400, tunnel=np.array([0.4, 0.6, 1e-6]), states=P.st.to_array(),
+                 final_cost=log["final_cost"], iterations=log["iterations"], polish_steps=np.array(log["polish_steps"]))
+    if "--skip-fixed-lag" in sys.argv:
+        return
 
     # ---- bench window 0: 1000-pose batch optimum, then 25 marginalised updates
     total = BENCH_WINDOW + max(UPDATES) + 1

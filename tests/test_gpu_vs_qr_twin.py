@@ -84,3 +84,19 @@ def test_fixed_lag_updates_vs_independent_qr_optimum(form):
           f"{res[None][1]:.3e} m (accept_rel 1e-9); strict rule: {res[0.0][0]:.3e} / {res[0.0][1]:.3e} m; marginal information rel. diff {res[None][2]:.1e}")
     assert res[None][1] <= 1e-8 and res[0.0][1] <= 1e-6
     assert res[None][2] <= 1e-6
+
+
+@pytest.mark.parametrize("form", ["partitioned", "one_wave_sweep"])
+def test_config3_tunnel_sequence_vs_independent_qr_optimum(form):
+    """BASELINE configs[3]: the LiDAR-degenerate tunnel sequence, batch LM from the dead-reckoning start, against the optimum
+    the QR twin found for it (tests/golden/qr_twin_tunnel.npz)."""
+    F = np.load(os.path.join(GOLD, "qr_twin_tunnel.npz"))
+    n = int(F["n"])
+    seq = synth.make_sequence(seed=int(F["seed"]), n_kf=n, tunnel=tuple(F["tunnel"]))
+    opts = dict(chunks=1, sweep_two_sided_max=0) if form == "one_wave_sweep" else {}
+    eng = _engine(None, [seq], n, 0, **opts)
+    eng.iterate(150)
+    a, r = helpers.ate(eng.get_states(0, 0, n), F["states"])
+    print(f"configs[3] tunnel, {form}: HIP vs independent QR optimum: ATE {a:.3e} m, rot {r:.3e} rad")
+    assert a <= 1e-8 and r <= 1e-6 and eng.read_lm(0)["solve_failures"] == 0
+    eng.close()

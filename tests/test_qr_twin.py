@@ -178,3 +178,18 @@ def test_c_oracle_fixed_lag_updates_against_the_independent_optimum(oracle, acce
     print(f"accept_rel {accept_rel}: C oracle vs independent QR optimum over {int(max(F['updates']))} updates: batch {a0:.3e} m, worst {worst:.3e} m")
     assert worst <= (1e-9 if accept_rel is None else 1e-6)
     assert float(np.max(F["last_polish_step_per_update"])) < 1e-10       # the fixture itself is converged
+
+
+def test_c_oracle_reaches_the_independent_optimum_on_the_tunnel_sequence(oracle):
+    """BASELINE configs[3]: the LiDAR-degenerate tunnel (anisotropic between-factor noise: 1e-6 x the nominal information along
+    the track for 20 % of the sequence) -- the weakly constrained direction is where a normal-equation solver and a QR
+    solver would part first.  C oracle (LM, Cholesky) against the independent QR optimum."""
+    F = np.load(os.path.join(GOLD, "qr_twin_tunnel.npz"))
+    n = int(F["n"])
+    seq = synth.make_sequence(seed=int(F["seed"]), n_kf=n, tunnel=tuple(F["tunnel"]))
+    prob = helpers.build_problem(oracle, seq)
+    win = helpers.oracle_window(oracle, prob)
+    win.lm(iterations=150)
+    a, r = helpers.ate(win.states, F["states"])
+    print(f"tunnel, n = {n}: C oracle vs independent QR optimum: ATE {a:.3e} m, rot {r:.3e} rad (twin's last Gauss-Newton step {F['polish_steps'][-1]:.1e})")
+    assert a <= 1e-8 and r <= 1e-6 and F["polish_steps"][-1] < 1e-10

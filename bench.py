@@ -721,6 +721,7 @@ def main():
             # latency of the same update on ONE window (what a single vehicle sees)
             sv = argparse.Namespace(**vars(args))
             one, one_feed = make_engine(sv, gpu, 1, one_seq, one_updates)
+            fed[id(one)] = 0            # (ids of closed engines can be reused: every engine starts its feed explicitly)
             for _ in range(2):
                 one_step(one, one_feed)
             one.sync()
@@ -736,6 +737,7 @@ def main():
             # bit-identical, tests/test_gpu_hip_graph.py): what replay does to the one-window latency
             try:
                 g1, g1_feed = make_engine(sv, gpu, 1, one_seq, one_updates, use_hip_graph=True)
+                fed[id(g1)] = 0
                 for _ in range(2):
                     one_step(g1, g1_feed)
                 g1.sync()

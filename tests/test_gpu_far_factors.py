@@ -135,3 +135,44 @@ def test_graph_manager_takes_any_pair_of_keys(oracle, compat):
         gm.addBetweenFactor(50, 70, (recs[0][0:4], recs[0][4:7]), np.eye(6))
     assert ei.value.code == -6
     gm.close()
+
+
+@pytest.mark.parametrize("lag", [0, 40])
+def test_far_factors_survive_compaction_and_growth(lag):
+    """The far list lives in window-local slots on the device and in absolute keys in the GraphManager: a handle whose engine
+    compacts (fixed lag, 64 slots) or grows (whole history, 64 initial slots) while far factors are alive must publish what a
+    roomy handle publishes; in fixed-lag mode the factors also age out of the window one after the other."""
+    from tests.test_gpu_graph_manager import _stream
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    n = 230
+    seq = synth.make_sequence(74, n)
+    traj_t, acc, gyr = _stream(seq)
+    rng = np.random.default_rng(9)
+    # a span-8 factor every 14 keyframes (they age out of the 40-keyframe lag); whole history: every 28, i.e. VF_MAX_EXTRA = 8 in all
+    far = {k: _far_record(seq, k - 8, k, rng) for k in range(20, n, 14 if lag else 28)}
+    assert lag or len(far) == 8
+    outs = []
+    for cap in (128 if lag else 64, 512):       # (fixed lag: slots are reclaimed in whole tiles of 64 below the window)
+        gm = GraphManager(capacity=cap, iterations=4, lag=lag, rel_tol=0, abs_tol=0)
+        gm.setInitialState(seq.gt_states[0])
+        out, i_imu = [], 0
+        for k in range(1, n):
+            while i_imu < traj_t.size and traj_t[i_imu] <= seq.kf_time[k] + 0.01:
+                gm.addIMUMeasurement(traj_t[i_imu], acc[i_imu], gyr[i_imu]); i_imu += 1
+            gm.reserveNode(seq.kf_time[k])
+            for a, b, q, t, c in zip(seq.btw_a, seq.btw_b, seq.btw_q, seq.btw_t, seq.btw_cov):
+                if b == k and a >= 1:
+                    gm.addBetweenFactor(int(a), int(b), (q, t), np.eye(6) * c)
+            if k in far:
+                gm.addBetweenFactor(k - 8, k, (far[k][0:4], far[k][4:7]), np.eye(6) * 0.05)
+            if k % 2 == 0:
+                gm.solve()
+                (q, t), v, b = gm.getState()
+                out.append(np.concatenate([q, t, v, b]))
+        outs.append(np.array(out))
+        gm.close()
+    small, big = outs
+    assert small.shape == big.shape and np.isfinite(small).all()
+    d = np.abs(small - big).max()
+    print(f"lag {lag}: small handle (compacting / growing with far factors alive) vs a 512-slot one: largest difference {d:.3e}")
+    assert d <= 1e-8

@@ -176,3 +176,28 @@ def test_far_factors_survive_compaction_and_growth(lag):
     d = np.abs(small - big).max()
     print(f"lag {lag}: small handle (compacting / growing with far factors alive) vs a 512-slot one: largest difference {d:.3e}")
     assert d <= 1e-8
+
+
+def test_far_factors_under_hip_graph_replay():
+    """the Woodbury solve (6 extra band solves per slot in use, memsets, the combine kernel) is part of the launch sequence a
+    use_hip_graph engine captures: replayed, it gives the bits of plain launches, and changing the list re-captures"""
+    n = 120
+    seq = synth.make_sequence(seed=93, n_kf=n)
+    rng = np.random.default_rng(3)
+    recs = np.array([_far_record(seq, 10, 100, rng), _far_record(seq, 30, 37, rng)])
+    from tests.test_gpu_ingest import _engine
+    eager, graph = _engine(None, [seq], n, 0), _engine(None, [seq], n, 0, use_hip_graph=True)
+    for e in (eager, graph):
+        e.set_extra_between(0, [10], [100], recs[:1])
+        e.iterate(6)
+        e.iterate(6)
+    np.testing.assert_array_equal(eager.get_states(0, 0, n), graph.get_states(0, 0, n))
+    for e in (eager, graph):
+        e.set_extra_between(0, [10, 30], [100, 37], recs)
+        e.iterate(6)
+    np.testing.assert_array_equal(eager.get_states(0, 0, n), graph.get_states(0, 0, n))
+    assert eager.read_lm(0) == graph.read_lm(0)
+    enabled, captures, replays = graph.graph_info()
+    assert enabled and replays == 3 and captures == 2
+    eager.close()
+    graph.close()

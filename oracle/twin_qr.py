@@ -93,6 +93,40 @@ def se3_log(R, t):
     return torch.cat([vee(L[..., :3, :3]), L[..., :3, 3]], -1)
 
 
+# ---------------------------------------------------------------- the Pose3 chart (a GTSAM BUILD OPTION the reference does not pin)
+# "expmap": Pose3 retract / localCoordinates by the full SE(3) exponential / logarithm (GTSAM_POSE3_EXPMAP + GTSAM_ROT3_EXPMAP,
+#   the defaults from 4.1 on) -- what the device, the C oracle and every fixture use.
+# "first_order_cayley": the 4.0.x defaults -- Pose3::FIRST_ORDER (retract (R Retract(w), t + R v), local (Local(R), t)) with
+#   Rot3::CAYLEY for rotation matrices (Retract(w) = (I - W/2)^-1 (I + W/2), its inverse for Local).  Only this module can switch
+#   (automatic differentiation makes the Jacobians follow): it measures what the unpinned option is worth in metres
+#   (tests/test_qr_twin.py::test_what_the_unpinned_pose3_chart_is_worth).
+POSE3_CHART = "expmap"
+
+
+def cayley(w):
+    I = torch.eye(3, dtype=w.dtype)
+    A = 0.5 * hat(w)
+    return torch.linalg.inv(I - A) @ (I + A)
+
+
+def cayley_inv(R):
+    I = torch.eye(3, dtype=R.dtype)
+    return 2.0 * vee((R - I) @ torch.linalg.inv(R + I))
+
+
+def pose_exp(xi):
+    """Pose3 chart at the origin, tangent [omega, v] -> (R, t)"""
+    if POSE3_CHART == "expmap":
+        return se3_exp(xi)
+    return cayley(xi[..., :3]), xi[..., 3:]
+
+
+def pose_log(R, t):
+    if POSE3_CHART == "expmap":
+        return se3_log(R, t)
+    return torch.cat([cayley_inv(R), t], -1)
+
+
 def quat_to_rot(q):
     q = q / torch.linalg.norm(q, dim=-1, keepdim=True)
     w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
@@ -146,7 +180,7 @@ class States:
         """Values::retract: Pose3 x Exp(d[0:6]) (full exponential), velocity and bias add; rotations re-orthonormalised
         (polar factor) so that rounding does not accumulate over the iterations"""
         d = torch.as_tensor(delta).reshape(self.n, DOF)
-        dR, dt = se3_exp(d[:, :6])
+        dR, dt = pose_exp(d[:, :6])
         R = self.R @ dR
         U, _, Vh = torch.linalg.svd(R)
         return States(U @ Vh, self.t + (self.R @ dt.unsqueeze(-1)).squeeze(-1), self.v + d[:, 6:9], self.b + d[:, 9:15])
@@ -156,7 +190,7 @@ class States:
 
 
 def _retract_one(R, t, v, b, d):
-    dR, dt = se3_exp(d[:6])
+    dR, dt = pose_exp(d[:6])
     return R @ dR, t + R @ dt, v + d[6:9], b + d[9:15]
 
 
@@ -183,20 +217,20 @@ def _imu_res(d, Ri, ti, vi, bi, Rj, tj, vj, bj, rec, W, g):
 
 def _btw_res(d, Ra, ta, Rb, tb, rec, W):
     """whitened BetweenFactor<Pose3> residual at (x_a Exp(d[:6]), x_b Exp(d[6:])): Logmap(measured^-1 (T_a^-1 T_b))"""
-    dRa, dta = se3_exp(d[:6])
-    dRb, dtb = se3_exp(d[6:])
+    dRa, dta = pose_exp(d[:6])
+    dRb, dtb = pose_exp(d[6:])
     Ra, ta = Ra @ dRa, ta + Ra @ dta
     Rb, tb = Rb @ dRb, tb + Rb @ dtb
     Rm, tm = quat_to_rot(rec[0:4]), rec[4:7]
     Rh, th = Ra.T @ Rb, Ra.T @ (tb - ta)
-    return W @ se3_log(Rm.T @ Rh, Rm.T @ (th - tm))
+    return W @ pose_log(Rm.T @ Rh, Rm.T @ (th - tm))
 
 
 def _prior_res(d, R, t, v, b, rec):
     """the three priors of GraphManager.cpp:27-35 on one keyframe: Local(prior, x) / sigma"""
     R, t, v, b = _retract_one(R, t, v, b, d)
     Rp, tp = quat_to_rot(rec[0:4]), rec[4:7]
-    xi = se3_log(Rp.T @ R, Rp.T @ (t - tp))
+    xi = pose_log(Rp.T @ R, Rp.T @ (t - tp))
     return torch.cat([xi, v - rec[7:10], b - rec[10:16]]) / rec[16:31]
 
 

@@ -1,6 +1,7 @@
 /* Minimal C caller of libvilfusion.so through include/vilfusion.h: what a non-Python host (the reference's C++ node, a
  * cgo / JNI binding) does.  Feeds a vehicle at rest for one second -- IMU at 200 Hz, a keyframe every 50 ms with an
- * identity odometry factor between consecutive keyframes -- and prints the estimate after each solve.
+ * identity odometry factor between consecutive keyframes, plus one loop closure between keyframes 12 apart (a "far" factor:
+ * GraphManager::addBetweenFactor takes any pair of keys, GraphManager.cpp:83-88) -- and prints the estimate after each solve.
  *
  *   gcc -I include examples/minimal.c -L vil_sensor_fusion_amd -lvilfusion -Wl,-rpath,$PWD/vil_sensor_fusion_amd -o /tmp/minimal
  *
@@ -46,6 +47,7 @@ int main(void) {
         uint64_t key = 0;
         if ((rc = vf_reserve_node(g, t, &key))) goto fail;
         if (prev && (rc = vf_add_between(g, prev, key, q_id, t0, cov))) goto fail;
+        if (key == 15 && (rc = vf_add_between(g, 3, key, q_id, t0, cov))) goto fail;    /* a place revisited: keys 3 and 15 */
         prev = key;
         if ((rc = vf_solve(g))) goto fail;
     }

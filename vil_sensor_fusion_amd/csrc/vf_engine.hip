@@ -74,6 +74,8 @@ struct vf_engine {
     double* stage = nullptr;  // device staging buffer (AoS)
     size_t stage_bytes = 0;
     double* sigma_dev = nullptr;
+    double sigma_host[15] = {0};    // what sigma_dev holds (vf_engine_slide uploads only a changed set)
+    bool sigma_valid = false;
     int* status_dev = nullptr;
     std::vector<int> h_lo, h_hi;  // host mirror of the active ranges
     // Warm start of vf_engine_iterate: true from the end of a solve until any entry point other than vf_engine_slide
@@ -1052,10 +1054,17 @@ int vf_engine_slide(vf_engine* e, const double* prior_sigma15, int marginalize) 
         if (rc) return rc;
     }
     if (e->warm) e->slid++;   // a slide is a change a warm start knows how to follow
-    HIPCHK(hipMemcpyAsync(e->sigma_dev, prior_sigma15, 15 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    // the sigmas are a caller temporary: uploaded (and waited for) only when they differ from what the device already holds, so
+    // that a run of updates with the same sigmas -- every fixed-lag loop -- enqueues without a host synchronisation
+    const bool fresh_sigma = !e->sigma_valid || memcmp(e->sigma_host, prior_sigma15, sizeof(e->sigma_host)) != 0;
+    if (fresh_sigma) {
+        HIPCHK(hipMemcpyAsync(e->sigma_dev, prior_sigma15, 15 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        memcpy(e->sigma_host, prior_sigma15, sizeof(e->sigma_host));
+        e->sigma_valid = true;
+    }
     vf::launch_slide(e->v, e->sigma_dev, marginalize ? 0 : 1, e->stream);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(e->stream));  // sigma is a caller temporary
     for (int w = 0; w < e->v.B; w++) { e->h_lo[w]++; e->h_hi[w]++; }
     return VF_OK;
 }

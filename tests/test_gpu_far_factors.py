@@ -201,3 +201,28 @@ def test_far_factors_under_hip_graph_replay():
     assert enabled and replays == 3 and captures == 2
     eager.close()
     graph.close()
+
+
+@pytest.mark.parametrize("cov", [1e-6, 10.0])
+def test_far_factor_information_extremes(oracle, cov):
+    """The Woodbury correction loses digits when U^T A^-1 U dwarfs the identity (a loop closure a million times stronger than
+    the odometry) -- but an inexact step only slows the iteration down, the fixed point is g = 0 whatever the solve's
+    accuracy: a very strong and a very weak far factor both end at the oracle's optimum."""
+    n = 160
+    seq = synth.make_sequence(seed=95, n_kf=n)
+    prob = helpers.build_problem(oracle, seq, perturb=0.002)
+    rng = np.random.default_rng(8)
+    rec = _far_record(seq, 15, 140, rng, cov=cov, noise=(1e-4, 1e-3))[None]
+    eng = Engine(EngineOpts(windows=1, capacity=n))
+    helpers.load_engine(eng, 0, prob)
+    eng.set_extra_between(0, [15], [140], rec)
+    eng.iterate(40)
+    p = dict(prob, btw_a=np.concatenate([prob["btw_a"], [15]]).astype(np.int32), btw_b=np.concatenate([prob["btw_b"], [140]]).astype(np.int32),
+             btw=np.vstack([prob["btw"], rec]))
+    win = helpers.oracle_window(oracle, p)
+    costs, _, _ = win.lm(iterations=40)
+    a, r = helpers.ate(eng.get_states(0, 0, n), win.states)
+    lm = eng.read_lm(0)
+    print(f"far factor with covariance {cov:g}: ATE vs oracle {a:.3e} m, cost {lm['cost']:.9e} vs {costs[-1]:.9e}, accepted {lm['accepted']} rejected {lm['rejected']}")
+    assert a <= 1e-6 and r <= 1e-6 and lm["solve_failures"] == 0 and abs(lm["cost"] - costs[-1]) <= 1e-7 * abs(costs[-1])
+    eng.close()

@@ -321,13 +321,13 @@ constexpr JMap make_jmap() {
 constexpr JMap JM = make_jmap();
 static_assert(JM.n[0] == JS_NI && JM.n[1] == JS_NJ, "J stream sizes");
 __device__ constexpr JMap JMD = make_jmap();             // the same tables in device memory, for run-time indexed reads
-VF_DI const double* jtile_ptr(const double* base, long gk) { return base + (size_t)(gk >> 3) * JT_STRIDE; }
+VF_DI const double* jtile_ptr(const double* base, long gk) { return base + (size_t)(gk >> JT_LOG) * JT_STRIDE; }
 // entry (row, col) of the Jacobian of the factor in slot gk of a J stream buffer (0 for a structural zero)
 VF_DI double jstream_entry(const double* jbuf, long gk, int row, int col) {
     const int e = JMD.idx[row * 30 + col];
     if (e < 0) return 0.0;
     const int pair = (jcol_is_j(col) ? JS_PI : 0) + (e >> 1);
-    return jbuf[(size_t)(gk >> 3) * JT_STRIDE + ((size_t)pair * JT + (gk & 7)) * 2 + (e & 1)];
+    return jbuf[(size_t)(gk >> JT_LOG) * JT_STRIDE + ((size_t)pair * JT + (gk & (JT - 1))) * 2 + (e & 1)];
 }
 
 // Where a factor's (r | J) goes.  K1: r into the AoSoA residual array, J into the factor's slot of its J-stream tile as
@@ -541,10 +541,10 @@ __device__ __forceinline__ void linearize_imu_factor(const View& v, int which, c
     if (k <= w_lo || k >= w_hi || w_done) return;
     const bool jac = !SH || !shard_skips_factor(v, w, k);
     const int b = w_sel ^ which;
-    double* jbuf = v.imu_j + (size_t)b * (size_t)(v.G >> 3) * JT_STRIDE;
+    double* jbuf = v.imu_j + (size_t)b * (size_t)(v.G >> JT_LOG) * JT_STRIDE;
     HbmSink sink;
     sink.out_r = v.imu_r + ((size_t)b * (size_t)(v.G >> 6) + (size_t)(gk >> 6)) * IMU_R * TILE + (gk & 63);
-    sink.slot = jbuf + (size_t)(gk >> 3) * JT_STRIDE + (gk & 7) * 2;
+    sink.slot = jbuf + (size_t)(gk >> JT_LOG) * JT_STRIDE + (gk & (JT - 1)) * 2;
     sink.jac = jac;
     linearize_imu_core(v, b, gk, sink);
 }
@@ -897,7 +897,7 @@ __host__ __device__ constexpr bool imu_field_is_zero(int f) {
     return r >= 10 + (c - 18) % 6;
 }
 #ifndef VF_K3_AT
-#define VF_K3_AT 8
+#define VF_K3_AT (1 << VF_JT_LOG)
 #endif
 #ifndef VF_K3_NT
 #define VF_K3_NT 256
@@ -1150,7 +1150,7 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
         constexpr int NOWN = JS_PAIRS * JT, NALL = NOWN + JS_PI, NJ = (NALL + K3_NT - 1) / K3_NT,
                       NB = ((AT + 3) * BTW_OUT + K3_NT - 1) / K3_NT;
         static_assert(AT == JT, "K3 tiles are the tiles of the J stream");
-        const d2_t* jt = (const d2_t*)(v.imu_j + ((size_t)b * (size_t)(v.G >> 3) + (size_t)(gk0 >> 3)) * JT_STRIDE);
+        const d2_t* jt = (const d2_t*)(v.imu_j + ((size_t)b * (size_t)(v.G >> JT_LOG) + (size_t)(gk0 >> JT_LOG)) * JT_STRIDE);
         const bool halo_ok = k0 + AT > lo && k0 + AT < hi;          // (then the next tile exists: k0 + AT < M)
         d2_t tj[NJ];
 #pragma unroll
@@ -1193,8 +1193,8 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
             const int e = it * K3_NT + tid;
             if (e < NALL) {
                 const int own = e < NOWN;
-                const int pr = own ? e >> 3 : e - NOWN;
-                const int fac = own ? e & 7 : AT;
+                const int pr = own ? e >> JT_LOG : e - NOWN;
+                const int fac = own ? e & (JT - 1) : AT;
                 const int kf = k0 + fac;
                 d2_t x = tj[it];
                 if (!(kf > lo && kf < hi)) { x.x = 0.0; x.y = 0.0; }        // factor outside the window: zeros
@@ -2693,7 +2693,7 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
     __shared__ double A[42 * 43];
     __shared__ double bv[42];
     const double* imu = v.imu_r + (size_t)b * tiles * IMU_R * TILE + (size_t)((g0 + 1) >> 6) * IMU_R * TILE + ((g0 + 1) & 63);   // residual
-    const double* jbuf = v.imu_j + (size_t)b * (size_t)(v.G >> 3) * JT_STRIDE;
+    const double* jbuf = v.imu_j + (size_t)b * (size_t)(v.G >> JT_LOG) * JT_STRIDE;
     const bool has_prior = v.prior_k[w] == lo;
     const bool has_mp = v.mp_on[w] != 0;
     const double* Pq = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT;
@@ -2854,7 +2854,7 @@ __global__ void k_gather_imu_lin(View v, int b, long g0, long n, double* aos) {
     const int f = (int)(i - rec * IMU_OUT);
     const long g = g0 + rec;
     if (f < IMU_R) aos[i] = v.imu_r[((size_t)b * (size_t)(v.G >> 6) + (size_t)(g >> 6)) * IMU_R * TILE + (size_t)f * TILE + (g & 63)];
-    else aos[i] = jstream_entry(v.imu_j + (size_t)b * (size_t)(v.G >> 3) * JT_STRIDE, g, (f - 15) / 30, (f - 15) % 30);
+    else aos[i] = jstream_entry(v.imu_j + (size_t)b * (size_t)(v.G >> JT_LOG) * JT_STRIDE, g, (f - 15) / 30, (f - 15) % 30);
 }
 __global__ void k_scatter_states(const double* aos, double* x, long G, int buf, long g0, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

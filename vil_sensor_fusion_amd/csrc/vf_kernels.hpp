@@ -16,7 +16,10 @@ constexpr int IMU_OUT = 465;    // r(15), J(15x30 row-major): the documented (ho
 //          128-B lines (146 of them per factor instead of 291 8-byte ones); a K3 workgroup copies ONE contiguous 18.7 KB
 //          block into LDS as it is, plus the i-side pairs of its halo factor (slot 0 of the next tile).
 constexpr int IMU_R = 15;
-constexpr int JT = 8;                               // keyframe slots per J tile (= K3's tile)
+#ifndef VF_JT_LOG
+#define VF_JT_LOG 3
+#endif
+constexpr int JT_LOG = VF_JT_LOG, JT = 1 << JT_LOG; // keyframe slots per J tile (= K3's tile): 8
 constexpr int JS_NI = 147, JS_NJ = 144;             // non-zero entries of the i-side / j-side columns
 constexpr int JS_PI = (JS_NI + 1) / 2, JS_PJ = (JS_NJ + 1) / 2, JS_PAIRS = JS_PI + JS_PJ;   // 74 + 72 pairs
 constexpr int JT_STRIDE = JS_PAIRS * JT * 2;        // 2336 doubles = 146 lines per tile

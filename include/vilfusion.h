@@ -376,7 +376,9 @@ int vf_add_between(vf_graph* g, uint64_t prev_key, uint64_t cur_key, const doubl
  * vf_get_imu_factor returns) instead of cutting one from the IMU buffer.  key must be the next key (current + 1); the
  * node time advances by the record's deltaTij. */
 int vf_add_imu_factor(vf_graph* g, uint64_t key, const double* rec190);
-/* GraphManager::solve (GraphManager.cpp:101-141) */
+/* GraphManager::solve (GraphManager.cpp:101-141).  With a fixed lag, a between factor (band or far) added after its older
+ * key has left the window is late odometry: the solve drops it, returns VF_ERR_BAD_KEY once, gives everything else it had
+ * taken back to the queues, and the next vf_solve runs on the rest. */
 int vf_solve(vf_graph* g);
 /* GraphManager::getState / getBias / getMostRecentPoseTime (GraphManager.cpp:164-178, 71-75) */
 int vf_get_state(vf_graph* g, double q[4], double t[3], double v[3], double bias[6]);

@@ -10,6 +10,10 @@ every consumer rebuilds the same problem from the seed; nothing of oracle/vf_ora
                          optimum from the IMU dead-reckoning start (seed 11)
   qr_twin_tunnel.npz     BASELINE configs[3]: the LiDAR-degenerate tunnel sequence (seed 41, 400 poses, 20 % of the LiDAR
                          between factors with 1e-6 x the nominal information along the track): batch optimum
+  qr_twin_10k.npz        BASELINE configs[4]: the 10 000-pose global smoother window bench.py spreads in time over the ranks
+                         (seed 4242): batch optimum, started from the ground truth (from IMU dead reckoning a window of
+                         333 s needs hundreds of LM trials; the optimum does not depend on the start); poses only
+                         (--with-10k: 30 more minutes of twin preintegration)
   qr_twin_fixed_lag.npz  the window of bench.py's GPU window 0 (seed 0, sequence length 1065 = what bench.py generates for
                          its defaults and for the driver's --steps 20 --warmup 5): the 1000-pose batch optimum
                          (BASELINE configs[2], update 0) and the window after u = 1..25 marginalised fixed-lag updates
@@ -66,6 +70,14 @@ def main():
         log = P.optimize(max_iterations=400, verbose=True)
         np.savez(os.path.join(HERE, "qr_twin_tunnel.npz"), seed=41, n=400, tunnel=np.array([0.4, 0.6, 1e-6]), states=P.st.to_array(),
                  final_cost=log["final_cost"], iterations=log["iterations"], polish_steps=np.array(log["polish_steps"]))
+    # ---- configs[4]: the 10 000-pose window
+    if "--with-10k" in sys.argv:
+        n = 10000
+        seq, imu, ba, bb, brec, prior = problem_inputs(4242, n, n)
+        P = tq.Problem(seq.gt_states, np.arange(1, n), imu[1:], ba, bb, brec, 0, prior)
+        log = P.optimize(max_iterations=100, verbose=True)
+        np.savez(os.path.join(HERE, "qr_twin_10k.npz"), seed=4242, n=n, poses=P.st.to_array()[:, :7], final_cost=log["final_cost"],
+                 iterations=log["iterations"], polish_steps=np.array(log["polish_steps"]))
     if "--skip-fixed-lag" in sys.argv:
         return
 

@@ -53,6 +53,16 @@ int main() {
     CHECK(vf_add_between(g, 50, 58, q, t3, eye) == VF_OK);        // room again
     CHECK(vf_solve(g) == VF_OK);
     CHECK(fake_extra_n.load() == 1);
+    // late odometry on a far pair: the older key left the window before the factor was added -> the next solve drops it and
+    // says so once (as for a late band factor), keeps everything else, and the solve after that is clean
+    CHECK(vf_add_between(g, 20, 60, q, t3, eye) == VF_OK);
+    const uint64_t k62 = node();
+    CHECK(vf_add_between(g, k62 - 1, k62, q, t3, eye) == VF_OK);
+    CHECK(vf_solve(g) == VF_ERR_BAD_KEY);
+    vf_graph_staged(g, &staged, &queued);
+    CHECK(staged == 1 && queued == 1);                             // given back: the band factor and the queued IMU factor
+    CHECK(vf_solve(g) == VF_OK);
+    CHECK(fake_extra_n.load() == 1);
     vf_destroy(g);
     printf("far-factor routing ok\n");
     return 0;

@@ -373,6 +373,9 @@ int vf_solve(vf_graph* g) {
     uint64_t last_key;
     double last_time;
     int staged_before;
+    bool late_far = false;          // a far factor added since the last solve whose older key had already left the window
+    unsigned long long late_a = 0, late_b = 0;
+    int late_n = 0;
     std::lock_guard<std::mutex> solve_lk(g->solve_mutex);
     {
         std::lock_guard<std::mutex> lk(g->graph_mutex);
@@ -383,15 +386,22 @@ int vf_solve(vf_graph* g) {
             g->band_end[bt.b] = 1;
         }
         // far factors whose older key has left the window (as of the previous solve: lo / key_base change under solve_mutex,
-        // which this thread holds) are gone for good: their information is dropped, not marginalised
+        // which this thread holds) are gone for good: their information is dropped, not marginalised.  One that was added
+        // SINCE that solve never made it into the window: late odometry, reported like a late band factor below
         {
             const uint64_t oldest = g->key_base + (uint64_t)g->lo;
             auto& fb = g->far_between;
+            for (size_t i = fb.size() - (size_t)g->far_new; i < fb.size(); i++)
+                if (fb[i].a < oldest) {
+                    if (!late_far) { late_a = fb[i].a; late_b = fb[i].b; }
+                    late_far = true;
+                    late_n++;
+                }
             fb.erase(std::remove_if(fb.begin(), fb.end(), [&](const PendingBetween& f) { return f.a < oldest; }), fb.end());
         }
         fars = g->far_between;
         g->far_new = 0;
-        staged_before = g->staged_count;
+        staged_before = g->staged_count - late_n;
         g->staged_count = 0;  // _graph->resize(0)
         last_key = g->current_key;
         last_time = g->last_pose_time;
@@ -412,6 +422,9 @@ int vf_solve(vf_graph* g) {
     // odometry) can never be added; it is dropped, the rest is given back, and the caller is told once
     {
         const uint64_t oldest = g->key_base + (uint64_t)g->lo;
+        if (late_far)
+            return give_back(gerr(VF_ERR_BAD_KEY, "between factor (%llu, %llu) dropped: key %llu left the fixed-lag window (oldest key %llu)",
+                        late_a, late_b, late_a, (unsigned long long)oldest));
         for (size_t i = 0; i < betweens.size(); i++)
             if (betweens[i].a < oldest) {
                 const unsigned long long a = betweens[i].a, b = betweens[i].b;

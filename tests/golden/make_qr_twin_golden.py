@@ -73,9 +73,17 @@ def main():
     # ---- configs[4]: the 10 000-pose window
     if "--with-10k" in sys.argv:
         n = 10000
-        seq, imu, ba, bb, brec, prior = problem_inputs(4242, n, n)
+        cache = "/tmp/qr_twin_10k_records.npy"          # 27 minutes of twin preintegration; not a fixture
+        if os.path.exists(cache):
+            seq = synth.make_sequence(seed=4242, n_kf=n)
+            imu = np.load(cache)
+            m = seq.btw_b < n
+            ba, bb, brec, prior = seq.btw_a[m], seq.btw_b[m], synth.between_records(seq)[m], np.concatenate([seq.gt_states[0], PRIOR_SIGMAS])
+        else:
+            seq, imu, ba, bb, brec, prior = problem_inputs(4242, n, n)
+            np.save(cache, imu)
         P = tq.Problem(seq.gt_states, np.arange(1, n), imu[1:], ba, bb, brec, 0, prior)
-        log = P.optimize(max_iterations=100, verbose=True)
+        log = P.optimize(max_iterations=6, polish=14, verbose=True)
         np.savez(os.path.join(HERE, "qr_twin_10k.npz"), seed=4242, n=n, poses=P.st.to_array()[:, :7], final_cost=log["final_cost"],
                  iterations=log["iterations"], polish_steps=np.array(log["polish_steps"]))
     if "--skip-fixed-lag" in sys.argv:

@@ -475,6 +475,8 @@ def main():
     ap.add_argument("--no-convergence-exit", action="store_true")
     ap.add_argument("--no-degeneracy", action="store_true")
     ap.add_argument("--no-graph-manager", action="store_true")
+    ap.add_argument("--solve-assemble-min", type=int, default=None,
+                    help="vf_engine_opts.solve_assemble_min of the headline engine (default: the library's)")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -517,7 +519,8 @@ def main():
         dist = D.init(backend=backend, device_id=torch.device("cuda", gpu) if backend == "nccl" else None)
     dev = torch.device("cuda", gpu)
 
-    eng, feed = make_engine(args, gpu, args.windows, seqs, updates)
+    eng, feed = make_engine(args, gpu, args.windows, seqs, updates,
+                            **({} if args.solve_assemble_min is None else {"solve_assemble_min": args.solve_assemble_min}))
     del seqs
     fed = {id(eng): 0}
 

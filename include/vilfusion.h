@@ -92,6 +92,12 @@ typedef struct {
                                 back substitution run as two kernels (same arithmetic, same bits): the back substitution needs
                                 9 KB of LDS instead of 38 and runs several waves per SIMD.  Pays once the batch is a multiple
                                 of the 1024 SIMDs of the part.  Default 2048; 0 = never. */
+    int solve_assemble_min;  /* whole-window sweeps: from this many windows on, the forward sweep forms the block rows of the
+                                normal equations itself, from the Jacobians K1 / K2 leave, and the assembly kernel (K3) is not
+                                launched: H is neither written nor read back (vf_engine_read_normal assembles it on demand).
+                                Same sums in another order: agrees with the two-kernel form to rounding, not to the bit.  Not
+                                used while a window holds far between factors, on sharded engines, or by the partitioned
+                                form.  0 = never. */
 } vf_engine_opts;
 
 void vf_engine_default_opts(vf_engine_opts* o);

@@ -213,6 +213,7 @@ void vf_engine_default_opts(vf_engine_opts* o) {
     o->use_hip_graph = 0;
     o->accept_rel = 1e-9;
     o->solve_split_min = 2048;
+    o->solve_assemble_min = 0;
 }
 
 int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
@@ -237,6 +238,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     v.lam_up = o->lambda_up; v.lam_down = o->lambda_down; v.lam_min = o->lambda_min; v.lam_max = o->lambda_max;
     v.accept_rel = o->accept_rel;
     v.split_min = o->solve_split_min > 0 ? o->solve_split_min : 0;
+    v.asm_min = o->solve_assemble_min > 0 ? o->solve_assemble_min : 0;
     HIPCHK(hipStreamCreate(&e->stream));
     HIPCHK(hipEventCreate(&e->ev0));
     HIPCHK(hipEventCreate(&e->ev1));
@@ -684,10 +686,16 @@ int vf_engine_linearize(vf_engine* e, int which) {
     HIPCHK(hipGetLastError());
     return VF_OK;
 }
+// the next vf_engine_solve forms the normal equations inside its forward sweep (vf_engine_opts.solve_assemble_min): K3 has
+// nothing to do.  Not while far factors are held (their correction solves from H and g) nor in the hybrid form.
+static bool assembles_in_solve(const vf_engine* e) {
+    return vf::asm_in_solve(e->v) && e->x_used == 0 && !(e->hybrid && e->v.stop_on);
+}
 int vf_engine_assemble(vf_engine* e) {
     DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (assembles_in_solve(e)) return VF_OK;
     vf::launch_assemble(e->v, e->stream);
     if (e->x_used > 0) vf::launch_extra_gradient(e->v, e->stream);   // the far factors' J^T r (their J^T J stays out of the band)
     HIPCHK(hipGetLastError());
@@ -708,6 +716,7 @@ int vf_engine_solve(vf_engine* e) {
         vf::View a = e->v;
         a.gvec = gvec;
         a.delta = delta;
+        if (!assembles_in_solve(e)) a.asm_min = 0;
         if (e->hybrid && e->v.stop_on) {
             vf::View p = e->partitioned_view();
             p.gvec = gvec;
@@ -1300,6 +1309,13 @@ int vf_engine_read_normal(vf_engine* e, int window, int k0, int n, double* Hband
     if (rc) return rc;
     if (n == 0) return VF_OK;
     const size_t g0 = (size_t)window * e->v.M + k0;
+    if (assembles_in_solve(e)) {
+        // H and g are not kept by the solves of this engine: assemble them now, for every window (any value outside 0 .. 63
+        // in `fresh` means "the whole window"; nothing else reads the flag on such an engine)
+        HIPCHK(hipMemsetAsync(e->v.fresh, 1, (size_t)e->v.B * sizeof(int), e->stream));
+        vf::launch_assemble(e->v, e->stream);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipStreamSynchronize(e->stream));
     if (Hband) {
         // device rows are packed for the solver (vf_kernels.hpp "Block row of H") -> the documented [n][4][15][15]

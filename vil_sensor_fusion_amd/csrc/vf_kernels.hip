@@ -1307,6 +1307,10 @@ constexpr int CW_P = CW_ID + 30;             // panel rows 15..42 at stride 15 (
 constexpr int CW_BC = CW_P + 28 * 15;
 constexpr int CW_TOTAL = CW_BC + 16;
 static_assert(CW_TOTAL * 8 <= 20480, "eight compact forward sweeps per CU (160 KB of LDS)");
+// Assembling forward sweep (SOLVE_ASM_FWD, k_band_forward_asm): the compact window, then the LDS image of ONE tile of the J
+// stream (8 factors at K3's stride LJS: pairs, residual, zero cell) and ONE between linearisation (78 words + the zero cell).
+constexpr int AS_LJ = CW_TOTAL, AS_LB = AS_LJ + JT * LJS, AS_TOTAL = AS_LB + 80;
+static_assert(AS_LJ % 2 == 0 && AS_TOTAL * 8 <= 40960, "four assembling sweeps per CU (one per SIMD)");
 // chunk forward sweep with a spike follower (k_chunk_forward): the panel of step k (43 rows x 15, then a
 // zero cell and a write sink) stays in a 4-slot LDS ring for the second wave; two hand-shake cells follow
 constexpr int RING_SLOT = 664;
@@ -1318,6 +1322,10 @@ constexpr int S_TOTAL_RING = S_BC_RING + 16;
 #define VF_PIVOT_PERMLANE 0      // 1: the scaled pivot column is replicated over the 16-lane rows by VALU lane swaps instead of through LDS
 #endif
 #define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define VF_PIVOT_SLOT(i) do {} while (0)     // places the generated pivot code leaves for its caller (tools/gen_pivot.py)
+#ifndef VF_AS_SLOTS
+#define VF_AS_SLOTS 1     // assembling sweep: 1 = its matrix-core pieces ride in the pivot code's places, 0 = in front of the Schur update
+#endif
 #define VF_SB() __builtin_amdgcn_sched_barrier(0)
 #ifdef VF_SOLVE_STAMPS   // diagnostic build only (tools/build_stamps.sh); never in the shipped library
 __device__ unsigned long long g_stamps[16];
@@ -1349,14 +1357,18 @@ constexpr int MID_TOTAL = 45 * MID_LD + 48;     // + the 45 solved increments ha
 //   as two kernels.  They hand over through HBM only (the panels and the rhs row the forward sweep stores anyway); the
 //   back substitution needs 9 KB of LDS instead of 38 and so runs two and more waves per SIMD where the fused kernel
 //   is held to one by the forward sweep's trailing window.
-enum { SOLVE_FULL = 0, SOLVE_TWISTED = 1, SOLVE_CHUNK_FWD = 2, SOLVE_CHUNK_BWD = 3, SOLVE_FULL_FWD = 4, SOLVE_FULL_BWD = 5 };
+// MODE 6 (assembling forward sweep, batches of >= View::asm_min windows): SOLVE_FULL_FWD that forms the block rows of H itself,
+//   from the J stream and the between linearisations K1 / K2 leave, on the matrix cores, under the waits of the pivot
+//   chain -- K3 is not launched, H is neither written nor read.  See "assembling sweep" below.
+enum { SOLVE_FULL = 0, SOLVE_TWISTED = 1, SOLVE_CHUNK_FWD = 2, SOLVE_CHUNK_BWD = 3, SOLVE_FULL_FWD = 4, SOLVE_FULL_BWD = 5, SOLVE_ASM_FWD = 6 };
 template <int MODE>
 __device__ __forceinline__ void band_solve_body(const View& v, double* __restrict__ S, double* __restrict__ S_other,
                                                 double* __restrict__ MID, const int w, const int lane, const int wave,
                                                 const ChunkGeom cg = ChunkGeom{0, 0, 0}, double* __restrict__ sep_out = nullptr) {
     constexpr bool TW = MODE == SOLVE_TWISTED;
     constexpr bool CH = MODE == SOLVE_CHUNK_FWD || MODE == SOLVE_CHUNK_BWD;
-    constexpr bool CW = MODE == SOLVE_FULL_FWD;          // compact trailing window ("CW_" map above); the names below shadow the full map
+    constexpr bool AS = MODE == SOLVE_ASM_FWD;           // rows of H assembled here (no K3)
+    constexpr bool CW = MODE == SOLVE_FULL_FWD || AS;    // compact trailing window ("CW_" map above); the names below shadow the full map
     constexpr int S_GD = CW ? CW_GD : vf::S_GD, S_DUMP = CW ? CW_DUMP : vf::S_DUMP, S_ZERO = CW ? CW_ZERO : vf::S_ZERO;
     constexpr int S_ID = CW ? CW_ID : vf::S_ID, S_P = CW ? CW_P : vf::S_P, S_BC = CW ? CW_BC : vf::S_BC;
     const int lo = v.lo[w], hi = v.hi[w];
@@ -1472,6 +1484,295 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     const int x9_off = lane < 54 ? (lane / 9) * LDW + 6 + lane % 9 : -1;
     const double mp_third = (v.mp_on[w] && n >= 3 && !rev && (!CH || cg.i0 == 0)) ? 1.0 : 0.0;
     WSYNC();
+
+    // ---- assembling sweep (AS): the block row of keyframe R is formed here instead of being read from H --------------------
+    // One "iteration" per row, K3's recurrence on one wave: with the operands of IMU factor R+1 in LDS (i side = keyframe R,
+    // j side = keyframe R+1; column 15 of an operand tile carries the whitened residual, so J^T r comes with J^T J)
+    //     Dfin = D + Ji^T [Ji | r]                       diagonal block + gradient of row R        (D: started one iteration ago)
+    //     On   = Jj^T Ji,  Dn = Jj^T [Jj | r]            coupling block and start of the diagonal of row R+1
+    //     Z    = X^T X,  X = [Ja | Jb | 0 0 0 | r]       everything the between factor ending at R contributes, in ONE tile (6 rows =
+    //                                                    two k-steps): Z[0:6, 0:6 | 15] = Ja^T [Ja | r] goes to the diagonal block +
+    //                                                    gradient of row R - d (still in the window), Z[6:12, 6:12 | 15] = Jb^T [Jb | r]
+    //                                                    to those of row R, Z[6:12, 0:6] = Jb^T Ja is the pose block of row R against R - d
+    // 14 v_mfma_f64_16x16x4 per row (a single wave gets one through every ~125 cycles, so their number is the price of the
+    // fusion: with the three between products formed separately there were 18); inside the elimination loop they are issued one at a time from the places the generated
+    // pivot code leaves for them (VF_PIVOT_SLOT), i.e. under the waits of the chain.  The J stream is read as K3 reads it --
+    // whole tiles of 8 factors, every 128-B line once -- but one tile per 8 steps: the next tile waits in registers (19
+    // 16-byte words per lane) and is written to LDS when the last factor of the current one has been used.  A between
+    // factor's term on its OLDER keyframe goes into that row's slot of the window (the row is at most three steps from its
+    // elimination, so it is still there), which is why one staged between linearisation is enough.
+    struct Asm { d4_t D, O, Dfin, Z, On, Dn; double ai[4], aj[4], xx[2]; int d, d_next; };
+    struct AsmNext { d2_t tj[19]; double tr[2], blA[2], blB[2]; int aA, aB, k0_next; };
+    constexpr int AS_NOWN = JS_PAIRS * JT;                       // 16-byte words of a tile
+    const int as_b = AS ? v.sel[w] : 0;
+    AsmMaps am = {};
+    int as_cD[4] = {}, as_cDs[4] = {}, as_cO[4] = {}, as_c1[2] = {}, as_c2[2] = {}, as_c3[2] = {}, as_rB[2] = {}, as_rS[2] = {}, as_bB[2] = {}, as_bS[2] = {}, as_oX[2] = {};
+    double as_bsgn[2] = {};
+    double as_dadd[4] = {}, as_dsgn[4] = {}, as_rsgn[2] = {};
+    const int as_hx = lane < 54 ? CW_D2 + (lane / 9) * 15 + 6 + lane % 9 : -1;
+    if constexpr (AS) {
+        am = make_asm_maps(v, w, lo, hi, lane);
+        const int ci = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int a = kq + 4 * r;
+            const bool tri = a < 15 && ci <= a, grad = a < 15 && ci == 15;
+            as_cD[r] = tri ? CW_D0 + h_tri(a, ci) : (grad ? S_GD + a : S_DUMP + 32 + lane);      // + PH * as_cDs
+            as_cDs[r] = tri ? CW_SLOT : (grad ? 15 : 0);
+            as_dadd[r] = (tri && a == ci) ? 1.0 : 0.0;
+            as_dsgn[r] = grad ? -1.0 : 1.0;                                                    // the window keeps -g
+            as_cO[r] = (a < 15 && ci < 15) ? CW_D1 + a * 15 + ci : -1;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            // rows 0..5 of Z (registers 0, 1): the older keyframe's term, into that row's slot
+            const int a6 = kq + 4 * r;
+            const bool tri = a6 < 6 && ci <= a6, grad = a6 < 6 && ci == 15;
+            as_rB[r] = tri ? CW_D0 + h_tri(a6, ci) : (grad ? S_GD + a6 : S_DUMP + 32 + lane);   // + slot * as_rS
+            as_rS[r] = tri ? CW_SLOT : (grad ? 15 : 0);
+            as_rsgn[r] = tri ? 1.0 : (grad ? -1.0 : 0.0);
+            // rows 6..11 of Z (registers 1, 2): columns 0..5 = the pose block against R - d, columns 6..11 | 15 = this row's own term
+            const int b6 = kq + 4 * (r + 1) - 6;
+            const bool brow = b6 >= 0 && b6 < 6;
+            const bool in = brow && ci < 6;
+            as_c1[r] = in ? CW_D1 + b6 * 15 + ci : -1;
+            as_c2[r] = in ? CW_D2 + b6 * 15 + ci : -1;
+            as_c3[r] = in ? CW_D3 + b6 * 6 + ci : -1;
+            const bool btri = brow && ci >= 6 && ci - 6 <= b6, bgrad = brow && ci == 15;
+            as_bB[r] = btri ? CW_D0 + h_tri(b6, ci - 6) : (bgrad ? S_GD + b6 : S_DUMP + 32 + lane);   // + PH * as_bS
+            as_bS[r] = btri ? CW_SLOT : (bgrad ? 15 : 0);
+            as_bsgn[r] = btri ? 1.0 : (bgrad ? -1.0 : 0.0);
+            // operand word of k-step r: X[4 r + kq][ci] in the staged linearisation (r: 0, Ja: 6, Jb: 42; its pad cell is zero)
+            const int row = 4 * r + kq;
+            as_oX[r] = row >= 6 ? BTW_OUT : (ci < 6 ? 6 + row * 6 + ci : (ci < 12 ? 42 + row * 6 + ci - 6 : (ci == 15 ? row : BTW_OUT)));
+        }
+        if (lane < JT) S[AS_LJ + lane * LJS + LJ_ZERO] = 0.0;
+        if (lane < 2) S[AS_LB + BTW_OUT + lane] = 0.0;
+    }
+    const size_t as_tiles = (size_t)(v.G >> 6);
+    // loads of the J tile that holds window slot k0 (a multiple of 8) and of its 8 residual vectors
+    auto as_tile_fetch = [=](int k0, AsmNext& nx) {
+        long gt = ((long)w * v.M + k0) >> JT_LOG;
+        const long gmax = (v.G >> JT_LOG) - 1;
+        gt = gt > gmax ? gmax : gt;                          // (rows past the window's end: any tile, zeroed at commit)
+        const d2_t* jt = (const d2_t*)(v.imu_j + ((size_t)as_b * (size_t)(v.G >> JT_LOG) + (size_t)gt) * JT_STRIDE);
+#pragma unroll
+        for (int it = 0; it < 19; it++) {
+            const int e = it * 64 + lane;
+            nx.tj[it] = jt[e < AS_NOWN ? e : AS_NOWN - 1];
+        }
+        const double* rb = v.imu_r + (size_t)as_b * as_tiles * IMU_R * TILE;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int e = lane + 64 * j < JT * IMU_R ? lane + 64 * j : JT * IMU_R - 1;
+            const int fac = e / IMU_R, a = e - fac * IMU_R;
+            const long gf = (gt << JT_LOG) + fac;
+            nx.tr[j] = rb[((size_t)(gf >> 6) * IMU_R + a) * TILE + (gf & 63)];
+        }
+    };
+    auto as_tile_commit = [&](int k0, const AsmNext& nx) {
+        // word e = 64 it + lane of the tile is pair 8 it + (lane >> 3) of factor lane & 7: one address per lane, the rest immediates
+        const int fac = lane & (JT - 1), kf = k0 + fac;
+        const bool keep = kf > lo && kf < hi;                    // a factor outside the window contributes zeros
+        double* dst = S + AS_LJ + fac * LJS + 2 * (lane >> JT_LOG);
+#pragma unroll
+        for (int it = 0; it < 19; it++) {
+            d2_t x = nx.tj[it];
+            x.x = keep ? x.x : 0.0;
+            x.y = keep ? x.y : 0.0;
+            if (it < 18 || lane < AS_NOWN - 18 * 64) *(d2_t*)(dst + it * (2 * 64 / JT)) = x;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int e = lane + 64 * j;
+            const int f2 = e / IMU_R, a = e - f2 * IMU_R, kf2 = k0 + f2;
+            if (e < JT * IMU_R) S[AS_LJ + f2 * LJS + LJ_R + a] = (kf2 > lo && kf2 < hi) ? nx.tr[j] : 0.0;
+        }
+    };
+    // between linearisation of the factor ending at sweep row R (words lane, lane + 64 of 78) and its older keyframe (-1: none)
+    // (the older keyframe comes back as loaded, one copy per lane: decoding it here would wait for the load on the spot)
+    auto as_btw_fetch = [=](int R, double (&bl)[2], int& a_raw) {
+        const int ks = lo + R;
+        long gs = (long)w * v.M + ks;
+        gs = gs < v.G ? gs : v.G - 1;
+        a_raw = v.btw_a[gs];
+        const double* bo = v.btw_out + (size_t)as_b * as_tiles * BTW_OUT * TILE + (size_t)(gs >> 6) * BTW_OUT * TILE + (gs & 63);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int f = lane + 64 * j < BTW_OUT ? lane + 64 * j : BTW_OUT - 1;
+            bl[j] = bo[(size_t)f * TILE];
+        }
+    };
+    // distance 1..3 from row R to the older keyframe of the between factor ending there; 0 = no factor
+    auto as_btw_dist = [=](int R, int a_raw) {
+        const int ks = lo + R;
+        const int a = __builtin_amdgcn_readfirstlane(a_raw);
+        return (R > 0 && ks < hi && a >= lo && a < ks) ? ks - a : 0;
+    };
+    auto as_btw_commit = [&](const double (&bl)[2], int d) {
+        S[AS_LB + lane] = d > 0 ? bl[0] : 0.0;
+        S[lane + 64 < BTW_OUT ? AS_LB + lane + 64 : S_DUMP + 32 + lane] = d > 0 ? bl[1] : 0.0;
+    };
+    // the matrix-core work of one iteration, cut into the pieces the pivot code's places take (piece 0: operand reads)
+    auto as_piece = [&](auto i_, Asm& z, const int fimg) {
+        constexpr int I = decltype(i_)::value;
+        auto mf = [](double a, double b, d4_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); };
+        if constexpr (I == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { z.ai[q] = S[fimg + am.offI[q]]; z.aj[q] = S[fimg + am.offJ[q]]; }
+#pragma unroll
+            for (int q = 0; q < 2; q++) z.xx[q] = S[AS_LB + as_oX[q]];
+        }
+        else if constexpr (I == 2) z.Dfin = mf(z.ai[0], z.ai[0], z.D);
+        else if constexpr (I == 3) z.Dn = mf(z.aj[0], z.aj[0], (d4_t){0, 0, 0, 0});
+        else if constexpr (I == 4) z.On = mf(z.aj[0], z.ai[0], (d4_t){0, 0, 0, 0});
+        else if constexpr (I == 5) z.Z = mf(z.xx[0], z.xx[0], (d4_t){0, 0, 0, 0});
+        else if constexpr (I == 7) z.Dfin = mf(z.ai[1], z.ai[1], z.Dfin);
+        else if constexpr (I == 8) z.Dn = mf(z.aj[1], z.aj[1], z.Dn);
+        else if constexpr (I == 9) z.On = mf(z.aj[1], z.ai[1], z.On);
+        else if constexpr (I == 10) z.Z = mf(z.xx[1], z.xx[1], z.Z);
+        else if constexpr (I == 12) z.Dfin = mf(z.ai[2], z.ai[2], z.Dfin);
+        else if constexpr (I == 13) z.Dn = mf(z.aj[2], z.aj[2], z.Dn);
+        else if constexpr (I == 14) z.On = mf(z.aj[2], z.ai[2], z.On);
+        else if constexpr (I == 15) z.Dfin = mf(z.ai[3], z.ai[3], z.Dfin);
+        else if constexpr (I == 16) z.Dn = mf(z.aj[3], z.aj[3], z.Dn);
+        else if constexpr (I == 17) z.On = mf(z.aj[3], z.ai[3], z.On);
+    };
+    // A into the diagonal block / gradient of row R - d, which sits in slot (PH - d) & 3 of the window.  Issued after the
+    // write-back of the previous step's Schur update and before this step's reads of it (LDS operations of a wave retire in order).
+    auto as_rmw = [&](auto ph, const Asm& z) {
+        constexpr int PH = decltype(ph)::value;
+        if (z.d > 0) {
+            const int sa = (PH + 4 - z.d) & 3;
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int addr = as_rB[r] + sa * as_rS[r];
+                S[addr] = fma(as_rsgn[r], z.Z[r], S[addr]);
+            }
+        }
+    };
+    // row R (sweep index, R & 3 == PH) into the slot the pivot keyframe frees
+    // (SPECIAL: the rows that can carry the prior / the marginal prior -- the first four, committed in front of the loop; a
+    // prior on a later keyframe is added by as_late_prior.  Their code, 150 loads, stays out of the elimination loop.)
+    auto as_commit = [&](auto ph, auto special_, int R, const Asm& z) {
+        constexpr int PH = decltype(ph)::value;
+        constexpr bool SPECIAL = decltype(special_)::value != 0;
+        constexpr int sb = PH * CW_SLOT;
+        const int ci = lane & 15, kq = lane >> 4;
+        const int kind = row_kind(R);
+        const double dg = kind == 0 ? lam : (kind == 1 ? 1.0 : 0.0);
+        d4_t Dv = z.Dfin, Ov = z.O;
+        double t2[2], t3[2], hxv = 0.0;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            t2[r] = z.d == 2 ? z.Z[r + 1] : 0.0;        // (rows 6..11 of Z)
+            t3[r] = z.d == 3 ? z.Z[r + 1] : 0.0;
+        }
+        const int k = lo + R;
+        const bool is_prior = SPECIAL && am.prior_key == k && kind == 0;
+        const int mo = (SPECIAL && am.marg_on && kind == 0) ? R : 99;
+        if (SPECIAL && (is_prior || mo < 3)) {       // (wave-uniform, the window's first rows only) the prior and the marginal prior, as K3 adds them
+            const double* Pq = v.prior_out + ((size_t)as_b * v.B + w) * PRIOR_OUT;
+            const double* ML = v.mp_L + (size_t)w * 729;
+            const double* Mg = v.mp_out + ((size_t)as_b * v.B + w) * 28;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int a = kq + 4 * r;
+                double add = 0.0;
+                if (is_prior && a < 15) {
+                    double sum = 0.0;
+                    for (int rr = 0; rr < 15; rr++)
+                        sum = fma(Pq[15 + rr * 15 + a], ci < 15 ? Pq[15 + rr * 15 + ci] : Pq[rr], sum);
+                    add += sum;
+                }
+                if (mo == 0 && a < 15) add += ci < 15 ? ML[a * 27 + ci] : Mg[a];
+                if ((mo == 1 || mo == 2) && a < 6 && (ci < 6 || ci == 15)) {
+                    const int ob = mo == 1 ? 15 : 21;
+                    add += ci < 6 ? ML[(ob + a) * 27 + ob + ci] : Mg[ob + a];
+                }
+                Dv[r] += add;
+                if (mo == 1 && a < 6 && ci < 15) Ov[r] += ML[(15 + a) * 27 + ci];                 // (lo+1 pose) x (lo: 15)
+                if (mo == 2 && a < 6 && ci < 6) Ov[r] += ML[(21 + a) * 27 + 15 + ci];             // (lo+2 pose) x (lo+1 pose)
+            }
+            if (mo == 2) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) { const int b6 = kq + 4 * (r + 1) - 6; if (b6 >= 0 && b6 < 6 && ci < 6) t2[r] += ML[(21 + b6) * 27 + ci]; }
+                if (lane < 54) hxv = ML[(21 + lane / 9) * 27 + 6 + lane % 9];                       // (lo+2 pose) x (velocity / bias of lo)
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) S[as_cD[r] + PH * as_cDs[r]] = fma(as_dsgn[r], Dv[r], as_dadd[r] * dg);
+#pragma unroll
+        for (int r = 0; r < 4; r++) S[as_cO[r] >= 0 ? sb + as_cO[r] : S_DUMP + 32 + lane] = Ov[r];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            S[as_c2[r] >= 0 ? sb + as_c2[r] : S_DUMP + 32 + lane] = t2[r];
+            S[as_c3[r] >= 0 ? sb + as_c3[r] : S_DUMP + 32 + lane] = t3[r];
+        }
+        S[as_hx >= 0 ? sb + as_hx : S_DUMP + 32 + lane] = hxv;
+        // the between factor's own-row term, and its pose block when it reaches back one keyframe only (that block is part of
+        // the 15 x 15 coupling written above): read-modify-write behind the stores (LDS operations retire in order)
+        if (z.d > 0) {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int addr = as_bB[r] + PH * as_bS[r];
+                S[addr] = fma(as_bsgn[r], z.Z[r + 1], S[addr]);
+            }
+            if (z.d == 1) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int addr = as_c1[r] >= 0 ? sb + as_c1[r] : S_DUMP + 32 + lane;
+                    S[addr] = S[addr] + z.Z[r + 1];
+                }
+            }
+        }
+    };
+    // a prior on a keyframe beyond the first four rows: J^T [J | r] is formed in front of the loop (as_lp: this lane's four
+    // words of the tile), and added to the row when it has just been committed (slot R & 3), before any step reads it
+    double as_lp[4] = {0.0, 0.0, 0.0, 0.0};
+    const int as_lp_row = (AS && am.prior_key >= lo + 4 && am.prior_key < hi) ? am.prior_key - lo : -1;
+    if constexpr (AS) {
+        if (as_lp_row >= 0) {
+            const int ci = lane & 15, kq = lane >> 4;
+            const double* Pq = v.prior_out + ((size_t)as_b * v.B + w) * PRIOR_OUT;
+#pragma unroll 1
+            for (int rr = 0; rr < 15; rr++) {
+                const double cv = ci < 15 ? Pq[15 + rr * 15 + ci] : Pq[rr];
+#pragma unroll
+                for (int r = 0; r < 4; r++) { const int a = kq + 4 * r; as_lp[r] = fma(a < 15 ? Pq[15 + rr * 15 + a] : 0.0, cv, as_lp[r]); }
+            }
+        }
+    }
+    auto as_late_prior = [&](int R) {
+        if (R == as_lp_row) {
+            const int sl = R & 3;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int addr = as_cD[r] + sl * as_cDs[r];
+                S[addr] = fma(as_dsgn[r], as_lp[r], S[addr]);
+            }
+        }
+    };
+    // Once the operands of iteration R are in registers (piece 0), the between linearisation of row R+1 may take their place
+    // in LDS: its loads are two steps old, and the newest stores in front of them in the memory queue -- the panel of
+    // the previous step -- a whole step, so the wait this needs is short (at the end of the step it would stand behind
+    // the panel stores just issued: 2 300 cycles per step, measured).  The loads of row R+3 go out behind it.
+    auto as_stage_btw = [&](int R, Asm& z, AsmNext& nx) {
+        z.d_next = as_btw_dist(R + 1, nx.aA);
+        as_btw_commit(nx.blA, z.d_next);
+        nx.blA[0] = nx.blB[0]; nx.blA[1] = nx.blB[1]; nx.aA = nx.aB;
+        as_btw_fetch(R + 3, nx.blB, nx.aB);
+    };
+    auto as_advance = [&](int R, Asm& z, AsmNext& nx) {
+        z.D = z.Dn;
+        z.O = z.On;
+        z.d = z.d_next;
+        if (((lo + R + 2) & (JT - 1)) == 0) {               // factor R+2 opens a new tile: the old one has been used up
+            as_tile_commit(nx.k0_next, nx);
+            nx.k0_next += JT;
+            as_tile_fetch(nx.k0_next, nx);
+        }
+    };
 
     // ---- H block row prefetch (HBM -> registers) and commit (registers -> LDS slot) ---------
     // (passed by value: captured-by-reference scalars ended up in scratch memory)
@@ -1608,10 +1909,43 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     unsigned long long st[16] = {0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
     if constexpr (MODE != SOLVE_CHUNK_BWD && MODE != SOLVE_FULL_BWD) {
+    Asm az;
+    AsmNext anx;
+    if constexpr (AS) {
+        az.D = az.O = az.Dfin = az.Z = az.On = az.Dn = (d4_t){0, 0, 0, 0};     // row 0 has no factor in front of it
+        az.d = az.d_next = 0;
+        anx.k0_next = (lo + 1) & ~(JT - 1);
+        as_tile_fetch(anx.k0_next, anx);
+        as_tile_commit(anx.k0_next, anx);
+        anx.k0_next += JT;
+        as_tile_fetch(anx.k0_next, anx);
+        { const double z2[2] = {0.0, 0.0}; as_btw_commit(z2, 0); }
+        as_btw_fetch(1, anx.blA, anx.aA);
+        as_btw_fetch(2, anx.blB, anx.aB);
+        WSYNC();
+        auto first = [&](auto ph, int R) {
+            const int fimg = AS_LJ + ((lo + R + 1) & (JT - 1)) * LJS;
+            as_piece(IC<0>{}, az, fimg);
+            as_stage_btw(R, az, anx);
+            as_piece(IC<2>{}, az, fimg);  as_piece(IC<3>{}, az, fimg);  as_piece(IC<4>{}, az, fimg);  as_piece(IC<5>{}, az, fimg);
+            as_piece(IC<7>{}, az, fimg);  as_piece(IC<8>{}, az, fimg);  as_piece(IC<9>{}, az, fimg);
+            as_piece(IC<10>{}, az, fimg); as_piece(IC<12>{}, az, fimg); as_piece(IC<13>{}, az, fimg);
+            as_piece(IC<14>{}, az, fimg); as_piece(IC<15>{}, az, fimg); as_piece(IC<16>{}, az, fimg); as_piece(IC<17>{}, az, fimg);
+            as_rmw(ph, az);
+            as_commit(ph, IC<1>{}, R, az);
+            as_advance(R, az, anx);
+            WSYNC();
+        };
+        first(IC<0>{}, 0);
+        first(IC<1>{}, 1);
+        first(IC<2>{}, 2);
+        first(IC<3>{}, 3);
+    } else {
     commit_row(IC<0>{}, fetch_row(0), row_kind(0), 0);
     commit_row(IC<1>{}, fetch_row(1), row_kind(1), 1);
     commit_row(IC<2>{}, fetch_row(2), row_kind(2), 2);
     commit_row(IC<3>{}, fetch_row(3), row_kind(3), 3);
+    }
     WSYNC();
     // ---- one elimination step, phase PH = k & 3 compile-time --------------------------------
     // `pend`, `pend2` = block rows of keyframes k+4, k+5 (fetched two steps and one step ago); this step fetches k+6.
@@ -1632,12 +1966,23 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         double pv_inv;
         const int pv_bcw = lane < 15 ? (RINGM ? S_BC_RING : S_BC) + lane : S_DUMP + 32 + lane;
         const int pv_bcr = (RINGM ? S_BC_RING : S_BC) + (lane & 15);
+        // (assembling sweep: iteration k + 4 -- row k + 4 from the operands of factor k + 5 -- rides in the pivot code's places)
+        const int as_fimg = AS_LJ + ((lo + k + 5) & (JT - 1)) * LJS;
+#undef VF_PIVOT_SLOT
+#if VF_AS_SLOTS
+#define VF_PIVOT_SLOT(i) do { if constexpr (AS) { as_piece(IC<(i)>{}, az, as_fimg); if constexpr ((i) == 1) as_stage_btw(k + 4, az, anx); if constexpr ((i) == 26) as_rmw(ph, az); VF_SB(); } } while (0)
+#else
+#define VF_PIVOT_SLOT(i) do {} while (0)
+#endif
 #if VF_PIVOT_PERMLANE
 #include "vf_pivot_15p.inc"
         (void)pv_bcw; (void)pv_bcr;
 #else
 #include "vf_pivot_15.inc"
 #endif
+#undef VF_PIVOT_SLOT
+#define VF_PIVOT_SLOT(i) do {} while (0)
+        (void)as_fimg;
         if (!(pv_inv < 1e300)) failed = 1;
         STAMP(2);
         // sub-panel + rhs -> LDS (MFMA operands); rows 15..57 -> HBM, one 128-B line per lane
@@ -1656,6 +2001,20 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         WSYNC();
         if constexpr (RINGM) { if (lane == 0) S[S_PROG] = (double)(k + 1); }   // panel k is complete in its ring slot
         STAMP(3);
+#if !VF_AS_SLOTS
+        if constexpr (AS) {
+            // the iteration's 18 matrix-core instructions, back to back: nothing else of this wave wants the vector unit
+            // here, the staging of the next between linearisation and the loads behind it issue in between
+            as_piece(IC<0>{}, az, as_fimg);
+            as_piece(IC<2>{}, az, as_fimg);  as_piece(IC<3>{}, az, as_fimg);  as_piece(IC<4>{}, az, as_fimg);
+            as_stage_btw(k + 4, az, anx);
+            as_piece(IC<5>{}, az, as_fimg);  as_piece(IC<7>{}, az, as_fimg);  as_piece(IC<8>{}, az, as_fimg);
+            as_piece(IC<9>{}, az, as_fimg);  as_piece(IC<10>{}, az, as_fimg); as_piece(IC<12>{}, az, as_fimg);
+            as_piece(IC<13>{}, az, as_fimg); as_piece(IC<14>{}, az, as_fimg); as_piece(IC<15>{}, az, as_fimg); as_piece(IC<16>{}, az, as_fimg);
+            as_piece(IC<17>{}, az, as_fimg);
+            as_rmw(ph, az);
+        }
+#endif
         // Schur update on the matrix cores: acc[t] = P_Ti P_Tj^T for the 3 lower 16x16 tiles
         // (the trailing entries are the accumulator input and the A operands are negated: T - P P^T leaves the matrix
         // cores ready to be written back, no accumulator read-out + subtraction pass)
@@ -1676,9 +2035,15 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         // While the twelve MFMAs run (64 cycles each on this part: the longest stretch of the step that needs no issue
         // slots), row k+4 is committed to the slot the pivot keyframe frees -- its panel is in registers, the operand and
         // accumulator reads above are ahead of these writes in the LDS queue, and the write-back below goes to other rows.
+        if constexpr (AS) {
+            as_commit(ph, IC<0>{}, k + 4, az);
+            as_late_prior(k + 4);
+            as_advance(k + 4, az, anx);          // (a dispatch on the phase around ONE copy of this was slower: the register copies where its four arms meet)
+        } else {
         commit_row(ph, pend, row_kind(k + 4), k + 4);
         pend = pend2;
         pend2 = fetch_row(k + 6);              // also in the shadow; two steps of slack for the HBM round trip
+        }
         STAMP(4);
 #pragma unroll
         for (int r = 0; r < 4; r++) { S[tgt_ph[PH][r]] = acc0[r]; S[tgt_ph[PH][4 + r]] = acc1[r]; S[tgt_ph[PH][8 + r]] = acc2[r]; }
@@ -1686,8 +2051,8 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         STAMP(5);
     };
     {
-        HRow pend = fetch_row(4);
-        HRow pend2 = fetch_row(5);
+        HRow pend = {}, pend2 = {};
+        if constexpr (!AS) { pend = fetch_row(4); pend2 = fetch_row(5); }
 #pragma unroll 1
         for (int k = 0; k < n4; k += 4) {
             step(IC<0>{}, k, pend, pend2);
@@ -1700,8 +2065,11 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #ifdef VF_K4_FWD_ONLY   // probe build only (tools/build_variant.sh): the forward sweep's share of the un-stamped kernel
     if constexpr (MODE == SOLVE_FULL) return;
 #endif
-    if constexpr (MODE == SOLVE_FULL_FWD) {
+    if constexpr (MODE == SOLVE_FULL_FWD || AS) {
         if (lane == 0) v.fail[w] = failed;
+#ifdef VF_SOLVE_STAMPS
+        if (w == 0 && lane == 0) { for (int i = 0; i < 6; i++) g_stamps[i] = st[i]; for (int i = 11; i < 16; i++) g_stamps[i] = st[i]; }
+#endif
         return;
     }
     if constexpr (MODE == SOLVE_CHUNK_FWD) {
@@ -1941,7 +2309,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     }
 #undef CBAR
 #ifdef VF_SOLVE_STAMPS
-    if (w == 0 && lane == 0) for (int i = 0; i < 16; i++) g_stamps[i] = st[i];
+    if (w == 0 && lane == 0) for (int i = (MODE == SOLVE_FULL_BWD ? 6 : 0); i < (MODE == SOLVE_FULL_BWD ? 11 : 16); i++) g_stamps[i] = st[i];
 #endif
     if constexpr (MODE == SOLVE_FULL) { if (lane == 0) v.fail[w] = failed; }
     else if constexpr (MODE != SOLVE_FULL_BWD) { if (lane == 0 && failed) atomicOr(v.fail + w, 1); }
@@ -1961,6 +2329,14 @@ __global__ void __launch_bounds__(64) k_band_forward(View v) {
     if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
     __shared__ double S[CW_TOTAL];
     band_solve_body<SOLVE_FULL_FWD>(v, S, nullptr, nullptr, w, threadIdx.x, 0);
+}
+// the assembling form (see SOLVE_ASM_FWD): one wave per SIMD, 39.7 KB of LDS; followed by k_band_backward
+__attribute__((amdgpu_waves_per_eu(1, 1)))
+__global__ void __launch_bounds__(64) k_band_forward_asm(View v) {
+    const int w = blockIdx.x;
+    if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
+    __shared__ __attribute__((aligned(16))) double S[AS_TOTAL];
+    band_solve_body<SOLVE_ASM_FWD>(v, S, nullptr, nullptr, w, threadIdx.x, 0);
 }
 __attribute__((amdgpu_waves_per_eu(2, 2)))
 __global__ void __launch_bounds__(64) k_band_backward(View v) {
@@ -2961,7 +3337,10 @@ void launch_band_solve(const View& v, hipStream_t s) {
     if (v.P >= 2) { launch_partitioned_solve(v, s); return; }
     // few windows: two waves per window from both ends (latency); many: one wave per window (throughput)
     if (v.B <= v.tw_max) hipLaunchKernelGGL(k_band_solve_tw, dim3(v.B), dim3(128), 0, s, v);
-    else if (v.split_min > 0 && v.B >= v.split_min) {
+    else if (asm_in_solve(v)) {
+        hipLaunchKernelGGL(k_band_forward_asm, dim3(v.B), dim3(64), 0, s, v);
+        hipLaunchKernelGGL(k_band_backward, dim3(v.B), dim3(64), 0, s, v);
+    } else if (v.split_min > 0 && v.B >= v.split_min) {
         hipLaunchKernelGGL(k_band_forward, dim3(v.B), dim3(64), 0, s, v);
         hipLaunchKernelGGL(k_band_backward, dim3(v.B), dim3(64), 0, s, v);
     } else hipLaunchKernelGGL(k_band_solve, dim3(v.B), dim3(64), 0, s, v);

@@ -172,6 +172,8 @@ struct View {
     int gate, gate_T;
     int tw_max;         // whole-window sweeps: up to this many windows two waves per window from both ends, above one wave per window
     int split_min;      // whole-window sweeps: from this many windows on, forward sweep and back substitution as two kernels (0 = never)
+    int asm_min;        // whole-window sweeps: from this many windows on, the forward sweep assembles H itself from the J stream and
+                        // K3 is not launched (0 = never; asm_in_solve() below)
     // "far" between factors: BetweenFactor<Pose3> on any pair of keyframes of a window (wider than the band, or a second factor
     // on an end key), at most x_max per window; kept out of the banded H and solved as a low-rank correction
     int x_max;          // 0 until vf_engine_set_extra_between is first called
@@ -181,6 +183,11 @@ struct View {
     double* x_out;      // [2][B][x_max][78] linearisations, double-buffered like btw_out
 };
 
+// does launch_band_solve(v) assemble the normal equations inside the forward sweep (so that launch_assemble may be skipped)?
+// One-wave whole-window sweeps of an unsharded engine only; the far-factor correction and the hybrid form solve from H.
+inline bool asm_in_solve(const View& v) {
+    return v.asm_min > 0 && v.B >= v.asm_min && v.P < 2 && v.B > v.tw_max && v.sh_G <= 1 && v.gate == 0;
+}
 // isotropic IMU covariances (ImuManagerRos.cpp:20-33)
 struct ImuCov { double acc, gyro, integration, bias_acc, bias_omega, bias_int; };
 void launch_preintegrate(const View& v, long g0, int n, const int* off, const double* steps, const double* bhat6,

@@ -83,8 +83,8 @@ def main():
             seq, imu, ba, bb, brec, prior = problem_inputs(4242, n, n)
             np.save(cache, imu)
         P = tq.Problem(seq.gt_states, np.arange(1, n), imu[1:], ba, bb, brec, 0, prior)
-        log = P.optimize(max_iterations=6, polish=14, verbose=True)
-        np.savez(os.path.join(HERE, "qr_twin_10k.npz"), seed=4242, n=n, poses=P.st.to_array()[:, :7], final_cost=log["final_cost"],
+        log = P.optimize(max_iterations=6, polish=6, verbose=True)
+        np.savez(os.path.join(HERE, "qr_twin_10k.npz"), seed=4242, n=n, states=P.st.to_array(), final_cost=log["final_cost"],
                  iterations=log["iterations"], polish_steps=np.array(log["polish_steps"]))
     if "--skip-fixed-lag" in sys.argv:
         return

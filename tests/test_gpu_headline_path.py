@@ -1,7 +1,8 @@
 """-m gpu: the EXACT path bench.py's headline number runs, against the oracle doing the same updates.
 
-bench.py: B = 1024 windows x 1000 poses -> launch_band_solve picks k_band_solve (one wave per window, the throughput form,
-B > vf_engine_opts.sweep_two_sided_max = 256), every update = vf_engine_slide(marginalize = 1) (K-marg: dense 27-dof prior,
+bench.py: B = 1024 windows x 1000 poses -> launch_band_solve picks the one-wave-per-window throughput form (B >
+vf_engine_opts.sweep_two_sided_max = 256), and from vf_engine_opts.solve_assemble_min = 1024 windows on its assembling variant
+(k_band_forward_asm + k_band_backward, no K3); both are run here, the second forced at 260 windows.  Every update = vf_engine_slide(marginalize = 1) (K-marg: dense 27-dof prior,
 6x15 strip on the window's third keyframe) + warm-started vf_engine_iterate(5).  Earlier marginalised-slide tests ran 2-3
 windows, i.e. the two-sided sweep or the partitioned form.  Here: > 256 windows of 1000 poses
 (distinct sequences in the sampled windows, factors preintegrated on the device as bench.py's make_engine does), >= 10
@@ -52,9 +53,11 @@ def _bench_like_engine(oracle, windows, sampled, slides, **opts):
     return eng, probs
 
 
-def test_one_wave_sweep_marginalised_warm_slides_vs_oracle(oracle):
+@pytest.mark.parametrize("form", ["k_band_solve", "assembling"])
+def test_one_wave_sweep_marginalised_warm_slides_vs_oracle(oracle, form):
     B, sampled = 260, (0, 129, 259)
-    eng, probs = _bench_like_engine(oracle, B, sampled, SLIDES)
+    opts = dict(solve_assemble_min=1 if form == "assembling" else 0)
+    eng, probs = _bench_like_engine(oracle, B, sampled, SLIDES, **opts)
     eng.iterate(INIT)
     refs = {w: helpers.FixedLagOracle(oracle, probs[w], N, ITERS, init_iterations=INIT) for w in sampled}
     for w in sampled:
@@ -79,9 +82,9 @@ def test_one_wave_sweep_marginalised_warm_slides_vs_oracle(oracle):
                 got, exp = eng.read_marginal(w), refs[w].marg.arrays()
                 assert got["on"] == 1
                 np.testing.assert_allclose(got["L"], exp["L"], atol=1e-9 * np.abs(exp["L"]).max())
-    print(f"k_band_solve (one wave per window), {B} windows x {N} poses, {SLIDES} marginalised warm slides: worst ATE {worst:.3e} m")
+    print(f"{form} (one wave per window), {B} windows x {N} poses, {SLIDES} marginalised warm slides: worst ATE {worst:.3e} m")
     # the same engine with warm start switched off gives the same bits (the headline's warm path against the cold one)
-    cold, _ = _bench_like_engine(oracle, B, sampled, SLIDES, cold_start=True)
+    cold, _ = _bench_like_engine(oracle, B, sampled, SLIDES, cold_start=True, **opts)
     cold.iterate(INIT)
     for s in range(1, SLIDES + 1):
         cold.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)

@@ -50,14 +50,15 @@ def test_split_solve_is_bit_identical_to_the_fused_kernel():
 
 
 def test_default_threshold_uses_the_split_form_from_2048_windows_on():
-    """vf_engine_opts.solve_split_min defaults to 2048: a 2048-window engine left at its defaults runs k_band_forward +
-    k_band_backward, also behind the termination rule's gate (hybrid K4), and gives the bits of the fused kernel."""
+    """vf_engine_opts.solve_split_min defaults to 2048: a 2048-window engine left at that default (and with the assembling
+    sweep, which would take precedence, switched off) runs k_band_forward + k_band_backward, also behind the termination
+    rule's gate (hybrid K4), and gives the bits of the fused kernel."""
     from vil_sensor_fusion_amd import Engine, EngineOpts
     n, B = 48, 2048
     seqs = [synth.make_sequence(seed=720 + i, n_kf=n + 2) for i in range(4)]
     engines = []
     for split in (None, 0):                       # library default (2048) / never
-        eng = Engine(EngineOpts(windows=B, capacity=n + 2, solve_split_min=split))
+        eng = Engine(EngineOpts(windows=B, capacity=n + 2, solve_split_min=split, solve_assemble_min=0))
         recs = [synth.between_records(s) for s in seqs]
         for w in range(B):
             s = seqs[w % 4]

@@ -213,7 +213,7 @@ void vf_engine_default_opts(vf_engine_opts* o) {
     o->use_hip_graph = 0;
     o->accept_rel = 1e-9;
     o->solve_split_min = 2048;
-    o->solve_assemble_min = 0;
+    o->solve_assemble_min = 1024;
 }
 
 int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {

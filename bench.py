@@ -646,6 +646,13 @@ def main():
         achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
         stages = {s: eng.time_stage(s, reps=5) for s in
                   ("linearize_imu", "linearize_between", "assemble", "assemble_idle", "solve", "retract", "decide")}
+        solve_form = eng.solve_form()
+        if solve_form == "assembling":
+            # K3 is not part of this engine's LM trial (the forward sweep of `solve` forms H itself): what the stage timer
+            # launched above is the stand-alone kernel, kept for comparison only
+            stages["assemble_k3_not_in_the_step"] = stages.pop("assemble")
+            stages.pop("assemble_idle")
+            stages["assemble"] = 0.0
         traffic = measured_traffic_per_imu_factor()
         prof = profiled_kernels()
         out = {
@@ -697,9 +704,17 @@ def main():
         # each way: 27 sub-diagonal rows + the rhs row x 15, and the 120 + 7 entries of L^-T its column pairs keep) + the
         # increment.
         k4_bytes_per_kf = 8 * (432 + 15 + 547 + 547 + 15)
+        k4_name = "k_band_solve (K4: damped block-banded Cholesky factorisation + both substitutions)"
+        if solve_form == "assembling":
+            # the assembling sweep reads the Jacobians instead of H and g: the J stream (528 doubles per factor incl. its
+            # padding), the residual (15), the between linearisation (78); panel, increment as above
+            k4_bytes_per_kf = 8 * (528 + 15 + 78 + 547 + 547 + 15)
+            k4_name = ("k_band_forward_asm + k_band_backward (K3 + K4 in one pass: block rows of J^T J formed on the matrix cores "
+                       "inside the forward sweep, damped block-banded Cholesky factorisation, both substitutions)")
         n_kf = args.windows * args.window
         k4_ach = n_kf * k4_bytes_per_kf / (stages["solve"] * 1e-3) / 1e9
-        out["roofline_solve"] = {"kernel": "k_band_solve (K4: damped block-banded Cholesky factorisation + both substitutions)",
+        out["solve_form"] = solve_form
+        out["roofline_solve"] = {"kernel": k4_name,
                                  "bound": "hbm", "achieved": k4_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                  "frac": k4_ach / HBM_PEAK_GBPS, "avg_launch_ms": stages["solve"],
                                  "algorithmic_bytes_per_keyframe": k4_bytes_per_kf,
@@ -714,6 +729,15 @@ def main():
                                                    "s_waitcnt 15 %; matrix pipes 11 % busy (DESIGN.md 7.9).  The HBM fraction is "
                                                    "quoted because it is what the kernel's traffic amounts to, not as its roofline",
                                  "traffic_note": "profiles/*_pmc_summary.md: k_band_solve read 2*FETCH_SIZE + WRITE_SIZE per launch"}
+        if solve_form == "assembling":
+            out["roofline_solve"]["irreducible_io_bytes_per_keyframe"] = 8 * (528 + 15 + 78 + 15)
+            out["roofline_solve"]["note"] = ("8.8 of the 13.8 KB per keyframe are the Cholesky panel written by the forward sweep and read "
+                                             "back by the backward one; the rest is the Jacobians K1 / K2 wrote (H is never stored)")
+            out["roofline_solve"]["what_bounds_it"] = (
+                "not HBM: one wave per SIMD (39.7 KB of LDS), whose step is the pivot chain of the 15 x 15 block plus 26 "
+                "v_mfma_f64_16x16x4 (12 of the Schur update, 14 that form the row of J^T J); a single wave gets one such "
+                "instruction through every ~143 cycles and the vector unit does not run under it (tools/probes/"
+                "mfma_f64_rate.hip: 34.7 TFLOP/s from one wave per SIMD, 47 at saturation).  DESIGN.md 7.13")
         if prof is not None:
             out["profiled_kernels"] = prof
         if conv is not None:

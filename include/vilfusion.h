@@ -260,6 +260,11 @@ int vf_engine_sync(vf_engine* e);
 /* vf_engine_opts.use_hip_graph: is replay active (0 once a capture failed or a caller's stream was handed in), how often the
  * launch sequence was captured, how many vf_engine_iterate calls were served by hipGraphLaunch */
 int vf_engine_graph_info(vf_engine* e, int* enabled, int* captures, long* replays);
+/* which form of K4 the next vf_engine_solve launches (it follows from the options, the batch and what the windows hold):
+ * 0 one wave per window, one kernel; 1 the same as forward sweep + back substitution (solve_split_min); 2 the assembling
+ * forward sweep + back substitution, no K3 (solve_assemble_min); 3 two waves per window from both ends; 4 partitioned;
+ * 5 hybrid of the one-wave and the partitioned form (termination rule on) */
+int vf_engine_solve_form(vf_engine* e, int* form);
 
 /* ---- read-back (synchronises) ---- */
 int vf_engine_read_imu_lin(vf_engine* e, int window, int which, int k0, int n, double* r15, double* J450);

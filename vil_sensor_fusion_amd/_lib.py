@@ -59,7 +59,7 @@ SYMBOLS = [
     "vf_engine_set_between", "vf_engine_clear_between", "vf_engine_set_extra_between", "vf_engine_set_prior",
     "vf_engine_linearize", "vf_engine_assemble", "vf_engine_solve", "vf_engine_retract",
     "vf_engine_decide", "vf_engine_iterate", "vf_engine_slide", "vf_engine_predict",
-    "vf_engine_sync", "vf_engine_graph_info",
+    "vf_engine_sync", "vf_engine_graph_info", "vf_engine_solve_form",
     "vf_engine_read_imu_lin", "vf_engine_read_between_lin", "vf_engine_read_normal",
     "vf_engine_read_delta", "vf_engine_read_panels", "vf_engine_read_lm",
     "vf_engine_time_stage", "vf_engine_time_iterate", "vf_engine_counts",

@@ -828,6 +828,17 @@ int vf_engine_iterate(vf_engine* e, int iterations) {
     mark_solved(e);
     return VF_OK;
 }
+int vf_engine_solve_form(vf_engine* e, int* form) {
+    if (!e || !form) return fail(VF_ERR_INVALID, "null argument");
+    const vf::View& v = e->v;
+    if (v.P >= 2) *form = 4;
+    else if (e->hybrid && v.stop_on) *form = 5;
+    else if (v.B <= v.tw_max) *form = 3;
+    else if (assembles_in_solve(e)) *form = 2;
+    else if (v.split_min > 0 && v.B >= v.split_min) *form = 1;
+    else *form = 0;
+    return VF_OK;
+}
 int vf_engine_graph_info(vf_engine* e, int* enabled, int* captures, long* replays) {
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (enabled) *enabled = (!e->graph_off && e->own_stream) ? 1 : 0;

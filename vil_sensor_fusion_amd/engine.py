@@ -229,6 +229,14 @@ class Engine:
         check(self._l.vf_engine_graph_info(self._h, C.byref(en), C.byref(cap), C.byref(rep)))
         return bool(en.value), cap.value, rep.value
 
+    SOLVE_FORMS = ("one_wave", "one_wave_split", "assembling", "two_sided", "partitioned", "hybrid")
+
+    def solve_form(self):
+        """which form of K4 the next solve launches (vf_engine_solve_form)"""
+        f = C.c_int()
+        check(self._l.vf_engine_solve_form(self._h, C.byref(f)))
+        return self.SOLVE_FORMS[f.value]
+
     # ---- time-sharded windows (see include/vilfusion.h; the collectives live in distributed.ShardedSolver)
     def set_stream(self, hip_stream):
         """Run every later stage on the caller's HIP stream (an integer hipStream_t, 0 = default stream)."""

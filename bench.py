@@ -706,9 +706,9 @@ def main():
         k4_bytes_per_kf = 8 * (432 + 15 + 547 + 547 + 15)
         k4_name = "k_band_solve (K4: damped block-banded Cholesky factorisation + both substitutions)"
         if solve_form == "assembling":
-            # the assembling sweep reads the Jacobians instead of H and g: the J stream (528 doubles per factor incl. its
-            # padding), the residual (15), the between linearisation (78); panel, increment as above
-            k4_bytes_per_kf = 8 * (528 + 15 + 78 + 547 + 547 + 15)
+            # the assembling sweep reads the Jacobians instead of H and g: the J stream (292 doubles per factor: the 291 entries
+            # that are not structurally zero + padding), the residual (15), the between linearisation (78); panel, increment as above
+            k4_bytes_per_kf = 8 * (292 + 15 + 78 + 547 + 547 + 15)
             k4_name = ("k_band_forward_asm + k_band_backward (K3 + K4 in one pass: block rows of J^T J formed on the matrix cores "
                        "inside the forward sweep, damped block-banded Cholesky factorisation, both substitutions)")
         n_kf = args.windows * args.window
@@ -730,8 +730,8 @@ def main():
                                                    "quoted because it is what the kernel's traffic amounts to, not as its roofline",
                                  "traffic_note": "profiles/*_pmc_summary.md: k_band_solve read 2*FETCH_SIZE + WRITE_SIZE per launch"}
         if solve_form == "assembling":
-            out["roofline_solve"]["irreducible_io_bytes_per_keyframe"] = 8 * (528 + 15 + 78 + 15)
-            out["roofline_solve"]["note"] = ("8.8 of the 13.8 KB per keyframe are the Cholesky panel written by the forward sweep and read "
+            out["roofline_solve"]["irreducible_io_bytes_per_keyframe"] = 8 * (292 + 15 + 78 + 15)
+            out["roofline_solve"]["note"] = ("8.8 of the 12.0 KB per keyframe are the Cholesky panel written by the forward sweep and read "
                                              "back by the backward one; the rest is the Jacobians K1 / K2 wrote (H is never stored)")
             out["roofline_solve"]["what_bounds_it"] = (
                 "not HBM: one wave per SIMD (39.7 KB of LDS), whose step is the pivot chain of the 15 x 15 block plus 26 "

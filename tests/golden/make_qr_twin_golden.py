@@ -11,9 +11,10 @@ every consumer rebuilds the same problem from the seed; nothing of oracle/vf_ora
   qr_twin_tunnel.npz     BASELINE configs[3]: the LiDAR-degenerate tunnel sequence (seed 41, 400 poses, 20 % of the LiDAR
                          between factors with 1e-6 x the nominal information along the track): batch optimum
   qr_twin_10k.npz        BASELINE configs[4]: the 10 000-pose global smoother window bench.py spreads in time over the ranks
-                         (seed 4242): batch optimum, started from the ground truth (from IMU dead reckoning a window of
-                         333 s needs hundreds of LM trials; the optimum does not depend on the start); poses only
-                         (--with-10k: 30 more minutes of twin preintegration)
+                         (seed 4242): the batch optimum, by six LM iterations from the ground truth and six undamped
+                         Gauss-Newton steps (damped steps creep along the window's soft mode; the full step crosses it:
+                         7.4, 3e-3, 4e-5, 7e-8, then the floor 1e-8).  --with-10k: 27 minutes of twin preintegration, cached
+                         under /tmp, + 10 minutes of QR
   qr_twin_fixed_lag.npz  the window of bench.py's GPU window 0 (seed 0, sequence length 1065 = what bench.py generates for
                          its defaults and for the driver's --steps 20 --warmup 5): the 1000-pose batch optimum
                          (BASELINE configs[2], update 0) and the window after u = 1..25 marginalised fixed-lag updates

@@ -100,3 +100,30 @@ def test_config3_tunnel_sequence_vs_independent_qr_optimum(form):
     print(f"configs[3] tunnel, {form}: HIP vs independent QR optimum: ATE {a:.3e} m, rot {r:.3e} rad")
     assert a <= 1e-8 and r <= 1e-6 and eng.read_lm(0)["solve_failures"] == 0
     eng.close()
+
+
+@pytest.mark.parametrize("form", ["partitioned", "one_wave_sweep"])
+def test_config4_10000_pose_optimum_is_a_fixed_point_of_the_device_path(form):
+    """BASELINE configs[4]: the 10 000-pose window, started AT the optimum undamped Gauss-Newton by QR found for it
+    (tests/golden/qr_twin_10k.npz; why not from dead reckoning: tests/test_qr_twin.py, the soft mode).  The device
+    preintegrates its own factors; five LM trials must all be accepted, leave the cost where it is (1e-12) and the
+    trajectory within 1e-8 m of the independent optimum."""
+    F = np.load(os.path.join(GOLD, "qr_twin_10k.npz"))
+    n = int(F["n"])
+    seq = synth.make_sequence(seed=int(F["seed"]), n_kf=n)
+    opts = dict(chunks=1, sweep_two_sided_max=0, solve_assemble_min=1) if form == "one_wave_sweep" else {}
+    eng = Engine(EngineOpts(windows=1, capacity=n, **opts))
+    eng.preintegrate(0, 1, seq.imu_off[1:n + 1], seq.imu_steps, np.zeros(6), synth.CARLA_IMU_COV)
+    eng.set_between(0, seq.btw_a, seq.btw_b, synth.between_records(seq))
+    eng.set_states(0, 0, F["states"])
+    eng.set_prior(0, 0, synth.prior_record(seq.gt_states[0], REFERENCE_PRIOR_SIGMAS))
+    eng.set_range(0, 0, n)
+    eng.iterate(5)
+    lm = eng.read_lm(0)
+    a, r = helpers.ate(eng.get_states(0, 0, n), F["states"])
+    print(f"configs[4], {form} ({eng.solve_form()}): started at the independent QR optimum, 5 trials: ATE {a:.3e} m, rot {r:.3e} rad, "
+          f"cost {lm['cost']:.12e} (QR twin {float(F['final_cost']):.12e}), accepted {lm['accepted']}")
+    assert abs(lm["cost"] - float(F["final_cost"])) <= 1e-11 * lm["cost"]
+    assert lm["accepted"] == 5 and lm["solve_failures"] == 0
+    assert a <= 1e-8 and r <= 1e-6
+    eng.close()

@@ -25,7 +25,8 @@ def _far_record(seq, a, b, rng, cov=0.05, noise=(5e-4, 5e-3)):
     return rec
 
 
-FAR = [(40, 46), (20, 130), (21, 131)]       # a span-6 factor whose end key 46 also has its band factor; a loop-closure pair
+FAR = [(40, 46), (20, 70), (21, 71)]         # a span-6 factor whose end key 46 also has its band factor; a loop-closure pair
+#                                              (span 50: the oracle's dense band costs span^2 -- at span 110 it was half of the GPU suite's time)
 
 
 @pytest.mark.parametrize("form", ["partitioned", "one_wave_sweep"])
@@ -49,7 +50,7 @@ def test_far_factors_match_the_oracle(oracle, form):
         p = dict(prob, btw_a=np.concatenate([prob["btw_a"], fa[sel]]).astype(np.int32),
                  btw_b=np.concatenate([prob["btw_b"], fb[sel]]).astype(np.int32), btw=np.vstack([prob["btw"], far_rec[sel]]))
         win = helpers.oracle_window(oracle, p)
-        assert win.bandwidth() == (110 if sel else 3)
+        assert win.bandwidth() == (50 if sel else 3)
         costs, _, _ = win.lm(iterations=20)
         got = eng.get_states(w, 0, n)
         a, r = helpers.ate(got, win.states)
@@ -96,7 +97,7 @@ def test_graph_manager_takes_any_pair_of_keys(oracle, compat):
     from vil_sensor_fusion_amd.graph_manager import GraphManager
     n = 120
     seq = synth.make_sequence(33, n)
-    far = [(30, 36), (10, 100), (11, 101)]
+    far = [(30, 36), (10, 60), (11, 61)]
     rng = np.random.default_rng(6)
     recs = [_far_record(seq, a, b, rng) for a, b in far]
     gm = GraphManager(capacity=128, iterations=25, rel_tol=0, abs_tol=0, reference_compat=compat)
@@ -212,12 +213,12 @@ def test_far_factor_information_extremes(oracle, cov):
     seq = synth.make_sequence(seed=95, n_kf=n)
     prob = helpers.build_problem(oracle, seq, perturb=0.002)
     rng = np.random.default_rng(8)
-    rec = _far_record(seq, 15, 140, rng, cov=cov, noise=(1e-4, 1e-3))[None]
+    rec = _far_record(seq, 15, 65, rng, cov=cov, noise=(1e-4, 1e-3))[None]
     eng = Engine(EngineOpts(windows=1, capacity=n))
     helpers.load_engine(eng, 0, prob)
-    eng.set_extra_between(0, [15], [140], rec)
+    eng.set_extra_between(0, [15], [65], rec)
     eng.iterate(40)
-    p = dict(prob, btw_a=np.concatenate([prob["btw_a"], [15]]).astype(np.int32), btw_b=np.concatenate([prob["btw_b"], [140]]).astype(np.int32),
+    p = dict(prob, btw_a=np.concatenate([prob["btw_a"], [15]]).astype(np.int32), btw_b=np.concatenate([prob["btw_b"], [65]]).astype(np.int32),
              btw=np.vstack([prob["btw"], rec]))
     win = helpers.oracle_window(oracle, p)
     costs, _, _ = win.lm(iterations=40)

@@ -115,6 +115,44 @@ def test_between_factor_spans_and_gaps(oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 7, 9, 13])
+def test_tiny_windows(oracle, n):
+    """windows shorter than the sweep's unroll, than a J-stream tile, than the profile: rows past the window's end are
+    identity rows, factors past it zeros."""
+    seq = synth.make_sequence(21, 24)
+    prob = helpers.build_problem(oracle, seq, perturb=0.01)
+    eng = Engine(EngineOpts(windows=2, capacity=24, solve_assemble_min=1, **SWEEP))
+    for w, lo in ((0, 0), (1, 6)):
+        helpers.load_engine(eng, w, prob, lo=lo, hi=lo + n)
+    assert eng.solve_form() == "assembling"
+    eng.iterate(12)
+    for w, lo in ((0, 0), (1, 6)):
+        win = helpers.oracle_window(oracle, prob, lo=lo, hi=lo + n)
+        costs, _, _ = win.lm(iterations=12)
+        a, r = helpers.ate(eng.get_states(w, lo, n), win.states)
+        assert a <= 1e-6 and r <= 1e-6, (n, w, a, r)
+        assert abs(eng.read_lm(w)["cost"] - costs[-1]) <= 1e-6 * max(costs[-1], 1e-9)
+    eng.close()
+
+
+def test_termination_rule_on_a_small_batch():
+    """GTSAM's LM rule on an engine too small for the hybrid form (<= 128 windows): windows that are done drop out of the later
+    trials of the assembling sweep as of every other kernel; same trial counts as the two-kernel form, states to rounding."""
+    n, B = 110, 6
+    seqs = [synth.make_sequence(seed=890 + i, n_kf=n + 2) for i in range(B)]
+    two, asm = _pair(seqs, n, 0)
+    for e in (two, asm):
+        e.set_convergence(1e-5, 1e-5)
+        e.iterate(30)
+    assert asm.solve_form() == "assembling" and two.solve_form() == "one_wave"
+    for w in range(B):
+        a, b = two.read_lm(w), asm.read_lm(w)
+        assert a["accepted"] + a["rejected"] == b["accepted"] + b["rejected"] < 30
+        assert np.abs(two.get_states(w, 0, n) - asm.get_states(w, 0, n)).max() <= 1e-9
+    two.close()
+    asm.close()
+
+
 def test_read_normal_assembles_on_demand():
     """vf_engine_read_normal on an engine whose solves never store H: the rows come from K3, launched for the read, and are
     the rows the two-kernel engine holds after the same trials."""

@@ -12,11 +12,11 @@ from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("form", ["partitioned", "one_wave_sweep"])
+@pytest.mark.parametrize("form", ["partitioned", "one_wave_sweep", "assembling_sweep"])
 def test_graph_replay_is_bit_identical_to_plain_launches(form):
     n, updates = 96, 10
     seqs = [synth.make_sequence(seed=500 + i, n_kf=n + updates + 1) for i in range(3)]
-    opts = dict(chunks=1, sweep_two_sided_max=0) if form == "one_wave_sweep" else {}
+    opts = {} if form == "partitioned" else dict(chunks=1, sweep_two_sided_max=0, solve_assemble_min=1 if form == "assembling_sweep" else 0)
     eager = _engine(None, seqs, n, updates, **opts)
     graph = _engine(None, seqs, n, updates, use_hip_graph=True, **opts)
     calls = 0

@@ -28,14 +28,16 @@ def _pair(seqs, n, updates, **opts):
 
 def test_first_trial_agrees_with_the_two_kernel_form_to_rounding():
     """One staged LM trial from the same linearisation: increments and Cholesky panels of K3 + k_band_solve against the
-    assembling sweep, ragged windows (identity-padded lengths), first slots 0 .. 8 (every position inside a tile)."""
+    assembling sweep, ragged windows (identity-padded lengths), first slots 0 .. 8 (every position inside a tile), the prior on the
+    first keyframe or on the twelfth."""
     n, B = 150, 10
     seqs = [synth.make_sequence(seed=810 + i, n_kf=n + 2) for i in range(B)]
     two, asm = _pair(seqs, n, 0)
     worst_p = worst_d = 0.0
     for e in (two, asm):
         for w in range(B):
-            e.set_prior(w, w % 9, synth.prior_record(seqs[w].gt_states[w % 9], REFERENCE_PRIOR_SIGMAS))
+            pk = w % 9 + (11 if w % 2 else 0)        # odd windows: the prior sits on a keyframe in the middle (rows past the first four take it by another path)
+            e.set_prior(w, pk, synth.prior_record(seqs[w].gt_states[pk], REFERENCE_PRIOR_SIGMAS))
             e.set_range(w, w % 9, n - 5 * (w % 4) - (w % 3))
         e.linearize()
         e.decide(init=True)

@@ -1323,6 +1323,21 @@ constexpr int S_TOTAL_RING = S_BC_RING + 16;
 #endif
 #define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define VF_PIVOT_SLOT(i) do {} while (0)     // places the generated pivot code leaves for its caller (tools/gen_pivot.py)
+#ifndef VF_AS_PLACEMENT
+#define VF_AS_PLACEMENT 0   // which of the pivot code's 28 places take the assembling sweep's 15 pieces (as_piece_of_slot)
+#endif
+// piece (the I of as_piece: 0 = operand reads, 2 .. 17 = one matrix instruction each, with gaps) issued at place `slot` of the
+// pivot code; 1 = none.  Placement 0: as early as possible (places 0 .. 17); 1: every other place; 2: as late as possible
+constexpr int as_piece_of_slot(int slot) {
+    constexpr int pieces[15] = {0, 2, 3, 4, 5, 7, 8, 9, 10, 12, 13, 14, 15, 16, 17};
+#if VF_AS_PLACEMENT == 0
+    return slot;
+#elif VF_AS_PLACEMENT == 1
+    return slot == 0 ? 0 : (slot % 2 == 1 ? pieces[(slot + 1) / 2] : 1);
+#else
+    return slot == 0 ? 0 : ((slot >= 12 && slot <= 25) ? pieces[slot - 11] : 1);
+#endif
+}
 #ifndef VF_AS_SLOTS
 #define VF_AS_SLOTS 1     // assembling sweep: 1 = its matrix-core pieces ride in the pivot code's places, 0 = in front of the Schur update
 #endif
@@ -1970,7 +1985,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         const int as_fimg = AS_LJ + ((lo + k + 5) & (JT - 1)) * LJS;
 #undef VF_PIVOT_SLOT
 #if VF_AS_SLOTS
-#define VF_PIVOT_SLOT(i) do { if constexpr (AS) { as_piece(IC<(i)>{}, az, as_fimg); if constexpr ((i) == 1) as_stage_btw(k + 4, az, anx); if constexpr ((i) == 26) as_rmw(ph, az); VF_SB(); } } while (0)
+#define VF_PIVOT_SLOT(i) do { if constexpr (AS) { as_piece(IC<as_piece_of_slot(i)>{}, az, as_fimg); if constexpr ((i) == 1) as_stage_btw(k + 4, az, anx); if constexpr ((i) == 26) as_rmw(ph, az); VF_SB(); } } while (0)
 #else
 #define VF_PIVOT_SLOT(i) do {} while (0)
 #endif

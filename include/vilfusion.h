@@ -97,7 +97,9 @@ typedef struct {
                                 launched: H is neither written nor read back (vf_engine_read_normal assembles it on demand).
                                 Same sums in another order: agrees with the two-kernel form to rounding, not to the bit.  Not
                                 used while a window holds far between factors, on sharded engines, or by the partitioned
-                                form.  0 = never. */
+                                form; in the hybrid solve (termination rule on) the sweep half uses it and the assembly
+                                kernel runs for the partitioned half only.  Default 1024 (below ~600 windows the assembly
+                                kernel's launch is shorter than what the sweep pays); 0 = never. */
 } vf_engine_opts;
 
 void vf_engine_default_opts(vf_engine_opts* o);

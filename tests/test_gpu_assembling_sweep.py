@@ -8,7 +8,7 @@ oracle it is held to the same bars as every other form.  Covered here: ragged wi
 all eight positions of a J-stream tile (slides), marginalised slides (6 x 15 strip of the marginal prior), a prior on
 a keyframe in the middle of the window, windows without any between factor and with factors reaching back 1, 2 and 3
 keyframes, vf_engine_read_normal on such an engine, and the cases in which the engine must NOT use the form (far
-factors, the termination rule's hybrid solve), where it has to give the bits of the two-kernel path."""
+factors; the partitioned half of the termination rule's hybrid solve), where it has to give the bits of the two-kernel path."""
 import numpy as np
 import pytest
 
@@ -183,8 +183,10 @@ def test_read_normal_assembles_on_demand():
 
 
 def test_forms_that_need_H_fall_back_to_the_two_kernel_path():
-    """Far between factors (their low-rank correction solves from H and g) and the termination rule's hybrid solve (the
-    partitioned form reads H): an engine asked for the assembling sweep must run K3 + K4 there and give their bits."""
+    """Far between factors (their low-rank correction solves from H and g): an engine asked for the assembling sweep must run
+    K3 + K4 there and give their bits.  The termination rule's hybrid solve: its partitioned half reads H, which K3 then
+    assembles for it alone (gated, and without trusting the `fresh` flags) -- below the hybrid threshold that half does
+    all the work, and the bits are those of the two-kernel engine.  (The sweep half under the rule: test_gpu_headline_path.)"""
     n, B = 80, 3
     seqs = [synth.make_sequence(seed=870 + i, n_kf=n + 4) for i in range(B)]
     two, asm = _pair(seqs, n, 2)

@@ -116,7 +116,8 @@ def test_two_sided_threshold_zero_forces_the_one_wave_form(oracle):
     eng.close()
 
 
-def test_hybrid_solve_with_termination_rule_marginalised_slides_vs_oracle(oracle):
+@pytest.mark.parametrize("sweep", ["k_band_solve", "assembling"])
+def test_hybrid_solve_with_termination_rule_marginalised_slides_vs_oracle(oracle, sweep):
     """bench.py's `with_convergence_exit` path: the same updates with GTSAM's LM rule on (1e-5 / 1e-5).  K4 launches both
     forms per trial; with 260 windows and the default threshold of 256 the sweep runs while more than 256 windows take
     trials and the partitioned form afterwards.  The oracle applies the same rule (vfo_lm rel_tol / abs_tol).
@@ -129,9 +130,12 @@ def test_hybrid_solve_with_termination_rule_marginalised_slides_vs_oracle(oracle
     under the rule the trajectories are compared at 1e-5 m, the costs at 1e-8 and the trial counts exactly +-1; then
     the rule is switched off and ONE update with all K trials must bring the two back within the 1e-6 m bar."""
     B, sampled = 260, (3, 200)
-    eng, probs = _bench_like_engine(oracle, B, sampled, SLIDES + 1)
+    # (sweep = "assembling": the sweep half of the hybrid forms its own rows of H and K3 runs for the partitioned half only --
+    # what a 1 024-window engine does under the rule)
+    eng, probs = _bench_like_engine(oracle, B, sampled, SLIDES + 1, solve_assemble_min=1 if sweep == "assembling" else 0)
     eng.iterate(INIT)
     eng.set_convergence(1e-5, 1e-5)
+    assert eng.solve_form() == "hybrid"
     refs = {w: helpers.FixedLagOracle(oracle, probs[w], N, ITERS, init_iterations=INIT) for w in sampled}
     for r in refs.values():
         r.rel_tol = r.abs_tol = 1e-5

@@ -691,11 +691,20 @@ int vf_engine_linearize(vf_engine* e, int which) {
 static bool assembles_in_solve(const vf_engine* e) {
     return vf::asm_in_solve(e->v) && e->x_used == 0 && !(e->hybrid && e->v.stop_on);
 }
+// hybrid solves (termination rule on): the sweep half assembles its own rows, K3 runs for the partitioned half only
+static bool assembles_in_hybrid(const vf_engine* e) {
+    return e->hybrid && e->v.stop_on && vf::asm_in_hybrid(e->v) && e->x_used == 0;
+}
 int vf_engine_assemble(vf_engine* e) {
     DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (assembles_in_solve(e)) return VF_OK;
+    if (assembles_in_hybrid(e)) {
+        vf::launch_assemble_for_partitioned(e->v, e->stream);
+        HIPCHK(hipGetLastError());
+        return VF_OK;
+    }
     vf::launch_assemble(e->v, e->stream);
     if (e->x_used > 0) vf::launch_extra_gradient(e->v, e->stream);   // the far factors' J^T r (their J^T J stays out of the band)
     HIPCHK(hipGetLastError());
@@ -716,7 +725,7 @@ int vf_engine_solve(vf_engine* e) {
         vf::View a = e->v;
         a.gvec = gvec;
         a.delta = delta;
-        if (!assembles_in_solve(e)) a.asm_min = 0;
+        if (!assembles_in_solve(e) && !assembles_in_hybrid(e)) a.asm_min = 0;
         if (e->hybrid && e->v.stop_on) {
             vf::View p = e->partitioned_view();
             p.gvec = gvec;
@@ -1320,7 +1329,7 @@ int vf_engine_read_normal(vf_engine* e, int window, int k0, int n, double* Hband
     if (rc) return rc;
     if (n == 0) return VF_OK;
     const size_t g0 = (size_t)window * e->v.M + k0;
-    if (assembles_in_solve(e)) {
+    if (assembles_in_solve(e) || assembles_in_hybrid(e)) {
         // H and g are not kept by the solves of this engine: assemble them now, for every window (any value outside 0 .. 63
         // in `fresh` means "the whole window"; nothing else reads the flag on such an engine)
         HIPCHK(hipMemsetAsync(e->v.fresh, 1, (size_t)e->v.B * sizeof(int), e->stream));

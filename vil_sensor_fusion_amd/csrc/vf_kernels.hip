@@ -1121,8 +1121,11 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     // as a launch can -- one flag read, no index arithmetic in front of it (an all-rejected batch used to take 0.73 ms)
     const int w = blockIdx.y;
     // (the window's scalars requested together, in front of the first test: one memory round trip, not three)
-    const int fr = v.fresh[w], lo = v.lo[w], hi = v.hi[w], w_sel = v.sel[w], w_done = v.stop_on ? v.done[w] : 0;
-    if (!fr || w_done) return;
+    // (hybrid solve of an engine whose sweep assembles its own rows: K3 works for the partitioned form only -- launched with
+    // gate = 2, it returns while the sweep is the form in charge, and when it does run it cannot trust `fresh`: the trials the
+    // sweep served never brought H up to date)
+    const int fr = v.gate == 2 ? 1 : v.fresh[w], lo = v.lo[w], hi = v.hi[w], w_sel = v.sel[w], w_done = v.stop_on ? v.done[w] : 0;
+    if (!fr || w_done || gated_off(v)) return;
     const int k0 = blockIdx.x * AT;
     const long gk0 = (long)w * v.M + k0;
     // warm start (k_linearize_tail): fr = 1 + appended keyframes; only rows near the ends of the window changed --
@@ -1329,7 +1332,7 @@ constexpr int S_TOTAL_RING = S_BC_RING + 16;
 // piece (the I of as_piece: 0 = operand reads, 2 .. 17 = one matrix instruction each, with gaps) issued at place `slot` of the
 // pivot code; 1 = none.  Placement 0: as early as possible (places 0 .. 17); 1: every other place; 2: as late as possible
 constexpr int as_piece_of_slot(int slot) {
-    constexpr int pieces[15] = {0, 2, 3, 4, 5, 7, 8, 9, 10, 12, 13, 14, 15, 16, 17};
+    [[maybe_unused]] constexpr int pieces[15] = {0, 2, 3, 4, 5, 7, 8, 9, 10, 12, 13, 14, 15, 16, 17};
 #if VF_AS_PLACEMENT == 0
     return slot;
 #elif VF_AS_PLACEMENT == 1
@@ -3310,6 +3313,12 @@ void launch_linearize_tail(const View& v, int nslid, hipStream_t s) {
 void launch_linearize_prior(const View& v, int which, hipStream_t s) {
     hipLaunchKernelGGL(k_linearize_prior, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, which);
 }
+// K3 for the partitioned half of a hybrid solve whose sweep half assembles its own rows (see k_assemble)
+void launch_assemble_for_partitioned(const View& v, hipStream_t s) {
+    View a = v;
+    a.gate = 2;
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)(v.M / AT), (unsigned)v.B), dim3(K3_NT), 0, s, a);
+}
 void launch_assemble(const View& v, hipStream_t s) {
     // (persistent forms were measured slower: one workgroup per CU with the next tile's loads in flight 5.1 ms, a plain
     // tile loop on 1024-2048 workgroups 4.0-4.3 ms, against 2.7 ms for one workgroup per tile -- stores count in vmcnt
@@ -3378,7 +3387,10 @@ void launch_band_solve_hybrid(const View& v, const View& vp, hipStream_t s) {
     View a = v, b = vp;
     a.gate = 1;
     b.gate = 2;
-    if (a.split_min > 0 && a.B >= a.split_min) {
+    if (asm_in_hybrid(v)) {
+        hipLaunchKernelGGL(k_band_forward_asm, dim3(a.B), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_band_backward, dim3(a.B), dim3(64), 0, s, a);
+    } else if (a.split_min > 0 && a.B >= a.split_min) {
         hipLaunchKernelGGL(k_band_forward, dim3(a.B), dim3(64), 0, s, a);
         hipLaunchKernelGGL(k_band_backward, dim3(a.B), dim3(64), 0, s, a);
     } else hipLaunchKernelGGL(k_band_solve, dim3(a.B), dim3(64), 0, s, a);

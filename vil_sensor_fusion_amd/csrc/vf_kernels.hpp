@@ -188,6 +188,10 @@ struct View {
 inline bool asm_in_solve(const View& v) {
     return v.asm_min > 0 && v.B >= v.asm_min && v.P < 2 && v.B > v.tw_max && v.sh_G <= 1 && v.gate == 0;
 }
+// the same question for the SWEEP half of a hybrid solve (launch_band_solve_hybrid; K3 then serves the partitioned half only)
+inline bool asm_in_hybrid(const View& v) {
+    return v.asm_min > 0 && v.B >= v.asm_min && v.P < 2 && v.B > v.tw_max && v.sh_G <= 1;
+}
 // isotropic IMU covariances (ImuManagerRos.cpp:20-33)
 struct ImuCov { double acc, gyro, integration, bias_acc, bias_omega, bias_int; };
 void launch_preintegrate(const View& v, long g0, int n, const int* off, const double* steps, const double* bhat6,
@@ -207,6 +211,7 @@ void launch_linearize_between_prior(const View& v, int which, hipStream_t s);   
 void launch_linearize_tail(const View& v, int nslid, hipStream_t s);   // warm start: factors of the appended keyframes + priors
 void launch_linearize_all(const View& v, int which, hipStream_t s);   // the three above in one launch (few windows)
 void launch_assemble(const View& v, hipStream_t s);
+void launch_assemble_for_partitioned(const View& v, hipStream_t s);   // hybrid solves with an assembling sweep (asm_in_hybrid)
 void launch_band_solve(const View& v, hipStream_t s);
 void launch_count_active(const View& v, hipStream_t s);
 // hybrid K4 (see View::gate): vp = the same engine viewed with the partitioned form's chunk count

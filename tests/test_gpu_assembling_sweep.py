@@ -225,3 +225,23 @@ def test_forms_that_need_H_fall_back_to_the_two_kernel_path():
         np.testing.assert_array_equal(engines[0].get_states(w, 0, n), engines[1].get_states(w, 0, n))
     for e in engines:
         e.close()
+
+
+def test_library_defaults_pick_the_form_by_batch():
+    """vf_engine_solve_form on engines left at the library's defaults: the partitioned form up to 128 windows, two waves per
+    window up to 256, one wave per window above, the assembling sweep from 1 024 on (bench.py's headline batch), the hybrid once the termination rule is
+    switched on (above 128 windows); chunks >= 2 is the partitioned form whatever the batch."""
+    for windows, form in ((2, "partitioned"), (128, "partitioned"), (129, "two_sided"), (256, "two_sided"), (300, "one_wave"), (1023, "one_wave"),
+                          (1024, "assembling"), (2048, "assembling")):
+        eng = Engine(EngineOpts(windows=windows, capacity=64))
+        assert eng.solve_form() == form, (windows, eng.solve_form())
+        if windows in (300, 1024):
+            eng.set_convergence(1e-5, 1e-5)
+            assert eng.solve_form() == "hybrid"
+        eng.close()
+    eng = Engine(EngineOpts(windows=1024, capacity=64, chunks=4))
+    assert eng.solve_form() == "partitioned"
+    eng.close()
+    eng = Engine(EngineOpts(windows=2048, capacity=64, solve_assemble_min=0))
+    assert eng.solve_form() == "one_wave_split"
+    eng.close()

@@ -18,14 +18,16 @@ pytestmark = pytest.mark.gpu
 TUNNEL = (0.4, 0.6, 1e-6)
 
 
-@pytest.mark.parametrize("chunks", [0, 1])
+@pytest.mark.parametrize("chunks", [0, 1, "assembling"])
 def test_tunnel_sequence_trajectory_parity(oracle, chunks):
+    """partitioned solver, one sweep, and the one-wave sweep that assembles its own rows of H (anisotropic between factors)"""
     from vil_sensor_fusion_amd import Engine, EngineOpts
     n = 400
     seq = synth.make_sequence(seed=41, n_kf=n, tunnel=TUNNEL)
     assert seq.tunnel.sum() == 80 and seq.btw_info.min() == 1e-6
     prob = helpers.build_problem(oracle, seq, perturb=0.005)
-    eng = Engine(EngineOpts(windows=1, capacity=n, chunks=chunks))
+    eng = Engine(EngineOpts(windows=1, capacity=n, chunks=1, sweep_two_sided_max=0, solve_assemble_min=1) if chunks == "assembling"
+                 else EngineOpts(windows=1, capacity=n, chunks=chunks))
     helpers.load_engine(eng, 0, prob)
     eng.iterate(8)
     win = helpers.oracle_window(oracle, prob)

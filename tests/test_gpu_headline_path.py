@@ -234,11 +234,13 @@ def test_two_lm_histories_back_to_back_report_their_own_numbers(oracle):
 
 
 def test_agreement_across_sequences(oracle):
-    """tools/accuracy_sweep.py at test size: six more sequences through the same path (260 windows, converged start, six
-    marginalised warm updates of five trials): GPU and oracle within 1e-8 m on every window after every update."""
+    """tools/accuracy_sweep.py at test size: six more sequences through the headline's path -- the assembling one-wave sweep,
+    260 windows, converged start, six marginalised warm updates of five trials: GPU and oracle within 1e-8 m on every
+    window after every update."""
     B, slides = 260, 6
     sampled = tuple(range(10, 250, 40))
-    eng, probs = _bench_like_engine(oracle, B, sampled, slides)
+    eng, probs = _bench_like_engine(oracle, B, sampled, slides, solve_assemble_min=1)
+    assert eng.solve_form() == "assembling"
     eng.iterate(INIT)
     refs = {w: helpers.FixedLagOracle(oracle, probs[w], N, ITERS, init_iterations=INIT) for w in sampled}
     worst = 0.0

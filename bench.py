@@ -738,6 +738,15 @@ def main():
                 "v_mfma_f64_16x16x4 (12 of the Schur update, 14 that form the row of J^T J); a single wave gets one such "
                 "instruction through every ~143 cycles and the vector unit does not run under it (tools/probes/"
                 "mfma_f64_rate.hip: 34.7 TFLOP/s from one wave per SIMD, 47 at saturation).  DESIGN.md 7.13")
+            mfma_flop = 26 * 2048.0 * n_kf           # per launch of the forward sweep: 12 (Schur update) + 14 (rows of J^T J) tiles per keyframe
+            out["roofline_solve"]["matrix_instruction_view"] = {
+                "bound": "mfma", "unit": "TFLOP/s", "flop_per_launch": mfma_flop,
+                "achieved": mfma_flop / (stages["solve"] * 1e-3) / 1e12,
+                "peak_measured_one_wave_per_simd": 34.7, "peak_measured_saturated": 47.3, "peak_data_sheet_f64_matrix": 78.6,
+                "frac_of_what_one_wave_per_simd_can_issue": mfma_flop / (stages["solve"] * 1e-3) / 1e12 / 34.7,
+                "note": "the time is that of forward sweep + back substitution (the stage timer's `solve`); the back substitution "
+                        "(0.92 ms of it) issues no matrix instruction; peaks measured by tools/probes/mfma_f64_rate.hip "
+                        "(profiles/r04_mfma_f64_rate.log)"}
         if prof is not None:
             out["profiled_kernels"] = prof
         if conv is not None:

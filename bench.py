@@ -477,6 +477,8 @@ def main():
     ap.add_argument("--no-graph-manager", action="store_true")
     ap.add_argument("--solve-assemble-min", type=int, default=None,
                     help="vf_engine_opts.solve_assemble_min of the headline engine (default: the library's)")
+    ap.add_argument("--solve-assemble-waves", type=int, default=None,
+                    help="vf_engine_opts.solve_assemble_waves of the headline engine (default: the library's)")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -520,7 +522,8 @@ def main():
     dev = torch.device("cuda", gpu)
 
     eng, feed = make_engine(args, gpu, args.windows, seqs, updates,
-                            **({} if args.solve_assemble_min is None else {"solve_assemble_min": args.solve_assemble_min}))
+                            **({} if args.solve_assemble_min is None else {"solve_assemble_min": args.solve_assemble_min}),
+                            **({} if args.solve_assemble_waves is None else {"solve_assemble_waves": args.solve_assemble_waves}))
     del seqs
     fed = {id(eng): 0}
 

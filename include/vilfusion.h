@@ -98,8 +98,12 @@ typedef struct {
                                 Same sums in another order: agrees with the two-kernel form to rounding, not to the bit.  Not
                                 used while a window holds far between factors, on sharded engines, or by the partitioned
                                 form; in the hybrid solve (termination rule on) the sweep half uses it and the assembly
-                                kernel runs for the partitioned half only.  Default 1024 (below ~600 windows the assembly
-                                kernel's launch is shorter than what the sweep pays); 0 = never. */
+                                kernel runs for the partitioned half only.  Default 768 (below ~500 windows the assembly
+                                kernel's launch is shorter than what the sweep pays, and the sweep pays it for rejected
+                                trials too); 0 = never. */
+    int solve_assemble_waves; /* 1: the assembling sweep is one wave per window; 2: two waves per window sharing its LDS, one
+                                eliminating, one assembling the rows; 0 (default): two up to 1536 windows, one beyond
+                                 */
 } vf_engine_opts;
 
 void vf_engine_default_opts(vf_engine_opts* o);

@@ -116,7 +116,7 @@ def test_defaults_do_not_depend_on_the_environment(lib, monkeypatch):
         o = _lib.EngineOptsC()
         lib.vf_engine_default_opts(C.byref(o))
         outs.append((o.chunks, o.sweep_two_sided_max, o.hybrid_threshold, o.cold_start, o.use_hip_graph, o.solve_split_min, o.solve_assemble_min))
-    assert outs[0] == outs[1] == (0, 256, 256, 0, 0, 2048, 1024)
+    assert outs[0] == outs[1] == (0, 256, 256, 0, 0, 2048, 768)
     csrc = os.path.join(ROOT, "vil_sensor_fusion_amd", "csrc")
     for f in os.listdir(csrc):
         if f.endswith((".hip", ".cpp", ".hpp")):

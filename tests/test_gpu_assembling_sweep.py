@@ -19,20 +19,22 @@ from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
 
 pytestmark = pytest.mark.gpu
 SWEEP = dict(chunks=1, sweep_two_sided_max=0)          # one wave per window whatever the batch
+WAVES = pytest.mark.parametrize("waves", [1, 2])       # the sweep as one wave per window / as eliminator + assembler wave (solve_assemble_waves)
 
 
-def _pair(seqs, n, updates, **opts):
+def _pair(seqs, n, updates, waves=1, **opts):
     return (_engine(None, seqs, n, updates, solve_assemble_min=0, **SWEEP, **opts),
-            _engine(None, seqs, n, updates, solve_assemble_min=1, **SWEEP, **opts))
+            _engine(None, seqs, n, updates, solve_assemble_min=1, solve_assemble_waves=waves, **SWEEP, **opts))
 
 
-def test_first_trial_agrees_with_the_two_kernel_form_to_rounding():
+@WAVES
+def test_first_trial_agrees_with_the_two_kernel_form_to_rounding(waves):
     """One staged LM trial from the same linearisation: increments and Cholesky panels of K3 + k_band_solve against the
     assembling sweep, ragged windows (identity-padded lengths), first slots 0 .. 8 (every position inside a tile), the prior on the
     first keyframe or on the twelfth."""
     n, B = 150, 10
     seqs = [synth.make_sequence(seed=810 + i, n_kf=n + 2) for i in range(B)]
-    two, asm = _pair(seqs, n, 0)
+    two, asm = _pair(seqs, n, 0, waves)
     worst_p = worst_d = 0.0
     for e in (two, asm):
         for w in range(B):
@@ -57,13 +59,14 @@ def test_first_trial_agrees_with_the_two_kernel_form_to_rounding():
     asm.close()
 
 
-def test_fixed_lag_updates_with_ingest_match_the_oracle(oracle):
+@WAVES
+def test_fixed_lag_updates_with_ingest_match_the_oracle(oracle, waves):
     """bench.py's update -- ingest (K0 at the current bias) + marginalised slide + 5 LM trials -- for 12 updates, so that the
     window's first slot passes through every position of a J-stream tile and the tile switch falls on every phase of the
     sweep; windows of different lengths; against helpers.FixedLagOracle doing the same."""
     n, updates, B = 160, 12, 5
     seqs = [synth.make_sequence(seed=830 + i, n_kf=n + updates + 2) for i in range(B)]
-    eng = _engine(None, seqs, n, updates, solve_assemble_min=1, **SWEEP)
+    eng = _engine(None, seqs, n, updates, solve_assemble_min=1, solve_assemble_waves=waves, **SWEEP)
     eng.iterate(60)
     prm = oracle.carla_imu_params()
     refs = []
@@ -92,7 +95,8 @@ def test_fixed_lag_updates_with_ingest_match_the_oracle(oracle):
     eng.close()
 
 
-def test_between_factor_spans_and_gaps(oracle):
+@WAVES
+def test_between_factor_spans_and_gaps(oracle, waves):
     """Between factors reaching back one, two and three keyframes, keyframes without any, and an IMU-only stretch: the older
     keyframe's term goes into a row that is already in the trailing window, at a distance the sweep only learns from the
     factor -- against the oracle on the same graph."""
@@ -105,7 +109,7 @@ def test_between_factor_spans_and_gaps(oracle):
     spans = prob["btw_b"][keep] - prob["btw_a"][keep]
     assert set(np.unique(spans)) >= {1, 2, 3}
     p2 = dict(prob, btw_a=prob["btw_a"][keep], btw_b=prob["btw_b"][keep], btw=prob["btw"][keep])
-    eng = Engine(EngineOpts(windows=3, capacity=n, solve_assemble_min=1, **SWEEP))
+    eng = Engine(EngineOpts(windows=3, capacity=n, solve_assemble_min=1, solve_assemble_waves=waves, **SWEEP))
     for w in range(3):
         helpers.load_engine(eng, w, p2, lo=0, hi=n - w)
     eng.iterate(25)
@@ -117,13 +121,14 @@ def test_between_factor_spans_and_gaps(oracle):
     eng.close()
 
 
+@WAVES
 @pytest.mark.parametrize("n", [2, 3, 4, 5, 7, 9, 13])
-def test_tiny_windows(oracle, n):
+def test_tiny_windows(oracle, n, waves):
     """windows shorter than the sweep's unroll, than a J-stream tile, than the profile: rows past the window's end are
     identity rows, factors past it zeros."""
     seq = synth.make_sequence(21, 24)
     prob = helpers.build_problem(oracle, seq, perturb=0.01)
-    eng = Engine(EngineOpts(windows=2, capacity=24, solve_assemble_min=1, **SWEEP))
+    eng = Engine(EngineOpts(windows=2, capacity=24, solve_assemble_min=1, solve_assemble_waves=waves, **SWEEP))
     for w, lo in ((0, 0), (1, 6)):
         helpers.load_engine(eng, w, prob, lo=lo, hi=lo + n)
     assert eng.solve_form() == "assembling"
@@ -137,12 +142,13 @@ def test_tiny_windows(oracle, n):
     eng.close()
 
 
-def test_termination_rule_on_a_small_batch():
+@WAVES
+def test_termination_rule_on_a_small_batch(waves):
     """GTSAM's LM rule on an engine too small for the hybrid form (<= 128 windows): windows that are done drop out of the later
     trials of the assembling sweep as of every other kernel; same trial counts as the two-kernel form, states to rounding."""
     n, B = 110, 6
     seqs = [synth.make_sequence(seed=890 + i, n_kf=n + 2) for i in range(B)]
-    two, asm = _pair(seqs, n, 0)
+    two, asm = _pair(seqs, n, 0, waves)
     for e in (two, asm):
         e.set_convergence(1e-5, 1e-5)
         e.iterate(30)
@@ -229,13 +235,13 @@ def test_forms_that_need_H_fall_back_to_the_two_kernel_path():
 
 def test_library_defaults_pick_the_form_by_batch():
     """vf_engine_solve_form on engines left at the library's defaults: the partitioned form up to 128 windows, two waves per
-    window up to 256, one wave per window above, the assembling sweep from 1 024 on (bench.py's headline batch), the hybrid once the termination rule is
+    window up to 256, one wave per window above, the assembling sweep from 768 on (bench.py's headline batch is 1 024), the hybrid once the termination rule is
     switched on (above 128 windows); chunks >= 2 is the partitioned form whatever the batch."""
-    for windows, form in ((2, "partitioned"), (128, "partitioned"), (129, "two_sided"), (256, "two_sided"), (300, "one_wave"), (1023, "one_wave"),
-                          (1024, "assembling"), (2048, "assembling")):
+    for windows, form in ((2, "partitioned"), (128, "partitioned"), (129, "two_sided"), (256, "two_sided"), (300, "one_wave"), (767, "one_wave"),
+                          (768, "assembling"), (1024, "assembling"), (2048, "assembling")):
         eng = Engine(EngineOpts(windows=windows, capacity=64))
         assert eng.solve_form() == form, (windows, eng.solve_form())
-        if windows in (300, 1024):
+        if windows in (300, 1024):       # (the hybrid's sweep half is the assembling one from 768 windows on as well)
             eng.set_convergence(1e-5, 1e-5)
             assert eng.solve_form() == "hybrid"
         eng.close()

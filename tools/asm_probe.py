@@ -31,7 +31,8 @@ def build(B, n, seqs, ragged=False, **opts):
 
 n, B0 = 100, 9
 seqs = [synth.make_sequence(seed=40 + i, n_kf=n + 8) for i in range(5)]
-a, b = build(B0, n, seqs, True, solve_split_min=1), build(B0, n, seqs, True, solve_split_min=1, solve_assemble_min=1)
+WAVES = int(os.environ.get("VF_ASM_WAVES", "1"))
+a, b = build(B0, n, seqs, True, solve_split_min=1), build(B0, n, seqs, True, solve_split_min=1, solve_assemble_min=1, solve_assemble_waves=WAVES)
 for e in (a, b):
     e.linearize(); e.decide(init=True); e.assemble(); e.solve(); e.sync()
 for w in range(B0):
@@ -52,8 +53,9 @@ a.close(); b.close()
 n = 1000
 seqs = [synth.make_sequence(seed=80 + i, n_kf=n + 8) for i in range(16)]
 for B in [int(x) for x in sys.argv[1:]] or [1024]:
-    for mode in ("fused K4", "split", "assembling"):
-        e = build(B, n, seqs, solve_split_min=0 if mode == "fused K4" else 1, solve_assemble_min=1 if mode == "assembling" else 0)
+    for mode in ("fused K4", "split", "assembling", "assembling, two waves"):
+        e = build(B, n, seqs, solve_split_min=0 if mode == "fused K4" else 1, solve_assemble_min=1 if mode.startswith("assembling") else 0,
+                  solve_assemble_waves=2 if mode.endswith("two waves") else 1)
         e.iterate(3)
         ts = [e.time_stage("solve", 5) for _ in range(3)]
         ta = [e.time_stage("assemble", 5) for _ in range(2)]

@@ -24,7 +24,7 @@ class EngineOptsC(C.Structure):
                 ("lambda0", C.c_double), ("lambda_up", C.c_double), ("lambda_down", C.c_double),
                 ("lambda_min", C.c_double), ("lambda_max", C.c_double), ("chunks", C.c_int),
                 ("sweep_two_sided_max", C.c_int), ("hybrid_threshold", C.c_int), ("cold_start", C.c_int),
-                ("use_hip_graph", C.c_int), ("accept_rel", C.c_double), ("solve_split_min", C.c_int), ("solve_assemble_min", C.c_int)]
+                ("use_hip_graph", C.c_int), ("accept_rel", C.c_double), ("solve_split_min", C.c_int), ("solve_assemble_min", C.c_int), ("solve_assemble_waves", C.c_int)]
 
 
 class ImuParamsC(C.Structure):

@@ -1313,7 +1313,8 @@ static_assert(CW_TOTAL * 8 <= 20480, "eight compact forward sweeps per CU (160 K
 // Assembling forward sweep (SOLVE_ASM_FWD, k_band_forward_asm): the compact window, then the LDS image of ONE tile of the J
 // stream (8 factors at K3's stride LJS: pairs, residual, zero cell) and ONE between linearisation (78 words + the zero cell).
 constexpr int AS_LJ = CW_TOTAL, AS_LB = AS_LJ + JT * LJS, AS_TOTAL = AS_LB + 80;
-static_assert(AS_LJ % 2 == 0 && AS_TOTAL * 8 <= 40960, "four assembling sweeps per CU (one per SIMD)");
+constexpr int AS_FLAGS = AS_TOTAL, AS2_TOTAL = AS_FLAGS + 4;     // two-wave form: [0] steps begun by the eliminator, [1] rows committed by the assembler, [2] J tiles put in place by the eliminator
+static_assert(AS_LJ % 2 == 0 && AS2_TOTAL * 8 <= 40960, "four assembling sweeps per CU (one per SIMD)");
 // chunk forward sweep with a spike follower (k_chunk_forward): the panel of step k (43 rows x 15, then a
 // zero cell and a write sink) stays in a 4-slot LDS ring for the second wave; two hand-shake cells follow
 constexpr int RING_SLOT = 664;
@@ -1341,6 +1342,9 @@ constexpr int as_piece_of_slot(int slot) {
     return slot == 0 ? 0 : ((slot >= 12 && slot <= 25) ? pieces[slot - 11] : 1);
 #endif
 }
+#ifndef VF_ASM2_VGPR
+#define VF_ASM2_VGPR 216
+#endif
 #ifndef VF_AS_SLOTS
 #define VF_AS_SLOTS 1     // assembling sweep: 1 = its matrix-core pieces ride in the pivot code's places, 0 = in front of the Schur update
 #endif
@@ -1378,15 +1382,22 @@ constexpr int MID_TOTAL = 45 * MID_LD + 48;     // + the 45 solved increments ha
 // MODE 6 (assembling forward sweep, batches of >= View::asm_min windows): SOLVE_FULL_FWD that forms the block rows of H itself,
 //   from the J stream and the between linearisations K1 / K2 leave, on the matrix cores, under the waits of the pivot
 //   chain -- K3 is not launched, H is neither written nor read.  See "assembling sweep" below.
-enum { SOLVE_FULL = 0, SOLVE_TWISTED = 1, SOLVE_CHUNK_FWD = 2, SOLVE_CHUNK_BWD = 3, SOLVE_FULL_FWD = 4, SOLVE_FULL_BWD = 5, SOLVE_ASM_FWD = 6 };
+// MODE 7 / 8 (k_band_forward_asm2): MODE 6 as TWO waves of one workgroup sharing its LDS -- wave 0 eliminates (SOLVE_ASM_A: the
+//   forward sweep of MODE 4 whose rows somebody else commits), wave 1 assembles (SOLVE_ASM_B: the row recurrence of MODE 6 and
+//   nothing else) and writes row k + 4 into the window between the eliminator's read of pivot row k and its Schur update's
+//   accumulator reads; two cells of LDS carry the hand-shake.  Eight waves per CU on the LDS of four sweeps: the matrix
+//   instructions of the two roles overlap each other's waits, which one wave cannot do for itself.
+enum { SOLVE_FULL = 0, SOLVE_TWISTED = 1, SOLVE_CHUNK_FWD = 2, SOLVE_CHUNK_BWD = 3, SOLVE_FULL_FWD = 4, SOLVE_FULL_BWD = 5, SOLVE_ASM_FWD = 6,
+       SOLVE_ASM_A = 7, SOLVE_ASM_B = 8 };
 template <int MODE>
 __device__ __forceinline__ void band_solve_body(const View& v, double* __restrict__ S, double* __restrict__ S_other,
                                                 double* __restrict__ MID, const int w, const int lane, const int wave,
                                                 const ChunkGeom cg = ChunkGeom{0, 0, 0}, double* __restrict__ sep_out = nullptr) {
     constexpr bool TW = MODE == SOLVE_TWISTED;
     constexpr bool CH = MODE == SOLVE_CHUNK_FWD || MODE == SOLVE_CHUNK_BWD;
-    constexpr bool AS = MODE == SOLVE_ASM_FWD;           // rows of H assembled here (no K3)
-    constexpr bool CW = MODE == SOLVE_FULL_FWD || AS;    // compact trailing window ("CW_" map above); the names below shadow the full map
+    constexpr bool ASA = MODE == SOLVE_ASM_A, ASB = MODE == SOLVE_ASM_B;   // the two roles of the two-wave assembling sweep
+    constexpr bool AS = MODE == SOLVE_ASM_FWD || ASB;    // rows of H assembled here (no K3)
+    constexpr bool CW = MODE == SOLVE_FULL_FWD || AS || ASA;   // compact trailing window ("CW_" map above); the names below shadow the full map
     constexpr int S_GD = CW ? CW_GD : vf::S_GD, S_DUMP = CW ? CW_DUMP : vf::S_DUMP, S_ZERO = CW ? CW_ZERO : vf::S_ZERO;
     constexpr int S_ID = CW ? CW_ID : vf::S_ID, S_P = CW ? CW_P : vf::S_P, S_BC = CW ? CW_BC : vf::S_BC;
     const int lo = v.lo[w], hi = v.hi[w];
@@ -1442,6 +1453,9 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     // Schur write-back targets (MFMA C layout): tile t in {(0,0),(1,0),(1,1)}, register r:
     //   i = 16*Ti + (lane>>4) + 4r (trailing row, 27 = rhs), j = 16*Tj + (lane&15)
     int tgt_ph[4][12];
+    // (the eliminator wave of the two-wave assembling sweep has 256 registers and keeps a J tile in 80 of them: it holds one
+    // base per target and forms the four phases' addresses as base + step * ((phase + shift) & 3) when it uses them)
+    int tgB[12] = {}, tgM[12] = {};
 #pragma unroll
     for (int q = 0; q < 12; q++) {
         const int t = q >> 2, r = q & 3;
@@ -1456,6 +1470,10 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             if constexpr (CW) {
                 const int e = rs - cs;   // 0, 1, 2 (rows k+1 .. k+3 against columns k+1 .. k+3)
                 const int blk = e == 0 ? CW_D0 + h_tri(ra, ca) : (e == 1 ? CW_D1 + ra * 15 + ca : CW_D2 + ra * 15 + ca);
+                if constexpr (ASA) {
+                    tgB[q] = !valid ? S_DUMP + 32 + lane : (i == 27 ? S_GD + ca : blk);
+                    tgM[q] = !valid ? 0 : (i == 27 ? 15 | (cs << 16) : CW_SLOT | (rs << 16));
+                } else
                 tgt_ph[ph][q] = !valid ? S_DUMP + 32 + lane : (i == 27 ? S_GD + cj : ((ph + rs) & 3) * CW_SLOT + blk);
             } else
             tgt_ph[ph][q] = !valid ? S_DUMP + 32 + lane
@@ -1520,13 +1538,13 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     // factor's term on its OLDER keyframe goes into that row's slot of the window (the row is at most three steps from its
     // elimination, so it is still there), which is why one staged between linearisation is enough.
     struct Asm { d4_t D, O, Dfin, Z, On, Dn; double ai[4], aj[4], xx[2]; int d, d_next; };
-    struct AsmNext { d2_t tj[19]; double tr[2], blA[2], blB[2]; int aA, aB, k0_next; };
+    struct AsmNext { d2_t tj[19]; double tr[2], blA[2], blB[2]; int aA, aB, k0_next, tiles_wanted; };
     constexpr int AS_NOWN = JS_PAIRS * JT;                       // 16-byte words of a tile
-    const int as_b = AS ? v.sel[w] : 0;
+    const int as_b = (AS || ASA) ? v.sel[w] : 0;
     AsmMaps am = {};
     int as_cD[4] = {}, as_cDs[4] = {}, as_cO[4] = {}, as_c1[2] = {}, as_c2[2] = {}, as_c3[2] = {}, as_rB[2] = {}, as_rS[2] = {}, as_bB[2] = {}, as_bS[2] = {}, as_oX[2] = {};
-    double as_bsgn[2] = {};
-    double as_dadd[4] = {}, as_dsgn[4] = {}, as_rsgn[2] = {};
+    // (signs and the diagonal's lambda are lane properties, formed where used: the window keeps -g, and the gradient is column 15 of every tile)
+    const double as_sgn = (lane & 15) == 15 ? -1.0 : 1.0;
     const int as_hx = lane < 54 ? CW_D2 + (lane / 9) * 15 + 6 + lane % 9 : -1;
     if constexpr (AS) {
         am = make_asm_maps(v, w, lo, hi, lane);
@@ -1537,8 +1555,6 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             const bool tri = a < 15 && ci <= a, grad = a < 15 && ci == 15;
             as_cD[r] = tri ? CW_D0 + h_tri(a, ci) : (grad ? S_GD + a : S_DUMP + 32 + lane);      // + PH * as_cDs
             as_cDs[r] = tri ? CW_SLOT : (grad ? 15 : 0);
-            as_dadd[r] = (tri && a == ci) ? 1.0 : 0.0;
-            as_dsgn[r] = grad ? -1.0 : 1.0;                                                    // the window keeps -g
             as_cO[r] = (a < 15 && ci < 15) ? CW_D1 + a * 15 + ci : -1;
         }
 #pragma unroll
@@ -1548,7 +1564,6 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             const bool tri = a6 < 6 && ci <= a6, grad = a6 < 6 && ci == 15;
             as_rB[r] = tri ? CW_D0 + h_tri(a6, ci) : (grad ? S_GD + a6 : S_DUMP + 32 + lane);   // + slot * as_rS
             as_rS[r] = tri ? CW_SLOT : (grad ? 15 : 0);
-            as_rsgn[r] = tri ? 1.0 : (grad ? -1.0 : 0.0);
             // rows 6..11 of Z (registers 1, 2): columns 0..5 = the pose block against R - d, columns 6..11 | 15 = this row's own term
             const int b6 = kq + 4 * (r + 1) - 6;
             const bool brow = b6 >= 0 && b6 < 6;
@@ -1559,7 +1574,6 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             const bool btri = brow && ci >= 6 && ci - 6 <= b6, bgrad = brow && ci == 15;
             as_bB[r] = btri ? CW_D0 + h_tri(b6, ci - 6) : (bgrad ? S_GD + b6 : S_DUMP + 32 + lane);   // + PH * as_bS
             as_bS[r] = btri ? CW_SLOT : (bgrad ? 15 : 0);
-            as_bsgn[r] = btri ? 1.0 : (bgrad ? -1.0 : 0.0);
             // operand word of k-step r: X[4 r + kq][ci] in the staged linearisation (r: 0, Ja: 6, Jb: 42; its pad cell is zero)
             const int row = 4 * r + kq;
             as_oX[r] = row >= 6 ? BTW_OUT : (ci < 6 ? 6 + row * 6 + ci : (ci < 12 ? 42 + row * 6 + ci - 6 : (ci == 15 ? row : BTW_OUT)));
@@ -1665,7 +1679,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 const int addr = as_rB[r] + sa * as_rS[r];
-                S[addr] = fma(as_rsgn[r], z.Z[r], S[addr]);
+                S[addr] = fma(as_sgn, z.Z[r], S[addr]);
             }
         }
     };
@@ -1719,7 +1733,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; r++) S[as_cD[r] + PH * as_cDs[r]] = fma(as_dsgn[r], Dv[r], as_dadd[r] * dg);
+        for (int r = 0; r < 4; r++) S[as_cD[r] + PH * as_cDs[r]] = fma(as_sgn, Dv[r], (lane & 15) == (lane >> 4) + 4 * r ? dg : 0.0);
 #pragma unroll
         for (int r = 0; r < 4; r++) S[as_cO[r] >= 0 ? sb + as_cO[r] : S_DUMP + 32 + lane] = Ov[r];
 #pragma unroll
@@ -1734,7 +1748,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 const int addr = as_bB[r] + PH * as_bS[r];
-                S[addr] = fma(as_bsgn[r], z.Z[r + 1], S[addr]);
+                S[addr] = fma(as_sgn, z.Z[r + 1], S[addr]);
             }
             if (z.d == 1) {
 #pragma unroll
@@ -1767,7 +1781,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int addr = as_cD[r] + sl * as_cDs[r];
-                S[addr] = fma(as_dsgn[r], as_lp[r], S[addr]);
+                S[addr] = fma(as_sgn, as_lp[r], S[addr]);
             }
         }
     };
@@ -1786,9 +1800,25 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         z.O = z.On;
         z.d = z.d_next;
         if (((lo + R + 2) & (JT - 1)) == 0) {               // factor R+2 opens a new tile: the old one has been used up
+            if constexpr (ASB) {
+                // two-wave form: the NEXT tile waits in the registers of the eliminator wave (which has a hundred to spare; this
+                // wave has none), and that wave puts it in place once it has seen row R committed -- i.e. the operands of
+                // factor R+1, the last of the old tile, read.  The first four rows, committed before the eliminator starts,
+                // fetch for themselves and wait for the memory.
+                if (R < 4) {
+                    as_tile_fetch(nx.k0_next, nx);
+                    as_tile_commit(nx.k0_next, nx);
+                    nx.k0_next += JT;
+                } else {
+                    nx.tiles_wanted++;
+                    int spin = 0;
+                    while (lds_peek(S + AS_FLAGS + 2) < (double)nx.tiles_wanted && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+                }
+            } else {
             as_tile_commit(nx.k0_next, nx);
             nx.k0_next += JT;
             as_tile_fetch(nx.k0_next, nx);
+            }
         }
     };
 
@@ -1933,15 +1963,17 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         az.D = az.O = az.Dfin = az.Z = az.On = az.Dn = (d4_t){0, 0, 0, 0};     // row 0 has no factor in front of it
         az.d = az.d_next = 0;
         anx.k0_next = (lo + 1) & ~(JT - 1);
+        anx.tiles_wanted = 0;
         as_tile_fetch(anx.k0_next, anx);
         as_tile_commit(anx.k0_next, anx);
         anx.k0_next += JT;
-        as_tile_fetch(anx.k0_next, anx);
+        if constexpr (!ASB) as_tile_fetch(anx.k0_next, anx);
         { const double z2[2] = {0.0, 0.0}; as_btw_commit(z2, 0); }
         as_btw_fetch(1, anx.blA, anx.aA);
         as_btw_fetch(2, anx.blB, anx.aB);
         WSYNC();
-        auto first = [&](auto ph, int R) {
+        // one iteration outside the elimination loop: the first four rows (whatever the form), and every row of the assembler wave
+        auto whole_row = [&](auto ph, auto special_, int R) {
             const int fimg = AS_LJ + ((lo + R + 1) & (JT - 1)) * LJS;
             as_piece(IC<0>{}, az, fimg);
             as_stage_btw(R, az, anx);
@@ -1949,15 +1981,41 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             as_piece(IC<7>{}, az, fimg);  as_piece(IC<8>{}, az, fimg);  as_piece(IC<9>{}, az, fimg);
             as_piece(IC<10>{}, az, fimg); as_piece(IC<12>{}, az, fimg); as_piece(IC<13>{}, az, fimg);
             as_piece(IC<14>{}, az, fimg); as_piece(IC<15>{}, az, fimg); as_piece(IC<16>{}, az, fimg); as_piece(IC<17>{}, az, fimg);
+            if constexpr (ASB && decltype(special_)::value == 0) {
+                // the window may be touched once the eliminator has read pivot row R - 4 (its Schur write-back of the step
+                // before is then done as well) and until it reads the accumulators of that step -- it waits for us there
+                int spin = 0;
+                while (lds_peek(S + AS_FLAGS) < (double)(R - 4) && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+            }
             as_rmw(ph, az);
-            as_commit(ph, IC<1>{}, R, az);
+            as_commit(ph, special_, R, az);
+            if constexpr (decltype(special_)::value == 0) as_late_prior(R);
+            WSYNC();
+            if constexpr (ASB) { if (lane == 0) S[AS_FLAGS + 1] = (double)R; }       // rows <= R are in the window
             as_advance(R, az, anx);
             WSYNC();
         };
-        first(IC<0>{}, 0);
-        first(IC<1>{}, 1);
-        first(IC<2>{}, 2);
-        first(IC<3>{}, 3);
+        whole_row(IC<0>{}, IC<1>{}, 0);
+        whole_row(IC<1>{}, IC<1>{}, 1);
+        whole_row(IC<2>{}, IC<1>{}, 2);
+        whole_row(IC<3>{}, IC<1>{}, 3);
+        if constexpr (ASB) {
+#pragma unroll 1
+            for (int R = 4; R < cnt + 4; R += 4) {
+                whole_row(IC<0>{}, IC<0>{}, R);
+                whole_row(IC<1>{}, IC<0>{}, R + 1);
+                whole_row(IC<2>{}, IC<0>{}, R + 2);
+                whole_row(IC<3>{}, IC<0>{}, R + 3);
+            }
+            return;
+        }
+    } else if constexpr (ASA) {
+        // the tile behind the one iteration 4 works on (factor lo + 5): ours to prefetch and to put in place from now on
+        anx.k0_next = (((lo + 5) >> JT_LOG) + 1) << JT_LOG;
+        anx.tiles_wanted = 0;
+        as_tile_fetch(anx.k0_next, anx);
+        int spin = 0;                  // the assembler wave commits the first four rows
+        while (lds_peek(S + AS_FLAGS + 1) < 3.0 && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(1);
     } else {
     commit_row(IC<0>{}, fetch_row(0), row_kind(0), 0);
     commit_row(IC<1>{}, fetch_row(1), row_kind(1), 1);
@@ -1977,6 +2035,10 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             const bool narrow = lane >= 36 && lane < 42;
 #pragma unroll
             for (int c = 6; c < 15; c++) p[c] = narrow ? 0.0 : p[c];
+        }
+        if constexpr (ASA) {    // pivot row k is in registers (and the write-back of step k - 1 behind us): its slot and the rows of the window are the assembler's
+            WSYNC();
+            if (lane == 0) S[AS_FLAGS] = (double)k;
         }
         STAMP(1);
         // panel factorisation: straight-line code in a fixed issue order (tools/gen_pivot.py); a non-positive
@@ -2033,6 +2095,19 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             as_rmw(ph, az);
         }
 #endif
+        if constexpr (ASA) {    // row k + 4 committed, the between terms it brings added to rows k + 1 .. k + 3
+            int spin = 0;
+            while (lds_peek(S + AS_FLAGS + 1) < (double)(k + 4) && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+            if (spin >= (1 << 22)) failed = 1;
+            if (((lo + k + 6) & (JT - 1)) == 0) {      // factor k + 6 opens a new tile, and the assembler has read the last operands of the old one
+                as_tile_commit(anx.k0_next, anx);
+                WSYNC();
+                anx.tiles_wanted++;
+                if (lane == 0) S[AS_FLAGS + 2] = (double)anx.tiles_wanted;
+                anx.k0_next += JT;
+                as_tile_fetch(anx.k0_next, anx);
+            }
+        }
         // Schur update on the matrix cores: acc[t] = P_Ti P_Tj^T for the 3 lower 16x16 tiles
         // (the trailing entries are the accumulator input and the A operands are negated: T - P P^T leaves the matrix
         // cores ready to be written back, no accumulator read-out + subtraction pass)
@@ -2040,8 +2115,14 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #pragma unroll
         for (int q = 0; q < 4; q++) { a0[q] = S[op0[q] + PH * RSLOT]; a1[q] = S[op1[q] + PH * RSLOT]; }
         d4_t acc0, acc1, acc2;
+        int tg[12];
 #pragma unroll
-        for (int r = 0; r < 4; r++) { acc0[r] = S[tgt_ph[PH][r]]; acc1[r] = S[tgt_ph[PH][4 + r]]; acc2[r] = S[tgt_ph[PH][8 + r]]; }
+        for (int q = 0; q < 12; q++) {
+            if constexpr (ASA) tg[q] = tgB[q] + (tgM[q] & 0xffff) * ((PH + (tgM[q] >> 16)) & 3);
+            else tg[q] = tgt_ph[PH][q];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) { acc0[r] = S[tg[r]]; acc1[r] = S[tg[4 + r]]; acc2[r] = S[tg[8 + r]]; }
 #pragma unroll
         for (int q = 0; q < 4; q++) { n0[q] = -a0[q]; n1[q] = -a1[q]; }
 #pragma unroll
@@ -2057,6 +2138,8 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             as_commit(ph, IC<0>{}, k + 4, az);
             as_late_prior(k + 4);
             as_advance(k + 4, az, anx);          // (a dispatch on the phase around ONE copy of this was slower: the register copies where its four arms meet)
+        } else if constexpr (ASA) {
+            // (nothing to commit or to fetch: the partner wave does both)
         } else {
         commit_row(ph, pend, row_kind(k + 4), k + 4);
         pend = pend2;
@@ -2064,13 +2147,13 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         }
         STAMP(4);
 #pragma unroll
-        for (int r = 0; r < 4; r++) { S[tgt_ph[PH][r]] = acc0[r]; S[tgt_ph[PH][4 + r]] = acc1[r]; S[tgt_ph[PH][8 + r]] = acc2[r]; }
+        for (int r = 0; r < 4; r++) { S[tg[r]] = acc0[r]; S[tg[4 + r]] = acc1[r]; S[tg[8 + r]] = acc2[r]; }
         WSYNC();
         STAMP(5);
     };
     {
         HRow pend = {}, pend2 = {};
-        if constexpr (!AS) { pend = fetch_row(4); pend2 = fetch_row(5); }
+        if constexpr (!AS && !ASA) { pend = fetch_row(4); pend2 = fetch_row(5); }
 #pragma unroll 1
         for (int k = 0; k < n4; k += 4) {
             step(IC<0>{}, k, pend, pend2);
@@ -2083,7 +2166,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #ifdef VF_K4_FWD_ONLY   // probe build only (tools/build_variant.sh): the forward sweep's share of the un-stamped kernel
     if constexpr (MODE == SOLVE_FULL) return;
 #endif
-    if constexpr (MODE == SOLVE_FULL_FWD || AS) {
+    if constexpr (MODE == SOLVE_FULL_FWD || AS || ASA) {
         if (lane == 0) v.fail[w] = failed;
 #ifdef VF_SOLVE_STAMPS
         if (w == 0 && lane == 0) { for (int i = 0; i < 6; i++) g_stamps[i] = st[i]; for (int i = 11; i < 16; i++) g_stamps[i] = st[i]; }
@@ -2355,6 +2438,20 @@ __global__ void __launch_bounds__(64) k_band_forward_asm(View v) {
     if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
     __shared__ __attribute__((aligned(16))) double S[AS_TOTAL];
     band_solve_body<SOLVE_ASM_FWD>(v, S, nullptr, nullptr, w, threadIdx.x, 0);
+}
+// the same as two waves per window: eliminator + assembler on one LDS image (SOLVE_ASM_A / SOLVE_ASM_B).  (Each role alone
+// fits the 256 registers a wave may have at two waves per SIMD -- 225 + 24 and 205 + 40; inlined into one kernel the allocator
+// takes all 256 as VGPRs and spills 17 to scratch unless it is told to keep some of the budget as AGPRs.)
+__attribute__((amdgpu_waves_per_eu(2, 2), amdgpu_num_vgpr(VF_ASM2_VGPR)))
+__global__ void __launch_bounds__(128) k_band_forward_asm2(View v) {
+    const int w = blockIdx.x;
+    if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
+    __shared__ __attribute__((aligned(16))) double S[AS2_TOTAL];
+    if (threadIdx.x < 3) S[AS_FLAGS + threadIdx.x] = threadIdx.x < 2 ? -1.0 : 0.0;
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wave == 0) band_solve_body<SOLVE_ASM_A>(v, S, nullptr, nullptr, w, lane, 0);
+    else band_solve_body<SOLVE_ASM_B>(v, S, nullptr, nullptr, w, lane, 0);
 }
 __attribute__((amdgpu_waves_per_eu(2, 2)))
 __global__ void __launch_bounds__(64) k_band_backward(View v) {
@@ -3362,7 +3459,8 @@ void launch_band_solve(const View& v, hipStream_t s) {
     // few windows: two waves per window from both ends (latency); many: one wave per window (throughput)
     if (v.B <= v.tw_max) hipLaunchKernelGGL(k_band_solve_tw, dim3(v.B), dim3(128), 0, s, v);
     else if (asm_in_solve(v)) {
-        hipLaunchKernelGGL(k_band_forward_asm, dim3(v.B), dim3(64), 0, s, v);
+        if (v.asm_waves == 2) hipLaunchKernelGGL(k_band_forward_asm2, dim3(v.B), dim3(128), 0, s, v);
+        else hipLaunchKernelGGL(k_band_forward_asm, dim3(v.B), dim3(64), 0, s, v);
         hipLaunchKernelGGL(k_band_backward, dim3(v.B), dim3(64), 0, s, v);
     } else if (v.split_min > 0 && v.B >= v.split_min) {
         hipLaunchKernelGGL(k_band_forward, dim3(v.B), dim3(64), 0, s, v);
@@ -3388,6 +3486,7 @@ void launch_band_solve_hybrid(const View& v, const View& vp, hipStream_t s) {
     a.gate = 1;
     b.gate = 2;
     if (asm_in_hybrid(v)) {
+        // (one wave per window here: with part of the windows done the two-wave form measured 5 % slower, bench `with_convergence_exit`)
         hipLaunchKernelGGL(k_band_forward_asm, dim3(a.B), dim3(64), 0, s, a);
         hipLaunchKernelGGL(k_band_backward, dim3(a.B), dim3(64), 0, s, a);
     } else if (a.split_min > 0 && a.B >= a.split_min) {

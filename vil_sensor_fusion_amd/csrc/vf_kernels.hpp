@@ -174,6 +174,7 @@ struct View {
     int split_min;      // whole-window sweeps: from this many windows on, forward sweep and back substitution as two kernels (0 = never)
     int asm_min;        // whole-window sweeps: from this many windows on, the forward sweep assembles H itself from the J stream and
                         // K3 is not launched (0 = never; asm_in_solve() below)
+    int asm_waves;      // ... as one wave per window (1) or as an eliminator wave + an assembler wave sharing the window's LDS (2)
     // "far" between factors: BetweenFactor<Pose3> on any pair of keyframes of a window (wider than the band, or a second factor
     // on an end key), at most x_max per window; kept out of the banded H and solved as a low-rank correction
     int x_max;          // 0 until vf_engine_set_extra_between is first called

@@ -47,6 +47,7 @@ class EngineOpts:
     accept_rel: float | None = None      # LM accept tolerance (None = the library's default 1e-9; 0 = strict decrease)
     solve_split_min: int | None = None   # one-wave sweeps: from this many windows on, forward sweep / back substitution as two kernels
     solve_assemble_min: int | None = None  # one-wave sweeps: from this many windows on, the forward sweep assembles H itself (no K3)
+    solve_assemble_waves: int | None = None  # 1: one wave per window; 2: eliminator + assembler wave on one LDS image
 
 
 class Engine:
@@ -70,6 +71,8 @@ class Engine:
             o.solve_split_min = opts.solve_split_min
         if opts.solve_assemble_min is not None:
             o.solve_assemble_min = opts.solve_assemble_min
+        if opts.solve_assemble_waves is not None:
+            o.solve_assemble_waves = opts.solve_assemble_waves
         self._h = C.c_void_p()
         check(self._l.vf_engine_create(C.byref(o), C.byref(self._h)))
         self.opts = opts

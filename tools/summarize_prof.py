@@ -120,7 +120,7 @@ for sub in ("sq_a", "sq_b", "sq_c"):
     for k, c in pmc_multi(sub).items():
         sq.setdefault(k, {}).update({n: v for n, v in c.items() if not (n == "SQ_WAVE_CYCLES" and sub != "sq_a" and "SQ_WAVE_CYCLES" in sq.get(k, {}))})
 if sq:
-    hot = [k for k in ("vf::k_linearize_imu", "vf::k_linearize_between_prior", "vf::k_assemble", "vf::k_band_solve", "vf::k_band_forward_asm", "vf::k_band_forward",
+    hot = [k for k in ("vf::k_linearize_imu", "vf::k_linearize_between_prior", "vf::k_assemble", "vf::k_band_solve", "vf::k_band_forward_asm", "vf::k_band_forward_asm2", "vf::k_band_forward",
                        "vf::k_band_backward", "vf::k_retract", "vf::k_decide") if k in sq]
     L = [f"# {tag}: SQ counters per kernel (rocprofv3 --pmc, separate passes; means over full launches of `bench.py --steps 3`)", "",
          "Units (MI355X_MICROARCH.md, `s_memtime` tick vs SQ PMC units): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; "

@@ -251,3 +251,33 @@ def test_library_defaults_pick_the_form_by_batch():
     eng = Engine(EngineOpts(windows=2048, capacity=64, solve_assemble_min=0))
     assert eng.solve_form() == "one_wave_split"
     eng.close()
+
+
+def test_two_waves_per_window_give_the_bits_of_one():
+    """k_band_forward_asm2 (eliminator wave + assembler wave on one LDS image, hand-shake through three LDS cells) issues the
+    instructions of k_band_forward_asm, row by row, in the same order: states, LM counters, panels and marginal priors are
+    identical bit for bit -- ragged windows, marginalised slides that move the first slot through a J-stream tile."""
+    n, updates, B = 140, 4, 7
+    seqs = [synth.make_sequence(seed=900 + i, n_kf=n + updates + 2) for i in range(B)]
+    one = _engine(None, seqs, n, updates, solve_assemble_min=1, solve_assemble_waves=1, **SWEEP)
+    two = _engine(None, seqs, n, updates, solve_assemble_min=1, solve_assemble_waves=2, **SWEEP)
+    for e in (one, two):
+        for w in range(B):
+            e.set_range(w, 0, n - 8 - (w % 4))        # (the keyframes the slides append have their factors resident)
+        e.iterate(25)
+    for w in range(B):
+        m = n - 8 - (w % 4)
+        np.testing.assert_array_equal(one.get_states(w, 0, m), two.get_states(w, 0, m))
+        assert one.read_lm(w) == two.read_lm(w)
+        np.testing.assert_array_equal(one.read_panels(w, 0, m), two.read_panels(w, 0, m))
+    for u in range(1, 4):
+        for e in (one, two):
+            e.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)
+            e.iterate(5)
+        for w in range(B):
+            m = n - 8 - (w % 4)
+            np.testing.assert_array_equal(one.get_states(w, u, m), two.get_states(w, u, m))
+    a, b = one.read_marginal(3), two.read_marginal(3)
+    np.testing.assert_array_equal(a["L"], b["L"])
+    one.close()
+    two.close()

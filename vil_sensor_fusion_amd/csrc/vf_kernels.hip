@@ -1342,9 +1342,6 @@ constexpr int as_piece_of_slot(int slot) {
     return slot == 0 ? 0 : ((slot >= 12 && slot <= 25) ? pieces[slot - 11] : 1);
 #endif
 }
-#ifndef VF_ASM2_VGPR
-#define VF_ASM2_VGPR 216
-#endif
 #ifndef VF_AS_SLOTS
 #define VF_AS_SLOTS 1     // assembling sweep: 1 = its matrix-core pieces ride in the pivot code's places, 0 = in front of the Schur update
 #endif
@@ -2442,14 +2439,17 @@ __global__ void __launch_bounds__(64) k_band_forward_asm(View v) {
 // the same as two waves per window: eliminator + assembler on one LDS image (SOLVE_ASM_A / SOLVE_ASM_B).  (Each role alone
 // fits the 256 registers a wave may have at two waves per SIMD -- 225 + 24 and 205 + 40; inlined into one kernel the allocator
 // takes all 256 as VGPRs and spills 17 to scratch unless it is told to keep some of the budget as AGPRs.)
-__attribute__((amdgpu_waves_per_eu(2, 2), amdgpu_num_vgpr(VF_ASM2_VGPR)))
+__attribute__((amdgpu_waves_per_eu(2, 2)))
 __global__ void __launch_bounds__(128) k_band_forward_asm2(View v) {
     const int w = blockIdx.x;
     if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
     __shared__ __attribute__((aligned(16))) double S[AS2_TOTAL];
+    // (Roles are fixed: wave 0 eliminates.  The dispatcher puts the two waves of a 128-thread workgroup on SIMDs (0, 2), (1, 3),
+    // (2, 1), (3, 0) in turn -- tools/probes/wave_placement.hip -- so the four workgroups of a CU leave every SIMD with one
+    // eliminator and one assembler; choosing the role from HW_ID instead measured 12 % slower.)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (threadIdx.x < 3) S[AS_FLAGS + threadIdx.x] = threadIdx.x < 2 ? -1.0 : 0.0;
     __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (wave == 0) band_solve_body<SOLVE_ASM_A>(v, S, nullptr, nullptr, w, lane, 0);
     else band_solve_body<SOLVE_ASM_B>(v, S, nullptr, nullptr, w, lane, 0);
 }

@@ -101,9 +101,9 @@ typedef struct {
                                 kernel runs for the partitioned half only.  Default 768 (below ~500 windows the assembly
                                 kernel's launch is shorter than what the sweep pays, and the sweep pays it for rejected
                                 trials too); 0 = never. */
-    int solve_assemble_waves; /* 1: the assembling sweep is one wave per window; 2: two waves per window sharing its LDS, one
-                                eliminating, one assembling the rows; 0 (default): two up to 1536 windows, one beyond
-                                 */
+    int solve_assemble_waves; /* 1: the assembling sweep is one wave per window; 2 (default): two waves per window sharing its
+                                LDS, one eliminating, one assembling the rows -- the same bits, 6-10 % faster; launched in
+                                chunks of 1024 windows, the workgroups the part holds at once */
 } vf_engine_opts;
 
 void vf_engine_default_opts(vf_engine_opts* o);

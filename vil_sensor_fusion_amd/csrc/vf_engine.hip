@@ -214,7 +214,7 @@ void vf_engine_default_opts(vf_engine_opts* o) {
     o->accept_rel = 1e-9;
     o->solve_split_min = 2048;
     o->solve_assemble_min = 768;
-    o->solve_assemble_waves = 0;
+    o->solve_assemble_waves = 2;
 }
 
 int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
@@ -240,9 +240,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     v.accept_rel = o->accept_rel;
     v.split_min = o->solve_split_min > 0 ? o->solve_split_min : 0;
     v.asm_min = o->solve_assemble_min > 0 ? o->solve_assemble_min : 0;
-    // (0 = by the batch: two waves per window while every window's workgroup is resident at once or nearly -- 4 per CU -- one beyond;
-    // measured at 512 .. 2048 windows)
-    v.asm_waves = o->solve_assemble_waves == 2 ? 2 : (o->solve_assemble_waves == 1 ? 1 : (v.B <= 1536 ? 2 : 1));
+    v.asm_waves = o->solve_assemble_waves == 1 ? 1 : 2;
     HIPCHK(hipStreamCreate(&e->stream));
     HIPCHK(hipEventCreate(&e->ev0));
     HIPCHK(hipEventCreate(&e->ev1));

@@ -1342,6 +1342,9 @@ constexpr int as_piece_of_slot(int slot) {
     return slot == 0 ? 0 : ((slot >= 12 && slot <= 25) ? pieces[slot - 11] : 1);
 #endif
 }
+#ifndef VF_ASM2_CHUNK
+#define VF_ASM2_CHUNK 1024
+#endif
 #ifndef VF_AS_SLOTS
 #define VF_AS_SLOTS 1     // assembling sweep: 1 = its matrix-core pieces ride in the pivot code's places, 0 = in front of the Schur update
 #endif
@@ -2440,8 +2443,8 @@ __global__ void __launch_bounds__(64) k_band_forward_asm(View v) {
 // fits the 256 registers a wave may have at two waves per SIMD -- 225 + 24 and 205 + 40; inlined into one kernel the allocator
 // takes all 256 as VGPRs and spills 17 to scratch unless it is told to keep some of the budget as AGPRs.)
 __attribute__((amdgpu_waves_per_eu(2, 2)))
-__global__ void __launch_bounds__(128) k_band_forward_asm2(View v) {
-    const int w = blockIdx.x;
+__global__ void __launch_bounds__(128) k_band_forward_asm2(View v, int w0) {
+    const int w = w0 + blockIdx.x;
     if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
     __shared__ __attribute__((aligned(16))) double S[AS2_TOTAL];
     // (Roles are fixed: wave 0 eliminates.  The dispatcher puts the two waves of a 128-thread workgroup on SIMDs (0, 2), (1, 3),
@@ -3459,7 +3462,12 @@ void launch_band_solve(const View& v, hipStream_t s) {
     // few windows: two waves per window from both ends (latency); many: one wave per window (throughput)
     if (v.B <= v.tw_max) hipLaunchKernelGGL(k_band_solve_tw, dim3(v.B), dim3(128), 0, s, v);
     else if (asm_in_solve(v)) {
-        if (v.asm_waves == 2) hipLaunchKernelGGL(k_band_forward_asm2, dim3(v.B), dim3(128), 0, s, v);
+        if (v.asm_waves == 2) {
+            // one launch per 1 024 windows -- the workgroups the part holds at once (4 per CU).  As ONE grid of 2 048 workgroups
+            // the second thousand, dispatched one by one into the slots the first leaves, ran 1.7x slower than the first
+            // (9.0 ms against 7.1 for the two launches; no such effect on the one-wave kernels)
+            for (int w0 = 0; w0 < v.B; w0 += VF_ASM2_CHUNK) hipLaunchKernelGGL(k_band_forward_asm2, dim3(v.B - w0 < VF_ASM2_CHUNK ? v.B - w0 : VF_ASM2_CHUNK), dim3(128), 0, s, v, w0);
+        }
         else hipLaunchKernelGGL(k_band_forward_asm, dim3(v.B), dim3(64), 0, s, v);
         hipLaunchKernelGGL(k_band_backward, dim3(v.B), dim3(64), 0, s, v);
     } else if (v.split_min > 0 && v.B >= v.split_min) {

@@ -1813,6 +1813,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
                     nx.tiles_wanted++;
                     int spin = 0;
                     while (lds_peek(S + AS_FLAGS + 2) < (double)nx.tiles_wanted && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+                    if (spin >= (1 << 22) && lane == 0) S[AS_FLAGS + 3] = 1.0;
                 }
             } else {
             as_tile_commit(nx.k0_next, nx);
@@ -1986,6 +1987,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
                 // before is then done as well) and until it reads the accumulators of that step -- it waits for us there
                 int spin = 0;
                 while (lds_peek(S + AS_FLAGS) < (double)(R - 4) && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+                if (spin >= (1 << 22) && lane == 0) S[AS_FLAGS + 3] = 1.0;      // (never seen: the eliminator reports it as a failed solve)
             }
             as_rmw(ph, az);
             as_commit(ph, special_, R, az);
@@ -2016,6 +2018,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         as_tile_fetch(anx.k0_next, anx);
         int spin = 0;                  // the assembler wave commits the first four rows
         while (lds_peek(S + AS_FLAGS + 1) < 3.0 && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+        if (spin >= (1 << 22)) failed = 1;
     } else {
     commit_row(IC<0>{}, fetch_row(0), row_kind(0), 0);
     commit_row(IC<1>{}, fetch_row(1), row_kind(1), 1);
@@ -2167,6 +2170,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     if constexpr (MODE == SOLVE_FULL) return;
 #endif
     if constexpr (MODE == SOLVE_FULL_FWD || AS || ASA) {
+        if constexpr (ASA) { if (lds_peek(S + AS_FLAGS + 3) != 0.0) failed = 1; }     // a wait of the assembler wave ran out
         if (lane == 0) v.fail[w] = failed;
 #ifdef VF_SOLVE_STAMPS
         if (w == 0 && lane == 0) { for (int i = 0; i < 6; i++) g_stamps[i] = st[i]; for (int i = 11; i < 16; i++) g_stamps[i] = st[i]; }
@@ -2451,7 +2455,7 @@ __global__ void __launch_bounds__(128) k_band_forward_asm2(View v, int w0) {
     // (2, 1), (3, 0) in turn -- tools/probes/wave_placement.hip -- so the four workgroups of a CU leave every SIMD with one
     // eliminator and one assembler; choosing the role from HW_ID instead measured 12 % slower.)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (threadIdx.x < 3) S[AS_FLAGS + threadIdx.x] = threadIdx.x < 2 ? -1.0 : 0.0;
+    if (threadIdx.x < 4) S[AS_FLAGS + threadIdx.x] = threadIdx.x < 2 ? -1.0 : 0.0;
     __syncthreads();
     if (wave == 0) band_solve_body<SOLVE_ASM_A>(v, S, nullptr, nullptr, w, lane, 0);
     else band_solve_body<SOLVE_ASM_B>(v, S, nullptr, nullptr, w, lane, 0);

@@ -9,8 +9,8 @@ from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
 B = int(sys.argv[1]); N = 1000
 seq = synth.make_sequence(0, N)
 rec = synth.between_records(seq)
-for asm in (0, 1):
-    eng = Engine(EngineOpts(windows=B, capacity=N, chunks=1, sweep_two_sided_max=0, solve_split_min=1, solve_assemble_min=asm))
+for asm, waves in ((0, 1), (1, 1), (1, 2)):
+    eng = Engine(EngineOpts(windows=B, capacity=N, chunks=1, sweep_two_sided_max=0, solve_split_min=1, solve_assemble_min=asm, solve_assemble_waves=waves))
     for w in range(B):
         eng.preintegrate(w, 1, seq.imu_off[1:], seq.imu_steps, np.zeros(6), synth.CARLA_IMU_COV)
         eng.set_between(w, seq.btw_a, seq.btw_b, rec)
@@ -20,7 +20,7 @@ for asm in (0, 1):
     for w in range(B):
         eng.set_range(w, 0, N)
     eng.linearize(0); eng.decide(init=True); eng.assemble(); eng.sync()
-    print('B', B, 'assembling' if asm else 'split', 'solve ms', eng.time_stage('solve', 3))
+    print('B', B, ('assembling, %d wave(s) per window' % waves) if asm else 'split', 'solve ms', eng.time_stage('solve', 3))
     st = (C.c_ulonglong * 16)()
     _lib.lib().vf_debug_solve_stamps(st)
     names = ['loop top (+ as_advance)', 'panel row LDS load', 'pivot chain (+ pieces)', 'P write + panel store', 'schur mfma + commit', 'write-back',

@@ -2067,6 +2067,10 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #define VF_PIVOT_SLOT(i) do {} while (0)
         (void)as_fimg;
         if (!(pv_inv < 1e300)) failed = 1;
+        // (two-wave form: ask now how far the assembler is -- the answer travels under the panel's stores, and if row k + 4
+        // is there already, which is the rule, the wait in front of the Schur update costs no LDS round trip)
+        double as_seen = 0.0;
+        if constexpr (ASA) as_seen = *(volatile double*)(S + AS_FLAGS + 1);
         STAMP(2);
         // sub-panel + rhs -> LDS (MFMA operands); rows 15..57 -> HBM, one 128-B line per lane
         if constexpr (RINGM) {
@@ -2100,7 +2104,8 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #endif
         if constexpr (ASA) {    // row k + 4 committed, the between terms it brings added to rows k + 1 .. k + 3
             int spin = 0;
-            while (lds_peek(S + AS_FLAGS + 1) < (double)(k + 4) && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+            if (as_seen < (double)(k + 4))
+                while (lds_peek(S + AS_FLAGS + 1) < (double)(k + 4) && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(1);
             if (spin >= (1 << 22)) failed = 1;
             if (((lo + k + 6) & (JT - 1)) == 0) {      // factor k + 6 opens a new tile, and the assembler has read the last operands of the old one
                 as_tile_commit(anx.k0_next, anx);

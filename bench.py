@@ -712,7 +712,12 @@ def main():
             # the assembling sweep reads the Jacobians instead of H and g: the J stream (292 doubles per factor: the 291 entries
             # that are not structurally zero + padding), the residual (15), the between linearisation (78); panel, increment as above
             k4_bytes_per_kf = 8 * (292 + 15 + 78 + 547 + 547 + 15)
-            k4_name = ("k_band_forward_asm + k_band_backward (K3 + K4 in one pass: block rows of J^T J formed on the matrix cores "
+            from vil_sensor_fusion_amd import _lib as _vl
+            _o = _vl.EngineOptsC()
+            _vl.lib().vf_engine_default_opts(_vl.C.byref(_o))
+            asm_waves = args.solve_assemble_waves if args.solve_assemble_waves in (1, 2) else (2 if _o.solve_assemble_waves != 1 else 1)
+            k4_name = (("k_band_forward_asm2 (two waves per window: eliminator + assembler on one LDS image)" if asm_waves == 2 else "k_band_forward_asm")
+                       + " + k_band_backward (K3 + K4 in one pass: block rows of J^T J formed on the matrix cores "
                        "inside the forward sweep, damped block-banded Cholesky factorisation, both substitutions)")
         n_kf = args.windows * args.window
         k4_ach = n_kf * k4_bytes_per_kf / (stages["solve"] * 1e-3) / 1e9
@@ -737,16 +742,19 @@ def main():
             out["roofline_solve"]["note"] = ("8.8 of the 12.0 KB per keyframe are the Cholesky panel written by the forward sweep and read "
                                              "back by the backward one; the rest is the Jacobians K1 / K2 wrote (H is never stored)")
             out["roofline_solve"]["what_bounds_it"] = (
-                "not HBM: one wave per SIMD (39.7 KB of LDS), whose step is the pivot chain of the 15 x 15 block plus 26 "
-                "v_mfma_f64_16x16x4 (12 of the Schur update, 14 that form the row of J^T J); a single wave gets one such "
-                "instruction through every ~143 cycles and the vector unit does not run under it (tools/probes/"
-                "mfma_f64_rate.hip: 34.7 TFLOP/s from one wave per SIMD, 47 at saturation).  DESIGN.md 7.13")
+                "not HBM: the float64 units of a SIMD.  One window-step is the pivot chain of the 15 x 15 block (vector instructions "
+                "at 7 cycles each) plus 26 v_mfma_f64_16x16x4 (12 of the Schur update, 14 that form the row of J^T J); a single wave "
+                "gets one matrix instruction through every ~143 cycles, its vector instructions do not run under it, and the part's "
+                "float64 matrix rate saturates at 47 TFLOP/s (tools/probes/mfma_f64_rate.hip); as two waves per window sharing the "
+                "window's LDS the two jobs overlap each other's waits.  DESIGN.md 7.13, 7.15")
+            out["roofline_solve"]["waves_per_window"] = asm_waves
             mfma_flop = 26 * 2048.0 * n_kf           # per launch of the forward sweep: 12 (Schur update) + 14 (rows of J^T J) tiles per keyframe
             out["roofline_solve"]["matrix_instruction_view"] = {
                 "bound": "mfma", "unit": "TFLOP/s", "flop_per_launch": mfma_flop,
                 "achieved": mfma_flop / (stages["solve"] * 1e-3) / 1e12,
-                "peak_measured_one_wave_per_simd": 34.7, "peak_measured_saturated": 47.3, "peak_data_sheet_f64_matrix": 78.6,
-                "frac_of_what_one_wave_per_simd_can_issue": mfma_flop / (stages["solve"] * 1e-3) / 1e12 / 34.7,
+                "peak_measured_one_wave_per_simd": 34.7, "peak_measured_two_waves_per_simd": 45.8, "peak_measured_saturated": 47.3,
+                "peak_data_sheet_f64_matrix": 78.6,
+                "frac_of_measured_peak_at_this_occupancy": mfma_flop / (stages["solve"] * 1e-3) / 1e12 / (45.8 if asm_waves == 2 else 34.7),
                 "note": "the time is that of forward sweep + back substitution (the stage timer's `solve`); the back substitution "
                         "(0.92 ms of it) issues no matrix instruction; peaks measured by tools/probes/mfma_f64_rate.hip "
                         "(profiles/r04_mfma_f64_rate.log)"}

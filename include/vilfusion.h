@@ -104,6 +104,20 @@ typedef struct {
     int solve_assemble_waves; /* 1: the assembling sweep is one wave per window; 2 (default): two waves per window sharing its
                                 LDS, one eliminating, one assembling the rows -- the same bits, 6-10 % faster; launched in
                                 chunks of 1024 windows, the workgroups the part holds at once */
+    /* Refined solve (DESIGN.md "Refined solve"; csrc/vf_refine.hip).  The reference factorises by QR (GraphManager.cpp:38); the
+     * device forms normal equations, whose condition number grows with the FOURTH power of the window length (a chain of
+     * combined-IMU factors is a double integrator): ~1e11 at 1000 keyframes, beyond 1e19 at 10 000, where a float64 Cholesky
+     * factor has the softest modes wrong by orders of magnitude and Gauss-Newton / LM creep instead of converging.  With
+     * refinement every solve is followed by N conjugate-gradient corrections on (J^T J + lambda I) d = -J^T r with the
+     * operator applied THROUGH J (accurate to cond(J), not cond(J)^2) and the Cholesky solve as preconditioner: each
+     * correction costs one more solve with the same factor shape plus two passes over the Jacobians, and removes one of the
+     * handful of modes the factor gets wrong.  -1 (default) = 12 corrections once a window is longer than
+     * refine_min_keyframes, none otherwise (the headline windows are untouched); 0 = never; N = always N (at most 64).
+     * Refining engines run the two-kernel form (K3 + K4); windows holding far factors are not refined. */
+    int refine_iterations;
+    int refine_min_keyframes;  /* default 2048 */
+    double refine_rel_stop;    /* a window stops correcting once res . M^-1 res has fallen to this, squared, times its first value
+                                  (default 1e-13), or stops being positive */
 } vf_engine_opts;
 
 void vf_engine_default_opts(vf_engine_opts* o);
@@ -200,6 +214,8 @@ typedef struct {
     long sep_per_chunk;     /* doubles per chunk in sep (= windows * 2248) */
     void* delta;            /* device: increments of all keyframe slots (non-owned entries are zero after solve_global), */
     long delta_count;       /*         then one failure flag per window: capacity * windows * 15 + windows doubles */
+    void* refine_delta;     /* device, shaped like delta: what vf_engine_solve_global leaves while a refinement is open (NULL when
+                               vf_engine_opts.refine_iterations == 0) */
 } vf_shard_info;
 /* Geometry of the partitioned solve, host only (no device needed): an n-keyframe window is cut into `count`
  * chunks (<= chunks; fit != 0: also <= sqrt(n)); chunk c = `interior` keyframes from window-local
@@ -214,6 +230,17 @@ int vf_engine_shard_info(vf_engine* e, vf_shard_info* out);
 int vf_engine_solve_local(vf_engine* e);    /* chunk sweeps + spikes of the owned chunks */
 int vf_engine_solve_global(vf_engine* e);   /* separator chain, back substitution of the owned chunks, zero the rest of delta */
 int vf_engine_reset_lambda(vf_engine* e);   /* lambda := lambda0, as vf_engine_iterate does before its first trial */
+/* The refined solve (vf_engine_opts.refine_iterations) on a time-sharded engine, staged like the solve: after the trial's two
+ * collectives,  vf_engine_refine_begin ; N x { vf_engine_solve_local, <all-gather sep>, vf_engine_solve_global, <all-reduce
+ * refine_delta>, vf_engine_refine_step } ; vf_engine_refine_end -- vf_engine_solve_local / _global work on the correction's
+ * right-hand side while a refinement is open; N = vf_engine_refine_count (0: this engine does not refine now; the same on
+ * every rank).  Unsharded engines do all of it inside vf_engine_solve. */
+int vf_engine_refine_count(vf_engine* e, int* iterations);
+int vf_engine_refine_begin(vf_engine* e);
+int vf_engine_refine_step(vf_engine* e);
+int vf_engine_refine_end(vf_engine* e);
+/* corrections the last refined solve of `window` applied, and res . M^-1 res at its end relative to its first value */
+int vf_engine_read_refine(vf_engine* e, int window, int* corrections, double* reduction);
 
 /* Reference-compat solve: what the reference computes per GraphManager::solve (GraphManager.cpp:38-43,126-127) -- ONE
  * iSAM2-like update: keyframes whose pending increment reaches relin_threshold in any component (ISAM2Params::
@@ -224,6 +251,9 @@ int vf_engine_reset_lambda(vf_engine* e);   /* lambda := lambda0, as vf_engine_i
  * k0 - 1 (GraphManager.cpp:152-153).  Exact where iSAM2 is approximate (its partial back-substitution stops below the
  * wildfire threshold).  Not for sharded engines; fixed-lag marginalisation is not part of this mode. */
 int vf_engine_isam_step(vf_engine* e, double relin_threshold);
+/* the opening of such an update on its own -- relinearise, lambda := 0, linearise at theta -- for callers that stage the
+ * solve themselves (time-sharded engines: vf_engine_assemble, vf_engine_solve_local, ..., vf_engine_retract follow) */
+int vf_engine_gn_begin(vf_engine* e, double relin_threshold);
 int vf_engine_predict_from_estimate(vf_engine* e, int window, int k0, int n);
 int vf_engine_get_estimate(vf_engine* e, int window, int k0, int n, double* state16);
 

@@ -4,6 +4,7 @@
 // without a gfx950 device every entry point fails with VF_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
@@ -159,6 +160,28 @@ struct vf_engine {
     double* x_gtmp = nullptr;
     double* x_Z = nullptr;
     size_t x_zstride = 0;
+    // refined solve (vf_refine.hip): work vectors, allocated on first use; refine_open: a time-sharded caller is between
+    // vf_engine_refine_begin and vf_engine_refine_end, and vf_engine_solve_local / _global work on (nres, z)
+    vf::Refine rq{};
+    bool rq_ready = false, refine_open = false;
+    int ensure_refine() {
+        if (rq_ready) return VF_OK;
+        const size_t G = (size_t)v.G, B = (size_t)v.B;
+        int rc;
+        if ((rc = alloc(&rq.x, G * 15)) || (rc = alloc(&rq.p, G * 15)) || (rc = alloc(&rq.Ap, G * 15)) ||
+            (rc = alloc(&rq.nres, G * 15 + 64)) || (rc = alloc(&rq.z, G * 15 + B)) || (rc = alloc(&rq.u_imu, G * 15)) ||
+            (rc = alloc(&rq.u_btw, G * 6)) || (rc = alloc(&rq.u_pri, B * 15)) || (rc = alloc(&rq.rz, B)) ||
+            (rc = alloc(&rq.rz0, B)) || (rc = alloc(&rq.stop, B)) || (rc = alloc(&rq.iters, B))) return rc;
+        rq_ready = true;
+        return VF_OK;
+    }
+    // corrections per solve: vf_engine_opts.refine_iterations, or (auto) 12 once a window is longer than refine_min_keyframes
+    int refine_iters() const {
+        if (opts.refine_iterations >= 0) return opts.refine_iterations;
+        int longest = 0;
+        for (int w = 0; w < v.B; w++) longest = std::max(longest, h_hi[w] - h_lo[w]);
+        return longest > opts.refine_min_keyframes ? 12 : 0;
+    }
     int ensure_stage(size_t bytes) {
         if (bytes <= stage_bytes) return VF_OK;
         if (stage) HIPCHK(hipFree(stage));
@@ -215,6 +238,9 @@ void vf_engine_default_opts(vf_engine_opts* o) {
     o->solve_split_min = 2048;
     o->solve_assemble_min = 768;
     o->solve_assemble_waves = 2;
+    o->refine_iterations = -1;       // auto: windows longer than refine_min_keyframes
+    o->refine_min_keyframes = 2048;
+    o->refine_rel_stop = 1e-13;
 }
 
 int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
@@ -224,6 +250,8 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
         return fail(VF_ERR_INVALID, "bandwidth must be in 1..%d", VF_MAX_BANDWIDTH);
     if (o->chunks < 0 || o->chunks > 4096) return fail(VF_ERR_INVALID, "chunks must be in 0..4096");
     if (!(o->accept_rel >= 0.0) || !(o->accept_rel < 1.0)) return fail(VF_ERR_INVALID, "accept_rel must be in [0, 1)");
+    if (o->refine_iterations < -1 || o->refine_iterations > 64) return fail(VF_ERR_INVALID, "refine_iterations must be in -1..64");
+    if (!(o->refine_rel_stop >= 0.0) || !(o->refine_rel_stop < 1.0)) return fail(VF_ERR_INVALID, "refine_rel_stop must be in [0, 1)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(VF_ERR_NO_DEVICE, "no HIP device visible; libvilfusion has no CPU path");
@@ -302,6 +330,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     v.rel_tol = v.abs_tol = 0.0;
     v.sh_r = 0;
     v.sh_G = 1;
+    v.sh_all_jac = o->refine_iterations != 0 ? 1 : 0;   // (the refined solve applies J on whole increments: every rank keeps every Jacobian)
     AL(e->lambda0_dev, (size_t)v.B);
     AL(e->sigma_dev, 16);
     AL(e->status_dev, 4);
@@ -691,11 +720,11 @@ int vf_engine_linearize(vf_engine* e, int which) {
 // the next vf_engine_solve forms the normal equations inside its forward sweep (vf_engine_opts.solve_assemble_min): K3 has
 // nothing to do.  Not while far factors are held (their correction solves from H and g) nor in the hybrid form.
 static bool assembles_in_solve(const vf_engine* e) {
-    return vf::asm_in_solve(e->v) && e->x_used == 0 && !(e->hybrid && e->v.stop_on);
+    return vf::asm_in_solve(e->v) && e->x_used == 0 && !(e->hybrid && e->v.stop_on) && e->refine_iters() == 0;
 }
 // hybrid solves (termination rule on): the sweep half assembles its own rows, K3 runs for the partitioned half only
 static bool assembles_in_hybrid(const vf_engine* e) {
-    return e->hybrid && e->v.stop_on && vf::asm_in_hybrid(e->v) && e->x_used == 0;
+    return e->hybrid && e->v.stop_on && vf::asm_in_hybrid(e->v) && e->x_used == 0 && e->refine_iters() == 0;
 }
 int vf_engine_assemble(vf_engine* e) {
     DeviceGuard dev_guard_(e);
@@ -748,8 +777,71 @@ int vf_engine_solve(vf_engine* e) {
                 band_solve(e->x_gtmp, e->x_Z + (size_t)(6 * s + j) * e->x_zstride);
             }
         vf::launch_extra_combine(e->v, e->x_Z, e->x_zstride, e->x_used, e->stream);   // (slots beyond x_used are empty in every window)
+    } else if (const int R = e->refine_iters()) {
+        // Refined solve (vf_refine.hip): the increment just computed is the start, the factorisation the preconditioner, of
+        // conjugate gradients on the normal equations with the operator applied through J -- R correction solves.
+        // (Windows holding far factors are not refined: their operator would need the far rows too.)
+        if (int rc = e->ensure_refine()) return rc;
+        vf::launch_refine_begin(e->v, e->rq, e->stream);
+        for (int it = 0; it < R; it++) {
+            band_solve(e->rq.nres, e->rq.z);
+            vf::launch_refine_step(e->v, e->rq, e->opts.refine_rel_stop, e->stream);
+        }
+        vf::launch_refine_end(e->v, e->rq, e->stream);
     }
     HIPCHK(hipGetLastError());
+    return VF_OK;
+}
+// ---- the refined solve on time-sharded engines, staged like the solve itself: after the trial's two collectives
+//   vf_engine_refine_begin ; R x { vf_engine_solve_local, <all-gather sep>, vf_engine_solve_global, <all-reduce refine_delta>,
+//   vf_engine_refine_step } ; vf_engine_refine_end
+// (vf_engine_solve_local / _global work on the correction's right-hand side while a refinement is open)
+int vf_engine_refine_count(vf_engine* e, int* iterations) {
+    if (!e || !iterations) return fail(VF_ERR_INVALID, "null argument");
+    *iterations = e->x_used > 0 ? 0 : e->refine_iters();
+    return VF_OK;
+}
+int vf_engine_refine_begin(vf_engine* e) {
+    DeviceGuard dev_guard_(e);
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    e->warm = false;
+    if (int rc = e->ensure_refine()) return rc;
+    vf::launch_refine_begin(e->v, e->rq, e->stream);
+    HIPCHK(hipGetLastError());
+    e->refine_open = true;
+    return VF_OK;
+}
+int vf_engine_refine_step(vf_engine* e) {
+    DeviceGuard dev_guard_(e);
+    if (!e || !e->refine_open) return fail(VF_ERR_INVALID, "no refinement open (vf_engine_refine_begin)");
+    vf::launch_refine_step(e->v, e->rq, e->opts.refine_rel_stop, e->stream);
+    HIPCHK(hipGetLastError());
+    return VF_OK;
+}
+int vf_engine_refine_end(vf_engine* e) {
+    DeviceGuard dev_guard_(e);
+    if (!e || !e->refine_open) return fail(VF_ERR_INVALID, "no refinement open (vf_engine_refine_begin)");
+    vf::launch_refine_end(e->v, e->rq, e->stream);
+    HIPCHK(hipGetLastError());
+    e->refine_open = false;
+    return VF_OK;
+}
+// corrections the last refined solve of `window` applied before its stopping rule (or the count) ended it; the ratio of the
+// preconditioned residual res . M^-1 res at the end to its first value
+int vf_engine_read_refine(vf_engine* e, int window, int* corrections, double* reduction) {
+    DeviceGuard dev_guard_(e);
+    int rc = check_window(e, window);
+    if (rc) return rc;
+    int it = 0;
+    double rz = 0.0, rz0 = 0.0;
+    if (e->rq_ready) {
+        HIPCHK(hipMemcpyAsync(&it, e->rq.iters + window, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(&rz, e->rq.rz + window, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(&rz0, e->rq.rz0 + window, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    if (corrections) *corrections = it;
+    if (reduction) *reduction = rz0 > 0.0 ? rz / rz0 : 0.0;
     return VF_OK;
 }
 int vf_engine_retract(vf_engine* e) {
@@ -804,7 +896,7 @@ int vf_engine_iterate(vf_engine* e, int iterations) {
     if (iterations < 0) return fail(VF_ERR_INVALID, "iterations < 0");
     if (int rc0 = not_sharded(e, "vf_engine_iterate")) return rc0;
     // (asynchronous, like the stages: every read-back synchronises the stream)
-    if (e->graph_off || !e->own_stream) {
+    if (e->graph_off || !e->own_stream || e->refine_iters() > 0) {
         const int rc = iterate_sequence(e, iterations);
         if (!rc) mark_solved(e);
         return rc;
@@ -919,6 +1011,11 @@ int vf_engine_shard_info(vf_engine* e, vf_shard_info* out) {
     out->sep = e->v.sepR;
     out->sep_per_chunk = (long)e->v.B * vf::SEPK;
     out->delta = e->v.delta; out->delta_count = e->v.G * 15 + e->v.B;
+    if (e->opts.refine_iterations != 0) {
+        if (int rc = e->ensure_refine()) return rc;
+        HIPCHK(hipStreamSynchronize(e->stream));
+        out->refine_delta = e->rq.z;
+    }
     return VF_OK;
 }
 static int check_sharded(vf_engine* e) {
@@ -937,7 +1034,9 @@ int vf_engine_solve_local(vf_engine* e) {
     if (e) e->warm = false;
     int rc = check_sharded(e);
     if (rc) return rc;
-    vf::launch_partitioned_local(e->v, e->stream);
+    vf::View a = e->v;
+    if (e->refine_open) { a.gvec = e->rq.nres; a.delta = e->rq.z; }
+    vf::launch_partitioned_local(a, e->stream);
     HIPCHK(hipGetLastError());
     return VF_OK;
 }
@@ -946,8 +1045,10 @@ int vf_engine_solve_global(vf_engine* e) {
     if (e) e->warm = false;
     int rc = check_sharded(e);
     if (rc) return rc;
-    vf::launch_partitioned_global(e->v, e->stream);
-    if (e->v.sh_G > 1) vf::launch_mask_delta(e->v, e->stream);
+    vf::View a = e->v;
+    if (e->refine_open) { a.gvec = e->rq.nres; a.delta = e->rq.z; }
+    vf::launch_partitioned_global(a, e->stream);
+    if (e->v.sh_G > 1) vf::launch_mask_delta(a, e->stream);
     HIPCHK(hipGetLastError());
     return VF_OK;
 }
@@ -1001,16 +1102,26 @@ int vf_engine_predict(vf_engine* e, int window, int k0, int n) {
 // v.delta = delta, the trial buffer = the estimate.  iSAM2 re-eliminates only the cliques a new factor touches; solving the
 // whole banded system with every factor linearised at theta gives the same increment (its partial back-substitution
 // stops below wildfireThreshold 1e-3 * ... of change; that approximation is NOT reproduced -- the full solve is exact).
-int vf_engine_isam_step(vf_engine* e, double relin_threshold) {
+// the opening of such an update, also for time-sharded engines (the caller then runs the staged solve -- vf_engine_assemble,
+// vf_engine_solve_local, ..., the refinement -- and vf_engine_retract): relinearise where the pending increment reaches the
+// threshold, lambda := 0 (Gauss-Newton), linearise every factor at theta
+int vf_engine_gn_begin(vf_engine* e, double relin_threshold) {
     DeviceGuard dev_guard_(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (!(relin_threshold >= 0.0)) return fail(VF_ERR_INVALID, "relinearisation threshold must be >= 0");
-    if (int rc0 = not_sharded(e, "vf_engine_isam_step")) return rc0;
     e->warm = false;
     int rc;
     vf::launch_relinearize(e->v, relin_threshold, e->stream);
     HIPCHK(hipMemsetAsync(e->v.lambda, 0, e->v.B * sizeof(double), e->stream));     // Gauss-Newton: no damping
-    if ((rc = vf_engine_linearize(e, 0)) || (rc = vf_engine_decide(e, 1)) || (rc = vf_engine_assemble(e)) ||
+    if ((rc = vf_engine_linearize(e, 0)) || (rc = vf_engine_decide(e, 1))) return rc;
+    return VF_OK;
+}
+int vf_engine_isam_step(vf_engine* e, double relin_threshold) {
+    DeviceGuard dev_guard_(e);
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (int rc0 = not_sharded(e, "vf_engine_isam_step")) return rc0;
+    int rc;
+    if ((rc = vf_engine_gn_begin(e, relin_threshold)) || (rc = vf_engine_assemble(e)) ||
         (rc = vf_engine_solve(e)) || (rc = vf_engine_retract(e))) return rc;
     std::vector<int> failed((size_t)e->v.B);
     HIPCHK(hipMemcpyAsync(failed.data(), e->v.fail, failed.size() * sizeof(int), hipMemcpyDeviceToHost, e->stream));

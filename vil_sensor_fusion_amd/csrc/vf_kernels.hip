@@ -22,6 +22,7 @@
 // chunk for K4 / K4p (panel factorisation in registers with v_readlane / DPP broadcasts,
 // trailing window in LDS, Schur / spike products on v_mfma_f64_16x16x4).
 #include "vf_kernels.hpp"
+#include "vf_jstream.hpp"
 #include "vf_math.hpp"
 #include <cstdlib>
 
@@ -60,7 +61,7 @@ VF_DI void own_range(const View& v, int w, int& klo, int& khi) {
 // keyframe), so it assembles the rows [klo, khi + 2) of H, and needs the linearisation of the factor slots that
 // feed them: 3 more (a row of H collects factors up to 3 keyframes ahead).
 VF_DI bool shard_skips_factor(const View& v, int w, int k) {
-    if (v.sh_G <= 1) return false;
+    if (v.sh_G <= 1 || v.sh_all_jac) return false;
     int klo, khi;
     own_range(v, w, klo, khi);
     const int kk = k - v.lo[w];
@@ -286,41 +287,6 @@ __global__ void __launch_bounds__(256) k_preintegrate_t(View v, long g0, int n, 
 #ifndef VF_K1_WAVES
 #define VF_K1_WAVES 1
 #endif
-// Order in which K1 produces the non-zero entries of the whitened 15x30 Jacobian (column index = GTSAM key order
-// X_i(6) V_i(3) X_j(6) V_j(3) B_i(6) B_j(6)), split by the keyframe the column belongs to: this IS the order of the J
-// stream in HBM (vf_kernels.hpp "imu_j"), so K1 stores pairs of consecutive entries of a side as it goes.
-struct JMap {
-    short idx[450];          // entry (row * 30 + col) -> position in its side's stream, -1 = structural zero
-    short fld[2 * JS_PAIRS]; // stream word (2 * pair + half, i-side pairs first) -> row * 30 + col, -1 = padding
-    int n[2];
-};
-__host__ __device__ constexpr bool jcol_is_j(int col) { return (col >= 9 && col < 18) || col >= 24; }
-constexpr JMap make_jmap() {
-    JMap m{};
-    for (int i = 0; i < 450; i++) m.idx[i] = -1;
-    for (int i = 0; i < 2 * JS_PAIRS; i++) m.fld[i] = -1;
-    m.n[0] = m.n[1] = 0;
-    auto emit = [&m](int row, int col) {
-        const int side = jcol_is_j(col) ? 1 : 0;
-        const int e = m.n[side]++;
-        m.idx[row * 30 + col] = (short)e;
-        m.fld[(side ? 2 * JS_PI : 0) + e] = (short)(row * 30 + col);
-    };
-    for (int c = 0; c < 3; c++) {               // (the loop nest of linearize_imu_core)
-        for (int a = 0; a < 9; a++) emit(a, c);
-        for (int a = 0; a < 6; a++) emit(a, 3 + c);
-        for (int a = 0; a < 9; a++) emit(a, 6 + c);
-        for (int a = 0; a < 9; a++) emit(a, 9 + c);
-        for (int a = 0; a <= 3 + c; a++) emit(a, 12 + c);
-        for (int a = 0; a < 9; a++) emit(a, 15 + c);
-    }
-    for (int c = 0; c < 6; c++)
-        for (int a = 0; a < 10 + c; a++) { emit(a, 18 + c); emit(a, 24 + c); }
-    return m;
-}
-constexpr JMap JM = make_jmap();
-static_assert(JM.n[0] == JS_NI && JM.n[1] == JS_NJ, "J stream sizes");
-__device__ constexpr JMap JMD = make_jmap();             // the same tables in device memory, for run-time indexed reads
 VF_DI const double* jtile_ptr(const double* base, long gk) { return base + (size_t)(gk >> JT_LOG) * JT_STRIDE; }
 // entry (row, col) of the Jacobian of the factor in slot gk of a J stream buffer (0 for a structural zero)
 VF_DI double jstream_entry(const double* jbuf, long gk, int row, int col) {
@@ -885,9 +851,6 @@ __global__ void __launch_bounds__(VF_K1_BLOCK, VF_K1_WAVES) k_linearize_tail(Vie
 // v_mfma_f64_16x16x4 (column 15 of a tile carries J^T r, so the gradient comes for free) and
 // writes the H block rows coalesced straight from the MFMA C layout.  The 6x6 between terms and
 // the prior are added on the VALU from LDS before the store.
-__host__ __device__ constexpr int imu_col(int side_j, int c) {
-    return c < 9 ? c + (side_j ? 9 : 0) : c + 9 + (side_j ? 6 : 0);
-}
 // structural zeros of the whitened 15x30 IMU Jacobian (k_linearize_imu never writes them, the buffers are zero-filled
 // at creation): field f = 15 + 30 r + c of a factor's (r | J) record
 __host__ __device__ constexpr bool imu_field_is_zero(int f) {

@@ -137,6 +137,8 @@ struct View {
     // of every window; states and factors are replicated, each rank linearises / assembles / eliminates its own
     // keyframes only.  sh_G <= 1: not sharded.
     int sh_r, sh_G;
+    int sh_all_jac;     // != 0: a time-sharded rank writes the Jacobian of EVERY factor, not only of those that feed its rows (the
+                        // refined solve applies J as an operator on whole increments, replicated on every rank)
     double* Vp;         // [G][15][32]         spikes: L^-1 (coupling of the chunk interior to its left separator)
     // the three below point into ONE buffer [P][B][SEPK] (at offsets 0, SEPM, 2 SEPM of a slot): element (c, w) of each sits
     // ((size_t)c * B + w) * SEPK further on
@@ -183,6 +185,27 @@ struct View {
     double* x_in;       // [B][x_max][28]
     double* x_out;      // [2][B][x_max][78] linearisations, double-buffered like btw_out
 };
+
+// Work vectors of the refined solve (vf_refine.hip): conjugate gradients on (J^T J + lambda I) d = -J^T r with the operator
+// applied through J and the engine's Cholesky solve as the preconditioner.  Allocated on first use.
+struct Refine {
+    double* x;          // [G][15]            the iterate (starts as the plain normal-equation solution)
+    double* p;          // [G][15]            search direction
+    double* Ap;         // [G][15]            J^T (J p) + lambda p
+    double* nres;       // [G][15] + 64       MINUS the residual -g - A x: the right-hand side the correction solves take as "g"
+    double* z;          // [G][15] + [B]      M^-1 res, shaped like View::delta (failure flags behind it on time-sharded engines)
+    double* u_imu;      // [15][G]            J p, rows of the IMU factor in each slot
+    double* u_btw;      // [6][G]             ... of the between factor in each slot
+    double* u_pri;      // [B][15]            ... of the prior
+    double* rz;         // [B]                res . M^-1 res (< 0: no direction yet)
+    double* rz0;        // [B]                its first value
+    int* stop;          // [B]                the window takes no further part (converged, failed, empty)
+    int* iters;         // [B]                corrections applied in the last solve
+};
+void launch_refine_begin(const View& v, const Refine& q, hipStream_t s);                  // x := delta, nres := g + A x
+void launch_refine_step(const View& v, const Refine& q, double rel_stop, hipStream_t s);  // after z := M^-1 res: direction, A p, update
+void launch_refine_end(const View& v, const Refine& q, hipStream_t s);                    // delta := x
+void launch_refine_apply(const View& v, const Refine& q, const double* p, double* out, hipStream_t s);   // out := J^T (J p) + lambda p
 
 // does launch_band_solve(v) assemble the normal equations inside the forward sweep (so that launch_assemble may be skipped)?
 // One-wave whole-window sweeps of an unsharded engine only; the far-factor correction and the hybrid form solve from H.

@@ -1,0 +1,270 @@
+// vf_refine.hip -- the refined solve: conjugate gradients on the normal equations with the operator applied THROUGH J.
+//
+// Why.  The reference factorises by QR (GraphManager.cpp:38 `factorization = ISAM2Params::QR`); the device forms the banded
+// normal equations H = J^T J and factorises them by Cholesky.  An n-keyframe chain of combined-IMU factors is a double
+// integrator: its softest modes have curvature ~ stiffness / n^4, so cond(H) ~ 1e11 at n = 1 000 and beyond 1e19 at
+// n = 10 000 (BASELINE configs[4]).  There the Cholesky factor of the float64 H has the soft eigenvalues wrong by orders of
+// magnitude: undamped Gauss-Newton by normal equations creeps (measured on the CPU oracle: 4.4 m from the QR optimum after 8
+// steps, still 0.12 m after 6 steps with an 80-bit H and factor), where QR of the whitened Jacobian (cond ~ 1e9) takes 4.
+// The Jacobian itself is accurate: J v costs eps |J| |v|, and J^T (J v) inherits cond(J), not cond(J)^2.  So the Cholesky
+// factor M = L L^T (whatever form the engine's K4 has: sweep, partitioned, time-sharded) is kept as a PRECONDITIONER and
+// the step is the conjugate-gradient solution of (J^T J + lambda I) d = -J^T r with A p evaluated as J^T (J p) + lambda p
+// (k_jv, k_jtu below): M^-1 A is the identity on all but the handful of soft modes M gets wrong, and CG removes one such
+// outlier per iteration -- 8 to 10 iterations reach the accuracy of the QR step (DESIGN.md "Refined solve").  Textbook name:
+// CGLS preconditioned by the Cholesky factor of the normal equations (Bjorck, Numerical Methods for Least Squares Problems, 7.4).
+//
+// Every vector is increment-shaped ([G][15], a window's keyframes [lo, hi)); scalars are per window; reductions are fixed
+// trees inside one workgroup per window, so a solve is bitwise reproducible and identical on every rank of a time-sharded window.
+#include "vf_kernels.hpp"
+#include "vf_jstream.hpp"
+
+namespace vf {
+
+#define VF_DI __device__ __forceinline__
+
+// did the plain solve of window w fail (normal equations not positive definite)?  On a time-sharded engine the other ranks'
+// flags arrive, summed, behind the increments (k_mask_delta + the all-reduce)
+VF_DI bool solve_failed(const View& v, int w) {
+    return v.fail[w] != 0 || (v.sh_G > 1 && v.delta[(size_t)v.G * 15 + w] > 0.0);
+}
+VF_DI bool refine_off(const View& v, const Refine& q, int w) {
+    return q.stop[w] != 0 || (v.stop_on && v.done[w]) || v.hi[w] - v.lo[w] <= 0;
+}
+// GTSAM column of the 15x30 Jacobian -> tangent component of its keyframe (inverse of imu_col)
+__host__ __device__ constexpr int col_comp(int col) { return col < 18 ? col % 9 : 9 + (col - 18) % 6; }
+
+// u = J p, one lane per factor slot: the IMU factor k-1 -> k (15 rows), the between factor a -> k (6 rows) and, in the lane
+// of its keyframe, the prior of GraphManager.cpp:27-35 (15 rows), all at the CURRENT linearisation (buffer sel).
+__global__ void __launch_bounds__(256) k_jv(View v, Refine q, const double* __restrict__ p) {
+    const long gk = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gk >= v.G) return;
+    const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
+    const int lo = v.lo[w], hi = v.hi[w], b = v.sel[w];
+    if (k < lo || k >= hi || refine_off(v, q, w)) return;
+    double pj[15];
+#pragma unroll
+    for (int c = 0; c < 15; c++) pj[c] = p[(size_t)gk * 15 + c];
+    if (v.prior_k[w] == k) {
+        const double* J = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT + 15;
+        for (int r = 0; r < 15; r++) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < 15; c++) s = fma(J[r * 15 + c], pj[c], s);
+            q.u_pri[(size_t)w * 15 + r] = s;
+        }
+    }
+    if (k == lo) return;
+    double pi[15], u[15];
+#pragma unroll
+    for (int c = 0; c < 15; c++) { pi[c] = p[(size_t)(gk - 1) * 15 + c]; u[c] = 0.0; }
+    const double* __restrict__ tile = v.imu_j + ((size_t)b * (size_t)(v.G >> JT_LOG) + (size_t)(gk >> JT_LOG)) * JT_STRIDE + (gk & (JT - 1)) * 2;
+#pragma unroll
+    for (int col = 0; col < 30; col++) {
+#pragma unroll
+        for (int row = 0; row < 15; row++) {
+            const int e = JM.idx[row * 30 + col];            // compile-time once unrolled
+            if (e < 0) continue;
+            const int side = jcol_is_j(col) ? 1 : 0;
+            const double val = tile[(size_t)((side ? JS_PI : 0) + (e >> 1)) * (JT * 2) + (e & 1)];
+            u[row] = fma(val, side ? pj[col_comp(col)] : pi[col_comp(col)], u[row]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 15; r++) q.u_imu[(size_t)r * v.G + gk] = u[r];
+    const int a = v.btw_a[gk];
+    if (a >= lo && a < k) {
+        const double* __restrict__ fb = v.btw_out + ((size_t)b * (size_t)(v.G >> 6) + (size_t)(gk >> 6)) * BTW_OUT * TILE + (gk & 63);
+        const double* pa = p + ((size_t)w * v.M + a) * 15;
+        double pa6[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) pa6[c] = pa[c];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) s = fma(fb[(size_t)(6 + r * 6 + c) * TILE], pa6[c], fma(fb[(size_t)(42 + r * 6 + c) * TILE], pj[c], s));
+            q.u_btw[(size_t)r * v.G + gk] = s;
+        }
+    }
+}
+
+// one side (columns of keyframe `side_j`) of J^T u of the IMU factor in slot g: o[c] += sum_row J[row][imu_col(side, c)] u[row]
+template <int SIDE>
+VF_DI void jt_side(const View& v, const Refine& q, int b, long g, double (&o)[15]) {
+    double u[15];
+#pragma unroll
+    for (int r = 0; r < 15; r++) u[r] = q.u_imu[(size_t)r * v.G + g];
+    const double* __restrict__ tile = v.imu_j + ((size_t)b * (size_t)(v.G >> JT_LOG) + (size_t)(g >> JT_LOG)) * JT_STRIDE + (g & (JT - 1)) * 2;
+#pragma unroll
+    for (int c = 0; c < 15; c++) {
+#pragma unroll
+        for (int row = 0; row < 15; row++) {
+            const int e = JM.idx[row * 30 + imu_col(SIDE, c)];
+            if (e < 0) continue;
+            o[c] = fma(tile[(size_t)((SIDE ? JS_PI : 0) + (e >> 1)) * (JT * 2) + (e & 1)], u[row], o[c]);
+        }
+    }
+}
+
+// out = J^T u + lambda p, one lane per keyframe (owner computes: the sums of a keyframe are formed in one fixed order),
+// plus the marginal prior's information times p (it is kept in information form: 27 x 27, on [lo: 15][lo+1: pose][lo+2: pose])
+__global__ void __launch_bounds__(256) k_jtu(View v, Refine q, const double* __restrict__ p, double* __restrict__ out) {
+    const long gk = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gk >= v.G) return;
+    const int w = (int)(gk / v.M), k = (int)(gk - (long)w * v.M);
+    const int lo = v.lo[w], hi = v.hi[w], b = v.sel[w];
+    if (k < lo || k >= hi || refine_off(v, q, w)) return;
+    const double lam = v.lambda[w];
+    double o[15];
+#pragma unroll
+    for (int c = 0; c < 15; c++) o[c] = lam * p[(size_t)gk * 15 + c];
+    if (k > lo) jt_side<1>(v, q, b, gk, o);
+    if (k + 1 < hi) jt_side<0>(v, q, b, gk + 1, o);
+    const size_t tiles = (size_t)(v.G >> 6);
+    if (k > lo) {
+        const int a = v.btw_a[gk];
+        if (a >= lo && a < k) {
+            const double* __restrict__ fb = v.btw_out + ((size_t)b * tiles + (size_t)(gk >> 6)) * BTW_OUT * TILE + (gk & 63);
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const double ur = q.u_btw[(size_t)r * v.G + gk];
+#pragma unroll
+                for (int c = 0; c < 6; c++) o[c] = fma(fb[(size_t)(42 + r * 6 + c) * TILE], ur, o[c]);
+            }
+        }
+    }
+    for (int d = 1; d <= 3; d++) {
+        const long g2 = gk + d;
+        if (k + d >= hi || v.btw_a[g2] != k) continue;
+        const double* __restrict__ fb = v.btw_out + ((size_t)b * tiles + (size_t)(g2 >> 6)) * BTW_OUT * TILE + (g2 & 63);
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const double ur = q.u_btw[(size_t)r * v.G + g2];
+#pragma unroll
+            for (int c = 0; c < 6; c++) o[c] = fma(fb[(size_t)(6 + r * 6 + c) * TILE], ur, o[c]);
+        }
+    }
+    if (v.prior_k[w] == k) {
+        const double* J = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT + 15;
+        for (int r = 0; r < 15; r++) {
+            const double ur = q.u_pri[(size_t)w * 15 + r];
+#pragma unroll
+            for (int c = 0; c < 15; c++) o[c] = fma(J[r * 15 + c], ur, o[c]);
+        }
+    }
+    if (v.mp_on[w] && hi - lo >= 3 && k - lo < 3) {
+        const int j = k - lo, r0 = j == 0 ? 0 : 15 + 6 * (j - 1), nr = j == 0 ? 15 : 6;
+        const double* L = v.mp_L + (size_t)w * 729;
+        const double* p0 = p + ((size_t)w * v.M + lo) * 15;
+        for (int i = 0; i < 27; i++) {
+            const double pv = i < 15 ? p0[i] : (i < 21 ? p0[15 + (i - 15)] : p0[30 + (i - 21)]);
+            for (int c = 0; c < nr; c++) o[c] = fma(L[(r0 + c) * 27 + i], pv, o[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 15; c++) out[(size_t)gk * 15 + c] = o[c];
+}
+
+// ---- per-window vector steps of the iteration: one 1024-thread workgroup per window, fixed-shape tree reductions
+VF_DI double block_sum(double s, double* red) {
+    const int tid = threadIdx.x;
+    red[tid] = s;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if (tid < st) red[tid] += red[tid + st];
+        __syncthreads();
+    }
+    const double t = red[0];
+    __syncthreads();
+    return t;
+}
+// x := delta (the plain normal-equation solution the engine's solve has just left); a window whose factorisation failed
+// takes no part
+__global__ void __launch_bounds__(1024) k_pcg_begin(View v, Refine q) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int lo = v.lo[w], hi = v.hi[w];
+    if (tid == 0) { q.stop[w] = (solve_failed(v, w) || hi - lo <= 0 || (v.stop_on && v.done[w])) ? 1 : 0; q.rz[w] = -1.0; q.rz0[w] = 0.0; q.iters[w] = 0; }
+    const size_t o = ((size_t)w * v.M + lo) * 15;
+    for (int e = tid; e < (hi - lo) * 15; e += 1024) q.x[o + e] = v.delta[o + e];
+}
+// nres := g + A x  (= minus the residual of the normal equations at x, with A x evaluated through J)
+__global__ void __launch_bounds__(1024) k_pcg_residual(View v, Refine q) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (refine_off(v, q, w)) return;
+    const int lo = v.lo[w], hi = v.hi[w];
+    const size_t o = ((size_t)w * v.M + lo) * 15;
+    for (int e = tid; e < (hi - lo) * 15; e += 1024) q.nres[o + e] = v.gvec[o + e] + q.Ap[o + e];
+}
+// after a correction solve z = M^-1 res (the engine's K4 run on nres):  rz' = res . z ;  p := z + (rz' / rz) p
+__global__ void __launch_bounds__(1024) k_pcg_direction(View v, Refine q, double rel_stop) {
+    __shared__ double red[1024];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (refine_off(v, q, w)) return;                 // (uniform over the workgroup)
+    const int lo = v.lo[w], hi = v.hi[w], n = (hi - lo) * 15;
+    const size_t o = ((size_t)w * v.M + lo) * 15;
+    const double rz = q.rz[w], rz0 = q.rz0[w];       // (read before the reduction's barriers: lane 0 rewrites them at the end)
+    double s = 0.0;
+    for (int e = tid; e < n; e += 1024) s = fma(-q.nres[o + e], q.z[o + e], s);
+    const double rzn = block_sum(s, red);
+    const bool first = rz < 0.0;
+    // stop: the preconditioned residual has lost rel_stop^2 of its first value, or is no longer positive (rounding floor, or
+    // a correction solve that failed)
+    if (!(rzn > 0.0) || (!first && rzn <= rel_stop * rel_stop * rz0)) {
+        if (tid == 0) q.stop[w] = 1;
+        return;
+    }
+    const double beta = first ? 0.0 : rzn / rz;
+    for (int e = tid; e < n; e += 1024) q.p[o + e] = first ? q.z[o + e] : fma(beta, q.p[o + e], q.z[o + e]);
+    if (tid == 0) { q.rz[w] = rzn; if (first) q.rz0[w] = rzn; }
+}
+// alpha = rz / (p . A p) ;  x += alpha p ;  nres += alpha A p
+__global__ void __launch_bounds__(1024) k_pcg_update(View v, Refine q) {
+    __shared__ double red[1024];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (refine_off(v, q, w)) return;
+    const int lo = v.lo[w], hi = v.hi[w], n = (hi - lo) * 15;
+    const size_t o = ((size_t)w * v.M + lo) * 15;
+    const double rz = q.rz[w];
+    double s = 0.0;
+    for (int e = tid; e < n; e += 1024) s = fma(q.p[o + e], q.Ap[o + e], s);
+    const double pAp = block_sum(s, red);
+    if (!(pAp > 0.0)) {
+        if (tid == 0) q.stop[w] = 1;
+        return;
+    }
+    const double alpha = rz / pAp;
+    for (int e = tid; e < n; e += 1024) {
+        q.x[o + e] = fma(alpha, q.p[o + e], q.x[o + e]);
+        q.nres[o + e] = fma(alpha, q.Ap[o + e], q.nres[o + e]);
+    }
+    if (tid == 0) q.iters[w] += 1;
+}
+// delta := x
+__global__ void __launch_bounds__(1024) k_pcg_end(View v, Refine q) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int lo = v.lo[w], hi = v.hi[w];
+    if (hi - lo <= 0 || solve_failed(v, w) || (v.stop_on && v.done[w])) return;
+    const size_t o = ((size_t)w * v.M + lo) * 15;
+    for (int e = tid; e < (hi - lo) * 15; e += 1024) v.delta[o + e] = q.x[o + e];
+}
+
+static inline unsigned nblk_(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+void launch_refine_apply(const View& v, const Refine& q, const double* p, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_jv, dim3(nblk_(v.G, 256)), dim3(256), 0, s, v, q, p);
+    hipLaunchKernelGGL(k_jtu, dim3(nblk_(v.G, 256)), dim3(256), 0, s, v, q, p, out);
+}
+void launch_refine_begin(const View& v, const Refine& q, hipStream_t s) {
+    hipLaunchKernelGGL(k_pcg_begin, dim3(v.B), dim3(1024), 0, s, v, q);
+    launch_refine_apply(v, q, q.x, q.Ap, s);
+    hipLaunchKernelGGL(k_pcg_residual, dim3(v.B), dim3(1024), 0, s, v, q);
+}
+void launch_refine_step(const View& v, const Refine& q, double rel_stop, hipStream_t s) {
+    hipLaunchKernelGGL(k_pcg_direction, dim3(v.B), dim3(1024), 0, s, v, q, rel_stop);
+    launch_refine_apply(v, q, q.p, q.Ap, s);
+    hipLaunchKernelGGL(k_pcg_update, dim3(v.B), dim3(1024), 0, s, v, q);
+}
+void launch_refine_end(const View& v, const Refine& q, hipStream_t s) {
+    hipLaunchKernelGGL(k_pcg_end, dim3(v.B), dim3(1024), 0, s, v, q);
+}
+
+}  // namespace vf

@@ -185,6 +185,8 @@ class ShardedSolver:
         self.sep_per = info.sep_per_chunk
         self.sep = wrap(info.sep, info.chunks * self.sep_per)
         self.delta = wrap(info.delta, info.delta_count)       # increments + one solve-failure flag per window
+        # refined solve (vf_engine_opts.refine_iterations): the correction solves leave their increments in a buffer of their own
+        self.refine_delta = wrap(info.refine_delta, info.delta_count) if info.refine_delta else None
         self.collectives = 0                                   # issued so far (0 when there is no process group)
         # whether the in-place form of the separator all-gather is usable is settled here, once, on every rank alike
         self.inplace_all_gather = (probe_inplace_all_gather(dist, self.device, self.rank, self.world)
@@ -214,6 +216,26 @@ class ShardedSolver:
         all_reduce_sum(self.dist, self.delta, self.backend)
         self._count()
 
+    def exchange_refine(self):
+        all_reduce_sum(self.dist, self.refine_delta, self.backend)
+        self._count()
+
+    def refine(self):
+        """the refined solve, staged: every correction is one more solve with the trial's factor shape (two collectives) and two
+        passes over the Jacobians, which every rank holds in full; the count is the same on every rank"""
+        e = self.eng
+        n = e.refine_count()
+        if not n:
+            return
+        e.refine_begin()
+        for _ in range(n):
+            e.solve_local()
+            self.exchange_sep()
+            e.solve_global()
+            self.exchange_refine()
+            e.refine_step()
+        e.refine_end()
+
     def phase_finish(self):
         e = self.eng
         e.retract()
@@ -231,7 +253,19 @@ class ShardedSolver:
         self.exchange_sep()
         self.phase_global()
         self.exchange_delta()
+        self.refine()
         self.phase_finish()
+
+    def gn_step(self, relin_threshold=1e-4):
+        """one reference-compat update (vf_engine_isam_step) of the time-sharded window: undamped Gauss-Newton about the
+        linearisation points, the estimate lands in the trial buffer (Engine.get_estimate)"""
+        self.eng.gn_begin(relin_threshold)
+        self.phase_local()
+        self.exchange_sep()
+        self.phase_global()
+        self.exchange_delta()
+        self.refine()
+        self.eng.retract()
 
     def iterate(self, iterations: int):
         self.begin()
@@ -279,21 +313,48 @@ class LockstepGroup:
                     dst.sep[r * per:(r + 1) * per].copy_(src.sep[r * per:(r + 1) * per])
         self.collectives += 1
 
-    def _all_reduce_delta(self):
-        total = self.torch.stack([s.delta for s in self.solvers]).sum(dim=0)
+    def _all_reduce(self, name):
+        total = self.torch.stack([getattr(s, name) for s in self.solvers]).sum(dim=0)
         for s in self.solvers:
-            s.delta.copy_(total)
+            getattr(s, name).copy_(total)
         self.collectives += 1
+
+    def _solve(self):
+        """one staged solve of all shards, the refinement included (ShardedSolver.trial up to the retraction)"""
+        for s in self.solvers:
+            s.phase_local()
+        self._all_gather_sep()
+        for s in self.solvers:
+            s.phase_global()
+        self._all_reduce("delta")
+        n = self.solvers[0].eng.refine_count()
+        if n:
+            for s in self.solvers:
+                s.eng.refine_begin()
+            for _ in range(n):
+                for s in self.solvers:
+                    s.eng.solve_local()
+                self._all_gather_sep()
+                for s in self.solvers:
+                    s.eng.solve_global()
+                self._all_reduce("refine_delta")
+                for s in self.solvers:
+                    s.eng.refine_step()
+            for s in self.solvers:
+                s.eng.refine_end()
 
     def iterate(self, iterations: int):
         for s in self.solvers:
             s.begin()
         for _ in range(iterations):
-            for s in self.solvers:
-                s.phase_local()
-            self._all_gather_sep()
-            for s in self.solvers:
-                s.phase_global()
-            self._all_reduce_delta()
+            self._solve()
             for s in self.solvers:
                 s.phase_finish()
+
+    def gn_step(self, relin_threshold=1e-4):
+        """one reference-compat update on every shard (ShardedSolver.gn_step)"""
+        for s in self.solvers:
+            s.eng.gn_begin(relin_threshold)
+        self._solve()
+        for s in self.solvers:
+            s.eng.retract()

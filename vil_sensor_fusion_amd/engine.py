@@ -48,6 +48,11 @@ class EngineOpts:
     solve_split_min: int | None = None   # one-wave sweeps: from this many windows on, forward sweep / back substitution as two kernels
     solve_assemble_min: int | None = None  # one-wave sweeps: from this many windows on, the forward sweep assembles H itself (no K3)
     solve_assemble_waves: int | None = None  # 1: one wave per window; 2: eliminator + assembler wave on one LDS image
+    # refined solve (vf_engine_opts.refine_iterations): conjugate-gradient corrections through J after every solve.  None = the
+    # library's default (-1: 12 corrections once a window is longer than refine_min_keyframes = 2048), 0 = never, N = always N
+    refine_iterations: int | None = None
+    refine_min_keyframes: int | None = None
+    refine_rel_stop: float | None = None
 
 
 class Engine:
@@ -73,6 +78,9 @@ class Engine:
             o.solve_assemble_min = opts.solve_assemble_min
         if opts.solve_assemble_waves is not None:
             o.solve_assemble_waves = opts.solve_assemble_waves
+        for name in ("refine_iterations", "refine_min_keyframes", "refine_rel_stop"):
+            if getattr(opts, name) is not None:
+                setattr(o, name, getattr(opts, name))
         self._h = C.c_void_p()
         check(self._l.vf_engine_create(C.byref(o), C.byref(self._h)))
         self.opts = opts
@@ -214,6 +222,31 @@ class Engine:
     def isam_step(self, relin_threshold=1e-4):
         """One reference-compat update (vf_engine_isam_step): get_states = linearisation points, get_estimate = estimate."""
         check(self._l.vf_engine_isam_step(self._h, C.c_double(relin_threshold)))
+
+    def gn_begin(self, relin_threshold=1e-4):
+        """the opening of a reference-compat update on its own (time-sharded callers stage the solve themselves)"""
+        check(self._l.vf_engine_gn_begin(self._h, C.c_double(relin_threshold)))
+
+    # ---- refined solve (include/vilfusion.h "refine_iterations")
+    def refine_count(self):
+        n = C.c_int()
+        check(self._l.vf_engine_refine_count(self._h, C.byref(n)))
+        return n.value
+
+    def refine_begin(self):
+        check(self._l.vf_engine_refine_begin(self._h))
+
+    def refine_step(self):
+        check(self._l.vf_engine_refine_step(self._h))
+
+    def refine_end(self):
+        check(self._l.vf_engine_refine_end(self._h))
+
+    def read_refine(self, window):
+        """(corrections applied by the last refined solve, res . M^-1 res at its end / at its start)"""
+        it, red = C.c_int(), C.c_double()
+        check(self._l.vf_engine_read_refine(self._h, window, C.byref(it), C.byref(red)))
+        return it.value, red.value
 
     def predict_from_estimate(self, window, k0, n):
         check(self._l.vf_engine_predict_from_estimate(self._h, window, k0, n))

@@ -118,6 +118,16 @@ typedef struct {
     int refine_min_keyframes;  /* default 2048 */
     double refine_rel_stop;    /* a window stops correcting once res . M^-1 res has fallen to this, squared, times its first value
                                   (default 1e-13), or stops being positive */
+    /* Non-monotone LM ("excursions").  On a long window the Gauss-Newton step moves the far end by metres through
+     * rotation-coupled dynamics; the stiff IMU residuals (sigma 2e-5 m) see the second-order part of that move, so the cost
+     * RISES after the step (13 -> 1700 on the 10 000-pose window) and falls below its start only after one or two more
+     * steps have corrected it (-> 10.78).  A monotone accept test rejects every such step and damped steps creep along the
+     * valley (profiles/r04_config4_soft_mode.log; gtsam's own LM rule does the same).  With lm_excursion = W > 0 up to W
+     * consecutive cost-raising trials are kept provisionally, each dividing lambda by lambda_down twice; a later trial whose
+     * cost is below the cost the excursion started from accepts them all; if the W+1-th still is not, the starting point
+     * is restored, lambda multiplied by lambda_up, and the trials count as rejected.  0 = the classical rule; -1
+     * (default) = 3 on engines that refine (windows longer than refine_min_keyframes), 0 otherwise. */
+    int lm_excursion;
 } vf_engine_opts;
 
 void vf_engine_default_opts(vf_engine_opts* o);
@@ -314,6 +324,11 @@ int vf_engine_read_delta(vf_engine* e, int window, int k0, int n, double* delta1
 int vf_engine_read_panels(vf_engine* e, int window, int k0, int n, double* panels688);
 int vf_engine_read_lm(vf_engine* e, int window, double* cost, double* lambda, int* accepted,
                       int* rejected, int* solve_failures);
+/* non-monotone LM: trials kept provisionally so far (not counted in accepted / rejected), and whether an excursion is open */
+int vf_engine_read_excursions(vf_engine* e, int window, int* provisional_trials, int* open_now);
+/* non-monotone LM: undo an excursion that is still open (restore the point it started from).  vf_engine_iterate does this
+ * after its last trial; callers that stage their trials (time-sharded windows) call it after theirs. */
+int vf_engine_close_excursions(vf_engine* e);
 
 /* ---- measurement: time `reps` launches of one stage with HIP events on the engine stream ---- */
 #define VF_STAGE_LINEARIZE_IMU 1

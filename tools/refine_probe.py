@@ -45,11 +45,16 @@ def gn(tag, steps=6, **opts):
 def lm(tag, trials, **opts):
     eng = load(**opts)
     print(f"== {tag}: form {eng.solve_form()}, refine count {eng.refine_count()}", flush=True)
+    eng.reset_lambda()
+    eng.linearize(0)
+    eng.decide(True)
     for it in range(trials):
-        eng.iterate(1) if it == 0 else (eng.assemble(), eng.solve(), eng.retract(), eng.linearize(1), eng.decide(False))
-        x = eng.get_states(0, 0, n)
-        a, _ = helpers.ate(x, F["states"])
-        print(f"  LM trial {it}: {eng.read_lm(0)} ATE {a:.3e}", flush=True)
+        eng.assemble(), eng.solve(), eng.retract(), eng.linearize(1), eng.decide(False)
+        a, _ = helpers.ate(eng.get_states(0, 0, n), F["states"])
+        print(f"  LM trial {it}: {eng.read_lm(0)} excursions {eng.read_excursions(0)} ATE {a:.3e}", flush=True)
+    eng.close_excursions()
+    a, _ = helpers.ate(eng.get_states(0, 0, n), F["states"])
+    print(f"  closed: {eng.read_lm(0)} ATE {a:.3e}")
     eng.close()
 
 
@@ -60,4 +65,5 @@ if __name__ == "__main__":
         gn("one sweep per window, refined", chunks=1, sweep_two_sided_max=0)
         gn("partitioned, NOT refined", steps=4, refine_iterations=0)
     if "lm" in what:
-        lm("LM partitioned refined", 12)
+        lm("LM, partitioned, refined, excursions (the defaults for a window this long)", 20)
+        lm("LM, partitioned, refined, classical accept rule", 20, lm_excursion=0)

@@ -182,6 +182,15 @@ struct vf_engine {
         for (int w = 0; w < v.B; w++) longest = std::max(longest, h_hi[w] - h_lo[w]);
         return longest > opts.refine_min_keyframes ? 12 : 0;
     }
+    // non-monotone LM (vf_engine_opts.lm_excursion): provisional trials allowed per excursion; auto = 3 on engines that refine
+    int excursion() const { return opts.lm_excursion >= 0 ? opts.lm_excursion : (refine_iters() > 0 ? 3 : 0); }
+    int ensure_excursion() {
+        if (v.x_best) return VF_OK;
+        int rc;
+        if ((rc = alloc(&v.x_best, 16 * (size_t)v.G)) || (rc = alloc(&v.ref_cost, (size_t)v.B)) || (rc = alloc(&v.prov, (size_t)v.B)) ||
+            (rc = alloc(&v.n_prov, (size_t)v.B)) || (rc = alloc(&v.relin, (size_t)v.B))) return rc;
+        return VF_OK;
+    }
     int ensure_stage(size_t bytes) {
         if (bytes <= stage_bytes) return VF_OK;
         if (stage) HIPCHK(hipFree(stage));
@@ -241,6 +250,7 @@ void vf_engine_default_opts(vf_engine_opts* o) {
     o->refine_iterations = -1;       // auto: windows longer than refine_min_keyframes
     o->refine_min_keyframes = 2048;
     o->refine_rel_stop = 1e-13;
+    o->lm_excursion = -1;            // auto: 3 on engines that refine, classical LM otherwise
 }
 
 int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
@@ -251,6 +261,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     if (o->chunks < 0 || o->chunks > 4096) return fail(VF_ERR_INVALID, "chunks must be in 0..4096");
     if (!(o->accept_rel >= 0.0) || !(o->accept_rel < 1.0)) return fail(VF_ERR_INVALID, "accept_rel must be in [0, 1)");
     if (o->refine_iterations < -1 || o->refine_iterations > 64) return fail(VF_ERR_INVALID, "refine_iterations must be in -1..64");
+    if (o->lm_excursion < -1 || o->lm_excursion > 16) return fail(VF_ERR_INVALID, "lm_excursion must be in -1..16");
     if (!(o->refine_rel_stop >= 0.0) || !(o->refine_rel_stop < 1.0)) return fail(VF_ERR_INVALID, "refine_rel_stop must be in [0, 1)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -852,11 +863,37 @@ int vf_engine_retract(vf_engine* e) {
     HIPCHK(hipGetLastError());
     return VF_OK;
 }
+// non-monotone LM: a failed excursion has put the point it started from back into the current buffer; its factors are
+// linearised again (the kernels skip every window whose flag is clear)
+static int relinearize_restored(vf_engine* e) {
+    vf::View a = e->v;
+    a.relin_only = 1;
+    if (a.B <= 128 || a.sh_G > 1) vf::launch_linearize_all(a, 0, e->stream);
+    else { vf::launch_linearize_imu(a, 0, e->stream); vf::launch_linearize_between_prior(a, 0, e->stream); }
+    HIPCHK(hipMemsetAsync(e->v.relin, 0, e->v.B * sizeof(int), e->stream));
+    return VF_OK;
+}
+// ... and an excursion still open when a solve's trials run out is undone (vf_engine_iterate does this itself; callers that
+// stage their trials -- time-sharded windows -- call it after the last one)
+int vf_engine_close_excursions(vf_engine* e) {
+    DeviceGuard dev_guard_(e);
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (!e->v.x_best) return VF_OK;
+    vf::launch_close_excursions(e->v, e->stream);
+    if (int rc = relinearize_restored(e)) return rc;
+    HIPCHK(hipGetLastError());
+    return VF_OK;
+}
 int vf_engine_decide(vf_engine* e, int init) {
     DeviceGuard dev_guard_(e);
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    e->v.nm_W = e->excursion();
+    if (e->v.nm_W > 0)
+        if (int rc = e->ensure_excursion()) return rc;
     vf::launch_decide(e->v, init ? 1 : 0, e->stream);
+    if (e->v.nm_W > 0 && !init)
+        if (int rc = relinearize_restored(e)) return rc;
     if (e->hybrid && e->v.stop_on) vf::launch_count_active(e->v, e->stream);   // what the next K4 launch gates on
     HIPCHK(hipGetLastError());
     return VF_OK;
@@ -881,6 +918,7 @@ static int iterate_sequence(vf_engine* e, int iterations) {
         if ((rc = vf_engine_linearize(e, 1))) return rc;
         if ((rc = vf_engine_decide(e, 0))) return rc;
     }
+    if (iterations > 0 && e->excursion() > 0 && (rc = vf_engine_close_excursions(e))) return rc;
     return VF_OK;
 }
 // the solve leaves every record, H row and g entry consistent with the current states: the next one may start warm.
@@ -896,7 +934,7 @@ int vf_engine_iterate(vf_engine* e, int iterations) {
     if (iterations < 0) return fail(VF_ERR_INVALID, "iterations < 0");
     if (int rc0 = not_sharded(e, "vf_engine_iterate")) return rc0;
     // (asynchronous, like the stages: every read-back synchronises the stream)
-    if (e->graph_off || !e->own_stream || e->refine_iters() > 0) {
+    if (e->graph_off || !e->own_stream || e->refine_iters() > 0 || e->excursion() > 0) {
         const int rc = iterate_sequence(e, iterations);
         if (!rc) mark_solved(e);
         return rc;
@@ -1519,6 +1557,20 @@ int vf_engine_read_lm(vf_engine* e, int window, double* cost, double* lambda, in
 }
 
 // ------------------------------------------------------------------ measurement
+int vf_engine_read_excursions(vf_engine* e, int window, int* provisional_trials, int* open_now) {
+    DeviceGuard dev_guard_(e);
+    int rc = check_window(e, window);
+    if (rc) return rc;
+    int np = 0, pr = 0;
+    if (e->v.x_best) {
+        HIPCHK(hipMemcpyAsync(&np, e->v.n_prov + window, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(&pr, e->v.prov + window, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    if (provisional_trials) *provisional_trials = np;
+    if (open_now) *open_now = pr;
+    return VF_OK;
+}
 int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms) {
     DeviceGuard dev_guard_(e);
     if (e) e->warm = false;

@@ -505,6 +505,7 @@ __device__ __forceinline__ void linearize_imu_factor(const View& v, int which, c
     // per test -- with one wave per SIMD nothing else hides them)
     const int w_lo = v.lo[w], w_hi = v.hi[w], w_sel = v.sel[w], w_done = v.stop_on ? v.done[w] : 0;
     if (k <= w_lo || k >= w_hi || w_done) return;
+    if (v.relin_only && !v.relin[w]) return;
     const bool jac = !SH || !shard_skips_factor(v, w, k);
     const int b = w_sel ^ which;
     double* jbuf = v.imu_j + (size_t)b * (size_t)(v.G >> JT_LOG) * JT_STRIDE;
@@ -607,6 +608,7 @@ __device__ __forceinline__ void linearize_between_factor(const View& v, int whic
     const int lo = v.lo[w], w_hi = v.hi[w], w_sel = v.sel[w], w_done = v.stop_on ? v.done[w] : 0;
     const int a = v.btw_a[gk];                 // (all five requested together: one round trip)
     if (k <= lo || k >= w_hi || w_done) return;
+    if (v.relin_only && !v.relin[w]) return;
     const bool jac = !SH || !shard_skips_factor(v, w, k);
     if (a < lo || a >= k) return;
     const int b = w_sel ^ which;
@@ -749,6 +751,7 @@ __global__ void __launch_bounds__(256) k_linearize_between(View v, int which) {
 
 __device__ __forceinline__ void linearize_prior_window(const View& v, int which, const int w) {
     if (w >= v.B || window_done(v, w)) return;
+    if (v.relin_only && !v.relin[w]) return;
     const int b = v.sel[w] ^ which;
     if (v.mp_on[w] && v.hi[w] - v.lo[w] >= 3) {
         // marginal prior: gm = L d + eta, cost = 0.5 d^T L d + eta^T d (fixed linearisation point)
@@ -3021,12 +3024,15 @@ __global__ void __launch_bounds__(1024) k_decide(View v, int init) {
         }
     }
     __shared__ double red[1024];
+    __shared__ int outcome_s;
     red[tid] = s;
     __syncthreads();
     for (int st = nt >> 1; st > 0; st >>= 1) {
         if (tid < st) red[tid] += red[tid + st];
         __syncthreads();
     }
+    // outcome of the trial: 0 rejected, 1 accepted, 2 kept provisionally (non-monotone LM: the cost rose, the excursion goes
+    // on), 3 the excursion failed (the point it started from is restored)
     if (tid == 0) {
         const double c = 0.5 * red[0];
         if (v.sh_G > 1 && !init) v.fail[w] = v.delta[(size_t)v.G * 15 + w] > 0.0 ? 1 : 0;   // a failed elimination on any rank rejects the trial
@@ -3035,34 +3041,76 @@ __global__ void __launch_bounds__(1024) k_decide(View v, int init) {
             v.fail[w] = 0;
             if (!(v.fresh[w] >= 2 && v.fresh[w] < 64)) v.fresh[w] = 1;   // (a warm start has marked the window "ends only")
             if (v.stop_on) v.done[w] = 0;
+            if (v.nm_W > 0) v.prov[w] = 0;
+            outcome_s = -1;
         } else {
             // accept unless the cost rises by more than the rounding floor of its own evaluation (View::accept_rel): at a
             // converged window a strict "c < cost" is decided by the last bits of two 1000-term sums, and a rejected
             // Newton step leaves the soft modes of the window where they were (DESIGN.md "Accept rule at the floor")
-            const bool ok = (v.fail[w] == 0) && (c < v.cost[w] + v.accept_rel * v.cost[w]);
-            if (v.fail[w]) v.n_fail[w] += 1;
-            v.fresh[w] = ok ? 1 : 0;
-            if (v.stop_on && v.fail[w] == 0) {
+            const int prov = v.nm_W > 0 ? v.prov[w] : 0;
+            const double refc = prov > 0 ? v.ref_cost[w] : v.cost[w];        // an excursion is judged against the point it left
+            const bool solved = v.fail[w] == 0;
+            const bool ok = solved && (c < refc + v.accept_rel * refc);
+            const int outcome = ok ? 1 : (v.nm_W > 0 && solved && prov < v.nm_W) ? 2 : (prov > 0 ? 3 : 0);
+            outcome_s = outcome | (prov << 8);
+            if (!solved) v.n_fail[w] += 1;
+            v.fresh[w] = outcome ? 1 : 0;
+            if (v.stop_on && solved && outcome < 2) {
                 // gtsam checkConvergence (absolute / relative decrease of the accepted step), applied to rejected
                 // trials too: a trial that changes the cost by less than the tolerance in either direction means
                 // the window sits at its rounding floor, where accept / reject is decided by the last bit
-                const double dec = fabs(v.cost[w] - c);
-                if (dec <= v.abs_tol || dec <= v.rel_tol * v.cost[w]) v.done[w] = 1;
+                const double dec = fabs(refc - c);
+                if (dec <= v.abs_tol || dec <= v.rel_tol * refc) v.done[w] = 1;
             }
-            if (ok) {
+            double l = v.lambda[w];
+            if (outcome == 1 || outcome == 2) {
+                if (outcome == 2 && prov == 0) v.ref_cost[w] = v.cost[w];
                 v.sel[w] ^= 1;
                 v.cost[w] = c;
-                v.n_acc[w] += 1;
-                const double l = v.lambda[w] / v.lam_down;
+                if (outcome == 1) v.n_acc[w] += 1; else v.n_prov[w] += 1;
+                // (a provisional trial divides twice: an excursion is the damped iteration's way towards the Gauss-Newton
+                // step, whose cost falls only once the stiff residuals its first-order move disturbed have been corrected)
+                l = outcome == 1 ? l / v.lam_down : l / (v.lam_down * v.lam_down);
                 v.lambda[w] = l < v.lam_min ? v.lam_min : l;
+                if (v.nm_W > 0) v.prov[w] = outcome == 1 ? 0 : prov + 1;
             } else {
                 v.n_rej[w] += 1;
-                const double l = v.lambda[w] * v.lam_up;
+                l *= v.lam_up;
                 v.lambda[w] = l > v.lam_max ? v.lam_max : l;
+                if (outcome == 3) { v.cost[w] = refc; v.prov[w] = 0; v.relin[w] = 1; }
             }
             v.fail[w] = 0;
         }
     }
+    if (v.nm_W > 0 && !init) {
+        __syncthreads();
+        const int outcome = outcome_s & 0xff, prov = outcome_s >> 8;
+        // (v.sel[w] was read into b = sel ^ 1 at the top: b ^ 1 is the buffer that was current when the trial was made)
+        if (outcome == 2 && prov == 0)
+            for (int e = tid; e < (hi - lo) * 16; e += nt) {
+                const int cc = e / (hi - lo), k = lo + e - cc * (hi - lo);
+                v.x_best[(size_t)cc * v.G + (size_t)w * v.M + k] = XS(b ^ 1, cc, (long)w * v.M + k);
+            }
+        if (outcome == 3)
+            for (int e = tid; e < (hi - lo) * 16; e += nt) {
+                const int cc = e / (hi - lo), k = lo + e - cc * (hi - lo);
+                XS(b ^ 1, cc, (long)w * v.M + k) = v.x_best[(size_t)cc * v.G + (size_t)w * v.M + k];
+            }
+    }
+}
+
+// non-monotone LM, end of a solve: an excursion still open when the trials run out is undone (the point it started from was
+// the best one seen)
+__global__ void __launch_bounds__(1024) k_close_excursion(View v) {
+    const int w = blockIdx.x, tid = threadIdx.x, nt = (int)blockDim.x;
+    const int prov = v.prov[w], lo = v.lo[w], hi = v.hi[w], b = v.sel[w];
+    __syncthreads();
+    if (prov <= 0 || hi - lo <= 0) return;
+    for (int e = tid; e < (hi - lo) * 16; e += nt) {
+        const int cc = e / (hi - lo), k = lo + e - cc * (hi - lo);
+        XS(b, cc, (long)w * v.M + k) = v.x_best[(size_t)cc * v.G + (size_t)w * v.M + k];
+    }
+    if (tid == 0) { v.cost[w] = v.ref_cost[w]; v.prov[w] = 0; v.relin[w] = 1; v.fresh[w] = 1; }
 }
 
 // ------------------------------------------------------------------------------------ a2
@@ -3477,6 +3525,9 @@ void launch_band_solve_hybrid(const View& v, const View& vp, hipStream_t s) {
 }
 void launch_retract(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_retract, dim3(nblk(v.G, 256)), dim3(256), 0, s, v);
+}
+void launch_close_excursions(const View& v, hipStream_t s) {
+    hipLaunchKernelGGL(k_close_excursion, dim3(v.B), dim3(v.B <= 64 ? 1024 : 256), 0, s, v);
 }
 void launch_decide(const View& v, int init, hipStream_t s) {
     hipLaunchKernelGGL(k_decide, dim3(v.B), dim3(v.B <= 64 ? 1024 : 256), 0, s, v, init);

@@ -158,6 +158,17 @@ struct View {
     int* n_fail;
     double lam_up, lam_down, lam_min, lam_max;
     double accept_rel;  // an LM trial is accepted iff new cost < cost + accept_rel * cost (vf_engine_opts.accept_rel)
+    // Non-monotone LM (vf_engine_opts.lm_excursion = nm_W > 0): up to nm_W consecutive trials that RAISE the cost are kept
+    // provisionally (an "excursion"); the first one saves the point it left (x_best, ref_cost).  A later trial whose cost is
+    // below ref_cost ends the excursion with everything accepted; the nm_W + 1-th that is not restores x_best (relin[w] = 1:
+    // its factors are linearised again by the conditional launch that follows k_decide).
+    int nm_W;
+    double* x_best;     // [16][G]
+    double* ref_cost;   // [B]
+    int* prov;          // [B] provisional trials since the reference point (0: the current point is the reference)
+    int* n_prov;        // [B] provisional trials over the life of the engine
+    int* relin;         // [B] the current buffer was restored: linearise it again
+    int relin_only;     // the linearisation kernels skip windows whose relin flag is clear
     // optional LM termination (off by default: every vf_engine_iterate runs its fixed number of trials).  With
     // stop_on, a window whose trial changes the cost by <= abs_tol, or by <= rel_tol relative to the cost
     // (gtsam::LevenbergMarquardtParams relativeErrorTol / absoluteErrorTol, checkConvergence; applied to
@@ -242,6 +253,7 @@ void launch_count_active(const View& v, hipStream_t s);
 void launch_band_solve_hybrid(const View& v, const View& vp, hipStream_t s);
 void launch_retract(const View& v, hipStream_t s);
 void launch_decide(const View& v, int init, hipStream_t s);
+void launch_close_excursions(const View& v, hipStream_t s);   // non-monotone LM: undo an excursion left open at the end of a solve
 void launch_partitioned_local(const View& v, hipStream_t s);    // chunk sweeps + spikes of the owned chunks
 void launch_partitioned_global(const View& v, hipStream_t s);   // separator chain (all of it) + back substitution of the owned chunks
 void launch_mask_delta(const View& v, hipStream_t s);           // zero the increments of keyframes this rank does not own

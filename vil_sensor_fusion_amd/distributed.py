@@ -271,6 +271,7 @@ class ShardedSolver:
         self.begin()
         for _ in range(iterations):
             self.trial()
+        self.eng.close_excursions()
 
 
 class _LocalRank:
@@ -350,6 +351,8 @@ class LockstepGroup:
             self._solve()
             for s in self.solvers:
                 s.phase_finish()
+        for s in self.solvers:
+            s.eng.close_excursions()
 
     def gn_step(self, relin_threshold=1e-4):
         """one reference-compat update on every shard (ShardedSolver.gn_step)"""

@@ -53,6 +53,7 @@ class EngineOpts:
     refine_iterations: int | None = None
     refine_min_keyframes: int | None = None
     refine_rel_stop: float | None = None
+    lm_excursion: int | None = None      # non-monotone LM: provisional cost-raising trials per excursion (None = default: 3 on refining engines)
 
 
 class Engine:
@@ -78,7 +79,7 @@ class Engine:
             o.solve_assemble_min = opts.solve_assemble_min
         if opts.solve_assemble_waves is not None:
             o.solve_assemble_waves = opts.solve_assemble_waves
-        for name in ("refine_iterations", "refine_min_keyframes", "refine_rel_stop"):
+        for name in ("refine_iterations", "refine_min_keyframes", "refine_rel_stop", "lm_excursion"):
             if getattr(opts, name) is not None:
                 setattr(o, name, getattr(opts, name))
         self._h = C.c_void_p()
@@ -340,6 +341,15 @@ class Engine:
                                         C.byref(rej), C.byref(fails)))
         return dict(cost=cost.value, lam=lam.value, accepted=acc.value, rejected=rej.value,
                     solve_failures=fails.value)
+
+    def close_excursions(self):
+        check(self._l.vf_engine_close_excursions(self._h))
+
+    def read_excursions(self, window):
+        """non-monotone LM: (trials kept provisionally so far, provisional trials of the excursion open now)"""
+        a, b = C.c_int(), C.c_int()
+        check(self._l.vf_engine_read_excursions(self._h, window, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     # ---- measurement
     def time_stage(self, stage, reps=10):

@@ -68,7 +68,8 @@ class LmOpts(C.Structure):
     _fields_ = [("lambda0", C.c_double), ("lambda_up", C.c_double), ("lambda_down", C.c_double),
                 ("lambda_min", C.c_double), ("lambda_max", C.c_double),
                 ("iterations", C.c_int), ("n_threads", C.c_int),
-                ("rel_tol", C.c_double), ("abs_tol", C.c_double), ("accept_rel", C.c_double)]
+                ("rel_tol", C.c_double), ("abs_tol", C.c_double), ("accept_rel", C.c_double),
+                ("refine", C.c_int), ("refine_rel_stop", C.c_double), ("excursion", C.c_int)]
 
 
 _lib = None
@@ -322,13 +323,26 @@ class Window:
         return cost, H, g
 
     def lm(self, iterations=5, lambda0=1e-5, up=10.0, down=10.0, lmin=1e-12, lmax=1e10,
-           n_threads=1, rel_tol=0.0, abs_tol=0.0, accept_rel=None):
-        o = LmOpts(lambda0, up, down, lmin, lmax, iterations, n_threads, rel_tol, abs_tol, ACCEPT_REL if accept_rel is None else accept_rel)
+           n_threads=1, rel_tol=0.0, abs_tol=0.0, accept_rel=None, refine=0, refine_rel_stop=1e-13, excursion=0):
+        """refine / excursion: the engine's refined solve and non-monotone accept rule (vf_engine_opts.refine_iterations,
+        lm_excursion); 0 / 0 = the classical normal-equation LM.  The engine switches both on by itself for windows longer
+        than 2048 keyframes; the oracle does what it is told."""
+        o = LmOpts(lambda0, up, down, lmin, lmax, iterations, n_threads, rel_tol, abs_tol, ACCEPT_REL if accept_rel is None else accept_rel,
+                   refine, refine_rel_stop, excursion)
         costs = np.zeros(iterations + 1)
         acc = np.zeros(iterations, dtype=np.int32)
         lam = lib().vfo_lm(C.byref(self.c), C.byref(o), _d(costs),
                            acc.ctypes.data_as(C.POINTER(C.c_int)))
         return costs, acc, lam
+
+
+def gn_step(win: "Window", refine=0, refine_rel_stop=1e-13):
+    """one undamped Gauss-Newton update of win.states (vfo_gn_step); returns (cost before, corrections applied)"""
+    c, it = C.c_double(), C.c_int()
+    rc = lib().vfo_gn_step(C.byref(win.c), C.c_int(refine), C.c_double(refine_rel_stop), C.byref(c), C.byref(it))
+    if rc != 0:
+        raise np.linalg.LinAlgError("normal equations not positive definite")
+    return c.value, it.value
 
 
 def band_solve(H, g, lam):

@@ -1183,16 +1183,192 @@ int vfo_band_solve(int n_kf, int w, const double* Hband, const double* g, double
     return rc;
 }
 
+/* ---- refined solve (the restatement of csrc/vf_refine.hip, formula for formula): conjugate gradients on
+ * (J^T J + lambda I) d = -J^T r with the operator applied THROUGH the stored Jacobians -- never through H -- and the band
+ * Cholesky solve as preconditioner.  The reference itself factorises by QR (GraphManager.cpp:38); normal equations of a long
+ * chain of combined-IMU factors lose its softest modes to rounding (cond ~ n^4), the Jacobian does not. */
+typedef struct {
+    double *imu;   /* per IMU factor: r(15) Ji(15x15) Jj(15x15), columns in per-keyframe tangent order */
+    double *btw;   /* per between factor: r(6) Ja(36) Jb(36) */
+    double *pri;   /* per prior: r(15) J(225) */
+} lin_store;
+
+static void lin_build(const vfo_problem* p, lin_store* S) {
+    S->imu = (double*)malloc(sizeof(double) * (size_t)(p->n_imu > 0 ? p->n_imu : 1) * 465);
+    S->btw = (double*)malloc(sizeof(double) * (size_t)(p->n_btw > 0 ? p->n_btw : 1) * 78);
+    S->pri = (double*)malloc(sizeof(double) * (size_t)(p->n_prior > 0 ? p->n_prior : 1) * 240);
+    for (int f = 0; f < p->n_imu; f++) {
+        double r[15], J[450];
+        double* o = S->imu + (size_t)f * 465;
+        vfo_imu_factor(p->imu_data + (size_t)f * VFO_IMU_DATA, p->gravity, p->states + 16 * p->imu_i[f],
+                       p->states + 16 * p->imu_j[f], 1, r, J);
+        memcpy(o, r, sizeof(r));
+        for (int a = 0; a < 15; a++)
+            for (int b = 0; b < 15; b++) {
+                o[15 + a * 15 + b] = J[a * 30 + IMU_COL_I[b]];
+                o[240 + a * 15 + b] = J[a * 30 + IMU_COL_J[b]];
+            }
+    }
+    for (int f = 0; f < p->n_btw; f++) {
+        double* o = S->btw + (size_t)f * 78;
+        vfo_between_factor(p->btw_data + (size_t)f * VFO_BTW_DATA, p->states + 16 * p->btw_a[f],
+                           p->states + 16 * p->btw_b[f], 1, o, o + 6, o + 42);
+    }
+    for (int f = 0; f < p->n_prior; f++) {
+        double* o = S->pri + (size_t)f * 240;
+        vfo_prior_factor(p->prior_data + (size_t)f * VFO_PRIOR_DATA, p->states + 16 * p->prior_k[f], o, o + 15);
+    }
+}
+static void lin_free(lin_store* S) { free(S->imu); free(S->btw); free(S->pri); }
+
+/* out = J^T (J v) + lambda v  (+ the marginal prior's information times v: it is kept in information form) */
+static void lin_apply(const vfo_problem* p, const lin_store* S, double lambda, const double* v, double* out) {
+    const int n = p->n_kf;
+    for (int i = 0; i < n * 15; i++) out[i] = lambda * v[i];
+    for (int f = 0; f < p->n_imu; f++) {
+        const double *Ji = S->imu + (size_t)f * 465 + 15, *Jj = Ji + 225;
+        const double *vi = v + 15 * p->imu_i[f], *vj = v + 15 * p->imu_j[f];
+        double u[15];
+        for (int a = 0; a < 15; a++) {
+            double s = 0.0;
+            for (int b = 0; b < 15; b++) s += Ji[a * 15 + b] * vi[b] + Jj[a * 15 + b] * vj[b];
+            u[a] = s;
+        }
+        double *oi = out + 15 * p->imu_i[f], *oj = out + 15 * p->imu_j[f];
+        for (int b = 0; b < 15; b++) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int a = 0; a < 15; a++) { s1 += Ji[a * 15 + b] * u[a]; s2 += Jj[a * 15 + b] * u[a]; }
+            oi[b] += s1;
+            oj[b] += s2;
+        }
+    }
+    for (int f = 0; f < p->n_btw; f++) {
+        const double *Ja = S->btw + (size_t)f * 78 + 6, *Jb = Ja + 36;
+        const double *va = v + 15 * p->btw_a[f], *vb = v + 15 * p->btw_b[f];
+        double u[6];
+        for (int a = 0; a < 6; a++) {
+            double s = 0.0;
+            for (int b = 0; b < 6; b++) s += Ja[a * 6 + b] * va[b] + Jb[a * 6 + b] * vb[b];
+            u[a] = s;
+        }
+        double *oa = out + 15 * p->btw_a[f], *ob = out + 15 * p->btw_b[f];
+        for (int b = 0; b < 6; b++) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int a = 0; a < 6; a++) { s1 += Ja[a * 6 + b] * u[a]; s2 += Jb[a * 6 + b] * u[a]; }
+            oa[b] += s1;
+            ob[b] += s2;
+        }
+    }
+    for (int f = 0; f < p->n_prior; f++) {
+        const double* J = S->pri + (size_t)f * 240 + 15;
+        const double* vk = v + 15 * p->prior_k[f];
+        double u[15];
+        for (int a = 0; a < 15; a++) {
+            double s = 0.0;
+            for (int b = 0; b < 15; b++) s += J[a * 15 + b] * vk[b];
+            u[a] = s;
+        }
+        double* ok = out + 15 * p->prior_k[f];
+        for (int b = 0; b < 15; b++) {
+            double s = 0.0;
+            for (int a = 0; a < 15; a++) s += J[a * 15 + b] * u[a];
+            ok[b] += s;
+        }
+    }
+    if (p->marg && p->marg->on) {
+        const vfo_marg* m = p->marg;
+        for (int i = 0; i < 27; i++) {
+            int ki, di;
+            marg_index(i, &ki, &di);
+            double s = 0.0;
+            for (int j = 0; j < 27; j++) {
+                int kj, dj;
+                marg_index(j, &kj, &dj);
+                s += m->L[i * 27 + j] * v[(m->k0 + kj) * 15 + dj];
+            }
+            out[(m->k0 + ki) * 15 + di] += s;
+        }
+    }
+}
+
+/* d (the plain normal-equation solution on entry) refined by at most `refine` corrections; L, y: the band solver's
+ * workspace; returns the corrections applied */
+static int refine_solution(const vfo_problem* p, int w, const double* H, const double* g, double lambda, int refine,
+                           double rel_stop, double* d, double* L, double* y) {
+    const int N = p->n_kf * 15;
+    lin_store S;
+    lin_build(p, &S);
+    double* x = (double*)malloc(sizeof(double) * (size_t)N * 5);
+    double *dir = x + N, *Ap = x + 2 * (size_t)N, *nres = x + 3 * (size_t)N, *z = x + 4 * (size_t)N;
+    memcpy(x, d, sizeof(double) * (size_t)N);
+    lin_apply(p, &S, lambda, x, Ap);
+    for (int i = 0; i < N; i++) nres[i] = g[i] + Ap[i];
+    double rz = -1.0, rz0 = 0.0;
+    int done = 0;
+    for (int it = 0; it < refine; it++) {
+        if (band_solve_ws(p->n_kf, w, H, nres, lambda, z, L, y) != 0) break;     /* z = M^-1 res */
+        double rzn = 0.0;
+        for (int i = 0; i < N; i++) rzn += -nres[i] * z[i];
+        const int first = rz < 0.0;
+        if (!(rzn > 0.0) || (!first && rzn <= rel_stop * rel_stop * rz0)) break;
+        const double beta = first ? 0.0 : rzn / rz;
+        for (int i = 0; i < N; i++) dir[i] = first ? z[i] : z[i] + beta * dir[i];
+        rz = rzn;
+        if (first) rz0 = rzn;
+        lin_apply(p, &S, lambda, dir, Ap);
+        double pAp = 0.0;
+        for (int i = 0; i < N; i++) pAp += dir[i] * Ap[i];
+        if (!(pAp > 0.0)) break;
+        const double alpha = rz / pAp;
+        for (int i = 0; i < N; i++) { x[i] += alpha * dir[i]; nres[i] += alpha * Ap[i]; }
+        done++;
+    }
+    memcpy(d, x, sizeof(double) * (size_t)N);
+    free(x);
+    lin_free(&S);
+    return done;
+}
+
+/* One reference-compat update on a batch problem: undamped Gauss-Newton at the current states (what one ISAM2::update
+ * amounts to when every variable is relinearised, GraphManager.cpp:126-127), states <- states (+) delta.  refine > 0: the
+ * step is refined as above.  Returns 0, or -1 when the normal equations are not positive definite. */
+int vfo_gn_step(vfo_problem* p, int refine, double rel_stop, double* cost_before, int* corrections) {
+    const int n = p->n_kf, w = vfo_bandwidth(p);
+    double* H = (double*)malloc(sizeof(double) * (size_t)n * (w + 1) * 225);
+    double* g = (double*)malloc(sizeof(double) * (size_t)n * 15);
+    double* d = (double*)malloc(sizeof(double) * (size_t)n * 15);
+    double* Lws = (double*)malloc(sizeof(double) * (size_t)n * 15 * (size_t)(w + 1) * 15);
+    double* yws = (double*)malloc(sizeof(double) * (size_t)n * 15);
+    const double c = vfo_assemble(p, w, H, g, 1);
+    if (cost_before) *cost_before = c;
+    int rc = band_solve_ws(n, w, H, g, 0.0, d, Lws, yws);
+    if (rc == 0) {
+        const int done = refine > 0 ? refine_solution(p, w, H, g, 0.0, refine, rel_stop, d, Lws, yws) : 0;
+        if (corrections) *corrections = done;
+        double x[16];
+        for (int k = 0; k < n; k++) {
+            vfo_retract(p->states + 16 * k, d + 15 * k, x);
+            memcpy(p->states + 16 * k, x, sizeof(x));
+        }
+    }
+    free(H); free(g); free(d); free(Lws); free(yws);
+    return rc;
+}
+
 double vfo_lm(vfo_problem* p, const vfo_lm_opts* o, double* costs_out, int* accepted_out) {
     /* One trial per iteration: linearise at x, solve (H + lambda I) d = -g, accept iff the
      * cost decreases (lambda /= down) else reject (lambda *= up).  Defaults follow
      * gtsam::LevenbergMarquardtParams (lambdaInitial 1e-5, lambdaFactor 10), the optimiser the
-     * reference leaves commented out at GraphManager.cpp:128-129. */
+     * reference leaves commented out at GraphManager.cpp:128-129.
+     * o->excursion = W > 0: the non-monotone rule of the engine (include/vilfusion.h "lm_excursion"; k_decide): up to W
+     * consecutive cost-raising trials are kept provisionally (accepted_out = 2), judged against the cost of the point the
+     * excursion left; the W+1-th that still is not below it restores that point (accepted_out = 3). */
     const int n = p->n_kf, w = vfo_bandwidth(p);
     double* H = (double*)malloc(sizeof(double) * (size_t)n * (w + 1) * 225);
     double* g = (double*)malloc(sizeof(double) * (size_t)n * 15);
     double* d = (double*)malloc(sizeof(double) * (size_t)n * 15);
     double* xs = (double*)malloc(sizeof(double) * (size_t)n * 16);
+    double* xbest = (double*)malloc(sizeof(double) * (size_t)n * 16);
     /* buffers of a trial, allocated once per solve: the trial's normal equations and the band solver's workspace */
     double* Hn = (double*)malloc(sizeof(double) * (size_t)n * (w + 1) * 225);
     double* gn = (double*)malloc(sizeof(double) * (size_t)n * 15);
@@ -1201,42 +1377,62 @@ double vfo_lm(vfo_problem* p, const vfo_lm_opts* o, double* costs_out, int* acce
     double lambda = o->lambda0;
     double cost = vfo_assemble(p, w, H, g, o->n_threads);
     if (costs_out) costs_out[0] = cost;
-    int converged = 0;
+    int converged = 0, prov = 0;
+    double ref_cost = cost;
     for (int it = 0; it < o->iterations; it++) {
         if (converged) {
             if (costs_out) costs_out[it + 1] = cost;
             if (accepted_out) accepted_out[it] = -1;
             continue;
         }
-        int ok = band_solve_ws(n, w, H, g, lambda, d, Lws, yws) == 0, acc = 0;
+        int ok = band_solve_ws(n, w, H, g, lambda, d, Lws, yws) == 0, outcome = 0;
+        const double refc = prov > 0 ? ref_cost : cost;
         if (ok) {
+            if (o->refine > 0) refine_solution(p, w, H, g, lambda, o->refine, o->refine_rel_stop, d, Lws, yws);
             memcpy(xs, p->states, sizeof(double) * (size_t)n * 16);
             for (int k = 0; k < n; k++) vfo_retract(xs + 16 * k, d + 15 * k, p->states + 16 * k);
             double cn = vfo_assemble(p, w, Hn, gn, o->n_threads);
+            outcome = (cn < refc + o->accept_rel * refc) ? 1 : (o->excursion > 0 && prov < o->excursion) ? 2 : (prov > 0 ? 3 : 0);
             /* termination (gtsam checkConvergence), also on a rejected trial within the tolerance: the
              * window then sits at its rounding floor */
-            if ((o->abs_tol > 0.0 || o->rel_tol > 0.0) &&
-                (fabs(cost - cn) <= o->abs_tol || fabs(cost - cn) <= o->rel_tol * cost)) converged = 1;
-            if (cn < cost + o->accept_rel * cost) { /* NaN compares false -> reject */
-                acc = 1;
+            if (outcome < 2 && (o->abs_tol > 0.0 || o->rel_tol > 0.0) &&
+                (fabs(refc - cn) <= o->abs_tol || fabs(refc - cn) <= o->rel_tol * refc)) converged = 1;
+            if (outcome == 1 || outcome == 2) { /* NaN compares false -> not 1 */
+                if (outcome == 2 && prov == 0) {
+                    ref_cost = cost;
+                    memcpy(xbest, xs, sizeof(double) * (size_t)n * 16);
+                }
                 cost = cn;
                 double* t = H; H = Hn; Hn = t;      /* the trial's normal equations become the current ones */
                 t = g; g = gn; gn = t;
+                prov = outcome == 1 ? 0 : prov + 1;
             } else {
                 memcpy(p->states, xs, sizeof(double) * (size_t)n * 16);
             }
+        } else if (prov > 0) outcome = 3;
+        if (outcome == 3) {           /* the excursion failed: back to the point it left */
+            memcpy(p->states, xbest, sizeof(double) * (size_t)n * 16);
+            cost = vfo_assemble(p, w, H, g, o->n_threads);
+            prov = 0;
         }
-        if (acc) {
+        if (outcome == 1) {
             lambda /= o->lambda_down;
+            if (lambda < o->lambda_min) lambda = o->lambda_min;
+        } else if (outcome == 2) {
+            lambda /= o->lambda_down * o->lambda_down;
             if (lambda < o->lambda_min) lambda = o->lambda_min;
         } else {
             lambda *= o->lambda_up;
             if (lambda > o->lambda_max) lambda = o->lambda_max;
         }
         if (costs_out) costs_out[it + 1] = cost;
-        if (accepted_out) accepted_out[it] = acc;
+        if (accepted_out) accepted_out[it] = outcome;
     }
-    free(H); free(g); free(d); free(xs);
+    if (prov > 0) {                   /* an excursion still open when the trials run out is undone */
+        memcpy(p->states, xbest, sizeof(double) * (size_t)n * 16);
+        if (costs_out) costs_out[o->iterations] = ref_cost;
+    }
+    free(H); free(g); free(d); free(xs); free(xbest);
     free(Hn); free(gn); free(Lws); free(yws);
     return lambda;
 }

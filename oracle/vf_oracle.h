@@ -133,6 +133,10 @@ typedef struct {
                                     <= rel_tol * cost (gtsam LevenbergMarquardtOptimizer checkConvergence) */
     double accept_rel;           /* a trial is accepted iff  new cost < cost + accept_rel * cost  (0: strict decrease; the
                                     engine's default is 1e-9: the rounding floor of the cost sum) */
+    int refine;                  /* > 0: every solve is followed by this many conjugate-gradient corrections through the
+                                    Jacobians (vf_engine_opts.refine_iterations; csrc/vf_refine.hip) */
+    double refine_rel_stop;      /* vf_engine_opts.refine_rel_stop */
+    int excursion;               /* vf_engine_opts.lm_excursion: provisional cost-raising trials per excursion (0: classical) */
 } vfo_lm_opts;
 
 /* total cost 0.5*sum |r|^2 at the current states */
@@ -145,8 +149,12 @@ double vfo_assemble(const vfo_problem* p, int w, double* Hband, double* g, int n
 /* Solve (H + lambda I) delta = -g by banded Cholesky. 0 ok / -1 not PD. */
 int vfo_band_solve(int n_kf, int w, const double* Hband, const double* g, double lambda,
                    double* delta);
+/* One undamped Gauss-Newton update at the current states (a reference-compat update with every variable relinearised,
+ * GraphManager.cpp:126-127), refined by `refine` corrections when > 0; states <- states (+) delta.  0 ok / -1 not PD. */
+int vfo_gn_step(vfo_problem* p, int refine, double rel_stop, double* cost_before, int* corrections);
 /* Fixed-trip LM; costs_out[iterations+1] (cost after each iteration, [0] = initial),
- * accepted_out[iterations] (-1 = trial not run: converged earlier). Returns final lambda. */
+ * accepted_out[iterations] (1 accepted, 0 rejected, -1 = trial not run: converged earlier; with excursions also 2 = kept
+ * provisionally, 3 = excursion failed, its starting point restored). Returns final lambda. */
 double vfo_lm(vfo_problem* p, const vfo_lm_opts* o, double* costs_out, int* accepted_out);
 
 /* d (27) of a marginal prior at the current states */

@@ -207,25 +207,34 @@ def test_lm_trajectory_parity(setup, oracle):
         print("   ATE vs ground truth", gt_ate)
 
 
-@pytest.mark.parametrize("n,iters,chunks", [(1000, 5, 0), (1000, 5, 1), (10000, 3, 0), (10000, 3, 1)])
-def test_full_size_windows_vs_oracle(oracle, n, iters, chunks):
+@pytest.mark.parametrize("n,iters,chunks,refined", [(1000, 5, 0, False), (1000, 5, 1, False), (10000, 3, 0, False), (10000, 3, 1, False),
+                                                    (10000, 8, 0, True), (10000, 8, 1, True)])
+def test_full_size_windows_vs_oracle(oracle, n, iters, chunks, refined):
     """BASELINE.json configs at full size: the 1000-pose window the metric is quoted on and the
     10 000-pose global smoother (here on one GPU), LM trajectory against the oracle; with the
-    partitioned solve (chunks=0: what one window gets by default) and with whole-window sweeps."""
+    partitioned solve (chunks=0: what one window gets by default) and with whole-window sweeps.
+    refined: the 10 000-pose window as the library runs it by default -- every solve refined through J, non-monotone accept
+    rule (a window that long is past what float64 normal equations resolve: DESIGN.md "Refined solve") -- against the
+    oracle doing the same, run until both have converged; not refined: the classical normal-equation LM, three shared trials."""
     from vil_sensor_fusion_amd import Engine, EngineOpts
     seq = synth.make_sequence(seed=5, n_kf=n)
     prob = helpers.build_problem(oracle, seq)
-    eng = Engine(EngineOpts(windows=1, capacity=n, chunks=chunks))
+    mode = {} if refined else dict(refine_iterations=0, lm_excursion=0)
+    eng = Engine(EngineOpts(windows=1, capacity=n, chunks=chunks, **mode))
     helpers.load_engine(eng, 0, prob)
+    assert (eng.refine_count() == 12) == refined
     eng.iterate(iters)
     win = helpers.oracle_window(oracle, prob)
-    costs, acc, _ = win.lm(iterations=iters)
+    costs, acc, _ = win.lm(iterations=iters, refine=12 if refined else 0, excursion=3 if refined else 0)
     ate, rot = helpers.ate(eng.get_states(0, 0, n), win.states)
     lm = eng.read_lm(0)
-    print(f"N={n} chunks={chunks}: ATE {ate:.3e} m rot {rot:.3e} rad; cost gpu {lm['cost']:.6e} oracle {costs[-1]:.6e}; "
-          f"accepted gpu {lm['accepted']} oracle {int(acc.sum())}")
+    print(f"N={n} chunks={chunks} refined={refined}: ATE {ate:.3e} m rot {rot:.3e} rad; cost gpu {lm['cost']:.9e} oracle {costs[-1]:.9e}; "
+          f"accepted gpu {lm['accepted']} oracle {int((acc == 1).sum())}; provisional gpu {eng.read_excursions(0)[0]} oracle {int((acc == 2).sum())}")
     assert ate <= 1e-6 and rot <= 1e-6
     assert lm["solve_failures"] == 0
+    if refined:
+        assert lm["accepted"] == int((acc == 1).sum()) and eng.read_excursions(0)[0] == int((acc == 2).sum())
+        assert abs(lm["cost"] - costs[-1]) <= 1e-9 * costs[-1]
 
 
 @pytest.mark.parametrize("extra_windows,chunks", [(0, 1), (300, 1), (300, 0), (0, 0)])

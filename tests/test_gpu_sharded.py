@@ -192,7 +192,7 @@ def test_bench_abandons_a_stalled_sharded_section():
 
 
 # ---------------------------------------------------------------- BASELINE configs[4] at its real geometry
-N4, CHUNKS4, ITERS4 = 10000, 96, 3
+N4, CHUNKS4, ITERS4, REFINE4 = 10000, 96, 10, 12     # (a window this long runs refined solves by default: 12 corrections each)
 
 
 def _problem4():
@@ -206,8 +206,10 @@ def test_config4_eight_shards_of_twelve_chunks_vs_oracle():
     """The 10 000-pose window cut into 96 chunks, owned 12 each by EIGHT shards -- the geometry of the 8-GPU run.  The pool
     gives one GPU and at most six GPU processes, so the eight shards are eight engines of one process
     (distributed.LockstepGroup: ShardedSolver's own phases, the two collectives of a trial carried out between the engines'
-    device buffers).  Gates: all shards hold identical states, equal to the unsharded engine to 1e-9, ATE <= 1e-6 m
-    against the oracle, two collectives per trial."""
+    device buffers).  The window is past what float64 normal equations resolve, so every solve is refined through J (the
+    library's default for it; 12 corrections = 12 more solves, two collectives each) and the accept rule is the
+    non-monotone one; ten trials converge it from dead reckoning.  Gates: all shards hold identical states, equal to the
+    unsharded engine to 1e-7 m (ATE), ATE <= 1e-6 m against the oracle doing the same, 2 x (1 + 12) collectives per trial."""
     import torch
     from vil_sensor_fusion_amd import Engine, EngineOpts, distributed as D
     oracle, prob = _problem4()
@@ -228,23 +230,27 @@ def test_config4_eight_shards_of_twelve_chunks_vs_oracle():
     group = D.LockstepGroup(engines, "cuda:0")
     group.iterate(ITERS4)
     torch.cuda.synchronize()
-    assert group.collectives == 2 * ITERS4
+    assert engines[0].refine_count() == REFINE4 and group.collectives == 2 * (1 + REFINE4) * ITERS4
     states = [e.get_states(0, 0, N4) for e in engines]
     lms = [e.read_lm(0) for e in engines]
     for r in range(1, world):
         np.testing.assert_array_equal(states[r], states[0])
         assert lms[r] == lms[0]
-    worst = float(np.abs(states[0] - ref_states).max())
-    assert worst <= 1e-9 and lms[0]["accepted"] == ref_lm["accepted"] and lms[0]["solve_failures"] == 0
+    # (two converged refined solves of a window whose softest modes sit at the rounding floor: compared as trajectories)
+    worst = helpers.ate(states[0], ref_states)[0]
+    assert worst <= 1e-7 and lms[0]["accepted"] == ref_lm["accepted"] and lms[0]["solve_failures"] == 0
     win = helpers.oracle_window(oracle, prob)
-    costs, acc, _ = win.lm(iterations=ITERS4)
+    costs, acc, _ = win.lm(iterations=ITERS4, refine=REFINE4, excursion=3)
     a, rot = helpers.ate(states[0], win.states)
-    print(f"8 shards x 12 chunks, {N4} poses: vs unsharded {worst:.3e}; vs oracle ATE {a:.3e} m rot {rot:.3e} rad; "
+    print(f"8 shards x 12 chunks, {N4} poses: vs unsharded ATE {worst:.3e} m; vs oracle ATE {a:.3e} m rot {rot:.3e} rad; "
           f"cost {lms[0]['cost']:.9e} oracle {costs[-1]:.9e}")
     assert a <= 1e-6 and rot <= 1e-6
-    assert abs(lms[0]["cost"] - costs[-1]) <= 1e-6 * abs(costs[-1])
+    assert abs(lms[0]["cost"] - costs[-1]) <= 1e-9 * abs(costs[-1])
     for e in engines:
         e.close()
+
+
+GLOO_REFINE, GLOO_UPDATES = 3, 2
 
 
 def _worker4(rank, world, port, q, prob):
@@ -254,14 +260,15 @@ def _worker4(rank, world, port, q, prob):
     import torch
     from vil_sensor_fusion_amd import Engine, EngineOpts, distributed as D
     dist = D.init(backend="gloo")
-    eng = Engine(EngineOpts(windows=1, capacity=N4 + 8, chunks=CHUNKS4))
+    eng = Engine(EngineOpts(windows=1, capacity=N4 + 8, chunks=CHUNKS4, refine_iterations=GLOO_REFINE))
     helpers.load_engine(eng, 0, prob)
     solver = D.ShardedSolver(eng, dist, "cuda:0", backend="gloo")
-    solver.iterate(ITERS4)
+    for _ in range(GLOO_UPDATES):
+        solver.gn_step(0.0)
     torch.cuda.synchronize()
-    assert solver.collectives == 2 * ITERS4
-    st = eng.get_states(0, 0, N4)
-    q.put((rank, st if rank == 0 else float(np.abs(st).sum()), eng.read_lm(0)))
+    assert solver.collectives == 2 * (1 + GLOO_REFINE) * GLOO_UPDATES
+    st = eng.get_estimate(0, 0, N4)
+    q.put((rank, st if rank == 0 else float(np.abs(st).sum())))
     D.barrier(dist)
     dist.destroy_process_group()
 
@@ -269,7 +276,12 @@ def _worker4(rank, world, port, q, prob):
 def test_config4_four_processes_over_gloo():
     """The same 10 000-pose window, 96 chunks, as FOUR real ranks (24 chunks each) in four processes sharing the box's GPU,
     exchanging over gloo -- as many processes as the pool's limit of six on the card leaves room for beside the test
-    runner.  The process boundary, the rendezvous and both collectives are real; only the transport is not RCCL."""
+    runner.  The process boundary, the rendezvous and the collectives are real; only the transport is not RCCL.  Two
+    reference-compat updates (Gauss-Newton), each solve refined by three corrections = 16 collectives; four processes
+    taking turns on one GPU are slow, so convergence is the lock-step test's business (above) and this one checks the
+    arithmetic: the ranks end with identical estimates, bit for bit those of four lock-step shards in ONE process."""
+    import torch
+    from vil_sensor_fusion_amd import Engine, EngineOpts, distributed as D
     oracle, prob = _problem4()
     world = 4
     ctx = mp.get_context("spawn")
@@ -284,12 +296,22 @@ def test_config4_four_processes_over_gloo():
         assert p.exitcode == 0
     s0 = res[0][1]
     for r in range(1, world):
-        assert res[r][1] == float(np.abs(s0).sum()) and res[r][2] == res[0][2]       # identical replicated states
-    win = helpers.oracle_window(oracle, prob)
-    win.lm(iterations=ITERS4)
-    a, rot = helpers.ate(s0, win.states)
-    print(f"4 ranks x 24 chunks over gloo, {N4} poses: ATE {a:.3e} m rot {rot:.3e} rad vs oracle; lm {res[0][2]}")
-    assert a <= 1e-6 and rot <= 1e-6 and res[0][2]["solve_failures"] == 0
+        assert res[r][1] == float(np.abs(s0).sum())                                  # identical replicated estimates
+    engines = []
+    for r in range(world):
+        e = Engine(EngineOpts(windows=1, capacity=N4 + 8, chunks=CHUNKS4, refine_iterations=GLOO_REFINE))
+        helpers.load_engine(e, 0, prob)
+        engines.append(e)
+    group = D.LockstepGroup(engines, "cuda:0")
+    for _ in range(GLOO_UPDATES):
+        group.gn_step(0.0)
+    torch.cuda.synchronize()
+    lock = engines[0].get_estimate(0, 0, N4)
+    worst = float(np.abs(lock - s0).max())
+    print(f"4 ranks x 24 chunks over gloo, {N4} poses, {GLOO_UPDATES} refined Gauss-Newton updates: largest difference from four lock-step shards {worst:.3e}")
+    np.testing.assert_array_equal(lock, s0)
+    for e in engines:
+        e.close()
 
 
 def test_shard_errors():

@@ -89,11 +89,12 @@ __global__ void __launch_bounds__(256) k_jv(View v, Refine q, const double* __re
 }
 
 // one side (columns of keyframe `side_j`) of J^T u of the IMU factor in slot g: o[c] += sum_row J[row][imu_col(side, c)] u[row]
-template <int SIDE>
+template <int SIDE, bool GRAD>
 VF_DI void jt_side(const View& v, const Refine& q, int b, long g, double (&o)[15]) {
     double u[15];
+    const double* __restrict__ res = v.imu_r + ((size_t)b * (size_t)(v.G >> 6) + (size_t)(g >> 6)) * IMU_R * TILE + (g & 63);
 #pragma unroll
-    for (int r = 0; r < 15; r++) u[r] = q.u_imu[(size_t)r * v.G + g];
+    for (int r = 0; r < 15; r++) u[r] = GRAD ? res[(size_t)r * TILE] : q.u_imu[(size_t)r * v.G + g];
     const double* __restrict__ tile = v.imu_j + ((size_t)b * (size_t)(v.G >> JT_LOG) + (size_t)(g >> JT_LOG)) * JT_STRIDE + (g & (JT - 1)) * 2;
 #pragma unroll
     for (int c = 0; c < 15; c++) {
@@ -107,7 +108,10 @@ VF_DI void jt_side(const View& v, const Refine& q, int b, long g, double (&o)[15
 }
 
 // out = J^T u + lambda p, one lane per keyframe (owner computes: the sums of a keyframe are formed in one fixed order),
-// plus the marginal prior's information times p (it is kept in information form: 27 x 27, on [lo: 15][lo+1: pose][lo+2: pose])
+// plus the marginal prior's information times p (it is kept in information form: 27 x 27, on [lo: 15][lo+1: pose][lo+2: pose]).
+// GRAD: out = J^T r, the gradient at the current linearisation, from the residuals the linearisation kernels left (a
+// time-sharded rank assembles g for its own rows only, but holds every residual and every Jacobian).
+template <bool GRAD>
 __global__ void __launch_bounds__(256) k_jtu(View v, Refine q, const double* __restrict__ p, double* __restrict__ out) {
     const long gk = (long)blockIdx.x * 256 + threadIdx.x;
     if (gk >= v.G) return;
@@ -117,9 +121,9 @@ __global__ void __launch_bounds__(256) k_jtu(View v, Refine q, const double* __r
     const double lam = v.lambda[w];
     double o[15];
 #pragma unroll
-    for (int c = 0; c < 15; c++) o[c] = lam * p[(size_t)gk * 15 + c];
-    if (k > lo) jt_side<1>(v, q, b, gk, o);
-    if (k + 1 < hi) jt_side<0>(v, q, b, gk + 1, o);
+    for (int c = 0; c < 15; c++) o[c] = GRAD ? 0.0 : lam * p[(size_t)gk * 15 + c];
+    if (k > lo) jt_side<1, GRAD>(v, q, b, gk, o);
+    if (k + 1 < hi) jt_side<0, GRAD>(v, q, b, gk + 1, o);
     const size_t tiles = (size_t)(v.G >> 6);
     if (k > lo) {
         const int a = v.btw_a[gk];
@@ -127,7 +131,7 @@ __global__ void __launch_bounds__(256) k_jtu(View v, Refine q, const double* __r
             const double* __restrict__ fb = v.btw_out + ((size_t)b * tiles + (size_t)(gk >> 6)) * BTW_OUT * TILE + (gk & 63);
 #pragma unroll
             for (int r = 0; r < 6; r++) {
-                const double ur = q.u_btw[(size_t)r * v.G + gk];
+                const double ur = GRAD ? fb[(size_t)r * TILE] : q.u_btw[(size_t)r * v.G + gk];
 #pragma unroll
                 for (int c = 0; c < 6; c++) o[c] = fma(fb[(size_t)(42 + r * 6 + c) * TILE], ur, o[c]);
             }
@@ -139,7 +143,7 @@ __global__ void __launch_bounds__(256) k_jtu(View v, Refine q, const double* __r
         const double* __restrict__ fb = v.btw_out + ((size_t)b * tiles + (size_t)(g2 >> 6)) * BTW_OUT * TILE + (g2 & 63);
 #pragma unroll
         for (int r = 0; r < 6; r++) {
-            const double ur = q.u_btw[(size_t)r * v.G + g2];
+            const double ur = GRAD ? fb[(size_t)r * TILE] : q.u_btw[(size_t)r * v.G + g2];
 #pragma unroll
             for (int c = 0; c < 6; c++) o[c] = fma(fb[(size_t)(6 + r * 6 + c) * TILE], ur, o[c]);
         }
@@ -147,7 +151,7 @@ __global__ void __launch_bounds__(256) k_jtu(View v, Refine q, const double* __r
     if (v.prior_k[w] == k) {
         const double* J = v.prior_out + ((size_t)b * v.B + w) * PRIOR_OUT + 15;
         for (int r = 0; r < 15; r++) {
-            const double ur = q.u_pri[(size_t)w * 15 + r];
+            const double ur = GRAD ? J[r - 15] : q.u_pri[(size_t)w * 15 + r];
 #pragma unroll
             for (int c = 0; c < 15; c++) o[c] = fma(J[r * 15 + c], ur, o[c]);
         }
@@ -156,6 +160,10 @@ __global__ void __launch_bounds__(256) k_jtu(View v, Refine q, const double* __r
         const int j = k - lo, r0 = j == 0 ? 0 : 15 + 6 * (j - 1), nr = j == 0 ? 15 : 6;
         const double* L = v.mp_L + (size_t)w * 729;
         const double* p0 = p + ((size_t)w * v.M + lo) * 15;
+        if (GRAD) {          // the marginal prior's gradient L d + eta, as k_linearize_prior left it
+            const double* gm = v.mp_out + ((size_t)b * v.B + w) * 28;
+            for (int c = 0; c < nr; c++) o[c] += gm[r0 + c];
+        } else
         for (int i = 0; i < 27; i++) {
             const double pv = i < 15 ? p0[i] : (i < 21 ? p0[15 + (i - 15)] : p0[30 + (i - 21)]);
             for (int c = 0; c < nr; c++) o[c] = fma(L[(r0 + c) * 27 + i], pv, o[c]);
@@ -187,13 +195,14 @@ __global__ void __launch_bounds__(1024) k_pcg_begin(View v, Refine q) {
     const size_t o = ((size_t)w * v.M + lo) * 15;
     for (int e = tid; e < (hi - lo) * 15; e += 1024) q.x[o + e] = v.delta[o + e];
 }
-// nres := g + A x  (= minus the residual of the normal equations at x, with A x evaluated through J)
+// nres := g + A x  (= minus the residual of the normal equations at x, with A x evaluated through J; g = J^T r is in q.p,
+// formed by k_jtu<true>: the same on every rank of a time-sharded window, whose K3 assembles only the rank's own rows)
 __global__ void __launch_bounds__(1024) k_pcg_residual(View v, Refine q) {
     const int w = blockIdx.x, tid = threadIdx.x;
     if (refine_off(v, q, w)) return;
     const int lo = v.lo[w], hi = v.hi[w];
     const size_t o = ((size_t)w * v.M + lo) * 15;
-    for (int e = tid; e < (hi - lo) * 15; e += 1024) q.nres[o + e] = v.gvec[o + e] + q.Ap[o + e];
+    for (int e = tid; e < (hi - lo) * 15; e += 1024) q.nres[o + e] = q.p[o + e] + q.Ap[o + e];
 }
 // after a correction solve z = M^-1 res (the engine's K4 run on nres):  rz' = res . z ;  p := z + (rz' / rz) p
 __global__ void __launch_bounds__(1024) k_pcg_direction(View v, Refine q, double rel_stop) {
@@ -251,11 +260,12 @@ __global__ void __launch_bounds__(1024) k_pcg_end(View v, Refine q) {
 static inline unsigned nblk_(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 void launch_refine_apply(const View& v, const Refine& q, const double* p, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_jv, dim3(nblk_(v.G, 256)), dim3(256), 0, s, v, q, p);
-    hipLaunchKernelGGL(k_jtu, dim3(nblk_(v.G, 256)), dim3(256), 0, s, v, q, p, out);
+    hipLaunchKernelGGL(k_jtu<false>, dim3(nblk_(v.G, 256)), dim3(256), 0, s, v, q, p, out);
 }
 void launch_refine_begin(const View& v, const Refine& q, hipStream_t s) {
     hipLaunchKernelGGL(k_pcg_begin, dim3(v.B), dim3(1024), 0, s, v, q);
     launch_refine_apply(v, q, q.x, q.Ap, s);
+    hipLaunchKernelGGL(k_jtu<true>, dim3(nblk_(v.G, 256)), dim3(256), 0, s, v, q, q.x, q.p);     // q.p := J^T r (p has no direction yet)
     hipLaunchKernelGGL(k_pcg_residual, dim3(v.B), dim3(1024), 0, s, v, q);
 }
 void launch_refine_step(const View& v, const Refine& q, double rel_stop, hipStream_t s) {

@@ -294,7 +294,11 @@ def time_sharded_window(args, info, dist, backend, dev):
             eng.close()
         return {"error": problem or "set-up failed on another rank"}
     solver = D.ShardedSolver(eng, dist, dev, backend=backend)
-    solver.iterate(trials)                       # converge + warm up (not timed)
+    # A window this long is past what float64 normal equations resolve (cond ~ n^4): the library refines every solve by
+    # conjugate gradients through J -- R more solves with the same factor shape, two collectives each -- and accepts trials
+    # non-monotonically (DESIGN.md "Refined solve").  First converge from dead reckoning (12 trials, not timed) ...
+    refine = eng.refine_count()
+    solver.iterate(12)
     torch.cuda.synchronize(dev)
     D.barrier(dist)
     reps = 3
@@ -307,13 +311,24 @@ def time_sharded_window(args, info, dist, backend, dev):
     per_trial = dt / (reps * (trials + 1e-30))
     out = {"window_keyframes": n, "ranks": info.world, "chunks": chunks, "chunks_per_rank": chunks // max(info.world, 1),
            "lm_trials_timed": reps * trials, "ms_per_lm_trial": per_trial * 1e3,
+           "refine_corrections_per_solve": refine, "ms_per_solve": per_trial * 1e3 / (1 + refine),
            "keyframe_relinearisations_per_s": n / per_trial,
-           "exchange_doubles_per_trial": chunks * 2248 + (n + 8 + 63) // 64 * 64 * 15 + 1,   # separator slots; increments of every slot + failure flag
-           "collectives_per_trial": D.ShardedSolver.COLLECTIVES_PER_TRIAL,
-           "collectives": "1 in-place all-gather (packed separator system) + 1 all-reduce (increments + failure flags); "
-                          "the cost needs none (every rank evaluates every residual)",
-           "collectives_issued": solver.collectives, "lm_trials_run": (reps + 1) * trials,
-           "backend": backend if dist is not None else "none", "final_cost": lm["cost"], "solve_failures": lm["solve_failures"]}
+           "exchange_doubles_per_solve": chunks * 2248 + (n + 8 + 63) // 64 * 64 * 15 + 1,   # separator slots; increments of every slot + failure flag
+           "collectives_per_trial": D.ShardedSolver.COLLECTIVES_PER_TRIAL * (1 + refine),
+           "collectives": "per solve 1 in-place all-gather (packed separator system) + 1 all-reduce (increments + failure flags), "
+                          "1 + refine_corrections_per_solve solves per trial; the cost and the operator J^T J need none (every rank "
+                          "holds every residual and every Jacobian)",
+           "collectives_issued": solver.collectives, "lm_trials_run": 12 + reps * trials,
+           "backend": backend if dist is not None else "none", "final_cost": lm["cost"], "solve_failures": lm["solve_failures"],
+           "lm": {"accepted": lm["accepted"], "rejected": lm["rejected"], "provisional": eng.read_excursions(0)[0]}}
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "qr_twin_10k.npz")
+    if n == 10000 and os.path.exists(gold):
+        # ... and say where it ended: against the optimum an independent Householder-QR optimiser found for this window
+        F = np.load(gold)
+        x = eng.get_states(0, 0, n)
+        d = x[:, 4:7] - F["states"][:, 4:7]
+        out["vs_independent_qr_optimum"] = {"ate_m": float(np.sqrt(np.mean(np.sum(d * d, axis=1)))), "qr_final_cost": float(F["final_cost"]),
+                                            "started_from": "IMU dead reckoning, 15 m (ATE) from it"}
     eng.close()
     return out
 

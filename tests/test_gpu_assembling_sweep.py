@@ -188,6 +188,35 @@ def test_read_normal_assembles_on_demand():
     asm.close()
 
 
+def test_read_normal_of_windows_the_termination_rule_has_finished():
+    """... and with the termination rule on (vf_engine_set_convergence): after a solve every converged window has done = 1, and
+    K3 skips such windows during a solve.  A read of H must assemble them all the same -- Engine.pose_information, the
+    per-keyframe 6x6 blocks the degeneracy metrics run on (BASELINE configs[2]), is asked for exactly those.  The rows must be
+    those of the two-kernel engine (which wrote H on its last accepted trial) to the rounding of their states."""
+    n, B = 70, 4
+    seqs = [synth.make_sequence(seed=870 + i, n_kf=n + 2) for i in range(B)]
+    two, asm = _pair(seqs, n, 0)
+    for e in (two, asm):
+        e.set_convergence(1e-5, 1e-5)
+        e.iterate(40)
+    assert asm.solve_form() in ("assembling", "hybrid")
+    for w in range(B):
+        Ha, ga = two.read_normal(w, 0, n)
+        Hb, gb = asm.read_normal(w, 0, n)
+        assert np.abs(Hb).max() > 0 and np.abs(Hb[:, 0, :6, :6]).min(axis=(1, 2)).max() >= 0
+        assert np.abs(Ha - Hb).max() <= 1e-6 * np.abs(Ha).max(), w
+        Pa, Pb = two.pose_information(w, 0, n), asm.pose_information(w, 0, n)
+        assert np.abs(Pb).max() > 0 and np.abs(Pa - Pb).max() <= 1e-6 * np.abs(Pa).max()
+        # the read is repeatable and leaves the solve state alone
+        Hc, _ = asm.read_normal(w, 0, n)
+        np.testing.assert_array_equal(Hb, Hc)
+    lm0 = asm.read_lm(0)
+    asm.iterate(2)
+    assert asm.read_lm(0)["solve_failures"] == lm0["solve_failures"] == 0
+    two.close()
+    asm.close()
+
+
 def test_forms_that_need_H_fall_back_to_the_two_kernel_path():
     """Far between factors (their low-rank correction solves from H and g): an engine asked for the assembling sweep must run
     K3 + K4 there and give their bits.  The termination rule's hybrid solve: its partitioned half reads H, which K3 then

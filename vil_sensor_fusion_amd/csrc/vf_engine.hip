@@ -160,6 +160,32 @@ struct vf_engine {
     double* x_gtmp = nullptr;
     double* x_Z = nullptr;
     size_t x_zstride = 0;
+    int x_zslots = 0;          // slots x_Z holds columns for (6 columns each); grown on demand, never beyond VF_MAX_EXTRA
+    // the device lists are allocated once (they stay in `allocs`); a failure half way leaves what exists in place and a
+    // later call picks up from there (no second allocation, nothing leaked)
+    int *x_la = nullptr, *x_lb = nullptr;
+    double *x_li = nullptr, *x_lo = nullptr;
+    int ensure_far(int slots) {
+        const size_t B = (size_t)v.B, X = VF_MAX_EXTRA;
+        int rc;
+        if (!x_la) { if ((rc = alloc(&x_la, B * X, false))) return rc; HIPCHK(hipMemsetAsync(x_la, 0xff, B * X * sizeof(int), stream)); }
+        if (!x_lb) { if ((rc = alloc(&x_lb, B * X, false))) return rc; HIPCHK(hipMemsetAsync(x_lb, 0xff, B * X * sizeof(int), stream)); }
+        if (!x_li && (rc = alloc(&x_li, B * X * vf::BTW_IN))) return rc;
+        if (!x_lo && (rc = alloc(&x_lo, 2 * B * X * vf::BTW_OUT))) return rc;
+        x_zstride = (size_t)v.G * 15 + B + 64;
+        if (!x_gtmp) HIPCHK(hipMalloc((void**)&x_gtmp, x_zstride * sizeof(double)));
+        if (slots > x_zslots) {
+            // the solved columns of the low-rank correction: 6 increment-shaped columns per slot IN USE (one far factor in
+            // one window of a 1024 x 1088 batch engine is 0.8 GB, not the 6.4 GB that VF_MAX_EXTRA slots would be)
+            double* z = nullptr;
+            HIPCHK(hipStreamSynchronize(stream));
+            HIPCHK(hipMalloc((void**)&z, 6 * (size_t)slots * x_zstride * sizeof(double)));
+            if (x_Z) (void)hipFree(x_Z);
+            x_Z = z;
+            x_zslots = slots;
+        }
+        return VF_OK;
+    }
     // refined solve (vf_refine.hip): work vectors, allocated on first use; refine_open: a time-sharded caller is between
     // vf_engine_refine_begin and vf_engine_refine_end, and vf_engine_solve_local / _global work on (nres, z)
     vf::Refine rq{};
@@ -530,20 +556,14 @@ int vf_engine_set_extra_between(vf_engine* e, int window, int n, const int32_t* 
         if (a[i] < 0 || b[i] >= M || a[i] >= b[i]) return fail(VF_ERR_BAD_KEY, "far between factor %d: need 0 <= a < b < capacity (a=%d b=%d)", i, a[i], b[i]);
         if (!(rec[(size_t)i * vf::BTW_IN + 7] > 0.0)) return fail(VF_ERR_NOT_SPD, "far between factor %d: singular square-root information", i);
     }
+    if (e->v.x_max == 0 && n == 0) return VF_OK;
+    {
+        int need = n;                   // slots in use once this call is through
+        for (int w = 0; w < B && e->v.x_max; w++) if (w != window) need = std::max(need, e->h_xn[w]);
+        if ((rc = e->ensure_far(need))) return rc;
+    }
     if (e->v.x_max == 0) {
-        if (n == 0) return VF_OK;
-        // first use: the per-window lists and the scratch of the low-rank correction (6 X increment-shaped columns)
-        const size_t zs = (size_t)e->v.G * 15 + (size_t)B + 64;
-        int *xa = nullptr, *xb = nullptr;
-        double *xi = nullptr, *xo = nullptr;
-        if ((rc = e->alloc(&xa, (size_t)B * X, false)) || (rc = e->alloc(&xb, (size_t)B * X, false)) ||
-            (rc = e->alloc(&xi, (size_t)B * X * vf::BTW_IN)) || (rc = e->alloc(&xo, 2 * (size_t)B * X * vf::BTW_OUT))) return rc;
-        HIPCHK(hipMemsetAsync(xa, 0xff, (size_t)B * X * sizeof(int), e->stream));
-        HIPCHK(hipMemsetAsync(xb, 0xff, (size_t)B * X * sizeof(int), e->stream));
-        HIPCHK(hipMalloc((void**)&e->x_gtmp, zs * sizeof(double)));
-        HIPCHK(hipMalloc((void**)&e->x_Z, 6 * (size_t)X * zs * sizeof(double)));
-        e->x_zstride = zs;
-        e->v.x_a = xa; e->v.x_b = xb; e->v.x_in = xi; e->v.x_out = xo;
+        e->v.x_a = e->x_la; e->v.x_b = e->x_lb; e->v.x_in = e->x_li; e->v.x_out = e->x_lo;
         e->v.x_max = X;
         e->h_xn.assign(B, 0);
         e->h_xa.assign(B, {});
@@ -1481,10 +1501,9 @@ int vf_engine_read_normal(vf_engine* e, int window, int k0, int n, double* Hband
     if (n == 0) return VF_OK;
     const size_t g0 = (size_t)window * e->v.M + k0;
     if (assembles_in_solve(e) || assembles_in_hybrid(e)) {
-        // H and g are not kept by the solves of this engine: assemble them now, for every window (any value outside 0 .. 63
-        // in `fresh` means "the whole window"; nothing else reads the flag on such an engine)
-        HIPCHK(hipMemsetAsync(e->v.fresh, 1, (size_t)e->v.B * sizeof(int), e->stream));
-        vf::launch_assemble(e->v, e->stream);
+        // H and g are not kept by the solves of this engine: assemble them now, for this window only, whether or not the
+        // termination rule has finished it (a converged window's H is what Engine.pose_information is asked for)
+        vf::launch_assemble_window(e->v, window, e->stream);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(e->stream));

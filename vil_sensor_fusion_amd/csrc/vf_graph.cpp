@@ -83,7 +83,14 @@ struct vf_graph {
     // and handed to the engine as "far" factors (vf_engine_set_extra_between) at every solve.  band_end[k] != 0: key k
     // already carries a band factor.  far_new counts the ones added since the last solve (they are part of graph()->size()).
     std::vector<PendingBetween> far_between;
-    std::vector<uint8_t> band_end;
+    std::deque<uint8_t> band_end;      // entry i: key band_base + i (trimmed below the window at every solve)
+    uint64_t band_base = 0;
+    bool has_band_end(uint64_t k) const { return k >= band_base && k - band_base < band_end.size() && band_end[k - band_base]; }
+    void set_band_end(uint64_t k, uint8_t v) {
+        if (k < band_base) return;
+        if (k - band_base >= band_end.size()) { if (!v) return; band_end.resize(k - band_base + 1, 0); }
+        band_end[k - band_base] = v;
+    }
     int far_new = 0;
     bool far_on_device = false;    // the engine holds a non-empty far list (written under solve_mutex only)
     int staged_count = 3;  // the three priors (GraphManager.cpp:33-35)
@@ -329,7 +336,7 @@ int vf_add_between(vf_graph* g, uint64_t prev, uint64_t cur, const double q[4], 
     if (!sqrt_info_upper6(cov, b.rec + 7)) return gerr(VF_ERR_NOT_SPD, "between covariance is not symmetric positive definite");
     std::lock_guard<std::mutex> lk(g->graph_mutex);  // GraphManager.cpp:85
     if (prev >= cur || cur > g->current_key) return gerr(VF_ERR_BAD_KEY, "between factor keys (%llu, %llu) not reserved in order", (unsigned long long)prev, (unsigned long long)cur);
-    bool band = cur - prev <= VF_MAX_BANDWIDTH && !(cur < g->band_end.size() && g->band_end[cur]);
+    bool band = cur - prev <= VF_MAX_BANDWIDTH && !g->has_band_end(cur);
     for (const auto& s : g->staged_between)
         if (s.b == cur) band = false;
     if (band) {
@@ -372,7 +379,7 @@ int vf_solve(vf_graph* g) {
     std::vector<PendingBetween> betweens, fars;
     uint64_t last_key;
     double last_time;
-    int staged_before;
+    int staged_before, far_new_before = 0;
     bool late_far = false;          // a far factor added since the last solve whose older key had already left the window
     unsigned long long late_a = 0, late_b = 0;
     int late_n = 0;
@@ -381,10 +388,9 @@ int vf_solve(vf_graph* g) {
         std::lock_guard<std::mutex> lk(g->graph_mutex);
         imus.swap(g->imu_queue);
         betweens.swap(g->staged_between);
-        for (const auto& bt : betweens) {         // these keys now carry their band factor (a second one goes to the far list)
-            if (g->band_end.size() <= bt.b) g->band_end.resize(bt.b + 1, 0);
-            g->band_end[bt.b] = 1;
-        }
+        for (const auto& bt : betweens) g->set_band_end(bt.b, 1);   // these keys now carry their band factor (a second one goes to the far list)
+        // (keys below the window can never be named again by a factor that is accepted: their marks are let go)
+        while (!g->band_end.empty() && g->band_base < g->key_base + (uint64_t)g->lo) { g->band_end.pop_front(); g->band_base++; }
         // far factors whose older key has left the window (as of the previous solve: lo / key_base change under solve_mutex,
         // which this thread holds) are gone for good: their information is dropped, not marginalised.  One that was added
         // SINCE that solve never made it into the window: late odometry, reported like a late band factor below
@@ -400,6 +406,7 @@ int vf_solve(vf_graph* g) {
             fb.erase(std::remove_if(fb.begin(), fb.end(), [&](const PendingBetween& f) { return f.a < oldest; }), fb.end());
         }
         fars = g->far_between;
+        far_new_before = g->far_new - late_n;      // (the late ones have just been erased and are reported below)
         g->far_new = 0;
         staged_before = g->staged_count - late_n;
         g->staged_count = 0;  // _graph->resize(0)
@@ -413,7 +420,8 @@ int vf_solve(vf_graph* g) {
     // of the queues and the next vf_solve repeats them -- AFTER the state lock is released (requeue below), never
     // while it is held.  solve_mutex (taken first, by vf_solve only) keeps a second solver from snapshotting newer
     // entries between the failure and the give-back.
-    bool requeue = false;
+    bool requeue = false, late_band = false;
+    uint64_t late_band_key = 0;
     auto give_back = [&](int code) { requeue = true; return code; };
     auto locked = [&]() -> int {
     std::lock_guard<std::mutex> sl(g->state_mutex);  // :117
@@ -428,6 +436,8 @@ int vf_solve(vf_graph* g) {
         for (size_t i = 0; i < betweens.size(); i++)
             if (betweens[i].a < oldest) {
                 const unsigned long long a = betweens[i].a, b = betweens[i].b;
+                late_band_key = betweens[i].b;          // (its end key carries no band factor after all: requeue clears the mark)
+                late_band = true;
                 betweens.erase(betweens.begin() + (long)i);
                 staged_before--;
                 return give_back(gerr(VF_ERR_BAD_KEY, "between factor (%llu, %llu) dropped: key %llu left the fixed-lag window (oldest key %llu)",
@@ -554,6 +564,10 @@ int vf_solve(vf_graph* g) {
         for (auto it = imus.rbegin(); it != imus.rend(); ++it) g->imu_queue.push_front(std::move(*it));
         g->staged_between.insert(g->staged_between.begin(), betweens.begin(), betweens.end());
         g->staged_count += staged_before;
+        // the far factors added since the last successful solve are still "new" for the solve that repeats this one (its
+        // late-odometry test looks at the new ones only), and a band factor dropped as late leaves its end key free again
+        g->far_new += far_new_before;
+        if (late_band) g->set_band_end(late_band_key, 0);
     }
     return rc;
 }

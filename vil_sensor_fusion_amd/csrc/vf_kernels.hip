@@ -1085,7 +1085,7 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     // grid = (tiles per window, windows).  A rejected LM trial leaves the current linearisation, hence H and g,
     // unchanged (k_decide clears `fresh` on reject; accept / init / slide set it): such a tile must cost as little
     // as a launch can -- one flag read, no index arithmetic in front of it (an all-rejected batch used to take 0.73 ms)
-    const int w = blockIdx.y;
+    const int w = blockIdx.y + v.w_first;
     // (the window's scalars requested together, in front of the first test: one memory round trip, not three)
     // (hybrid solve of an engine whose sweep assembles its own rows: K3 works for the partitioned form only -- launched with
     // gate = 2, it returns while the sweep is the form in charge, and when it does run it cannot trust `fresh`: the trials the
@@ -3444,6 +3444,15 @@ void launch_assemble(const View& v, hipStream_t s) {
     // tile loop on 1024-2048 workgroups 4.0-4.3 ms, against 2.7 ms for one workgroup per tile -- stores count in vmcnt
     // on this ISA, so a loop waits for its own H stores before it can use the next tile's loads)
     hipLaunchKernelGGL(k_assemble, dim3((unsigned)(v.M / AT), (unsigned)v.B), dim3(K3_NT), 0, s, v);
+}
+void launch_assemble_window(const View& v, int window, hipStream_t s) {
+    // (gate = 2: K3 ignores `fresh`; stop_on = 0: a window the termination rule has finished is assembled too)
+    View a = v;
+    a.gate = 2;
+    a.gate_T = 1 << 30;          // ... and gated_off() lets a gate-2 launch run while n_active <= gate_T
+    a.stop_on = 0;
+    a.w_first = window;
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)(v.M / AT), 1u), dim3(K3_NT), 0, s, a);
 }
 void launch_partitioned_local(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_chunk_forward, dim3((unsigned)v.B * (unsigned)v.P), dim3(128), 0, s, v);

@@ -169,6 +169,7 @@ struct View {
     int* n_prov;        // [B] provisional trials over the life of the engine
     int* relin;         // [B] the current buffer was restored: linearise it again
     int relin_only;     // the linearisation kernels skip windows whose relin flag is clear
+    int w_first;        // K3 only: the first window of its grid (launch_assemble_window: H and g of ONE window on demand)
     // optional LM termination (off by default: every vf_engine_iterate runs its fixed number of trials).  With
     // stop_on, a window whose trial changes the cost by <= abs_tol, or by <= rel_tol relative to the cost
     // (gtsam::LevenbergMarquardtParams relativeErrorTol / absoluteErrorTol, checkConvergence; applied to
@@ -246,6 +247,7 @@ void launch_linearize_between_prior(const View& v, int which, hipStream_t s);   
 void launch_linearize_tail(const View& v, int nslid, hipStream_t s);   // warm start: factors of the appended keyframes + priors
 void launch_linearize_all(const View& v, int which, hipStream_t s);   // the three above in one launch (few windows)
 void launch_assemble(const View& v, hipStream_t s);
+void launch_assemble_window(const View& v, int window, hipStream_t s);   // H and g of one window, whatever its fresh / done flags say
 void launch_assemble_for_partitioned(const View& v, hipStream_t s);   // hybrid solves with an assembling sweep (asm_in_hybrid)
 void launch_band_solve(const View& v, hipStream_t s);
 void launch_count_active(const View& v, hipStream_t s);

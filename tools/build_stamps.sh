@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../vil_sensor_fusion_amd/csrc"
 mkdir -p build_stamps
-for f in vf_kernels vf_engine vf_degeneracy; do
+for f in vf_kernels vf_engine vf_degeneracy vf_refine; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -DVF_SOLVE_STAMPS -c $f.hip -o build_stamps/$f.o &
 done
 wait

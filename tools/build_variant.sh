@@ -11,6 +11,6 @@ mkdir -p $R/tools/variants
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -Wall -Wno-unused-function "$@" \
     -c $C/vf_kernels.hip -o $R/tools/variants/vf_kernels_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/variants/libvilfusion_$name.so \
-    $R/tools/variants/vf_kernels_$name.o $C/build/vf_engine.o $C/build/vf_degeneracy.o $C/build/vf_graph.o
+    $R/tools/variants/vf_kernels_$name.o $C/build/vf_engine.o $C/build/vf_degeneracy.o $C/build/vf_refine.o $C/build/vf_graph.o
 rm -f $R/tools/variants/vf_kernels_$name.o
 echo built $name

@@ -1286,6 +1286,8 @@ static_assert(AS_LJ % 2 == 0 && AS2_TOTAL * 8 <= 40960, "four assembling sweeps 
 constexpr int RING_SLOT = 664;
 constexpr int S_PROG = S_P + 4 * RING_SLOT;   // panels completed by the sweep
 constexpr int S_CONS = S_PROG + 1;            // panels consumed by the follower
+constexpr int S_RING_OUT = S_PROG + 2;        // != 0: a wait on the ring ran out (the chunk's solve is reported failed; later waits do not wait)
+constexpr int RING_SPIN_MAX = 1 << 22;        // polls (each an LDS read + s_sleep): seconds, against the microseconds a step takes
 constexpr int S_BC_RING = S_PROG + 8;
 constexpr int S_TOTAL_RING = S_BC_RING + 16;
 #ifndef VF_PIVOT_PERMLANE
@@ -2041,7 +2043,13 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         // sub-panel + rhs -> LDS (MFMA operands); rows 15..57 -> HBM, one 128-B line per lane
         if constexpr (RINGM) {
             // slot PH still holds the panel of step k-4: wait until the follower has read it
-            if (follower) while (lds_peek(S + S_CONS) < (double)(k - 3)) __builtin_amdgcn_s_sleep(1);
+            // (bounded, like every hand-shake of the two-wave sweep: a follower that never reports must end as a failed solve,
+            // not as a wave that spins until the GPU is reset)
+            if (follower) {
+                int spin = 0;
+                while (lds_peek(S + S_CONS) < (double)(k - 3) && lds_peek(S + S_RING_OUT) == 0.0 && ++spin < RING_SPIN_MAX) __builtin_amdgcn_s_sleep(1);
+                if (spin >= RING_SPIN_MAX) { failed = 1; if (lane == 0) S[S_RING_OUT] = 1.0; }
+            }
         }
 #pragma unroll
         for (int c = 0; c < 15; c++) S[pw_off + PH * RSLOT + c] = p[c];
@@ -2072,6 +2080,9 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
             int spin = 0;
             if (as_seen < (double)(k + 4))
                 while (lds_peek(S + AS_FLAGS + 1) < (double)(k + 4) && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+#ifdef VF_RING_WITHHOLD     // fault-injection build only (tools/variants/libvilfusion_withhold.so): window 1's eliminator is told, once,
+            if (w == 1 && k == 8) spin = 1 << 22;          // that its assembler never answered
+#endif
             if (spin >= (1 << 22)) failed = 1;
             if (((lo + k + 6) & (JT - 1)) == 0) {      // factor k + 6 opens a new tile, and the assembler has read the last operands of the old one
                 as_tile_commit(anx.k0_next, anx);
@@ -2531,7 +2542,19 @@ __device__ __forceinline__ void chunk_spike(const View& v, double* S, int w, int
     }
 #pragma unroll 1
     for (int k = 0; k < cg.ni; k++) {
-        while (lds_peek(S + S_PROG) < (double)(k + 1)) __builtin_amdgcn_s_sleep(1);
+        {
+            int spin = 0;
+#ifdef VF_RING_WITHHOLD     // stamp / fault-injection build only: the follower of chunk 1 of window 0 never sees its producer
+            if (w == 0 && c == 1) spin = RING_SPIN_MAX;
+            else
+#endif
+            while (lds_peek(S + S_PROG) < (double)(k + 1) && lds_peek(S + S_RING_OUT) == 0.0 && ++spin < RING_SPIN_MAX) __builtin_amdgcn_s_sleep(1);
+            if (spin >= RING_SPIN_MAX) {
+                // the producer never published panel k: this chunk's solve is reported failed (k_decide rejects the trial, the
+                // window's other chunks and every other window are untouched); from here on neither wave waits for the other
+                if (lane == 0) { S[S_RING_OUT] = 1.0; atomicOr(v.fail + w, 1); }
+            }
+        }
         const double* Pk = S + S_P + (k & 3) * RING_SLOT;
         double linv[4], x1[4], x23[4], yv[4];
 #pragma unroll
@@ -2632,6 +2655,7 @@ __global__ void __launch_bounds__(128) k_chunk_forward(View v) {
     if (threadIdx.x < 4) S[S_P + threadIdx.x * RING_SLOT + 645] = 0.0;   // zero cell of every ring slot
     if (threadIdx.x == 4) S[S_PROG] = 0.0;
     if (threadIdx.x == 5) S[S_CONS] = 0.0;
+    if (threadIdx.x == 6) S[S_RING_OUT] = 0.0;
     __syncthreads();
     if (wave == 0) band_solve_body<SOLVE_CHUNK_FWD>(v, S, nullptr, nullptr, w, lane, 0, cg, v.sepR + ((size_t)c * v.B + w) * SEPK);
     else if (c > 0) chunk_spike(v, S, w, c, cg, lane);

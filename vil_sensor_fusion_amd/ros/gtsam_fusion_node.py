@@ -12,7 +12,8 @@ relinearises all of it, so a solve gets slower as the bag gets longer -- a node 
 solver/capacity (default lag + 192, or 4096 initial slots when lag = 0), solver/iterations, solver/rel_tol and
 solver/abs_tol (LM termination, default 1e-5 / 1e-5 = gtsam's LevenbergMarquardtParams; 0 / 0 = always `iterations` trials),
 solver/device, solver/initial_state (16 doubles q t v bias: the anchor X(0), V(0), B(0) and the means of their priors; default =
-the reference's identity / at rest, GraphManager.cpp:20-35), reference_compat (poseDiff quirk).
+the reference's identity / at rest, GraphManager.cpp:20-35), reference_compat (poseDiff quirk), noise_order_compat
+(constant-covariance order quirk; both default to true = what the reference does).
 NOTE the default solver/lag = 1000 is a deviation: the reference smooths an unbounded iSAM2 graph (= solver/lag 0 here).
 
 Threading: roscpp's ros::spin() runs every callback of the reference node on ONE thread (gtsam_fusion_node.cpp:101).
@@ -35,7 +36,9 @@ from ..sensor_manager import Odometry, SensorManager
 def odometry_from_msg(m) -> Odometry:
     """nav_msgs/Odometry -> the fields the reference reads (SensorManagerRos.cpp:122-158)"""
     p, q = m.pose.pose.position, m.pose.pose.orientation
-    return Odometry(m.header.stamp.to_sec(), [p.x, p.y, p.z], [q.w, q.x, q.y, q.z], list(m.twist.covariance))
+    st = m.header.stamp
+    ns = int(st.secs) * 10 ** 9 + int(st.nsecs) if hasattr(st, "secs") and hasattr(st, "nsecs") else None
+    return Odometry(st.to_sec(), [p.x, p.y, p.z], [q.w, q.x, q.y, q.z], list(m.twist.covariance), stamp_ns=ns)
 
 
 class FusionNode:
@@ -62,6 +65,7 @@ class FusionNode:
         self.subs = [rospy.Subscriber(P("imu/topic"), msgs.Imu, queue_size=100, callback=self._serialised(self.imu_callback))]   # ImuManagerRos.cpp:11
         self.sensor_managers = {}
         compat = bool(P("reference_compat", True))
+        noise_compat = bool(P("noise_order_compat", True))      # SURVEY 3.5-2 (sensor_manager.SensorManager.noise_order_compat)
         for name, cfg in sorted(P("sensors").items()):                                   # gtsam_fusion_node.cpp:32-56
             kind = cfg.get("sensor_type")
             if kind not in ("PointCloud2", "Image"):
@@ -76,7 +80,7 @@ class FusionNode:
             sm = SensorManager(self.graph, bool(cfg["optimize_after_odom"]), use_cov,
                                0.0 if use_cov else float(cfg["covariance_linear"]),      # SensorManagerRos.h:50-54
                                0.0 if use_cov else float(cfg["covariance_angular"]),
-                               float(cfg.get("max_time_skip", float("inf"))), reference_compat=compat)
+                               float(cfg.get("max_time_skip", float("inf"))), reference_compat=compat, noise_order_compat=noise_compat)
             self.sensor_managers[name] = sm
             msg_type = msgs.PointCloud2 if kind == "PointCloud2" else msgs.Image
             self.subs.append(rospy.Subscriber(cfg["sensor_topic"], msg_type, queue_size=1,                    # SensorManagerRos.h:59

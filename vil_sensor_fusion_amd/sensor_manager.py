@@ -28,11 +28,22 @@ def _qrot(q, v):
     return _qmul(_qmul(q, np.concatenate([[0.0], v])), _qinv(q))[1:]
 
 
-class Odometry:
-    """The fields of nav_msgs/Odometry the reference reads."""
+def ros_duration_sec(later_ns: int, earlier_ns: int) -> float:
+    """(later - earlier).toSec() as roscpp computes it: the difference of two ros::Time is a ros::Duration in INTEGER
+    (sec, nsec), and toSec() = sec + 1e-9 * nsec (rostime duration.h).  Matters at the boundary: stamps exactly 0.1 s apart
+    give exactly the double 0.1, and `0.1 < max_time_skip` with the YAML's 0.1 is false (SensorManagerRos.cpp:47)."""
+    d = int(later_ns) - int(earlier_ns)
+    sec, nsec = divmod(d, 10 ** 9)
+    return float(sec) + 1e-9 * float(nsec)
 
-    def __init__(self, stamp, position, orientation_wxyz, twist_covariance=None):
+
+class Odometry:
+    """The fields of nav_msgs/Odometry the reference reads.  stamp_ns: header.stamp as integer nanoseconds (what ros::Time
+    holds); when absent it is the float stamp rounded to the nanosecond (exact for simulated time, not for epoch stamps)."""
+
+    def __init__(self, stamp, position, orientation_wxyz, twist_covariance=None, stamp_ns=None):
         self.stamp = float(stamp)
+        self.stamp_ns = int(round(self.stamp * 1e9)) if stamp_ns is None else int(stamp_ns)
         self.position = np.asarray(position, dtype=np.float64)
         self.orientation = np.asarray(orientation_wxyz, dtype=np.float64)
         self.twist_covariance = None if twist_covariance is None else np.asarray(twist_covariance, dtype=np.float64).reshape(6, 6)
@@ -40,7 +51,8 @@ class Odometry:
 
 class SensorManager:
     def __init__(self, graph_manager, optimize_after_odom, use_odom_covariance=False,
-                 covariance_linear=0.1, covariance_angular=0.1, max_time_skip=0.1, reference_compat=True):
+                 covariance_linear=0.1, covariance_angular=0.1, max_time_skip=0.1, reference_compat=True,
+                 noise_order_compat=True):
         self.gm = graph_manager
         self.optimize_after_odom = optimize_after_odom
         self.use_odom_covariance = use_odom_covariance
@@ -48,6 +60,12 @@ class SensorManager:
         self.covariance_angular = covariance_angular
         self.max_time_skip = max_time_skip
         self.reference_compat = reference_compat
+        # the reference fills the constant covariance [lin, lin, lin, ang, ang, ang] (SensorManagerRos.cpp:91-97)
+        # and hands it to a factor whose tangent order is [rot, trans]: the rotation gets covariance_linear, the translation
+        # covariance_angular.  True reproduces that (benign in config/carla: 0.2 / 0.2, 0.1 / 0.1; not in config/san_rafael:
+        # 1e-6 / 1e-7, 1e-3 / 1e-4); False puts each where its name says.
+        self.noise_order_compat = noise_order_compat
+        self.skipped = []            # (previous stamp, stamp) of consecutive odometry messages the max_time_skip test refused
         self.keys_and_times = deque()
         self.last_valid_odom = None
         self.last_valid_key = None
@@ -73,11 +91,11 @@ class SensorManager:
         return qr, dxr, after.twist_covariance
 
     def _add_between(self, a, b, pose, cov):
-        """addBetweenFactor, failing soft where the device's band is narrower than iSAM2's arbitrary topology
-        (GraphManager.cpp:83-88 takes any pair of keys; libvilfusion takes |b - a| <= 3 keyframes and one factor per end
-        key -- INTEGRATION.md "Topology limits").  With Carla's max_time_skip = 0.1 s (20 Hz camera + 10 Hz LiDAR keyframes)
-        no factor the reference would add is wider; without it (config/san_rafael has no max_time_skip) an odometry gap
-        produces one, which is dropped here like a missed odometry message (:41-45 warns and carries on the same way)."""
+        """addBetweenFactor, failing soft where the library cannot take a factor iSAM2 would (GraphManager.cpp:83-88 takes any
+        pair of keys).  The library takes any pair too -- a span wider than 3 keyframes or a second factor on an end key
+        becomes a "far" factor (vf_engine_set_extra_between) -- but holds at most VF_MAX_EXTRA = 8 of those per window
+        (INTEGRATION.md "Limits"): the ninth comes back as VF_ERR_CAPACITY and is dropped here like a missed odometry
+        message (:41-45 warns and carries on the same way)."""
         from ._lib import VilFusionError
         try:
             self.gm.addBetweenFactor(a, b, pose, cov)
@@ -105,12 +123,19 @@ class SensorManager:
             self.warnings.append(f"odometry at {msg.stamp} has no corresponding key")   # :41-45
             return False
         added = False
-        if self.last_valid_odom is not None and (msg.stamp - self.last_valid_odom.stamp) < self.max_time_skip:
+        # :47 -- strict "<" on a ros::Duration: a 10 Hz source with exact stamps and the YAML's max_time_skip = 0.1
+        # (config/carla/fusion_params.yaml:10) never passes it
+        within = self.last_valid_odom is not None and ros_duration_sec(msg.stamp_ns, self.last_valid_odom.stamp_ns) < self.max_time_skip
+        if self.last_valid_odom is not None and not within:
+            self.skipped.append((self.last_valid_odom.stamp, msg.stamp))
+        if within:
             q, t, tw = self.poseDiff(self.last_valid_odom, msg)
             if self.use_odom_covariance:
                 cov_ros = tw.T.copy()       # std::copy into a column-major Matrix66 (:87)
-            else:                           # :91-97, filled [lin,lin,lin,ang,ang,ang] as the reference does
+            elif self.noise_order_compat:   # :91-97, filled [lin,lin,lin,ang,ang,ang] as the reference does
                 cov_ros = np.diag([self.covariance_linear] * 3 + [self.covariance_angular] * 3)
+            else:                           # Pose3 tangent order [rot, trans]
+                cov_ros = np.diag([self.covariance_angular] * 3 + [self.covariance_linear] * 3)
             added = self._add_between(self.last_valid_key, found[1], (q, t), cov_ros)
             if added and self.optimize_after_odom:
                 self.gm.solve()

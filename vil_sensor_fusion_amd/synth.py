@@ -185,7 +185,8 @@ class Sequence:
 TUNNEL_NOMINAL_EIG = 4.0e4     # scan-matching information per direction: log det of a 3x3 block = 31.8 > 28.9
 
 
-def make_sequence(seed: int, n_kf: int, vio: bool = True, lidar: bool = True, tunnel=None, keep_raw: bool = False) -> Sequence:
+def make_sequence(seed: int, n_kf: int, vio: bool = True, lidar: bool = True, tunnel=None, keep_raw: bool = False,
+                  odom_noise=None) -> Sequence:
     """n_kf keyframes interleaving camera (20 Hz) and LiDAR (10 Hz) stamps; keyframe 0 is the
     anchor (the reference's prior node X(0), GraphManager.cpp:20-35).
 
@@ -194,7 +195,12 @@ def make_sequence(seed: int, n_kf: int, vio: bool = True, lidar: bool = True, tu
     direction is `scale` x nominal (the measurement noise there grows accordingly), and the per-scan 6x6
     scan-matching Hessians (`loam_hessians`, what loam::OptStatus.hessian carries to the degeneracy filter,
     degerate_odometry_filter.cpp:29-47) lose the same factor in their along-track eigenvalue -- the tunnel stretch
-    of the reference's Carla evaluation (DEGEN_TRANS, make_prettier_graphs.py:81-84)."""
+    of the reference's Carla evaluation (DEGEN_TRANS, make_prettier_graphs.py:81-84).
+
+    odom_noise = ((vio_rot, vio_trans), (lidar_rot, lidar_trans)): 1-sigma of the simulated odometry increments instead of
+    VIO_NOISE / LIDAR_NOISE (a replay of config/san_rafael, whose factor covariances are 1e-3 ... 1e-7, uses odometry as
+    good as those covariances claim)."""
+    vio_noise, lidar_noise = odom_noise if odom_noise is not None else (VIO_NOISE, LIDAR_NOISE)
     horizon = n_kf * LIDAR_DT + 1.0      # enough stamps whichever sources are enabled
     cam = np.arange(0, int(horizon / CAM_DT) + 1) * CAM_DT
     lid = np.arange(0, int(horizon / LIDAR_DT) + 1) * LIDAR_DT + LIDAR_PHASE
@@ -226,7 +232,7 @@ def make_sequence(seed: int, n_kf: int, vio: bool = True, lidar: bool = True, tu
         f0, f1, t_scale = tunnel
         in_tunnel[int(f0 * n_kf):int(f1 * n_kf)] = True
     ba, bb, bq, bt, bc, bi = [], [], [], [], [], []
-    for sid, (nr, nt), cov in ((0, VIO_NOISE, VIO_COV), (1, LIDAR_NOISE, LIDAR_COV)):
+    for sid, (nr, nt), cov in ((0, vio_noise, VIO_COV), (1, lidar_noise, LIDAR_COV)):
         idx = np.nonzero(sensor == sid)[0]
         for a, b in zip(idx[:-1], idx[1:]):
             info = np.ones(6)

@@ -128,6 +128,17 @@ typedef struct {
      * is restored, lambda multiplied by lambda_up, and the trials count as rejected.  0 = the classical rule; -1
      * (default) = 3 on engines that refine (windows longer than refine_min_keyframes), 0 otherwise. */
     int lm_excursion;
+    /* Gauge floor of the fixed-lag marginal prior (vf_engine_marginalize / vf_engine_slide(marginalize = 1); no reference code:
+     * the reference's iSAM2 graph never marginalises).  Every factor of a window is invariant under a global translation and
+     * a rotation about gravity; what the window knows about those four directions is carried by the marginal prior alone --
+     * the memory of the anchor prior (GraphManager.cpp:27-35), which decays with every marginalisation (measured on a
+     * 200-keyframe window: 2e-3, 1e-4, 1e-5, 8e-7 after 100, 500, 1 000, 2 000 updates) until it is below the float64 rounding
+     * of the 1e9-scale entries beside it: H becomes indefinite, LM trials are rejected at random (2 000+ updates), then solves
+     * fail (3 500 updates of 1 000-keyframe windows; profiles/r05_soak_*).  Eigenvalues of that 4 x 4 information that have
+     * fallen below gauge_floor are lifted back to it at every marginalisation.  Default 1e-3 = a 30 m sigma on WHERE the window
+     * is: it constrains nothing the factors can see, and a prior whose gauge information is still above it (the first
+     * ~150 updates) is not touched, bit for bit.  0 = off. */
+    double gauge_floor;
 } vf_engine_opts;
 
 void vf_engine_default_opts(vf_engine_opts* o);
@@ -251,6 +262,19 @@ int vf_engine_refine_step(vf_engine* e);
 int vf_engine_refine_end(vf_engine* e);
 /* corrections the last refined solve of `window` applied, and res . M^-1 res at its end relative to its first value */
 int vf_engine_read_refine(vf_engine* e, int window, int* corrections, double* reduction);
+
+/* The same from C (RCCL): the library issues the collectives itself, on the engine's stream, through the communicator the
+ * caller hands in -- an ncclComm_t created by the caller (ncclCommInitRank: one rank per GPU), passed as void* so that this
+ * header needs no RCCL header.  librccl is looked up with dlopen when one of these is first called: the library has no
+ * link-time communication dependency.  vf_shard_iterate = vf_engine_iterate for a time-sharded engine (every rank calls it
+ * with the same arguments; 2 x (1 + refinement corrections) collectives per LM trial); vf_shard_gn_step = vf_engine_isam_step.
+ * vf_shard_exchange_plan (host only): what a rank sends -- its slice [sep_offset, sep_offset + sep_count) of the sep buffer
+ * of sep_total doubles, all-gathered in place, and delta_count doubles all-reduced -- for callers that bring another
+ * transport (vil_sensor_fusion_amd/distributed.py exchanges the same ranges through torch.distributed). */
+int vf_shard_iterate(vf_engine* e, void* nccl_comm, int iterations);
+int vf_shard_gn_step(vf_engine* e, void* nccl_comm, double relin_threshold);
+int vf_shard_exchange_plan(int windows, int capacity, int chunks, int rank, int world, long* sep_offset, long* sep_count,
+                           long* sep_total, long* delta_count);
 
 /* Reference-compat solve: what the reference computes per GraphManager::solve (GraphManager.cpp:38-43,126-127) -- ONE
  * iSAM2-like update: keyframes whose pending increment reaches relin_threshold in any component (ISAM2Params::

@@ -60,6 +60,7 @@ class Problem(C.Structure):
                 ("gravity", C.c_double * 3), ("marg", C.POINTER(Marg))]
 
 
+GAUGE_FLOOR = 1e-3   # default of vf_engine_opts.gauge_floor
 ACCEPT_REL = 1e-9    # default accept tolerance of vfo_lm = vf_engine_opts.accept_rel's default (include/vilfusion.h).  A constant:
 #                      callers that want another rule pass accept_rel to Window.lm / FixedLagOracle, nobody assigns to this name
 
@@ -301,10 +302,11 @@ class Window:
         self.marg = marg
         self.c.marg = C.pointer(marg) if marg is not None else None
 
-    def marginalize(self, m=0):
-        """Schur complement of every factor touching keyframe m onto [m+1:15][m+2:pose][m+3:pose]."""
+    def marginalize(self, m=0, gauge_floor=0.0):
+        """Schur complement of every factor touching keyframe m onto [m+1:15][m+2:pose][m+3:pose]; gauge_floor:
+        vf_engine_opts.gauge_floor (the engine's default is GAUGE_FLOOR, the oracle does what it is told)."""
         out = Marg()
-        rc = lib().vfo_marginalize(C.byref(self.c), C.c_int(m), C.byref(out))
+        rc = lib().vfo_marginalize_floor(C.byref(self.c), C.c_int(m), C.c_double(gauge_floor), C.byref(out))
         if rc != 0:
             raise np.linalg.LinAlgError("marginalisation failed")
         return out

@@ -24,6 +24,7 @@
 #include <string.h>
 
 static double marg_cost(const vfo_marg* m, const double* states, double* grad);
+int vfo_marginalize_floor(const vfo_problem* p, int m, double gauge_floor, vfo_marg* out);
 
 /* ------------------------------------------------------------------ small dense helpers */
 
@@ -1005,7 +1006,107 @@ double vfo_assemble(const vfo_problem* p, int w, double* Hband, double* g, int n
     return cost;
 }
 
-int vfo_marginalize(const vfo_problem* p, int m, vfo_marg* out) {
+/* Gauge floor of a marginal prior (vf_engine_opts.gauge_floor; k_marginalize does the same arithmetic).  Every factor of the
+ * window is invariant under a global translation and a rotation about gravity: what the window knows about those four
+ * directions is G^T L G of its marginal prior alone -- the memory of the anchor prior, which decays with every
+ * marginalisation (measured: 2e-3, 1e-4, 1e-5, 8e-7 after 100, 500, 1000, 2000 updates of a 200-keyframe window) until it is
+ * below the rounding of the 1e9-scale entries beside it; from there H is indefinite in float64, trials are rejected at
+ * random and after ~3 000 updates solves fail.  The floor lifts the eigenvalues of G^T L G that have fallen below `floor` back
+ * to it: information 1e-3 = a 30 m sigma on WHERE the window is, which constrains nothing the factors can see.  Prior
+ * means are untouched (the term has zero gradient at the linearisation point, d = 0). */
+static void jacobi4(double M[16], double V[16]) {
+    for (int i = 0; i < 16; i++) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 10; sweep++)
+        for (int p = 0; p < 3; p++)
+            for (int q = p + 1; q < 4; q++) {
+                const double apq = M[p * 4 + q];
+                if (apq == 0.0) continue;
+                const double theta = (M[q * 4 + q] - M[p * 4 + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 4; k++) {          /* columns p, q of M and of V */
+                    const double mkp = M[k * 4 + p], mkq = M[k * 4 + q];
+                    M[k * 4 + p] = c * mkp - sn * mkq;
+                    M[k * 4 + q] = sn * mkp + c * mkq;
+                    const double vkp = V[k * 4 + p], vkq = V[k * 4 + q];
+                    V[k * 4 + p] = c * vkp - sn * vkq;
+                    V[k * 4 + q] = sn * vkp + c * vkq;
+                }
+                for (int k = 0; k < 4; k++) {          /* rows p, q of M */
+                    const double mpk = M[p * 4 + k], mqk = M[q * 4 + k];
+                    M[p * 4 + k] = c * mpk - sn * mqk;
+                    M[q * 4 + k] = sn * mpk + c * mqk;
+                }
+            }
+}
+static void gauge_floor_apply(vfo_marg* mg, const double gravity[3], double floor) {
+    if (!(floor > 0.0)) return;
+    double G[27 * 4];
+    memset(G, 0, sizeof(G));
+    double gn = sqrt(dot3(gravity, gravity)), ez[3] = {0, 0, 1};
+    if (gn > 0.0) for (int i = 0; i < 3; i++) ez[i] = -gravity[i] / gn;       /* "up" */
+    const double* x0 = mg->xbar;
+    for (int j = 0; j < 3; j++) {
+        const double* x = mg->xbar + 16 * j;
+        double R[9], dt[3] = {x[4] - x0[4], x[5] - x0[5], x[6] - x0[6]}, lever[3];
+        vfo_quat_to_rot(x, R);
+        cross3(ez, dt, lever);
+        const int o = j == 0 ? 0 : 15 + 6 * (j - 1);
+        for (int c = 0; c < 3; c++) {
+            for (int a = 0; a < 3; a++) G[(o + 3 + c) * 4 + a] = R[a * 3 + c];                 /* translation along world axis a: R^T e_a */
+            G[(o + c) * 4 + 3] = R[0 * 3 + c] * ez[0] + R[1 * 3 + c] * ez[1] + R[2 * 3 + c] * ez[2];   /* yaw: R^T e_z */
+            G[(o + 3 + c) * 4 + 3] = R[0 * 3 + c] * lever[0] + R[1 * 3 + c] * lever[1] + R[2 * 3 + c] * lever[2];
+        }
+        if (j == 0) {
+            double vy[3];
+            cross3(ez, x + 7, vy);                                                            /* world-frame velocity turns with the yaw */
+            for (int c = 0; c < 3; c++) G[(6 + c) * 4 + 3] = vy[c];
+        }
+    }
+    for (int a = 0; a < 4; a++) {                       /* modified Gram-Schmidt */
+        for (int b = 0; b < a; b++) {
+            double s = 0.0;
+            for (int i = 0; i < 27; i++) s += G[i * 4 + a] * G[i * 4 + b];
+            for (int i = 0; i < 27; i++) G[i * 4 + a] -= s * G[i * 4 + b];
+        }
+        double nn = 0.0;
+        for (int i = 0; i < 27; i++) nn += G[i * 4 + a] * G[i * 4 + a];
+        nn = sqrt(nn);
+        for (int i = 0; i < 27; i++) G[i * 4 + a] /= nn;
+    }
+    double T[27 * 4], M[16], V[16];
+    for (int i = 0; i < 27; i++)
+        for (int a = 0; a < 4; a++) {
+            double s = 0.0;
+            for (int j = 0; j < 27; j++) s += 0.5 * (mg->L[i * 27 + j] + mg->L[j * 27 + i]) * G[j * 4 + a];
+            T[i * 4 + a] = s;
+        }
+    for (int a = 0; a < 4; a++)
+        for (int b = 0; b < 4; b++) {
+            double s = 0.0;
+            for (int i = 0; i < 27; i++) s += G[i * 4 + a] * T[i * 4 + b];
+            M[a * 4 + b] = s;
+        }
+    for (int a = 0; a < 4; a++)
+        for (int b = a + 1; b < 4; b++) M[a * 4 + b] = M[b * 4 + a] = 0.5 * (M[a * 4 + b] + M[b * 4 + a]);
+    jacobi4(M, V);
+    for (int e = 0; e < 4; e++) {
+        const double lift = floor - M[e * 4 + e];
+        if (!(lift > 0.0)) continue;
+        double q[27];
+        for (int i = 0; i < 27; i++) {
+            double s = 0.0;
+            for (int a = 0; a < 4; a++) s += G[i * 4 + a] * V[a * 4 + e];
+            q[i] = s;
+        }
+        for (int i = 0; i < 27; i++)
+            for (int j = 0; j < 27; j++) mg->L[i * 27 + j] += lift * q[i] * q[j];
+    }
+}
+
+int vfo_marginalize(const vfo_problem* p, int m, vfo_marg* out) { return vfo_marginalize_floor(p, m, 0.0, out); }
+
+int vfo_marginalize_floor(const vfo_problem* p, int m, double gauge_floor, vfo_marg* out) {
     /* variables [m:15][m+1:15][m+2 pose:6][m+3 pose:6] = 42; only factors touching m */
     double A[42 * 42], b[42];
     memset(A, 0, sizeof(A));
@@ -1117,6 +1218,9 @@ int vfo_marginalize(const vfo_problem* p, int m, vfo_marg* out) {
     }
     /* the 27 kept dofs are [m+1: 15][m+2 pose][m+3 pose]: exactly rows 15..41 of the 42-vector */
     memcpy(out->xbar, p->states + 16 * (m + 1), sizeof(double) * 48);
+    for (int i = 0; i < 27; i++)             /* (the device stores the symmetric part) */
+        for (int j = i + 1; j < 27; j++) out->L[i * 27 + j] = out->L[j * 27 + i] = 0.5 * (out->L[i * 27 + j] + out->L[j * 27 + i]);
+    gauge_floor_apply(out, p->gravity, gauge_floor);
     return 0;
 }
 

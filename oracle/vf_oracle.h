@@ -163,6 +163,9 @@ void vfo_marg_delta(const vfo_marg* m, const double* states, double d[27]);
  * touching m (its prior / marginal prior, imu factor m -> m+1, between factors starting at m),
  * linearised at the current states, onto [m+1: 15][m+2: pose][m+3: pose]. out->k0 = m+1. */
 int vfo_marginalize(const vfo_problem* p, int m, vfo_marg* out);
+/* ... with the gauge floor of vf_engine_opts.gauge_floor (0 = none): eigenvalues of the prior's information about the window's
+ * global translation and yaw that have decayed below `gauge_floor` are lifted back to it */
+int vfo_marginalize_floor(const vfo_problem* p, int m, double gauge_floor, vfo_marg* out);
 
 #ifdef __cplusplus
 }

@@ -87,7 +87,7 @@ class FixedLagOracle:
     prob: helpers.build_problem(...) of a sequence with at least n + updates keyframes (its `states` beyond the first
     window are ignored: appended keyframes are predicted from the running estimate, as the engine does)."""
 
-    def __init__(self, oracle, prob, n, iterations, threads=1, init_iterations=None, accept_rel=None, ingest=None, refine=0):
+    def __init__(self, oracle, prob, n, iterations, threads=1, init_iterations=None, accept_rel=None, ingest=None, refine=0, gauge_floor=None):
         """init_iterations: LM trials of the initial solve (default: `iterations`).  A 1000-pose window started from
         IMU dead reckoning needs 50-150 trials to converge; slid while still far from its optimum it stays in a regime
         where two float64 implementations drift apart by 1e-5 m (DESIGN.md "Converged start")."""
@@ -97,6 +97,7 @@ class FixedLagOracle:
         # GraphManager::reserveNode does (GraphManager.cpp:59) and as vf_engine_ingest_tail does on the device
         self.ingest = ingest
         self.accept_rel = accept_rel                 # None: the oracle's default (= the engine's); 0: strict decrease
+        self.gauge_floor = oracle.GAUGE_FLOOR if gauge_floor is None else gauge_floor     # vf_engine_opts.gauge_floor (None: its default)
         self.refine = refine                         # > 0: every solve refined through J (vf_engine_opts.refine_iterations)
         self.rel_tol = self.abs_tol = 0.0            # > 0: GTSAM's LM termination rule in the updates that follow
         self.states = prob["states"].copy()
@@ -121,7 +122,7 @@ class FixedLagOracle:
     def update(self):
         """one fixed-lag update; returns the window's states afterwards (keyframes [s, s + n))"""
         p, n = self.prob, self.n
-        self.marg = self.win.marginalize(0)          # (self.win still holds the previous window, its prior / marginal prior attached)
+        self.marg = self.win.marginalize(0, self.gauge_floor)   # (self.win still holds the previous window, its prior / marginal prior attached)
         self.marg.k0 = 0
         self.s += 1
         s = self.s

@@ -71,7 +71,7 @@ class GraphOracle:
         self.states[k] = self.o.predict(rec190, self.g, self.states[k - 1])
         self.hi += 1
         if self.hi - self.s > self.lag and self.solved - self.s >= 3:
-            self.marg = self.win.marginalize(0)          # (one keyframe per solve: at most one leaves)
+            self.marg = self.win.marginalize(0, self.o.GAUGE_FLOOR)          # (one keyframe per solve: at most one leaves)
             self.marg.k0 = 0
             self.s += 1
             assert self.hi - self.s <= self.lag

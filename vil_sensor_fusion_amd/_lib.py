@@ -25,7 +25,7 @@ class EngineOptsC(C.Structure):
                 ("lambda_min", C.c_double), ("lambda_max", C.c_double), ("chunks", C.c_int),
                 ("sweep_two_sided_max", C.c_int), ("hybrid_threshold", C.c_int), ("cold_start", C.c_int),
                 ("use_hip_graph", C.c_int), ("accept_rel", C.c_double), ("solve_split_min", C.c_int), ("solve_assemble_min", C.c_int), ("solve_assemble_waves", C.c_int),
-                ("refine_iterations", C.c_int), ("refine_min_keyframes", C.c_int), ("refine_rel_stop", C.c_double), ("lm_excursion", C.c_int)]
+                ("refine_iterations", C.c_int), ("refine_min_keyframes", C.c_int), ("refine_rel_stop", C.c_double), ("lm_excursion", C.c_int), ("gauge_floor", C.c_double)]
 
 
 class ImuParamsC(C.Structure):
@@ -69,7 +69,7 @@ SYMBOLS = [
     "vf_engine_set_stream", "vf_engine_set_shard", "vf_engine_shard_info", "vf_engine_solve_local",
     "vf_engine_solve_global", "vf_engine_reset_lambda",
     "vf_engine_refine_count", "vf_engine_refine_begin", "vf_engine_refine_step", "vf_engine_refine_end", "vf_engine_read_refine",
-    "vf_engine_gn_begin", "vf_engine_read_excursions", "vf_engine_close_excursions",
+    "vf_engine_gn_begin", "vf_shard_iterate", "vf_shard_gn_step", "vf_shard_exchange_plan", "vf_engine_read_excursions", "vf_engine_close_excursions",
     "vf_chunk_geometry", "vf_shard_range", "vf_engine_set_convergence",
     "vf_engine_isam_step", "vf_engine_predict_from_estimate", "vf_engine_get_estimate",
     "vf_graph_default_opts", "vf_create", "vf_destroy", "vf_add_imu", "vf_reserve_node",

@@ -13,6 +13,8 @@
 #include <utility>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "../../include/vilfusion.h"
 #include "vf_kernels.hpp"
 
@@ -277,6 +279,7 @@ void vf_engine_default_opts(vf_engine_opts* o) {
     o->refine_min_keyframes = 2048;
     o->refine_rel_stop = 1e-13;
     o->lm_excursion = -1;            // auto: 3 on engines that refine, classical LM otherwise
+    o->gauge_floor = 1e-3;
 }
 
 int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
@@ -287,6 +290,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     if (o->chunks < 0 || o->chunks > 4096) return fail(VF_ERR_INVALID, "chunks must be in 0..4096");
     if (!(o->accept_rel >= 0.0) || !(o->accept_rel < 1.0)) return fail(VF_ERR_INVALID, "accept_rel must be in [0, 1)");
     if (o->refine_iterations < -1 || o->refine_iterations > 64) return fail(VF_ERR_INVALID, "refine_iterations must be in -1..64");
+    if (!(o->gauge_floor >= 0.0) || !(o->gauge_floor < 1e6)) return fail(VF_ERR_INVALID, "gauge_floor must be in [0, 1e6)");
     if (o->lm_excursion < -1 || o->lm_excursion > 16) return fail(VF_ERR_INVALID, "lm_excursion must be in -1..16");
     if (!(o->refine_rel_stop >= 0.0) || !(o->refine_rel_stop < 1.0)) return fail(VF_ERR_INVALID, "refine_rel_stop must be in [0, 1)");
     int ndev = 0;
@@ -367,6 +371,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     v.rel_tol = v.abs_tol = 0.0;
     v.sh_r = 0;
     v.sh_G = 1;
+    v.gauge_floor = o->gauge_floor;
     v.sh_all_jac = o->refine_iterations != 0 ? 1 : 0;   // (the refined solve applies J on whole increments: every rank keeps every Jacobian)
     AL(e->lambda0_dev, (size_t)v.B);
     AL(e->sigma_dev, 16);
@@ -1110,6 +1115,108 @@ int vf_engine_solve_global(vf_engine* e) {
     HIPCHK(hipGetLastError());
     return VF_OK;
 }
+// ------------------------------------------------------------------ the collectives of a time-sharded window from C (RCCL)
+// A C / C++ caller (the reference's node is C++) cannot reach torch.distributed: here the library issues the two collectives
+// of a solve itself, on the engine's stream, through the communicator the caller hands in (ncclComm_t; created by the caller
+// with ncclCommInitRank / ncclCommInitAll).  librccl is looked up at run time (dlopen): libvilfusion.so itself keeps no
+// communication dependency, and a process that never calls these entry points never loads it.
+namespace {
+typedef int (*rccl_all_gather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*rccl_all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*rccl_error_string_t)(int);
+struct Rccl {
+    void* handle = nullptr;
+    rccl_all_gather_t all_gather = nullptr;
+    rccl_all_reduce_t all_reduce = nullptr;
+    rccl_error_string_t error_string = nullptr;
+    bool tried = false;
+};
+Rccl g_rccl;
+constexpr int RCCL_FLOAT64 = 8, RCCL_SUM = 0;      // ncclFloat64, ncclSum (rccl.h)
+int rccl_load() {
+    if (g_rccl.all_gather) return VF_OK;
+    if (!g_rccl.tried) {
+        g_rccl.tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            g_rccl.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (g_rccl.handle) break;
+        }
+        if (g_rccl.handle) {
+            g_rccl.all_gather = (rccl_all_gather_t)dlsym(g_rccl.handle, "ncclAllGather");
+            g_rccl.all_reduce = (rccl_all_reduce_t)dlsym(g_rccl.handle, "ncclAllReduce");
+            g_rccl.error_string = (rccl_error_string_t)dlsym(g_rccl.handle, "ncclGetErrorString");
+        }
+    }
+    if (!g_rccl.all_gather || !g_rccl.all_reduce) return fail(VF_ERR_DEVICE, "librccl not found (dlopen librccl.so.1): %s", dlerror() ? dlerror() : "symbols missing");
+    return VF_OK;
+}
+int rccl_check(int rc, const char* what) {
+    if (rc == 0) return VF_OK;
+    return fail(VF_ERR_DEVICE, "%s failed: %s", what, g_rccl.error_string ? g_rccl.error_string(rc) : "rccl error");
+}
+// one staged solve of the shard: local phase, all-gather of the packed separator system (in place: the rank's own slice of
+// the receive buffer is its send buffer), global phase, all-reduce of increments + failure flags; then the refinement, each
+// correction the same two collectives on the correction's buffers
+int shard_solve(vf_engine* e, void* comm) {
+    int rc;
+    const vf::View& v = e->v;
+    const size_t per_chunk = (size_t)v.B * vf::SEPK, per_rank = (size_t)(v.P / v.sh_G) * per_chunk;
+    const size_t nd = (size_t)v.G * 15 + (size_t)v.B;
+    auto exchange = [&](double* delta) -> int {
+        int r;
+        if ((r = vf_engine_solve_local(e))) return r;
+        if ((r = rccl_check(g_rccl.all_gather(v.sepR + (size_t)v.sh_r * per_rank, v.sepR, per_rank, RCCL_FLOAT64, comm, e->stream), "ncclAllGather"))) return r;
+        if ((r = vf_engine_solve_global(e))) return r;
+        return rccl_check(g_rccl.all_reduce(delta, delta, nd, RCCL_FLOAT64, RCCL_SUM, comm, e->stream), "ncclAllReduce");
+    };
+    if ((rc = vf_engine_assemble(e)) || (rc = exchange(e->v.delta))) return rc;
+    int R = 0;
+    if ((rc = vf_engine_refine_count(e, &R))) return rc;
+    if (R > 0) {
+        if ((rc = vf_engine_refine_begin(e))) return rc;
+        for (int it = 0; it < R; it++)
+            if ((rc = exchange(e->rq.z)) || (rc = vf_engine_refine_step(e))) return rc;
+        if ((rc = vf_engine_refine_end(e))) return rc;
+    }
+    return VF_OK;
+}
+int shard_ready(vf_engine* e, void* comm, const char* what) {
+    if (!e || !comm) return fail(VF_ERR_INVALID, "%s: null argument", what);
+    if (e->v.P < 2 || e->v.P_fit) return fail(VF_ERR_INVALID, "%s: the engine needs an explicit chunk count (vf_engine_opts.chunks >= 2) and vf_engine_set_shard", what);
+    return rccl_load();
+}
+}  // namespace
+
+int vf_shard_exchange_plan(int windows, int capacity, int chunks, int rank, int world, long* sep_offset, long* sep_count,
+                           long* sep_total, long* delta_count) {
+    if (windows < 1 || capacity < 1 || chunks < 2 || world < 1 || rank < 0 || rank >= world || chunks % world != 0)
+        return fail(VF_ERR_INVALID, "bad exchange-plan query");
+    const long M = (capacity + 63) / 64 * 64, per_chunk = (long)windows * vf::SEPK, per_rank = (long)(chunks / world) * per_chunk;
+    if (sep_offset) *sep_offset = rank * per_rank;
+    if (sep_count) *sep_count = per_rank;
+    if (sep_total) *sep_total = (long)chunks * per_chunk;
+    if (delta_count) *delta_count = (long)windows * M * 15 + windows;
+    return VF_OK;
+}
+int vf_shard_iterate(vf_engine* e, void* nccl_comm, int iterations) {
+    DeviceGuard dev_guard_(e);
+    int rc = shard_ready(e, nccl_comm, "vf_shard_iterate");
+    if (rc) return rc;
+    if (iterations < 0) return fail(VF_ERR_INVALID, "iterations < 0");
+    if ((rc = vf_engine_reset_lambda(e)) || (rc = vf_engine_linearize(e, 0)) || (rc = vf_engine_decide(e, 1))) return rc;
+    for (int it = 0; it < iterations; it++)
+        if ((rc = shard_solve(e, nccl_comm)) || (rc = vf_engine_retract(e)) || (rc = vf_engine_linearize(e, 1)) || (rc = vf_engine_decide(e, 0))) return rc;
+    if (iterations > 0 && (rc = vf_engine_close_excursions(e))) return rc;
+    return VF_OK;
+}
+int vf_shard_gn_step(vf_engine* e, void* nccl_comm, double relin_threshold) {
+    DeviceGuard dev_guard_(e);
+    int rc = shard_ready(e, nccl_comm, "vf_shard_gn_step");
+    if (rc) return rc;
+    if ((rc = vf_engine_gn_begin(e, relin_threshold)) || (rc = shard_solve(e, nccl_comm)) || (rc = vf_engine_retract(e))) return rc;
+    return VF_OK;
+}
+
 int vf_engine_set_convergence(vf_engine* e, double rel_tol, double abs_tol) {
     DeviceGuard dev_guard_(e);
     if (e) e->warm = false;

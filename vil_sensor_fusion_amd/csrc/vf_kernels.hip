@@ -3306,6 +3306,112 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
         }
         __syncthreads();
     }
+    // Gauge floor (vf_engine_opts.gauge_floor).  Every factor of the window is invariant under a global translation and a
+    // rotation about gravity; what the window knows about those four directions is G^T L G of this prior alone -- the memory
+    // of the anchor prior, which decays with every marginalisation until it is below the rounding of the 1e9-scale entries
+    // beside it (cond(H) 5e12 after 100 updates of a 200-keyframe window, 1e16 after 2 000, indefinite after 3 000: LM trials
+    // rejected at random, then failed solves).  Eigenvalues of G^T L G that have fallen below the floor are lifted back to it
+    // (1e-3 = a 30 m sigma on WHERE the window is: nothing the factors can see).
+    if (v.gauge_floor > 0.0) {
+        __shared__ double Gq[27 * 4], Tq[27 * 4], Mq[16], Vq[16], lift[4];
+        for (int e = lane; e < 729; e += 256) {          // the symmetric part, in place
+            const int i = e / 27, j = e - i * 27;
+            if (j > i) { const double sy = 0.5 * (A[(15 + i) * 43 + 15 + j] + A[(15 + j) * 43 + 15 + i]); A[(15 + i) * 43 + 15 + j] = sy; A[(15 + j) * 43 + 15 + i] = sy; }
+        }
+        for (int e = lane; e < 108; e += 256) Gq[e] = 0.0;
+        __syncthreads();
+        if (lane < 3) {                                  // lane j: the rows of kept keyframe j
+            const int j = lane, o = j == 0 ? 0 : 15 + 6 * (j - 1);
+            const State s0 = load_state(v, b, g0 + 1), sj = load_state(v, b, g0 + 1 + j);
+            const M3 R = qrot(sj.q);
+            const double gn = sqrt(v.grav[0] * v.grav[0] + v.grav[1] * v.grav[1] + v.grav[2] * v.grav[2]);
+            const V3 ez = gn > 0.0 ? v3(-v.grav[0] / gn, -v.grav[1] / gn, -v.grav[2] / gn) : v3(0.0, 0.0, 1.0);
+            const V3 dt = sj.t - s0.t;
+            const V3 lever = v3(ez.y * dt.z - ez.z * dt.y, ez.z * dt.x - ez.x * dt.z, ez.x * dt.y - ez.y * dt.x);
+            for (int c = 0; c < 3; c++) {
+                for (int a = 0; a < 3; a++) Gq[(o + 3 + c) * 4 + a] = R.a[a * 3 + c];
+                Gq[(o + c) * 4 + 3] = R.a[0 * 3 + c] * ez.x + R.a[1 * 3 + c] * ez.y + R.a[2 * 3 + c] * ez.z;
+                Gq[(o + 3 + c) * 4 + 3] = R.a[0 * 3 + c] * lever.x + R.a[1 * 3 + c] * lever.y + R.a[2 * 3 + c] * lever.z;
+            }
+            if (j == 0) {
+                Gq[6 * 4 + 3] = ez.y * sj.vel.z - ez.z * sj.vel.y;
+                Gq[7 * 4 + 3] = ez.z * sj.vel.x - ez.x * sj.vel.z;
+                Gq[8 * 4 + 3] = ez.x * sj.vel.y - ez.y * sj.vel.x;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {                                 // modified Gram-Schmidt, 4 columns of 27
+            for (int a = 0; a < 4; a++) {
+                for (int bb = 0; bb < a; bb++) {
+                    double s = 0.0;
+                    for (int i = 0; i < 27; i++) s += Gq[i * 4 + a] * Gq[i * 4 + bb];
+                    for (int i = 0; i < 27; i++) Gq[i * 4 + a] -= s * Gq[i * 4 + bb];
+                }
+                double nn = 0.0;
+                for (int i = 0; i < 27; i++) nn += Gq[i * 4 + a] * Gq[i * 4 + a];
+                nn = sqrt(nn);
+                for (int i = 0; i < 27; i++) Gq[i * 4 + a] /= nn;
+            }
+        }
+        __syncthreads();
+        if (lane < 108) {
+            const int i = lane >> 2, a = lane & 3;
+            double s = 0.0;
+            for (int j = 0; j < 27; j++) s += A[(15 + i) * 43 + 15 + j] * Gq[j * 4 + a];
+            Tq[lane] = s;
+        }
+        __syncthreads();
+        if (lane < 16) {
+            const int a = lane >> 2, bb = lane & 3;
+            double s = 0.0;
+            for (int i = 0; i < 27; i++) s += Gq[i * 4 + a] * Tq[i * 4 + bb];
+            Mq[lane] = s;
+        }
+        __syncthreads();
+        if (lane == 0) {                                 // cyclic Jacobi on the 4 x 4 (10 sweeps)
+            for (int a = 0; a < 4; a++)
+                for (int bb = a + 1; bb < 4; bb++) { const double sy = 0.5 * (Mq[a * 4 + bb] + Mq[bb * 4 + a]); Mq[a * 4 + bb] = sy; Mq[bb * 4 + a] = sy; }
+            for (int i = 0; i < 16; i++) Vq[i] = (i % 5 == 0) ? 1.0 : 0.0;
+            for (int sweep = 0; sweep < 10; sweep++)
+                for (int p = 0; p < 3; p++)
+                    for (int q = p + 1; q < 4; q++) {
+                        const double apq = Mq[p * 4 + q];
+                        if (apq == 0.0) continue;
+                        const double theta = (Mq[q * 4 + q] - Mq[p * 4 + p]) / (2.0 * apq);
+                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                        for (int kk = 0; kk < 4; kk++) {
+                            const double mkp = Mq[kk * 4 + p], mkq = Mq[kk * 4 + q];
+                            Mq[kk * 4 + p] = c * mkp - sn * mkq;
+                            Mq[kk * 4 + q] = sn * mkp + c * mkq;
+                            const double vkp = Vq[kk * 4 + p], vkq = Vq[kk * 4 + q];
+                            Vq[kk * 4 + p] = c * vkp - sn * vkq;
+                            Vq[kk * 4 + q] = sn * vkp + c * vkq;
+                        }
+                        for (int kk = 0; kk < 4; kk++) {
+                            const double mpk = Mq[p * 4 + kk], mqk = Mq[q * 4 + kk];
+                            Mq[p * 4 + kk] = c * mpk - sn * mqk;
+                            Mq[q * 4 + kk] = sn * mpk + c * mqk;
+                        }
+                    }
+            for (int e = 0; e < 4; e++) { const double l = v.gauge_floor - Mq[e * 4 + e]; lift[e] = l > 0.0 ? l : 0.0; }
+        }
+        __syncthreads();
+        if (lane < 108) {                                // q_e = G V[:, e]
+            const int i = lane >> 2, e = lane & 3;
+            double s = 0.0;
+            for (int a = 0; a < 4; a++) s += Gq[i * 4 + a] * Vq[a * 4 + e];
+            Tq[lane] = s;
+        }
+        __syncthreads();
+        for (int e = lane; e < 729; e += 256) {
+            const int i = e / 27, j = e - i * 27;
+            double add = 0.0;
+            for (int q = 0; q < 4; q++) add += lift[q] * Tq[i * 4 + q] * Tq[j * 4 + q];
+            A[(15 + i) * 43 + 15 + j] += add;
+        }
+        __syncthreads();
+    }
     // new marginal prior on [m+1:15][m+2 pose][m+3 pose] = rows 15..41, relinearised at the current states
     for (int e = lane; e < 729 + 27; e += 256) {
         if (e < 729) { const int i = e / 27, j = e - i * 27; v.mp_L[(size_t)w * 729 + e] = 0.5 * (A[(15 + i) * 43 + 15 + j] + A[(15 + j) * 43 + 15 + i]); }

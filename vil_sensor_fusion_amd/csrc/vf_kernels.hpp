@@ -169,6 +169,8 @@ struct View {
     int* n_prov;        // [B] provisional trials over the life of the engine
     int* relin;         // [B] the current buffer was restored: linearise it again
     int relin_only;     // the linearisation kernels skip windows whose relin flag is clear
+    double gauge_floor; // k_marginalize: eigenvalues of the marginal prior's information about the window's global translation and yaw
+                        // that have decayed below this are lifted back to it (vf_engine_opts.gauge_floor; 0 = off)
     int w_first;        // K3 only: the first window of its grid (launch_assemble_window: H and g of ONE window on demand)
     // optional LM termination (off by default: every vf_engine_iterate runs its fixed number of trials).  With
     // stop_on, a window whose trial changes the cost by <= abs_tol, or by <= rel_tol relative to the cost

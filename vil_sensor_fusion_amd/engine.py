@@ -53,6 +53,7 @@ class EngineOpts:
     refine_iterations: int | None = None
     refine_min_keyframes: int | None = None
     refine_rel_stop: float | None = None
+    gauge_floor: float | None = None     # floor of the marginal prior's information about global translation / yaw (None = default 1e-3; 0 = off)
     lm_excursion: int | None = None      # non-monotone LM: provisional cost-raising trials per excursion (None = default: 3 on refining engines)
 
 
@@ -79,7 +80,7 @@ class Engine:
             o.solve_assemble_min = opts.solve_assemble_min
         if opts.solve_assemble_waves is not None:
             o.solve_assemble_waves = opts.solve_assemble_waves
-        for name in ("refine_iterations", "refine_min_keyframes", "refine_rel_stop", "lm_excursion"):
+        for name in ("refine_iterations", "refine_min_keyframes", "refine_rel_stop", "lm_excursion", "gauge_floor"):
             if getattr(opts, name) is not None:
                 setattr(o, name, getattr(opts, name))
         self._h = C.c_void_p()

@@ -781,6 +781,30 @@ def main():
                 "note": "the time is that of forward sweep + back substitution (the stage timer's `solve`); the back substitution "
                         "(0.92 ms of it) issues no matrix instruction; peaks measured by tools/probes/mfma_f64_rate.hip "
                         "(profiles/r04_mfma_f64_rate.log)"}
+        # The issue view: the forward sweep is bound by what one SIMD can ISSUE in float64, not by HBM.  From
+        # the committed counter passes of this same command (profiles/*_sq_counters.md -> kernel_durations.json): every wave64
+        # vector instruction occupies the SIMD's 16 lanes for 4 cycles (float64 FMA at full rate: 78.6 TFLOP/s = 16 lanes x 2 x
+        # 1024 SIMDs x 2.4 GHz), a v_mfma_f64_16x16x4 (2048 flop) the matrix pipe for 64 cycles at the data-sheet rate and 106
+        # at the rate this part saturates at (47.3 TFLOP/s, tools/probes/mfma_f64_rate.hip); a SIMD has launch x 2.4e9 cycles.
+        fwd_key = next((k for k in ("vf::k_band_forward_asm2", "vf::k_band_forward_asm", "vf::k_band_solve") if prof and k in prof.get("kernels", {})), None)
+        if fwd_key and "sq" in prof["kernels"][fwd_key] and "valu_insts_per_launch" in prof["kernels"][fwd_key]["sq"]:
+            pk, sqc = prof["kernels"][fwd_key], prof["kernels"][fwd_key]["sq"]
+            simd_cycles = pk["full_avg_ms"] * 1e-3 * 2.4e9 * 1024 / n_kf
+            valu_c = (sqc["valu_insts_per_launch"] - sqc["mfma_f64_insts_per_launch"]) * 4.0 / n_kf
+            f64_c = sqc["valu_f64_insts_per_launch"] * 4.0 / n_kf
+            mf = sqc["mfma_f64_insts_per_launch"] / n_kf
+            out["roofline_solve"]["issue_view"] = {
+                "kernel": fwd_key, "bound": "float64 issue of a SIMD (vector unit + matrix pipe)", "unit": "SIMD cycles per keyframe",
+                "available": simd_cycles, "vector_instructions_issue": valu_c, "of_which_float64": f64_c,
+                "matrix_instructions_per_keyframe": mf, "matrix_pipe_at_data_sheet_rate": mf * 64.0, "matrix_pipe_at_measured_saturation": mf * 2048.0 / (47.3e12 / 1024 / 2.4e9),
+                "matrix_pipe_busy_measured": sqc["mfma_busy_cycles_per_launch"] / n_kf,
+                "frac_issue_serial": (valu_c + mf * 2048.0 / (47.3e12 / 1024 / 2.4e9)) / simd_cycles,
+                "frac_issue_overlapped": max(valu_c, mf * 2048.0 / (47.3e12 / 1024 / 2.4e9)) / simd_cycles,
+                "note": "frac_issue_serial: vector and matrix work of a SIMD one after the other (what ONE wave per SIMD can do: its "
+                        "vector instructions do not issue under its own matrix instruction); frac_issue_overlapped: both units busy "
+                        "at once (two waves per SIMD, perfectly interleaved).  The kernel sits between the two; the rest is the pivot "
+                        "chain's dependent-result latency (wait / issue-stall columns of the counter table)",
+                "source": prof["source"]}
         if prof is not None:
             out["profiled_kernels"] = prof
         if conv is not None:

@@ -172,7 +172,7 @@ def main():
             elif time.time() - last_print > 60:
                 print(f"   ... solve {k}", flush=True)
                 last_print = time.time()
-        print(f"GraphManager soak: {gupdates} solves, no failed solve, worst ATE vs the oracle at a checkpoint {worst:.3e} m (bar 1e-8)", flush=True)
+        print(f"GraphManager soak: {gupdates} solves, no failed solve, worst ATE vs the oracle at a checkpoint {worst:.3e} m", flush=True)
         gm.close()
 
     # ================================================================ (a) batch engine, headline solver form
@@ -259,7 +259,8 @@ def main():
                 print(f"   ... update {u}", flush=True)
                 last_print = time.time()
         print(f"engine soak: {U} updates x {B} windows = {U * B} window-updates, {compactions} compactions, no failed solve, "
-              f"worst ATE vs the oracle at a checkpoint {worst:.3e} m (bar 1e-8)", flush=True)
+              f"worst ATE vs the oracle at a checkpoint {worst:.3e} m (unaligned: the window's global pose is a gauge the factors cannot see; "
+              f"compare the oracle against itself on inputs perturbed in the last place, same column)", flush=True)
         eng.close()
         for p in pending:
             p.get(timeout=3600)

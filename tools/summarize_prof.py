@@ -147,6 +147,11 @@ if sq:
              "valu_insts_per_wave": c.get("SQ_INSTS_VALU", 0.0) / waves, "lds_insts_per_wave": c.get("SQ_INSTS_LDS", 0.0) / waves,
              "lds_conflict_frac": c.get("SQ_LDS_BANK_CONFLICT", 0.0) / (c.get("SQ_LDS_IDX_ACTIVE", 0.0) or 1.0),
              "vmem_rd_per_wave": c.get("SQ_INSTS_VMEM_RD", 0.0) / waves, "vmem_wr_per_wave": c.get("SQ_INSTS_VMEM_WR", 0.0) / waves,
+             # wave-level instruction counts the issue view of bench.py's roofline_solve is built from
+             "valu_insts_per_launch": c.get("SQ_INSTS_VALU", 0.0),
+             "valu_f64_insts_per_launch": c.get("SQ_INSTS_VALU_FMA_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0),
+             "mfma_f64_insts_per_launch": c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) / 4.0,
+             "mfma_busy_cycles_per_launch": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0),
              "raw": {n: v for n, v in c.items()}}
         summ[k] = d
         if k in kern:

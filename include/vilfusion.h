@@ -134,11 +134,17 @@ typedef struct {
      * the memory of the anchor prior (GraphManager.cpp:27-35), which decays with every marginalisation (measured on a
      * 200-keyframe window: 2e-3, 1e-4, 1e-5, 8e-7 after 100, 500, 1 000, 2 000 updates) until it is below the float64 rounding
      * of the 1e9-scale entries beside it: H becomes indefinite, LM trials are rejected at random (2 000+ updates), then solves
-     * fail (3 500 updates of 1 000-keyframe windows; profiles/r05_soak_*).  Eigenvalues of that 4 x 4 information that have
-     * fallen below gauge_floor are lifted back to it at every marginalisation.  Default 1e-3 = a 30 m sigma on WHERE the window
-     * is: it constrains nothing the factors can see, and a prior whose gauge information is still above it (the first
-     * ~150 updates) is not touched, bit for bit.  0 = off. */
+     * fail (3 500 updates of 1 000-keyframe windows; profiles/r05_soak_*).  gauge_floor is the value below which the
+     * window's own softest eigenvalues (those of H along its global translation / yaw) are not allowed to fall: at every
+     * marginalisation the eigenvalues of the prior's 4 x 4 gauge information below gauge_floor * n / 3 (n keyframes in the
+     * window: a unit gauge vector of the window has 3 / n of its weight on the three keyframes the prior touches) are lifted
+     * back to that.  Default 3e-4, two orders above the rounding of H's largest entries (2e-6): for 1 000 keyframes an
+     * information of 0.1 on WHERE the window is -- a 3 m sigma; it constrains nothing the factors can see, and a prior whose
+     * gauge information is still above it (the first tens of updates) is not touched, bit for bit.  0 = off. */
     double gauge_floor;
+    int hybrid_active_list;  /* hybrid solves (termination rule on, > 128 windows): the one-wave sweeps take their windows from a compacted
+                                list of those still taking trials, so that the active ones are dispatched first (default 1; 0 = window i
+                                is workgroup i as before; same bits either way) */
 } vf_engine_opts;
 
 void vf_engine_default_opts(vf_engine_opts* o);
@@ -164,9 +170,17 @@ int vf_engine_clear_between(vf_engine* e, int window, int k0, int n);
  * -- the band solver once more per column of U (6 per factor) and one small dense system per window.  A FALLBACK for
  * the rare window with such factors, several times slower than a band-only window; at most VF_MAX_EXTRA per window.
  * The call REPLACES the window's list (n = 0 clears it); records as for vf_engine_set_between.  A factor whose older
- * keyframe leaves the window (slide / drop_oldest / marginalize) stops contributing: its information is dropped, not
- * marginalised.  Engines holding far factors start every solve cold.  Not for time-sharded engines. */
+ * keyframe a leaves the window (vf_engine_slide / vf_engine_drop_oldest) is TRANSPORTED to keyframe a + 1: with D the
+ * current estimate of T_a^-1 T_a+1 its measurement becomes D^-1 Z -- the same residual in the same tangent frame, D taken
+ * as exact (the IMU factor between the two knows it to 2e-5 m, a between factor claims 1e-2 ... 0.5 m) -- so the information
+ * of a loop closure outlives the keyframe it was anchored on, as in the reference's unbounded graph (GraphManager.cpp:83-88);
+ * one that reaches its own end keyframe is dropped.  Engines holding far factors start every solve cold.  Not for
+ * time-sharded engines. */
 int vf_engine_set_extra_between(vf_engine* e, int window, int n, const int32_t* a, const int32_t* b, const double* rec28);
+/* the window's far factors as they stand (vf_engine_slide / vf_engine_drop_oldest TRANSPORT a far factor whose older keyframe
+ * leaves the window to the next keyframe -- see below), and how many were transported / dropped at their own end keyframe
+ * over the life of the engine; any output pointer may be NULL */
+int vf_engine_get_extra_between(vf_engine* e, int window, int* n, int32_t* a, int32_t* b, double* rec28, long* transported, long* ended);
 /* the three priors of GraphManager.cpp:27-35 as one diagonal 15-row factor on keyframe k */
 int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec31);
 

@@ -60,7 +60,13 @@ class Problem(C.Structure):
                 ("gravity", C.c_double * 3), ("marg", C.POINTER(Marg))]
 
 
-GAUGE_FLOOR = 1e-3   # default of vf_engine_opts.gauge_floor
+GAUGE_FLOOR = 3e-4   # default of vf_engine_opts.gauge_floor: the floor of the WINDOW's softest eigenvalues
+
+
+def prior_gauge_floor(n_kf, floor=GAUGE_FLOOR):
+    """what k_marginalize lifts the marginal prior's gauge information to, for a window of n_kf keyframes (floor * n / 3)"""
+    return floor * n_kf / 3.0
+
 ACCEPT_REL = 1e-9    # default accept tolerance of vfo_lm = vf_engine_opts.accept_rel's default (include/vilfusion.h).  A constant:
 #                      callers that want another rule pass accept_rel to Window.lm / FixedLagOracle, nobody assigns to this name
 
@@ -304,7 +310,7 @@ class Window:
 
     def marginalize(self, m=0, gauge_floor=0.0):
         """Schur complement of every factor touching keyframe m onto [m+1:15][m+2:pose][m+3:pose]; gauge_floor:
-        vf_engine_opts.gauge_floor (the engine's default is GAUGE_FLOOR, the oracle does what it is told)."""
+        the floor of the PRIOR's gauge information, prior_gauge_floor(n) for the engine's behaviour (the oracle does what it is told)."""
         out = Marg()
         rc = lib().vfo_marginalize_floor(C.byref(self.c), C.c_int(m), C.c_double(gauge_floor), C.byref(out))
         if rc != 0:

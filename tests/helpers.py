@@ -62,6 +62,21 @@ def ate(states_a, states_b):
     return float(np.sqrt(np.mean(np.sum(d * d, axis=1)))), float(np.max(2 * np.arccos(w)))
 
 
+def ate_gauge_aligned(states_a, states_b):
+    """ATE after removing what no factor of a fixed-lag window can see: a global translation and a rotation about gravity (z)
+    of trajectory a, fitted in closed form (planar Procrustes on x, y; mean offset in z).  For comparing two runs of a
+    smoother whose global pose is carried by a decaying prior only."""
+    pa, pb = states_a[:, 4:7], states_b[:, 4:7]
+    ca, cb = pa.mean(axis=0), pb.mean(axis=0)
+    xa, xb = pa - ca, pb - cb
+    s = np.sum(xa[:, 0] * xb[:, 1] - xa[:, 1] * xb[:, 0])
+    c = np.sum(xa[:, 0] * xb[:, 0] + xa[:, 1] * xb[:, 1])
+    psi = np.arctan2(s, c)
+    R = np.array([[np.cos(psi), -np.sin(psi), 0.0], [np.sin(psi), np.cos(psi), 0.0], [0.0, 0.0, 1.0]])
+    d = xa @ R.T - xb
+    return float(np.sqrt(np.mean(np.sum(d * d, axis=1)))), float(psi), float(np.linalg.norm(cb - ca))
+
+
 SWEEP_TOLS = (1e-3, 1e-4, 1e-5, 1e-6, 1e-7)
 
 
@@ -122,7 +137,7 @@ class FixedLagOracle:
     def update(self):
         """one fixed-lag update; returns the window's states afterwards (keyframes [s, s + n))"""
         p, n = self.prob, self.n
-        self.marg = self.win.marginalize(0, self.gauge_floor)   # (self.win still holds the previous window, its prior / marginal prior attached)
+        self.marg = self.win.marginalize(0, self.o.prior_gauge_floor(self.n, self.gauge_floor))   # (self.win still holds the previous window, its prior / marginal prior attached)
         self.marg.k0 = 0
         self.s += 1
         s = self.s

@@ -4,10 +4,14 @@
 #include <atomic>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/vilfusion.h"
 
-struct vf_engine { int dummy; };
+// (the far list is kept the way the real engine keeps it: replaced by vf_engine_set_extra_between, transported to the next
+// keyframe when its older keyframe is dropped, shifted by a compaction)
+struct FarEntry { int a, b; double rec[VF_BTW_RECORD]; };
+struct vf_engine { int lo = 0, hi = 0; std::vector<FarEntry> far; };
 static thread_local std::string g_err;
 std::atomic<int> fake_fail_preintegrate{0};   // != 0: vf_engine_preintegrate fails (the solve gives its queues back)
 std::atomic<long> fake_iterates{0};
@@ -22,7 +26,7 @@ int vf_engine_create(const vf_engine_opts*, vf_engine** out) { *out = new vf_eng
 void vf_engine_destroy(vf_engine* e) { delete e; }
 int vf_engine_set_states(vf_engine*, int, int, int, const double*) { return VF_OK; }
 int vf_engine_set_prior(vf_engine*, int, int, const double*) { return VF_OK; }
-int vf_engine_set_range(vf_engine*, int, int, int) { return VF_OK; }
+int vf_engine_set_range(vf_engine* e, int, int lo, int hi) { e->lo = lo; e->hi = hi; return VF_OK; }
 int vf_engine_set_convergence(vf_engine*, double, double) { return VF_OK; }
 int vf_engine_set_imu(vf_engine*, int, int, int, const double*) { return VF_OK; }
 int vf_engine_preintegrate(vf_engine*, int, int, int, const int32_t*, const double*, const double*, const vf_imu_params*) {
@@ -32,7 +36,9 @@ int vf_engine_preintegrate(vf_engine*, int, int, int, const int32_t*, const doub
 int vf_engine_predict(vf_engine*, int, int, int) { return VF_OK; }
 int vf_engine_predict_from_estimate(vf_engine*, int, int, int) { return VF_OK; }
 int vf_engine_set_between(vf_engine*, int, int n, const int32_t*, const int32_t*, const double*) { fake_band_n = n; return VF_OK; }
-int vf_engine_set_extra_between(vf_engine*, int, int n, const int32_t* a, const int32_t* b, const double*) {
+int vf_engine_set_extra_between(vf_engine* e, int, int n, const int32_t* a, const int32_t* b, const double* rec) {
+    e->far.clear();
+    for (int i = 0; i < n; i++) { FarEntry f; f.a = a[i]; f.b = b[i]; memcpy(f.rec, rec + (size_t)i * VF_BTW_RECORD, sizeof(f.rec)); e->far.push_back(f); }
     fake_extra_n = n;
     fake_extra_calls++;
     fake_extra_a0 = n ? a[0] : -1;
@@ -40,8 +46,32 @@ int vf_engine_set_extra_between(vf_engine*, int, int n, const int32_t* a, const 
     return VF_OK;
 }
 int vf_engine_marginalize(vf_engine*) { return VF_OK; }
-int vf_engine_drop_oldest(vf_engine*) { return VF_OK; }
-int vf_engine_compact(vf_engine*, int) { return VF_OK; }
+int vf_engine_drop_oldest(vf_engine* e) {
+    std::vector<FarEntry> keep;
+    for (auto f : e->far) {
+        if (f.a == e->lo) { if (f.a + 1 >= f.b) continue; f.a++; }
+        keep.push_back(f);
+    }
+    e->far.swap(keep);
+    e->lo++;
+    return VF_OK;
+}
+int vf_engine_compact(vf_engine* e, int shift) {
+    for (auto& f : e->far) { f.a -= shift; f.b -= shift; }
+    e->lo -= shift; e->hi -= shift;
+    return VF_OK;
+}
+int vf_engine_get_extra_between(vf_engine* e, int, int* n, int32_t* a, int32_t* b, double* rec, long* tr, long* en) {
+    if (n) *n = (int)e->far.size();
+    for (size_t i = 0; i < e->far.size(); i++) {
+        if (a) a[i] = e->far[i].a;
+        if (b) b[i] = e->far[i].b;
+        if (rec) memcpy(rec + i * VF_BTW_RECORD, e->far[i].rec, sizeof(e->far[i].rec));
+    }
+    if (tr) *tr = 0;
+    if (en) *en = 0;
+    return VF_OK;
+}
 int vf_engine_grow(vf_engine*, int) { return VF_OK; }
 int vf_engine_isam_step(vf_engine*, double) { return VF_OK; }
 int vf_engine_iterate(vf_engine*, int) { fake_iterates++; return VF_OK; }

@@ -43,9 +43,20 @@ int main() {
     for (int i = 0; i < 5; i++) CHECK(vf_add_between(g, 1 + i, 8 + (uint64_t)i % 4, q, t3, eye) == VF_OK);
     CHECK(vf_add_between(g, 3, 12, q, t3, eye) == VF_ERR_CAPACITY);   // the ninth
     CHECK(vf_add_between(g, 12, 3, q, t3, eye) == VF_ERR_BAD_KEY);
-    // keys leave the fixed-lag window (lag 16): far factors whose older key is gone are dropped from the list
-    for (int k = 13; k <= 60; k++) { const uint64_t key = node(); CHECK(vf_add_between(g, key - 1, key, q, t3, eye) == VF_OK); CHECK(vf_solve(g) == VF_OK); }
-    CHECK(fake_extra_n.load() == 0);
+    // keys leave the fixed-lag window (lag 16): a far factor whose older key is marginalised is TRANSPORTED to the next keyframe by
+    // the engine (vf_engine_drop_oldest) and the GraphManager's entry follows -- the factor (2, 9) is (3, 9) after key 2 has
+    // left, (4, 9) after key 3 ... -- until it reaches its own end key and is dropped
+    int seen_moved = 0;
+    for (int k = 13; k <= 60; k++) {
+        const uint64_t key = node();
+        CHECK(vf_add_between(g, key - 1, key, q, t3, eye) == VF_OK);
+        CHECK(vf_solve(g) == VF_OK);
+        if (key == 20) {            // window = keys [5, 20]: every older key so far has been transported up to 5 or ended before
+            CHECK(fake_extra_n.load() >= 1 && fake_extra_a0.load() >= 0);
+            seen_moved = 1;
+        }
+    }
+    CHECK(seen_moved == 1 && fake_extra_n.load() == 0);
     const int calls = fake_extra_calls.load();
     node();
     CHECK(vf_solve(g) == VF_OK);

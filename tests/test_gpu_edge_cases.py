@@ -452,3 +452,85 @@ def test_engine_grow_carries_the_problem_over(oracle):
     with pytest.raises(VilFusionError):
         small.grow(320)                     # must exceed the current capacity
     small.close(); big.close()
+
+
+def test_gauge_floor_on_the_device_matches_the_oracle_and_keeps_long_runs_solvable(oracle):
+    """vf_engine_opts.gauge_floor in k_marginalize against vfo_marginalize_floor (tests/test_oracle_marginalization.py says what
+    it is for): 900 fixed-lag updates of 64-keyframe windows, with compaction cycles.  With the floor (the default) device and
+    oracle carry the same marginal prior (information to 1e-6 of its largest entry), its gauge information sits at
+    floor * n / 3 or above, nothing fails and next to nothing is rejected; with the floor off the device's own window ends
+    with its global translation information below that and falling (the 1 000-keyframe windows of tools/soak.py reach the
+    rounding level after ~2 000 updates and fail after ~3 500), which is what the floor is there to prevent."""
+    from tests.test_gpu_ingest import _feed
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    n, U, K = 64, 900, 4
+    seqs = [synth.make_sequence(seed=430 + i, n_kf=n + U + 2) for i in range(2)]
+    prm = oracle.carla_imu_params()
+    res = {}
+    for floor in (None, 0.0):
+        cap = n + 128
+        eng = Engine(EngineOpts(windows=len(seqs), capacity=cap, gauge_floor=floor))
+        for w, seq in enumerate(seqs):
+            eng.preintegrate(w, 1, seq.imu_off[1:n + 1], seq.imu_steps, np.zeros(6), synth.CARLA_IMU_COV)
+            m = seq.btw_b < n
+            eng.set_between(w, seq.btw_a[m], seq.btw_b[m], synth.between_records(seq)[m])
+            eng.set_states(w, 0, seq.gt_states[0].reshape(1, 16))
+            eng.set_prior(w, 0, synth.prior_record(seq.gt_states[0], REFERENCE_PRIOR_SIGMAS))
+            eng.set_range(w, 0, 1)
+        eng.predict(-1, 1, n - 1)
+        for w in range(len(seqs)):
+            eng.set_range(w, 0, n)
+        eng.iterate(60)
+        refs = None
+        if floor is None:
+            refs = [helpers.FixedLagOracle(oracle, helpers.build_problem(oracle, s), n, K, init_iterations=60, ingest=(s, prm)) for s in seqs]
+        base = 0
+        for u in range(1, U + 1):
+            k = n + u - 1
+            if k - base >= cap:
+                shift = (k - n - base) // 64 * 64
+                eng.compact(shift)
+                base += shift
+            off, steps, cov, a, rec = _feed(seqs, k)
+            eng.ingest_tail(off, steps, cov, np.where(a >= 0, a - base, -1).astype(np.int32), rec)
+            eng.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)
+            eng.iterate(K)
+            if refs:
+                for r in refs:
+                    r.update()
+        eng.ingest_status()
+        lms = [eng.read_lm(w) for w in range(len(seqs))]
+        mp = [eng.read_marginal(w) for w in range(len(seqs))]
+        st = [eng.get_states(w, U - base, n) for w in range(len(seqs))]
+        res[floor] = dict(lm=lms, mp=mp, states=st, refs=refs)
+        eng.close()
+
+    def gauge_info(mp):
+        """eigenvalues of G^T L G, G = the prior's orthonormalised translation / yaw directions (as k_marginalize builds them)"""
+        x, L = mp["xbar"], mp["L"]
+        G = np.zeros((27, 4))
+        for j in range(3):
+            R = synth.quat_to_rot(x[j, :4])
+            o = 0 if j == 0 else 15 + 6 * (j - 1)
+            G[o + 3:o + 6, :3] = R.T
+            G[o:o + 3, 3] = R.T @ np.array([0.0, 0.0, 1.0])
+            G[o + 3:o + 6, 3] = R.T @ np.cross([0.0, 0.0, 1.0], x[j, 4:7] - x[0, 4:7])
+        G[6:9, 3] = np.cross([0.0, 0.0, 1.0], x[0, 7:10])
+        Q, _ = np.linalg.qr(G)
+        return np.linalg.eigvalsh(Q.T @ (0.5 * (L + L.T)) @ Q)
+
+    on, off_ = res[None], res[0.0]
+    want = oracle.prior_gauge_floor(n)
+    for w in range(len(seqs)):
+        ref = on["refs"][w]
+        Lo = np.array(ref.marg.L[:]).reshape(27, 27)
+        dL = np.abs(on["mp"][w]["L"] - Lo).max() / np.abs(Lo).max()
+        a, r = helpers.ate(on["states"][w], ref.window_states)
+        gi_on, gi_off = gauge_info(on["mp"][w]), gauge_info(off_["mp"][w])
+        print(f"window {w}: {U} updates; with the floor: marginal information vs oracle {dL:.1e}, ATE {a:.2e} m, gauge information {gi_on} (floor {want:.2e}), "
+              f"lm {on['lm'][w]}; without: gauge information {gi_off}, lm {off_['lm'][w]}")
+        # (unaligned ATE between two float64 runs of a gauge-free smoother is a random walk of the gauge: 1e-5 m by now)
+        assert dL <= 1e-6 and a <= 1e-4 and r <= 1e-5
+        assert gi_on.min() >= 0.98 * want and on["lm"][w]["solve_failures"] == 0 and on["lm"][w]["rejected"] <= 20
+        assert abs(on["lm"][w]["cost"] - ref.costs[-1]) <= 1e-6 * ref.costs[-1]
+        assert gi_off.min() < 0.6 * want                        # without the floor the information has decayed below it (and goes on decaying)

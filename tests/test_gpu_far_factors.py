@@ -143,7 +143,6 @@ def test_far_factors_survive_compaction_and_growth(lag):
     """The far list lives in window-local slots on the device and in absolute keys in the GraphManager: a handle whose engine
     compacts (fixed lag, 64 slots) or grows (whole history, 64 initial slots) while far factors are alive must publish what a
     roomy handle publishes; in fixed-lag mode the factors also age out of the window one after the other."""
-    from tests.test_gpu_graph_manager import _stream
     from vil_sensor_fusion_amd.graph_manager import GraphManager
     n = 230
     seq = synth.make_sequence(74, n)
@@ -227,3 +226,99 @@ def test_far_factor_information_extremes(oracle, cov):
     print(f"far factor with covariance {cov:g}: ATE vs oracle {a:.3e} m, cost {lm['cost']:.9e} vs {costs[-1]:.9e}, accepted {lm['accepted']} rejected {lm['rejected']}")
     assert a <= 1e-6 and r <= 1e-6 and lm["solve_failures"] == 0 and abs(lm["cost"] - costs[-1]) <= 1e-7 * abs(costs[-1])
     eng.close()
+
+
+def test_a_loop_closure_outlives_its_anchor_keyframe(oracle):
+    """iSAM2 keeps every BetweenFactor for good (GraphManager.cpp:83-88).  Here a far factor whose older keyframe leaves the
+    fixed-lag window is TRANSPORTED to the next keyframe (vf_engine_slide: Z' = D^-1 Z with D the current estimate of the step
+    between the two; include/vilfusion.h) instead of being dropped as it was until round 4.  An 80-keyframe window slides 50
+    times over a 130-keyframe clip with one precise loop closure (keyframes 6 <-> 72); the last window is compared with the
+    WHOLE-HISTORY batch optimum of the oracle (all 130 keyframes, all factors): with transport it stays as close as the
+    fixed-lag window without any far factor stays to ITS batch optimum (the marginal prior's linearisation is the error
+    left); with the factor dropped when its anchor leaves (the old behaviour, emulated) it is several times farther."""
+    total, n, a0, b0, K = 130, 80, 6, 72, 6
+    seq = synth.make_sequence(seed=93, n_kf=total)
+    prob = helpers.build_problem(oracle, seq)
+    rng = np.random.default_rng(7)
+    far = _far_record(seq, a0, b0, rng, cov=1e-4, noise=(1e-4, 1e-3)).reshape(1, 28)
+    fa, fb = np.array([a0], dtype=np.int32), np.array([b0], dtype=np.int32)
+    p_far = dict(prob, btw_a=np.concatenate([prob["btw_a"], fa]).astype(np.int32), btw_b=np.concatenate([prob["btw_b"], fb]).astype(np.int32),
+                 btw=np.vstack([prob["btw"], far]))
+    refs = {}
+    for name, p in (("with", p_far), ("without", prob)):
+        win = helpers.oracle_window(oracle, p)
+        win.lm(iterations=40)
+        refs[name] = win.states.copy()
+    moved = helpers.ate(refs["with"][total - n:], refs["without"][total - n:])[0]
+
+    def run(mode):
+        eng = Engine(EngineOpts(windows=1, capacity=total))
+        helpers.load_engine(eng, 0, prob, 0, n)
+        if mode != "none":
+            eng.set_extra_between(0, fa, fb, far)
+        eng.iterate(40)
+        for s in range(1, total - n + 1):
+            if mode == "dropped" and s == a0 + 1:
+                eng.set_extra_between(0, [], [], np.zeros((0, 28)))        # (what the library did until round 4)
+            eng.slide(marginalize=True)
+            eng.iterate(K)
+        out = eng.get_states(0, total - n, n), eng.get_extra_between(0), eng.read_lm(0)
+        eng.close()
+        return out
+
+    x_t, (ea, eb, erec, transported, ended), lm = run("transport")
+    x_d, _, _ = run("dropped")
+    x_n, _, _ = run("none")
+    e_t = helpers.ate(x_t, refs["with"][total - n:])[0]
+    e_d = helpers.ate(x_d, refs["with"][total - n:])[0]
+    e_n = helpers.ate(x_n, refs["without"][total - n:])[0]
+    print(f"loop closure ({a0}, {b0}) across 50 slides of an {n}-keyframe window: the closure moves the last window's batch optimum by {moved:.3e} m; "
+          f"fixed lag vs whole-history batch: transported {e_t:.3e} m, dropped at the anchor's exit {e_d:.3e} m, (no far factor at all, vs its own batch: {e_n:.3e} m); "
+          f"far list now a = {ea.tolist()} b = {eb.tolist()}, transported {transported} times")
+    assert lm["solve_failures"] == 0
+    assert ea.tolist() == [total - n] and eb.tolist() == [b0] and transported == total - n - a0 and ended == 0
+    assert moved > 1e-3                                  # the closure matters on this clip
+    assert e_t < 0.4 * e_d and e_t < 3.0 * e_n + 1e-4
+
+
+def test_graph_manager_keeps_a_loop_closure_across_its_lag():
+    """The same through the GraphManager (vf_add_between routes the wide factor to the far list; vf_solve marginalises with a
+    lag of 40): the published estimate after the anchor key has left the window follows the whole-history handle (lag = 0,
+    the reference's unbounded graph) fed the same factors, several times closer than a lag-40 handle that never got the
+    loop closure."""
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    total, a0, b0 = 110, 5, 38
+    seq = synth.make_sequence(seed=94, n_kf=total, keep_raw=True)
+    rng = np.random.default_rng(8)
+    rec = _far_record(seq, a0, b0, rng, cov=1e-4, noise=(1e-4, 1e-3))
+    cov = {c: np.eye(6) * c for c in (synth.VIO_COV, synth.LIDAR_COV)}
+    by_end = {int(b): i for i, b in enumerate(seq.btw_b)}
+
+    def run(lag, closure):
+        gm = GraphManager(capacity=256, lag=lag, iterations=6, rel_tol=0.0, abs_tol=0.0)
+        gm.setInitialState(seq.gt_states[0])
+        gm.addIMUMeasurement(0.0, seq.imu_acc[0], seq.imu_gyro[0])
+        i_imu = 0
+        for k in range(1, total):
+            while i_imu < seq.imu_t.size and seq.imu_t[i_imu] <= seq.kf_time[k] + 0.011:
+                gm.addIMUMeasurement(seq.imu_t[i_imu], seq.imu_acc[i_imu], seq.imu_gyro[i_imu])
+                i_imu += 1
+            assert gm.reserveNode(seq.kf_time[k]) == k
+            if k in by_end:
+                i = by_end[k]
+                gm.addBetweenFactor(int(seq.btw_a[i]), k, (seq.btw_q[i], seq.btw_t[i]), cov[float(seq.btw_cov[i])])
+            if closure and k == b0:
+                gm.addBetweenFactor(a0, b0, (rec[0:4], rec[4:7]), np.eye(6) * 1e-4)
+            gm.solve()
+        st = gm.lmStats()
+        tr = gm.trajectory(total - 31, 30)             # the last 30 keys: inside every handle's window
+        gm.close()
+        return tr, st
+
+    whole, st0 = run(0, True)
+    lagged, st1 = run(40, True)
+    blind, st2 = run(40, False)
+    d_keep = helpers.ate(lagged, whole)[0]
+    d_blind = helpers.ate(blind, whole)[0]
+    print(f"GraphManager, loop closure ({a0}, {b0}), lag 40 vs whole history over the last 30 keys: with the closure transported {d_keep:.3e} m, never given the closure {d_blind:.3e} m")
+    assert st1["solve_failures"] == 0 and d_keep < 0.4 * d_blind

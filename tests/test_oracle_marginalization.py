@@ -81,3 +81,46 @@ def test_fixed_lag_with_marginalisation_tracks_the_batch_solution(oracle):
     print(f"ATE of the last window vs full batch: marginalised {e_marg:.3e} m, re-anchored {e_anchor:.3e} m")
     assert e_marg < 5e-3
     assert e_marg <= e_anchor * 1.05
+
+
+def _gauge_information(win, oracle):
+    """smallest eigenvalues of the window's normal equations (dense): the four softest are its global translation and yaw"""
+    _, H, _ = win.assemble()
+    N = H.shape[0]
+    D = np.zeros((N * 15, N * 15))
+    for k in range(N):
+        for d in range(H.shape[1]):
+            if k - d >= 0:
+                D[k * 15:(k + 1) * 15, (k - d) * 15:(k - d + 1) * 15] = H[k, d]
+                D[(k - d) * 15:(k - d + 1) * 15, k * 15:(k + 1) * 15] = H[k, d].T
+    return np.linalg.eigvalsh(D)[:4]
+
+
+def test_gauge_floor_keeps_a_long_running_fixed_lag_window_solvable(oracle):
+    """Every factor of a window is invariant under a global translation and a rotation about gravity: what the window knows
+    about WHERE it is is the memory of the anchor prior carried by the marginal prior, and that decays with every
+    marginalisation.  Without a floor it falls below the float64 rounding of the 1e9-scale entries beside it (here after
+    ~2 000 updates of a 100-keyframe window): the normal equations turn indefinite and LM trials are rejected at random --
+    on the device the same chain ends in failed solves (profiles/r05_soak_*).  With vf_engine_opts.gauge_floor (3e-4, the
+    default; k_marginalize / vfo_marginalize_floor) the four softest eigenvalues stay at the floor and nothing is rejected;
+    while the information is still above the floor the prior is not touched, bit for bit."""
+    n, U = 100, 2600
+    seq = synth.make_sequence(seed=71, n_kf=n + U + 2)
+    prob = helpers.build_problem(oracle, seq)
+    out = {}
+    for floor in (0.0, oracle.GAUGE_FLOOR):
+        ref = helpers.FixedLagOracle(oracle, prob, n, 5, init_iterations=120, ingest=(seq, oracle.carla_imu_params()), gauge_floor=floor)
+        rejected, early = 0, None
+        for u in range(1, U + 1):
+            ref.update()
+            rejected += int(np.sum(ref.acc == 0))
+            if u == 20:
+                early = (ref.window_states.copy(), np.array(ref.marg.L[:]))
+        out[floor] = dict(rejected=rejected, soft=_gauge_information(ref.win, oracle), early=early)
+    a, b = out[0.0], out[oracle.GAUGE_FLOOR]
+    print(f"{U} updates of a {n}-keyframe window: without the floor {a['rejected']} rejected trials, softest eigenvalues of H {a['soft']}; "
+          f"with it {b['rejected']}, {b['soft']}")
+    np.testing.assert_array_equal(a["early"][0], b["early"][0])           # 20 updates in: the floor has not been needed yet
+    np.testing.assert_array_equal(a["early"][1], b["early"][1])
+    assert a["soft"][0] < 1e-5 and a["rejected"] > 20 * max(b["rejected"], 1)
+    assert b["soft"][0] > 0.5 * oracle.GAUGE_FLOOR and b["rejected"] <= 10

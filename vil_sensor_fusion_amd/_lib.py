@@ -25,7 +25,7 @@ class EngineOptsC(C.Structure):
                 ("lambda_min", C.c_double), ("lambda_max", C.c_double), ("chunks", C.c_int),
                 ("sweep_two_sided_max", C.c_int), ("hybrid_threshold", C.c_int), ("cold_start", C.c_int),
                 ("use_hip_graph", C.c_int), ("accept_rel", C.c_double), ("solve_split_min", C.c_int), ("solve_assemble_min", C.c_int), ("solve_assemble_waves", C.c_int),
-                ("refine_iterations", C.c_int), ("refine_min_keyframes", C.c_int), ("refine_rel_stop", C.c_double), ("lm_excursion", C.c_int), ("gauge_floor", C.c_double)]
+                ("refine_iterations", C.c_int), ("refine_min_keyframes", C.c_int), ("refine_rel_stop", C.c_double), ("lm_excursion", C.c_int), ("gauge_floor", C.c_double), ("hybrid_active_list", C.c_int)]
 
 
 class ImuParamsC(C.Structure):
@@ -57,7 +57,7 @@ SYMBOLS = [
     "vf_last_error", "vf_version", "vf_device_count",
     "vf_engine_default_opts", "vf_engine_create", "vf_engine_destroy",
     "vf_engine_set_range", "vf_engine_set_states", "vf_engine_get_states", "vf_engine_set_imu",
-    "vf_engine_set_between", "vf_engine_clear_between", "vf_engine_set_extra_between", "vf_engine_set_prior",
+    "vf_engine_set_between", "vf_engine_clear_between", "vf_engine_set_extra_between", "vf_engine_get_extra_between", "vf_engine_set_prior",
     "vf_engine_linearize", "vf_engine_assemble", "vf_engine_solve", "vf_engine_retract",
     "vf_engine_decide", "vf_engine_iterate", "vf_engine_slide", "vf_engine_predict",
     "vf_engine_sync", "vf_engine_graph_info", "vf_engine_solve_form",

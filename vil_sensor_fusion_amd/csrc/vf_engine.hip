@@ -92,6 +92,8 @@ struct vf_engine {
     bool hybrid = false;
     int hybrid_P = 0;
     double *h_Vp = nullptr, *h_sep = nullptr, *h_sepL = nullptr;
+    int* act_list = nullptr;   // compacted list of the windows still taking trials (vf_engine_opts.hybrid_active_list): handed to the hybrid's
+                               // sweeps and to k_count_active only -- every other launch sees View::act = null
     vf::View partitioned_view() const {
         vf::View p = v;
         p.P = hybrid_P;
@@ -162,6 +164,7 @@ struct vf_engine {
     double* x_gtmp = nullptr;
     double* x_Z = nullptr;
     size_t x_zstride = 0;
+    long far_transported = 0, far_ended = 0;   // far factors moved on to the next keyframe when theirs left the window / dropped at their own end
     int x_zslots = 0;          // slots x_Z holds columns for (6 columns each); grown on demand, never beyond VF_MAX_EXTRA
     // the device lists are allocated once (they stay in `allocs`); a failure half way leaves what exists in place and a
     // later call picks up from there (no second allocation, nothing leaked)
@@ -279,7 +282,8 @@ void vf_engine_default_opts(vf_engine_opts* o) {
     o->refine_min_keyframes = 2048;
     o->refine_rel_stop = 1e-13;
     o->lm_excursion = -1;            // auto: 3 on engines that refine, classical LM otherwise
-    o->gauge_floor = 1e-3;
+    o->gauge_floor = 3e-4;
+    o->hybrid_active_list = 1;
 }
 
 int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
@@ -797,6 +801,7 @@ int vf_engine_solve(vf_engine* e) {
             vf::View p = e->partitioned_view();
             p.gvec = gvec;
             p.delta = delta;
+            a.act = e->act_list;
             vf::launch_band_solve_hybrid(a, p, e->stream);
         } else vf::launch_band_solve(a, e->stream);
     };
@@ -919,7 +924,11 @@ int vf_engine_decide(vf_engine* e, int init) {
     vf::launch_decide(e->v, init ? 1 : 0, e->stream);
     if (e->v.nm_W > 0 && !init)
         if (int rc = relinearize_restored(e)) return rc;
-    if (e->hybrid && e->v.stop_on) vf::launch_count_active(e->v, e->stream);   // what the next K4 launch gates on
+    if (e->hybrid && e->v.stop_on) {          // what the next K4 launch gates on (and the list its sweeps take their windows from)
+        vf::View c = e->v;
+        c.act = e->act_list;
+        vf::launch_count_active(c, e->stream);
+    }
     HIPCHK(hipGetLastError());
     return VF_OK;
 }
@@ -1235,7 +1244,7 @@ int vf_engine_set_convergence(vf_engine* e, double rel_tol, double abs_tol) {
             const size_t BP = (size_t)v.B * e->hybrid_P;
             int rc;
             if ((rc = e->alloc(&e->h_Vp, (size_t)v.G * vf::VROW)) || (rc = e->alloc(&e->h_sep, BP * vf::SEPK)) ||
-                (rc = e->alloc(&e->h_sepL, BP * vf::SEPL))) return rc;
+                (rc = e->alloc(&e->h_sepL, BP * vf::SEPL)) || (e->opts.hybrid_active_list && (rc = e->alloc(&e->act_list, (size_t)v.B)))) return rc;
             e->hybrid = true;
         }
     }
@@ -1338,9 +1347,87 @@ int vf_engine_marginalize(vf_engine* e) {
     return VF_OK;
 }
 
+// ---- far between factors across a slide.  A far factor (a -> b) whose older keyframe a is about to leave the window is
+// TRANSPORTED to the next keyframe: with D = T_a^-1 T_a+1 at the current estimate, the measurement Z of T_a^-1 T_b becomes
+// Z' = D^-1 Z of T_a+1^-1 T_b -- the same residual Log(Z^-1 T_a^-1 T_b), in the same tangent frame (at b), so the square-root
+// information stays as it is.  D is known from the IMU factor between the two keyframes to ~2e-5 m / 2e-4 rad, against the
+// 1e-2 ... 0.5 m a between factor claims: treating it as exact is the approximation.  The information of a loop closure
+// thereby outlives the keyframe it was anchored on (iSAM2 keeps every factor for good, GraphManager.cpp:83-88); a factor
+// that reaches its own end keyframe (a + 1 == b) has nothing left to say and is dropped.  Host side: the lists are host
+// mirrors, two states are read back per window that has such a factor (rare: a synchronisation only then).
+namespace {
+void quat_to_rot_(const double* q, double* R) {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
+}
+void quat_mul_(const double* a, const double* b, double* o) {
+    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+}  // namespace
+static int transport_far(vf_engine* e) {
+    if (e->x_used == 0) return VF_OK;
+    for (int w = 0; w < e->v.B; w++) {
+        const int lo = e->h_lo[w];
+        bool any = false;
+        for (int i = 0; i < e->h_xn[w]; i++) any = any || e->h_xa[w][i] == lo;
+        if (!any || e->h_hi[w] - lo < 2) continue;
+        double st[32];
+        if (int rc = vf_engine_get_states(e, w, lo, 2, st)) return rc;
+        // D = T_lo^-1 T_lo+1
+        double R0[9], qc[4] = {st[0], -st[1], -st[2], -st[3]}, qD[4], dt[3] = {st[20] - st[4], st[21] - st[5], st[22] - st[6]}, tD[3];
+        quat_to_rot_(st, R0);
+        quat_mul_(qc, st + 16, qD);
+        for (int c = 0; c < 3; c++) tD[c] = R0[0 * 3 + c] * dt[0] + R0[1 * 3 + c] * dt[1] + R0[2 * 3 + c] * dt[2];
+        double RD[9], qDc[4] = {qD[0], -qD[1], -qD[2], -qD[3]};
+        quat_to_rot_(qD, RD);
+        std::vector<int> a, b;
+        std::vector<double> rec;
+        for (int i = 0; i < e->h_xn[w]; i++) {
+            double r[vf::BTW_IN];
+            memcpy(r, e->h_xrec[w].data() + (size_t)i * vf::BTW_IN, sizeof(r));
+            int ai = e->h_xa[w][i];
+            if (ai == lo) {
+                if (lo + 1 >= e->h_xb[w][i]) { e->far_ended++; continue; }      // reached its own end keyframe
+                double q2[4], d[3] = {r[4] - tD[0], r[5] - tD[1], r[6] - tD[2]};
+                quat_mul_(qDc, r, q2);                                          // R' = R_D^T R_Z
+                const double nq = std::sqrt(q2[0] * q2[0] + q2[1] * q2[1] + q2[2] * q2[2] + q2[3] * q2[3]);
+                for (int c = 0; c < 4; c++) r[c] = q2[c] / nq;
+                for (int c = 0; c < 3; c++) r[4 + c] = RD[0 * 3 + c] * d[0] + RD[1 * 3 + c] * d[1] + RD[2 * 3 + c] * d[2];   // t' = R_D^T (t_Z - t_D)
+                ai = lo + 1;
+                e->far_transported++;
+            }
+            a.push_back(ai);
+            b.push_back(e->h_xb[w][i]);
+            rec.insert(rec.end(), r, r + vf::BTW_IN);
+        }
+        if (int rc = vf_engine_set_extra_between(e, w, (int)a.size(), a.data(), b.data(), rec.data())) return rc;
+    }
+    return VF_OK;
+}
+int vf_engine_get_extra_between(vf_engine* e, int window, int* n, int32_t* a, int32_t* b, double* rec28, long* transported, long* ended) {
+    int rc = check_window(e, window);
+    if (rc) return rc;
+    const int cnt = e->v.x_max ? e->h_xn[window] : 0;
+    if (n) *n = cnt;
+    for (int i = 0; i < cnt; i++) {
+        if (a) a[i] = e->h_xa[window][i];
+        if (b) b[i] = e->h_xb[window][i];
+        if (rec28) memcpy(rec28 + (size_t)i * vf::BTW_IN, e->h_xrec[window].data() + (size_t)i * vf::BTW_IN, sizeof(double) * vf::BTW_IN);
+    }
+    if (transported) *transported = e->far_transported;
+    if (ended) *ended = e->far_ended;
+    return VF_OK;
+}
+
 int vf_engine_drop_oldest(vf_engine* e) {
     DeviceGuard dev_guard_(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (int rc = transport_far(e)) return rc;
     for (int w = 0; w < e->v.B; w++) {
         if (e->h_hi[w] - e->h_lo[w] < 2) return fail(VF_ERR_INVALID, "window %d too short", w);
         const int lo = e->h_lo[w] + 1;
@@ -1360,6 +1447,7 @@ int vf_engine_slide(vf_engine* e, const double* prior_sigma15, int marginalize) 
         int rc = vf_engine_marginalize(e);
         if (rc) return rc;
     }
+    if (int rc = transport_far(e)) return rc;
     if (e->warm) e->slid++;   // a slide is a change a warm start knows how to follow
     // the sigmas are a caller temporary: uploaded (and waited for) only when they differ from what the device already holds, so
     // that a run of updates with the same sigmas -- every fixed-lag loop -- enqueues without a host synchronisation

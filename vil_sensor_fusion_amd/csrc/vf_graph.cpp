@@ -32,7 +32,7 @@ struct PendingImu {            // one queued CombinedImuFactor (GraphManager::_i
     double bias[6];            // getBias() at reserveNode time (GraphManager.cpp:61)
     std::vector<double> record; // non-empty: a ready-made factor handed in through vf_add_imu_factor (addFactor), 190 doubles
 };
-struct PendingBetween { uint64_t a, b; double rec[VF_BTW_RECORD]; };
+struct PendingBetween { uint64_t a, b; double rec[VF_BTW_RECORD]; bool on_device = false; };
 
 // R upper-triangular, R^T R = cov^-1 (noiseModel::Gaussian::Covariance, SensorManagerRos.cpp:99).
 // 6x6 noise-model construction is factor *construction*, done once per measurement on the host
@@ -79,8 +79,9 @@ struct vf_graph {
     std::deque<PendingImu> imu_queue;
     std::vector<PendingBetween> staged_between;
     // Between factors the band cannot hold -- wider than VF_MAX_BANDWIDTH keyframes, or a second one ending at a key (loop
-    // closures; iSAM2 takes any pair of keys, GraphManager.cpp:83-88): kept here for as long as both keys are in the window
-    // and handed to the engine as "far" factors (vf_engine_set_extra_between) at every solve.  band_end[k] != 0: key k
+    // closures; iSAM2 takes any pair of keys, GraphManager.cpp:83-88): handed to the engine as "far" factors
+    // (vf_engine_set_extra_between) at every solve.  When the older key of one leaves the fixed-lag window the engine
+    // transports the factor to the next keyframe (vf_engine_drop_oldest; include/vilfusion.h) and the entry here follows.  band_end[k] != 0: key k
     // already carries a band factor.  far_new counts the ones added since the last solve (they are part of graph()->size()).
     std::vector<PendingBetween> far_between;
     std::deque<uint8_t> band_end;      // entry i: key band_base + i (trimmed below the window at every solve)
@@ -380,6 +381,8 @@ int vf_solve(vf_graph* g) {
     uint64_t last_key;
     double last_time;
     int staged_before, far_new_before = 0;
+    bool fars_changed = false;
+    size_t fars_snapshot = 0;
     bool late_far = false;          // a far factor added since the last solve whose older key had already left the window
     unsigned long long late_a = 0, late_b = 0;
     int late_n = 0;
@@ -406,6 +409,7 @@ int vf_solve(vf_graph* g) {
             fb.erase(std::remove_if(fb.begin(), fb.end(), [&](const PendingBetween& f) { return f.a < oldest; }), fb.end());
         }
         fars = g->far_between;
+        fars_snapshot = fars.size();
         far_new_before = g->far_new - late_n;      // (the late ones have just been erased and are reported below)
         g->far_new = 0;
         staged_before = g->staged_count - late_n;
@@ -514,13 +518,36 @@ int vf_solve(vf_graph* g) {
     // fixed-lag window: marginalise the keyframes that fall out of the lag, one at a time, at the
     // linearisation of the previous solve (their factors have not changed since)
     const int last_slot = (int)(last_key - g->key_base);
+    bool marginalised = false;
     while (g->opts.lag > 0 && last_slot + 1 - g->lo > g->opts.lag && (int)(g->solved_key - g->key_base) - g->lo >= 3) {
         if ((rc = vf_engine_marginalize(g->eng))) return give_back(rc);
         if ((rc = vf_engine_drop_oldest(g->eng))) return give_back(rc);
         g->lo++;      // (kept in step with the device: a keyframe that has been marginalised stays marginalised)
+        marginalised = true;
     }
     const int lo = g->lo;
     lap("marginalize");
+    if (marginalised && g->far_on_device) {
+        // the engine has moved the far factors whose older key left on to the next keyframe (or dropped one that reached its
+        // own end): the entries that were on the device are replaced by what the engine holds now
+        int cnt = 0;
+        int32_t ea[VF_MAX_EXTRA], eb[VF_MAX_EXTRA];
+        double erec[VF_MAX_EXTRA * VF_BTW_RECORD];
+        if ((rc = vf_engine_get_extra_between(g->eng, 0, &cnt, ea, eb, erec, nullptr, nullptr))) return give_back(rc);
+        std::vector<PendingBetween> moved;
+        for (int i = 0; i < cnt; i++) {
+            PendingBetween f;
+            f.a = (uint64_t)ea[i] + g->key_base;
+            f.b = (uint64_t)eb[i] + g->key_base;
+            memcpy(f.rec, erec + (size_t)i * VF_BTW_RECORD, sizeof(f.rec));
+            f.on_device = true;
+            moved.push_back(f);
+        }
+        for (const auto& f : fars)
+            if (!f.on_device) moved.push_back(f);
+        fars.swap(moved);
+        fars_changed = true;
+    }
     if (!fars.empty() || g->far_on_device) {
         // far between factors still inside the window, in window-local slots (the engine ignores one whose older keyframe
         // is below `lo`; the list is re-sent at every solve, so compaction and growth need no bookkeeping here)
@@ -534,6 +561,8 @@ int vf_solve(vf_graph* g) {
         }
         if ((rc = vf_engine_set_extra_between(g->eng, 0, (int)a.size(), a.data(), b.data(), rec.data()))) return give_back(rc);
         g->far_on_device = !a.empty();
+        for (auto& f : fars)
+            if (!(f.a < g->key_base + (uint64_t)lo || f.b > last_key)) { fars_changed = fars_changed || !f.on_device; f.on_device = true; }
         lap("set_extra");
     }
     if ((rc = vf_engine_set_range(g->eng, 0, lo, last_slot + 1))) return give_back(rc);
@@ -559,6 +588,16 @@ int vf_solve(vf_graph* g) {
     return VF_OK;
     };
     const int rc = locked();
+    if (fars_changed) {
+        // the entries snapshotted above are the front of the list (others only append, under graph_mutex): replace them by
+        // their current form (transported keys / records, on_device marks)
+        std::lock_guard<std::mutex> lk(g->graph_mutex);
+        if (g->far_between.size() >= fars_snapshot) {
+            std::vector<PendingBetween> now(fars);
+            now.insert(now.end(), g->far_between.begin() + (long)fars_snapshot, g->far_between.end());
+            g->far_between.swap(now);
+        }
+    }
     if (requeue) {
         std::lock_guard<std::mutex> lk(g->graph_mutex);
         for (auto it = imus.rbegin(); it != imus.rend(); ++it) g->imu_queue.push_front(std::move(*it));

@@ -39,6 +39,12 @@ VF_DI bool gated_off(const View& v) {
     return v.gate == 1 ? na <= v.gate_T : na > v.gate_T;
 }
 
+// one-wave sweeps: workgroup `slot` -> window (identity unless the launch carries the compacted list of active windows)
+VF_DI int sweep_window(const View& v, int slot) {
+    if (!v.act) return slot;
+    return slot < *v.n_active ? v.act[slot] : -1;
+}
+
 // Time-sharded windows: the window-local keyframe range [klo, khi) and the chunk range [c0, c1) rank sh_r owns.
 // A chunk owns its interior keyframes and the separator that follows it; a factor belongs to its later keyframe.
 VF_DI void own_chunks(const View& v, int Pe, int& c0, int& c1) {
@@ -2403,8 +2409,8 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 }
 
 __global__ void __launch_bounds__(64) k_band_solve(View v) {
-    const int w = blockIdx.x;
-    if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
+    const int w = sweep_window(v, blockIdx.x);
+    if (w < 0 || v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
     __shared__ double S[S_TOTAL];
     band_solve_body<SOLVE_FULL>(v, S, nullptr, nullptr, w, threadIdx.x, 0);
 }
@@ -2412,16 +2418,16 @@ __global__ void __launch_bounds__(64) k_band_solve(View v) {
 // the split form (see SOLVE_FULL_FWD / SOLVE_FULL_BWD)
 __attribute__((amdgpu_waves_per_eu(2, 2)))
 __global__ void __launch_bounds__(64) k_band_forward(View v) {
-    const int w = blockIdx.x;
-    if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
+    const int w = sweep_window(v, blockIdx.x);
+    if (w < 0 || v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
     __shared__ double S[CW_TOTAL];
     band_solve_body<SOLVE_FULL_FWD>(v, S, nullptr, nullptr, w, threadIdx.x, 0);
 }
 // the assembling form (see SOLVE_ASM_FWD): one wave per SIMD, 39.7 KB of LDS; followed by k_band_backward
 __attribute__((amdgpu_waves_per_eu(1, 1)))
 __global__ void __launch_bounds__(64) k_band_forward_asm(View v) {
-    const int w = blockIdx.x;
-    if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
+    const int w = sweep_window(v, blockIdx.x);
+    if (w < 0 || v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
     __shared__ __attribute__((aligned(16))) double S[AS_TOTAL];
     band_solve_body<SOLVE_ASM_FWD>(v, S, nullptr, nullptr, w, threadIdx.x, 0);
 }
@@ -2444,8 +2450,8 @@ __global__ void __launch_bounds__(128) k_band_forward_asm2(View v, int w0) {
 }
 __attribute__((amdgpu_waves_per_eu(2, 2)))
 __global__ void __launch_bounds__(64) k_band_backward(View v) {
-    const int w = blockIdx.x;
-    if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
+    const int w = sweep_window(v, blockIdx.x);
+    if (w < 0 || v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
     // the back substitution touches nothing of the trailing window [0, S_GD + 64): its LDS starts at the write sink
     __shared__ double Sb[S_TOTAL - S_DUMP];
     band_solve_body<SOLVE_FULL_BWD>(v, Sb - S_DUMP, nullptr, nullptr, w, threadIdx.x, 0);
@@ -3311,7 +3317,8 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
     // of the anchor prior, which decays with every marginalisation until it is below the rounding of the 1e9-scale entries
     // beside it (cond(H) 5e12 after 100 updates of a 200-keyframe window, 1e16 after 2 000, indefinite after 3 000: LM trials
     // rejected at random, then failed solves).  Eigenvalues of G^T L G that have fallen below the floor are lifted back to it
-    // (1e-3 = a 30 m sigma on WHERE the window is: nothing the factors can see).
+    // (the default keeps the window's softest eigenvalue at 3e-4, two orders above the rounding of its largest entries: for
+    // 1 000 keyframes an information of 0.1 on WHERE the window is, a 3 m sigma -- nothing the factors can see).
     if (v.gauge_floor > 0.0) {
         __shared__ double Gq[27 * 4], Tq[27 * 4], Mq[16], Vq[16], lift[4];
         for (int e = lane; e < 729; e += 256) {          // the symmetric part, in place
@@ -3394,7 +3401,10 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
                             Mq[q * 4 + kk] = sn * mpk + c * mqk;
                         }
                     }
-            for (int e = 0; e < 4; e++) { const double l = v.gauge_floor - Mq[e * 4 + e]; lift[e] = l > 0.0 ? l : 0.0; }
+            // (the floor is set on the WINDOW's eigenvalue: a unit gauge vector of an n-keyframe window has 3 / n of its weight
+            // on the three keyframes this prior touches)
+            const double floor_p = v.gauge_floor * (double)(v.hi[w] - v.lo[w]) / 3.0;
+            for (int e = 0; e < 4; e++) { const double l = floor_p - Mq[e * 4 + e]; lift[e] = l > 0.0 ? l : 0.0; }
         }
         __syncthreads();
         if (lane < 108) {                                // q_e = G V[:, e]
@@ -3636,14 +3646,29 @@ void launch_band_solve(const View& v, hipStream_t s) {
 }
 // windows of the running solve that still take LM trials (termination rule on)
 __global__ void __launch_bounds__(1024) k_count_active(View v) {
-    __shared__ int cnt;
-    if (threadIdx.x == 0) cnt = 0;
+    // ... and their compacted list, in window order (a block-wide inclusive scan per 1024 windows)
+    __shared__ int scan[1024];
+    __shared__ int base;
+    const int tid = threadIdx.x;
+    if (tid == 0) base = 0;
     __syncthreads();
-    int mine = 0;
-    for (int w = threadIdx.x; w < v.B; w += blockDim.x) mine += (v.hi[w] > v.lo[w] && !v.done[w]) ? 1 : 0;
-    if (mine) atomicAdd(&cnt, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) *v.n_active = cnt;
+    for (int w0 = 0; w0 < v.B; w0 += 1024) {
+        const int w = w0 + tid;
+        const int on = (w < v.B && v.hi[w] > v.lo[w] && !v.done[w]) ? 1 : 0;
+        scan[tid] = on;
+        __syncthreads();
+        for (int st = 1; st < 1024; st <<= 1) {
+            const int add = tid >= st ? scan[tid - st] : 0;
+            __syncthreads();
+            scan[tid] += add;
+            __syncthreads();
+        }
+        if (on && v.act) v.act[base + scan[tid] - 1] = w;
+        __syncthreads();
+        if (tid == 0) base += scan[1023];
+        __syncthreads();
+    }
+    if (tid == 0) *v.n_active = base;
 }
 void launch_count_active(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_count_active, dim3(1), dim3(1024), 0, s, v);
@@ -3652,6 +3677,7 @@ void launch_band_solve_hybrid(const View& v, const View& vp, hipStream_t s) {
     View a = v, b = vp;
     a.gate = 1;
     b.gate = 2;
+    // (a.act, when the engine has allocated it: the sweeps visit the active windows first)
     if (asm_in_hybrid(v)) {
         // (one wave per window here: with part of the windows done the two-wave form measured 5 % slower, bench `with_convergence_exit`)
         hipLaunchKernelGGL(k_band_forward_asm, dim3(a.B), dim3(64), 0, s, a);

@@ -186,6 +186,8 @@ struct View {
     // than gate_T windows are active), 2 = this is the partitioned form (runs otherwise).
     int* n_active;      // [1]  windows of the current solve that still take trials (k_count_active)
     int gate, gate_T;
+    int* act;           // [B] or null: compacted list of the windows still taking trials (k_count_active); the one-wave sweeps of a hybrid
+                        // solve then map workgroup i to window act[i], so that the active windows are dispatched first and contiguously
     int tw_max;         // whole-window sweeps: up to this many windows two waves per window from both ends, above one wave per window
     int split_min;      // whole-window sweeps: from this many windows on, forward sweep and back substitution as two kernels (0 = never)
     int asm_min;        // whole-window sweeps: from this many windows on, the forward sweep assembles H itself from the J stream and

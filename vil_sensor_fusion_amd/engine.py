@@ -54,6 +54,7 @@ class EngineOpts:
     refine_min_keyframes: int | None = None
     refine_rel_stop: float | None = None
     gauge_floor: float | None = None     # floor of the marginal prior's information about global translation / yaw (None = default 1e-3; 0 = off)
+    hybrid_active_list: int | None = None  # hybrid solves: sweeps take their windows from the compacted list of active ones (None = default 1)
     lm_excursion: int | None = None      # non-monotone LM: provisional cost-raising trials per excursion (None = default: 3 on refining engines)
 
 
@@ -80,7 +81,7 @@ class Engine:
             o.solve_assemble_min = opts.solve_assemble_min
         if opts.solve_assemble_waves is not None:
             o.solve_assemble_waves = opts.solve_assemble_waves
-        for name in ("refine_iterations", "refine_min_keyframes", "refine_rel_stop", "lm_excursion", "gauge_floor"):
+        for name in ("refine_iterations", "refine_min_keyframes", "refine_rel_stop", "lm_excursion", "gauge_floor", "hybrid_active_list"):
             if getattr(opts, name) is not None:
                 setattr(o, name, getattr(opts, name))
         self._h = C.c_void_p()
@@ -131,6 +132,13 @@ class Engine:
         r = np.ascontiguousarray(rec, dtype=np.float64).reshape(-1, BTW_RECORD)
         assert a.size == b.size == r.shape[0]
         check(self._l.vf_engine_set_extra_between(self._h, window, a.size, _i(a), _i(b), _d(r)))
+
+    def get_extra_between(self, window):
+        """(a, b, records, transported so far, dropped at their own end so far): the window's far factors as they stand"""
+        n, tr, en = C.c_int(), C.c_long(), C.c_long()
+        a, b, r = np.zeros(8, dtype=np.int32), np.zeros(8, dtype=np.int32), np.zeros((8, BTW_RECORD))
+        check(self._l.vf_engine_get_extra_between(self._h, window, C.byref(n), _i(a), _i(b), _d(r), C.byref(tr), C.byref(en)))
+        return a[:n.value].copy(), b[:n.value].copy(), r[:n.value].copy(), tr.value, en.value
 
     def clear_between(self, window, k0, n):
         check(self._l.vf_engine_clear_between(self._h, window, k0, n))

@@ -143,6 +143,7 @@ def test_far_factors_survive_compaction_and_growth(lag):
     """The far list lives in window-local slots on the device and in absolute keys in the GraphManager: a handle whose engine
     compacts (fixed lag, 64 slots) or grows (whole history, 64 initial slots) while far factors are alive must publish what a
     roomy handle publishes; in fixed-lag mode the factors also age out of the window one after the other."""
+    from tests.test_gpu_graph_manager import _stream
     from vil_sensor_fusion_amd.graph_manager import GraphManager
     n = 230
     seq = synth.make_sequence(74, n)

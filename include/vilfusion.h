@@ -174,13 +174,15 @@ int vf_engine_clear_between(vf_engine* e, int window, int k0, int n);
  * current estimate of T_a^-1 T_a+1 its measurement becomes D^-1 Z -- the same residual in the same tangent frame, D taken
  * as exact (the IMU factor between the two knows it to 2e-5 m, a between factor claims 1e-2 ... 0.5 m) -- so the information
  * of a loop closure outlives the keyframe it was anchored on, as in the reference's unbounded graph (GraphManager.cpp:83-88);
- * one that reaches its own end keyframe is dropped.  Engines holding far factors start every solve cold.  Not for
+ * once the factor is short enough to lie within the marginal prior's reach (it ends at a + 1 .. a + 3) the marginalisation of a
+ * absorbs it into the prior exactly as it absorbs a band factor, so its information outlives BOTH its ends.  Engines holding far factors start every solve cold.  Not for
  * time-sharded engines. */
 int vf_engine_set_extra_between(vf_engine* e, int window, int n, const int32_t* a, const int32_t* b, const double* rec28);
 /* the window's far factors as they stand (vf_engine_slide / vf_engine_drop_oldest TRANSPORT a far factor whose older keyframe
- * leaves the window to the next keyframe -- see below), and how many were transported / dropped at their own end keyframe
- * over the life of the engine; any output pointer may be NULL */
-int vf_engine_get_extra_between(vf_engine* e, int window, int* n, int32_t* a, int32_t* b, double* rec28, long* transported, long* ended);
+ * leaves the window to the next keyframe -- see below), and how many were transported / dropped by a slide that does not
+ * marginalise / absorbed into the marginal prior over the life of the engine; any output pointer may be NULL */
+int vf_engine_get_extra_between(vf_engine* e, int window, int* n, int32_t* a, int32_t* b, double* rec28, long* transported, long* ended,
+                                long* absorbed);
 /* the three priors of GraphManager.cpp:27-35 as one diagonal 15-row factor on keyframe k */
 int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec31);
 

@@ -49,7 +49,7 @@ int vf_engine_marginalize(vf_engine*) { return VF_OK; }
 int vf_engine_drop_oldest(vf_engine* e) {
     std::vector<FarEntry> keep;
     for (auto f : e->far) {
-        if (f.a == e->lo) { if (f.a + 1 >= f.b) continue; f.a++; }
+        if (f.a == e->lo) { if (f.b - f.a <= 3) continue; f.a++; }      // (short enough for the marginal prior: absorbed)
         keep.push_back(f);
     }
     e->far.swap(keep);
@@ -61,7 +61,7 @@ int vf_engine_compact(vf_engine* e, int shift) {
     e->lo -= shift; e->hi -= shift;
     return VF_OK;
 }
-int vf_engine_get_extra_between(vf_engine* e, int, int* n, int32_t* a, int32_t* b, double* rec, long* tr, long* en) {
+int vf_engine_get_extra_between(vf_engine* e, int, int* n, int32_t* a, int32_t* b, double* rec, long* tr, long* en, long* ab) {
     if (n) *n = (int)e->far.size();
     for (size_t i = 0; i < e->far.size(); i++) {
         if (a) a[i] = e->far[i].a;
@@ -70,6 +70,7 @@ int vf_engine_get_extra_between(vf_engine* e, int, int* n, int32_t* a, int32_t* 
     }
     if (tr) *tr = 0;
     if (en) *en = 0;
+    if (ab) *ab = 0;
     return VF_OK;
 }
 int vf_engine_grow(vf_engine*, int) { return VF_OK; }

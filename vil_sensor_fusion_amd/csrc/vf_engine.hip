@@ -164,7 +164,9 @@ struct vf_engine {
     double* x_gtmp = nullptr;
     double* x_Z = nullptr;
     size_t x_zstride = 0;
-    long far_transported = 0, far_ended = 0;   // far factors moved on to the next keyframe when theirs left the window / dropped at their own end
+    long far_transported = 0, far_ended = 0, far_absorbed = 0;   // far factors moved on to the next keyframe when theirs left the window /
+                                                                 // dropped without a marginalisation / absorbed into the marginal prior
+    bool marg_since_drop = false;   // vf_engine_marginalize ran since the last vf_engine_drop_oldest (the GraphManager's call pair)
     int x_zslots = 0;          // slots x_Z holds columns for (6 columns each); grown on demand, never beyond VF_MAX_EXTRA
     // the device lists are allocated once (they stay in `allocs`); a failure half way leaves what exists in place and a
     // later call picks up from there (no second allocation, nothing leaked)
@@ -1344,6 +1346,7 @@ int vf_engine_marginalize(vf_engine* e) {
     HIPCHK(hipMemcpyAsync(&status, e->status_dev, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (status) return fail(VF_ERR_INDETERMINATE, "marginalisation: pivot block of the oldest keyframe not positive definite");
+    e->marg_since_drop = true;
     return VF_OK;
 }
 
@@ -1369,7 +1372,7 @@ void quat_mul_(const double* a, const double* b, double* o) {
     o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
 }
 }  // namespace
-static int transport_far(vf_engine* e) {
+static int transport_far(vf_engine* e, bool marginalised) {
     if (e->x_used == 0) return VF_OK;
     for (int w = 0; w < e->v.B; w++) {
         const int lo = e->h_lo[w];
@@ -1392,7 +1395,10 @@ static int transport_far(vf_engine* e) {
             memcpy(r, e->h_xrec[w].data() + (size_t)i * vf::BTW_IN, sizeof(r));
             int ai = e->h_xa[w][i];
             if (ai == lo) {
-                if (lo + 1 >= e->h_xb[w][i]) { e->far_ended++; continue; }      // reached its own end keyframe
+                // within the marginal prior's reach (ends at lo+1 .. lo+3): k_marginalize has just absorbed it, like a band
+                // factor -- its information lives on in the prior; without a marginalisation (re-anchoring slide) it goes the
+                // way the band factors of the dropped keyframe go
+                if (e->h_xb[w][i] - lo <= 3) { if (marginalised) e->far_absorbed++; else e->far_ended++; continue; }
                 double q2[4], d[3] = {r[4] - tD[0], r[5] - tD[1], r[6] - tD[2]};
                 quat_mul_(qDc, r, q2);                                          // R' = R_D^T R_Z
                 const double nq = std::sqrt(q2[0] * q2[0] + q2[1] * q2[1] + q2[2] * q2[2] + q2[3] * q2[3]);
@@ -1409,7 +1415,7 @@ static int transport_far(vf_engine* e) {
     }
     return VF_OK;
 }
-int vf_engine_get_extra_between(vf_engine* e, int window, int* n, int32_t* a, int32_t* b, double* rec28, long* transported, long* ended) {
+int vf_engine_get_extra_between(vf_engine* e, int window, int* n, int32_t* a, int32_t* b, double* rec28, long* transported, long* ended, long* absorbed) {
     int rc = check_window(e, window);
     if (rc) return rc;
     const int cnt = e->v.x_max ? e->h_xn[window] : 0;
@@ -1421,13 +1427,15 @@ int vf_engine_get_extra_between(vf_engine* e, int window, int* n, int32_t* a, in
     }
     if (transported) *transported = e->far_transported;
     if (ended) *ended = e->far_ended;
+    if (absorbed) *absorbed = e->far_absorbed;
     return VF_OK;
 }
 
 int vf_engine_drop_oldest(vf_engine* e) {
     DeviceGuard dev_guard_(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
-    if (int rc = transport_far(e)) return rc;
+    if (int rc = transport_far(e, e->marg_since_drop)) return rc;
+    e->marg_since_drop = false;
     for (int w = 0; w < e->v.B; w++) {
         if (e->h_hi[w] - e->h_lo[w] < 2) return fail(VF_ERR_INVALID, "window %d too short", w);
         const int lo = e->h_lo[w] + 1;
@@ -1447,7 +1455,8 @@ int vf_engine_slide(vf_engine* e, const double* prior_sigma15, int marginalize) 
         int rc = vf_engine_marginalize(e);
         if (rc) return rc;
     }
-    if (int rc = transport_far(e)) return rc;
+    if (int rc = transport_far(e, marginalize != 0)) return rc;
+    e->marg_since_drop = false;
     if (e->warm) e->slid++;   // a slide is a change a warm start knows how to follow
     // the sigmas are a caller temporary: uploaded (and waited for) only when they differ from what the device already holds, so
     // that a run of updates with the same sigmas -- every fixed-lag loop -- enqueues without a host synchronisation

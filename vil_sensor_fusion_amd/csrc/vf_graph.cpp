@@ -533,7 +533,7 @@ int vf_solve(vf_graph* g) {
         int cnt = 0;
         int32_t ea[VF_MAX_EXTRA], eb[VF_MAX_EXTRA];
         double erec[VF_MAX_EXTRA * VF_BTW_RECORD];
-        if ((rc = vf_engine_get_extra_between(g->eng, 0, &cnt, ea, eb, erec, nullptr, nullptr))) return give_back(rc);
+        if ((rc = vf_engine_get_extra_between(g->eng, 0, &cnt, ea, eb, erec, nullptr, nullptr, nullptr))) return give_back(rc);
         std::vector<PendingBetween> moved;
         for (int i = 0; i < cnt; i++) {
             PendingBetween f;

@@ -3252,6 +3252,24 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
     // eighth of a GraphManager solve.)
     __shared__ double LJ[15 * 30 + 15];
     __shared__ double LBt[3 * BTW_OUT];
+    // far between factors that start at m and end within the prior's reach (m+1 .. m+3) are absorbed into the marginal prior
+    // like band factors: a far factor is transported from keyframe to keyframe while its anchor leaves the window (vf_engine.hip
+    // "transport_far") until it is this short, and its information then outlives both its ends
+    __shared__ double LXt[MAX_EXTRA * BTW_OUT];
+    __shared__ int xd[MAX_EXTRA];
+    if (lane < MAX_EXTRA) {
+        int d = 0;
+        if (lane < v.x_max) {
+            const int i = w * v.x_max + lane, a = v.x_a[i], kb = v.x_b[i];
+            if (a == lo && kb - lo >= 1 && kb - lo <= 3 && kb < hi) d = kb - lo;
+        }
+        xd[lane] = d;
+    }
+    __syncthreads();
+    for (int e = lane; e < MAX_EXTRA * BTW_OUT; e += 256) {
+        const int s = e / BTW_OUT, f = e - s * BTW_OUT;
+        LXt[e] = (s < v.x_max && xd[s]) ? v.x_out[(((size_t)b * v.B + w) * v.x_max + s) * BTW_OUT + f] : 0.0;
+    }
     for (int e = lane; e < 15 * 30 + 15; e += 256)
         LJ[e] = e < 450 ? jstream_entry(jbuf, g0 + 1, e / 30, e % 30) : imu[(size_t)(e - 450) * TILE];
     for (int e = lane; e < 3 * BTW_OUT; e += 256) {
@@ -3261,7 +3279,6 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
     }
     __syncthreads();
     auto JI = [&](int r, int c30) { return LJ[r * 30 + c30]; };
-    auto BT = [&](int d, int f) { return LBt[(d - 1) * BTW_OUT + f]; };
     // index maps of the 42-vector: [m:15][m+1:15][m+2 pose][m+3 pose]
     auto imu_c = [](int i) { return i < 15 ? imu_col(0, i) : imu_col(1, i - 15); };   // i < 30
     auto mp_i = [](int i) { return i < 15 ? i : (i < 21 ? i : (i >= 30 && i < 36 ? i - 9 : -1)); };   // 42-index -> 27-index
@@ -3273,16 +3290,18 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
             const int ci = imu_c(i);
             for (int r = 0; r < 15; r++) sum = fma(JI(r, ci), is_b ? LJ[450 + r] : JI(r, imu_c(j)), sum);
         }
-        for (int d = 1; d <= 3; d++) {      // between factors m -> m+d: Ja on m pose, Jb on (m+d) pose
-            if (!bd[d - 1]) continue;
+        for (int q = 0; q < 3 + MAX_EXTRA; q++) {      // between factors m -> m+d: Ja on m pose, Jb on (m+d) pose (band slots, then far slots)
+            const int d = q < 3 ? (bd[q] ? q + 1 : 0) : xd[q - 3];
+            if (!d) continue;
+            const double* F = q < 3 ? LBt + q * BTW_OUT : LXt + (q - 3) * BTW_OUT;
             const int ob = d == 1 ? 15 : (d == 2 ? 30 : 36);
             const int ia = i < 6 ? i : -1, ib = (i >= ob && i < ob + 6) ? i - ob : -1;
             const int ja = (!is_b && j < 6) ? j : -1, jb = (!is_b && j >= ob && j < ob + 6) ? j - ob : -1;
             if (ia < 0 && ib < 0) continue;
             if (!is_b && ja < 0 && jb < 0) continue;
             for (int r = 0; r < 6; r++) {
-                const double xi = ia >= 0 ? BT(d, 6 + r * 6 + ia) : BT(d, 42 + r * 6 + ib);
-                const double xj = is_b ? BT(d, r) : (ja >= 0 ? BT(d, 6 + r * 6 + ja) : BT(d, 42 + r * 6 + jb));
+                const double xi = ia >= 0 ? F[6 + r * 6 + ia] : F[42 + r * 6 + ib];
+                const double xj = is_b ? F[r] : (ja >= 0 ? F[6 + r * 6 + ja] : F[42 + r * 6 + jb]);
                 sum = fma(xi, xj, sum);
             }
         }

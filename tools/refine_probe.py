@@ -58,12 +58,35 @@ def lm(tag, trials, **opts):
     eng.close()
 
 
+def trace(steps=3, corrections=14):
+    """the refinement correction by correction (staged calls): how fast res . M^-1 res falls, and what each correction is worth in
+    the Gauss-Newton update it belongs to (ATE of the estimate one would get by stopping there)"""
+    eng = load(refine_iterations=corrections)
+    for it in range(steps):
+        eng.gn_begin(0.0)
+        eng.assemble(), eng.solve_local(), eng.solve_global()
+        theta = eng.get_states(0, 0, n)
+        eng.refine_begin()
+        row = []
+        for c in range(corrections):
+            eng.solve_local(), eng.solve_global(), eng.refine_step()
+            k, red = eng.read_refine(0)
+            row.append(f"{c + 1}:{red:.1e}" + ("" if k == c + 1 else "(stopped)"))
+        eng.refine_end()
+        eng.retract()
+        a, _ = helpers.ate(eng.get_estimate(0, 0, n), F["states"])
+        print(f"  GN update {it}: reduction of res.M^-1 res after each correction: {' '.join(row)}; ATE after the update {a:.3e} m", flush=True)
+    eng.close()
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["gn"]
     if "gn" in what:
         gn("partitioned, refined (auto)")
         gn("one sweep per window, refined", chunks=1, sweep_two_sided_max=0)
         gn("partitioned, NOT refined", steps=4, refine_iterations=0)
+    if "trace" in what:
+        trace()
     if "lm" in what:
         lm("LM, partitioned, refined, excursions (the defaults for a window this long)", 20)
         lm("LM, partitioned, refined, classical accept rule", 20, lm_excursion=0)

@@ -115,7 +115,8 @@ typedef struct {
      * refine_min_keyframes, none otherwise (the headline windows are untouched); 0 = never; N = always N (at most 64).
      * Refining engines run the two-kernel form (K3 + K4); windows holding far factors are not refined. */
     int refine_iterations;
-    int refine_min_keyframes;  /* default 2048 */
+    int refine_min_keyframes;  /* default 1536: Gauss-Newton by normal equations alone contracts by 0.025 per update at 1 250 keyframes, 0.1 at
+                                  1 500, 0.3 at 2 000, 0.7 at 3 000 and creeps beyond */
     double refine_rel_stop;    /* a window stops correcting once res . M^-1 res has fallen to this, squared, times its first value
                                   (default 1e-13), or stops being positive */
     /* Non-monotone LM ("excursions").  On a long window the Gauss-Newton step moves the far end by metres through

@@ -334,7 +334,7 @@ class Window:
            n_threads=1, rel_tol=0.0, abs_tol=0.0, accept_rel=None, refine=0, refine_rel_stop=1e-13, excursion=0):
         """refine / excursion: the engine's refined solve and non-monotone accept rule (vf_engine_opts.refine_iterations,
         lm_excursion); 0 / 0 = the classical normal-equation LM.  The engine switches both on by itself for windows longer
-        than 2048 keyframes; the oracle does what it is told."""
+        than 1536 keyframes; the oracle does what it is told."""
         o = LmOpts(lambda0, up, down, lmin, lmax, iterations, n_threads, rel_tol, abs_tol, ACCEPT_REL if accept_rel is None else accept_rel,
                    refine, refine_rel_stop, excursion)
         costs = np.zeros(iterations + 1)

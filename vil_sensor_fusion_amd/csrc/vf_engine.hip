@@ -281,7 +281,7 @@ void vf_engine_default_opts(vf_engine_opts* o) {
     o->solve_assemble_min = 768;
     o->solve_assemble_waves = 2;
     o->refine_iterations = -1;       // auto: windows longer than refine_min_keyframes
-    o->refine_min_keyframes = 2048;
+    o->refine_min_keyframes = 1536;
     o->refine_rel_stop = 1e-13;
     o->lm_excursion = -1;            // auto: 3 on engines that refine, classical LM otherwise
     o->gauge_floor = 3e-4;
@@ -1340,6 +1340,9 @@ int vf_engine_marginalize(vf_engine* e) {
     for (int w = 0; w < e->v.B; w++)
         if (e->h_hi[w] - e->h_lo[w] < 4) return fail(VF_ERR_INVALID, "window %d: marginalisation needs >= 4 keyframes", w);
     HIPCHK(hipMemsetAsync(e->status_dev, 0, sizeof(int), e->stream));
+    // far factors the prior is about to absorb: their linearisation at the current states (a compaction, a transport or any
+    // other re-sending of the list since the last solve has zeroed the buffers)
+    if (e->x_used > 0) vf::launch_linearize_extra(e->v, 0, e->stream);
     vf::launch_marginalize(e->v, e->status_dev, e->stream);
     HIPCHK(hipGetLastError());
     int status = 0;

@@ -129,7 +129,8 @@ struct View {
     double* zrow;       // [900] zeros
     double* delta;      // [G][15] + [B]       increments; tail: solve-failure flag per window (time-sharded windows: summed
                         //                     over the ranks together with the increments, one all-reduce)
-    double* Lp;         // [G][43][16]         Cholesky panels (15 of 16 columns used)
+    double* Lp;         // [G][PANEL = 550]    Cholesky panels packed to their profile ("Cholesky panel of one keyframe" above: 547 of the 43 x 15
+                        //                     doubles; vf_engine_read_panels hands out the documented [43][16])
     // partitioned solve (allocated when P >= 2)
     int P;              // chunks per window (0/1 = whole-window sweeps)
     int P_fit;          // 1: use fewer chunks on short windows (see chunk_count)

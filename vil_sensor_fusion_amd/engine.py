@@ -49,7 +49,7 @@ class EngineOpts:
     solve_assemble_min: int | None = None  # one-wave sweeps: from this many windows on, the forward sweep assembles H itself (no K3)
     solve_assemble_waves: int | None = None  # 1: one wave per window; 2: eliminator + assembler wave on one LDS image
     # refined solve (vf_engine_opts.refine_iterations): conjugate-gradient corrections through J after every solve.  None = the
-    # library's default (-1: 12 corrections once a window is longer than refine_min_keyframes = 2048), 0 = never, N = always N
+    # library's default (-1: 12 corrections once a window is longer than refine_min_keyframes = 1536), 0 = never, N = always N
     refine_iterations: int | None = None
     refine_min_keyframes: int | None = None
     refine_rel_stop: float | None = None

@@ -208,7 +208,7 @@ def test_lm_trajectory_parity(setup, oracle):
 
 
 @pytest.mark.parametrize("n,iters,chunks,refined", [(1000, 5, 0, False), (1000, 5, 1, False), (10000, 3, 0, False), (10000, 3, 1, False),
-                                                    (10000, 8, 0, True), (10000, 8, 1, True)])
+                                                    (10000, 12, 0, True), (10000, 12, 1, True)])
 def test_full_size_windows_vs_oracle(oracle, n, iters, chunks, refined):
     """BASELINE.json configs at full size: the 1000-pose window the metric is quoted on and the
     10 000-pose global smoother (here on one GPU), LM trajectory against the oracle; with the

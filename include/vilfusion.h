@@ -499,6 +499,10 @@ int vf_graph_staged(vf_graph* g, int* staged_factors, int* queued_imu_factors);
 /* diagnostics (extra): cost after the last solve and the LM trials accepted / rejected / failed (normal equations not
  * positive definite) over the life of the handle */
 int vf_graph_lm_stats(vf_graph* g, double* cost, int* accepted, int* rejected, int* solve_failures);
+/* diagnostics (extra): keyframes in the window of the last solve; conjugate-gradient corrections every solve of the handle's
+ * engine is now followed by (vf_engine_opts.refine_iterations: 0 until the window outgrows refine_min_keyframes -- a
+ * whole-history handle, lag = 0, gets there by itself -- 12 from then on); LM trials kept provisionally so far (lm_excursion) */
+int vf_graph_solver_info(vf_graph* g, int* window_keyframes, int* refine_corrections, int* provisional_trials);
 /* smoothed states of keys [key0, key0+n) after the last solve (extra; iSAM2 calculateEstimate) */
 int vf_get_trajectory(vf_graph* g, uint64_t key0, int n, double* state16);
 /* preintegrated record of the factor ending at `key` (extra; firstFactor->preintegratedMeasurements()) */

@@ -46,6 +46,8 @@ int vf_engine_set_extra_between(vf_engine* e, int, int n, const int32_t* a, cons
     return VF_OK;
 }
 int vf_engine_marginalize(vf_engine*) { return VF_OK; }
+int vf_engine_refine_count(vf_engine*, int* n) { if (n) *n = 0; return VF_OK; }
+int vf_engine_read_excursions(vf_engine*, int, int* a, int* b) { if (a) *a = 0; if (b) *b = 0; return VF_OK; }
 int vf_engine_drop_oldest(vf_engine* e) {
     std::vector<FarEntry> keep;
     for (auto f : e->far) {

@@ -471,3 +471,50 @@ def test_small_initial_capacity_grows_past_its_first_tile():
         gm.close()
     assert outs[0].shape == outs[1].shape and np.isfinite(outs[0]).all()
     assert np.abs(outs[0] - outs[1]).max() <= 1e-8
+
+
+@pytest.mark.parametrize("compat", [False, True])
+def test_whole_history_handle_crosses_the_refinement_threshold(oracle, compat):
+    """lag = 0 is the reference's mode (an unbounded iSAM2 graph, GraphManager.cpp:17-43), and its history grows past what
+    float64 normal equations resolve (vf_engine_opts.refine_min_keyframes = 1536: plain Gauss-Newton contracts by 0.3 per
+    update at 2 000 keyframes and creeps at 4 000).  The handle must switch to refined solves by itself when it
+    gets there: 1 900 keyframes fed like the node, a solve every 10; before the threshold no correction, after it 12 per
+    solve; the smoothed trajectory at the end against the oracle's refined batch optimum of the same factors (the device's
+    own IMU records) -- LM to convergence, and the reference-compat solve (one Gauss-Newton update per vf_solve)."""
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    n = 1900
+    seq = synth.make_sequence(75, n)
+    traj_t, acc, gyr = _stream(seq)
+    gm = GraphManager(capacity=2048, iterations=5, lag=0, reference_compat=compat, rel_tol=0.0, abs_tol=0.0)     # (every solve runs its 5 trials)
+    gm.setInitialState(seq.gt_states[0])
+    i_imu, seen = 0, {}
+    for k in range(1, n):
+        while i_imu < traj_t.size and traj_t[i_imu] <= seq.kf_time[k] + 0.01:
+            gm.addIMUMeasurement(traj_t[i_imu], acc[i_imu], gyr[i_imu])
+            i_imu += 1
+        gm.reserveNode(seq.kf_time[k])
+        for a, b, q, t, c in zip(seq.btw_a[seq.btw_b == k], seq.btw_b[seq.btw_b == k], seq.btw_q[seq.btw_b == k], seq.btw_t[seq.btw_b == k], seq.btw_cov[seq.btw_b == k]):
+            if a >= 1:
+                gm.addBetweenFactor(int(a), int(b), (q, t), np.eye(6) * c)
+        if k % 10 == 0 or k == n - 1:
+            gm.solve()
+            seen[k] = gm.solverInfo()
+    assert seen[1500][1] == 0 and seen[1500][0] == 1501          # below the threshold: the normal equations alone
+    assert seen[1600][1] == 12 and seen[n - 1] [1] == 12          # above it: 12 corrections per solve
+    for _ in range(3):
+        gm.solve()                                               # (reference-compat: a few more updates settle the last keyframes)
+    got = gm.trajectory(0, n)
+    recs = np.zeros((n, 190))
+    for k in range(1, n):
+        recs[k] = gm.imuFactor(k)
+    m = seq.btw_a >= 1
+    prob = dict(n=n, states=got.copy(), imu=recs, btw_a=seq.btw_a[m], btw_b=seq.btw_b[m], btw=synth.between_records(seq)[m],
+                prior=synth.prior_record(seq.gt_states[0], np.array([1e-6] * 3 + [5e-5] * 3 + [1e-5] * 3 + [1e-7] * 6)), gravity=np.array([0.0, 0.0, -9.81]))
+    win = helpers.oracle_window(oracle, prob)
+    for _ in range(4):
+        oracle.gn_step(win, refine=12)
+    a, r = helpers.ate(got, win.states)
+    st = gm.lmStats()
+    print(f"whole history, reference_compat={compat}: {n} keyframes, refinement on from 1 537; trajectory vs the oracle's refined optimum: ATE {a:.3e} m, rot {r:.3e} rad; lm {st}, provisional trials {seen[n - 1][2]}")
+    assert a <= 1e-6 and r <= 1e-6 and st["solve_failures"] == 0
+    gm.close()

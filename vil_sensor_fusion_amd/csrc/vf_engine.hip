@@ -1186,8 +1186,11 @@ int shard_solve(vf_engine* e, void* comm) {
     if (R > 0) {
         if ((rc = vf_engine_refine_begin(e))) return rc;
         for (int it = 0; it < R; it++)
-            if ((rc = exchange(e->rq.z)) || (rc = vf_engine_refine_step(e))) return rc;
-        if ((rc = vf_engine_refine_end(e))) return rc;
+            if ((rc = exchange(e->rq.z)) || (rc = vf_engine_refine_step(e))) {
+                e->refine_open = false;       // (a failed collective must not leave later solves on the correction's buffers)
+                return rc;
+            }
+        if ((rc = vf_engine_refine_end(e))) { e->refine_open = false; return rc; }
     }
     return VF_OK;
 }

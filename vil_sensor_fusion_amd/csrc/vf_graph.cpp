@@ -629,6 +629,16 @@ int vf_graph_lm_stats(vf_graph* g, double* cost, int* accepted, int* rejected, i
     return vf_engine_read_lm(g->eng, 0, cost, nullptr, accepted, rejected, solve_failures);
 }
 
+int vf_graph_solver_info(vf_graph* g, int* window_keyframes, int* refine_corrections, int* provisional_trials) {
+    if (!g) return gerr(VF_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->state_mutex);
+    if (window_keyframes) *window_keyframes = (int)(g->solved_key - g->key_base) + 1 - g->lo;
+    int rc;
+    if (refine_corrections && (rc = vf_engine_refine_count(g->eng, refine_corrections))) return rc;
+    if (provisional_trials && (rc = vf_engine_read_excursions(g->eng, 0, provisional_trials, nullptr))) return rc;
+    return VF_OK;
+}
+
 int vf_get_trajectory(vf_graph* g, uint64_t key0, int n, double* state16) {
     if (!g || !state16) return gerr(VF_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(g->state_mutex);

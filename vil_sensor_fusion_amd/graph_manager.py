@@ -146,6 +146,12 @@ class GraphManager:
         check(self._l.vf_graph_lm_stats(self._h, C.byref(c), C.byref(a), C.byref(r), C.byref(f)))
         return dict(cost=c.value, accepted=a.value, rejected=r.value, solve_failures=f.value)
 
+    def solverInfo(self):
+        """(keyframes in the window of the last solve, refinement corrections per solve now, provisional LM trials so far)"""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(self._l.vf_graph_solver_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def trajectory(self, key0, n):
         s = np.zeros((n, 16))
         check(self._l.vf_get_trajectory(self._h, C.c_uint64(key0), n, _d(s)))

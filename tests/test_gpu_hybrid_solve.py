@@ -12,9 +12,9 @@ from vil_sensor_fusion_amd import Engine, EngineOpts, synth
 pytestmark = pytest.mark.gpu
 
 
-def _run(threshold, probs, picks, n, B, iters):
+def _run(threshold, probs, picks, n, B, iters, active_list=None):
     """threshold = vf_engine_opts.hybrid_threshold (None: never the partitioned form)"""
-    eng = Engine(EngineOpts(windows=B, capacity=n + 10, hybrid_threshold=-1 if threshold is None else threshold))
+    eng = Engine(EngineOpts(windows=B, capacity=n + 10, hybrid_threshold=-1 if threshold is None else threshold, hybrid_active_list=active_list))
     for w, (lo, hi) in picks.items():
         helpers.load_engine(eng, w, probs[w], lo=lo, hi=hi)
     eng.set_convergence(1e-5, 1e-5)
@@ -46,3 +46,18 @@ def test_hybrid_solve_matches_sweeps_and_oracle(oracle):
             assert abs(lm["accepted"] + lm["rejected"] - trials) <= 1, (name, w, lm, trials)
         assert np.abs(mixed[w][0] - sweep[w][0]).max() <= 1e-9 and np.abs(always[w][0] - sweep[w][0]).max() <= 1e-9
     assert any(sweep[w][1]["accepted"] + sweep[w][1]["rejected"] < iters for w in picks)      # the rule did stop some windows early
+
+
+def test_compacted_active_list_changes_nothing_but_the_dispatch(oracle):
+    """vf_engine_opts.hybrid_active_list: under the termination rule the hybrid's one-wave sweeps take their windows from the
+    compacted list of those still taking trials (k_count_active), so that the active ones are dispatched first; window i is
+    then no longer workgroup i -- same windows, same arithmetic, the same bits as with the list off."""
+    n, B, iters = 120, 200, 8
+    picks = {w: (0, n - (w % 7)) for w in (0, 3, 50, 51, 52, 120, 199)}
+    probs = {w: helpers.build_problem(oracle, synth.make_sequence(seed=700 + w, n_kf=n), perturb=0.002 * (1 + w % 5)) for w in picks}
+    on = _run(3, probs, picks, n, B, iters, active_list=1)
+    off = _run(3, probs, picks, n, B, iters, active_list=0)
+    for w in picks:
+        np.testing.assert_array_equal(on[w][0], off[w][0])
+        assert on[w][1] == off[w][1]
+    assert len({on[w][1]["accepted"] + on[w][1]["rejected"] for w in picks}) > 1         # windows did stop at different trials

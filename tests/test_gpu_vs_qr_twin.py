@@ -218,3 +218,36 @@ def test_config4_lm_from_dead_reckoning_reaches_the_qr_optimum(form):
         print(f"   ... classical accept rule, 30 trials: {a:.3f} m away, cost {eng.read_lm(0)['cost']:.6f}")
         assert a > 1.0
         eng.close()
+
+
+def test_config4_a_failed_excursion_restores_the_point_it_left(oracle):
+    """The restore path of the non-monotone rule (k_decide outcome 3: the W + 1-th trial of an excursion is still above the cost
+    it started from -> the saved states come back, their factors are linearised again, lambda goes up): with lm_excursion = 1
+    the 10 000-pose window from dead reckoning alternates provisional trial / restore while lambda climbs (the damped
+    step's second-order terms raise the cost 13.4 -> 659 -> 38 ...), then finds its way down.  Device and oracle must take
+    the same decisions trial for trial; their states agree to what nine trials through costs of several thousand leave of
+    float64 (4e-5 m: the sequence is nowhere near converged -- convergence is the business of the tests above)."""
+    F = np.load(os.path.join(GOLD, "qr_twin_10k.npz"))
+    eng, n = _config4_engine(F, lm_excursion=1)
+    K = 9
+    eng.iterate(K)
+    lm, ex = eng.read_lm(0), eng.read_excursions(0)
+    seq = synth.make_sequence(seed=int(F["seed"]), n_kf=n)
+    recs = np.zeros((n, 190))
+    recs[1:] = eng.get_imu(0, 1, n - 1)
+    g = np.array([0.0, 0.0, -9.81])
+    x0 = np.zeros((n, 16))
+    x0[0] = seq.gt_states[0]
+    for k in range(1, n):
+        x0[k] = oracle.predict(recs[k], g, x0[k - 1])
+    prob = dict(n=n, states=x0, imu=recs, btw_a=seq.btw_a, btw_b=seq.btw_b, btw=synth.between_records(seq),
+                prior=synth.prior_record(seq.gt_states[0], REFERENCE_PRIOR_SIGMAS), gravity=g)
+    win = helpers.oracle_window(oracle, prob)
+    costs, acc, _ = win.lm(iterations=K, refine=12, excursion=1)
+    a, r = helpers.ate(eng.get_states(0, 0, n), win.states)
+    print(f"configs[4], lm_excursion = 1, {K} trials: oracle outcomes {acc.tolist()} costs {' '.join(f'{c:.6g}' for c in costs)}; device: {lm}, provisional {ex}; ATE device vs oracle {a:.3e} m")
+    assert int((acc == 3).sum()) >= 2                              # the restore path ran
+    assert lm["accepted"] == int((acc == 1).sum()) and lm["rejected"] == int(((acc == 0) | (acc == 3)).sum()) and ex[0] == int((acc == 2).sum())
+    assert abs(lm["cost"] - costs[-1]) <= 1e-4 * costs[-1] and a <= 1e-3 and r <= 1e-4 and lm["solve_failures"] == 0
+    assert lm["cost"] < costs[0] and ex[1] == 0                      # below where it started, no excursion left open
+    eng.close()

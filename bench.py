@@ -221,6 +221,16 @@ def cpu_baseline(args, seq_len):
                     host_cores_available=cores, wall_s_including_setup=wall,
                     sample=f"{cores} independent {n}-pose windows, one per core, {per} fixed-lag updates each (the same "
                            f"marginalised update), {args.iterations} LM trials per update; " + note)
+        # SURVEY 8d also names the other way a CPU can use its cores on this workload: ONE window, OpenMP over its factors
+        # (the oracle's linearisation loop; assembly, Cholesky and the cost stay serial, as in GTSAM without TBB).  Reported
+        # beside the other two: it is the latency form, the one-window-per-core figure above the throughput form.
+        try:
+            dt_omp, _, _ = _cpu_updates((2000, n, n + per + 1, per, args.iterations, cores, -1, args.init_iterations))
+            allc["one_window_openmp_over_factors"] = {"value": per / dt_omp, "unit": "keyframes/s", "threads": cores,
+                                                      "sample": f"{per} updates of one {n}-pose window, linearisation of its factors "
+                                                                f"on {cores} OpenMP threads, the rest serial"}
+        except Exception as exc:   # noqa: BLE001
+            allc["one_window_openmp_over_factors"] = {"error": f"{type(exc).__name__}: {exc}"}
     return one, allc, reference
 
 

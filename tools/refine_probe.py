@@ -85,6 +85,8 @@ if __name__ == "__main__":
         gn("partitioned, refined (auto)")
         gn("one sweep per window, refined", chunks=1, sweep_two_sided_max=0)
         gn("partitioned, NOT refined", steps=4, refine_iterations=0)
+    if "gnp" in what:
+        gn("partitioned, refined (auto)", steps=4)
     if "trace" in what:
         trace()
     if "lm" in what:

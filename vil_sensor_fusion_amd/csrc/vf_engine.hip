@@ -204,7 +204,8 @@ struct vf_engine {
         if ((rc = alloc(&rq.x, G * 15)) || (rc = alloc(&rq.p, G * 15)) || (rc = alloc(&rq.Ap, G * 15)) ||
             (rc = alloc(&rq.nres, G * 15 + 64)) || (rc = alloc(&rq.z, G * 15 + B)) || (rc = alloc(&rq.u_imu, G * 15)) ||
             (rc = alloc(&rq.u_btw, G * 6)) || (rc = alloc(&rq.u_pri, B * 15)) || (rc = alloc(&rq.rz, B)) ||
-            (rc = alloc(&rq.rz0, B)) || (rc = alloc(&rq.stop, B)) || (rc = alloc(&rq.iters, B))) return rc;
+            (rc = alloc(&rq.rz0, B)) || (rc = alloc(&rq.stop, B)) || (rc = alloc(&rq.iters, B)) ||
+            (rc = alloc(&rq.part, B * 64)) || (rc = alloc(&rq.coef, B)) || (rc = alloc(&rq.first, B))) return rc;
         rq_ready = true;
         return VF_OK;
     }

@@ -218,6 +218,9 @@ struct Refine {
     double* rz0;        // [B]                its first value
     int* stop;          // [B]                the window takes no further part (converged, failed, empty)
     int* iters;         // [B]                corrections applied in the last solve
+    double* part;       // [B][64]            partial sums of the two dot products of a correction (k_pcg_dot)
+    double* coef;       // [B]                beta / alpha of the step in flight (k_pcg_scalar -> k_pcg_axpy)
+    int* first;         // [B]                the direction in flight is the first one (p := z)
 };
 void launch_refine_begin(const View& v, const Refine& q, hipStream_t s);                  // x := delta, nres := g + A x
 void launch_refine_step(const View& v, const Refine& q, double rel_stop, hipStream_t s);  // after z := M^-1 res: direction, A p, update

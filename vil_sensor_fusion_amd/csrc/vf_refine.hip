@@ -13,8 +13,9 @@
 // outlier per iteration -- 8 to 10 iterations reach the accuracy of the QR step (DESIGN.md "Refined solve").  Textbook name:
 // CGLS preconditioned by the Cholesky factor of the normal equations (Bjorck, Numerical Methods for Least Squares Problems, 7.4).
 //
-// Every vector is increment-shaped ([G][15], a window's keyframes [lo, hi)); scalars are per window; reductions are fixed
-// trees inside one workgroup per window, so a solve is bitwise reproducible and identical on every rank of a time-sharded window.
+// Every vector is increment-shaped ([G][15], a window's keyframes [lo, hi)); scalars are per window; every sum is formed in one
+// fixed order (64 partial sums per window, added by one lane), so a solve is bitwise reproducible and identical on every rank of a
+// time-sharded window.
 #include "vf_kernels.hpp"
 #include "vf_jstream.hpp"
 
@@ -173,88 +174,103 @@ __global__ void __launch_bounds__(256) k_jtu(View v, Refine q, const double* __r
     for (int c = 0; c < 15; c++) out[(size_t)gk * 15 + c] = o[c];
 }
 
-// ---- per-window vector steps of the iteration: one 1024-thread workgroup per window, fixed-shape tree reductions
-VF_DI double block_sum(double s, double* red) {
-    const int tid = threadIdx.x;
-    red[tid] = s;
-    __syncthreads();
-    for (int st = 512; st > 0; st >>= 1) {
-        if (tid < st) red[tid] += red[tid + st];
-        __syncthreads();
-    }
-    const double t = red[0];
-    __syncthreads();
-    return t;
-}
+// ---- whole-vector steps at the ends of a refinement (PCG_NB workgroups per window, as the steps of a correction below)
+constexpr int PCG_NB = 64, PCG_NT = 256;
 // x := delta (the plain normal-equation solution the engine's solve has just left); a window whose factorisation failed
 // takes no part
-__global__ void __launch_bounds__(1024) k_pcg_begin(View v, Refine q) {
-    const int w = blockIdx.x, tid = threadIdx.x;
-    const int lo = v.lo[w], hi = v.hi[w];
-    if (tid == 0) { q.stop[w] = (solve_failed(v, w) || hi - lo <= 0 || (v.stop_on && v.done[w])) ? 1 : 0; q.rz[w] = -1.0; q.rz0[w] = 0.0; q.iters[w] = 0; }
+__global__ void __launch_bounds__(PCG_NT) k_pcg_begin(View v, Refine q) {
+    const int w = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x;
+    const int lo = v.lo[w], hi = v.hi[w], n = (hi - lo) * 15;
+    if (bx == 0 && tid == 0) { q.stop[w] = (solve_failed(v, w) || hi - lo <= 0 || (v.stop_on && v.done[w])) ? 1 : 0; q.rz[w] = -1.0; q.rz0[w] = 0.0; q.iters[w] = 0; }
+    if (n <= 0) return;
     const size_t o = ((size_t)w * v.M + lo) * 15;
-    for (int e = tid; e < (hi - lo) * 15; e += 1024) q.x[o + e] = v.delta[o + e];
+    const int per = (n + PCG_NB - 1) / PCG_NB, e0 = bx * per, e1 = min(n, e0 + per);
+    for (int e = e0 + tid; e < e1; e += PCG_NT) q.x[o + e] = v.delta[o + e];
 }
 // nres := g + A x  (= minus the residual of the normal equations at x, with A x evaluated through J; g = J^T r is in q.p,
 // formed by k_jtu<true>: the same on every rank of a time-sharded window, whose K3 assembles only the rank's own rows)
-__global__ void __launch_bounds__(1024) k_pcg_residual(View v, Refine q) {
-    const int w = blockIdx.x, tid = threadIdx.x;
-    if (refine_off(v, q, w)) return;
-    const int lo = v.lo[w], hi = v.hi[w];
-    const size_t o = ((size_t)w * v.M + lo) * 15;
-    for (int e = tid; e < (hi - lo) * 15; e += 1024) q.nres[o + e] = q.p[o + e] + q.Ap[o + e];
-}
-// after a correction solve z = M^-1 res (the engine's K4 run on nres):  rz' = res . z ;  p := z + (rz' / rz) p
-__global__ void __launch_bounds__(1024) k_pcg_direction(View v, Refine q, double rel_stop) {
-    __shared__ double red[1024];
-    const int w = blockIdx.x, tid = threadIdx.x;
-    if (refine_off(v, q, w)) return;                 // (uniform over the workgroup)
-    const int lo = v.lo[w], hi = v.hi[w], n = (hi - lo) * 15;
-    const size_t o = ((size_t)w * v.M + lo) * 15;
-    const double rz = q.rz[w], rz0 = q.rz0[w];       // (read before the reduction's barriers: lane 0 rewrites them at the end)
-    double s = 0.0;
-    for (int e = tid; e < n; e += 1024) s = fma(-q.nres[o + e], q.z[o + e], s);
-    const double rzn = block_sum(s, red);
-    const bool first = rz < 0.0;
-    // stop: the preconditioned residual has lost rel_stop^2 of its first value, or is no longer positive (rounding floor, or
-    // a correction solve that failed)
-    if (!(rzn > 0.0) || (!first && rzn <= rel_stop * rel_stop * rz0)) {
-        if (tid == 0) q.stop[w] = 1;
-        return;
-    }
-    const double beta = first ? 0.0 : rzn / rz;
-    for (int e = tid; e < n; e += 1024) q.p[o + e] = first ? q.z[o + e] : fma(beta, q.p[o + e], q.z[o + e]);
-    if (tid == 0) { q.rz[w] = rzn; if (first) q.rz0[w] = rzn; }
-}
-// alpha = rz / (p . A p) ;  x += alpha p ;  nres += alpha A p
-__global__ void __launch_bounds__(1024) k_pcg_update(View v, Refine q) {
-    __shared__ double red[1024];
-    const int w = blockIdx.x, tid = threadIdx.x;
+__global__ void __launch_bounds__(PCG_NT) k_pcg_residual(View v, Refine q) {
+    const int w = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x;
     if (refine_off(v, q, w)) return;
     const int lo = v.lo[w], hi = v.hi[w], n = (hi - lo) * 15;
     const size_t o = ((size_t)w * v.M + lo) * 15;
-    const double rz = q.rz[w];
+    const int per = (n + PCG_NB - 1) / PCG_NB, e0 = bx * per, e1 = min(n, e0 + per);
+    for (int e = e0 + tid; e < e1; e += PCG_NT) q.nres[o + e] = q.p[o + e] + q.Ap[o + e];
+}
+// ---- the two dot products and the two vector updates of a correction.  A window can be 10^4 keyframes long (150 000
+// entries): each step is three small launches -- partial sums by PCG_NB workgroups per window, one lane per window that adds
+// the partials in a fixed order and derives the step's scalars, PCG_NB workgroups per window applying them -- instead of one
+// 1024-thread workgroup walking the whole window (measured on the 10 000-pose window: 143 + 94 us per correction before,
+// against 600 us for the band solve the correction is made for).  Sums are formed in one fixed order whatever the rank.
+// mode 0: res . z = -nres . z ;  mode 1: p . A p
+__global__ void __launch_bounds__(PCG_NT) k_pcg_dot(View v, Refine q, int mode) {
+    __shared__ double red[PCG_NT];
+    const int w = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x;
+    if (refine_off(v, q, w)) return;
+    const int lo = v.lo[w], hi = v.hi[w], n = (hi - lo) * 15;
+    const size_t o = ((size_t)w * v.M + lo) * 15;
+    const int per = (n + PCG_NB - 1) / PCG_NB, e0 = bx * per, e1 = min(n, e0 + per);
+    const double* a = mode == 0 ? q.nres : q.p;
+    const double* b = mode == 0 ? q.z : q.Ap;
     double s = 0.0;
-    for (int e = tid; e < n; e += 1024) s = fma(q.p[o + e], q.Ap[o + e], s);
-    const double pAp = block_sum(s, red);
-    if (!(pAp > 0.0)) {
-        if (tid == 0) q.stop[w] = 1;
-        return;
+    for (int e = e0 + tid; e < e1; e += PCG_NT) s = fma(a[o + e], b[o + e], s);
+    red[tid] = s;
+    __syncthreads();
+    for (int st = PCG_NT / 2; st > 0; st >>= 1) {
+        if (tid < st) red[tid] += red[tid + st];
+        __syncthreads();
     }
-    const double alpha = rz / pAp;
-    for (int e = tid; e < n; e += 1024) {
-        q.x[o + e] = fma(alpha, q.p[o + e], q.x[o + e]);
-        q.nres[o + e] = fma(alpha, q.Ap[o + e], q.nres[o + e]);
+    if (tid == 0) q.part[(size_t)w * PCG_NB + bx] = mode == 0 ? -red[0] : red[0];
+}
+// one lane per window: the step's scalars.  mode 0 (after a correction solve z = M^-1 res): rz' = res . z, the stopping rule,
+// beta = rz' / rz (coef; first direction: p := z);  mode 1: alpha = rz / (p . A p) (coef)
+__global__ void __launch_bounds__(64) k_pcg_scalar(View v, Refine q, int mode, double rel_stop) {
+    const int w = blockIdx.x * 64 + threadIdx.x;
+    if (w >= v.B || refine_off(v, q, w)) return;
+    double s = 0.0;
+    for (int i = 0; i < PCG_NB; i++) s += q.part[(size_t)w * PCG_NB + i];
+    if (mode == 0) {
+        const double rz = q.rz[w], rz0 = q.rz0[w];
+        const bool first = rz < 0.0;
+        // stop: the preconditioned residual has lost rel_stop^2 of its first value, or is no longer positive (rounding floor,
+        // or a correction solve that failed)
+        if (!(s > 0.0) || (!first && s <= rel_stop * rel_stop * rz0)) { q.stop[w] = 1; return; }
+        q.coef[w] = first ? 0.0 : s / rz;
+        q.first[w] = first ? 1 : 0;
+        q.rz[w] = s;
+        if (first) q.rz0[w] = s;
+    } else {
+        if (!(s > 0.0)) { q.stop[w] = 1; return; }
+        q.coef[w] = q.rz[w] / s;
+        q.iters[w] += 1;
     }
-    if (tid == 0) q.iters[w] += 1;
+}
+// mode 0: p := z + beta p (first: p := z);  mode 1: x += alpha p, nres += alpha A p
+__global__ void __launch_bounds__(PCG_NT) k_pcg_axpy(View v, Refine q, int mode) {
+    const int w = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x;
+    if (refine_off(v, q, w)) return;
+    const int lo = v.lo[w], hi = v.hi[w], n = (hi - lo) * 15;
+    const size_t o = ((size_t)w * v.M + lo) * 15;
+    const int per = (n + PCG_NB - 1) / PCG_NB, e0 = bx * per, e1 = min(n, e0 + per);
+    const double c = q.coef[w];
+    if (mode == 0) {
+        const bool first = q.first[w] != 0;
+        for (int e = e0 + tid; e < e1; e += PCG_NT) q.p[o + e] = first ? q.z[o + e] : fma(c, q.p[o + e], q.z[o + e]);
+    } else {
+        for (int e = e0 + tid; e < e1; e += PCG_NT) {
+            q.x[o + e] = fma(c, q.p[o + e], q.x[o + e]);
+            q.nres[o + e] = fma(c, q.Ap[o + e], q.nres[o + e]);
+        }
+    }
 }
 // delta := x
-__global__ void __launch_bounds__(1024) k_pcg_end(View v, Refine q) {
-    const int w = blockIdx.x, tid = threadIdx.x;
-    const int lo = v.lo[w], hi = v.hi[w];
-    if (hi - lo <= 0 || solve_failed(v, w) || (v.stop_on && v.done[w])) return;
+__global__ void __launch_bounds__(PCG_NT) k_pcg_end(View v, Refine q) {
+    const int w = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x;
+    const int lo = v.lo[w], hi = v.hi[w], n = (hi - lo) * 15;
+    if (n <= 0 || solve_failed(v, w) || (v.stop_on && v.done[w])) return;
     const size_t o = ((size_t)w * v.M + lo) * 15;
-    for (int e = tid; e < (hi - lo) * 15; e += 1024) v.delta[o + e] = q.x[o + e];
+    const int per = (n + PCG_NB - 1) / PCG_NB, e0 = bx * per, e1 = min(n, e0 + per);
+    for (int e = e0 + tid; e < e1; e += PCG_NT) v.delta[o + e] = q.x[o + e];
 }
 
 static inline unsigned nblk_(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
@@ -263,18 +279,23 @@ void launch_refine_apply(const View& v, const Refine& q, const double* p, double
     hipLaunchKernelGGL(k_jtu<false>, dim3(nblk_(v.G, 256)), dim3(256), 0, s, v, q, p, out);
 }
 void launch_refine_begin(const View& v, const Refine& q, hipStream_t s) {
-    hipLaunchKernelGGL(k_pcg_begin, dim3(v.B), dim3(1024), 0, s, v, q);
+    hipLaunchKernelGGL(k_pcg_begin, dim3(PCG_NB, (unsigned)v.B), dim3(PCG_NT), 0, s, v, q);
     launch_refine_apply(v, q, q.x, q.Ap, s);
     hipLaunchKernelGGL(k_jtu<true>, dim3(nblk_(v.G, 256)), dim3(256), 0, s, v, q, q.x, q.p);     // q.p := J^T r (p has no direction yet)
-    hipLaunchKernelGGL(k_pcg_residual, dim3(v.B), dim3(1024), 0, s, v, q);
+    hipLaunchKernelGGL(k_pcg_residual, dim3(PCG_NB, (unsigned)v.B), dim3(PCG_NT), 0, s, v, q);
 }
 void launch_refine_step(const View& v, const Refine& q, double rel_stop, hipStream_t s) {
-    hipLaunchKernelGGL(k_pcg_direction, dim3(v.B), dim3(1024), 0, s, v, q, rel_stop);
+    const dim3 grid(PCG_NB, (unsigned)v.B);
+    hipLaunchKernelGGL(k_pcg_dot, grid, dim3(PCG_NT), 0, s, v, q, 0);
+    hipLaunchKernelGGL(k_pcg_scalar, dim3(nblk_(v.B, 64)), dim3(64), 0, s, v, q, 0, rel_stop);
+    hipLaunchKernelGGL(k_pcg_axpy, grid, dim3(PCG_NT), 0, s, v, q, 0);
     launch_refine_apply(v, q, q.p, q.Ap, s);
-    hipLaunchKernelGGL(k_pcg_update, dim3(v.B), dim3(1024), 0, s, v, q);
+    hipLaunchKernelGGL(k_pcg_dot, grid, dim3(PCG_NT), 0, s, v, q, 1);
+    hipLaunchKernelGGL(k_pcg_scalar, dim3(nblk_(v.B, 64)), dim3(64), 0, s, v, q, 1, rel_stop);
+    hipLaunchKernelGGL(k_pcg_axpy, grid, dim3(PCG_NT), 0, s, v, q, 1);
 }
 void launch_refine_end(const View& v, const Refine& q, hipStream_t s) {
-    hipLaunchKernelGGL(k_pcg_end, dim3(v.B), dim3(1024), 0, s, v, q);
+    hipLaunchKernelGGL(k_pcg_end, dim3(PCG_NB, (unsigned)v.B), dim3(PCG_NT), 0, s, v, q);
 }
 
 }  // namespace vf

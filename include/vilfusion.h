@@ -126,8 +126,11 @@ typedef struct {
      * valley (profiles/r04_config4_soft_mode.log; gtsam's own LM rule does the same).  With lm_excursion = W > 0 up to W
      * consecutive cost-raising trials are kept provisionally, each dividing lambda by lambda_down twice; a later trial whose
      * cost is below the cost the excursion started from accepts them all; if the W+1-th still is not, the starting point
-     * is restored, lambda multiplied by lambda_up, and the trials count as rejected.  0 = the classical rule; -1
-     * (default) = 3 on engines that refine (windows longer than refine_min_keyframes), 0 otherwise. */
+     * is restored, lambda multiplied by lambda_up, and the trials count as rejected.  An excursion still open when a solve's
+     * trials run out is undone.  Under this rule lambda PERSISTS from one solve to the next (the first starts from lambda0):
+     * lambda0 = 1e-5 is six orders above the soft eigenvalues of a window long enough to be refined, and a solve of five
+     * trials that starts there each time spends them all coming down, or repeats the same failed excursion for ever.  0 = the classical rule; -1 (default) = 3 on engines that refine (windows longer than
+     * refine_min_keyframes), 0 otherwise. */
     int lm_excursion;
     /* Gauge floor of the fixed-lag marginal prior (vf_engine_marginalize / vf_engine_slide(marginalize = 1); no reference code:
      * the reference's iSAM2 graph never marginalises).  Every factor of a window is invariant under a global translation and

@@ -1,0 +1,43 @@
+"""-m gpu: the library's DEFAULTS on windows past the reach of float64 normal equations (vf_engine_opts.refine_min_keyframes =
+1536), at lengths and on sequences other than the one BASELINE configs[4] fixture: from IMU dead reckoning, LM in
+solves of five trials (what a GraphManager's vf_solve runs) and the reference's Gauss-Newton updates, against the oracle's
+refined optimum of the same factors.  What this pins beside convergence itself: the damping persists from one solve to the next
+under the non-monotone rule (a solve of five trials that restarted from lambda0 each time never got a 6 000-keyframe window
+out of its first excursion, and crept at 8 000), and the windows just above the threshold behave like the ones far above it."""
+import numpy as np
+import pytest
+
+from tests import helpers
+from vil_sensor_fusion_amd import Engine, EngineOpts, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,seed", [(1600, 11), (2500, 12), (6000, 12)])
+def test_defaults_converge_long_windows_from_dead_reckoning(oracle, n, seed):
+    seq = synth.make_sequence(seed=seed, n_kf=n)
+    prob = helpers.build_problem(oracle, seq)
+    ref = helpers.oracle_window(oracle, prob)
+    for _ in range(7):
+        oracle.gn_step(ref, refine=12)
+    start = helpers.ate(prob["states"], ref.states)[0]
+    eng = Engine(EngineOpts(windows=1, capacity=n))
+    helpers.load_engine(eng, 0, prob)
+    assert eng.refine_count() == 12
+    hist = []
+    for _ in range(3):
+        eng.iterate(5)
+        hist.append(helpers.ate(eng.get_states(0, 0, n), ref.states)[0])
+    lm, ex = eng.read_lm(0), eng.read_excursions(0)
+    eng.close()
+    eng = Engine(EngineOpts(windows=1, capacity=n))
+    helpers.load_engine(eng, 0, prob)
+    gn = []
+    for _ in range(5):
+        eng.isam_step(0.0)
+        gn.append(helpers.ate(eng.get_estimate(0, 0, n), ref.states)[0])
+    eng.close()
+    print(f"n = {n}, seed {seed}: dead reckoning {start:.2f} m from the oracle's refined optimum; LM after 5 / 10 / 15 trials: "
+          f"{' '.join(f'{a:.1e}' for a in hist)} m ({lm['accepted']} accepted, {ex[0]} provisional, {lm['rejected']} rejected); Gauss-Newton per update: "
+          f"{' '.join(f'{a:.1e}' for a in gn)} m")
+    assert start > 0.5 and hist[-1] <= 1e-6 and gn[-1] <= 1e-6 and lm["solve_failures"] == 0 and ex[1] == 0

@@ -3140,7 +3140,18 @@ __global__ void __launch_bounds__(1024) k_close_excursion(View v) {
         const int cc = e / (hi - lo), k = lo + e - cc * (hi - lo);
         XS(b, cc, (long)w * v.M + k) = v.x_best[(size_t)cc * v.G + (size_t)w * v.M + k];
     }
-    if (tid == 0) { v.cost[w] = v.ref_cost[w]; v.prov[w] = 0; v.relin[w] = 1; v.fresh[w] = 1; }
+    // (relin doubles as "this solve ended inside an excursion": the next solve then keeps the damping the excursion had reached
+    // instead of starting from lambda0 again -- k_reset_lambda -- or a window that needs more trials than one solve has would
+    // repeat the same first trials for ever)
+    if (tid == 0) { v.cost[w] = v.ref_cost[w]; v.prov[w] = 0; v.relin[w] = 1; v.fresh[w] = 1; v.carry[w] = 1; }
+}
+// every solve starts from lambda0, as a fresh LevenbergMarquardtOptimizer would -- except a window whose previous solve was cut
+// off inside an excursion (non-monotone LM), which goes on from the damping it had reached
+__global__ void __launch_bounds__(256) k_reset_lambda(View v, const double* __restrict__ lambda0) {
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= v.B) return;
+    if (v.carry && v.carry[w]) { v.carry[w] = 0; return; }
+    v.lambda[w] = lambda0[w];
 }
 
 // ------------------------------------------------------------------------------------ a2
@@ -3709,6 +3720,9 @@ void launch_band_solve_hybrid(const View& v, const View& vp, hipStream_t s) {
 }
 void launch_retract(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_retract, dim3(nblk(v.G, 256)), dim3(256), 0, s, v);
+}
+void launch_reset_lambda(const View& v, const double* lambda0, hipStream_t s) {
+    hipLaunchKernelGGL(k_reset_lambda, dim3(nblk(v.B, 256)), dim3(256), 0, s, v, lambda0);
 }
 void launch_close_excursions(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_close_excursion, dim3(v.B), dim3(v.B <= 64 ? 1024 : 256), 0, s, v);

@@ -169,6 +169,7 @@ struct View {
     int* prov;          // [B] provisional trials since the reference point (0: the current point is the reference)
     int* n_prov;        // [B] provisional trials over the life of the engine
     int* relin;         // [B] the current buffer was restored: linearise it again
+    int* carry;         // [B] the last solve ended inside an excursion: the next one keeps its lambda (k_reset_lambda)
     int relin_only;     // the linearisation kernels skip windows whose relin flag is clear
     double gauge_floor; // k_marginalize: eigenvalues of the marginal prior's information about the window's global translation and yaw
                         // that have decayed below this are lifted back to it (vf_engine_opts.gauge_floor; 0 = off)
@@ -263,7 +264,8 @@ void launch_count_active(const View& v, hipStream_t s);
 void launch_band_solve_hybrid(const View& v, const View& vp, hipStream_t s);
 void launch_retract(const View& v, hipStream_t s);
 void launch_decide(const View& v, int init, hipStream_t s);
-void launch_close_excursions(const View& v, hipStream_t s);   // non-monotone LM: undo an excursion left open at the end of a solve
+void launch_close_excursions(const View& v, hipStream_t s);
+void launch_reset_lambda(const View& v, const double* lambda0, hipStream_t s);   // lambda := lambda0 at the start of a solve (see k_reset_lambda)   // non-monotone LM: undo an excursion left open at the end of a solve
 void launch_partitioned_local(const View& v, hipStream_t s);    // chunk sweeps + spikes of the owned chunks
 void launch_partitioned_global(const View& v, hipStream_t s);   // separator chain (all of it) + back substitution of the owned chunks
 void launch_mask_delta(const View& v, hipStream_t s);           // zero the increments of keyframes this rank does not own

@@ -102,7 +102,7 @@ class FixedLagOracle:
     prob: helpers.build_problem(...) of a sequence with at least n + updates keyframes (its `states` beyond the first
     window are ignored: appended keyframes are predicted from the running estimate, as the engine does)."""
 
-    def __init__(self, oracle, prob, n, iterations, threads=1, init_iterations=None, accept_rel=None, ingest=None, refine=0, gauge_floor=None):
+    def __init__(self, oracle, prob, n, iterations, threads=1, init_iterations=None, accept_rel=None, ingest=None, refine=0, gauge_floor=None, excursion=0):
         """init_iterations: LM trials of the initial solve (default: `iterations`).  A 1000-pose window started from
         IMU dead reckoning needs 50-150 trials to converge; slid while still far from its optimum it stays in a regime
         where two float64 implementations drift apart by 1e-5 m (DESIGN.md "Converged start")."""
@@ -113,13 +113,16 @@ class FixedLagOracle:
         self.ingest = ingest
         self.accept_rel = accept_rel                 # None: the oracle's default (= the engine's); 0: strict decrease
         self.gauge_floor = oracle.GAUGE_FLOOR if gauge_floor is None else gauge_floor     # vf_engine_opts.gauge_floor (None: its default)
+        self.excursion = excursion                   # vf_engine_opts.lm_excursion (with it lambda persists from solve to solve, as on the device)
+        self.lam = None
         self.refine = refine                         # > 0: every solve refined through J (vf_engine_opts.refine_iterations)
         self.rel_tol = self.abs_tol = 0.0            # > 0: GTSAM's LM termination rule in the updates that follow
         self.states = prob["states"].copy()
         self.s, self.marg = 0, None
         self.win = self._window(0, None, True)
-        self.costs, self.acc, _ = self.win.lm(iterations=iterations if init_iterations is None else init_iterations, n_threads=threads,
-                                              accept_rel=accept_rel, refine=refine)
+        self.costs, self.acc, lam = self.win.lm(iterations=iterations if init_iterations is None else init_iterations, n_threads=threads,
+                                                accept_rel=accept_rel, refine=refine, excursion=excursion)
+        self.lam = lam if excursion else None
         self.states[:n] = self.win.states
 
     def _window(self, lo, marg, with_prior):
@@ -150,8 +153,10 @@ class FixedLagOracle:
             p["imu"][new] = self.o.pim_to_record(pim)
         self.states[s + n - 1] = self.o.predict(p["imu"][s + n - 1], p["gravity"], self.states[s + n - 2])
         self.win = self._window(s, self.marg, False)
-        self.costs, self.acc, _ = self.win.lm(iterations=self.K, n_threads=self.threads, rel_tol=self.rel_tol, abs_tol=self.abs_tol,
-                                              accept_rel=self.accept_rel, refine=self.refine)
+        kw = {} if self.lam is None else {"lambda0": self.lam}
+        self.costs, self.acc, lam = self.win.lm(iterations=self.K, n_threads=self.threads, rel_tol=self.rel_tol, abs_tol=self.abs_tol,
+                                                accept_rel=self.accept_rel, refine=self.refine, excursion=self.excursion, **kw)
+        self.lam = lam if self.excursion else None
         self.states[s:s + n] = self.win.states
         return self.win.states
 

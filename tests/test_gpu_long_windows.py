@@ -41,3 +41,38 @@ def test_defaults_converge_long_windows_from_dead_reckoning(oracle, n, seed):
           f"{' '.join(f'{a:.1e}' for a in hist)} m ({lm['accepted']} accepted, {ex[0]} provisional, {lm['rejected']} rejected); Gauss-Newton per update: "
           f"{' '.join(f'{a:.1e}' for a in gn)} m")
     assert start > 0.5 and hist[-1] <= 1e-6 and gn[-1] <= 1e-6 and lm["solve_failures"] == 0 and ex[1] == 0
+
+
+def test_fixed_lag_updates_of_a_window_that_refines(oracle):
+    """A fixed-lag window longer than the threshold: refined solves, the non-monotone rule with its persisting damping, the
+    marginal prior's information in the operator (k_jtu applies L p: the prior is kept in information form), the gauge floor
+    and the warm start all at once -- 1 700 keyframes, eight marginalised updates of four trials with the appended factor
+    preintegrated at the current bias, against the oracle doing the same."""
+    from tests.test_gpu_ingest import _engine, _feed
+    from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
+    n, U, K = 1700, 8, 4
+    seq = synth.make_sequence(seed=13, n_kf=n + U + 2)
+    eng = _engine(None, [seq], n, U)
+    assert eng.refine_count() == 12
+    eng.iterate(20)
+    prob = helpers.build_problem(oracle, seq)
+    ref = helpers.FixedLagOracle(oracle, prob, n, K, init_iterations=20, ingest=(seq, oracle.carla_imu_params()), refine=12, excursion=3)
+    a0 = helpers.ate(eng.get_states(0, 0, n), ref.window_states)[0]
+    worst = 0.0
+    for u in range(1, U + 1):
+        eng.ingest_tail(*_feed([seq], n + u - 1))
+        eng.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)
+        eng.iterate(K)
+        ref.update()
+        a, r = helpers.ate(eng.get_states(0, u, n), ref.window_states)
+        worst = max(worst, a)
+        assert r <= 1e-6
+    eng.ingest_status()
+    lm = eng.read_lm(0)
+    got = eng.read_marginal(0)
+    dL = np.abs(got["L"] - np.array(ref.marg.L[:]).reshape(27, 27)).max() / np.abs(got["L"]).max()
+    print(f"fixed lag, {n} keyframes (refined): batch optimum {a0:.3e} m from the oracle's, worst over {U} updates {worst:.3e} m; cost {lm['cost']:.9f} "
+          f"vs {ref.costs[-1]:.9f}; marginal information rel. diff {dL:.1e}; lm {lm}")
+    assert a0 <= 1e-6 and worst <= 1e-6 and dL <= 1e-6 and lm["solve_failures"] == 0
+    assert abs(lm["cost"] - ref.costs[-1]) <= 1e-8 * ref.costs[-1]
+    eng.close()

@@ -345,3 +345,38 @@ def test_shard_errors():
         with pytest.raises(VilFusionError):
             whole_window_call()                  # a shard cannot run whole-window stages on its own
     eng.close()
+
+
+def test_config4_shards_take_the_same_decisions_through_failed_excursions():
+    """The non-monotone rule on a time-sharded window: every rank evaluates the whole cost and must take the same decision --
+    provisional, accepted, restored (the saved states come back and the factors of EVERY rank are linearised again) -- as the
+    unsharded engine.  lm_excursion = 1 makes the 10 000-pose window alternate provisional trial / restore (tests/
+    test_gpu_vs_qr_twin.py::test_config4_a_failed_excursion_restores_the_point_it_left); four shards in lock step."""
+    import torch
+    from vil_sensor_fusion_amd import Engine, EngineOpts, distributed as D
+    oracle, prob = _problem4()
+    K = 9
+    ref = Engine(EngineOpts(windows=1, capacity=N4 + 8, chunks=CHUNKS4, lm_excursion=1))
+    helpers.load_engine(ref, 0, prob)
+    ref.iterate(K)
+    want = (ref.read_lm(0), ref.read_excursions(0), ref.get_states(0, 0, N4))
+    ref.close()
+    engines = []
+    for r in range(4):
+        e = Engine(EngineOpts(windows=1, capacity=N4 + 8, chunks=CHUNKS4, lm_excursion=1))
+        helpers.load_engine(e, 0, prob)
+        engines.append(e)
+    group = D.LockstepGroup(engines, "cuda:0")
+    group.iterate(K)
+    torch.cuda.synchronize()
+    got = [(e.read_lm(0), e.read_excursions(0), e.get_states(0, 0, N4)) for e in engines]
+    for r in range(1, 4):
+        assert got[r][0] == got[0][0] and got[r][1] == got[0][1]
+        np.testing.assert_array_equal(got[r][2], got[0][2])
+    a = helpers.ate(got[0][2], want[2])[0]
+    print(f"4 shards, lm_excursion = 1, {K} trials: {got[0][0]}, provisional {got[0][1]}; unsharded: {want[0]}, {want[1]}; ATE {a:.3e} m")
+    assert want[0]["rejected"] >= 2 and want[1][0] >= 3                        # the restore path ran
+    assert {k: got[0][0][k] for k in ("accepted", "rejected", "solve_failures")} == {k: want[0][k] for k in ("accepted", "rejected", "solve_failures")}
+    assert got[0][1] == want[1] and a <= 1e-3
+    for e in engines:
+        e.close()

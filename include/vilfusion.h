@@ -111,14 +111,16 @@ typedef struct {
      * refinement every solve is followed by N conjugate-gradient corrections on (J^T J + lambda I) d = -J^T r with the
      * operator applied THROUGH J (accurate to cond(J), not cond(J)^2) and the Cholesky solve as preconditioner: each
      * correction costs one more solve with the same factor shape plus two passes over the Jacobians, and removes one of the
-     * handful of modes the factor gets wrong.  -1 (default) = 12 corrections once a window is longer than
+     * handful of modes the factor gets wrong.  -1 (default) = up to 12 corrections once a window is longer than
      * refine_min_keyframes, none otherwise (the headline windows are untouched); 0 = never; N = always N (at most 64).
      * Refining engines run the two-kernel form (K3 + K4); windows holding far factors are not refined. */
     int refine_iterations;
     int refine_min_keyframes;  /* default 1536: Gauss-Newton by normal equations alone contracts by 0.025 per update at 1 250 keyframes, 0.1 at
                                   1 500, 0.3 at 2 000, 0.7 at 3 000 and creeps beyond */
     double refine_rel_stop;    /* a window stops correcting once res . M^-1 res has fallen to this, squared, times its first value
-                                  (default 1e-13), or stops being positive */
+                                  (default 1e-8), or stops being positive; its remaining correction solves are skipped on the
+                                  device (no host synchronisation).  How many corrections that takes grows with the window: 4 at
+                                  1 600 keyframes, 5 at 2 500, 7 at 4 000, 9 at 6 000, 12 at 10 000 (tools/refine_trace_sizes.py) */
     /* Non-monotone LM ("excursions").  On a long window the Gauss-Newton step moves the far end by metres through
      * rotation-coupled dynamics; the stiff IMU residuals (sigma 2e-5 m) see the second-order part of that move, so the cost
      * RISES after the step (13 -> 1700 on the 10 000-pose window) and falls below its start only after one or two more

@@ -331,7 +331,7 @@ class Window:
         return cost, H, g
 
     def lm(self, iterations=5, lambda0=1e-5, up=10.0, down=10.0, lmin=1e-12, lmax=1e10,
-           n_threads=1, rel_tol=0.0, abs_tol=0.0, accept_rel=None, refine=0, refine_rel_stop=1e-13, excursion=0):
+           n_threads=1, rel_tol=0.0, abs_tol=0.0, accept_rel=None, refine=0, refine_rel_stop=1e-8, excursion=0):
         """refine / excursion: the engine's refined solve and non-monotone accept rule (vf_engine_opts.refine_iterations,
         lm_excursion); 0 / 0 = the classical normal-equation LM.  The engine switches both on by itself for windows longer
         than 1536 keyframes; the oracle does what it is told."""
@@ -344,7 +344,7 @@ class Window:
         return costs, acc, lam
 
 
-def gn_step(win: "Window", refine=0, refine_rel_stop=1e-13):
+def gn_step(win: "Window", refine=0, refine_rel_stop=1e-8):
     """one undamped Gauss-Newton update of win.states (vfo_gn_step); returns (cost before, corrections applied)"""
     c, it = C.c_double(), C.c_int()
     rc = lib().vfo_gn_step(C.byref(win.c), C.c_int(refine), C.c_double(refine_rel_stop), C.byref(c), C.byref(it))

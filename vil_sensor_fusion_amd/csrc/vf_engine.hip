@@ -197,10 +197,12 @@ struct vf_engine {
     // vf_engine_refine_begin and vf_engine_refine_end, and vf_engine_solve_local / _global work on (nres, z)
     vf::Refine rq{};
     bool rq_ready = false, refine_open = false;
+    int* rq_stop_host = nullptr;     // [B] pinned: the stop flags, read back between corrections (vf_engine_solve)
     int ensure_refine() {
         if (rq_ready) return VF_OK;
         const size_t G = (size_t)v.G, B = (size_t)v.B;
         int rc;
+        HIPCHK(hipHostMalloc((void**)&rq_stop_host, B * sizeof(int), hipHostMallocDefault));
         if ((rc = alloc(&rq.x, G * 15)) || (rc = alloc(&rq.p, G * 15)) || (rc = alloc(&rq.Ap, G * 15)) ||
             (rc = alloc(&rq.nres, G * 15 + 64)) || (rc = alloc(&rq.z, G * 15 + B)) || (rc = alloc(&rq.u_imu, G * 15)) ||
             (rc = alloc(&rq.u_btw, G * 6)) || (rc = alloc(&rq.u_pri, B * 15)) || (rc = alloc(&rq.rz, B)) ||
@@ -283,7 +285,7 @@ void vf_engine_default_opts(vf_engine_opts* o) {
     o->solve_assemble_waves = 2;
     o->refine_iterations = -1;       // auto: windows longer than refine_min_keyframes
     o->refine_min_keyframes = 1536;
-    o->refine_rel_stop = 1e-13;
+    o->refine_rel_stop = 1e-8;
     o->lm_excursion = -1;            // auto: 3 on engines that refine, classical LM otherwise
     o->gauge_floor = 3e-4;
     o->hybrid_active_list = 1;
@@ -410,6 +412,7 @@ void vf_engine_destroy(vf_engine* e) {
     if (e->stage) (void)hipFree(e->stage);
     if (e->pre_buf) (void)hipFree(e->pre_buf);
     if (e->in_host) (void)hipHostFree(e->in_host);
+    if (e->rq_stop_host) (void)hipHostFree(e->rq_stop_host);
     if (e->in_dev) (void)hipFree(e->in_dev);
     if (e->in_status) (void)hipFree(e->in_status);
     for (auto ev : e->in_ev) if (ev) (void)hipEventDestroy(ev);
@@ -795,10 +798,13 @@ int vf_engine_solve(vf_engine* e) {
     if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (int rc = not_sharded(e, "vf_engine_solve")) return rc;
-    auto band_solve = [&](double* gvec, double* delta) {      // the engine's K4 form on another right-hand side / increment buffer
+    auto band_solve = [&](double* gvec, double* delta, const int* skip = nullptr) {      // the engine's K4 form on another right-hand side / increment buffer
         vf::View a = e->v;
         a.gvec = gvec;
         a.delta = delta;
+        // (skip: windows that take no part -- a refinement's correction solves pass its stop flags, which include the windows
+        // the termination rule has finished, so that a window whose corrections have converged costs its later solves nothing)
+        if (skip) { a.stop_on = 1; a.done = const_cast<int*>(skip); }
         if (!assembles_in_solve(e) && !assembles_in_hybrid(e)) a.asm_min = 0;
         if (e->hybrid && e->v.stop_on) {
             vf::View p = e->partitioned_view();
@@ -828,8 +834,18 @@ int vf_engine_solve(vf_engine* e) {
         if (int rc = e->ensure_refine()) return rc;
         vf::launch_refine_begin(e->v, e->rq, e->stream);
         for (int it = 0; it < R; it++) {
-            band_solve(e->rq.nres, e->rq.z);
+            band_solve(e->rq.nres, e->rq.z, e->rq.stop);
             vf::launch_refine_step(e->v, e->rq, e->opts.refine_rel_stop, e->stream);
+            // How many corrections a window needs grows with its length (4 at 1 600 keyframes, 12 at 10 000): after the
+            // 4th, 6th, ... the stop flags are read back, and once every window has stopped the rest are not issued
+            // (a skipped correction is ~15 empty launches; the read-back costs one stream synchronisation)
+            if (it >= 3 && it % 2 == 1 && it + 1 < R) {
+                HIPCHK(hipMemcpyAsync(e->rq_stop_host, e->rq.stop, e->v.B * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+                HIPCHK(hipStreamSynchronize(e->stream));
+                bool live = false;
+                for (int w = 0; w < e->v.B && !live; w++) live = e->rq_stop_host[w] == 0;
+                if (!live) break;
+            }
         }
         vf::launch_refine_end(e->v, e->rq, e->stream);
     }
@@ -1116,7 +1132,7 @@ int vf_engine_solve_local(vf_engine* e) {
     int rc = check_sharded(e);
     if (rc) return rc;
     vf::View a = e->v;
-    if (e->refine_open) { a.gvec = e->rq.nres; a.delta = e->rq.z; }
+    if (e->refine_open) { a.gvec = e->rq.nres; a.delta = e->rq.z; a.stop_on = 1; a.done = e->rq.stop; }    // (converged windows are skipped)
     vf::launch_partitioned_local(a, e->stream);
     HIPCHK(hipGetLastError());
     return VF_OK;
@@ -1127,7 +1143,7 @@ int vf_engine_solve_global(vf_engine* e) {
     int rc = check_sharded(e);
     if (rc) return rc;
     vf::View a = e->v;
-    if (e->refine_open) { a.gvec = e->rq.nres; a.delta = e->rq.z; }
+    if (e->refine_open) { a.gvec = e->rq.nres; a.delta = e->rq.z; a.stop_on = 1; a.done = e->rq.stop; }
     vf::launch_partitioned_global(a, e->stream);
     if (e->v.sh_G > 1) vf::launch_mask_delta(a, e->stream);
     HIPCHK(hipGetLastError());

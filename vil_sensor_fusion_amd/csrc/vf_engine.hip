@@ -202,7 +202,7 @@ struct vf_engine {
         if (rq_ready) return VF_OK;
         const size_t G = (size_t)v.G, B = (size_t)v.B;
         int rc;
-        HIPCHK(hipHostMalloc((void**)&rq_stop_host, B * sizeof(int), hipHostMallocDefault));
+        if (!rq_stop_host) HIPCHK(hipHostMalloc((void**)&rq_stop_host, B * sizeof(int), hipHostMallocDefault));
         if ((rc = alloc(&rq.x, G * 15)) || (rc = alloc(&rq.p, G * 15)) || (rc = alloc(&rq.Ap, G * 15)) ||
             (rc = alloc(&rq.nres, G * 15 + 64)) || (rc = alloc(&rq.z, G * 15 + B)) || (rc = alloc(&rq.u_imu, G * 15)) ||
             (rc = alloc(&rq.u_btw, G * 6)) || (rc = alloc(&rq.u_pri, B * 15)) || (rc = alloc(&rq.rz, B)) ||

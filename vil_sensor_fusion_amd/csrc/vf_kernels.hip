@@ -1296,6 +1296,12 @@ constexpr int S_RING_OUT = S_PROG + 2;        // != 0: a wait on the ring ran ou
 constexpr int RING_SPIN_MAX = 1 << 22;        // polls (each an LDS read + s_sleep): seconds, against the microseconds a step takes
 constexpr int S_BC_RING = S_PROG + 8;
 constexpr int S_TOTAL_RING = S_BC_RING + 16;
+#ifndef VF_ASM2_BSLEEP
+#define VF_ASM2_BSLEEP 1    // s_sleep argument of the assembler's polls (units of 64 clocks)
+#endif
+#ifndef VF_ASM2_PRIO
+#define VF_ASM2_PRIO 1      // two-wave assembling sweep: 1 = the eliminator's instructions issue first (s_setprio), 2 = the assembler's, 0 = neither
+#endif
 #ifndef VF_PIVOT_PERMLANE
 #define VF_PIVOT_PERMLANE 0      // 1: the scaled pivot column is replicated over the 16-lane rows by VALU lane swaps instead of through LDS
 #endif
@@ -1786,7 +1792,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
                 } else {
                     nx.tiles_wanted++;
                     int spin = 0;
-                    while (lds_peek(S + AS_FLAGS + 2) < (double)nx.tiles_wanted && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+                    while (lds_peek(S + AS_FLAGS + 2) < (double)nx.tiles_wanted && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(VF_ASM2_BSLEEP);
                     if (spin >= (1 << 22) && lane == 0) S[AS_FLAGS + 3] = 1.0;
                 }
             } else {
@@ -1960,7 +1966,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
                 // the window may be touched once the eliminator has read pivot row R - 4 (its Schur write-back of the step
                 // before is then done as well) and until it reads the accumulators of that step -- it waits for us there
                 int spin = 0;
-                while (lds_peek(S + AS_FLAGS) < (double)(R - 4) && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+                while (lds_peek(S + AS_FLAGS) < (double)(R - 4) && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(VF_ASM2_BSLEEP);
                 if (spin >= (1 << 22) && lane == 0) S[AS_FLAGS + 3] = 1.0;      // (never seen: the eliminator reports it as a failed solve)
             }
             as_rmw(ph, az);
@@ -2445,6 +2451,11 @@ __global__ void __launch_bounds__(128) k_band_forward_asm2(View v, int w0) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (threadIdx.x < 4) S[AS_FLAGS + threadIdx.x] = threadIdx.x < 2 ? -1.0 : 0.0;
     __syncthreads();
+#if VF_ASM2_PRIO
+    // Issue priority to the eliminator: its steps are the critical path, the assembler has 40 % slack, and the two share one
+    // SIMD's float64 units (solve 3.66 -> 3.50 ms at 1 024 windows; priority to the assembler: 3.63)
+    if ((wave == 0) == (VF_ASM2_PRIO == 1)) __builtin_amdgcn_s_setprio(3);
+#endif
     if (wave == 0) band_solve_body<SOLVE_ASM_A>(v, S, nullptr, nullptr, w, lane, 0);
     else band_solve_body<SOLVE_ASM_B>(v, S, nullptr, nullptr, w, lane, 0);
 }

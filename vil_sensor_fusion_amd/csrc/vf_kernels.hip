@@ -3720,7 +3720,9 @@ void launch_band_solve_hybrid(const View& v, const View& vp, hipStream_t s) {
     b.gate = 2;
     // (a.act, when the engine has allocated it: the sweeps visit the active windows first)
     if (asm_in_hybrid(v)) {
-        // (one wave per window here: with part of the windows done the two-wave form measured 5 % slower, bench `with_convergence_exit`)
+        // (one wave per window here: with part of the windows done the two-wave form measured 5 % slower in round 4; with the
+        // compacted list and the eliminator's priority of round 5 it is level -- 9.66 against 9.64 ms per update,
+        // tools/ab_conv_exit.py -- its second trial faster, its first slower; left as it was)
         hipLaunchKernelGGL(k_band_forward_asm, dim3(a.B), dim3(64), 0, s, a);
         hipLaunchKernelGGL(k_band_backward, dim3(a.B), dim3(64), 0, s, a);
     } else if (a.split_min > 0 && a.B >= a.split_min) {

@@ -175,20 +175,27 @@ int vf_engine_clear_between(vf_engine* e, int window, int k0, int n);
  * low-rank correction: g gets their J^T r, and every LM trial solves (H_band + lambda I + U U^T) delta = -g by Woodbury
  * -- the band solver once more per column of U (6 per factor) and one small dense system per window.  A FALLBACK for
  * the rare window with such factors, several times slower than a band-only window; at most VF_MAX_EXTRA per window.
- * The call REPLACES the window's list (n = 0 clears it); records as for vf_engine_set_between.  A factor whose older
- * keyframe a leaves the window (vf_engine_slide / vf_engine_drop_oldest) is TRANSPORTED to keyframe a + 1: with D the
- * current estimate of T_a^-1 T_a+1 its measurement becomes D^-1 Z -- the same residual in the same tangent frame, D taken
- * as exact (the IMU factor between the two knows it to 2e-5 m, a between factor claims 1e-2 ... 0.5 m) -- so the information
- * of a loop closure outlives the keyframe it was anchored on, as in the reference's unbounded graph (GraphManager.cpp:83-88);
- * once the factor is short enough to lie within the marginal prior's reach (it ends at a + 1 .. a + 3) the marginalisation of a
- * absorbs it into the prior exactly as it absorbs a band factor, so its information outlives BOTH its ends.  Engines holding far factors start every solve cold.  Not for
- * time-sharded engines. */
+ * The call REPLACES the window's list (n = 0 clears it); records as for vf_engine_set_between.
+ * A far factor outlives the keyframe it is anchored on, as in the reference's unbounded graph (GraphManager.cpp:83-88).  When
+ * its older keyframe a is MARGINALISED (vf_engine_marginalize / vf_engine_slide(.., 1)) the factor is marginalised with it,
+ * exactly at the current linearisation: it leaves this list and joins the window's LINEAR far factor -- six whitened rows
+ * per far end over the three keyframes of the marginal prior and all the far ends (marginalising a keyframe that several far
+ * factors touch couples their far ends: they are one factor from then on) -- which every later marginalisation re-expresses
+ * the same way, and whose far ends are folded into the marginal prior as they come within its reach (the leaving keyframe
+ * + 3): the information of a loop closure outlives BOTH its ends, and a fixed-lag window follows the whole-history optimum
+ * across them to 1e-7 m (tests/test_gpu_far_factors.py).  (Far ends count against VF_MAX_EXTRA; vf_engine_get_linear_far
+ * lists them.)  A slide that does not marginalise re-anchors the
+ * factor on keyframe a + 1 instead -- Z' = D^-1 Z with D the current estimate of T_a^-1 T_a+1, taken as exact -- and drops
+ * the linear ones, as it drops the band factors of the keyframe that leaves.  Engines holding far factors start every solve
+ * cold.  Not for time-sharded engines. */
 int vf_engine_set_extra_between(vf_engine* e, int window, int n, const int32_t* a, const int32_t* b, const double* rec28);
-/* the window's far factors as they stand (vf_engine_slide / vf_engine_drop_oldest TRANSPORT a far factor whose older keyframe
- * leaves the window to the next keyframe -- see below), and how many were transported / dropped by a slide that does not
- * marginalise / absorbed into the marginal prior over the life of the engine; any output pointer may be NULL */
+/* the window's (nonlinear) far factors as they stand, and how many far factors were transported (made linear by a
+ * marginalisation, or re-anchored by a slide without one) / dropped by a slide that does not marginalise / absorbed into the
+ * marginal prior over the life of the engine; any output pointer may be NULL */
 int vf_engine_get_extra_between(vf_engine* e, int window, int* n, int32_t* a, int32_t* b, double* rec28, long* transported, long* ended,
                                 long* absorbed);
+/* the window's linear far factors: their number and the window-local keyframe each one ends at (far_end: VF_MAX_EXTRA ints, or NULL) */
+int vf_engine_get_linear_far(vf_engine* e, int window, int* n, int32_t* far_end);
 /* the three priors of GraphManager.cpp:27-35 as one diagonal 15-row factor on keyframe k */
 int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec31);
 

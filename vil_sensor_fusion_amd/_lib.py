@@ -57,7 +57,7 @@ SYMBOLS = [
     "vf_last_error", "vf_version", "vf_device_count",
     "vf_engine_default_opts", "vf_engine_create", "vf_engine_destroy",
     "vf_engine_set_range", "vf_engine_set_states", "vf_engine_get_states", "vf_engine_set_imu",
-    "vf_engine_set_between", "vf_engine_clear_between", "vf_engine_set_extra_between", "vf_engine_get_extra_between", "vf_engine_set_prior",
+    "vf_engine_set_between", "vf_engine_clear_between", "vf_engine_set_extra_between", "vf_engine_get_extra_between", "vf_engine_get_linear_far", "vf_engine_set_prior",
     "vf_engine_linearize", "vf_engine_assemble", "vf_engine_solve", "vf_engine_retract",
     "vf_engine_decide", "vf_engine_iterate", "vf_engine_slide", "vf_engine_predict",
     "vf_engine_sync", "vf_engine_graph_info", "vf_engine_solve_form",

@@ -172,6 +172,23 @@ struct vf_engine {
     // later call picks up from there (no second allocation, nothing leaked)
     int *x_la = nullptr, *x_lb = nullptr;
     double *x_li = nullptr, *x_lo = nullptr;
+    // linear far factors (View::xl_*; made and kept by k_marginalize): the host mirrors only their number and far ends
+    std::vector<std::vector<int>> h_lb;
+    int h_ln(int w) const { return h_lb.empty() ? 0 : (int)h_lb[w].size(); }
+    void attach_far() {              // after ensure_far: the View sees the slot arrays, the host mirrors exist
+        if (v.x_max) return;
+        v.x_a = x_la; v.x_b = x_lb; v.x_in = x_li; v.x_out = x_lo;
+        v.x_max = VF_MAX_EXTRA;
+        h_xn.assign(v.B, 0);
+        h_xa.assign(v.B, {});
+        h_xb.assign(v.B, {});
+        h_xrec.assign(v.B, {});
+        h_lb.assign(v.B, {});
+    }
+    void recount_far() {
+        x_used = 0;
+        for (int w = 0; w < v.B && v.x_max; w++) x_used = std::max(x_used, h_xn[w] + h_ln(w));
+    }
     int ensure_far(int slots) {
         const size_t B = (size_t)v.B, X = VF_MAX_EXTRA;
         int rc;
@@ -179,6 +196,8 @@ struct vf_engine {
         if (!x_lb) { if ((rc = alloc(&x_lb, B * X, false))) return rc; HIPCHK(hipMemsetAsync(x_lb, 0xff, B * X * sizeof(int), stream)); }
         if (!x_li && (rc = alloc(&x_li, B * X * vf::BTW_IN))) return rc;
         if (!x_lo && (rc = alloc(&x_lo, 2 * B * X * vf::BTW_OUT))) return rc;
+        if (!v.xl_n && ((rc = alloc(&v.xl_n, B)) || (rc = alloc(&v.xl_b, B * X)) || (rc = alloc(&v.xl_U, B * X * 6 * vf::XL_LD)) || (rc = alloc(&v.xl_r0, B * X * 6)) ||
+                        (rc = alloc(&v.xl_bx, B * X * 7)) || (rc = alloc(&v.xl_out, 2 * B * X * 6)))) return rc;
         x_zstride = (size_t)v.G * 15 + B + 64;
         if (!x_gtmp) HIPCHK(hipMalloc((void**)&x_gtmp, x_zstride * sizeof(double)));
         if (slots > x_zslots) {
@@ -564,7 +583,9 @@ int vf_engine_set_extra_between(vf_engine* e, int window, int n, const int32_t* 
     int rc = check_window(e, window);
     if (rc) return rc;
     if (int rs = not_sharded_(e, "vf_engine_set_extra_between")) return rs;
-    if (n < 0 || n > VF_MAX_EXTRA) return fail(VF_ERR_CAPACITY, "at most %d far between factors per window (got %d)", VF_MAX_EXTRA, n);
+    if (n < 0 || n + e->h_ln(window) > VF_MAX_EXTRA)
+        return fail(VF_ERR_CAPACITY, "at most %d far between factors per window (got %d, and %d carried on from keyframes that have been marginalised)",
+                    VF_MAX_EXTRA, n, e->h_ln(window));
     if (n > 0 && (!a || !b || !rec)) return fail(VF_ERR_INVALID, "null argument");
     const int M = e->v.M, B = e->v.B, X = VF_MAX_EXTRA;
     for (int i = 0; i < n; i++) {
@@ -573,18 +594,11 @@ int vf_engine_set_extra_between(vf_engine* e, int window, int n, const int32_t* 
     }
     if (e->v.x_max == 0 && n == 0) return VF_OK;
     {
-        int need = n;                   // slots in use once this call is through
-        for (int w = 0; w < B && e->v.x_max; w++) if (w != window) need = std::max(need, e->h_xn[w]);
+        int need = n + e->h_ln(window);                   // slots in use once this call is through
+        for (int w = 0; w < B && e->v.x_max; w++) if (w != window) need = std::max(need, e->h_xn[w] + e->h_ln(w));
         if ((rc = e->ensure_far(need))) return rc;
     }
-    if (e->v.x_max == 0) {
-        e->v.x_a = e->x_la; e->v.x_b = e->x_lb; e->v.x_in = e->x_li; e->v.x_out = e->x_lo;
-        e->v.x_max = X;
-        e->h_xn.assign(B, 0);
-        e->h_xa.assign(B, {});
-        e->h_xb.assign(B, {});
-        e->h_xrec.assign(B, {});
-    }
+    e->attach_far();
     e->h_xa[window].assign(a, a + n);
     e->h_xb[window].assign(b, b + n);
     e->h_xrec[window].assign(rec, rec + (size_t)n * vf::BTW_IN);
@@ -600,8 +614,7 @@ int vf_engine_set_extra_between(vf_engine* e, int window, int n, const int32_t* 
         HIPCHK(hipMemsetAsync(e->v.x_out + ((size_t)bf * B + window) * X * vf::BTW_OUT, 0, (size_t)X * vf::BTW_OUT * sizeof(double), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->h_xn[window] = n;
-    e->x_used = 0;
-    for (int w = 0; w < B; w++) e->x_used = e->h_xn[w] > e->x_used ? e->h_xn[w] : e->x_used;
+    e->recount_far();
     e->epoch++;        // (the number of band solves per trial is baked into a captured launch sequence)
     return VF_OK;
 }
@@ -1405,30 +1418,49 @@ void quat_mul_(const double* a, const double* b, double* o) {
 static int transport_far(vf_engine* e, bool marginalised) {
     if (e->x_used == 0) return VF_OK;
     for (int w = 0; w < e->v.B; w++) {
-        const int lo = e->h_lo[w];
-        bool any = false;
+        const int lo = e->h_lo[w], hi = e->h_hi[w];
+        bool any = !e->h_lb[w].empty();
         for (int i = 0; i < e->h_xn[w]; i++) any = any || e->h_xa[w][i] == lo;
-        if (!any || e->h_hi[w] - lo < 2) continue;
-        double st[32];
-        if (int rc = vf_engine_get_states(e, w, lo, 2, st)) return rc;
-        // D = T_lo^-1 T_lo+1
-        double R0[9], qc[4] = {st[0], -st[1], -st[2], -st[3]}, qD[4], dt[3] = {st[20] - st[4], st[21] - st[5], st[22] - st[6]}, tD[3];
-        quat_to_rot_(st, R0);
-        quat_mul_(qc, st + 16, qD);
-        for (int c = 0; c < 3; c++) tD[c] = R0[0 * 3 + c] * dt[0] + R0[1 * 3 + c] * dt[1] + R0[2 * 3 + c] * dt[2];
-        double RD[9], qDc[4] = {qD[0], -qD[1], -qD[2], -qD[3]};
-        quat_to_rot_(qD, RD);
+        if (!any || hi - lo < 2) continue;
+        // (1) the linear far factors -- all of them have the leaving keyframe in their support.  k_marginalize has absorbed the
+        // ones that end at lo + 3 and re-expressed the others over the next three keyframes, in this order; without a
+        // marginalisation (re-anchoring slide) they go the way the band factors of the dropped keyframe go.
+        std::vector<int> lb;
+        for (int kb : e->h_lb[w]) {
+            if (!marginalised) e->far_ended++;
+            else if (kb == lo + 3) e->far_absorbed++;
+            else lb.push_back(kb);
+        }
+        const bool had_linear = !e->h_lb[w].empty();
+        // (2) the nonlinear ones anchored at lo
+        double st[32], R0[9], qD[4], tD[3], RD[9], qDc[4];
+        bool have_D = false;
         std::vector<int> a, b;
         std::vector<double> rec;
         for (int i = 0; i < e->h_xn[w]; i++) {
             double r[vf::BTW_IN];
             memcpy(r, e->h_xrec[w].data() + (size_t)i * vf::BTW_IN, sizeof(r));
             int ai = e->h_xa[w][i];
+            const int kb = e->h_xb[w][i];
             if (ai == lo) {
                 // within the marginal prior's reach (ends at lo+1 .. lo+3): k_marginalize has just absorbed it, like a band
-                // factor -- its information lives on in the prior; without a marginalisation (re-anchoring slide) it goes the
-                // way the band factors of the dropped keyframe go
-                if (e->h_xb[w][i] - lo <= 3) { if (marginalised) e->far_absorbed++; else e->far_ended++; continue; }
+                // factor -- its information lives on in the prior
+                if (kb - lo <= 3) { if (marginalised) e->far_absorbed++; else e->far_ended++; continue; }
+                // marginalised with its far end inside the window: k_marginalize has made it a linear far factor (exact
+                // at the current linearisation), behind the survivors of (1)
+                if (marginalised && kb < hi) { lb.push_back(kb); e->far_transported++; continue; }
+                // no marginalisation (or an end the window has not reached yet): re-anchored on the next keyframe, the step
+                // between the two taken as exact
+                if (!have_D) {
+                    if (int rc = vf_engine_get_states(e, w, lo, 2, st)) return rc;
+                    double qc[4] = {st[0], -st[1], -st[2], -st[3]}, dt[3] = {st[20] - st[4], st[21] - st[5], st[22] - st[6]};     // D = T_lo^-1 T_lo+1
+                    quat_to_rot_(st, R0);
+                    quat_mul_(qc, st + 16, qD);
+                    for (int c = 0; c < 3; c++) tD[c] = R0[0 * 3 + c] * dt[0] + R0[1 * 3 + c] * dt[1] + R0[2 * 3 + c] * dt[2];
+                    quat_to_rot_(qD, RD);
+                    qDc[0] = qD[0]; qDc[1] = -qD[1]; qDc[2] = -qD[2]; qDc[3] = -qD[3];
+                    have_D = true;
+                }
                 double q2[4], d[3] = {r[4] - tD[0], r[5] - tD[1], r[6] - tD[2]};
                 quat_mul_(qDc, r, q2);                                          // R' = R_D^T R_Z
                 const double nq = std::sqrt(q2[0] * q2[0] + q2[1] * q2[1] + q2[2] * q2[2] + q2[3] * q2[3]);
@@ -1438,11 +1470,21 @@ static int transport_far(vf_engine* e, bool marginalised) {
                 e->far_transported++;
             }
             a.push_back(ai);
-            b.push_back(e->h_xb[w][i]);
+            b.push_back(kb);
             rec.insert(rec.end(), r, r + vf::BTW_IN);
         }
+        e->h_lb[w] = lb;
+        if (had_linear && !marginalised) HIPCHK(hipMemsetAsync(e->v.xl_n + w, 0, sizeof(int), e->stream));
         if (int rc = vf_engine_set_extra_between(e, w, (int)a.size(), a.data(), b.data(), rec.data())) return rc;
     }
+    return VF_OK;
+}
+int vf_engine_get_linear_far(vf_engine* e, int window, int* n, int32_t* far_end) {
+    int rc = check_window(e, window);
+    if (rc) return rc;
+    const int cnt = e->v.x_max ? e->h_ln(window) : 0;
+    if (n) *n = cnt;
+    for (int i = 0; i < cnt && far_end; i++) far_end[i] = e->h_lb[window][i];
     return VF_OK;
 }
 int vf_engine_get_extra_between(vf_engine* e, int window, int* n, int32_t* a, int32_t* b, double* rec28, long* transported, long* ended, long* absorbed) {
@@ -1592,6 +1634,12 @@ int vf_engine_compact(vf_engine* e, int shift) {
         }
         if (int rc = vf_engine_set_extra_between(e, w, (int)a.size(), a.data(), b.data(), r.data())) return rc;
     }
+    for (int w = 0; w < v.B && v.x_max > 0; w++) {          // ... and so do the far ends of the linear ones (always inside the window)
+        if (e->h_lb[w].empty()) continue;
+        for (int& kb : e->h_lb[w]) kb -= shift;
+        HIPCHK(hipMemcpyAsync(v.xl_b + (size_t)w * v.x_max, e->h_lb[w].data(), e->h_lb[w].size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
     return VF_OK;
 }
 
@@ -1647,11 +1695,31 @@ int vf_engine_grow(vf_engine* e, int new_capacity) {
     if (!e->own_stream) {          // the caller's stream stays the one every later stage runs on
         if ((rc = vf_engine_set_stream(n, (void*)e->stream))) { vf_engine_destroy(n); return rc; }
     }
-    for (int w = 0; w < e->v.B && e->v.x_max > 0; w++)       // far between factors: re-sent from the host copies
-        if (e->h_xn[w] > 0 && (rc = vf_engine_set_extra_between(n, w, e->h_xn[w], e->h_xa[w].data(), e->h_xb[w].data(), e->h_xrec[w].data()))) {
-            vf_engine_destroy(n);
-            return rc;
+    if (e->v.x_max > 0 && e->x_used > 0) {
+        // far between factors: the linear ones (they exist on the device only; their arrays do not depend on the capacity) copied,
+        // the others re-sent from the host copies
+        bool linear = false;
+        for (int w = 0; w < e->v.B; w++) linear = linear || !e->h_lb[w].empty();
+        if (linear) {
+            if ((rc = n->ensure_far(e->x_used))) { vf_engine_destroy(n); return rc; }
+            const size_t Bx = (size_t)B * VF_MAX_EXTRA;
+            hipError_t he = hipMemcpyAsync(n->v.xl_n, e->v.xl_n, B * sizeof(int), hipMemcpyDeviceToDevice, n->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync(n->v.xl_b, e->v.xl_b, Bx * sizeof(int), hipMemcpyDeviceToDevice, n->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync(n->v.xl_U, e->v.xl_U, Bx * 6 * vf::XL_LD * sizeof(double), hipMemcpyDeviceToDevice, n->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync(n->v.xl_r0, e->v.xl_r0, Bx * 6 * sizeof(double), hipMemcpyDeviceToDevice, n->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync(n->v.xl_bx, e->v.xl_bx, Bx * 7 * sizeof(double), hipMemcpyDeviceToDevice, n->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(n->stream);
+            if (he != hipSuccess) { vf_engine_destroy(n); return fail(VF_ERR_DEVICE, "vf_engine_grow: device copy failed: %s", hipGetErrorString(he)); }
+            n->attach_far();
+            n->h_lb = e->h_lb;
         }
+        for (int w = 0; w < e->v.B; w++)
+            if (e->h_xn[w] > 0 && (rc = vf_engine_set_extra_between(n, w, e->h_xn[w], e->h_xa[w].data(), e->h_xb[w].data(), e->h_xrec[w].data()))) {
+                vf_engine_destroy(n);
+                return rc;
+            }
+        n->recount_far();
+    }
     std::swap(*e, *n);             // *e: the grown engine; *n: the old buffers
     n->own_stream = n->own_stream && n->stream != e->stream;
     vf_engine_destroy(n);

@@ -626,20 +626,78 @@ __device__ __forceinline__ void linearize_between_factor(const View& v, int whic
 // ---- "far" between factors (View::x_*): BetweenFactor<Pose3> on ANY pair of keyframes of a window -- a span wider than
 // the band, or a second factor on an end key (loop closures; GraphManager.cpp:83-88 takes any pair of keys).  They stay
 // out of the banded H: the solve treats them as a low-rank correction (launch_extra_* below, vf_engine_solve).
-// One lane per (window, slot); a slot that is empty or reaches outside the window writes zeros (no cost, no rows).
+// A window's slots: first its LINEAR far factors (View::xl_*: far factors whose older keyframe has been marginalised), then
+// the entries of x_a / x_b.  FarRef resolves a slot: kind -1 = empty or reaching outside the window (no cost, no rows).
+VF_DI void marg_delta(const View& v, int w, int b, double (&d)[27]);
+struct FarRef { int kind, idx, a, kb, nl; };
+VF_DI FarRef far_ref(const View& v, int w, int s) {
+    FarRef f{-1, 0, 0, 0, 0};
+    const int nl = v.xl_n[w], lo = v.lo[w], hi = v.hi[w];
+    if (s < nl) {
+        if (hi - lo > 3 && v.mp_on[w]) { f.kind = 1; f.idx = s; f.a = lo; f.kb = v.xl_b[w * v.x_max + s]; f.nl = nl; }
+    } else if (s - nl < v.x_max) {
+        const int i = w * v.x_max + s - nl, a = v.x_a[i], kb = v.x_b[i];
+        if (!(a < lo || kb >= hi || a >= kb)) { f.kind = 0; f.idx = s - nl; f.a = a; f.kb = kb; }
+    }
+    return f;
+}
+VF_DI int far_cols(const FarRef& f) { return f.kind == 1 ? 27 + 6 * f.nl : 12; }
+// column c of a slot's six rows -> (window-local keyframe, dof of its 15)
+VF_DI void far_col(const View& v, int w, const FarRef& f, int c, int& k, int& d) {
+    if (f.kind == 1) {
+        if (c < 15) { k = f.a; d = c; }
+        else if (c < 21) { k = f.a + 1; d = c - 15; }
+        else if (c < 27) { k = f.a + 2; d = c - 21; }
+        else { const int e = (c - 27) / 6; k = v.xl_b[w * v.x_max + e]; d = c - 27 - 6 * e; }
+    } else if (c < 6) { k = f.a; d = c; }
+    else { k = f.kb; d = c - 6; }
+}
+// entry (row j, column c) of the whitened Jacobian / residual j, at the states of buffer `buf`
+VF_DI double far_jac(const View& v, int w, const FarRef& f, int buf, int j, int c) {
+    if (f.kind == 1) return v.xl_U[((size_t)w * 6 * v.x_max + 6 * f.idx + j) * XL_LD + c];
+    return v.x_out[(((size_t)buf * v.B + w) * v.x_max + f.idx) * BTW_OUT + 6 + (c < 6 ? 0 : 36) + j * 6 + (c < 6 ? c : c - 6)];
+}
+VF_DI double far_res(const View& v, int w, const FarRef& f, int buf, int j) {
+    if (f.kind == 1) return v.xl_out[((size_t)buf * v.B + w) * 6 * v.x_max + 6 * f.idx + j];
+    return v.x_out[(((size_t)buf * v.B + w) * v.x_max + f.idx) * BTW_OUT + j];
+}
+// One lane per (window, index): entry `index` of the window's nonlinear list, and far end `index` of its linear far factor
+// (the six rows that belong to it)
 __global__ void __launch_bounds__(64) k_linearize_extra(View v, int which) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= v.B * v.x_max) return;
-    const int w = i / v.x_max;
+    const int w = i / v.x_max, s = i - w * v.x_max;
     if (window_done(v, w)) return;
     const int b = v.sel[w] ^ which, lo = v.lo[w], hi = v.hi[w];
-    const int a = v.x_a[i], kb = v.x_b[i];
-    double* out = v.x_out + ((size_t)b * v.B * v.x_max + i) * BTW_OUT;
-    if (a < lo || kb >= hi || a >= kb) {
-        for (int f = 0; f < BTW_OUT; f++) out[f] = 0.0;
-        return;
+    {
+        const int a = v.x_a[i], kb = v.x_b[i];
+        double* out = v.x_out + ((size_t)b * v.B * v.x_max + i) * BTW_OUT;
+        if (a < lo || kb >= hi || a >= kb) { for (int f = 0; f < BTW_OUT; f++) out[f] = 0.0; }
+        else between_core<false>(v, b, (long)w * v.M + a, (long)w * v.M + kb, v.x_in + (size_t)i * BTW_IN, 1, out, 1, true);
     }
-    between_core<false>(v, b, (long)w * v.M + a, (long)w * v.M + kb, v.x_in + (size_t)i * BTW_IN, 1, out, 1, true);
+    double* lout = v.xl_out + ((size_t)b * v.B + w) * 6 * v.x_max + 6 * s;
+    const int nl = v.xl_n[w];
+    if (s < nl && hi - lo > 3 && v.mp_on[w]) {
+        double dh[27];
+        marg_delta(v, w, b, dh);
+        const double* U = v.xl_U + ((size_t)w * 6 * v.x_max + 6 * s) * XL_LD;
+        double acc[6];
+        for (int j = 0; j < 6; j++) {
+            acc[j] = v.xl_r0[(size_t)w * 6 * v.x_max + 6 * s + j];
+            for (int c = 0; c < 27; c++) acc[j] = fma(U[j * XL_LD + c], dh[c], acc[j]);
+        }
+        for (int e = 0; e < nl; e++) {
+            const double* xb = v.xl_bx + ((size_t)w * v.x_max + e) * 7;
+            const State st = load_state(v, b, (long)w * v.M + v.xl_b[w * v.x_max + e]);
+            const Q4 qb = q4(xb[0], xb[1], xb[2], xb[3]);
+            const Xi6 xi = se3_log(qmul(qconj(qb), st.q), mulT(qrot(qb), st.t - v3(xb[4], xb[5], xb[6])));
+            const double d6[6] = {xi.w.x, xi.w.y, xi.w.z, xi.u.x, xi.u.y, xi.u.z};
+            for (int j = 0; j < 6; j++)
+                for (int c = 0; c < 6; c++) acc[j] = fma(U[j * XL_LD + 27 + 6 * e + c], d6[c], acc[j]);
+        }
+        for (int j = 0; j < 6; j++) lout[j] = acc[j];
+    } else
+        for (int j = 0; j < 6; j++) lout[j] = 0.0;
 }
 // g += J^T r of the far factors, for the windows whose rows K3 has just rewritten (same test as k_assemble; engines that
 // hold far factors never warm-start, so "rewritten" means the whole window)
@@ -648,31 +706,43 @@ __global__ void __launch_bounds__(64) k_extra_gradient(View v) {
     if (!v.fresh[w] || window_done(v, w)) return;
     const int b = v.sel[w];
     for (int s = 0; s < v.x_max; s++) {              // sequential over the slots: two factors may share a keyframe
-        const int i = w * v.x_max + s;
-        const int a = v.x_a[i], kb = v.x_b[i];
-        if (a < v.lo[w] || kb >= v.hi[w] || a >= kb) continue;
-        const double* f = v.x_out + ((size_t)b * v.B * v.x_max + i) * BTW_OUT;
-        if (lane < 12) {
-            const int c = lane % 6, side = lane / 6;
-            double acc = 0.0;
-            for (int r = 0; r < 6; r++) acc = fma(f[6 + 36 * side + r * 6 + c], f[r], acc);
-            v.gvec[((size_t)w * v.M + (side ? kb : a)) * 15 + c] += acc;
+        const FarRef f = far_ref(v, w, s);
+        const int nc = f.kind >= 0 ? far_cols(f) : 0;
+        for (int c0 = 0; c0 < nc; c0 += 64) {        // (and over the column groups: two far ends may be the same keyframe)
+            const int c = c0 + lane;
+            if (c < nc) {
+                int k, d;
+                far_col(v, w, f, c, k, d);
+                double acc = 0.0;
+                for (int r = 0; r < 6; r++) acc = fma(far_jac(v, w, f, b, r, c), far_res(v, w, f, b, r), acc);
+                bool first = true;                   // of the columns that land on this (keyframe, dof): far-end columns only
+                if (f.kind == 1 && c >= 27)
+                    for (int c2 = 27 + d; c2 < nc; c2 += 6) {
+                        if (c2 == c) continue;
+                        int k2, d2;
+                        far_col(v, w, f, c2, k2, d2);
+                        if (k2 != k) continue;
+                        if (c2 < c) { first = false; break; }
+                        for (int r = 0; r < 6; r++) acc = fma(far_jac(v, w, f, b, r, c2), far_res(v, w, f, b, r), acc);
+                    }
+                if (first) v.gvec[((size_t)w * v.M + k) * 15 + d] += acc;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
-// right-hand side number (s, j) of the low-rank correction: column j of the far factor in slot s of every window,
-// u = [Ja[j][:] at pose a, Jb[j][:] at pose b], into a zeroed increment-shaped buffer
+// right-hand side number (s, j) of the low-rank correction: row j of the far factor in slot s of every window, scattered
+// over the keyframes it touches, into a zeroed increment-shaped buffer
 __global__ void __launch_bounds__(64) k_extra_rhs(View v, int s, int j, double* __restrict__ gtmp) {
     const int w = blockIdx.x * 64 + threadIdx.x;
     if (w >= v.B || window_done(v, w)) return;
-    const int i = w * v.x_max + s;
-    const int a = v.x_a[i], kb = v.x_b[i];
-    if (a < v.lo[w] || kb >= v.hi[w] || a >= kb) return;
-    const double* f = v.x_out + ((size_t)v.sel[w] * v.B * v.x_max + i) * BTW_OUT;
-    for (int c = 0; c < 6; c++) {
-        gtmp[((size_t)w * v.M + a) * 15 + c] = f[6 + j * 6 + c];
-        gtmp[((size_t)w * v.M + kb) * 15 + c] = f[42 + j * 6 + c];
+    const FarRef f = far_ref(v, w, s);
+    if (f.kind < 0) return;
+    const int b = v.sel[w], nc = far_cols(f);
+    for (int c = 0; c < nc; c++) {
+        int k, d;
+        far_col(v, w, f, c, k, d);
+        gtmp[((size_t)w * v.M + k) * 15 + d] += far_jac(v, w, f, b, j, c);
     }
 }
 // delta = y - Z (I + U^T Z)^-1 U^T y  (Woodbury; A = H_band + lambda I, y = -A^-1 g in v.delta, column q of Zm = -A^-1 u_q as
@@ -683,20 +753,21 @@ __global__ void __launch_bounds__(256) k_extra_combine(View v, const double* __r
     __shared__ double cvec[MM];
     const int w = blockIdx.x, tid = threadIdx.x;
     if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w)) return;
-    const int m = 6 * slots, lo = v.lo[w], hi = v.hi[w];      // slots in use (the rest are empty in every window)
-    const double* xo = v.x_out + ((size_t)v.sel[w] * v.B + w) * v.x_max * BTW_OUT;
+    const int m = 6 * slots, lo = v.lo[w], hi = v.hi[w], b = v.sel[w];      // slots in use (the rest are empty in every window)
     // C[p][q] = delta_pq - u_p . Zm_q  (= delta_pq + u_p^T A^-1 u_q), C[p][m] = u_p . y
     for (int e = tid; e < m * (m + 1); e += 256) {
         const int p = e / (m + 1), q = e - p * (m + 1);
-        const int s = p / 6, j = p - 6 * s, i = w * v.x_max + s;
-        const int a = v.x_a[i], kb = v.x_b[i];
+        const int s = p / 6, j = p - 6 * s;
+        const FarRef f = far_ref(v, w, s);
         double acc = 0.0;
-        if (!(a < lo || kb >= hi || a >= kb)) {
-            const double* f = xo + (size_t)s * BTW_OUT;
-            const double* col = q < m ? Zm + (size_t)q * zstride : v.delta;
-            const double* za = col + ((size_t)w * v.M + a) * 15;
-            const double* zb = col + ((size_t)w * v.M + kb) * 15;
-            for (int c = 0; c < 6; c++) acc = fma(f[6 + j * 6 + c], za[c], fma(f[42 + j * 6 + c], zb[c], acc));
+        if (f.kind >= 0) {
+            const double* col = (q < m ? Zm + (size_t)q * zstride : v.delta) + (size_t)w * v.M * 15;
+            const int nc = far_cols(f);
+            for (int c = 0; c < nc; c++) {
+                int k, d;
+                far_col(v, w, f, c, k, d);
+                acc = fma(far_jac(v, w, f, b, j, c), col[(size_t)k * 15 + d], acc);
+            }
         }
         C[p][q] = q < m ? (p == q ? 1.0 : 0.0) - acc : acc;
     }
@@ -3059,9 +3130,10 @@ __global__ void __launch_bounds__(1024) k_decide(View v, int init) {
             for (int r = 0; r < 15; r++) s = fma(f[r], f[r], s);
         }
         if (v.mp_on[w] && hi - lo >= 3) s += 2.0 * v.mp_out[((size_t)b * v.B + w) * 28 + 27];
-        for (int xs = 0; xs < v.x_max; xs++) {           // far between factors (empty slots hold zeros)
+        for (int xs = 0; xs < v.x_max; xs++) {           // far between factors, nonlinear and linear (empty slots hold zeros)
             const double* f = v.x_out + (((size_t)b * v.B + w) * v.x_max + xs) * BTW_OUT;
-            for (int r = 0; r < 6; r++) s = fma(f[r], f[r], s);
+            const double* fl = v.xl_out + ((size_t)b * v.B + w) * 6 * v.x_max + 6 * xs;
+            for (int r = 0; r < 6; r++) s = fma(f[r], f[r], fma(fl[r], fl[r], s));
         }
     }
     __shared__ double red[1024];
@@ -3249,6 +3321,7 @@ __global__ void __launch_bounds__(256) k_relinearize(View v, double threshold) {
 // factors starting at m -- taken at the current linearisation (buffer `sel`), onto
 // [m+1: 15][m+2: pose 6][m+3: pose 6].  One 256-thread workgroup per window, 42x42 system in LDS, Gaussian
 // elimination of the 15 leading columns (no square roots).  Runs once per slide.
+template <bool FAR>
 __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
     const int w = blockIdx.x, lane = threadIdx.x;
     const int lo = v.lo[w], hi = v.hi[w];
@@ -3336,6 +3409,83 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
         if (is_b) bv[i] = sum; else A[i * 43 + j] = sum;
     }
     __syncthreads();
+    // ---- FAR: the window's linear far factor (View::xl_*; every row of it has the leaving keyframe in its support) and the
+    // nonlinear far factors anchored at m whose end lies beyond the prior's reach are marginalised WITH m, jointly and exactly
+    // at the current linearisation.  With W = [W_mn | W_b | r] their whitened rows over (m and the prior's keyframes n: the 42
+    // columns of A; the far ends b: 6 each; residual), the system to eliminate m from is
+    //     [A + W_mn^T W_mn   (W_b^T W_mn)^T]         [bv + W_mn^T r]
+    //     [W_b^T W_mn         W_b^T W_b    ]    and  [W_b^T r      ]
+    // whose far-end rows are kept in E (the A block and bv in place).  A far end that has come within the prior's reach
+    // (m + 3) is folded into the columns of that keyframe first.  After the 15 pivots, (n, b) hold the exact marginal S; it is
+    // split again into a prior on n alone and six rows per far end:
+    //     S_bb = L L^T,  X = L^-1 [S_bn | eta_b],  rows U' = [X_n | L^T], r' = x_eta;  prior: S_nn - X_n^T X_n, eta_n - X_n^T x_eta
+    // (U'^T U' + prior = S).  Rows and far ends are written back compacted; the far ends' linearisation points move to the
+    // current states, like the prior's.
+    constexpr int FR = FAR ? 6 * MAX_EXTRA : 1, FC = 42 + 6 * MAX_EXTRA + 1;      // rows of W / E, their columns
+    __shared__ double Wf[FR * FC], E[FR * FC];
+    __shared__ int f_kb[MAX_EXTRA], f_src[MAX_EXTRA], f_fold[MAX_EXTRA], f_T, f_live;
+    if constexpr (FAR) {
+        const int nl_old = v.xl_n[w];
+        if (lane == 0) {
+            // far ends of the joint factor: the old linear ones, then the nonlinear far factors this marginalisation converts
+            // (f_src: -1 - e = old far end e, i >= 0 = entry i of the nonlinear list)
+            int T = 0;
+            for (int e = 0; e < nl_old; e++) { f_kb[T] = v.xl_b[w * v.x_max + e]; f_src[T] = -1 - e; f_fold[T] = f_kb[T] == lo + 3; T++; }
+            for (int i = 0; i < v.x_max && T < MAX_EXTRA; i++) {
+                const int a = v.x_a[w * v.x_max + i], kb = v.x_b[w * v.x_max + i];
+                if (a == lo && kb - lo > 3 && kb < hi) { f_kb[T] = kb; f_src[T] = i; f_fold[T] = 0; T++; }
+            }
+            f_T = T;
+        }
+        __syncthreads();
+        const int T = f_T, R = 6 * T, NC = 42 + 6 * T + 1;       // (columns: 0..41 as A, 42 + 6 t + c far end t, NC - 1 residual)
+        for (int e = lane; e < R * FC; e += 256) {
+            const int row = e / FC, c = e - row * FC, t = row / 6, j = row - 6 * t;
+            double x = 0.0;
+            if (c < NC) {
+                const bool res = c == NC - 1;
+                const int tc = (c >= 42 && !res) ? (c - 42) / 6 : -1, cc = tc >= 0 ? c - 42 - 6 * tc : 0;
+                if (f_src[t] < 0) {
+                    // row (6 e + j) of the old factor: columns [m: 0..14][m+1 pose: 15..20][m+2 pose: 21..26][far end q: 27 + 6 q ..]
+                    const int eo = -1 - f_src[t];
+                    const double* U = v.xl_U + ((size_t)w * 6 * v.x_max + 6 * eo + j) * XL_LD;
+                    if (res) x = v.xl_out[((size_t)b * v.B + w) * 6 * v.x_max + 6 * eo + j];
+                    else if (c < 21) x = U[c];                                     // m, pose of m + 1
+                    else if (c >= 30 && c < 36) x = U[21 + c - 30];                // pose of m + 2
+                    else if (tc >= 0 && f_src[tc] < 0) x = U[27 + 6 * (-1 - f_src[tc]) + cc];   // (old far ends keep their order: tc = that end)
+                } else {
+                    const double* F = v.x_out + (((size_t)b * v.B + w) * v.x_max + f_src[t]) * BTW_OUT;
+                    if (res) x = F[j];
+                    else if (c < 6) x = F[6 + j * 6 + c];
+                    else if (tc == t) x = F[42 + j * 6 + cc];
+                }
+            }
+            Wf[e] = x;
+        }
+        __syncthreads();
+        // a far end at m + 3: its columns join the pose columns of that keyframe (36..41)
+        for (int e = lane; e < R * 6; e += 256) {
+            const int row = e / 6, c = e - row * 6;
+            double add = 0.0;
+            for (int t = 0; t < T; t++)
+                if (f_fold[t]) { add += Wf[row * FC + 42 + 6 * t + c]; Wf[row * FC + 42 + 6 * t + c] = 0.0; }
+            Wf[row * FC + 36 + c] += add;
+        }
+        __syncthreads();
+        for (int e = lane; e < 42 * 43; e += 256) {
+            const int i = e / 43, j = e - i * 43;
+            double sum = 0.0;
+            for (int r = 0; r < R; r++) sum = fma(Wf[r * FC + i], j < 42 ? Wf[r * FC + j] : Wf[r * FC + NC - 1], sum);
+            if (j < 42) A[i * 43 + j] += sum; else bv[i] += sum;
+        }
+        for (int e = lane; e < R * FC; e += 256) {
+            const int p = e / FC, c = e - p * FC;
+            double sum = 0.0;
+            if (c < NC) for (int r = 0; r < R; r++) sum = fma(Wf[r * FC + 42 + p], Wf[r * FC + c], sum);
+            E[e] = sum;
+        }
+        __syncthreads();
+    }
     int bad = 0;
     for (int c = 0; c < 15; c++) {
         const double d = A[c * 43 + c];
@@ -3350,6 +3500,86 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
             const int i = c + 1 + (is_b ? e - m * m : e / m), j = is_b ? -1 : c + 1 + (e - (e / m) * m);
             const double u = A[i * 43 + c] * inv * (is_b ? bv[c] : A[j * 43 + c]);
             if (is_b) bv[i] -= u; else A[i * 43 + j] -= u;
+        }
+        if constexpr (FAR) {
+            // the far-end rows: E[p][j] -= E[p][c] / d * (row c of the whole system)[j]; row c is A[c][.] over the 42 columns,
+            // E[.][c] over the far-end columns (symmetry), bv[c] for the right-hand side
+            const int R = 6 * f_T, NC = 42 + R + 1;
+            for (int e = lane; e < R * FC; e += 256) {
+                const int p = e / FC, j = e - p * FC;
+                if (j <= c || j >= NC) continue;
+                const double rc = j < 42 ? A[c * 43 + j] : (j < NC - 1 ? E[(j - 42) * FC + c] : bv[c]);
+                E[e] -= E[p * FC + c] * inv * rc;
+            }
+        }
+        __syncthreads();
+    }
+    if constexpr (FAR) {
+        // ---- split the marginal over (n, far ends) into the prior on n and six rows per live far end
+        const int T = f_T;
+        if (lane == 0) { int L = 0; for (int t = 0; t < T; t++) if (!f_fold[t]) f_src[L++] = t; f_live = L; }    // (f_src: now the live far ends, in order)
+        __syncthreads();
+        const int Lv = f_live, RL = 6 * Lv;
+        auto pr = [&](int q) { return 6 * f_src[q / 6] + q % 6; };              // live row / column q -> row of E (column 42 + that)
+        // S_bb (live x live) -> Wf[q][q2] (row stride FC), then Cholesky in place, right-looking, entry-parallel
+        for (int e = lane; e < RL * RL; e += 256) { const int q = e / RL, q2 = e - q * RL; Wf[q * FC + q2] = 0.5 * (E[pr(q) * FC + 42 + pr(q2)] + E[pr(q2) * FC + 42 + pr(q)]); }
+        __syncthreads();
+        for (int c = 0; c < RL; c++) {
+            const double d = Wf[c * FC + c];
+            if (!(d > 0.0)) bad = 1;
+            const double sd = sqrt(d > 0.0 ? d : 1.0);
+            __syncthreads();
+            for (int q = c + lane; q < RL; q += 256) Wf[q * FC + c] = q == c ? sd : Wf[q * FC + c] / sd;
+            __syncthreads();
+            const int rem = RL - 1 - c;
+            for (int e = lane; e < rem * rem; e += 256) {
+                const int q = c + 1 + e / rem, q2 = c + 1 + (e - (e / rem) * rem);
+                if (q2 <= q) Wf[q * FC + q2] -= Wf[q * FC + c] * Wf[q2 * FC + c];
+            }
+            __syncthreads();
+        }
+        // X = L^-1 [S_bn | eta_b]: thread per column (27 + 1), into Wf[q][RL + col]
+        if (lane < 28) {
+            const int src = lane < 27 ? 15 + lane : 42 + 6 * T;                 // column of E: n's 27 (A's 15..41), the right-hand side
+            for (int q = 0; q < RL; q++) {
+                double a = E[pr(q) * FC + src];
+                for (int k = 0; k < q; k++) a = fma(-Wf[q * FC + k], Wf[k * FC + RL + lane], a);
+                Wf[q * FC + RL + lane] = a / Wf[q * FC + q];
+            }
+        }
+        __syncthreads();
+        // the prior on n loses what the rows now carry
+        for (int e = lane; e < 27 * 28; e += 256) {
+            const int i = e / 28, j = e - i * 28;
+            double sum = 0.0;
+            for (int q = 0; q < RL; q++) sum = fma(Wf[q * FC + RL + i], Wf[q * FC + RL + j], sum);
+            if (j < 27) A[(15 + i) * 43 + 15 + j] -= sum; else bv[15 + i] -= sum;
+        }
+        // the rows: [X_n | L^T] over [n: 27][live far ends: 6 each], residual x_eta -- both buffers, the linearisation point
+        // being the current states from here on
+        for (int e = lane; e < RL * XL_LD; e += 256) {
+            const int q = e / XL_LD, c = e - q * XL_LD;
+            double x = 0.0;
+            if (c < 27) x = Wf[q * FC + RL + c];
+            else if (c - 27 < RL && c - 27 >= q) x = Wf[(c - 27) * FC + q];     // L^T: upper triangle
+            v.xl_U[((size_t)w * 6 * v.x_max + q) * XL_LD + c] = x;
+        }
+        for (int q = lane; q < 6 * v.x_max; q += 256) {
+            const double x = q < RL ? Wf[q * FC + RL + 27] : 0.0;
+            v.xl_r0[(size_t)w * 6 * v.x_max + q] = x;
+            v.xl_out[((size_t)0 * v.B + w) * 6 * v.x_max + q] = x;
+            v.xl_out[((size_t)1 * v.B + w) * 6 * v.x_max + q] = x;
+        }
+        __syncthreads();                                 // (xl_b is read through f_kb, written below)
+        if (lane < Lv * 7) {
+            const int q = lane / 7, c = lane - 7 * q;
+            v.xl_bx[((size_t)w * v.x_max + q) * 7 + c] = XS(b, c, (long)w * v.M + f_kb[f_src[q]]);
+        }
+        if (lane >= 64 && lane < 64 + Lv) v.xl_b[w * v.x_max + lane - 64] = f_kb[f_src[lane - 64]];
+        if (lane == 128) v.xl_n[w] = Lv;
+        if (lane >= 192 && lane < 192 + v.x_max) {       // the nonlinear entries that have just become linear (the host re-sends the list without them)
+            const int i = w * v.x_max + lane - 192;
+            if (v.x_a[i] == lo && v.x_b[i] - lo > 3 && v.x_b[i] < hi) v.x_a[i] = -1;
         }
         __syncthreads();
     }
@@ -3754,7 +3984,8 @@ void launch_slide(const View& v, const double* sigma15_dev, int reanchor, hipStr
     hipLaunchKernelGGL(k_slide, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, sigma15_dev, reanchor);
 }
 void launch_marginalize(const View& v, int* status, hipStream_t s) {
-    hipLaunchKernelGGL(k_marginalize, dim3(v.B), dim3(256), 0, s, v, status);
+    if (v.x_max > 0) hipLaunchKernelGGL(k_marginalize<true>, dim3(v.B), dim3(256), 0, s, v, status);
+    else hipLaunchKernelGGL(k_marginalize<false>, dim3(v.B), dim3(256), 0, s, v, status);
 }
 void launch_shift_copy(const double* src, double* dst, long n, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_shift_copy, dim3(nblk(n, 256)), dim3(256), 0, s, src, dst, n);

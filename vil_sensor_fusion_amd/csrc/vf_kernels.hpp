@@ -25,7 +25,8 @@ constexpr int JS_PI = (JS_NI + 1) / 2, JS_PJ = (JS_NJ + 1) / 2, JS_PAIRS = JS_PI
 constexpr int JT_STRIDE = JS_PAIRS * JT * 2;        // 2336 doubles = 146 lines per tile
 constexpr int BTW_IN = 28;      // q(4), t(3), R packed upper (21)
 constexpr int BTW_OUT = 78;     // r(6), Ja(36), Jb(36)
-constexpr int MAX_EXTRA = 8;    // far between factors per window (= VF_MAX_EXTRA of include/vilfusion.h)
+constexpr int MAX_EXTRA = 8;
+constexpr int XL_LD = 27 + 6 * MAX_EXTRA;     // row stride of the linear far factor (View::xl_U): 27 head columns + 6 per far end    // far between factors per window (= VF_MAX_EXTRA of include/vilfusion.h)
 constexpr int PRIOR_IN = 31;    // mean state (16), sigma (15)
 constexpr int PRIOR_OUT = 240;  // r(15), J(15x15)
 // Block row of H of one keyframe k, as the solver reads it (512 doubles, 4 KB):
@@ -202,6 +203,21 @@ struct View {
     int* x_b;
     double* x_in;       // [B][x_max][28]
     double* x_out;      // [2][B][x_max][78] linearisations, double-buffered like btw_out
+    // LINEAR far factors: what far factors become when the marginalisation eliminates their older keyframe (k_marginalize).
+    // Marginalising a keyframe that several far factors touch couples their far ends, so the window holds them as ONE linear
+    // factor: xl_n far ends, six whitened rows per far end, every row over [lo: 15][lo+1: pose][lo+2: pose][far end 0: pose] ..
+    // [far end xl_n-1: pose] (row stride XL_LD), and a residual at the linearisation point -- the marginal prior's own (mp_x)
+    // for the three head keyframes, xl_bx for the far ends:
+    //     r(x) = r0 + U [Local(mp_x -> x_lo .. x_lo+2) (27); Local(xl_bx[e] -> x_{b_e}) (6 each)]
+    // Re-expressed by every later marginalisation (its support always includes the keyframe that leaves); a far end that
+    // comes within the prior's reach is folded into the prior.  In a window's slot numbering the far ends come first: slot
+    // s < xl_n is rows 6 s .. 6 s + 5, slot xl_n + i is entry i of x_a / x_b.  Linear + nonlinear <= x_max per window.
+    int* xl_n;          // [B]
+    int* xl_b;          // [B][x_max] window-local keyframe of each far end
+    double* xl_U;       // [B][6 x_max][XL_LD]
+    double* xl_r0;      // [B][6 x_max]
+    double* xl_bx;      // [B][x_max][7] (q w x y z, t)
+    double* xl_out;     // [2][B][6 x_max] residual at the states of each buffer
 };
 
 // Work vectors of the refined solve (vf_refine.hip): conjugate gradients on (J^T J + lambda I) d = -J^T r with the operator

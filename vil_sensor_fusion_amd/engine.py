@@ -141,6 +141,12 @@ class Engine:
         check(self._l.vf_engine_get_extra_between(self._h, window, C.byref(n), _i(a), _i(b), _d(r), C.byref(tr), C.byref(en), C.byref(ab)))
         return a[:n.value].copy(), b[:n.value].copy(), r[:n.value].copy(), tr.value, en.value, ab.value
 
+    def get_linear_far(self, window):
+        """window-local keyframes the window's LINEAR far factors end at (far factors whose older keyframe has been marginalised)"""
+        n, b = C.c_int(), np.zeros(8, dtype=np.int32)
+        check(self._l.vf_engine_get_linear_far(self._h, window, C.byref(n), _i(b)))
+        return b[:n.value].copy()
+
     def clear_between(self, window, k0, n):
         check(self._l.vf_engine_clear_between(self._h, window, k0, n))
 

@@ -81,7 +81,8 @@ struct vf_graph {
     // Between factors the band cannot hold -- wider than VF_MAX_BANDWIDTH keyframes, or a second one ending at a key (loop
     // closures; iSAM2 takes any pair of keys, GraphManager.cpp:83-88): handed to the engine as "far" factors
     // (vf_engine_set_extra_between) at every solve.  When the older key of one leaves the fixed-lag window the engine
-    // transports the factor to the next keyframe (vf_engine_drop_oldest; include/vilfusion.h) and the entry here follows.  band_end[k] != 0: key k
+    // marginalises the factor with it and keeps it from then on as linear rows of its own (include/vilfusion.h): the entry
+    // here goes (the list is replaced by what vf_engine_get_extra_between reports).  band_end[k] != 0: key k
     // already carries a band factor.  far_new counts the ones added since the last solve (they are part of graph()->size()).
     std::vector<PendingBetween> far_between;
     std::deque<uint8_t> band_end;      // entry i: key band_base + i (trimmed below the window at every solve)
@@ -528,8 +529,8 @@ int vf_solve(vf_graph* g) {
     const int lo = g->lo;
     lap("marginalize");
     if (marginalised && g->far_on_device) {
-        // the engine has moved the far factors whose older key left on to the next keyframe (or dropped one that reached its
-        // own end): the entries that were on the device are replaced by what the engine holds now
+        // the engine has marginalised the far factors whose older key left together with that key (they are linear rows of its
+        // own now): the entries that were on the device are replaced by what the engine's list holds now
         int cnt = 0;
         int32_t ea[VF_MAX_EXTRA], eb[VF_MAX_EXTRA];
         double erec[VF_MAX_EXTRA * VF_BTW_RECORD];
@@ -590,7 +591,7 @@ int vf_solve(vf_graph* g) {
     const int rc = locked();
     if (fars_changed) {
         // the entries snapshotted above are the front of the list (others only append, under graph_mutex): replace them by
-        // their current form (transported keys / records, on_device marks)
+        // their current form (the ones the engine has taken over are gone; on_device marks)
         std::lock_guard<std::mutex> lk(g->graph_mutex);
         if (g->far_between.size() >= fars_snapshot) {
             std::vector<PendingBetween> now(fars);

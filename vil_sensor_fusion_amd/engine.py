@@ -134,8 +134,8 @@ class Engine:
         check(self._l.vf_engine_set_extra_between(self._h, window, a.size, _i(a), _i(b), _d(r)))
 
     def get_extra_between(self, window):
-        """(a, b, records, transported so far, dropped without a marginalisation so far, absorbed into the marginal prior so far):
-        the window's far factors as they stand"""
+        """(a, b, records, made linear by a marginalisation or re-anchored by a slide without one so far, dropped without a
+        marginalisation so far, absorbed into the marginal prior so far): the window's nonlinear far factors as they stand"""
         n, tr, en, ab = C.c_int(), C.c_long(), C.c_long(), C.c_long()
         a, b, r = np.zeros(8, dtype=np.int32), np.zeros(8, dtype=np.int32), np.zeros((8, BTW_RECORD))
         check(self._l.vf_engine_get_extra_between(self._h, window, C.byref(n), _i(a), _i(b), _d(r), C.byref(tr), C.byref(en), C.byref(ab)))

@@ -75,6 +75,7 @@ int vf_engine_get_extra_between(vf_engine* e, int, int* n, int32_t* a, int32_t* 
     if (ab) *ab = 0;
     return VF_OK;
 }
+int vf_engine_get_linear_far(vf_engine*, int, int* n, int32_t*) { if (n) *n = 0; return VF_OK; }
 int vf_engine_grow(vf_engine*, int) { return VF_OK; }
 int vf_engine_isam_step(vf_engine*, double) { return VF_OK; }
 int vf_engine_iterate(vf_engine*, int) { fake_iterates++; return VF_OK; }

@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -95,6 +96,7 @@ struct vf_graph {
     }
     int far_new = 0;
     bool far_on_device = false;    // the engine holds a non-empty far list (written under solve_mutex only)
+    std::atomic<int> far_linear{0};  // far ends of the engine's linear far factor (far factors marginalised with their older key): they share VF_MAX_EXTRA
     int staged_count = 3;  // the three priors (GraphManager.cpp:33-35)
     uint64_t current_key = 0;
     double last_pose_time = -1.0;
@@ -345,7 +347,7 @@ int vf_add_between(vf_graph* g, uint64_t prev, uint64_t cur, const double q[4], 
         g->staged_between.push_back(b);
     } else {
         // not a band factor: a far factor, solved as a low-rank correction (slower; include/vilfusion.h).  The list is bounded.
-        if ((int)g->far_between.size() >= VF_MAX_EXTRA)
+        if ((int)g->far_between.size() + g->far_linear.load() >= VF_MAX_EXTRA)
             return gerr(VF_ERR_CAPACITY, "between factor (%llu, %llu) spans %llu keyframes or shares its end key, and the window already holds %d such factors",
                         (unsigned long long)prev, (unsigned long long)cur, (unsigned long long)(cur - prev), VF_MAX_EXTRA);
         g->far_between.push_back(b);
@@ -528,7 +530,7 @@ int vf_solve(vf_graph* g) {
     }
     const int lo = g->lo;
     lap("marginalize");
-    if (marginalised && g->far_on_device) {
+    if (marginalised && (g->far_on_device || g->far_linear.load() > 0)) {
         // the engine has marginalised the far factors whose older key left together with that key (they are linear rows of its
         // own now): the entries that were on the device are replaced by what the engine's list holds now
         int cnt = 0;
@@ -548,6 +550,9 @@ int vf_solve(vf_graph* g) {
             if (!f.on_device) moved.push_back(f);
         fars.swap(moved);
         fars_changed = true;
+        int lin = 0;
+        if ((rc = vf_engine_get_linear_far(g->eng, 0, &lin, nullptr))) return give_back(rc);
+        g->far_linear.store(lin);
     }
     if (!fars.empty() || g->far_on_device) {
         // far between factors still inside the window, in window-local slots (the engine ignores one whose older keyframe

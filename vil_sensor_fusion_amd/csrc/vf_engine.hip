@@ -641,6 +641,13 @@ int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec) {
     HIPCHK(hipMemcpyAsync(e->v.prior_in + (size_t)window * vf::PRIOR_IN, rec, vf::PRIOR_IN * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->v.prior_k + window, &k, sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemsetAsync(e->v.mp_on + window, 0, sizeof(int), e->stream));   // a fresh anchor replaces any marginal prior
+    if (e->v.x_max > 0 && e->h_ln(window) > 0) {                               // ... and the linear far factor that is expressed around it
+        HIPCHK(hipMemsetAsync(e->v.xl_n + window, 0, sizeof(int), e->stream));
+        e->far_ended += e->h_ln(window);
+        e->h_lb[window].clear();
+        e->recount_far();
+        e->epoch++;
+    }
     HIPCHK(hipStreamSynchronize(e->stream));
     return VF_OK;
 }

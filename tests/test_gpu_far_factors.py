@@ -29,7 +29,7 @@ FAR = [(40, 46), (20, 70), (21, 71)]         # a span-6 factor whose end key 46 
 #                                              (span 50: the oracle's dense band costs span^2 -- at span 110 it was half of the GPU suite's time)
 
 
-@pytest.mark.parametrize("form", ["partitioned", "one_wave_sweep"])
+@pytest.mark.parametrize("form", ["partitioned", "one_wave_sweep", "refined"])
 def test_far_factors_match_the_oracle(oracle, form):
     n = 200
     seq = synth.make_sequence(seed=91, n_kf=n)
@@ -38,6 +38,10 @@ def test_far_factors_match_the_oracle(oracle, form):
     far_rec = np.array([_far_record(seq, a, b, rng) for a, b in FAR])
     fa, fb = np.array([a for a, _ in FAR], dtype=np.int32), np.array([b for _, b in FAR], dtype=np.int32)
     opts = dict(chunks=1, sweep_two_sided_max=0) if form == "one_wave_sweep" else {}
+    if form == "refined":
+        # the refined solve (the default of windows longer than 1 536 keyframes, forced here): the far factors are rows of the
+        # operator of its conjugate gradients instead of a Woodbury correction -- 8 + 6 per slot corrections at most
+        opts = dict(refine_iterations=8, lm_excursion=0)
     # three windows on one engine: all three far factors, none, the loop-closure pair only
     eng = Engine(EngineOpts(windows=3, capacity=n, **opts))
     for w in range(3):
@@ -382,3 +386,39 @@ def test_far_capacity_counts_the_factors_the_engine_has_taken_over():
     # one every 2 keys fills the 8 slots after 16 keys, then one is taken whenever one has been folded into the prior
     assert taken[:8] == list(range(45, 61, 2)) and refused and refused[0] == 61 and len(taken) > 10
     assert st["solve_failures"] == 0 and np.isfinite(t).all()
+
+
+def test_refined_windows_take_far_factors_as_rows_of_the_operator(oracle):
+    """A window long enough to be refined (vf_engine_opts.refine_iterations; here forced on a short one) that holds far
+    factors -- nonlinear ones and, after their anchors have been marginalised, the linear far factor -- solves them inside
+    the refinement's conjugate gradients (k_far_apply: six more rows of J per slot, the band factor as preconditioner, one
+    band solve per correction) where an unrefined window applies the Woodbury correction (six band solves per slot).  Same
+    normal equations: the two engines stay together over 60 marginalised slides, through the conversion of both closures and
+    the folding of both into the prior."""
+    total, n, K = 130, 60, 6
+    seq = synth.make_sequence(seed=95, n_kf=total)
+    prob = helpers.build_problem(oracle, seq)
+    rng = np.random.default_rng(12)
+    closures = ((4, 50), (9, 57))
+    fa, fb = np.array([c[0] for c in closures], dtype=np.int32), np.array([c[1] for c in closures], dtype=np.int32)
+    far = np.stack([_far_record(seq, a, b, rng, cov=1e-4, noise=(1e-4, 1e-3)) for a, b in closures])
+    out = {}
+    for name, opts in (("woodbury", {}), ("refined", dict(refine_iterations=8, lm_excursion=0))):
+        eng = Engine(EngineOpts(windows=1, capacity=total, **opts))
+        helpers.load_engine(eng, 0, prob, 0, n)
+        eng.set_extra_between(0, fa, fb, far)
+        eng.iterate(30)
+        snaps = []
+        for s in range(1, 61):
+            eng.slide(marginalize=True)
+            eng.iterate(K)
+            if s in (3, 8, 30, 49, 60):               # both nonlinear / one converted / both linear / first folded / both folded
+                snaps.append((eng.get_states(0, s, n), eng.get_extra_between(0)[0].tolist(), eng.get_linear_far(0).tolist()))
+        out[name] = (snaps, eng.read_lm(0))
+        eng.close()
+    for (sa, na, la), (sb, nb, lb) in zip(out["woodbury"][0], out["refined"][0]):
+        d = np.abs(sa - sb).max()
+        print(f"nonlinear far list {na}, linear far ends {la}: Woodbury vs refined operator, largest state difference {d:.3e}")
+        assert na == nb and la == lb and d <= 1e-8
+    assert [x[1:] for x in out["woodbury"][0]] == [([4, 9], []), ([9], [50]), ([], [50, 57]), ([], [57]), ([], [])]
+    assert out["woodbury"][1]["solve_failures"] == 0 and out["refined"][1]["solve_failures"] == 0

@@ -174,6 +174,55 @@ __global__ void __launch_bounds__(256) k_jtu(View v, Refine q, const double* __r
     for (int c = 0; c < 15; c++) out[(size_t)gk * 15 + c] = o[c];
 }
 
+// ---- far between factors (View::x_*, xl_*; vf_far.hpp): six more rows of J per slot.  One workgroup per window, after k_jtu:
+// out += U^T (U p) (GRAD: out += U^T r), slot by slot (two slots may touch the same keyframe) and, within a slot, one lane
+// per column, the lane of the first of several columns that land on one (keyframe, dof) adding them all.
+#include "vf_far.hpp"
+template <bool GRAD>
+__global__ void __launch_bounds__(64) k_far_apply(View v, Refine q, const double* __restrict__ p, double* __restrict__ out) {
+    const int w = blockIdx.x, lane = threadIdx.x;
+    if (v.hi[w] - v.lo[w] <= 0 || refine_off(v, q, w)) return;
+    const int b = v.sel[w];
+    __shared__ double u[6];
+    for (int s = 0; s < v.x_max; s++) {
+        const FarRef f = far_ref(v, w, s);
+        if (f.kind < 0) continue;                    // (the same for every lane)
+        const int nc = far_cols(f);
+        if (lane < 6) {
+            double acc = GRAD ? far_res(v, w, f, b, lane) : 0.0;
+            if (!GRAD)
+                for (int c = 0; c < nc; c++) {
+                    int k, d;
+                    far_col(v, w, f, c, k, d);
+                    acc = fma(far_jac(v, w, f, b, lane, c), p[((size_t)w * v.M + k) * 15 + d], acc);
+                }
+            u[lane] = acc;
+        }
+        __syncthreads();
+        for (int c0 = 0; c0 < nc; c0 += 64) {
+            const int c = c0 + lane;
+            if (c < nc) {
+                int k, d;
+                far_col(v, w, f, c, k, d);
+                double acc = 0.0;
+                for (int r = 0; r < 6; r++) acc = fma(far_jac(v, w, f, b, r, c), u[r], acc);
+                bool first = true;
+                if (f.kind == 1 && c >= 27)
+                    for (int c2 = 27 + d; c2 < nc; c2 += 6) {
+                        if (c2 == c) continue;
+                        int k2, d2;
+                        far_col(v, w, f, c2, k2, d2);
+                        if (k2 != k) continue;
+                        if (c2 < c) { first = false; break; }
+                        for (int r = 0; r < 6; r++) acc = fma(far_jac(v, w, f, b, r, c2), u[r], acc);
+                    }
+                if (first) out[((size_t)w * v.M + k) * 15 + d] += acc;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- whole-vector steps at the ends of a refinement (PCG_NB workgroups per window, as the steps of a correction below)
 constexpr int PCG_NB = 64, PCG_NT = 256;
 // x := delta (the plain normal-equation solution the engine's solve has just left); a window whose factorisation failed
@@ -277,11 +326,13 @@ static inline unsigned nblk_(long n, int bs) { return (unsigned)((n + bs - 1) / 
 void launch_refine_apply(const View& v, const Refine& q, const double* p, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_jv, dim3(nblk_(v.G, 256)), dim3(256), 0, s, v, q, p);
     hipLaunchKernelGGL(k_jtu<false>, dim3(nblk_(v.G, 256)), dim3(256), 0, s, v, q, p, out);
+    if (v.x_max > 0) hipLaunchKernelGGL(k_far_apply<false>, dim3(v.B), dim3(64), 0, s, v, q, p, out);
 }
 void launch_refine_begin(const View& v, const Refine& q, hipStream_t s) {
     hipLaunchKernelGGL(k_pcg_begin, dim3(PCG_NB, (unsigned)v.B), dim3(PCG_NT), 0, s, v, q);
     launch_refine_apply(v, q, q.x, q.Ap, s);
     hipLaunchKernelGGL(k_jtu<true>, dim3(nblk_(v.G, 256)), dim3(256), 0, s, v, q, q.x, q.p);     // q.p := J^T r (p has no direction yet)
+    if (v.x_max > 0) hipLaunchKernelGGL(k_far_apply<true>, dim3(v.B), dim3(64), 0, s, v, q, q.x, q.p);
     hipLaunchKernelGGL(k_pcg_residual, dim3(PCG_NB, (unsigned)v.B), dim3(PCG_NT), 0, s, v, q);
 }
 void launch_refine_step(const View& v, const Refine& q, double rel_stop, hipStream_t s) {

@@ -114,8 +114,7 @@ typedef struct {
      * handful of modes the factor gets wrong.  -1 (default) = up to 12 corrections once a window is longer than
      * refine_min_keyframes, none otherwise (the headline windows are untouched); 0 = never; N = always N (at most 64).
      * Refining engines run the two-kernel form (K3 + K4).  Far factors of a refined engine are rows of the refinement's operator
-     * instead of a Woodbury correction (6 more corrections per far-factor slot in use, 60 at most; each correction is one band
-     * solve where the Woodbury form takes six per slot). */
+     * too, and the Woodbury solve (band factor + the far factors' columns, computed once per trial) is its preconditioner. */
     int refine_iterations;
     int refine_min_keyframes;  /* default 1536: Gauss-Newton by normal equations alone contracts by 0.025 per update at 1 250 keyframes, 0.1 at
                                   1 500, 0.3 at 2 000, 0.7 at 3 000 and creeps beyond */

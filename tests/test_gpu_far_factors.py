@@ -40,7 +40,7 @@ def test_far_factors_match_the_oracle(oracle, form):
     opts = dict(chunks=1, sweep_two_sided_max=0) if form == "one_wave_sweep" else {}
     if form == "refined":
         # the refined solve (the default of windows longer than 1 536 keyframes, forced here): the far factors are rows of the
-        # operator of its conjugate gradients instead of a Woodbury correction -- 8 + 6 per slot corrections at most
+        # operator of its conjugate gradients too, the Woodbury solve is their preconditioner
         opts = dict(refine_iterations=8, lm_excursion=0)
     # three windows on one engine: all three far factors, none, the loop-closure pair only
     eng = Engine(EngineOpts(windows=3, capacity=n, **opts))
@@ -390,11 +390,10 @@ def test_far_capacity_counts_the_factors_the_engine_has_taken_over():
 
 def test_refined_windows_take_far_factors_as_rows_of_the_operator(oracle):
     """A window long enough to be refined (vf_engine_opts.refine_iterations; here forced on a short one) that holds far
-    factors -- nonlinear ones and, after their anchors have been marginalised, the linear far factor -- solves them inside
-    the refinement's conjugate gradients (k_far_apply: six more rows of J per slot, the band factor as preconditioner, one
-    band solve per correction) where an unrefined window applies the Woodbury correction (six band solves per slot).  Same
-    normal equations: the two engines stay together over 60 marginalised slides, through the conversion of both closures and
-    the folding of both into the prior."""
+    factors -- nonlinear ones and, after their anchors have been marginalised, the linear far factor -- has their rows in the
+    operator of the refinement's conjugate gradients (k_far_apply: six more rows of J per slot) and the Woodbury solve as its
+    preconditioner.  Same normal equations as the unrefined engine's: the two stay together over 60 marginalised slides,
+    through the conversion of both closures and the folding of both into the prior."""
     total, n, K = 130, 60, 6
     seq = synth.make_sequence(seed=95, n_kf=total)
     prob = helpers.build_problem(oracle, seq)

@@ -76,3 +76,43 @@ def test_fixed_lag_updates_of_a_window_that_refines(oracle):
     assert a0 <= 1e-6 and worst <= 1e-6 and dL <= 1e-6 and lm["solve_failures"] == 0
     assert abs(lm["cost"] - ref.costs[-1]) <= 1e-8 * ref.costs[-1]
     eng.close()
+
+
+def test_a_long_window_with_loop_closures_converges_by_the_defaults(oracle):
+    """The reference's own use of loop closures: an unbounded graph (lag = 0) that has grown past 1 536 keyframes and takes a
+    BetweenFactor between keys far apart (GraphManager.cpp:83-88).  Such a window is refined by default: its far factors are
+    rows of the refinement's operator (k_far_apply) and the Woodbury solve is the preconditioner.  No oracle can hold a band
+    1 500 keyframes wide, so the check is against the library's other route to the same optimum: the unrefined engine
+    (normal equations + Woodbury correction), which at 1 700 keyframes still converges, only slower (contraction 0.16 per
+    Gauss-Newton update against 1e-2).  Same start (the refined optimum WITHOUT the closures, so both only have the closures'
+    correction to find), 8 Gauss-Newton updates each."""
+    from tests.test_gpu_far_factors import _far_record
+    n = 1700
+    seq = synth.make_sequence(seed=14, n_kf=n)
+    prob = helpers.build_problem(oracle, seq)
+    ref = helpers.oracle_window(oracle, prob)
+    for _ in range(6):
+        oracle.gn_step(ref, refine=12)
+    prob = dict(prob, states=ref.states.copy())
+    rng = np.random.default_rng(15)
+    closures = ((100, 1650), (400, 1200))
+    fa, fb = np.array([c[0] for c in closures], dtype=np.int32), np.array([c[1] for c in closures], dtype=np.int32)
+    far = np.stack([_far_record(seq, a, b, rng, cov=1e-4, noise=(1e-4, 1e-3)) for a, b in closures])
+    out = {}
+    for name, opts in (("defaults", {}), ("unrefined", dict(refine_iterations=0, lm_excursion=0))):
+        eng = Engine(EngineOpts(windows=1, capacity=n, **opts))
+        helpers.load_engine(eng, 0, prob)
+        eng.set_extra_between(0, fa, fb, far)
+        assert eng.refine_count() == (12 if name == "defaults" else 0)
+        hist = []
+        for _ in range(8):
+            eng.isam_step(0.0)
+            hist.append(eng.get_estimate(0, 0, n))
+        out[name] = hist
+        eng.close()
+    moved = helpers.ate(out["defaults"][-1], prob["states"])[0]
+    d = [helpers.ate(a, out["defaults"][-1])[0] for a in out["defaults"][:-1]]
+    du = [helpers.ate(a, out["defaults"][-1])[0] for a in out["unrefined"]]
+    print(f"{n} keyframes, closures {closures}: they move the optimum by {moved:.3e} m; distance to the refined engine's 8th update -- "
+          f"refined, updates 1..7: {' '.join(f'{x:.1e}' for x in d)}; unrefined (Woodbury), updates 1..8: {' '.join(f'{x:.1e}' for x in du)}")
+    assert moved > 1e-3 and d[3] <= 1e-7 and du[-1] <= 1e-6

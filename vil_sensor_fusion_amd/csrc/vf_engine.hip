@@ -835,28 +835,7 @@ int vf_engine_solve(vf_engine* e) {
         } else vf::launch_band_solve(a, e->stream);
     };
     band_solve(e->v.gvec, e->v.delta);
-    const int R_far = e->x_used > 0 ? e->refine_iters() : 0;
-    if (R_far > 0) {
-        // Far factors in a window that is refined: no Woodbury correction -- the band solution is the start, the band factor
-        // the preconditioner, and the far rows are part of the operator J (k_far_apply): conjugate gradients removes the
-        // 6-per-slot directions the preconditioner does not know in as many extra corrections, each ONE band solve where the
-        // Woodbury form takes six per slot.  (The right-hand side the band solve took already holds the far factors' J^T r.)
-        if (int rc = e->ensure_refine()) return rc;
-        const int R = std::min(R_far + 6 * e->x_used, 60);
-        vf::launch_refine_begin(e->v, e->rq, e->stream);
-        for (int it = 0; it < R; it++) {
-            band_solve(e->rq.nres, e->rq.z, e->rq.stop);
-            vf::launch_refine_step(e->v, e->rq, e->opts.refine_rel_stop, e->stream);
-            if (it >= 3 && it % 2 == 1 && it + 1 < R) {
-                HIPCHK(hipMemcpyAsync(e->rq_stop_host, e->rq.stop, e->v.B * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-                HIPCHK(hipStreamSynchronize(e->stream));
-                bool live = false;
-                for (int w = 0; w < e->v.B && !live; w++) live = e->rq_stop_host[w] == 0;
-                if (!live) break;
-            }
-        }
-        vf::launch_refine_end(e->v, e->rq, e->stream);
-    } else if (e->x_used > 0) {
+    if (e->x_used > 0) {
         // Far between factors: (H_band + lambda I + U U^T) delta = -g by Woodbury -- the band solver once more per column of
         // U (6 per slot in use; it refactorises every time: a fallback for the rare window with such factors, not a fast
         // path), then one small dense system per window (k_extra_combine).
@@ -868,13 +847,25 @@ int vf_engine_solve(vf_engine* e) {
                 band_solve(e->x_gtmp, e->x_Z + (size_t)(6 * s + j) * e->x_zstride);
             }
         vf::launch_extra_combine(e->v, e->x_Z, e->x_zstride, e->x_used, e->stream);   // (slots beyond x_used are empty in every window)
-    } else if (const int R = e->refine_iters()) {
+    }
+    if (const int R = e->refine_iters()) {
         // Refined solve (vf_refine.hip): the increment just computed is the start, the factorisation the preconditioner, of
-        // conjugate gradients on the normal equations with the operator applied through J -- R correction solves.
+        // conjugate gradients on the normal equations with the operator applied through J -- R correction solves.  With far
+        // factors the operator has their rows too (k_far_apply) and the preconditioner is the Woodbury solve above: every
+        // correction is one band solve combined with the columns Z that are already there.  (The band factor alone will not
+        // do as the preconditioner: against the 1e-10 curvature of a long window's soft modes a loop closure's information is
+        // an eigenvalue of 1e14 in M^-1 A, and the band-only start answers the closure's gradient with a step of kilometres.)
         if (int rc = e->ensure_refine()) return rc;
         vf::launch_refine_begin(e->v, e->rq, e->stream);
         for (int it = 0; it < R; it++) {
             band_solve(e->rq.nres, e->rq.z, e->rq.stop);
+            if (e->x_used > 0) {
+                vf::View a = e->v;
+                a.delta = e->rq.z;
+                a.stop_on = 1;
+                a.done = e->rq.stop;
+                vf::launch_extra_combine(a, e->x_Z, e->x_zstride, e->x_used, e->stream);
+            }
             vf::launch_refine_step(e->v, e->rq, e->opts.refine_rel_stop, e->stream);
             // How many corrections a window needs grows with its length (4 at 1 600 keyframes, 12 at 10 000): after the
             // 4th, 6th, ... the stop flags are read back, and once every window has stopped the rest are not issued
@@ -898,7 +889,7 @@ int vf_engine_solve(vf_engine* e) {
 // (vf_engine_solve_local / _global work on the correction's right-hand side while a refinement is open)
 int vf_engine_refine_count(vf_engine* e, int* iterations) {
     if (!e || !iterations) return fail(VF_ERR_INVALID, "null argument");
-    *iterations = e->x_used > 0 && e->refine_iters() > 0 ? std::min(e->refine_iters() + 6 * e->x_used, 60) : e->refine_iters();
+    *iterations = e->refine_iters();
     return VF_OK;
 }
 int vf_engine_refine_begin(vf_engine* e) {

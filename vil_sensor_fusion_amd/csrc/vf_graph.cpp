@@ -397,9 +397,10 @@ int vf_solve(vf_graph* g) {
         for (const auto& bt : betweens) g->set_band_end(bt.b, 1);   // these keys now carry their band factor (a second one goes to the far list)
         // (keys below the window can never be named again by a factor that is accepted: their marks are let go)
         while (!g->band_end.empty() && g->band_base < g->key_base + (uint64_t)g->lo) { g->band_end.pop_front(); g->band_base++; }
-        // far factors whose older key has left the window (as of the previous solve: lo / key_base change under solve_mutex,
-        // which this thread holds) are gone for good: their information is dropped, not marginalised.  One that was added
-        // SINCE that solve never made it into the window: late odometry, reported like a late band factor below
+        // A far factor whose older key has left the window (as of the previous solve: lo / key_base change under solve_mutex,
+        // which this thread holds) is no business of this list: one that was on the device then was marginalised with its key and
+        // lives on in the engine (the list was replaced after that solve's marginalisations); one that was added SINCE that
+        // solve never made it into the window -- late odometry, reported like a late band factor below
         {
             const uint64_t oldest = g->key_base + (uint64_t)g->lo;
             auto& fb = g->far_between;

@@ -418,6 +418,37 @@ def graph_manager_section(lag=1000, extra=120):
         out[name] = {"solve_ms_mean": float(steady.mean()), "solve_ms_p99": float(np.percentile(steady, 99)),
                      "solves_timed": int(steady.size)}
     out["solve_ms_mean"] = out["default_termination"]["solve_ms_mean"]
+    # ... and with a loop closure alive: a far factor (GraphManager.cpp:83-88 takes any pair of keys) costs six more band
+    # solves per LM trial while it is in the window -- nonlinear at first, then, once its older key has been marginalised,
+    # as the engine's linear far factor
+    try:
+        gm = GraphManager(capacity=lag + 192, lag=lag, iterations=5)
+        gm.setInitialState(seq.gt_states[0])
+        gm.addIMUMeasurement(0.0, seq.imu_steps[0, 1:4], seq.imu_steps[0, 4:7])
+        t, times, a0, b0 = 0.0, {}, 40, lag - 100
+        for k in range(1, nkf):
+            for st in seq.imu_steps[seq.imu_off[k]:seq.imu_off[k + 1]]:
+                t += st[0]
+                gm.addIMUMeasurement(t, st[1:4], st[4:7])
+            gm.reserveNode(t)
+            for i in np.nonzero(seq.btw_b == k)[0]:
+                if seq.btw_a[i] >= 0:
+                    gm.addBetweenFactor(int(seq.btw_a[i]), k, (seq.btw_q[i], seq.btw_t[i]), np.eye(6) * seq.btw_cov[i])
+            if k == b0:                                  # the closure a0 <-> b0, measured as the ground truth has it
+                Ra, Rb = synth.quat_to_rot(seq.gt_states[a0, :4]), synth.quat_to_rot(seq.gt_states[b0, :4])
+                gm.addBetweenFactor(a0, b0, (synth.rot_to_quat(Ra.T @ Rb), Ra.T @ (seq.gt_states[b0, 4:7] - seq.gt_states[a0, 4:7])), np.eye(6) * 1e-4)
+            t0 = time.perf_counter()
+            gm.solve()
+            times[k] = (time.perf_counter() - t0) * 1e3
+        st = gm.lmStats()
+        gm.close()
+        nonlin = [times[k] for k in range(b0 + 5, lag + a0 - 2)]            # both keys in the window
+        linear = [times[k] for k in range(lag + a0 + 8, nkf)]               # the older key marginalised, the closure a linear far factor
+        out["with_a_loop_closure"] = {"keys": [a0, b0], "solve_ms_mean_nonlinear_far_factor": float(np.mean(nonlin)) if nonlin else None,
+                                      "solve_ms_mean_linear_far_factor": float(np.mean(linear)) if linear else None,
+                                      "solves_timed": [len(nonlin), len(linear)], "solve_failures": st["solve_failures"]}
+    except Exception as exc:   # noqa: BLE001
+        out["with_a_loop_closure"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
 
 

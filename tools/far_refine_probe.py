@@ -1,3 +1,6 @@
+"""Windows of 300 / 1 700 / 4 000 keyframes with loop closures (far factors), started at the refined optimum WITHOUT the
+closures: distance from that start after every Gauss-Newton update / every 3 LM trials, refined (far rows in the operator, Woodbury
+as the preconditioner) and unrefined (normal equations + Woodbury).  usage (GPU box): python tools/far_refine_probe.py"""
 import sys, os, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from oracle import oracle

@@ -421,3 +421,80 @@ def test_refined_windows_take_far_factors_as_rows_of_the_operator(oracle):
         assert na == nb and la == lb and d <= 1e-8
     assert [x[1:] for x in out["woodbury"][0]] == [([4, 9], []), ([9], [50]), ([], [50, 57]), ([], [57]), ([], [])]
     assert out["woodbury"][1]["solve_failures"] == 0 and out["refined"][1]["solve_failures"] == 0
+
+
+def test_random_loop_closures_through_a_fixed_lag_handle():
+    """Bookkeeping under load: a GraphManager with a lag of 50 and 128 slots (so that it compacts while far factors of both
+    kinds are alive) takes a loop closure between random keys every few keyframes -- up to the capacity of eight alive at a
+    time; the ones refused are simply not added to any handle -- and must publish what (a) a roomy handle with the same lag
+    publishes (to 1e-8: compaction moves slots, nothing else) and (b) a whole-history handle publishes (lag = 0: every factor
+    kept for good, as in the reference) to 1e-6 m: far factors converted, re-expressed at every marginalisation, sharing their
+    older keys, folded into the prior one after the other."""
+    from tests.test_gpu_graph_manager import _stream
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    n, lag = 260, 50
+    seq = synth.make_sequence(79, n)
+    traj_t, acc, gyr = _stream(seq)
+    rng = np.random.default_rng(21)
+    plan = {}
+    k = 30
+    while k < n - 5:
+        span = int(rng.integers(8, min(lag - 6, k - 1)))
+        plan[k] = (k - span, _far_record(seq, k - span, k, rng, cov=1e-3, noise=(3e-4, 3e-3)))
+        k += int(rng.integers(3, 12))
+    handles = {"small": GraphManager(capacity=128, iterations=5, lag=lag, rel_tol=0, abs_tol=0),
+               "roomy": GraphManager(capacity=512, iterations=5, lag=lag, rel_tol=0, abs_tol=0),
+               "whole": GraphManager(capacity=512, iterations=5, lag=0, rel_tol=0, abs_tol=0)}
+    out = {name: [] for name in handles}
+    for gm in handles.values():
+        gm.setInitialState(seq.gt_states[0])
+    i_imu, taken, refused = 0, 0, 0
+    for k in range(1, n):
+        j = i_imu
+        for name, gm in handles.items():
+            j = i_imu
+            while j < traj_t.size and traj_t[j] <= seq.kf_time[k] + 0.01:
+                gm.addIMUMeasurement(traj_t[j], acc[j], gyr[j]); j += 1
+            gm.reserveNode(seq.kf_time[k])
+            for a, b, q, t, c in zip(seq.btw_a, seq.btw_b, seq.btw_q, seq.btw_t, seq.btw_cov):
+                if b == k and a >= 1:
+                    gm.addBetweenFactor(int(a), int(b), (q, t), np.eye(6) * c)
+        i_imu = j
+        if k in plan:
+            a, rec = plan[k]
+            try:                                          # the small handle decides (the fixed-lag ones agree; the whole-history one has room when they do)
+                handles["small"].addBetweenFactor(a, k, (rec[0:4], rec[4:7]), np.eye(6) * 1e-3)
+                ok = True
+            except VilFusionError as exc:
+                assert exc.code == -6, exc
+                ok = False
+            if ok:
+                taken += 1
+                handles["roomy"].addBetweenFactor(a, k, (rec[0:4], rec[4:7]), np.eye(6) * 1e-3)
+                try:
+                    if "whole" in handles:
+                        handles["whole"].addBetweenFactor(a, k, (rec[0:4], rec[4:7]), np.eye(6) * 1e-3)
+                except VilFusionError as exc:             # (the whole-history handle never lets a far factor go: its eight slots fill up)
+                    assert exc.code == -6, exc
+                    handles["whole"] = None
+            else:
+                refused += 1
+        for name, gm in handles.items():
+            if gm is None:
+                continue
+            gm.solve()
+            (q, t), v, b = gm.getState()
+            out[name].append(np.concatenate([q, t, v, b]))
+        if "whole" in handles and handles["whole"] is None:
+            handles.pop("whole")
+    stats = {name: gm.lmStats() for name, gm in handles.items()}
+    for gm in handles.values():
+        gm.close()
+    small, roomy, whole = np.array(out["small"]), np.array(out["roomy"]), np.array(out["whole"])
+    d_room = np.abs(small - roomy).max()
+    m = whole.shape[0]
+    d_whole = np.sqrt(np.mean(np.sum((small[:m, 4:7] - whole[:, 4:7]) ** 2, axis=1))) if m else float("nan")
+    print(f"{taken} closures taken, {refused} refused for capacity; small vs roomy handle: {d_room:.3e}; fixed lag vs whole history over the first {m} solves "
+          f"(the whole-history handle holds at most 8 far factors for good): position rms {d_whole:.3e} m; lm {stats}")
+    assert taken >= 12 and d_room <= 1e-8 and m >= 60 and d_whole <= 1e-6
+    assert all(s["solve_failures"] == 0 for s in stats.values())

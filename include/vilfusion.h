@@ -152,6 +152,10 @@ typedef struct {
     int hybrid_active_list;  /* hybrid solves (termination rule on, > 128 windows): the one-wave sweeps take their windows from a compacted
                                 list of those still taking trials, so that the active ones are dispatched first (default 1; 0 = window i
                                 is workgroup i as before; same bits either way) */
+    int far_batch_columns;   /* single-window engines (the GraphManager's) holding far factors: the 6 Woodbury columns per far factor
+                                are solved as ONE batch on a second, internal engine of 48 windows -- a copy of the window's H per
+                                column -- instead of one band solve after the other (default 1; costs that engine's memory, about
+                                20 KB per keyframe slot and column; 0 = sequential columns as on batch engines; same bits) */
 } vf_engine_opts;
 
 void vf_engine_default_opts(vf_engine_opts* o);

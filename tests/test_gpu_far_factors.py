@@ -498,3 +498,35 @@ def test_random_loop_closures_through_a_fixed_lag_handle():
           f"(the whole-history handle holds at most 8 far factors for good): position rms {d_whole:.3e} m; lm {stats}")
     assert taken >= 12 and d_room <= 1e-8 and m >= 60 and d_whole <= 1e-6
     assert all(s["solve_failures"] == 0 for s in stats.values())
+
+
+def test_batched_woodbury_columns_are_the_sequential_ones_bit_for_bit(oracle):
+    """vf_engine_opts.far_batch_columns: a single-window engine (the GraphManager's) solves the 6 Woodbury columns of every far
+    factor as ONE partitioned solve of an internal 48-window engine -- window q a copy of the window's H with column q of U as
+    right-hand side -- where a batch engine runs its band solver once per column.  The same kernels on the same numbers:
+    states, costs and trial counts agree to the last bit, nonlinear far factors and (after marginalised slides) linear ones."""
+    total, n = 120, 70
+    seq = synth.make_sequence(seed=97, n_kf=total)
+    prob = helpers.build_problem(oracle, seq, perturb=0.002)
+    rng = np.random.default_rng(13)
+    closures = ((3, 60), (8, 41), (8, 66), (10, 50), (12, 64), (15, 58), (20, 69), (25, 45))       # (VF_MAX_EXTRA of them: 48 columns)
+    fa, fb = np.array([c[0] for c in closures], dtype=np.int32), np.array([c[1] for c in closures], dtype=np.int32)
+    far = np.stack([_far_record(seq, a, b, rng, cov=1e-3) for a, b in closures])
+    out = []
+    for batch in (1, 0):
+        eng = Engine(EngineOpts(windows=1, capacity=total, far_batch_columns=batch))
+        helpers.load_engine(eng, 0, prob, 0, n)
+        eng.set_extra_between(0, fa, fb, far)
+        eng.iterate(12)
+        snaps = [(eng.get_states(0, 0, n), eng.read_lm(0))]
+        for s in range(1, 41):
+            eng.slide(marginalize=True)
+            eng.iterate(4)
+            if s in (5, 12, 40):
+                snaps.append((eng.get_states(0, s, n), eng.read_lm(0), eng.get_linear_far(0).tolist()))
+        out.append(snaps)
+        eng.close()
+    for a, b in zip(*out):
+        np.testing.assert_array_equal(a[0], b[0])
+        assert a[1:] == b[1:]
+    assert out[0][2][2] == [60, 41, 66, 50] and out[0][3][2] == [60, 66, 50, 64, 58, 69, 45] and out[0][0][1]["solve_failures"] == 0 and out[0][3][1]["solve_failures"] == 0

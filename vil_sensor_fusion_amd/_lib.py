@@ -25,7 +25,7 @@ class EngineOptsC(C.Structure):
                 ("lambda_min", C.c_double), ("lambda_max", C.c_double), ("chunks", C.c_int),
                 ("sweep_two_sided_max", C.c_int), ("hybrid_threshold", C.c_int), ("cold_start", C.c_int),
                 ("use_hip_graph", C.c_int), ("accept_rel", C.c_double), ("solve_split_min", C.c_int), ("solve_assemble_min", C.c_int), ("solve_assemble_waves", C.c_int),
-                ("refine_iterations", C.c_int), ("refine_min_keyframes", C.c_int), ("refine_rel_stop", C.c_double), ("lm_excursion", C.c_int), ("gauge_floor", C.c_double), ("hybrid_active_list", C.c_int)]
+                ("refine_iterations", C.c_int), ("refine_min_keyframes", C.c_int), ("refine_rel_stop", C.c_double), ("lm_excursion", C.c_int), ("gauge_floor", C.c_double), ("hybrid_active_list", C.c_int), ("far_batch_columns", C.c_int)]
 
 
 class ImuParamsC(C.Structure):

@@ -172,6 +172,12 @@ struct vf_engine {
     // later call picks up from there (no second allocation, nothing leaked)
     int *x_la = nullptr, *x_lb = nullptr;
     double *x_li = nullptr, *x_lo = nullptr;
+    // Woodbury columns of a single-window engine as one batch: a second engine of 6 x VF_MAX_EXTRA windows and the same
+    // capacity, on this engine's stream; window q holds a copy of the window's H and column q of U as right-hand side
+    // (k_cols_prepare), one partitioned solve of it returns all of Z.  Made when the first far factor arrives, never inside a
+    // solve (a solve may be under stream capture); absent (sequential columns, as on batch engines) if it cannot be had.
+    vf_engine* far_columns = nullptr;
+    bool is_far_columns = false;
     // linear far factors (View::xl_*; made and kept by k_marginalize): the host mirrors only their number and far ends
     std::vector<std::vector<int>> h_lb;
     int h_ln(int w) const { return h_lb.empty() ? 0 : (int)h_lb[w].size(); }
@@ -308,6 +314,7 @@ void vf_engine_default_opts(vf_engine_opts* o) {
     o->lm_excursion = -1;            // auto: 3 on engines that refine, classical LM otherwise
     o->gauge_floor = 3e-4;
     o->hybrid_active_list = 1;
+    o->far_batch_columns = 1;
 }
 
 int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
@@ -435,6 +442,7 @@ void vf_engine_destroy(vf_engine* e) {
     if (e->in_dev) (void)hipFree(e->in_dev);
     if (e->in_status) (void)hipFree(e->in_status);
     for (auto ev : e->in_ev) if (ev) (void)hipEventDestroy(ev);
+    if (e->far_columns) { vf_engine_destroy(e->far_columns); e->far_columns = nullptr; }
     if (e->x_gtmp) (void)hipFree(e->x_gtmp);
     if (e->x_Z) (void)hipFree(e->x_Z);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -599,6 +607,18 @@ int vf_engine_set_extra_between(vf_engine* e, int window, int n, const int32_t* 
         if ((rc = e->ensure_far(need))) return rc;
     }
     e->attach_far();
+    if (n > 0 && !e->far_columns && !e->is_far_columns && B == 1 && e->v.P >= 2 && e->opts.far_batch_columns) {
+        vf_engine_opts co = e->opts;
+        co.windows = 6 * VF_MAX_EXTRA;
+        co.capacity = M;
+        co.use_hip_graph = 0;
+        vf_engine* c = nullptr;
+        if (vf_engine_create(&co, &c) == VF_OK) {
+            c->is_far_columns = true;
+            if (c->v.P == e->v.P && c->v.P_fit == e->v.P_fit && vf_engine_set_stream(c, (void*)e->stream) == VF_OK) e->far_columns = c;
+            else vf_engine_destroy(c);
+        }
+    }
     e->h_xa[window].assign(a, a + n);
     e->h_xb[window].assign(b, b + n);
     e->h_xrec[window].assign(rec, rec + (size_t)n * vf::BTW_IN);
@@ -835,18 +855,30 @@ int vf_engine_solve(vf_engine* e) {
         } else vf::launch_band_solve(a, e->stream);
     };
     band_solve(e->v.gvec, e->v.delta);
+    const double* far_Z = e->x_Z;
+    size_t far_zstride = e->x_zstride;
     if (e->x_used > 0) {
         // Far between factors: (H_band + lambda I + U U^T) delta = -g by Woodbury -- the band solver once more per column of
         // U (6 per slot in use; it refactorises every time: a fallback for the rare window with such factors, not a fast
         // path), then one small dense system per window (k_extra_combine).
-        const size_t gbytes = ((size_t)e->v.G * 15 + 64) * sizeof(double);
-        for (int s = 0; s < e->x_used; s++)
-            for (int j = 0; j < 6; j++) {
-                HIPCHK(hipMemsetAsync(e->x_gtmp, 0, gbytes, e->stream));
-                vf::launch_extra_rhs(e->v, s, j, e->x_gtmp, e->stream);
-                band_solve(e->x_gtmp, e->x_Z + (size_t)(6 * s + j) * e->x_zstride);
-            }
-        vf::launch_extra_combine(e->v, e->x_Z, e->x_zstride, e->x_used, e->stream);   // (slots beyond x_used are empty in every window)
+        if (e->far_columns) {
+            // (single-window engines: every column in ONE partitioned solve of the column engine -- same kernels, same bits)
+            const vf::View& c = e->far_columns->v;
+            vf::launch_cols_prepare(e->v, c, 6 * e->x_used, e->stream);
+            vf::launch_partitioned_solve(c, e->stream);
+            vf::launch_cols_fail(e->v, c, 6 * e->x_used, e->stream);
+            far_Z = c.delta;
+            far_zstride = (size_t)c.M * 15;
+        } else {
+            const size_t gbytes = ((size_t)e->v.G * 15 + 64) * sizeof(double);
+            for (int s = 0; s < e->x_used; s++)
+                for (int j = 0; j < 6; j++) {
+                    HIPCHK(hipMemsetAsync(e->x_gtmp, 0, gbytes, e->stream));
+                    vf::launch_extra_rhs(e->v, s, j, e->x_gtmp, e->stream);
+                    band_solve(e->x_gtmp, e->x_Z + (size_t)(6 * s + j) * e->x_zstride);
+                }
+        }
+        vf::launch_extra_combine(e->v, far_Z, far_zstride, e->x_used, e->stream);   // (slots beyond x_used are empty in every window)
     }
     if (const int R = e->refine_iters()) {
         // Refined solve (vf_refine.hip): the increment just computed is the start, the factorisation the preconditioner, of
@@ -864,7 +896,7 @@ int vf_engine_solve(vf_engine* e) {
                 a.delta = e->rq.z;
                 a.stop_on = 1;
                 a.done = e->rq.stop;
-                vf::launch_extra_combine(a, e->x_Z, e->x_zstride, e->x_used, e->stream);
+                vf::launch_extra_combine(a, far_Z, far_zstride, e->x_used, e->stream);
             }
             vf::launch_refine_step(e->v, e->rq, e->opts.refine_rel_stop, e->stream);
             // How many corrections a window needs grows with its length (4 at 1 600 keyframes, 12 at 10 000): after the
@@ -1114,6 +1146,7 @@ int vf_engine_set_stream(vf_engine* e, void* hip_stream) {
     e->drop_graph();
     e->stream = (hipStream_t)hip_stream;      // nullptr = the device's default stream
     e->own_stream = false;
+    if (e->far_columns) return vf_engine_set_stream(e->far_columns, hip_stream);
     return VF_OK;
 }
 int vf_engine_set_shard(vf_engine* e, int rank, int world) {

@@ -714,6 +714,47 @@ __global__ void __launch_bounds__(64) k_extra_rhs(View v, int s, int j, double* 
         gtmp[((size_t)w * v.M + k) * 15 + d] += far_jac(v, w, f, b, j, c);
     }
 }
+// ---- the Woodbury columns of a SINGLE-window engine as one batch (vf_engine.hip "far_columns"): window q of the view `c` (an
+// engine of 6 x MAX_EXTRA windows with the same capacity) is a copy of the window's block rows of H with column q of U as its
+// right-hand side, so that ONE partitioned solve of `c` returns every column of Z where the window's own solver would be run
+// once per column.  Same kernels on the same numbers: the same bits.
+__global__ void __launch_bounds__(256) k_cols_prepare(View v, View c, int ncols) {
+    const int k = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
+    const int lo = v.lo[0], hi = v.hi[0];
+    if (window_done(v, 0)) ncols = 0;            // (the termination rule has finished the window: its column windows are empty too)
+    // (every window of `c` takes part in the launch -- the separator arrays are laid out by its window count -- the ones beyond
+    // the columns in use as empty windows)
+    // (mp_on: the solver asks it whether row lo + 2 carries the marginal prior's coupling to lo, the block at H_DX)
+    if (k == 0 && tid == 0) { c.lo[q] = q < ncols ? lo : 0; c.hi[q] = q < ncols ? hi : 0; c.lambda[q] = v.lambda[0]; c.fail[q] = 0; c.mp_on[q] = v.mp_on[0]; }
+    if (k < lo || k >= hi || q >= ncols) return;
+    const double* __restrict__ src = v.H + (size_t)k * HROW;
+    double* __restrict__ dst = c.H + ((size_t)q * c.M + k) * HROW;
+    for (int i = tid; i < HROW; i += 256) dst[i] = src[i];
+    if (tid < 15) c.gvec[((size_t)q * c.M + k) * 15 + tid] = 0.0;
+}
+__global__ void __launch_bounds__(64) k_cols_rhs(View v, View c, int ncols) {
+    const int q = threadIdx.x;
+    if (q >= ncols || window_done(v, 0)) return;
+    const FarRef f = far_ref(v, 0, q / 6);
+    if (f.kind < 0) return;
+    const int b = v.sel[0], nc = far_cols(f), j = q % 6;
+    for (int col = 0; col < nc; col++) {
+        int k, d;
+        far_col(v, 0, f, col, k, d);
+        c.gvec[((size_t)q * c.M + k) * 15 + d] += far_jac(v, 0, f, b, j, col);
+    }
+}
+__global__ void __launch_bounds__(64) k_cols_fail(View v, View c, int ncols) {
+    const int q = threadIdx.x;
+    if (q < ncols && !window_done(v, 0) && c.fail[q]) v.fail[0] = 1;
+}
+void launch_cols_prepare(const View& v, const View& c, int ncols, hipStream_t s) {
+    hipLaunchKernelGGL(k_cols_prepare, dim3((unsigned)v.M, (unsigned)c.B), dim3(256), 0, s, v, c, ncols);
+    hipLaunchKernelGGL(k_cols_rhs, dim3(1), dim3(64), 0, s, v, c, ncols);
+}
+void launch_cols_fail(const View& v, const View& c, int ncols, hipStream_t s) {
+    hipLaunchKernelGGL(k_cols_fail, dim3(1), dim3(64), 0, s, v, c, ncols);
+}
 // delta = y - Z (I + U^T Z)^-1 U^T y  (Woodbury; A = H_band + lambda I, y = -A^-1 g in v.delta, column q of Zm = -A^-1 u_q as
 // the band solver returned it for the right-hand side u_q): one workgroup per window, the m = 6 x_max square system in LDS.
 __global__ void __launch_bounds__(256) k_extra_combine(View v, const double* __restrict__ Zm, size_t zstride, int slots) {

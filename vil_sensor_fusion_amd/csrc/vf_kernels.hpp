@@ -265,6 +265,9 @@ void launch_linearize_extra(const View& v, int which, hipStream_t s);       // f
 void launch_extra_gradient(const View& v, hipStream_t s);                    // g += J^T r of the far factors, after K3
 void launch_extra_rhs(const View& v, int slot, int row, double* gtmp, hipStream_t s);
 void launch_extra_combine(const View& v, const double* Zm, size_t zstride, int slots, hipStream_t s);
+void launch_cols_prepare(const View& v, const View& c, int ncols, hipStream_t s);    // single-window engines: the Woodbury columns as one batch
+void launch_cols_fail(const View& v, const View& c, int ncols, hipStream_t s);
+void launch_partitioned_solve(const View& v, hipStream_t s);
 void launch_linearize_imu(const View& v, int which, hipStream_t s);
 void launch_linearize_between(const View& v, int which, hipStream_t s);
 void launch_linearize_prior(const View& v, int which, hipStream_t s);

@@ -55,6 +55,7 @@ class EngineOpts:
     refine_rel_stop: float | None = None
     gauge_floor: float | None = None     # floor of the marginal prior's information about global translation / yaw (None = default 1e-3; 0 = off)
     hybrid_active_list: int | None = None  # hybrid solves: sweeps take their windows from the compacted list of active ones (None = default 1)
+    far_batch_columns: int | None = None   # single-window engines: the Woodbury columns of far factors as one batched solve (None = default 1)
     lm_excursion: int | None = None      # non-monotone LM: provisional cost-raising trials per excursion (None = default: 3 on refining engines)
 
 
@@ -81,7 +82,7 @@ class Engine:
             o.solve_assemble_min = opts.solve_assemble_min
         if opts.solve_assemble_waves is not None:
             o.solve_assemble_waves = opts.solve_assemble_waves
-        for name in ("refine_iterations", "refine_min_keyframes", "refine_rel_stop", "lm_excursion", "gauge_floor", "hybrid_active_list"):
+        for name in ("refine_iterations", "refine_min_keyframes", "refine_rel_stop", "lm_excursion", "gauge_floor", "hybrid_active_list", "far_batch_columns"):
             if getattr(opts, name) is not None:
                 setattr(o, name, getattr(opts, name))
         self._h = C.c_void_p()

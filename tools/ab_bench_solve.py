@@ -1,5 +1,6 @@
 """A/B of library variants on the BENCH's engine (capacity = window + updates + 1, windows slid a few times):
-stage timings of K4 / K3 / K1 and the whole step.  usage: python tools/ab_bench_solve.py <variant.so> ... (each in a child process)"""
+stage timings of K4 / K3 / K1 and the whole step.  TIMING ONLY: run the parity tests on a variant (tools/ab_asm_variants.sh, or
+the suite with the variant copied over libvilfusion.so) before believing its numbers -- a build that reads the wrong panels is fast.  usage: python tools/ab_bench_solve.py <variant.so> ... (each in a child process)"""
 import os, subprocess, sys
 if len(sys.argv) > 2:
     for so in sys.argv[1:]:

@@ -2345,8 +2345,9 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     }
     struct PRow { d2_t x[8]; };
 #ifndef VF_BWD_PD
-#define VF_BWD_PD 12     // (4 / 8 / 12 / 16 panels ahead: 24.72 / 24.55 / 24.42 / 24.45 ms per update step on one box, round 5)
+#define VF_BWD_PD 4
 #endif
+    static_assert(VF_BWD_PD == 2 || VF_BWD_PD == 4, "the back substitution keeps 2 or 4 panel slots: any other depth reads panels it has not loaded");
     constexpr int PD = MODE == SOLVE_FULL_BWD ? VF_BWD_PD : 4;      // panels prefetched ahead of the recursion
     // Backward sweep: lane r < 28 holds panel row r (sub-diagonal rows and the rhs row: they go through LDS); the rows of
     // L^-T sit in lanes XL .. XL+14 of ONE 16-lane row, where s and x are formed as well, so that both matrix-vector

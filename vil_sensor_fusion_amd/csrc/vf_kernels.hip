@@ -2345,7 +2345,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     }
     struct PRow { d2_t x[8]; };
 #ifndef VF_BWD_PD
-#define VF_BWD_PD 4
+#define VF_BWD_PD 2      // (2 against 4 slots: solve stage 3.44 against 3.48-3.50 ms at 1 024 windows, 178 against 240 registers; round 5)
 #endif
     static_assert(VF_BWD_PD == 2 || VF_BWD_PD == 4, "the back substitution keeps 2 or 4 panel slots: any other depth reads panels it has not loaded");
     constexpr int PD = MODE == SOLVE_FULL_BWD ? VF_BWD_PD : 4;      // panels prefetched ahead of the recursion

@@ -423,13 +423,16 @@ def test_refined_windows_take_far_factors_as_rows_of_the_operator(oracle):
     assert out["woodbury"][1]["solve_failures"] == 0 and out["refined"][1]["solve_failures"] == 0
 
 
-def test_random_loop_closures_through_a_fixed_lag_handle():
+@pytest.mark.parametrize("tol", [0.0, None])
+def test_random_loop_closures_through_a_fixed_lag_handle(tol):
     """Bookkeeping under load: a GraphManager with a lag of 50 and 128 slots (so that it compacts while far factors of both
     kinds are alive) takes a loop closure between random keys every few keyframes -- up to the capacity of eight alive at a
     time; the ones refused are simply not added to any handle -- and must publish what (a) a roomy handle with the same lag
     publishes (to 1e-8: compaction moves slots, nothing else) and (b) a whole-history handle publishes (lag = 0: every factor
     kept for good, as in the reference) to 1e-6 m: far factors converted, re-expressed at every marginalisation, sharing their
-    older keys, folded into the prior one after the other."""
+    older keys, folded into the prior one after the other.  tol = None: the default termination rule, under which a window
+    still carries its `done` flag when the next solve marginalises -- the far factors must be linearised for that all the same
+    (a compaction in between has zeroed their records: tools/far_soak.py found the marginal's far-end block singular there)."""
     from tests.test_gpu_graph_manager import _stream
     from vil_sensor_fusion_amd.graph_manager import GraphManager
     n, lag = 260, 50
@@ -442,9 +445,9 @@ def test_random_loop_closures_through_a_fixed_lag_handle():
         span = int(rng.integers(8, min(lag - 6, k - 1)))
         plan[k] = (k - span, _far_record(seq, k - span, k, rng, cov=1e-3, noise=(3e-4, 3e-3)))
         k += int(rng.integers(3, 12))
-    handles = {"small": GraphManager(capacity=128, iterations=5, lag=lag, rel_tol=0, abs_tol=0),
-               "roomy": GraphManager(capacity=512, iterations=5, lag=lag, rel_tol=0, abs_tol=0),
-               "whole": GraphManager(capacity=512, iterations=5, lag=0, rel_tol=0, abs_tol=0)}
+    handles = {"small": GraphManager(capacity=128, iterations=5, lag=lag, rel_tol=tol, abs_tol=tol),
+               "roomy": GraphManager(capacity=512, iterations=5, lag=lag, rel_tol=tol, abs_tol=tol),
+               "whole": GraphManager(capacity=512, iterations=5, lag=0, rel_tol=tol, abs_tol=tol)}
     out = {name: [] for name in handles}
     for gm in handles.values():
         gm.setInitialState(seq.gt_states[0])
@@ -496,7 +499,7 @@ def test_random_loop_closures_through_a_fixed_lag_handle():
     d_whole = np.sqrt(np.mean(np.sum((small[:m, 4:7] - whole[:, 4:7]) ** 2, axis=1))) if m else float("nan")
     print(f"{taken} closures taken, {refused} refused for capacity; small vs roomy handle: {d_room:.3e}; fixed lag vs whole history over the first {m} solves "
           f"(the whole-history handle holds at most 8 far factors for good): position rms {d_whole:.3e} m; lm {stats}")
-    assert taken >= 12 and d_room <= 1e-8 and m >= 60 and d_whole <= 1e-6
+    assert taken >= 12 and d_room <= 1e-8 and m >= 60 and d_whole <= (1e-6 if tol == 0.0 else 1e-4)      # (windows that stop at the rule's 1e-5 are that far from converged)
     assert all(s["solve_failures"] == 0 for s in stats.values())
 
 

@@ -1433,12 +1433,17 @@ int vf_engine_marginalize(vf_engine* e) {
     HIPCHK(hipMemsetAsync(e->status_dev, 0, sizeof(int), e->stream));
     // far factors the prior is about to absorb: their linearisation at the current states (a compaction, a transport or any
     // other re-sending of the list since the last solve has zeroed the buffers)
-    if (e->x_used > 0) vf::launch_linearize_extra(e->v, 0, e->stream);
+    if (e->x_used > 0) {
+        vf::View a = e->v;
+        a.stop_on = 0;       // (a window the termination rule finished in the last solve still has its `done` flag up: linearise it all the same)
+        vf::launch_linearize_extra(a, 0, e->stream);
+    }
     vf::launch_marginalize(e->v, e->status_dev, e->stream);
     HIPCHK(hipGetLastError());
     int status = 0;
     HIPCHK(hipMemcpyAsync(&status, e->status_dev, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (status & 4) return fail(VF_ERR_INDETERMINATE, "marginalisation: the far ends' block of the marginal is not positive definite");
     if (status) return fail(VF_ERR_INDETERMINATE, "marginalisation: pivot block of the oldest keyframe not positive definite");
     e->marg_since_drop = true;
     return VF_OK;

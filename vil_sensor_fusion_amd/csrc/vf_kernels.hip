@@ -3537,7 +3537,11 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
         __syncthreads();
         for (int c = 0; c < RL; c++) {
             const double d = Wf[c * FC + c];
-            if (!(d > 0.0)) bad = 1;
+            if (!(d > 0.0)) bad |= 4;                // (status bit 4: the far ends' block of the marginal is not positive definite)
+#ifdef VF_DEBUG_FAR
+            if (!(d > 0.0) && lane == 0) printf("[far] window %d lo %d: S_bb pivot %d of %d = %.6e (T %d, live %d; far ends %d %d %d %d %d %d %d %d; fold %d %d %d %d %d %d %d %d; first diag %.3e)\n", w, lo, c, RL, d, T, Lv,
+                                                f_kb[0], f_kb[1], f_kb[2], f_kb[3], f_kb[4], f_kb[5], f_kb[6], f_kb[7], f_fold[0], f_fold[1], f_fold[2], f_fold[3], f_fold[4], f_fold[5], f_fold[6], f_fold[7], Wf[0]);
+#endif
             const double sd = sqrt(d > 0.0 ? d : 1.0);
             __syncthreads();
             for (int q = c + lane; q < RL; q += 256) Wf[q * FC + c] = q == c ? sd : Wf[q * FC + c] / sd;
@@ -3721,7 +3725,7 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
     if (lane == 0) {
         v.mp_on[w] = 1;
         v.prior_k[w] = -1;
-        if (bad) atomicOr(status, 1);
+        if (bad) atomicOr(status, bad & 4 ? 4 : 1);
     }
 }
 

@@ -533,3 +533,43 @@ def test_batched_woodbury_columns_are_the_sequential_ones_bit_for_bit(oracle):
         np.testing.assert_array_equal(a[0], b[0])
         assert a[1:] == b[1:]
     assert out[0][2][2] == [60, 41, 66, 50] and out[0][3][2] == [60, 66, 50, 64, 58, 69, 45] and out[0][0][1]["solve_failures"] == 0 and out[0][3][1]["solve_failures"] == 0
+
+
+def test_windows_of_a_batch_engine_keep_their_own_far_factors(oracle):
+    """A batch engine whose windows hold different far factors (none, one, three sharing a key) through 50 marginalised slides
+    -- conversions, re-expressions and foldings at different slides in different windows, the Woodbury columns solved one
+    after the other for the whole batch -- against one single-window engine per window (whose columns go through the column
+    engine): the same states to the last bit."""
+    total, n, K = 120, 60, 4
+    seqs = [synth.make_sequence(seed=300 + w, n_kf=total) for w in range(4)]
+    probs = [helpers.build_problem(oracle, s, perturb=0.002) for s in seqs]
+    rng = np.random.default_rng(17)
+    plans = [(), ((5, 48),), ((2, 40), (9, 55), (9, 31)), ((20, 58), (1, 12))]
+    fars = [(np.array([c[0] for c in p], dtype=np.int32), np.array([c[1] for c in p], dtype=np.int32),
+             np.stack([_far_record(seqs[w], a, b, rng, cov=1e-3) for a, b in p]) if p else np.zeros((0, 28))) for w, p in enumerate(plans)]
+
+    def run(eng, windows):
+        for slot, w in enumerate(windows):
+            helpers.load_engine(eng, slot, probs[w], 0, n)
+            if len(fars[w][0]):
+                eng.set_extra_between(slot, *fars[w])
+        eng.iterate(15)
+        out = []
+        for s in range(1, 51):
+            eng.slide(marginalize=True)
+            eng.iterate(K)
+            if s in (4, 12, 30, 50):
+                out.append([(eng.get_states(slot, s, n), eng.get_linear_far(slot).tolist()) for slot in range(len(windows))])
+        lm = [eng.read_lm(slot) for slot in range(len(windows))]
+        eng.close()
+        return out, lm
+
+    batch, lm_b = run(Engine(EngineOpts(windows=4, capacity=total)), [0, 1, 2, 3])
+    for w in range(4):
+        single, lm_s = run(Engine(EngineOpts(windows=1, capacity=total)), [w])
+        for snap_b, snap_s in zip(batch, single):
+            np.testing.assert_array_equal(snap_b[w][0], snap_s[0][0])
+            assert snap_b[w][1] == snap_s[0][1]
+        assert lm_b[w] == lm_s[0] and lm_b[w]["solve_failures"] == 0
+    assert [x[1] for x in batch[1]] == [[], [48], [40, 55, 31], []]            # after 12 slides: every anchor but 20 has left, (1, 12) has been folded
+    assert [x[1] for x in batch[2]] == [[], [48], [40, 55], [58]] and [x[1] for x in batch[3]] == [[], [], [55], [58]]

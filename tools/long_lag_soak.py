@@ -1,0 +1,44 @@
+"""A fixed-lag GraphManager whose lag is past the refinement threshold (1 700 keyframes: refined solves, excursions, the
+marginal prior in the operator, gauge floor, warm starts), compacting every 64 keyframes, against a roomy handle fed the
+same stream: same states to the bit, no failed solve.  usage (GPU box): python tools/long_lag_soak.py [updates] [lag]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from tests.test_gpu_graph_manager import _stream
+from vil_sensor_fusion_amd import synth
+from vil_sensor_fusion_amd.graph_manager import GraphManager
+updates, lag = int(sys.argv[1]) if len(sys.argv) > 1 else 600, int(sys.argv[2]) if len(sys.argv) > 2 else 1700
+n = lag + updates
+seq = synth.make_sequence(87, n)
+traj_t, acc, gyr = _stream(seq)
+handles = {"small": GraphManager(capacity=lag + 64, iterations=5, lag=lag), "roomy": GraphManager(capacity=lag + updates + 64, iterations=5, lag=lag)}
+for gm in handles.values():
+    gm.setInitialState(seq.gt_states[0])
+i_imu, worst, t0, times = 0, 0.0, time.time(), []
+for k in range(1, n):
+    j = i_imu
+    for gm in handles.values():
+        j = i_imu
+        while j < traj_t.size and traj_t[j] <= seq.kf_time[k] + 0.01:
+            gm.addIMUMeasurement(traj_t[j], acc[j], gyr[j]); j += 1
+        gm.reserveNode(seq.kf_time[k])
+        for a, b, q, t, c in zip(seq.btw_a[seq.btw_b == k], seq.btw_b[seq.btw_b == k], seq.btw_q[seq.btw_b == k], seq.btw_t[seq.btw_b == k], seq.btw_cov[seq.btw_b == k]):
+            if a >= 1:
+                gm.addBetweenFactor(int(a), int(b), (q, t), np.eye(6) * c)
+    i_imu = j
+    if k < lag and k % 20:
+        continue                                         # (filling the window: a solve every 20 keyframes)
+    out = []
+    for name, gm in handles.items():
+        ts = time.perf_counter()
+        gm.solve()
+        if name == "small" and k >= lag:
+            times.append((time.perf_counter() - ts) * 1e3)
+        (q, t), v, b = gm.getState()
+        out.append(np.concatenate([q, t, v, b]))
+    worst = max(worst, float(np.abs(out[0] - out[1]).max()))
+    if k % 200 == 0 or k == n - 1:
+        print(f"key {k}: worst difference compacting vs roomy handle so far {worst:.3e}; solver info {handles['small'].solverInfo()}; lm {handles['small'].lmStats()}; "
+              f"vf_solve mean {np.mean(times) if times else float('nan'):.2f} ms; {time.time() - t0:.0f} s", flush=True)
+st = [gm.lmStats() for gm in handles.values()]
+print(f"long-lag soak: lag {lag}, {updates} fixed-lag updates; worst difference {worst:.3e}; failed solves {st[0]['solve_failures']} / {st[1]['solve_failures']}; vf_solve mean {np.mean(times):.2f} ms, p99 {np.percentile(times, 99):.2f} ms")

@@ -202,8 +202,8 @@ struct vf_engine {
         if (!x_lb) { if ((rc = alloc(&x_lb, B * X, false))) return rc; HIPCHK(hipMemsetAsync(x_lb, 0xff, B * X * sizeof(int), stream)); }
         if (!x_li && (rc = alloc(&x_li, B * X * vf::BTW_IN))) return rc;
         if (!x_lo && (rc = alloc(&x_lo, 2 * B * X * vf::BTW_OUT))) return rc;
-        if (!v.xl_n && ((rc = alloc(&v.xl_n, B)) || (rc = alloc(&v.xl_b, B * X)) || (rc = alloc(&v.xl_U, B * X * 6 * vf::XL_LD)) || (rc = alloc(&v.xl_r0, B * X * 6)) ||
-                        (rc = alloc(&v.xl_bx, B * X * 7)) || (rc = alloc(&v.xl_out, 2 * B * X * 6)))) return rc;
+        if ((!v.xl_n && (rc = alloc(&v.xl_n, B))) || (!v.xl_b && (rc = alloc(&v.xl_b, B * X))) || (!v.xl_U && (rc = alloc(&v.xl_U, B * X * 6 * vf::XL_LD))) ||
+            (!v.xl_r0 && (rc = alloc(&v.xl_r0, B * X * 6))) || (!v.xl_bx && (rc = alloc(&v.xl_bx, B * X * 7))) || (!v.xl_out && (rc = alloc(&v.xl_out, 2 * B * X * 6)))) return rc;
         x_zstride = (size_t)v.G * 15 + B + 64;
         if (!x_gtmp) HIPCHK(hipMalloc((void**)&x_gtmp, x_zstride * sizeof(double)));
         if (slots > x_zslots) {
@@ -1245,7 +1245,10 @@ int rccl_load() {
             g_rccl.error_string = (rccl_error_string_t)dlsym(g_rccl.handle, "ncclGetErrorString");
         }
     }
-    if (!g_rccl.all_gather || !g_rccl.all_reduce) return fail(VF_ERR_DEVICE, "librccl not found (dlopen librccl.so.1): %s", dlerror() ? dlerror() : "symbols missing");
+    if (!g_rccl.all_gather || !g_rccl.all_reduce) {
+        const char* why = dlerror();          // (a second call would return null: the message is consumed by the first)
+        return fail(VF_ERR_DEVICE, "librccl not found (dlopen librccl.so.1): %s", why ? why : "symbols missing");
+    }
     return VF_OK;
 }
 int rccl_check(int rc, const char* what) {

@@ -1452,14 +1452,18 @@ int vf_engine_marginalize(vf_engine* e) {
     return VF_OK;
 }
 
-// ---- far between factors across a slide.  A far factor (a -> b) whose older keyframe a is about to leave the window is
-// TRANSPORTED to the next keyframe: with D = T_a^-1 T_a+1 at the current estimate, the measurement Z of T_a^-1 T_b becomes
+// ---- far between factors across a slide: the host's side of what k_marginalize<FAR> has just done on the device.  A far
+// factor (a -> b) whose older keyframe a has been MARGINALISED was marginalised with it: it is part of the window's linear far
+// factor now (View::xl_*), or -- with its far end within the new prior's reach -- inside the prior; the lists here are host
+// mirrors and apply the same rule in the same order (survivors of the linear list, then the nonlinear entries anchored at the
+// leaving keyframe, by index).  The information of a loop closure thereby outlives the keyframe it was anchored on (iSAM2
+// keeps every factor for good, GraphManager.cpp:83-88).
+// A slide that does NOT marginalise (re-anchoring: the keyframe is dropped, its band factors with it) re-anchors a nonlinear
+// far factor on the next keyframe instead: with D = T_a^-1 T_a+1 at the current estimate, the measurement Z of T_a^-1 T_b becomes
 // Z' = D^-1 Z of T_a+1^-1 T_b -- the same residual Log(Z^-1 T_a^-1 T_b), in the same tangent frame (at b), so the square-root
-// information stays as it is.  D is known from the IMU factor between the two keyframes to ~2e-5 m / 2e-4 rad, against the
-// 1e-2 ... 0.5 m a between factor claims: treating it as exact is the approximation.  The information of a loop closure
-// thereby outlives the keyframe it was anchored on (iSAM2 keeps every factor for good, GraphManager.cpp:83-88); a factor
-// that reaches its own end keyframe (a + 1 == b) has nothing left to say and is dropped.  Host side: the lists are host
-// mirrors, two states are read back per window that has such a factor (rare: a synchronisation only then).
+// information stays as it is; D is known from the IMU factor between the two keyframes to ~2e-5 m / 2e-4 rad, against the
+// 1e-2 ... 0.5 m a between factor claims, and is taken as exact (two states are read back per window that has such a factor).
+// The linear rows, expressed around the prior that such a slide discards, end there.
 namespace {
 void quat_to_rot_(const double* q, double* R) {
     const double w = q[0], x = q[1], y = q[2], z = q[3];

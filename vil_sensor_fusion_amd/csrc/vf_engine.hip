@@ -376,6 +376,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     if (v.P < 2) v.P = 0;
     AL(v.H, G * vf::HROW);
     AL(v.gvec, G * 15 + 64); // + slack: the solver's row fetch reads 64 lanes of a 15-double row (the excess is never used)
+    AL(v.place, vf::PLACE_CELLS);
     AL(v.zrow, vf::HROW);         // a block row of zeros: what the solver fetches for rows outside the window
     AL(v.delta, G * 15 + (size_t)v.B);   // + one solve-failure flag per window (time-sharded windows: reduced with the increments)
     AL(v.Lp, G * vf::PANEL);

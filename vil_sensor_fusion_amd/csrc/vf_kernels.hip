@@ -1366,7 +1366,7 @@ static_assert(CW_TOTAL * 8 <= 20480, "eight compact forward sweeps per CU (160 K
 // Assembling forward sweep (SOLVE_ASM_FWD, k_band_forward_asm): the compact window, then the LDS image of ONE tile of the J
 // stream (8 factors at K3's stride LJS: pairs, residual, zero cell) and ONE between linearisation (78 words + the zero cell).
 constexpr int AS_LJ = CW_TOTAL, AS_LB = AS_LJ + JT * LJS, AS_TOTAL = AS_LB + 80;
-constexpr int AS_FLAGS = AS_TOTAL, AS2_TOTAL = AS_FLAGS + 4;     // two-wave form: [0] steps begun by the eliminator, [1] rows committed by the assembler, [2] J tiles put in place by the eliminator
+constexpr int AS_FLAGS = AS_TOTAL, AS2_TOTAL = AS_FLAGS + 8;     // two-wave form: [0] steps begun by the eliminator, [1] rows committed by the assembler, [2] J tiles put in place by the eliminator
 static_assert(AS_LJ % 2 == 0 && AS2_TOTAL * 8 <= 40960, "four assembling sweeps per CU (one per SIMD)");
 // chunk forward sweep with a spike follower (k_chunk_forward): the panel of step k (43 rows x 15, then a
 // zero cell and a write sink) stays in a 4-slot LDS ring for the second wave; two hand-shake cells follow
@@ -1377,6 +1377,9 @@ constexpr int S_RING_OUT = S_PROG + 2;        // != 0: a wait on the ring ran ou
 constexpr int RING_SPIN_MAX = 1 << 22;        // polls (each an LDS read + s_sleep): seconds, against the microseconds a step takes
 constexpr int S_BC_RING = S_PROG + 8;
 constexpr int S_TOTAL_RING = S_BC_RING + 16;
+#ifndef VF_ASM2_ROLES
+#define VF_ASM2_ROLES 1     // two-wave assembling sweep: 1 = the workgroups of a CU agree on one eliminator per SIMD (View::place), 0 = wave 0 eliminates
+#endif
 #ifndef VF_ASM2_BSLEEP
 #define VF_ASM2_BSLEEP 1    // s_sleep argument of the assembler's polls (units of 64 clocks)
 #endif
@@ -2524,21 +2527,54 @@ __global__ void __launch_bounds__(64) k_band_forward_asm(View v) {
 // takes all 256 as VGPRs and spills 17 to scratch unless it is told to keep some of the budget as AGPRs.)
 __attribute__((amdgpu_waves_per_eu(2, 2)))
 __global__ void __launch_bounds__(128) k_band_forward_asm2(View v, int w0) {
-    const int w = w0 + blockIdx.x;
-    if (v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
+    const int w = sweep_window(v, w0 + blockIdx.x);
+    if (w < 0 || v.hi[w] - v.lo[w] <= 0 || window_done(v, w) || gated_off(v)) return;
     __shared__ __attribute__((aligned(16))) double S[AS2_TOTAL];
-    // (Roles are fixed: wave 0 eliminates.  The dispatcher puts the two waves of a 128-thread workgroup on SIMDs (0, 2), (1, 3),
-    // (2, 1), (3, 0) in turn -- tools/probes/wave_placement.hip -- so the four workgroups of a CU leave every SIMD with one
-    // eliminator and one assembler; choosing the role from HW_ID instead measured 12 % slower.)
+    // Roles.  Every SIMD should hold ONE eliminator and one assembler: the two roles of two windows share its float64 units,
+    // and two eliminators on one SIMD are two critical paths in each other's way (the same kernel on the same windows: 2.56 ms
+    // balanced, 3.10-3.20 ms not).  Which SIMDs the two waves of a workgroup land on follows the dispatcher's round-robin state,
+    // i.e. whatever the PREVIOUS kernel left behind: after k_decide the four workgroups of a CU come out as (0, 2), (1, 3), (2, 1),
+    // (3, 0) and "wave 0 eliminates" is balanced; after the gated-off K3 launch of the hybrid solve, or in another process, it
+    // is not (tools/hybrid_full_probe.py, trace_context.py; a placement kernel in front moved the step between 23.3 and 26.7 ms).
+    // So the workgroups of a CU agree among themselves: each claims, in a per-CU bit mask (View::place, cleared by the launch),
+    // the SIMD of its wave 0 for its eliminator, or -- that one taken -- the SIMD of its wave 1, and swaps its roles then.  The
+    // waves of a CU's workgroups form cycles over its four SIMDs (two waves each), so the greedy claim ends with one eliminator
+    // per SIMD whatever the order of arrival.
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (threadIdx.x < 4) S[AS_FLAGS + threadIdx.x] = threadIdx.x < 2 ? -1.0 : 0.0;
+    int swapped = 0;
+#if VF_ASM2_ROLES
+    {
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13]
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));     // XCC_ID [3:0]
+        if (lane == 0) S[AS_FLAGS + 4 + wave] = (double)((hw >> 4) & 3);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int s0 = (int)S[AS_FLAGS + 4], s1 = (int)S[AS_FLAGS + 5];
+            unsigned* cell = v.place + ((xcc & 7) << 8 | ((hw >> 8) & 0xff));               // (xcc, se, sh, cu)
+            int sw = 0;
+            if (s0 != s1) {
+                const unsigned o0 = atomicOr(cell, 1u << s0);
+                if (o0 & (1u << s0)) {
+                    const unsigned o1 = atomicOr(cell, 1u << s1);
+                    sw = (o1 & (1u << s1)) ? 0 : 1;
+                }
+            }
+            S[AS_FLAGS + 6] = (double)sw;
+        }
+        __syncthreads();
+        swapped = __builtin_amdgcn_readfirstlane((int)S[AS_FLAGS + 6]);
+    }
+#else
     __syncthreads();
+#endif
+    const bool eliminator = (wave == 0) != (swapped != 0);
 #if VF_ASM2_PRIO
     // Issue priority to the eliminator: its steps are the critical path, the assembler has 40 % slack, and the two share one
     // SIMD's float64 units (solve 3.66 -> 3.50 ms at 1 024 windows; priority to the assembler: 3.63)
-    if ((wave == 0) == (VF_ASM2_PRIO == 1)) __builtin_amdgcn_s_setprio(3);
+    if (eliminator == (VF_ASM2_PRIO == 1)) __builtin_amdgcn_s_setprio(3);
 #endif
-    if (wave == 0) band_solve_body<SOLVE_ASM_A>(v, S, nullptr, nullptr, w, lane, 0);
+    if (eliminator) band_solve_body<SOLVE_ASM_A>(v, S, nullptr, nullptr, w, lane, 0);
     else band_solve_body<SOLVE_ASM_B>(v, S, nullptr, nullptr, w, lane, 0);
 }
 __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -3912,16 +3948,23 @@ __global__ void __launch_bounds__(256) k_mask_delta(View v) {
 void launch_mask_delta(const View& v, hipStream_t s) {
     hipLaunchKernelGGL(k_mask_delta, dim3(nblk(v.G, 256)), dim3(256), 0, s, v);
 }
+static void launch_asm2(const View& v, hipStream_t s) {
+    // one launch per 1 024 windows -- the workgroups the part holds at once (4 per CU).  As ONE grid of 2 048 workgroups
+    // the second thousand, dispatched one by one into the slots the first leaves, ran 1.7x slower than the first
+    // (9.0 ms against 7.1 for the two launches; no such effect on the one-wave kernels)
+    for (int w0 = 0; w0 < v.B; w0 += VF_ASM2_CHUNK) {
+        const unsigned nb = (unsigned)(v.B - w0 < VF_ASM2_CHUNK ? v.B - w0 : VF_ASM2_CHUNK);
+        if (VF_ASM2_ROLES) (void)hipMemsetAsync(v.place, 0, PLACE_CELLS * sizeof(unsigned), s);      // the per-CU claims of this launch
+        hipLaunchKernelGGL(k_band_forward_asm2, dim3(nb), dim3(128), 0, s, v, w0);
+    }
+}
 void launch_band_solve(const View& v, hipStream_t s) {
     if (v.P >= 2) { launch_partitioned_solve(v, s); return; }
     // few windows: two waves per window from both ends (latency); many: one wave per window (throughput)
     if (v.B <= v.tw_max) hipLaunchKernelGGL(k_band_solve_tw, dim3(v.B), dim3(128), 0, s, v);
     else if (asm_in_solve(v)) {
         if (v.asm_waves == 2) {
-            // one launch per 1 024 windows -- the workgroups the part holds at once (4 per CU).  As ONE grid of 2 048 workgroups
-            // the second thousand, dispatched one by one into the slots the first leaves, ran 1.7x slower than the first
-            // (9.0 ms against 7.1 for the two launches; no such effect on the one-wave kernels)
-            for (int w0 = 0; w0 < v.B; w0 += VF_ASM2_CHUNK) hipLaunchKernelGGL(k_band_forward_asm2, dim3(v.B - w0 < VF_ASM2_CHUNK ? v.B - w0 : VF_ASM2_CHUNK), dim3(128), 0, s, v, w0);
+            launch_asm2(v, s);
         }
         else hipLaunchKernelGGL(k_band_forward_asm, dim3(v.B), dim3(64), 0, s, v);
         hipLaunchKernelGGL(k_band_backward, dim3(v.B), dim3(64), 0, s, v);
@@ -3965,9 +4008,11 @@ void launch_band_solve_hybrid(const View& v, const View& vp, hipStream_t s) {
     b.gate = 2;
     // (a.act, when the engine has allocated it: the sweeps visit the active windows first)
     if (asm_in_hybrid(v)) {
-        // (one wave per window here: with part of the windows done the two-wave form measured 5 % slower in round 4; with the
-        // compacted list and the eliminator's priority of round 5 it is level -- 9.66 against 9.64 ms per update,
-        // tools/ab_conv_exit.py -- its second trial faster, its first slower; left as it was)
+        // (two waves per window here too, round 5: with the compacted list, the eliminator's priority and -- what had made it
+        // 5 % slower than one wave in round 4 and 21 % slower than itself in the headline's launch -- the placement kernel in
+        // front of it, launch_asm2)
+        if (a.asm_waves == 2 && a.act) launch_asm2(a, s);
+        else
         hipLaunchKernelGGL(k_band_forward_asm, dim3(a.B), dim3(64), 0, s, a);
         hipLaunchKernelGGL(k_band_backward, dim3(a.B), dim3(64), 0, s, a);
     } else if (a.split_min > 0 && a.B >= a.split_min) {

@@ -25,6 +25,7 @@ constexpr int JS_PI = (JS_NI + 1) / 2, JS_PJ = (JS_NJ + 1) / 2, JS_PAIRS = JS_PI
 constexpr int JT_STRIDE = JS_PAIRS * JT * 2;        // 2336 doubles = 146 lines per tile
 constexpr int BTW_IN = 28;      // q(4), t(3), R packed upper (21)
 constexpr int BTW_OUT = 78;     // r(6), Ja(36), Jb(36)
+constexpr int PLACE_CELLS = 2048;  // (xcc 3 bits, se / sh / cu 8 bits of HW_ID)
 constexpr int MAX_EXTRA = 8;
 constexpr int XL_LD = 27 + 6 * MAX_EXTRA;     // row stride of the linear far factor (View::xl_U): 27 head columns + 6 per far end    // far between factors per window (= VF_MAX_EXTRA of include/vilfusion.h)
 constexpr int PRIOR_IN = 31;    // mean state (16), sigma (15)
@@ -196,6 +197,7 @@ struct View {
     int asm_min;        // whole-window sweeps: from this many windows on, the forward sweep assembles H itself from the J stream and
                         // K3 is not launched (0 = never; asm_in_solve() below)
     int asm_waves;      // ... as one wave per window (1) or as an eliminator wave + an assembler wave sharing the window's LDS (2)
+    unsigned* place;    // [PLACE_CELLS] per-CU claims of the two-wave sweep's launch (which SIMDs have their eliminator): k_band_forward_asm2
     // "far" between factors: BetweenFactor<Pose3> on any pair of keyframes of a window (wider than the band, or a second factor
     // on an end key), at most x_max per window; kept out of the banded H and solved as a low-rank correction
     int x_max;          // 0 until vf_engine_set_extra_between is first called

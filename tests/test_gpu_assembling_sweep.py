@@ -310,3 +310,47 @@ def test_two_waves_per_window_give_the_bits_of_one():
     np.testing.assert_array_equal(a["L"], b["L"])
     one.close()
     two.close()
+
+
+def test_swapped_roles_are_the_same_sweep():
+    """The two waves of a workgroup of the two-wave sweep take their roles from a per-CU agreement (one eliminator per SIMD,
+    DESIGN.md 7.16): wave 1 eliminates where wave 0's SIMD already has an eliminator.  Where that happens depends on the
+    dispatcher, so the swapped path is exercised by a build in which EVERY workgroup swaps (tools/variants/
+    libvilfusion_swapped.so, -DVF_ASM2_ROLES=2, made by __graft_entry__.build()): the same states and LM counters as the
+    product library, bit for bit, over LM trials and marginalised slides of ragged windows.  Each library in a child process."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variant = os.path.join(root, "tools", "variants", "libvilfusion_swapped.so")
+    if not os.path.exists(variant):
+        pytest.fail(f"{variant} missing: run __graft_entry__.build()")
+    child = r'''
+import json, sys, hashlib
+sys.path.insert(0, %(root)r)
+if sys.argv[1] != "product":
+    from vil_sensor_fusion_amd import _lib
+    _lib._SO = %(variant)r
+import numpy as np
+from tests.test_gpu_ingest import _engine
+from vil_sensor_fusion_amd import synth
+from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
+n, B = 130, 12
+seqs = [synth.make_sequence(seed=830 + i, n_kf=n + 8) for i in range(B)]
+eng = _engine(None, seqs, n, 6, solve_assemble_min=1, solve_assemble_waves=2, chunks=1, sweep_two_sided_max=0)
+for w in range(B):
+    eng.set_range(w, 0, n - 8 - (w %% 7))
+assert eng.solve_form() == "assembling"
+eng.iterate(8)
+h = hashlib.sha256()
+for s in range(1, 5):
+    eng.slide(REFERENCE_PRIOR_SIGMAS, marginalize=True)
+    eng.iterate(4)
+for w in range(B):
+    h.update(eng.get_states(w, 4, n - 8 - (w %% 7)).tobytes())
+print("RESULT " + json.dumps({"sha": h.hexdigest(), "lm": [eng.read_lm(w) for w in range(B)]}))
+''' % {"root": root, "variant": variant}
+    outs = []
+    for which in ("product", "swapped"):
+        res = subprocess.run([sys.executable, "-c", child, which], capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+        outs.append(json.loads([l for l in res.stdout.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    assert outs[0] == outs[1] and all(lm["solve_failures"] == 0 and lm["accepted"] > 0 for lm in outs[0]["lm"])

@@ -1378,7 +1378,7 @@ constexpr int RING_SPIN_MAX = 1 << 22;        // polls (each an LDS read + s_sle
 constexpr int S_BC_RING = S_PROG + 8;
 constexpr int S_TOTAL_RING = S_BC_RING + 16;
 #ifndef VF_ASM2_ROLES
-#define VF_ASM2_ROLES 1     // two-wave assembling sweep: 1 = the workgroups of a CU agree on one eliminator per SIMD (View::place), 0 = wave 0 eliminates
+#define VF_ASM2_ROLES 1     // two-wave assembling sweep: 1 = the workgroups of a CU agree on one eliminator per SIMD (View::place), 0 = wave 0 eliminates, 2 = wave 1 does (test build)
 #endif
 #ifndef VF_ASM2_BSLEEP
 #define VF_ASM2_BSLEEP 1    // s_sleep argument of the assembler's polls (units of 64 clocks)
@@ -2564,6 +2564,7 @@ __global__ void __launch_bounds__(128) k_band_forward_asm2(View v, int w0) {
         }
         __syncthreads();
         swapped = __builtin_amdgcn_readfirstlane((int)S[AS_FLAGS + 6]);
+        if (VF_ASM2_ROLES == 2) swapped = 1;          // (test build: wave 1 eliminates in every workgroup)
     }
 #else
     __syncthreads();

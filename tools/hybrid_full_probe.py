@@ -1,6 +1,9 @@
 """The update of bench.py under a termination rule that never fires (tolerances 1e-300: the hybrid launch path with every
-window active in all five trials) -- for a kernel trace: is the sweep slower under the hybrid launch than in the headline's, or only
-after the light phase a real rule leaves?  usage: python tools/hybrid_full_probe.py <lib.so> [tol]"""
+window active in all five trials), between two phases with the rule off -- for a kernel trace (tools/trace_tail.py,
+tools/trace_context.py): is the two-wave sweep slower under the hybrid launch than in the headline's?  It was, by 21 %: the roles of
+its two waves were fixed and their SIMD placement depends on the kernel that ran before.  Compare
+tools/build_variant.sh roles0 -DVF_ASM2_ROLES=0 (fixed roles) with the product library (roles agreed per CU).
+usage: python tools/hybrid_full_probe.py <lib.so> [tol]"""
 import os, sys, time, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vil_sensor_fusion_amd import _lib

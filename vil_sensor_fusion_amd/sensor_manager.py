@@ -65,12 +65,14 @@ class SensorManager:
         # covariance_angular.  True reproduces that (benign in config/carla: 0.2 / 0.2, 0.1 / 0.1; not in config/san_rafael:
         # 1e-6 / 1e-7, 1e-3 / 1e-4); False puts each where its name says.
         self.noise_order_compat = noise_order_compat
-        self.skipped = []            # (previous stamp, stamp) of consecutive odometry messages the max_time_skip test refused
+        # diagnostics kept for the caller, bounded (a node runs for hours: the last `keep` entries of each)
+        keep = 4096
+        self.skipped = deque(maxlen=keep)    # (previous stamp, stamp) of consecutive odometry messages the max_time_skip test refused
         self.keys_and_times = deque()
         self.last_valid_odom = None
         self.last_valid_key = None
         self.has_received_odometry = False
-        self.warnings = []
+        self.warnings = deque(maxlen=keep)
 
     # SensorManagerRos.h:91-103
     def sensorCallback(self, stamp):

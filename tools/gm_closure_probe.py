@@ -25,6 +25,6 @@ for k in range(1, nkf):
     st0 = gm.lmStats()
     t0 = time.perf_counter()
     gm.solve()
-    if k >= nkf - 4:
+    if k >= nkf - 4 or b0 - 1 <= k <= b0 + 1:
         st1 = gm.lmStats()
         print("solve", k, f"{(time.perf_counter() - t0) * 1e3:.3f} ms, trials", st1["accepted"] + st1["rejected"] - st0["accepted"] - st0["rejected"], flush=True)

@@ -498,6 +498,131 @@ def profiled_kernels():
     return json.load(open(path)) if os.path.exists(path) else None
 
 
+def roofline_k1(eng):
+    """roofline of the Jacobian-evaluation kernel K1, measured live with HIP events on the engine's own stream:
+    algorithmic bytes of one launch / average launch duration; PMC traffic from the committed counter passes."""
+    counts = eng.counts()
+    k1_ms = eng.time_stage("linearize_imu", reps=20)
+    alg_bytes = counts["imu"] * IMU_BYTES
+    achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
+    traffic = measured_traffic_per_imu_factor()
+    return {"kernel": "k_linearize_imu (K1: CombinedImuFactor residual + whitened 15x30 Jacobian)",
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None if (traffic is None or "stale" in traffic) else traffic["k1_bytes_per_imu_factor"] * counts["imu"],
+            "traffic_source": None if traffic is None else traffic.get("source", traffic.get("stale")),
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,
+            "avg_launch_ms_source": "HIP events on the engine's stream, 20 back-to-back launches (vf_engine_time_stage)",
+            "algorithmic_bytes_per_imu_factor": IMU_BYTES,
+            "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+            "priced_on_survey_dense_figure_5496": {
+                "achieved": counts["imu"] * IMU_BYTES_DENSE / (k1_ms * 1e-3) / 1e9,
+                "frac": counts["imu"] * IMU_BYTES_DENSE / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "note": "counts the 159 structurally zero Jacobian entries that are no longer written"}}
+
+
+LINE_LIMIT = 4096        # the driver keeps the tail of stdout: the ONE JSON line must fit well inside it
+
+
+def _r(x, sig=6):
+    """floats at `sig` significant digits (the line is a summary; bench_detail.json keeps full precision)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}") if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return _r(float(x), sig)
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(full, detail_name="bench_detail.json"):
+    """The ONE JSON line the driver parses: the contract keys, `roofline`, `cpu_baseline` and a handful of labelled scalars,
+    <= LINE_LIMIT characters.  Everything else bench.py measures (per-kernel profile, issue view, K6 table, the
+    time-sharded window, prose) is in `full`, which main() writes to bench_detail.json beside this script."""
+    out = _pick(full, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data")
+    out["vs_baseline"] = full.get("vs_baseline")
+    cfg = full.get("config", {})
+    out["config"] = _pick(cfg, "workload", "window_keyframes", "windows_per_gpu", "lm_trials_per_update", "parallelism")
+    acc = full.get("accuracy")
+    if acc:
+        out["accuracy"] = _pick(acc, "ate_m", "rot_rad", "ate_m_max", "within_bar_all", "updates", "bar_m")
+        out["accuracy"]["vs"] = "CPU oracle, same updates (GTSAM cannot be run here)"
+        qr = acc.get("vs_independent_qr") or {}
+        if "ate_m" in qr:
+            out["accuracy"]["vs_independent_qr_ate_m"] = qr["ate_m"]
+    if "stage_ms" in full:
+        out["stage_ms"] = _r({k: v for k, v in full["stage_ms"].items() if not k.startswith("assemble_k3")}, 4)
+    if "solve_form" in full:
+        out["solve_form"] = full["solve_form"]
+    rf = full.get("roofline")
+    if rf:
+        out["roofline"] = _pick(rf, "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic",
+                                "avg_launch_ms", "profiled_avg_launch_ms", "profiled_frac", "profiled_source",
+                                "algorithmic_bytes_per_imu_factor")
+        out["roofline"].setdefault("traffic", None)
+        out["roofline"]["kernel"] = "k_linearize_imu (K1)"
+    rs = full.get("roofline_solve")
+    if rs:
+        out["roofline_solve"] = _pick(rs, "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")
+        out["roofline_solve"]["kernel"] = "band solve (K3+K4)" if full.get("solve_form") == "assembling" else "k_band_solve (K4)"
+        mv = rs.get("matrix_instruction_view")
+        if mv:
+            out["roofline_solve"]["mfma_f64_tflops"] = mv["achieved"]
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind")
+        out["cpu_baseline"]["sample"] = (f"{cfg.get('window_keyframes')}-pose window, same fixed-lag update, "
+                                         f"{cfg.get('lm_trials_per_update')} LM trials, C oracle on 1 core (not GTSAM: cannot be built here)")
+    ca = full.get("cpu_baseline_all_cores")
+    if ca:
+        out["cpu_baseline_all_cores"] = _pick(ca, "value", "cores")
+    for key, sub in (("with_convergence_exit", ("value", "ms_per_step", "error")),
+                     ("incremental_update", ("value", "ms_per_step", "relinearised_frac", "error")),
+                     ("single_window", ("ms_per_update", "solve_ms")),
+                     ("graph_manager", ("solve_ms_mean",))):
+        if isinstance(full.get(key), dict):
+            out[key] = _pick(full[key], *sub)
+    gm = full.get("graph_manager")
+    if isinstance(gm, dict) and isinstance(gm.get("default_termination"), dict):
+        out["graph_manager"]["solve_ms_p99"] = gm["default_termination"].get("solve_ms_p99")
+    ts = full.get("time_sharded_window")
+    if isinstance(ts, dict):
+        out["time_sharded_window"] = _pick(ts, "window_keyframes", "ranks", "ms_per_lm_trial", "error")
+    k6 = (full.get("degeneracy_k6") or {}).get("roofline_k6", {}).get("kernels")
+    if k6:
+        out["degeneracy_k6_ns_per_matrix"] = {k: v["ns_per_matrix"] for k, v in k6.items() if k.endswith("/f64")}
+    out["detail"] = detail_name
+    out = _r(out)
+    line = json.dumps(out, separators=(",", ":"))
+    # never print a line the driver cannot keep: shed the optional objects, least important first
+    for victim in ("degeneracy_k6_ns_per_matrix", "time_sharded_window", "stage_ms", "roofline_solve", "single_window",
+                   "graph_manager", "accuracy", "cpu_baseline_all_cores", "with_convergence_exit", "incremental_update"):
+        if len(line) <= LINE_LIMIT:
+            break
+        out.pop(victim, None)
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line) <= LINE_LIMIT, len(line)
+    return line
+
+
+def write_detail(full, path=None):
+    path = path or os.path.join(os.environ.get("VF_BENCH_DETAIL_DIR", ROOT), "bench_detail.json")
+    try:
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        return path
+    except OSError as exc:       # a read-only checkout must not cost the line
+        print(f"bench.py: could not write {path}: {exc}", file=sys.stderr)
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -660,6 +785,10 @@ def main():
             conv["value"] = info.world * args.windows / (slow * 1e-3)
             conv["unit"] = "keyframes/s"
 
+    # K1's roofline is measured before the one section that holds collectives, so that the fallback line of a stalled
+    # multi-rank run carries it too
+    roofline = roofline_k1(eng) if info.rank == 0 else None
+
     sharded = None
     if not args.no_sharded and 96 % info.world == 0:
         # every rank reports whether its side is healthy before any collective of this section is entered
@@ -671,17 +800,21 @@ def main():
             def bail():
                 if info.rank == 0:
                     kfs = D.whole_job_throughput(summaries, dt)
-                    print(json.dumps({
+                    fb = {
                         "metric": "keyframes/sec fixed-lag update, 1k-pose window; ATE vs GTSAM ref", "value": kfs,
                         "unit": "keyframes/s", "n_gpus": info.world, "steps": args.steps, "warmup": args.warmup,
                         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                         "dtype": "f64", "data": "synthetic",
                         "config": {"workload": f"fixed-lag update of {args.window}-pose VIL windows, {args.iterations} LM trials "
                                                f"per update, {args.windows} independent windows per GPU",
+                                   "window_keyframes": args.window, "windows_per_gpu": args.windows, "lm_trials_per_update": args.iterations,
                                    "parallelism": f"independent windows sharded over {info.world} rank(s), no data-path collective"},
+                        "accuracy": accuracy, "roofline": roofline,
                         "with_convergence_exit": conv,
                         "time_sharded_window": {"error": f"no result within {args.sharded_timeout} s: section abandoned, "
-                                                         "the ranks left without tearing the process group down"}}), flush=True)
+                                                         "the ranks left without tearing the process group down"}}
+                    write_detail(fb)
+                    print(compact_line(fb), flush=True)
                 # a stalled collective is a failure of the run, not a success: the headline line is out, the status says
                 # which part hung (every rank leaves with the same code; spawn_ranks hands it on)
                 os._exit(EXIT_SHARDED_SECTION_HUNG)
@@ -700,9 +833,7 @@ def main():
         kf_per_s = D.whole_job_throughput(summaries, dt)
         # roofline of the Jacobian-evaluation kernel K1, measured live with HIP events on the
         # engine's own stream: algorithmic bytes of one launch / average launch duration
-        k1_ms = eng.time_stage("linearize_imu", reps=20)
         alg_bytes = counts["imu"] * IMU_BYTES
-        achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
         stages = {s: eng.time_stage(s, reps=5) for s in
                   ("linearize_imu", "linearize_between", "assemble", "assemble_idle", "solve", "retract", "decide")}
         solve_form = eng.solve_form()
@@ -712,7 +843,6 @@ def main():
             stages["assemble_k3_not_in_the_step"] = stages.pop("assemble")
             stages.pop("assemble_idle")
             stages["assemble"] = 0.0
-        traffic = measured_traffic_per_imu_factor()
         prof = profiled_kernels()
         out = {
             "metric": "keyframes/sec fixed-lag update, 1k-pose window; ATE vs GTSAM ref",
@@ -730,19 +860,7 @@ def main():
             # (short objects first: a reader of the line's head sees the result, its accuracy and where the step's time goes)
             "accuracy": accuracy,
             "stage_ms": dict(stages, h2d=ingest_ms[0], preintegrate_tail=ingest_ms[1]),
-            "roofline": {"kernel": "k_linearize_imu (K1: CombinedImuFactor residual + whitened 15x30 Jacobian)",
-                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None if (traffic is None or "stale" in traffic) else traffic["k1_bytes_per_imu_factor"] * counts["imu"],
-                         "traffic_source": None if traffic is None else traffic.get("source", traffic.get("stale")),
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,
-                         "avg_launch_ms_source": "HIP events on the engine's stream, 20 back-to-back launches (vf_engine_time_stage)",
-                         "algorithmic_bytes_per_imu_factor": IMU_BYTES,
-                         "frac_of_measured_copy_peak_6290": achieved / 6290.0,
-                         "priced_on_survey_dense_figure_5496": {
-                             "achieved": counts["imu"] * IMU_BYTES_DENSE / (k1_ms * 1e-3) / 1e9,
-                             "frac": counts["imu"] * IMU_BYTES_DENSE / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                             "note": "counts the 159 structurally zero Jacobian entries that are no longer written"}},
+            "roofline": roofline,
             "ingest": {"in_timed_step": True,
                        "what": "per update and window: the new keyframe's raw IMU samples (7 doubles each) + its 28-double between "
                                "record, one pinned host->device copy for all windows (stage_ms.h2d); K0 with each window's current "
@@ -895,7 +1013,8 @@ def main():
             if cpu_all is not None:
                 out["cpu_baseline_all_cores"] = cpu_all
                 out["cpu_baseline_all_cores"]["gpu_over_cpu_node"] = kf_per_s / cpu_all["value"]
-        line = json.dumps(out)
+        write_detail(out)
+        line = compact_line(out)
     else:
         line = None
     D.barrier(dist)

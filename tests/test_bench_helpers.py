@@ -62,3 +62,45 @@ def test_cpu_leg_is_the_marginalised_update(oracle):
     # the appended factors were preintegrated again with the bias estimate of the moment (GraphManager.cpp:59), not with 0
     assert np.abs(ref.prob["imu"][n + steps - 1][10:16]).max() > 0 and not np.abs(prob["imu"][n + steps - 1][10:16]).any()
     assert ref.marg is not None and ref.marg.on == 1 and dt > 0 and gt.shape == (n, 16)
+
+
+def test_the_one_json_line_fits_the_drivers_tail():
+    """BENCH_r05.parsed was null because the line had grown to 21 KB.  The line is built from the full report
+    (here: the committed 21 KB report of round 5) and must stay under 4 KB, parse, and carry the contract keys + roofline +
+    cpu_baseline; everything else goes to bench_detail.json."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = json.load(open(os.path.join(root, "profiles", "r05d_bench_default.json")))
+    assert len(json.dumps(full)) > 15000
+    line = bench.compact_line(full)
+    assert len(line) < 4096 and "\n" not in line
+    got = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "detail"):
+        assert k in got, k
+    assert got["vs_baseline"] is None and got["config"]["workload"] and "model" not in got["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in got["roofline"], k
+    assert abs(got["roofline"]["frac"] - got["roofline"]["achieved"] / got["roofline"]["peak"]) < 1e-5
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in got["cpu_baseline"], k
+    assert abs(got["value"] / full["value"] - 1) < 1e-5 and abs(got["ms_per_step"] / full["ms_per_step"] - 1) < 1e-5
+    assert "profiled_kernels" not in got and "issue_view" not in json.dumps(got)
+    # a report stuffed with junk still yields a line that fits (optional objects are shed, the contract keys never)
+    fat = dict(full, stage_ms={f"k{i}": 1.0 / 3 for i in range(400)})
+    got = json.loads(bench.compact_line(fat))
+    assert "roofline" in got and "cpu_baseline" in got and "stage_ms" not in got
+
+
+def test_fallback_line_of_a_stalled_multi_rank_run_carries_roofline():
+    fb = {"metric": "m", "value": 1.0, "unit": "keyframes/s", "n_gpus": 8, "steps": 2, "warmup": 1, "ms_per_step": 3.0,
+          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+          "config": {"workload": "w"}, "roofline": {"bound": "hbm", "achieved": 5000.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.625, "traffic": None},
+          "time_sharded_window": {"error": "no result"}}
+    got = json.loads(bench.compact_line(fb))
+    assert got["roofline"]["frac"] == 0.625 and got["roofline"]["traffic"] is None and got["time_sharded_window"]["error"]
+
+
+def test_detail_file_is_written_where_asked(tmp_path, monkeypatch):
+    monkeypatch.setenv("VF_BENCH_DETAIL_DIR", str(tmp_path))
+    p = bench.write_detail({"a": [1, 2, 3]})
+    assert json.load(open(p)) == {"a": [1, 2, 3]}

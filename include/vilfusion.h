@@ -156,8 +156,31 @@ typedef struct {
                                 are solved as ONE batch on a second, internal engine of 48 windows -- a copy of the window's H per
                                 column -- instead of one band solve after the other (default 1; costs that engine's memory, about
                                 20 KB per keyframe slot and column; 0 = sequential columns as on batch engines; same bits) */
+    /* Incremental updates: the banded form of what ISAM2::update does with relinearizeThreshold / relinearizeSkip 1
+     * (GraphManager.cpp:37-43,126-127).  != 0: vf_engine_isam_step relinearises only the keyframes whose pending increment
+     * reaches the threshold, and linearises, assembles and eliminates again only from the first keyframe that moved or whose
+     * factors are new: forward elimination is causal in time, so the Cholesky panels in front of it stand; the sweep restarts
+     * from a checkpoint of its trailing window (one per 8 keyframe slots, 0.77 KB per slot) and the back substitution stops
+     * once three consecutive increments come out as they were.  The cost of an update then follows the number of keyframes
+     * it touches, not the length of the window.  Same arithmetic in the same order as the one-wave whole-window sweep: with
+     * wildfire = 0 the increments equal that sweep's to the bit.  Windows that hold far factors, and refining engines, take the
+     * full update.  2 = the same kernels started at the window's first keyframe every time (what the incremental update is
+     * checked against, bit for bit: tests/test_gpu_incremental.py).  Default 0.
+     * MEASURED (DESIGN.md "Incremental updates"): on the synthetic Carla stream one update moves the estimate of a keyframe
+     * 1 500 keyframes back by 2-3 mm -- the IMU chain is stiff (2e-5 m), the odometry factors soft (0.3 m), so every update
+     * re-estimates tilt and bias for the whole history -- and with the reference's threshold of 1e-4 nine keyframes in ten are
+     * relinearised at every update: the suffix IS the window, here as in iSAM2.  The mode pays when the threshold is
+     * loose or the graph has stiff odometry; it is off by default. */
+    int incremental;
+    double wildfire;         /* incremental updates: an increment that changes by at most this in every component counts as unchanged
+                                (ISAM2Params::wildfireThreshold, 1e-3 in GTSAM); default 0 = bitwise */
 } vf_engine_opts;
 
+/* incremental engines (vf_engine_opts.incremental): updates made so far by vf_engine_isam_step, how many of them eliminated the
+ * whole window (the first, and every one after an entry point the bookkeeping does not follow); for `window`, the keyframe slot
+ * the last forward sweep started at and the slot the last back substitution stopped at (-1 on other engines) */
+int vf_engine_incremental_info(vf_engine* e, int window, long* updates, long* whole_window_updates, int* first_eliminated,
+                               int* last_substituted);
 void vf_engine_default_opts(vf_engine_opts* o);
 int vf_engine_create(const vf_engine_opts* o, vf_engine** out);
 void vf_engine_destroy(vf_engine* e);
@@ -467,6 +490,10 @@ typedef struct {
      * lag == 0 (the reference's graph is unbounded).  Default 0. */
     int reference_compat;
     double relin_threshold;
+    /* incremental != 0 (with reference_compat): the update is done incrementally (vf_engine_opts.incremental -- read its
+     * MEASURED note -- and .wildfire): a vf_solve costs what the keyframes it touches cost.  Default 0. */
+    int incremental;
+    double wildfire;
 } vf_graph_opts;
 
 /* (time, pose q_wxyz, position, velocity, bias[acc,gyro]) -- GraphManager::OptimizationCallback
@@ -520,6 +547,10 @@ int vf_graph_lm_stats(vf_graph* g, double* cost, int* accepted, int* rejected, i
  * engine is now followed by (vf_engine_opts.refine_iterations: 0 until the window outgrows refine_min_keyframes -- a
  * whole-history handle, lag = 0, gets there by itself -- 12 from then on); LM trials kept provisionally so far (lm_excursion) */
 int vf_graph_solver_info(vf_graph* g, int* window_keyframes, int* refine_corrections, int* provisional_trials);
+/* diagnostics (extra; handles made with incremental != 0): updates so far, how many of them re-eliminated the whole history, and
+ * the keys the last update's forward sweep started at / its back substitution stopped at */
+int vf_graph_incremental_info(vf_graph* g, long* updates, long* whole_window_updates, uint64_t* first_eliminated_key,
+                              uint64_t* last_substituted_key);
 /* smoothed states of keys [key0, key0+n) after the last solve (extra; iSAM2 calculateEstimate) */
 int vf_get_trajectory(vf_graph* g, uint64_t key0, int n, double* state16);
 /* preintegrated record of the factor ending at `key` (extra; firstFactor->preintegratedMeasurements()) */

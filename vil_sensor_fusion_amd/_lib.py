@@ -25,7 +25,8 @@ class EngineOptsC(C.Structure):
                 ("lambda_min", C.c_double), ("lambda_max", C.c_double), ("chunks", C.c_int),
                 ("sweep_two_sided_max", C.c_int), ("hybrid_threshold", C.c_int), ("cold_start", C.c_int),
                 ("use_hip_graph", C.c_int), ("accept_rel", C.c_double), ("solve_split_min", C.c_int), ("solve_assemble_min", C.c_int), ("solve_assemble_waves", C.c_int),
-                ("refine_iterations", C.c_int), ("refine_min_keyframes", C.c_int), ("refine_rel_stop", C.c_double), ("lm_excursion", C.c_int), ("gauge_floor", C.c_double), ("hybrid_active_list", C.c_int), ("far_batch_columns", C.c_int)]
+                ("refine_iterations", C.c_int), ("refine_min_keyframes", C.c_int), ("refine_rel_stop", C.c_double), ("lm_excursion", C.c_int), ("gauge_floor", C.c_double), ("hybrid_active_list", C.c_int), ("far_batch_columns", C.c_int),
+                ("incremental", C.c_int), ("wildfire", C.c_double)]
 
 
 class ImuParamsC(C.Structure):
@@ -44,7 +45,7 @@ class GraphOptsC(C.Structure):
     _fields_ = [("capacity", C.c_int), ("lag", C.c_int), ("iterations", C.c_int), ("device", C.c_int),
                 ("prior_sigma", C.c_double * 15), ("rel_tol", C.c_double), ("abs_tol", C.c_double),
                 ("cold_start", C.c_int), ("fixed_capacity", C.c_int), ("reference_compat", C.c_int),
-                ("relin_threshold", C.c_double)]
+                ("relin_threshold", C.c_double), ("incremental", C.c_int), ("wildfire", C.c_double)]
 
 
 CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -71,11 +72,11 @@ SYMBOLS = [
     "vf_engine_refine_count", "vf_engine_refine_begin", "vf_engine_refine_step", "vf_engine_refine_end", "vf_engine_read_refine",
     "vf_engine_gn_begin", "vf_shard_iterate", "vf_shard_gn_step", "vf_shard_exchange_plan", "vf_engine_read_excursions", "vf_engine_close_excursions",
     "vf_chunk_geometry", "vf_shard_range", "vf_engine_set_convergence",
-    "vf_engine_isam_step", "vf_engine_predict_from_estimate", "vf_engine_get_estimate",
+    "vf_engine_isam_step", "vf_engine_predict_from_estimate", "vf_engine_get_estimate", "vf_engine_incremental_info",
     "vf_graph_default_opts", "vf_create", "vf_destroy", "vf_add_imu", "vf_reserve_node",
     "vf_add_between", "vf_solve", "vf_get_state", "vf_get_bias", "vf_most_recent_pose_time",
     "vf_set_callback", "vf_graph_staged", "vf_get_trajectory", "vf_get_imu_factor",
-    "vf_add_imu_factor", "vf_get_most_recent_estimate", "vf_graph_lm_stats", "vf_graph_solver_info", "vf_set_initial_state",
+    "vf_add_imu_factor", "vf_get_most_recent_estimate", "vf_graph_lm_stats", "vf_graph_solver_info", "vf_set_initial_state", "vf_graph_incremental_info",
     "vf_degeneracy_batch", "vf_dopt_filter_f32",
 ]
 

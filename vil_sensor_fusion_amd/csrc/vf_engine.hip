@@ -87,6 +87,13 @@ struct vf_engine {
     int slid = 0;             // keyframes appended since the last solve
     int redo = 0;             // slots in front of the old window end whose factors changed since (see touch())
     bool no_warm = false;     // vf_engine_opts.cold_start: every solve starts cold (tests compare the two)
+    // Incremental updates (vf_engine_opts.incremental; vf_kernels.hpp "Incremental Gauss-Newton updates"): inc_valid = the panels
+    // and checkpoints on the device are those of the problem as it was after the last vf_engine_isam_step, and everything
+    // that changed since is an append -- inc_slid slides, or (one-window engines) writes at or beyond slot inc_first_dirty.
+    // Any other entry point that writes (cold()) voids it: the next update eliminates the whole window.
+    bool inc_valid = false;
+    int inc_slid = 0, inc_first_dirty = 0x7fffffff;
+    long inc_updates = 0, inc_full = 0;      // incremental updates so far; those that eliminated from the window's first keyframe
     // hybrid K4 (vf_kernels.hpp "View::gate"): buffers and chunk count of the partitioned form for a sweep engine, allocated
     // when the termination rule is first switched on
     bool hybrid = false;
@@ -263,6 +270,12 @@ struct vf_engine {
     }
 };
 
+// anything the warm start / the incremental update do not know how to follow: the next solve starts from nothing
+static inline void cold(vf_engine* e) {
+    e->warm = false;
+    e->inc_valid = false;
+}
+
 DeviceGuard::DeviceGuard(const vf_engine* e) {
     if (!e) return;
     want = e->opts.device;
@@ -315,6 +328,8 @@ void vf_engine_default_opts(vf_engine_opts* o) {
     o->gauge_floor = 3e-4;
     o->hybrid_active_list = 1;
     o->far_batch_columns = 1;
+    o->incremental = 0;
+    o->wildfire = 0.0;
 }
 
 int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
@@ -409,6 +424,14 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     v.sh_G = 1;
     v.gauge_floor = o->gauge_floor;
     v.sh_all_jac = o->refine_iterations != 0 ? 1 : 0;   // (the refined solve applies J on whole increments: every rank keeps every Jacobian)
+    v.wildfire = o->wildfire >= 0.0 ? o->wildfire : 0.0;
+    if (o->incremental) {
+        AL(v.inc_k, (size_t)v.B);
+        AL(v.inc_stop, (size_t)v.B);
+        AL(v.inc_from, (size_t)v.B);
+        AL(v.ck, (G >> vf::CK_LOG) * vf::CK_SZ);
+        HIPCHK(hipMemsetAsync(v.inc_k, 0x7f, v.B * sizeof(int), e->stream));
+    }
     AL(e->lambda0_dev, (size_t)v.B);
     AL(e->sigma_dev, 16);
     AL(e->status_dev, 4);
@@ -461,12 +484,21 @@ void vf_engine_destroy(vf_engine* e) {
 // covered) lengthens the tail that is linearised again (`redo`), up to the 8 keyframes k_linearize_tail handles.
 static void touch(vf_engine* e, int window, int first_slot) {
     if (!e) return;
+    if (e->inc_valid && e->v.B == 1 && window == 0 && first_slot > e->h_lo[0]) {
+        // (incremental engines follow a write anywhere behind the window's first keyframe: the update starts in front of it)
+        if (first_slot < e->inc_first_dirty) e->inc_first_dirty = first_slot;
+        if (!e->warm) return;
+        const int inside = e->h_hi[0] - first_slot;
+        if (inside > e->redo) e->redo = inside;
+        if (e->redo > 8) e->warm = false;
+        return;
+    }
     if (e->warm && e->v.B == 1 && window == 0 && first_slot > e->h_lo[0]) {
         const int inside = e->h_hi[0] - first_slot;          // <= 0: beyond the current end
         if (inside > e->redo) e->redo = inside;
         if (e->redo <= 8) return;
     }
-    e->warm = false;
+    cold(e);
 }
 static int not_sharded_(vf_engine* e, const char* what) {
     if (e && e->v.sh_G > 1) return fail(VF_ERR_INVALID, "%s: not for time-sharded engines", what);
@@ -487,12 +519,18 @@ static int check_range(vf_engine* e, int window, int k0, int n) {
 int vf_engine_set_range(vf_engine* e, int window, int lo, int hi) {
     DeviceGuard dev_guard_(e);
     int rc = check_window(e, window);
-    if (rc) { if (e) e->warm = false; return rc; }
-    if (lo < 0 || hi < lo || hi > e->v.M) { e->warm = false; return fail(VF_ERR_BAD_KEY, "bad range [%d,%d)", lo, hi); }
+    if (rc) { if (e) cold(e); return rc; }
+    if (lo < 0 || hi < lo || hi > e->v.M) { cold(e); return fail(VF_ERR_BAD_KEY, "bad range [%d,%d)", lo, hi); }
     // growing the end of the one window of a warm engine = appending keyframes (see touch()); its start is moved by
     // vf_engine_drop_oldest only
-    if (e->warm && e->v.B == 1 && lo == e->h_lo[0] && hi >= e->h_hi[0] && e->h_hi[0] > e->h_lo[0]) e->slid += hi - e->h_hi[0];
-    else e->warm = false;
+    const bool grows = e->v.B == 1 && lo == e->h_lo[0] && hi >= e->h_hi[0] && e->h_hi[0] > e->h_lo[0];
+    const bool inc_keeps = grows && e->inc_valid;
+    if (e->warm && grows) e->slid += hi - e->h_hi[0];
+    else cold(e);
+    if (inc_keeps) {
+        e->inc_valid = true;
+        if (hi > e->h_hi[0] && e->h_hi[0] < e->inc_first_dirty) e->inc_first_dirty = e->h_hi[0];
+    }
     HIPCHK(hipMemcpyAsync(e->v.lo + window, &lo, sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->v.hi + window, &hi, sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -503,7 +541,7 @@ int vf_engine_set_range(vf_engine* e, int window, int lo, int hi) {
 
 int vf_engine_set_states(vf_engine* e, int window, int k0, int n, const double* s) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (!s) return fail(VF_ERR_INVALID, "null states");
@@ -588,7 +626,7 @@ int vf_engine_set_between(vf_engine* e, int window, int n, const int32_t* a, con
 
 int vf_engine_set_extra_between(vf_engine* e, int window, int n, const int32_t* a, const int32_t* b, const double* rec) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     int rc = check_window(e, window);
     if (rc) return rc;
     if (int rs = not_sharded_(e, "vf_engine_set_extra_between")) return rs;
@@ -642,7 +680,7 @@ int vf_engine_set_extra_between(vf_engine* e, int window, int n, const int32_t* 
 
 int vf_engine_clear_between(vf_engine* e, int window, int k0, int n) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
     if (n == 0) return VF_OK;
@@ -653,7 +691,7 @@ int vf_engine_clear_between(vf_engine* e, int window, int k0, int n) {
 
 int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     int rc = check_range(e, window, k, 1);
     if (rc) return rc;
     if (!rec) return fail(VF_ERR_INVALID, "null record");
@@ -786,7 +824,7 @@ int vf_engine_get_imu(vf_engine* e, int window, int k0, int n, double* rec) {
 // ------------------------------------------------------------------ stages
 int vf_engine_linearize(vf_engine* e, int which) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     which = which ? 1 : 0;
     // a new linearisation of the CURRENT states invalidates H, g and starts a new solve (no window is converged yet)
@@ -815,7 +853,7 @@ static bool assembles_in_hybrid(const vf_engine* e) {
 }
 int vf_engine_assemble(vf_engine* e) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (assembles_in_solve(e)) return VF_OK;
     if (assembles_in_hybrid(e)) {
@@ -836,7 +874,7 @@ static int not_sharded(vf_engine* e, const char* what) {
 }
 int vf_engine_solve(vf_engine* e) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (int rc = not_sharded(e, "vf_engine_solve")) return rc;
     auto band_solve = [&](double* gvec, double* delta, const int* skip = nullptr) {      // the engine's K4 form on another right-hand side / increment buffer
@@ -928,7 +966,7 @@ int vf_engine_refine_count(vf_engine* e, int* iterations) {
 int vf_engine_refine_begin(vf_engine* e) {
     DeviceGuard dev_guard_(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
-    e->warm = false;
+    cold(e);
     if (int rc = e->ensure_refine()) return rc;
     vf::launch_refine_begin(e->v, e->rq, e->stream);
     HIPCHK(hipGetLastError());
@@ -970,7 +1008,7 @@ int vf_engine_read_refine(vf_engine* e, int window, int* corrections, double* re
 }
 int vf_engine_retract(vf_engine* e) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     vf::launch_retract(e->v, e->stream);
     HIPCHK(hipGetLastError());
@@ -1004,7 +1042,7 @@ int vf_engine_close_excursions(vf_engine* e) {
 }
 int vf_engine_decide(vf_engine* e, int init) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     e->v.nm_W = e->excursion();
     if (e->v.nm_W > 0)
@@ -1140,7 +1178,7 @@ int vf_shard_range(int n, int chunks, int fit, int rank, int world, int* chunk_l
 // ------------------------------------------------------------------ time-sharded windows (multi-GPU)
 int vf_engine_set_stream(vf_engine* e, void* hip_stream) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->own_stream && e->stream) HIPCHK(hipStreamDestroy(e->stream));
@@ -1152,7 +1190,7 @@ int vf_engine_set_stream(vf_engine* e, void* hip_stream) {
 }
 int vf_engine_set_shard(vf_engine* e, int rank, int world) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (world < 1 || rank < 0 || rank >= world) return fail(VF_ERR_INVALID, "bad shard %d of %d", rank, world);
     if (world > 1 && (e->v.P < 2 || e->v.P_fit))
@@ -1193,7 +1231,7 @@ static int check_sharded(vf_engine* e) {
 }
 int vf_engine_solve_local(vf_engine* e) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     int rc = check_sharded(e);
     if (rc) return rc;
     vf::View a = e->v;
@@ -1204,7 +1242,7 @@ int vf_engine_solve_local(vf_engine* e) {
 }
 int vf_engine_solve_global(vf_engine* e) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     int rc = check_sharded(e);
     if (rc) return rc;
     vf::View a = e->v;
@@ -1324,7 +1362,7 @@ int vf_shard_gn_step(vf_engine* e, void* nccl_comm, double relin_threshold) {
 
 int vf_engine_set_convergence(vf_engine* e, double rel_tol, double abs_tol) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (!(rel_tol >= 0.0) || !(abs_tol >= 0.0)) return fail(VF_ERR_INVALID, "tolerances must be >= 0");
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1380,17 +1418,53 @@ int vf_engine_gn_begin(vf_engine* e, double relin_threshold) {
     DeviceGuard dev_guard_(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (!(relin_threshold >= 0.0)) return fail(VF_ERR_INVALID, "relinearisation threshold must be >= 0");
-    e->warm = false;
+    cold(e);
     int rc;
     vf::launch_relinearize(e->v, relin_threshold, e->stream);
     HIPCHK(hipMemsetAsync(e->v.lambda, 0, e->v.B * sizeof(double), e->stream));     // Gauss-Newton: no damping
     if ((rc = vf_engine_linearize(e, 0)) || (rc = vf_engine_decide(e, 1))) return rc;
     return VF_OK;
 }
+// The same update done incrementally (vf_engine_opts.incremental): relinearise, then linearise / assemble / eliminate only from
+// the first keyframe that changed, back-substitute until the increments stop changing (vf_kernels.hpp "Incremental
+// Gauss-Newton updates").  The first update of an engine, and every update after an entry point the bookkeeping does not
+// follow, covers the whole window.
+static int isam_step_incremental(vf_engine* e, double relin_threshold) {
+    const int invalid = (e->inc_valid && e->opts.incremental != 2) ? 0 : 1;     // (incremental = 2: the same kernels over the whole window, every time)
+    int appended = e->inc_slid;
+    if (e->v.B == 1 && e->inc_first_dirty != 0x7fffffff) appended = std::max(appended, e->h_hi[0] - e->inc_first_dirty);
+    vf::View a = e->v;
+    a.inc_on = 1;
+    a.inc_prior = (invalid || e->inc_slid > 0) ? 1 : 0;
+    a.stop_on = 0;
+    vf::launch_inc_begin(a, relin_threshold, appended, invalid, e->stream);
+    HIPCHK(hipMemsetAsync(e->v.lambda, 0, e->v.B * sizeof(double), e->stream));     // Gauss-Newton: no damping
+    if (a.B <= 128) vf::launch_linearize_all(a, 0, e->stream);
+    else { vf::launch_linearize_imu(a, 0, e->stream); vf::launch_linearize_between_prior(a, 0, e->stream); }
+    vf::launch_assemble(a, e->stream);
+    vf::launch_inc_solve(a, e->stream);
+    vf::launch_inc_retract(a, e->stream);
+    HIPCHK(hipGetLastError());
+    cold(e);
+    e->inc_slid = 0;
+    e->inc_first_dirty = 0x7fffffff;
+    e->inc_updates++;
+    if (invalid) e->inc_full++;
+    std::vector<int> failed((size_t)e->v.B);
+    HIPCHK(hipMemcpyAsync(failed.data(), e->v.fail, failed.size() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int w = 0; w < e->v.B; w++)
+        if (failed[w]) return fail(VF_ERR_INDETERMINATE, "window %d: normal equations not positive definite (underdetermined graph)", w);
+    e->inc_valid = true;
+    return VF_OK;
+}
 int vf_engine_isam_step(vf_engine* e, double relin_threshold) {
     DeviceGuard dev_guard_(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (int rc0 = not_sharded(e, "vf_engine_isam_step")) return rc0;
+    if (!(relin_threshold >= 0.0)) return fail(VF_ERR_INVALID, "relinearisation threshold must be >= 0");
+    // (far factors are solved as a low-rank correction of the whole band: such windows take the full update)
+    if (e->v.ck && e->x_used == 0 && e->refine_iters() == 0) return isam_step_incremental(e, relin_threshold);
     int rc;
     if ((rc = vf_engine_gn_begin(e, relin_threshold)) || (rc = vf_engine_assemble(e)) ||
         (rc = vf_engine_solve(e)) || (rc = vf_engine_retract(e))) return rc;
@@ -1399,13 +1473,29 @@ int vf_engine_isam_step(vf_engine* e, double relin_threshold) {
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int w = 0; w < e->v.B; w++)
         if (failed[w]) return fail(VF_ERR_INDETERMINATE, "window %d: normal equations not positive definite (underdetermined graph)", w);
-    e->warm = false;
+    cold(e);
+    return VF_OK;
+}
+int vf_engine_incremental_info(vf_engine* e, int window, long* updates, long* whole_window_updates, int* first_eliminated, int* last_substituted) {
+    DeviceGuard dev_guard_(e);
+    int rc = check_window(e, window);
+    if (rc) return rc;
+    if (updates) *updates = e->inc_updates;
+    if (whole_window_updates) *whole_window_updates = e->inc_full;
+    int from = -1, stop = -1;
+    if (e->v.ck) {
+        HIPCHK(hipMemcpyAsync(&from, e->v.inc_from + window, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(&stop, e->v.inc_stop + window, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    if (first_eliminated) *first_eliminated = from;
+    if (last_substituted) *last_substituted = stop;
     return VF_OK;
 }
 int vf_engine_predict_from_estimate(vf_engine* e, int window, int k0, int n) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    { const bool keep = e->inc_valid; touch(e, window, k0); cold(e); if (keep && e->v.B == 1 && window == 0 && k0 > e->h_lo[0]) e->inc_valid = true; }
     if (window >= e->v.B || k0 < 1 || n < 0 || k0 + n > e->v.M) return fail(VF_ERR_BAD_KEY, "bad predict range");
     if (n == 0) return VF_OK;
     vf::launch_predict(e->v, window, k0, n, 1, e->stream);
@@ -1594,6 +1684,7 @@ int vf_engine_slide(vf_engine* e, const double* prior_sigma15, int marginalize) 
     if (int rc = transport_far(e, marginalize != 0)) return rc;
     e->marg_since_drop = false;
     if (e->warm) e->slid++;   // a slide is a change a warm start knows how to follow
+    if (e->inc_valid) e->inc_slid++;
     // the sigmas are a caller temporary: uploaded (and waited for) only when they differ from what the device already holds, so
     // that a run of updates with the same sigmas -- every fixed-lag loop -- enqueues without a host synchronisation
     const bool fresh_sigma = !e->sigma_valid || memcmp(e->sigma_host, prior_sigma15, sizeof(e->sigma_host)) != 0;
@@ -1625,7 +1716,7 @@ int vf_engine_read_marginal(vf_engine* e, int window, int* on, double* xbar48, d
 // end.  shift must be a multiple of 64 (whole AoSoA tiles) and <= every window's lo.
 int vf_engine_compact(vf_engine* e, int shift) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     vf::View& v = e->v;
     if (shift <= 0 || shift % 64 != 0 || shift >= v.M) return fail(VF_ERR_INVALID, "shift must be a positive multiple of 64 below the capacity");
@@ -1787,7 +1878,7 @@ int vf_engine_grow(vf_engine* e, int new_capacity) {
     std::swap(*e, *n);             // *e: the grown engine; *n: the old buffers
     n->own_stream = n->own_stream && n->stream != e->stream;
     vf_engine_destroy(n);
-    e->warm = false;
+    cold(e);
     e->slid = e->redo = 0;
     e->epoch++;
     // the linearisation of the current states is part of the state other entry points rely on (vf_engine_marginalize reads
@@ -1958,7 +2049,7 @@ int vf_engine_read_excursions(vf_engine* e, int window, int* provisional_trials,
 }
 int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     if (!e || !avg_ms || reps < 1) return fail(VF_ERR_INVALID, "bad argument");
     vf::View tv = e->v;
     tv.stop_on = 0;           // stage timings are of the full work, whatever the windows' convergence flags say
@@ -1994,7 +2085,7 @@ int vf_engine_time_stage(vf_engine* e, int stage, int reps, float* avg_ms) {
 
 int vf_engine_time_iterate(vf_engine* e, int iterations, float* ms) {
     DeviceGuard dev_guard_(e);
-    if (e) e->warm = false;
+    if (e) cold(e);
     if (!e || !ms) return fail(VF_ERR_INVALID, "bad argument");
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipEventRecord(e->ev0, e->stream));

@@ -141,6 +141,8 @@ void vf_graph_default_opts(vf_graph_opts* o) {
     o->fixed_capacity = 0;
     o->reference_compat = 0;
     o->relin_threshold = 1e-4;   // GraphManager.cpp:40
+    o->incremental = 0;
+    o->wildfire = 0.0;
 }
 
 int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** out) {
@@ -152,6 +154,8 @@ int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** ou
     if (!(o.rel_tol >= 0.0) || !(o.abs_tol >= 0.0)) return gerr(VF_ERR_INVALID, "tolerances must be >= 0");
     if (o.reference_compat && o.lag != 0) return gerr(VF_ERR_INVALID, "reference_compat needs lag == 0 (the reference's graph is unbounded)");
     if (o.reference_compat && !(o.relin_threshold >= 0.0)) return gerr(VF_ERR_INVALID, "relin_threshold must be >= 0");
+    if (o.incremental && !o.reference_compat) return gerr(VF_ERR_INVALID, "incremental needs reference_compat (the update it makes incremental is the iSAM2-like one)");
+    if (o.incremental && !(o.wildfire >= 0.0)) return gerr(VF_ERR_INVALID, "wildfire must be >= 0");
     const double covs[6] = {imu->acc_cov, imu->gyro_cov, imu->integration_cov, imu->bias_acc_cov, imu->bias_omega_cov, imu->bias_acc_omega_int};
     for (double c : covs)
         if (!(c > 0.0) || !std::isfinite(c)) return gerr(VF_ERR_NOT_SPD, "IMU covariances must be finite and > 0");
@@ -165,6 +169,15 @@ int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** ou
     eo.capacity = o.capacity;
     eo.device = o.device;
     eo.cold_start = o.cold_start;
+    if (o.incremental) {
+        // (the refined solve corrects a whole-window factorisation through J; the incremental update keeps the panels of an
+        // elimination that ran forward in time from the anchor prior -- every pivot block is the conditional information of a
+        // keyframe given its past, well conditioned whatever the history's length -- and does without)
+        eo.incremental = o.incremental == 2 ? 2 : 1;
+        eo.wildfire = o.wildfire;
+        eo.refine_iterations = 0;
+        eo.lm_excursion = 0;
+    }
     vf_engine* eng = nullptr;
     int rc = vf_engine_create(&eo, &eng);
     if (rc) return rc;
@@ -643,6 +656,16 @@ int vf_graph_solver_info(vf_graph* g, int* window_keyframes, int* refine_correct
     int rc;
     if (refine_corrections && (rc = vf_engine_refine_count(g->eng, refine_corrections))) return rc;
     if (provisional_trials && (rc = vf_engine_read_excursions(g->eng, 0, provisional_trials, nullptr))) return rc;
+    return VF_OK;
+}
+
+int vf_graph_incremental_info(vf_graph* g, long* updates, long* whole_window_updates, uint64_t* first_eliminated_key, uint64_t* last_substituted_key) {
+    if (!g) return gerr(VF_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->state_mutex);
+    int a = -1, b = -1;
+    if (int rc = vf_engine_incremental_info(g->eng, 0, updates, whole_window_updates, &a, &b)) return rc;
+    if (first_eliminated_key) *first_eliminated_key = a < 0 ? 0 : (uint64_t)a + g->key_base;
+    if (last_substituted_key) *last_substituted_key = b < 0 ? 0 : (uint64_t)b + g->key_base;
     return VF_OK;
 }
 

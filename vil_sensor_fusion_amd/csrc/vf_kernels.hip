@@ -512,6 +512,7 @@ __device__ __forceinline__ void linearize_imu_factor(const View& v, int which, c
     const int w_lo = v.lo[w], w_hi = v.hi[w], w_sel = v.sel[w], w_done = v.stop_on ? v.done[w] : 0;
     if (k <= w_lo || k >= w_hi || w_done) return;
     if (v.relin_only && !v.relin[w]) return;
+    if (v.inc_on && k < v.inc_k[w]) return;      // incremental update: both keyframes of the factor are where they were
     const bool jac = !SH || !shard_skips_factor(v, w, k);
     const int b = w_sel ^ which;
     double* jbuf = v.imu_j + (size_t)b * (size_t)(v.G >> JT_LOG) * JT_STRIDE;
@@ -615,6 +616,7 @@ __device__ __forceinline__ void linearize_between_factor(const View& v, int whic
     const int a = v.btw_a[gk];                 // (all five requested together: one round trip)
     if (k <= lo || k >= w_hi || w_done) return;
     if (v.relin_only && !v.relin[w]) return;
+    if (v.inc_on && k < v.inc_k[w]) return;
     const bool jac = !SH || !shard_skips_factor(v, w, k);
     if (a < lo || a >= k) return;
     const int b = w_sel ^ which;
@@ -839,6 +841,7 @@ __global__ void __launch_bounds__(256) k_linearize_between(View v, int which) {
 __device__ __forceinline__ void linearize_prior_window(const View& v, int which, const int w) {
     if (w >= v.B || window_done(v, w)) return;
     if (v.relin_only && !v.relin[w]) return;
+    if (v.inc_on && !v.inc_prior && v.inc_k[w] > v.lo[w] + 2) return;   // (the priors sit on the window's first three keyframes)
     const int b = v.sel[w] ^ which;
     if (v.mp_on[w] && v.hi[w] - v.lo[w] >= 3) {
         // marginal prior: gm = L d + eta, cost = 0.5 d^T L d + eta^T d (fixed linearisation point)
@@ -1177,10 +1180,15 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     // (hybrid solve of an engine whose sweep assembles its own rows: K3 works for the partitioned form only -- launched with
     // gate = 2, it returns while the sweep is the form in charge, and when it does run it cannot trust `fresh`: the trials the
     // sweep served never brought H up to date)
-    const int fr = v.gate == 2 ? 1 : v.fresh[w], lo = v.lo[w], hi = v.hi[w], w_sel = v.sel[w], w_done = v.stop_on ? v.done[w] : 0;
+    const int fr = (v.gate == 2 || v.inc_on) ? 1 : v.fresh[w], lo = v.lo[w], hi = v.hi[w], w_sel = v.sel[w], w_done = v.stop_on ? v.done[w] : 0;
+    const int ik = v.inc_on ? v.inc_k[w] : 0;
     if (!fr || w_done || gated_off(v)) return;
     const int k0 = blockIdx.x * AT;
     const long gk0 = (long)w * v.M + k0;
+    // incremental update: a factor reaches three keyframes back, so the rows from inc_k - 3 on are new -- all of them when
+    // the sweep starts at the window's first keyframe (the head rows carry the marginal prior of the last slide)
+    const int inc_rlo = (v.inc_on && inc_start(ik, lo) > lo) ? ik - 3 : lo;
+    if (k0 + AT <= inc_rlo) return;
     // warm start (k_linearize_tail): fr = 1 + appended keyframes; only rows near the ends of the window changed --
     // head: the marginal prior / the factors that left with the oldest keyframe reach rows lo .. lo+3;
     // tail: a new factor at slot b touches rows b-3 .. b
@@ -1191,6 +1199,7 @@ __global__ void __launch_bounds__(K3_NT) k_assemble(View v) {
     rhi += lo;
     if (v.sh_G > 1 && rhi + 2 <= hi) rhi += 2;   // tail rows of the rank's last chunk (see shard_skips_factor)
     else if (v.sh_G > 1) rhi = hi;
+    rlo = rlo > inc_rlo ? rlo : inc_rlo;
     if (k0 + AT <= rlo || k0 >= rhi) return; // no owned active keyframe in this tile (uniform)
     K3STAMP(0);
     const int b = w_sel;
@@ -1451,8 +1460,11 @@ constexpr int MID_TOTAL = 45 * MID_LD + 48;     // + the 45 solved increments ha
 //   nothing else) and writes row k + 4 into the window between the eliminator's read of pivot row k and its Schur update's
 //   accumulator reads; two cells of LDS carry the hand-shake.  Eight waves per CU on the LDS of four sweeps: the matrix
 //   instructions of the two roles overlap each other's waits, which one wave cannot do for itself.
+// MODE 9 / 10 (incremental updates, View::inc_*): the forward sweep of SOLVE_FULL started at keyframe cg.i0 of the window from a
+//   checkpoint of its trailing window (and leaving one at every CK-th keyframe slot it passes), and the back substitution of
+//   SOLVE_FULL_BWD that stops once it reproduces the increments that are there, below keyframe cg.ni of the window.
 enum { SOLVE_FULL = 0, SOLVE_TWISTED = 1, SOLVE_CHUNK_FWD = 2, SOLVE_CHUNK_BWD = 3, SOLVE_FULL_FWD = 4, SOLVE_FULL_BWD = 5, SOLVE_ASM_FWD = 6,
-       SOLVE_ASM_A = 7, SOLVE_ASM_B = 8 };
+       SOLVE_ASM_A = 7, SOLVE_ASM_B = 8, SOLVE_INC_FWD = 9, SOLVE_INC_BWD = 10 };
 template <int MODE>
 __device__ __forceinline__ void band_solve_body(const View& v, double* __restrict__ S, double* __restrict__ S_other,
                                                 double* __restrict__ MID, const int w, const int lane, const int wave,
@@ -1462,12 +1474,13 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     constexpr bool ASA = MODE == SOLVE_ASM_A, ASB = MODE == SOLVE_ASM_B;   // the two roles of the two-wave assembling sweep
     constexpr bool AS = MODE == SOLVE_ASM_FWD || ASB;    // rows of H assembled here (no K3)
     constexpr bool CW = MODE == SOLVE_FULL_FWD || AS || ASA;   // compact trailing window ("CW_" map above); the names below shadow the full map
+    constexpr bool INCF = MODE == SOLVE_INC_FWD, INCB = MODE == SOLVE_INC_BWD;
     constexpr int S_GD = CW ? CW_GD : vf::S_GD, S_DUMP = CW ? CW_DUMP : vf::S_DUMP, S_ZERO = CW ? CW_ZERO : vf::S_ZERO;
     constexpr int S_ID = CW ? CW_ID : vf::S_ID, S_P = CW ? CW_P : vf::S_P, S_BC = CW ? CW_BC : vf::S_BC;
     const int lo = v.lo[w], hi = v.hi[w];
-    const int n = CH ? cg.ni + (cg.has_sep ? 3 : 0) : hi - lo;     // real rows of this sweep
+    const int n = CH ? cg.ni + (cg.has_sep ? 3 : 0) : hi - lo - (INCF ? cg.i0 : 0);     // real rows of this sweep
     const double lam = v.lambda[w];
-    const size_t base = (size_t)w * v.M + lo + (CH ? cg.i0 : 0);
+    const size_t base = (size_t)w * v.M + lo + ((CH || INCF) ? cg.i0 : 0);
     int failed = 0;
     // sweep geometry: sweep index kk -> window keyframe j(kk); kinds of rows: 0 real, 1 identity, 2 zero
     const bool rev = TW && wave == 1;
@@ -1582,7 +1595,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     const int s6_off = lane < 36 ? (lane / 6) * LDW + lane % 6 : -1;
     const int s6_srcT = lane < 36 ? (lane % 6) * 6 + lane / 6 : 0;      // reverse sweep: transposed
     const int x9_off = lane < 54 ? (lane / 9) * LDW + 6 + lane % 9 : -1;
-    const double mp_third = (v.mp_on[w] && n >= 3 && !rev && (!CH || cg.i0 == 0)) ? 1.0 : 0.0;
+    const double mp_third = (v.mp_on[w] && n >= 3 && !rev && ((!CH && !INCF) || cg.i0 == 0)) ? 1.0 : 0.0;
     WSYNC();
 
     // ---- assembling sweep (AS): the block row of keyframe R is formed here instead of being read from H --------------------
@@ -2021,7 +2034,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #ifdef VF_SOLVE_STAMPS
     unsigned long long st[16] = {0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
-    if constexpr (MODE != SOLVE_CHUNK_BWD && MODE != SOLVE_FULL_BWD) {
+    if constexpr (MODE != SOLVE_CHUNK_BWD && MODE != SOLVE_FULL_BWD && !INCB) {
     Asm az;
     AsmNext anx;
     if constexpr (AS) {
@@ -2088,6 +2101,21 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     commit_row(IC<1>{}, fetch_row(1), row_kind(1), 1);
     commit_row(IC<2>{}, fetch_row(2), row_kind(2), 2);
     commit_row(IC<3>{}, fetch_row(3), row_kind(3), 3);
+    if constexpr (INCF) {
+        // the sweep's trailing window as the elimination of the keyframes in front of keyframe cg.i0 left it: the 27 dof
+        // [k: 15][k+1: pose][k+2: pose] and their rhs, over the rows just committed (slots 0 .. 2: sweep index 0 is phase 0)
+        if (cg.i0 > 0) {
+            const double* __restrict__ ckp = v.ck + (base >> CK_LOG) * CK_SZ;
+            for (int e = lane; e < SEP * 28; e += 64) {
+                const int i = e / 28, jc = e - i * 28;
+                const int oi = i < 15 ? 0 : (i < 21 ? 1 : 2), ai = i < 15 ? i : (i < 21 ? i - 15 : i - 21);
+                const int oj = jc < 15 ? 0 : (jc < 21 ? 1 : 2), aj = jc < 15 ? jc : (jc < 21 ? jc - 15 : jc - 21);
+                const double val = ckp[e];
+                if (jc == 27) S[S_GD + oi * 15 + ai] = val;
+                else if (jc <= i) S[S_WD + (oi * 15 + ai) * LDW + oj * 15 + aj] = val;
+            }
+        }
+    }
     }
     WSYNC();
     // ---- one elimination step, phase PH = k & 3 compile-time --------------------------------
@@ -2095,6 +2123,26 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     auto step = [&](auto ph, int k, HRow& pend, HRow& pend2) {
         constexpr int PH = decltype(ph)::value;
         STAMP(0);
+        if constexpr (INCF) {
+            // a checkpoint at every CK-th keyframe SLOT (sweeps of later updates start at other keyframes of the window, the
+            // slot grid stays): keyframe k + j sits in slot (PH + j) & 3 of the window
+            if (k > 0 && ((base + (size_t)k) & (CK - 1)) == 0) {
+                double* __restrict__ ckp = v.ck + ((base + (size_t)k) >> CK_LOG) * CK_SZ;
+                for (int e = lane; e < SEP * 28; e += 64) {
+                    const int i = e / 28, jc = e - i * 28;
+                    const int oi = i < 15 ? 0 : (i < 21 ? 1 : 2), ai = i < 15 ? i : (i < 21 ? i - 15 : i - 21);
+                    double val;
+                    if (jc == 27) val = S[S_GD + ((PH + oi) & 3) * 15 + ai];
+                    else {
+                        const int hi_i = i >= jc ? i : jc, lo_i = i >= jc ? jc : i;
+                        const int oa = hi_i < 15 ? 0 : (hi_i < 21 ? 1 : 2), a = hi_i < 15 ? hi_i : (hi_i < 21 ? hi_i - 15 : hi_i - 21);
+                        const int ob = lo_i < 15 ? 0 : (lo_i < 21 ? 1 : 2), bb = lo_i < 15 ? lo_i : (lo_i < 21 ? lo_i - 15 : lo_i - 21);
+                        val = S[S_WD + (((PH + oa) & 3) * 15 + a) * LDW + ((PH + ob) & 3) * 15 + bb];
+                    }
+                    ckp[e] = val;
+                }
+            }
+        }
         double p[15];
 #pragma unroll
         for (int c = 0; c < 15; c++) p[c] = S[ri_ph[PH] + c];
@@ -2247,7 +2295,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #ifdef VF_K4_FWD_ONLY   // probe build only (tools/build_variant.sh): the forward sweep's share of the un-stamped kernel
     if constexpr (MODE == SOLVE_FULL) return;
 #endif
-    if constexpr (MODE == SOLVE_FULL_FWD || AS || ASA) {
+    if constexpr (MODE == SOLVE_FULL_FWD || AS || ASA || INCF) {
         if constexpr (ASA) { if (lds_peek(S + AS_FLAGS + 3) != 0.0) failed = 1; }     // a wait of the assembler wave ran out
         if (lane == 0) v.fail[w] = failed;
 #ifdef VF_SOLVE_STAMPS
@@ -2351,7 +2399,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #define VF_BWD_PD 2      // (2 against 4 slots: solve stage 3.44 against 3.48-3.50 ms at 1 024 windows, 178 against 240 registers; round 5)
 #endif
     static_assert(VF_BWD_PD == 2 || VF_BWD_PD == 4, "the back substitution keeps 2 or 4 panel slots: any other depth reads panels it has not loaded");
-    constexpr int PD = MODE == SOLVE_FULL_BWD ? VF_BWD_PD : 4;      // panels prefetched ahead of the recursion
+    constexpr int PD = (MODE == SOLVE_FULL_BWD || INCB) ? VF_BWD_PD : 4;      // panels prefetched ahead of the recursion
     // Backward sweep: lane r < 28 holds panel row r (sub-diagonal rows and the rhs row: they go through LDS); the rows of
     // L^-T sit in lanes XL .. XL+14 of ONE 16-lane row, where s and x are formed as well, so that both matrix-vector
     // products of the recursion broadcast their vector with DPP row_newbcast inside v_fmac_f64 (one instruction per term
@@ -2388,7 +2436,8 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     // wait in sequence (about 2 600 cycles for 200 instructions); LDS accesses of one wave execute in issue order, so
     // the write -> read hand-offs below need a compiler barrier, not a wait.
 #define CBAR() asm volatile("" ::: "memory")
-    struct Col { double row[15], pv[15], y, part; };   // of one keyframe, in lanes XL .. XL+14: its L^-T row, its column data
+    struct Col { double row[15], pv[15], y, part, dold; };   // of one keyframe, in lanes XL .. XL+14: its L^-T row, its column data
+    int inc_run = 0;      // INCB: consecutive keyframes whose increment came out as it was
     auto prep = [&](auto ph, int k, PRow& slot, Col& o) {
         constexpr int PH = decltype(ph)::value;          // = k & 3
         constexpr int b2 = S_DL + ((PH + 2) & 3) * 15, b3 = S_DL + ((PH + 3) & 3) * 15;
@@ -2397,6 +2446,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
 #pragma unroll
         for (int c = 0; c < 7; c++) { o.row[2 * c] = keep * slot.x[c].x; o.row[2 * c + 1] = keep * slot.x[c].y; }
         o.row[14] = keep * slot.x[7].x;
+        if constexpr (INCB) o.dold = (xl_lane && k >= 0 && pivot_real(k)) ? dbase[(size_t)kf_of(k) * 15 + lane - XL] : 0.0;
         slot = load_panel(k - PD);   // PD steps ahead, into the slot just consumed (slot = k & (PD - 1): no register rotation)
 #pragma unroll
         for (int c = 0; c < 15; c++) S[bw_off + c] = o.row[c];
@@ -2449,6 +2499,10 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         S[xl_lane ? S_DL + PH * 15 + lane - XL : dl_w] = x;
         // (head keyframes of a chunk: only their velocity / bias increments are this sweep's; the pose part is the separator's)
         if (xl_lane && pivot_real(k) && !(CH && cg.i0 > 0 && k < 2 && lane < XL + 6)) dbase[(size_t)kf_of(k) * 15 + lane - XL] = x;
+        if constexpr (INCB) {
+            const bool moved = xl_lane && pivot_real(k) && fabs(x - c_.dold) > v.wildfire;
+            inc_run = __builtin_amdgcn_ballot_w64(moved) != 0 ? 0 : inc_run + 1;
+        }
         xprev = x;
         STAMP(10);
     };
@@ -2462,9 +2516,10 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
         // increment of the keyframe after the last pivot (slot n4 & 3 = 0): zero, or the separator's / the middle system's
         double xprev = S[xl_lane ? S_DL + lane - XL : S_ZERO];
         Col ca, cb;
-        if constexpr (MODE == SOLVE_FULL_BWD) {
+        if constexpr (MODE == SOLVE_FULL_BWD || INCB) {
             // two waves per SIMD: the partner wave covers this one's LDS round trips, so the recursion is not software-
             // pipelined here -- one set of column registers instead of two keeps the kernel inside 256 registers
+            int stop_at = 0;
 #pragma unroll 1
             for (int k = n4 - 1; k >= 3; k -= 4) {
                 prep(IC<3>{}, k, p3, ca);
@@ -2475,7 +2530,13 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
                 solve(IC<1>{}, k - 2, ca, xprev);
                 prep(IC<0>{}, k - 3, p0, ca);
                 solve(IC<0>{}, k - 3, ca, xprev);
+                if constexpr (INCB) {
+                    // keyframes k-3 .. k-1 came out as they were and every panel in front of k-3 is the old one (cg.ni: the first
+                    // keyframe the forward sweep eliminated again): so would every increment in front of them
+                    if (inc_run >= 3 && k - 3 <= cg.ni) { stop_at = k - 3; break; }
+                }
             }
+            if constexpr (INCB) { if (lane == 0) v.inc_stop[w] = lo + stop_at; }
         } else {
         prep(IC<3>{}, n4 - 1, p3, ca);
 #pragma unroll 1
@@ -2496,7 +2557,7 @@ __device__ __forceinline__ void band_solve_body(const View& v, double* __restric
     if (w == 0 && lane == 0) for (int i = (MODE == SOLVE_FULL_BWD ? 6 : 0); i < (MODE == SOLVE_FULL_BWD ? 11 : 16); i++) g_stamps[i] = st[i];
 #endif
     if constexpr (MODE == SOLVE_FULL) { if (lane == 0) v.fail[w] = failed; }
-    else if constexpr (MODE != SOLVE_FULL_BWD) { if (lane == 0 && failed) atomicOr(v.fail + w, 1); }
+    else if constexpr (MODE != SOLVE_FULL_BWD && !INCB) { if (lane == 0 && failed) atomicOr(v.fail + w, 1); }
 }
 
 __global__ void __launch_bounds__(64) k_band_solve(View v) {
@@ -2585,6 +2646,27 @@ __global__ void __launch_bounds__(64) k_band_backward(View v) {
     // the back substitution touches nothing of the trailing window [0, S_GD + 64): its LDS starts at the write sink
     __shared__ double Sb[S_TOTAL - S_DUMP];
     band_solve_body<SOLVE_FULL_BWD>(v, Sb - S_DUMP, nullptr, nullptr, w, threadIdx.x, 0);
+}
+
+// incremental updates (View::inc_*): the suffix of the window from the checkpoint in front of the first changed keyframe
+__global__ void __launch_bounds__(64) k_inc_forward(View v) {
+    const int w = blockIdx.x;
+    const int lo = v.lo[w], hi = v.hi[w];
+    if (hi - lo <= 0) return;
+    const int m = inc_start(v.inc_k[w], lo);
+    if (threadIdx.x == 0) v.inc_from[w] = m < hi ? m : hi;
+    if (m >= hi) { if (threadIdx.x == 0) v.fail[w] = 0; return; }      // nothing changed: the factorisation stands
+    __shared__ double S[S_TOTAL];
+    band_solve_body<SOLVE_INC_FWD>(v, S, nullptr, nullptr, w, threadIdx.x, 0, ChunkGeom{m - lo, 0, 0});
+}
+__global__ void __launch_bounds__(64) k_inc_backward(View v) {
+    const int w = blockIdx.x;
+    const int lo = v.lo[w], hi = v.hi[w];
+    if (hi - lo <= 0) return;
+    const int m = inc_start(v.inc_k[w], lo);
+    if (m >= hi) { if (threadIdx.x == 0) v.inc_stop[w] = hi; return; }
+    __shared__ double Sb[S_TOTAL - S_DUMP];
+    band_solve_body<SOLVE_INC_BWD>(v, Sb - S_DUMP, nullptr, nullptr, w, threadIdx.x, 0, ChunkGeom{0, m - lo, 0});
 }
 
 // two waves per window (see band_solve_body); windows shorter than 32 keyframes are left to wave 0 alone
@@ -3364,6 +3446,63 @@ __global__ void __launch_bounds__(256) k_relinearize(View v, double threshold) {
     for (int a = 0; a < 15; a++) d[a] = 0.0;
 }
 
+// The same for incremental updates (View::inc_*), which also need to know WHERE the first change is: the first slot whose
+// linearisation point moves here, or the first of the `appended` keyframes at the window's end (their factors are new), or
+// the window's first keyframe when the caller says the factorisation is void.  Only keyframes from inc_stop on have an
+// increment that the last back substitution touched.  inc_k is INT_MAX when this runs (k_inc_retract leaves it so).
+__global__ void __launch_bounds__(256) k_inc_begin(View v, double threshold, int appended, int invalid) {
+    const int w = blockIdx.y;
+    const int lo = v.lo[w], hi = v.hi[w];
+    const int from = invalid ? lo : v.inc_stop[w];
+    const int k = (from & ~255) + (int)(blockIdx.x * 256 + threadIdx.x);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicMin(v.inc_k + w, invalid ? lo : (hi - appended > lo ? hi - appended : lo));
+    if (k < lo || k < from || k >= hi) return;
+    const long gk = (long)w * v.M + k;
+    double* d = v.delta + (size_t)gk * 15;
+    double m = 0.0;
+#pragma unroll
+    for (int a = 0; a < 15; a++) m = fmax(m, fabs(d[a]));
+    if (!(m >= threshold)) return;
+    const int b = v.sel[w];
+    const State s = load_state(v, b, gk);
+    State o;
+    Q4 dq;
+    V3 dtv;
+    se3_exp(v3(d[0], d[1], d[2]), v3(d[3], d[4], d[5]), &dq, &dtv);
+    o.q = qnormalize(qmul(s.q, dq));
+    o.t = s.t + mul(qrot(s.q), dtv);
+    o.vel = s.vel + v3(d[6], d[7], d[8]);
+    o.ba = s.ba + v3(d[9], d[10], d[11]);
+    o.bg = s.bg + v3(d[12], d[13], d[14]);
+    store_state(v, b, gk, o);
+#pragma unroll
+    for (int a = 0; a < 15; a++) d[a] = 0.0;
+    atomicMin(v.inc_k + w, k);
+}
+// the estimate theta (+) delta of the keyframes whose increment the back substitution touched, into the trial buffer (k_retract
+// for the rest of the library); the last thing an incremental update does: inc_k is ready for the next one
+__global__ void __launch_bounds__(256) k_inc_retract(View v) {
+    const int w = blockIdx.y;
+    const int lo = v.lo[w], hi = v.hi[w], from = v.inc_stop[w];
+    const int k = (from & ~255) + (int)(blockIdx.x * 256 + threadIdx.x);
+    if (blockIdx.x == 0 && threadIdx.x == 0) v.inc_k[w] = 0x7fffffff;
+    if (k < lo || k < from || k >= hi) return;
+    const long gk = (long)w * v.M + k;
+    const int b = v.sel[w];
+    const State s = load_state(v, b, gk);
+    const double* d = v.delta + (size_t)gk * 15;
+    State o;
+    Q4 dq;
+    V3 dtv;
+    se3_exp(v3(d[0], d[1], d[2]), v3(d[3], d[4], d[5]), &dq, &dtv);
+    o.q = qnormalize(qmul(s.q, dq));
+    o.t = s.t + mul(qrot(s.q), dtv);
+    o.vel = s.vel + v3(d[6], d[7], d[8]);
+    o.ba = s.ba + v3(d[9], d[10], d[11]);
+    o.bg = s.bg + v3(d[12], d[13], d[14]);
+    store_state(v, b ^ 1, gk, o);
+}
+
 // Fixed-lag marginalisation of the oldest keyframe m = lo: the Schur complement of
 // every factor touching m -- its prior or marginal prior, the IMU factor m -> m+1, the between
 // factors starting at m -- taken at the current linearisation (buffer `sel`), onto
@@ -4040,6 +4179,16 @@ void launch_predict(const View& v, int window, int k0, int n, int from_trial, hi
 }
 void launch_relinearize(const View& v, double threshold, hipStream_t s) {
     hipLaunchKernelGGL(k_relinearize, dim3(nblk(v.G, 256)), dim3(256), 0, s, v, threshold);
+}
+void launch_inc_begin(const View& v, double threshold, int appended, int invalid, hipStream_t s) {
+    hipLaunchKernelGGL(k_inc_begin, dim3((unsigned)nblk(v.M, 256), (unsigned)v.B), dim3(256), 0, s, v, threshold, appended, invalid);
+}
+void launch_inc_solve(const View& v, hipStream_t s) {
+    hipLaunchKernelGGL(k_inc_forward, dim3(v.B), dim3(64), 0, s, v);
+    hipLaunchKernelGGL(k_inc_backward, dim3(v.B), dim3(64), 0, s, v);
+}
+void launch_inc_retract(const View& v, hipStream_t s) {
+    hipLaunchKernelGGL(k_inc_retract, dim3((unsigned)nblk(v.M, 256), (unsigned)v.B), dim3(256), 0, s, v);
 }
 void launch_slide(const View& v, const double* sigma15_dev, int reanchor, hipStream_t s) {
     hipLaunchKernelGGL(k_slide, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, sigma15_dev, reanchor);

@@ -220,7 +220,33 @@ struct View {
     double* xl_r0;      // [B][6 x_max]
     double* xl_bx;      // [B][x_max][7] (q w x y z, t)
     double* xl_out;     // [2][B][6 x_max] residual at the states of each buffer
+    // Incremental Gauss-Newton updates (vf_engine_opts.incremental; csrc "suffix re-elimination"): the banded form of what
+    // ISAM2::update does with relinearizeSkip 1 (GraphManager.cpp:37-43,126-127).  The forward sweep is causal in time, so the
+    // panel of a keyframe depends on nothing newer than the factors that touch it: after an update only the keyframes from
+    // the first one whose linearisation point moved, or whose factors changed, are linearised, assembled and eliminated
+    // again; the sweep restarts from a CHECKPOINT of its trailing window -- the partially eliminated 27 x 27 block (+ rhs) of
+    // [k: 15][k+1: pose][k+2: pose] that the elimination of the keyframes in front of k leaves (the sep_out of a chunk sweep) --
+    // kept for every CK-th keyframe slot; and the back substitution stops once three consecutive increments come out as
+    // they were (the wildfire threshold of iSAM2; 0 = to the bit).
+    int inc_on;         // 0: off.  != 0: K1 / K2 / K3 work from inc_k[w] on (0 elsewhere in the library)
+    int inc_prior;      // != 0: the priors are linearised whatever inc_k says (the marginal prior has just changed: a slide)
+    int* inc_k;         // [B] first keyframe slot changed since the factorisation in Lp / ck was made (INT_MAX: none)
+    int* inc_stop;      // [B] slot at which the last back substitution stopped: increments below it are as they were
+    int* inc_from;      // [B] slot at which the last forward sweep started (diagnostics: vf_engine_incremental_info)
+    double* ck;         // [G / CK][CK_SZ] checkpoints (slot k -> entry k / CK of its window, written by every sweep that passes it)
+    double wildfire;    // back substitution: an increment that changes by at most this in every component counts as unchanged
 };
+constexpr int CK_LOG = 3, CK = 1 << CK_LOG;       // a checkpoint every 8 keyframe slots
+constexpr int CK_SZ = 768;                        // 27 x 28 doubles (SEPM), padded
+// first keyframe slot the incremental forward sweep eliminates again, given the first changed slot: a factor reaches three
+// keyframes back (the rows of H from inc_k - 3 on are new), and the checkpoint at m holds the rows m .. m + 2 at their values
+// of then, so m + 2 < inc_k - 3; m on the checkpoint grid; a sweep that would start within the window's first rows (where
+// the prior / the marginal prior sit) starts at the window's first keyframe instead, from nothing
+__host__ __device__ inline int inc_start(int inc_k, int lo) {
+    if (inc_k < lo + 6) return lo;
+    const int m = (inc_k - 6) & ~(CK - 1);
+    return m < lo + 4 ? lo : m;
+}
 
 // Work vectors of the refined solve (vf_refine.hip): conjugate gradients on (J^T J + lambda I) d = -J^T r with the operator
 // applied through J and the engine's Cholesky solve as the preconditioner.  Allocated on first use.
@@ -292,6 +318,11 @@ void launch_partitioned_global(const View& v, hipStream_t s);   // separator cha
 void launch_mask_delta(const View& v, hipStream_t s);           // zero the increments of keyframes this rank does not own
 void launch_predict(const View& v, int window, int k0, int n, int from_trial, hipStream_t s);
 void launch_relinearize(const View& v, double threshold, hipStream_t s);   // reference-compat solves: theta <- theta (+) delta where |delta| >= threshold
+// incremental updates (View::inc_*): relinearise where the pending increment reaches the threshold and note the first slot
+// that changed (with `appended` keyframes new at the window's end; invalid: everything), the suffix solve, the estimate
+void launch_inc_begin(const View& v, double threshold, int appended, int invalid, hipStream_t s);
+void launch_inc_solve(const View& v, hipStream_t s);
+void launch_inc_retract(const View& v, hipStream_t s);
 void launch_slide(const View& v, const double* sigma15_dev, int reanchor, hipStream_t s);
 void launch_marginalize(const View& v, int* status, hipStream_t s);
 void launch_shift_copy(const double* src, double* dst, long n, hipStream_t s);

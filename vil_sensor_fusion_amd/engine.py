@@ -56,6 +56,8 @@ class EngineOpts:
     gauge_floor: float | None = None     # floor of the marginal prior's information about global translation / yaw (None = default 1e-3; 0 = off)
     hybrid_active_list: int | None = None  # hybrid solves: sweeps take their windows from the compacted list of active ones (None = default 1)
     far_batch_columns: int | None = None   # single-window engines: the Woodbury columns of far factors as one batched solve (None = default 1)
+    incremental: int | None = None         # isam_step re-eliminates only from the first keyframe that changed (None = default 0)
+    wildfire: float | None = None          # ... and its back substitution stops once increments change by <= this (None = default 0: bitwise)
     lm_excursion: int | None = None      # non-monotone LM: provisional cost-raising trials per excursion (None = default: 3 on refining engines)
 
 
@@ -82,7 +84,7 @@ class Engine:
             o.solve_assemble_min = opts.solve_assemble_min
         if opts.solve_assemble_waves is not None:
             o.solve_assemble_waves = opts.solve_assemble_waves
-        for name in ("refine_iterations", "refine_min_keyframes", "refine_rel_stop", "lm_excursion", "gauge_floor", "hybrid_active_list", "far_batch_columns"):
+        for name in ("refine_iterations", "refine_min_keyframes", "refine_rel_stop", "lm_excursion", "gauge_floor", "hybrid_active_list", "far_batch_columns", "incremental", "wildfire"):
             if getattr(opts, name) is not None:
                 setattr(o, name, getattr(opts, name))
         self._h = C.c_void_p()
@@ -240,6 +242,13 @@ class Engine:
     def isam_step(self, relin_threshold=1e-4):
         """One reference-compat update (vf_engine_isam_step): get_states = linearisation points, get_estimate = estimate."""
         check(self._l.vf_engine_isam_step(self._h, C.c_double(relin_threshold)))
+
+    def incremental_info(self, window=0):
+        """incremental engines: updates so far, how many of them eliminated the whole window, and for `window` the slot the
+        last forward sweep started at / the last back substitution stopped at"""
+        u, f, a, b = C.c_long(), C.c_long(), C.c_int(), C.c_int()
+        check(self._l.vf_engine_incremental_info(self._h, window, C.byref(u), C.byref(f), C.byref(a), C.byref(b)))
+        return dict(updates=u.value, whole_window_updates=f.value, first_eliminated=a.value, last_substituted=b.value)
 
     def gn_begin(self, relin_threshold=1e-4):
         """the opening of a reference-compat update on its own (time-sharded callers stage the solve themselves)"""

@@ -29,7 +29,7 @@ class GraphManager:
 
     def __init__(self, imu_params=CARLA_IMU, capacity=4096, lag=0, iterations=5, device=0,
                  prior_sigma=None, rel_tol=None, abs_tol=None, reference_compat=False, relin_threshold=None,
-                 cold_start=False, fixed_capacity=False):
+                 cold_start=False, fixed_capacity=False, incremental=False, wildfire=None):
         """iterations: LM trials per solve at most; a solve stops earlier once a trial changes the cost by <= abs_tol or
         <= rel_tol * cost (defaults 1e-5 / 1e-5, gtsam::LevenbergMarquardtParams; 0 / 0: always `iterations` trials)."""
         self._l = _lib.lib()
@@ -51,6 +51,10 @@ class GraphManager:
         o.fixed_capacity = int(bool(fixed_capacity))   # lag = 0: fail with VF_ERR_CAPACITY instead of growing the engine
         if relin_threshold is not None:
             o.relin_threshold = relin_threshold
+        # incremental (with reference_compat): a solve re-eliminates only from the first keyframe that changed (vilfusion.h)
+        o.incremental = int(incremental)          # (2: the incremental kernels over the whole history every time -- what tests compare with)
+        if wildfire is not None:
+            o.wildfire = wildfire
         self._h = C.c_void_p()
         check(self._l.vf_create(C.byref(p), C.byref(o), C.byref(self._h)))
         self._cbs = []
@@ -151,6 +155,13 @@ class GraphManager:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         check(self._l.vf_graph_solver_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def incrementalInfo(self):
+        """incremental handles: updates so far, how many re-eliminated the whole history, the keys the last update's forward
+        sweep started at / its back substitution stopped at"""
+        u, f, a, b = C.c_long(), C.c_long(), C.c_uint64(), C.c_uint64()
+        check(self._l.vf_graph_incremental_info(self._h, C.byref(u), C.byref(f), C.byref(a), C.byref(b)))
+        return dict(updates=u.value, whole_window_updates=f.value, first_eliminated_key=a.value, last_substituted_key=b.value)
 
     def trajectory(self, key0, n):
         s = np.zeros((n, 16))

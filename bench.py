@@ -895,8 +895,8 @@ def main():
             # that are not structurally zero + padding), the residual (15), the between linearisation (78); panel, increment as above
             k4_bytes_per_kf = 8 * (292 + 15 + 78 + 547 + 547 + 15)
             from vil_sensor_fusion_amd import _lib as _vl
-            _o = _vl.EngineOptsC()
-            _vl.lib().vf_engine_default_opts(_vl.C.byref(_o))
+            _o = _vl.EngineTuningC()
+            _vl.lib().vf_engine_default_tuning(_vl.C.byref(_o))
             asm_waves = args.solve_assemble_waves if args.solve_assemble_waves in (1, 2) else (2 if _o.solve_assemble_waves != 1 else 1)
             k4_name = (("k_band_forward_asm2 (two waves per window: eliminator + assembler on one LDS image)" if asm_waves == 2 else "k_band_forward_asm")
                        + " + k_band_backward (K3 + K4 in one pass: block rows of J^T J formed on the matrix cores "

@@ -53,6 +53,10 @@ int vf_device_count(int* count);
 typedef struct vf_engine vf_engine;
 
 typedef struct {
+    uint32_t struct_size;   /* sizeof(vf_engine_opts) in the header the CALLER was compiled against; vf_engine_default_opts sets
+                               it.  The struct only ever grows at its end: a caller built against an older, shorter header is
+                               served with the defaults for the fields it does not know; a size the library does not know
+                               (larger than its own, or 0) is refused with VF_ERR_INVALID */
     int windows;            /* B */
     int capacity;           /* keyframes per window, rounded up to a multiple of 64 */
     int bandwidth;          /* max |a-b| of a between factor, 1..VF_MAX_BANDWIDTH */
@@ -63,19 +67,7 @@ typedef struct {
                                solve (chunks joined by 27-dof separators, about sqrt(n) of them for an
                                n-keyframe window: one-window latency); more windows -> one sweep per window
                                (throughput).  1 = always sweeps.  P >= 2 = partitioned solve with P chunks. */
-    /* Solver-form switches.  vf_engine_default_opts sets the measured optimum; they are fields, not environment variables,
-     * so that the library's behaviour never depends on the caller's environment (tests and tools set them to reach one
-     * form on purpose). */
-    int sweep_two_sided_max; /* whole-window sweeps: up to this many windows, two waves per window eliminate from both ends
-                                (latency); above, one wave per window (throughput).  Default 256; 0 = always one wave. */
-    int hybrid_threshold;    /* with vf_engine_set_convergence on a sweep engine of > 128 windows: once at most this many
-                                windows still take trials, K4 runs as the partitioned form.  Default 256; < 0 = never. */
     int cold_start;          /* != 0: every vf_engine_iterate linearises all factors (no warm start); default 0 */
-    int use_hip_graph;       /* != 0: vf_engine_iterate replays its launch sequence from a captured hipGraph, re-captured whenever
-                                the trial count, the warm-start tail or a scalar baked into the kernel arguments changes
-                                (vf_engine_graph_info counts captures and replays).  Bit-identical to plain launches
-                                (tests/test_gpu_hip_graph.py); measured no faster, the stream never runs empty (bench.py
-                                `single_window.with_hip_graph`); default 0 */
     double accept_rel;       /* an LM trial is accepted iff  new cost < cost + accept_rel * cost.  Default 1e-9: the rounding
                                 floor of the cost of a 1000-pose window (a sum of ~30 000 squared whitened residuals, the IMU
                                 ones scaled by 5e4) is ~1e-10 of its value; with a strict "decreases" test (accept_rel = 0) a
@@ -88,22 +80,6 @@ typedef struct {
                                 minModelFidelity (1e-3), which this library does not evaluate.  Where the optimum is does not
                                 depend on either rule: tests/test_gpu_vs_qr_twin.py holds the result to an independent QR
                                 optimiser that uses the gain-ratio test. */
-    int solve_split_min;     /* whole-window sweeps (one wave per window): from this many windows on, the forward sweep and the
-                                back substitution run as two kernels (same arithmetic, same bits): the back substitution needs
-                                9 KB of LDS instead of 38 and runs several waves per SIMD.  Pays once the batch is a multiple
-                                of the 1024 SIMDs of the part (DESIGN.md 7.11).  Default 2048; 0 = never. */
-    int solve_assemble_min;  /* whole-window sweeps: from this many windows on, the forward sweep forms the block rows of the
-                                normal equations itself, from the Jacobians K1 / K2 leave, and the assembly kernel (K3) is not
-                                launched: H is neither written nor read back (vf_engine_read_normal assembles it on demand).
-                                Same sums in another order: agrees with the two-kernel form to rounding, not to the bit.  Not
-                                used while a window holds far between factors, on sharded engines, or by the partitioned
-                                form; in the hybrid solve (termination rule on) the sweep half uses it and the assembly
-                                kernel runs for the partitioned half only.  Default 768 (below ~500 windows the assembly
-                                kernel's launch is shorter than what the sweep pays, and the sweep pays it for rejected
-                                trials too); 0 = never (DESIGN.md 7.13, 7.15). */
-    int solve_assemble_waves; /* 1: the assembling sweep is one wave per window; 2 (default): two waves per window sharing its
-                                LDS, one eliminating, one assembling the rows -- the same bits, 6-10 % faster; launched in
-                                chunks of 1024 windows, the workgroups the part holds at once (DESIGN.md 7.15) */
     /* Refined solve (DESIGN.md "Refined solve"; csrc/vf_refine.hip).  The reference factorises by QR (GraphManager.cpp:38); the
      * device forms normal equations, whose condition number grows with the FOURTH power of the window length (a chain of
      * combined-IMU factors is a double integrator): ~1e11 at 1000 keyframes, beyond 1e19 at 10 000, where a float64 Cholesky
@@ -149,13 +125,6 @@ typedef struct {
      * information of 0.1 on WHERE the window is -- a 3 m sigma; it constrains nothing the factors can see, and a prior whose
      * gauge information is still above it (the first tens of updates) is not touched, bit for bit.  0 = off. */
     double gauge_floor;
-    int hybrid_active_list;  /* hybrid solves (termination rule on, > 128 windows): the one-wave sweeps take their windows from a compacted
-                                list of those still taking trials, so that the active ones are dispatched first (default 1; 0 = window i
-                                is workgroup i as before; same bits either way) */
-    int far_batch_columns;   /* single-window engines (the GraphManager's) holding far factors: the 6 Woodbury columns per far factor
-                                are solved as ONE batch on a second, internal engine of 48 windows -- a copy of the window's H per
-                                column -- instead of one band solve after the other (default 1; costs that engine's memory, about
-                                20 KB per keyframe slot and column; 0 = sequential columns as on batch engines; same bits) */
     /* Incremental updates: the banded form of what ISAM2::update does with relinearizeThreshold / relinearizeSkip 1
      * (GraphManager.cpp:37-43,126-127).  != 0: vf_engine_isam_step relinearises only the keyframes whose pending increment
      * reaches the threshold, and linearises, assembles and eliminates again only from the first keyframe that moved or whose
@@ -171,18 +140,71 @@ typedef struct {
      * re-estimates tilt and bias for the whole history -- and with the reference's threshold of 1e-4 nine keyframes in ten are
      * relinearised at every update: the suffix IS the window, here as in iSAM2.  The mode pays when the threshold is
      * loose or the graph has stiff odometry; it is off by default. */
+    /* VF_ABI_TAIL: the fields from here to the end of the struct were added after the first sized release (tests/test_abi.py
+     * builds a caller against the struct without them) */
     int incremental;
     double wildfire;         /* incremental updates: an increment that changes by at most this in every component counts as unchanged
                                 (ISAM2Params::wildfireThreshold, 1e-3 in GTSAM); default 0 = bitwise */
 } vf_engine_opts;
+/* Solver-form switches: how the library maps the solve onto the part, not what it computes.  vf_engine_default_tuning sets the
+ * measured optimum and vf_engine_create uses exactly that; a binding of the reference never touches this struct.  They are
+ * fields, not environment variables, so that the library's behaviour never depends on the caller's environment; tests and
+ * tools/ set them (vf_engine_create_tuned) to reach one form on purpose.  Grows at its end only, like vf_engine_opts. */
+typedef struct {
+    uint32_t struct_size;
+    int sweep_two_sided_max; /* whole-window sweeps: up to this many windows, two waves per window eliminate from both ends
+                                (latency); above, one wave per window (throughput).  Default 256; 0 = always one wave. */
+    int hybrid_threshold;    /* with vf_engine_set_convergence on a sweep engine of > 128 windows: once at most this many
+                                windows still take trials, K4 runs as the partitioned form.  Default 256; < 0 = never. */
+    int use_hip_graph;       /* != 0: vf_engine_iterate replays its launch sequence from a captured hipGraph, re-captured whenever
+                                the trial count, the warm-start tail or a scalar baked into the kernel arguments changes
+                                (vf_engine_graph_info counts captures and replays).  Bit-identical to plain launches
+                                (tests/test_gpu_hip_graph.py); measured no faster, the stream never runs empty (bench.py
+                                `single_window.with_hip_graph`); default 0 */
+    int solve_split_min;     /* whole-window sweeps (one wave per window): from this many windows on, the forward sweep and the
+                                back substitution run as two kernels (same arithmetic, same bits): the back substitution needs
+                                9 KB of LDS instead of 38 and runs several waves per SIMD.  Pays once the batch is a multiple
+                                of the 1024 SIMDs of the part (DESIGN.md 7.11).  Default 2048; 0 = never. */
+    int solve_assemble_min;  /* whole-window sweeps: from this many windows on, the forward sweep forms the block rows of the
+                                normal equations itself, from the Jacobians K1 / K2 leave, and the assembly kernel (K3) is not
+                                launched: H is neither written nor read back (vf_engine_read_normal assembles it on demand).
+                                Same sums in another order: agrees with the two-kernel form to rounding, not to the bit.  Not
+                                used while a window holds far between factors, on sharded engines, or by the partitioned
+                                form; in the hybrid solve (termination rule on) the sweep half uses it and the assembly
+                                kernel runs for the partitioned half only.  Default 768 (below ~500 windows the assembly
+                                kernel's launch is shorter than what the sweep pays, and the sweep pays it for rejected
+                                trials too); 0 = never (DESIGN.md 7.13, 7.15). */
+    int solve_assemble_waves; /* 1: the assembling sweep is one wave per window; 2 (default): two waves per window sharing its
+                                LDS, one eliminating, one assembling the rows -- the same bits, 6-10 % faster; launched in
+                                chunks of 1024 windows, the workgroups the part holds at once (DESIGN.md 7.15) */
+    int hybrid_active_list;  /* hybrid solves (termination rule on, > 128 windows): the one-wave sweeps take their windows from a compacted
+                                list of those still taking trials, so that the active ones are dispatched first (default 1; 0 = window i
+                                is workgroup i as before; same bits either way) */
+    int far_batch_columns;   /* single-window engines (the GraphManager's) holding far factors: the 6 Woodbury columns per far factor
+                                are solved as ONE batch on a second, internal engine of 48 windows -- a copy of the window's H per
+                                column -- instead of one band solve after the other (default 1; costs that engine's memory, about
+                                20 KB per keyframe slot and column; 0 = sequential columns as on batch engines; same bits) */
+} vf_engine_tuning;
+
 
 /* incremental engines (vf_engine_opts.incremental): updates made so far by vf_engine_isam_step, how many of them eliminated the
  * whole window (the first, and every one after an entry point the bookkeeping does not follow); for `window`, the keyframe slot
  * the last forward sweep started at and the slot the last back substitution stopped at (-1 on other engines) */
 int vf_engine_incremental_info(vf_engine* e, int window, long* updates, long* whole_window_updates, int* first_eliminated,
                                int* last_substituted);
+/* vf_engine_default_opts(o) fills the sizeof(vf_engine_opts) bytes of the header this translation unit was compiled against (the
+ * macro below hands that size to the library); bindings that mirror the struct by hand (ctypes, cgo, JNI) call the function of the
+ * same name, which fills the library's own size, or vf_engine_default_opts_sized with theirs. */
 void vf_engine_default_opts(vf_engine_opts* o);
+void vf_engine_default_opts_sized(vf_engine_opts* o, uint32_t struct_size);
+void vf_engine_default_tuning(vf_engine_tuning* t);
+void vf_engine_default_tuning_sized(vf_engine_tuning* t, uint32_t struct_size);
+#ifndef VF_NO_SIZED_DEFAULTS
+#define vf_engine_default_opts(o) vf_engine_default_opts_sized((o), (uint32_t)sizeof(vf_engine_opts))
+#define vf_engine_default_tuning(t) vf_engine_default_tuning_sized((t), (uint32_t)sizeof(vf_engine_tuning))
+#endif
 int vf_engine_create(const vf_engine_opts* o, vf_engine** out);
+int vf_engine_create_tuned(const vf_engine_opts* o, const vf_engine_tuning* t, vf_engine** out);   /* t = NULL: the defaults */
 void vf_engine_destroy(vf_engine* e);
 
 /* host -> device staging (each converts AoS records to the AoSoA device layout) */
@@ -471,6 +493,7 @@ int vf_dopt_filter_f32(const float* hessians36, int count, float rot_thr, float 
 typedef struct vf_graph vf_graph;
 
 typedef struct {
+    uint32_t struct_size; /* sizeof(vf_graph_opts) in the caller's header (vf_graph_default_opts sets it); same rule as vf_engine_opts */
     int capacity;    /* keyframe slots on the device (keys 0..capacity-1), rounded up to a multiple of 64 by vf_create (the
                         engine allocates whole tiles); with lag = 0 the INITIAL number: vf_solve doubles it whenever the
                         history outgrows it (vf_engine_grow), unless fixed_capacity != 0 */
@@ -492,6 +515,7 @@ typedef struct {
     double relin_threshold;
     /* incremental != 0 (with reference_compat): the update is done incrementally (vf_engine_opts.incremental -- read its
      * MEASURED note -- and .wildfire): a vf_solve costs what the keyframes it touches cost.  Default 0. */
+    /* VF_ABI_TAIL: as in vf_engine_opts */
     int incremental;
     double wildfire;
 } vf_graph_opts;
@@ -502,6 +526,10 @@ typedef void (*vf_callback)(void* user, double time, const double q[4], const do
                             const double v[3], const double bias[6]);
 
 void vf_graph_default_opts(vf_graph_opts* o);
+void vf_graph_default_opts_sized(vf_graph_opts* o, uint32_t struct_size);
+#ifndef VF_NO_SIZED_DEFAULTS
+#define vf_graph_default_opts(o) vf_graph_default_opts_sized((o), (uint32_t)sizeof(vf_graph_opts))
+#endif
 /* GraphManager::GraphManager(imuManager) + IMUManager::IMUManager(params) + getImuParams
  * (GraphManager.cpp:15-44, IMUManager.cpp:13-17, ImuManagerRos.cpp:14-36) */
 int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** out);
@@ -540,6 +568,15 @@ int vf_set_callback(vf_graph* g, vf_callback cb, void* user);
 /* GraphManager::graph()->size(): factors staged since the last solve (3 priors at start +
  * between factors; IMU factors wait in the queue, GraphManager.cpp:66,150) and the queue length */
 int vf_graph_staged(vf_graph* g, int* staged_factors, int* queued_imu_factors);
+/* GraphManager::graph() (GraphManager.h:42, GraphManager.cpp:46-49), by index 0 .. staged_factors - 1: what the reference's tests
+ * read from the staged NonlinearFactorGraph (test/UnitTests.cpp:200,222-233: its size, a factor's keys, measured()).
+ * kind 0 / 1 / 2: PriorFactor<Pose3> on X(0) (q, t = its mean, cov36 = diag sigma^2 in [rot, trans] order), PriorFactor<Vector3>
+ * on V(0) (t = mean, top-left 3 x 3 of cov36), PriorFactor<ConstantBias> on B(0) (t = accelerometer part, q[1..3] = gyro part,
+ * q[0] = 0; cov36 6 x 6) -- all three on key1 = key2 = 0, present until the first solve takes them.  kind 3: BetweenFactor<Pose3>
+ * X(key1) -> X(key2), measured() = (q, t) with q normalised as gtsam::Rot3(w, x, y, z) does, cov36 as handed in.  Any output
+ * pointer may be null.  VF_ERR_BAD_KEY beyond the end. */
+int vf_graph_get_staged(vf_graph* g, int index, int* kind, uint64_t* key1, uint64_t* key2, double q[4], double t[3],
+                        double cov36[36]);
 /* diagnostics (extra): cost after the last solve and the LM trials accepted / rejected / failed (normal equations not
  * positive definite) over the life of the handle */
 int vf_graph_lm_stats(vf_graph* g, double* cost, int* accepted, int* rejected, int* solve_failures);

@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 
+#define VF_NO_SIZED_DEFAULTS      /* this file DEFINES the functions the header's macros of the same name would shadow */
 #include "../../include/vilfusion.h"
 
 // (the far list is kept the way the real engine keeps it: replaced by vf_engine_set_extra_between, transported to the next
@@ -21,7 +22,8 @@ std::atomic<int> fake_band_n{-1}, fake_extra_n{-1}, fake_extra_calls{0}, fake_ex
 extern "C" {
 const char* vf_last_error(void) { return g_err.c_str(); }
 void vf_set_last_error_(const char* m) { g_err = m ? m : ""; }
-void vf_engine_default_opts(vf_engine_opts* o) { memset(o, 0, sizeof(*o)); o->windows = 1; o->capacity = 1088; o->bandwidth = 3; }
+void vf_engine_default_opts(vf_engine_opts* o) { memset(o, 0, sizeof(*o)); o->struct_size = (uint32_t)sizeof(*o); o->windows = 1; o->capacity = 1088; o->bandwidth = 3; }
+int vf_engine_incremental_info(vf_engine*, int, long* u, long* f, int* a, int* b) { if (u) *u = 0; if (f) *f = 0; if (a) *a = -1; if (b) *b = -1; return VF_OK; }
 int vf_engine_create(const vf_engine_opts*, vf_engine** out) { *out = new vf_engine(); return VF_OK; }
 void vf_engine_destroy(vf_engine* e) { delete e; }
 int vf_engine_set_states(vf_engine*, int, int, int, const double*) { return VF_OK; }

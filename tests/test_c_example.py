@@ -41,6 +41,20 @@ def test_c_example_runs_on_the_gpu(tmp_path):
     assert "20 keyframes, 20 callbacks" in p.stdout
 
 
+@pytest.mark.gpu
+def test_c_example_built_against_the_shorter_structs_runs_on_the_gpu(tmp_path):
+    """examples/minimal.c compiled against include/vilfusion.h WITHOUT the fields behind the VF_ABI_TAIL markers (a binding built
+    against an older release): struct_size tells the library how much of vf_graph_opts the caller knows, the rest gets defaults"""
+    from tests.test_abi import _truncated_header
+    exe = str(tmp_path / "minimal_old")
+    libdir = os.path.join(ROOT, "vil_sensor_fusion_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", _truncated_header(tmp_path), os.path.join(ROOT, "examples", "minimal.c"),
+                           "-L", libdir, "-lvilfusion", f"-Wl,-rpath,{libdir}", "-lm", "-o", exe])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    assert "20 keyframes, 20 callbacks" in p.stdout
+
+
 def _build_sharded(tmp_path):
     import __graft_entry__ as g
     from vil_sensor_fusion_amd import _lib

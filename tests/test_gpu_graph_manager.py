@@ -58,6 +58,47 @@ def test_kat_imu_manager_test1():
     np.testing.assert_allclose(rec[4:7], 0.0011875, rtol=1e-13)
 
 
+def test_kat_sensor_manager_test1_through_the_c_abi():
+    """UnitTests.cpp:159-234 against libvilfusion.so itself: graph()->nrFactors() 3 -> 4, the staged factor's
+    keys X(1) -> X(2), measured() = (1, 1, 1), read back through vf_graph_get_staged; and the three priors in front of it."""
+    from vil_sensor_fusion_amd import VilFusionError
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    from vil_sensor_fusion_amd.sensor_manager import Odometry, SensorManager
+    gm = GraphManager(capacity=64)
+    for i in range(0, 140):                                   # IMU at 200 Hz from t = 0 (reserveNode cuts its factors from it)
+        gm.addIMUMeasurement(i * 0.005, [0.0, 0.0, 9.81], [0.0, 0.0, 0.0])
+    sm = SensorManager(gm, optimize_after_odom=False, covariance_linear=0.1, covariance_angular=0.01, max_time_skip=1.0)
+    assert sm.sensorCallback(0.0) is None
+    sm.odometryCallback(Odometry(0.0, [0, 0, 0], [1, 0, 0, 0]))
+    assert gm.graphSize() == 3                                # :200
+    # (the sequence that produces the stale test's expectations under the current reference code: tests/test_sensor_manager.py)
+    sm.sensorCallback(0.25)
+    sm.odometryCallback(Odometry(0.25, [0, 0, 0], [1, 0, 0, 0]))
+    assert gm.graphSize() == 3
+    sm.sensorCallback(0.5)
+    sm.odometryCallback(Odometry(0.5, [1, 1, 1], [0.5, 0.5, 0.5, 0.5]))
+    assert gm.graphSize() == 4                                # :222
+    assert gm.getMostRecentPoseTime() == (0.5, 2)             # :224-226
+    g = gm.graph()
+    assert [f["kind"] for f in g] == ["prior_pose", "prior_velocity", "prior_bias", "between"]     # GraphManager.cpp:33-35, then :86-87
+    f = g[3]                                                  # graph()->at(3), :228
+    assert f["keys"] == (1, 2)                                # :229-230
+    np.testing.assert_array_equal(f["measured"][1], [1.0, 1.0, 1.0])      # :231-233 (EXPECT_DOUBLE_EQ)
+    np.testing.assert_allclose(f["measured"][0], [0.5, 0.5, 0.5, 0.5], atol=1e-15)
+    np.testing.assert_allclose(np.diag(f["covariance"]), [0.1, 0.1, 0.1, 0.01, 0.01, 0.01])   # SensorManagerRos.cpp:91-97
+    np.testing.assert_allclose(np.sqrt(np.diag(g[0]["covariance"])), [1e-6] * 3 + [5e-5] * 3)  # GraphManager.cpp:27-28
+    np.testing.assert_allclose(np.sqrt(np.diag(g[1]["covariance"])[:3]), [1e-5] * 3)           # :30
+    np.testing.assert_allclose(np.sqrt(np.diag(g[2]["covariance"])), [1e-7] * 6)               # :31
+    assert g[0]["keys"] == (0, 0) and np.array_equal(g[0]["measured"][0], [1, 0, 0, 0])
+    with pytest.raises(VilFusionError):
+        gm._l.vf_graph_get_staged  # noqa: B018 (the symbol exists)
+        from vil_sensor_fusion_amd._lib import check
+        check(gm._l.vf_graph_get_staged(gm._h, 4, None, None, None, None, None, None))
+    gm.solve()                                                # _graph->resize(0), GraphManager.cpp:114
+    assert gm.graphSize() == 0 and gm.graph() == []
+    gm.close()
+
+
 def _drive(gm_factory, oracle, seq, solve_every=10):
     """Feed a synthetic sequence through the GraphManager API as the ROS node would."""
     from vil_sensor_fusion_amd.sensor_manager import Odometry, SensorManager
@@ -297,6 +338,9 @@ def test_failed_solve_gives_its_factors_back():
         gm.solve()
     assert ei.value.code == -6
     assert (gm.graphSize(), gm.imuQueueSize()) == (staged, queued)
+    g = gm.graph()
+    assert len(g) == staged and [f["kind"] for f in g[:3]] == ["prior_pose", "prior_velocity", "prior_bias"]
+    assert all(f["kind"] == "between" for f in g[3:]) and [f["keys"][1] for f in g[3:]] == sorted(f["keys"][1] for f in g[3:])
     gm.close()
     # late odometry: a between factor from a keyframe the window has already dropped
     gm = GraphManager(capacity=128, lag=8, iterations=3)
@@ -314,6 +358,7 @@ def test_failed_solve_gives_its_factors_back():
         gm.solve()
     assert ei.value.code == -2 and "dropped" in str(ei.value)
     assert gm.graphSize() == 1                         # the good factor is still staged
+    assert [(f["kind"], f["keys"]) for f in gm.graph()] == [("between", (27, 29))]     # ... and graph() shows it, not the dropped one
     gm.solve()
     assert gm.graphSize() == 0
     (q, tt), v, b = gm.getState()

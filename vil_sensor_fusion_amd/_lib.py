@@ -19,14 +19,21 @@ def lib_path() -> str:
 
 
 class EngineOptsC(C.Structure):
-    _fields_ = [("windows", C.c_int), ("capacity", C.c_int), ("bandwidth", C.c_int),
+    _fields_ = [("struct_size", C.c_uint32), ("windows", C.c_int), ("capacity", C.c_int), ("bandwidth", C.c_int),
                 ("device", C.c_int), ("gravity", C.c_double * 3),
                 ("lambda0", C.c_double), ("lambda_up", C.c_double), ("lambda_down", C.c_double),
                 ("lambda_min", C.c_double), ("lambda_max", C.c_double), ("chunks", C.c_int),
-                ("sweep_two_sided_max", C.c_int), ("hybrid_threshold", C.c_int), ("cold_start", C.c_int),
-                ("use_hip_graph", C.c_int), ("accept_rel", C.c_double), ("solve_split_min", C.c_int), ("solve_assemble_min", C.c_int), ("solve_assemble_waves", C.c_int),
-                ("refine_iterations", C.c_int), ("refine_min_keyframes", C.c_int), ("refine_rel_stop", C.c_double), ("lm_excursion", C.c_int), ("gauge_floor", C.c_double), ("hybrid_active_list", C.c_int), ("far_batch_columns", C.c_int),
+                ("cold_start", C.c_int), ("accept_rel", C.c_double),
+                ("refine_iterations", C.c_int), ("refine_min_keyframes", C.c_int), ("refine_rel_stop", C.c_double),
+                ("lm_excursion", C.c_int), ("gauge_floor", C.c_double),
                 ("incremental", C.c_int), ("wildfire", C.c_double)]
+
+
+class EngineTuningC(C.Structure):
+    """solver-form switches (include/vilfusion.h vf_engine_tuning): what tests and tools set to reach one form on purpose"""
+    _fields_ = [("struct_size", C.c_uint32), ("sweep_two_sided_max", C.c_int), ("hybrid_threshold", C.c_int), ("use_hip_graph", C.c_int),
+                ("solve_split_min", C.c_int), ("solve_assemble_min", C.c_int), ("solve_assemble_waves", C.c_int),
+                ("hybrid_active_list", C.c_int), ("far_batch_columns", C.c_int)]
 
 
 class ImuParamsC(C.Structure):
@@ -42,7 +49,7 @@ class ShardInfoC(C.Structure):
 
 
 class GraphOptsC(C.Structure):
-    _fields_ = [("capacity", C.c_int), ("lag", C.c_int), ("iterations", C.c_int), ("device", C.c_int),
+    _fields_ = [("struct_size", C.c_uint32), ("capacity", C.c_int), ("lag", C.c_int), ("iterations", C.c_int), ("device", C.c_int),
                 ("prior_sigma", C.c_double * 15), ("rel_tol", C.c_double), ("abs_tol", C.c_double),
                 ("cold_start", C.c_int), ("fixed_capacity", C.c_int), ("reference_compat", C.c_int),
                 ("relin_threshold", C.c_double), ("incremental", C.c_int), ("wildfire", C.c_double)]
@@ -56,7 +63,8 @@ _lib = None
 # every symbol include/vilfusion.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "vf_last_error", "vf_version", "vf_device_count",
-    "vf_engine_default_opts", "vf_engine_create", "vf_engine_destroy",
+    "vf_engine_default_opts", "vf_engine_default_opts_sized", "vf_engine_default_tuning", "vf_engine_default_tuning_sized",
+    "vf_engine_create", "vf_engine_create_tuned", "vf_engine_destroy",
     "vf_engine_set_range", "vf_engine_set_states", "vf_engine_get_states", "vf_engine_set_imu",
     "vf_engine_set_between", "vf_engine_clear_between", "vf_engine_set_extra_between", "vf_engine_get_extra_between", "vf_engine_get_linear_far", "vf_engine_set_prior",
     "vf_engine_linearize", "vf_engine_assemble", "vf_engine_solve", "vf_engine_retract",
@@ -73,10 +81,10 @@ SYMBOLS = [
     "vf_engine_gn_begin", "vf_shard_iterate", "vf_shard_gn_step", "vf_shard_exchange_plan", "vf_engine_read_excursions", "vf_engine_close_excursions",
     "vf_chunk_geometry", "vf_shard_range", "vf_engine_set_convergence",
     "vf_engine_isam_step", "vf_engine_predict_from_estimate", "vf_engine_get_estimate", "vf_engine_incremental_info",
-    "vf_graph_default_opts", "vf_create", "vf_destroy", "vf_add_imu", "vf_reserve_node",
+    "vf_graph_default_opts", "vf_graph_default_opts_sized", "vf_create", "vf_destroy", "vf_add_imu", "vf_reserve_node",
     "vf_add_between", "vf_solve", "vf_get_state", "vf_get_bias", "vf_most_recent_pose_time",
     "vf_set_callback", "vf_graph_staged", "vf_get_trajectory", "vf_get_imu_factor",
-    "vf_add_imu_factor", "vf_get_most_recent_estimate", "vf_graph_lm_stats", "vf_graph_solver_info", "vf_set_initial_state", "vf_graph_incremental_info",
+    "vf_add_imu_factor", "vf_get_most_recent_estimate", "vf_graph_lm_stats", "vf_graph_solver_info", "vf_set_initial_state", "vf_graph_incremental_info", "vf_graph_get_staged",
     "vf_degeneracy_batch", "vf_dopt_filter_f32",
 ]
 
@@ -92,6 +100,10 @@ def lib():
         l.vf_version.restype = C.c_char_p
         l.vf_engine_destroy.restype = None
         l.vf_engine_default_opts.restype = None
+        l.vf_engine_default_tuning.restype = None
+        l.vf_engine_default_opts_sized.restype = None
+        l.vf_engine_default_tuning_sized.restype = None
+        l.vf_graph_default_opts_sized.restype = None
         l.vf_graph_default_opts.restype = None
         l.vf_destroy.restype = None
         _lib = l

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -53,6 +54,7 @@ struct DeviceGuard {
 struct vf_engine {
     vf::View v{};
     vf_engine_opts opts{};
+    vf_engine_tuning tune{};
     hipStream_t stream = nullptr;
     bool own_stream = true;   // false once the caller has handed in its own stream (vf_engine_set_stream)
     // vf_engine_opts.use_hip_graph: vf_engine_iterate replays its launch sequence (6 + 9 K kernels / memsets) from a captured
@@ -301,9 +303,11 @@ int vf_device_count(int* count) {
     return VF_OK;
 }
 
-void vf_engine_default_opts(vf_engine_opts* o) {
-    if (!o) return;
+#undef vf_engine_default_opts
+#undef vf_engine_default_tuning
+static void engine_defaults(vf_engine_opts* o) {
     memset(o, 0, sizeof(*o));
+    o->struct_size = (uint32_t)sizeof(*o);
     o->windows = 1;
     o->capacity = 1088;
     o->bandwidth = 3;
@@ -313,27 +317,70 @@ void vf_engine_default_opts(vf_engine_opts* o) {
     // GraphManager.cpp:128-129): lambdaInitial 1e-5, lambdaFactor 10
     o->lambda0 = 1e-5; o->lambda_up = 10.0; o->lambda_down = 10.0;
     o->lambda_min = 1e-12; o->lambda_max = 1e10;
-    o->sweep_two_sided_max = 256;
-    o->hybrid_threshold = 256;   // partitioned form: 0.0095 ms per window; the sweep: 2.9 ms whatever their number
     o->cold_start = 0;
-    o->use_hip_graph = 0;
     o->accept_rel = 1e-9;
-    o->solve_split_min = 2048;
-    o->solve_assemble_min = 768;
-    o->solve_assemble_waves = 2;
     o->refine_iterations = -1;       // auto: windows longer than refine_min_keyframes
     o->refine_min_keyframes = 1536;
     o->refine_rel_stop = 1e-8;
     o->lm_excursion = -1;            // auto: 3 on engines that refine, classical LM otherwise
     o->gauge_floor = 3e-4;
-    o->hybrid_active_list = 1;
-    o->far_batch_columns = 1;
     o->incremental = 0;
     o->wildfire = 0.0;
 }
+static void tuning_defaults(vf_engine_tuning* t) {
+    memset(t, 0, sizeof(*t));
+    t->struct_size = (uint32_t)sizeof(*t);
+    t->sweep_two_sided_max = 256;
+    t->hybrid_threshold = 256;   // partitioned form: 0.0095 ms per window; the sweep: 2.9 ms whatever their number
+    t->use_hip_graph = 0;
+    t->solve_split_min = 2048;
+    t->solve_assemble_min = 768;
+    t->solve_assemble_waves = 2;
+    t->hybrid_active_list = 1;
+    t->far_batch_columns = 1;
+}
+// The caller's struct may be shorter than the library's (built against an older header): only its own bytes are written, and
+// struct_size says how many those are.  A struct the library does not know (longer than its own) gets the bytes it does know.
+void vf_engine_default_opts_sized(vf_engine_opts* o, uint32_t struct_size) {
+    if (!o || struct_size < sizeof(uint32_t)) return;
+    vf_engine_opts full;
+    engine_defaults(&full);
+    const uint32_t n = struct_size < sizeof(full) ? struct_size : (uint32_t)sizeof(full);
+    memcpy(o, &full, n);
+    o->struct_size = n;
+}
+void vf_engine_default_opts(vf_engine_opts* o) { vf_engine_default_opts_sized(o, (uint32_t)sizeof(vf_engine_opts)); }
+void vf_engine_default_tuning_sized(vf_engine_tuning* t, uint32_t struct_size) {
+    if (!t || struct_size < sizeof(uint32_t)) return;
+    vf_engine_tuning full;
+    tuning_defaults(&full);
+    const uint32_t n = struct_size < sizeof(full) ? struct_size : (uint32_t)sizeof(full);
+    memcpy(t, &full, n);
+    t->struct_size = n;
+}
+void vf_engine_default_tuning(vf_engine_tuning* t) { vf_engine_default_tuning_sized(t, (uint32_t)sizeof(vf_engine_tuning)); }
 
-int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
-    if (!o || !out) return fail(VF_ERR_INVALID, "null argument");
+int vf_engine_create(const vf_engine_opts* o, vf_engine** out) { return vf_engine_create_tuned(o, nullptr, out); }
+int vf_engine_create_tuned(const vf_engine_opts* o_in, const vf_engine_tuning* t_in, vf_engine** out) {
+    if (!o_in || !out) return fail(VF_ERR_INVALID, "null argument");
+    // the structs as THIS library knows them: the caller's bytes over the defaults
+    vf_engine_opts o_full;
+    vf_engine_tuning t_full;
+    engine_defaults(&o_full);
+    tuning_defaults(&t_full);
+    if (o_in->struct_size < 8 || o_in->struct_size > sizeof(o_full))
+        return fail(VF_ERR_INVALID, "vf_engine_opts.struct_size = %u: this library knows sizes up to %zu (fill the struct with vf_engine_default_opts; "
+                    "a caller built against a newer header needs a newer library)", o_in->struct_size, sizeof(o_full));
+    memcpy(&o_full, o_in, o_in->struct_size);
+    o_full.struct_size = (uint32_t)sizeof(o_full);
+    if (t_in) {
+        if (t_in->struct_size < 8 || t_in->struct_size > sizeof(t_full))
+            return fail(VF_ERR_INVALID, "vf_engine_tuning.struct_size = %u: this library knows sizes up to %zu", t_in->struct_size, sizeof(t_full));
+        memcpy(&t_full, t_in, t_in->struct_size);
+        t_full.struct_size = (uint32_t)sizeof(t_full);
+    }
+    const vf_engine_opts* o = &o_full;
+    const vf_engine_tuning* t = &t_full;
     if (o->windows < 1 || o->capacity < 2) return fail(VF_ERR_INVALID, "windows >= 1 and capacity >= 2 required");
     if (o->bandwidth < 1 || o->bandwidth > VF_MAX_BANDWIDTH)
         return fail(VF_ERR_INVALID, "bandwidth must be in 1..%d", VF_MAX_BANDWIDTH);
@@ -350,6 +397,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     HIPCHK(hipSetDevice(o->device));
     vf_engine* e = new vf_engine();
     e->opts = *o;
+    e->tune = *t;
     vf::View& v = e->v;
     v.B = o->windows;
     v.M = (o->capacity + 63) / 64 * 64;
@@ -357,9 +405,9 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     for (int i = 0; i < 3; i++) v.grav[i] = o->gravity[i];
     v.lam_up = o->lambda_up; v.lam_down = o->lambda_down; v.lam_min = o->lambda_min; v.lam_max = o->lambda_max;
     v.accept_rel = o->accept_rel;
-    v.split_min = o->solve_split_min > 0 ? o->solve_split_min : 0;
-    v.asm_min = o->solve_assemble_min > 0 ? o->solve_assemble_min : 0;
-    v.asm_waves = o->solve_assemble_waves == 1 ? 1 : 2;
+    v.split_min = t->solve_split_min > 0 ? t->solve_split_min : 0;
+    v.asm_min = t->solve_assemble_min > 0 ? t->solve_assemble_min : 0;
+    v.asm_waves = t->solve_assemble_waves == 1 ? 1 : 2;
     HIPCHK(hipStreamCreate(&e->stream));
     HIPCHK(hipEventCreate(&e->ev0));
     HIPCHK(hipEventCreate(&e->ev1));
@@ -416,14 +464,14 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     AL(v.done, (size_t)v.B);
     AL(v.n_active, 4);
     v.gate = 0;
-    v.gate_T = o->hybrid_threshold;
-    v.tw_max = o->sweep_two_sided_max;
+    v.gate_T = t->hybrid_threshold;
+    v.tw_max = t->sweep_two_sided_max;
     v.stop_on = 0;
     v.rel_tol = v.abs_tol = 0.0;
     v.sh_r = 0;
     v.sh_G = 1;
     v.gauge_floor = o->gauge_floor;
-    v.sh_all_jac = o->refine_iterations != 0 ? 1 : 0;   // (the refined solve applies J on whole increments: every rank keeps every Jacobian)
+    v.sh_all_jac = 0;         // set at every linearisation: 1 while the engine refines (the refined solve applies J on whole increments)
     v.wildfire = o->wildfire >= 0.0 ? o->wildfire : 0.0;
     if (o->incremental) {
         AL(v.inc_k, (size_t)v.B);
@@ -444,7 +492,7 @@ int vf_engine_create(const vf_engine_opts* o, vf_engine** out) {
     // measured on MI355X (ROCm 7.0, one 1000-pose window, K = 5): 2.99 ms replayed from the graph vs 2.91 ms
     // with plain asynchronous launches -- the queue is never empty, so there is no launch gap to remove.
     // Hence opt-in only.
-    e->graph_off = o->use_hip_graph == 0;
+    e->graph_off = t->use_hip_graph == 0;
     e->no_warm = o->cold_start != 0;
     HIPCHK(hipStreamSynchronize(e->stream));
     e->h_lo.assign(v.B, 0);
@@ -646,13 +694,15 @@ int vf_engine_set_extra_between(vf_engine* e, int window, int n, const int32_t* 
         if ((rc = e->ensure_far(need))) return rc;
     }
     e->attach_far();
-    if (n > 0 && !e->far_columns && !e->is_far_columns && B == 1 && e->v.P >= 2 && e->opts.far_batch_columns) {
+    if (n > 0 && !e->far_columns && !e->is_far_columns && B == 1 && e->v.P >= 2 && e->tune.far_batch_columns) {
         vf_engine_opts co = e->opts;
         co.windows = 6 * VF_MAX_EXTRA;
         co.capacity = M;
-        co.use_hip_graph = 0;
+        co.incremental = 0;
+        vf_engine_tuning ct = e->tune;
+        ct.use_hip_graph = 0;
         vf_engine* c = nullptr;
-        if (vf_engine_create(&co, &c) == VF_OK) {
+        if (vf_engine_create_tuned(&co, &ct, &c) == VF_OK) {
             c->is_far_columns = true;
             if (c->v.P == e->v.P && c->v.P_fit == e->v.P_fit && vf_engine_set_stream(c, (void*)e->stream) == VF_OK) e->far_columns = c;
             else vf_engine_destroy(c);
@@ -827,6 +877,10 @@ int vf_engine_linearize(vf_engine* e, int which) {
     if (e) cold(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     which = which ? 1 : 0;
+    // time-sharded ranks write the Jacobian of every factor only while the solve is refined (windows longer than
+    // refine_min_keyframes, or refine_iterations > 0): otherwise each writes what feeds its own rows, and K1's traffic shrinks
+    // with the world size
+    e->v.sh_all_jac = e->refine_iters() > 0 ? 1 : 0;
     // a new linearisation of the CURRENT states invalidates H, g and starts a new solve (no window is converged yet)
     if (!which) {
         HIPCHK(hipMemsetAsync(e->v.fresh, 0x01, e->v.B * sizeof(int), e->stream));
@@ -889,6 +943,7 @@ int vf_engine_solve(vf_engine* e) {
             vf::View p = e->partitioned_view();
             p.gvec = gvec;
             p.delta = delta;
+            if (skip) { p.stop_on = 1; p.done = const_cast<int*>(skip); }     // (the partitioned half skips the same windows)
             a.act = e->act_list;
             vf::launch_band_solve_hybrid(a, p, e->stream);
         } else vf::launch_band_solve(a, e->stream);
@@ -941,7 +996,9 @@ int vf_engine_solve(vf_engine* e) {
             // How many corrections a window needs grows with its length (4 at 1 600 keyframes, 12 at 10 000): after the
             // 4th, 6th, ... the stop flags are read back, and once every window has stopped the rest are not issued
             // (a skipped correction is ~15 empty launches; the read-back costs one stream synchronisation)
-            if (it >= 3 && it % 2 == 1 && it + 1 < R) {
+            hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(e->stream, &capturing);      // (a caller capturing its own stream: no read-back, every correction is issued)
+            if (it >= 3 && it % 2 == 1 && it + 1 < R && capturing == hipStreamCaptureStatusNone) {
                 HIPCHK(hipMemcpyAsync(e->rq_stop_host, e->rq.stop, e->v.B * sizeof(int), hipMemcpyDeviceToHost, e->stream));
                 HIPCHK(hipStreamSynchronize(e->stream));
                 bool live = false;
@@ -1211,7 +1268,8 @@ int vf_engine_shard_info(vf_engine* e, vf_shard_info* out) {
     out->sep = e->v.sepR;
     out->sep_per_chunk = (long)e->v.B * vf::SEPK;
     out->delta = e->v.delta; out->delta_count = e->v.G * 15 + e->v.B;
-    if (e->opts.refine_iterations != 0) {
+    // (the refinement's work vectors only for engines that refine as their windows stand NOW: ask again after loading longer ones)
+    if (e->refine_iters() > 0) {
         if (int rc = e->ensure_refine()) return rc;
         HIPCHK(hipStreamSynchronize(e->stream));
         out->refine_delta = e->rq.z;
@@ -1270,9 +1328,11 @@ struct Rccl {
 };
 Rccl g_rccl;
 constexpr int RCCL_FLOAT64 = 8, RCCL_SUM = 0;      // ncclFloat64, ncclSum (rccl.h)
+std::once_flag g_rccl_once;
+std::string g_rccl_why;
 int rccl_load() {
-    if (g_rccl.all_gather) return VF_OK;
-    if (!g_rccl.tried) {
+    // (two engines on two threads may ask at once: the library is opened by one of them)
+    std::call_once(g_rccl_once, [] {
         g_rccl.tried = true;
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             g_rccl.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -1283,11 +1343,13 @@ int rccl_load() {
             g_rccl.all_reduce = (rccl_all_reduce_t)dlsym(g_rccl.handle, "ncclAllReduce");
             g_rccl.error_string = (rccl_error_string_t)dlsym(g_rccl.handle, "ncclGetErrorString");
         }
-    }
-    if (!g_rccl.all_gather || !g_rccl.all_reduce) {
-        const char* why = dlerror();          // (a second call would return null: the message is consumed by the first)
-        return fail(VF_ERR_DEVICE, "librccl not found (dlopen librccl.so.1): %s", why ? why : "symbols missing");
-    }
+        if (!g_rccl.all_gather || !g_rccl.all_reduce) {
+            const char* why = dlerror();
+            g_rccl_why = why ? why : "symbols missing";
+        }
+    });
+    if (!g_rccl.all_gather || !g_rccl.all_reduce)
+        return fail(VF_ERR_DEVICE, "librccl not found (dlopen librccl.so.1): %s", g_rccl_why.c_str());
     return VF_OK;
 }
 int rccl_check(int rc, const char* what) {
@@ -1371,14 +1433,14 @@ int vf_engine_set_convergence(vf_engine* e, double rel_tol, double abs_tol) {
     e->v.stop_on = (rel_tol > 0.0 || abs_tol > 0.0) ? 1 : 0;
     e->epoch++;
     // sweep engines (large batches): once few windows are left taking trials, K4 switches to the partitioned form
-    if (e->v.stop_on && e->v.P == 0 && e->v.B > 128 && !e->hybrid && e->opts.hybrid_threshold >= 0) {
+    if (e->v.stop_on && e->v.P == 0 && e->v.B > 128 && !e->hybrid && e->tune.hybrid_threshold >= 0) {
         vf::View& v = e->v;
         e->hybrid_P = vf::chunk_count(v.M, 96, 1);
         if (e->hybrid_P >= 2) {
             const size_t BP = (size_t)v.B * e->hybrid_P;
             int rc;
             if ((rc = e->alloc(&e->h_Vp, (size_t)v.G * vf::VROW)) || (rc = e->alloc(&e->h_sep, BP * vf::SEPK)) ||
-                (rc = e->alloc(&e->h_sepL, BP * vf::SEPL)) || (e->opts.hybrid_active_list && (rc = e->alloc(&e->act_list, (size_t)v.B)))) return rc;
+                (rc = e->alloc(&e->h_sepL, BP * vf::SEPL)) || (e->tune.hybrid_active_list && (rc = e->alloc(&e->act_list, (size_t)v.B)))) return rc;
             e->hybrid = true;
         }
     }
@@ -1810,7 +1872,7 @@ int vf_engine_grow(vf_engine* e, int new_capacity) {
     vf_engine_opts o = e->opts;
     o.capacity = M1;
     vf_engine* n = nullptr;
-    int rc = vf_engine_create(&o, &n);
+    int rc = vf_engine_create_tuned(&o, &e->tune, &n);
     if (rc) return rc;
     const vf::View &a = e->v, &b = n->v;
     const int B = a.B;
@@ -1875,6 +1937,28 @@ int vf_engine_grow(vf_engine* e, int new_capacity) {
             }
         n->recount_far();
     }
+    // what the solver remembers from solve to solve: the non-monotone rule's damping / excursion state (a whole-history handle
+    // grows again and again: each solve after a grow would otherwise restart from lambda0) and the far factors' counters
+    if (e->v.x_best) {
+        if ((rc = n->ensure_excursion())) { vf_engine_destroy(n); return rc; }
+        hipError_t he = hipSuccess;
+        auto cpx = [&](void* dst, const void* src, size_t bytes) { if (he == hipSuccess) he = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, n->stream); };
+        cpx(n->v.carry, e->v.carry, B * sizeof(int));
+        cpx(n->v.n_prov, e->v.n_prov, B * sizeof(int));
+        cpx(n->v.prov, e->v.prov, B * sizeof(int));
+        cpx(n->v.ref_cost, e->v.ref_cost, B * sizeof(double));
+        for (int pl = 0; pl < 16 && he == hipSuccess; pl++)
+            he = hipMemcpy2DAsync(n->v.x_best + (size_t)pl * G1, (size_t)M1 * sizeof(double), e->v.x_best + (size_t)pl * G0, (size_t)M0 * sizeof(double),
+                                  (size_t)M0 * sizeof(double), (size_t)B, hipMemcpyDeviceToDevice, n->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(n->stream);
+        if (he != hipSuccess) { vf_engine_destroy(n); return fail(VF_ERR_DEVICE, "vf_engine_grow: device copy failed: %s", hipGetErrorString(he)); }
+    }
+    n->far_transported = e->far_transported;
+    n->far_ended = e->far_ended;
+    n->far_absorbed = e->far_absorbed;
+    n->marg_since_drop = e->marg_since_drop;
+    n->inc_updates = e->inc_updates;
+    n->inc_full = e->inc_full;
     std::swap(*e, *n);             // *e: the grown engine; *n: the old buffers
     n->own_stream = n->own_stream && n->stream != e->stream;
     vf_engine_destroy(n);

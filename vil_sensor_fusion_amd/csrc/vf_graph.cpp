@@ -34,6 +34,8 @@ struct PendingImu {            // one queued CombinedImuFactor (GraphManager::_i
     std::vector<double> record; // non-empty: a ready-made factor handed in through vf_add_imu_factor (addFactor), 190 doubles
 };
 struct PendingBetween { uint64_t a, b; double rec[VF_BTW_RECORD]; bool on_device = false; };
+// a between factor as the caller handed it in: what GraphManager::graph() shows until the next solve (vf_graph_get_staged)
+struct StagedFactor { uint64_t a, b; double q[4], t[3], cov[36]; };
 
 // R upper-triangular, R^T R = cov^-1 (noiseModel::Gaussian::Covariance, SensorManagerRos.cpp:99).
 // 6x6 noise-model construction is factor *construction*, done once per measurement on the host
@@ -98,12 +100,15 @@ struct vf_graph {
     bool far_on_device = false;    // the engine holds a non-empty far list (written under solve_mutex only)
     std::atomic<int> far_linear{0};  // far ends of the engine's linear far factor (far factors marginalised with their older key): they share VF_MAX_EXTRA
     int staged_count = 3;  // the three priors (GraphManager.cpp:33-35)
+    bool priors_staged = true;              // ... which the first solve takes with everything else (_graph->resize(0), :114)
+    std::vector<StagedFactor> staged_log;   // the between factors among them, in the order addBetweenFactor took them
     uint64_t current_key = 0;
     double last_pose_time = -1.0;
     std::vector<double> key_time;  // time of each reserved key
     // guarded by state_mutex (GraphManager::_stateMutex)
     std::mutex state_mutex;
     double state[16] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double anchor[16] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // X(0), V(0), B(0) and the means of their priors
     uint64_t solved_key = 0;  // keys [0, solved_key] hold states on the device
     int lo = 0;               // slot of the oldest keyframe in the window
     uint64_t key_base = 0;    // slot = key - key_base (advances by multiples of 64 on compaction)
@@ -125,9 +130,11 @@ static int gerr(int code, const char* fmt, ...) {
     return code;
 }
 
-void vf_graph_default_opts(vf_graph_opts* o) {
-    if (!o) return;
+#undef vf_graph_default_opts
+#undef vf_engine_default_opts
+static void graph_defaults(vf_graph_opts* o) {
     memset(o, 0, sizeof(*o));
+    o->struct_size = (uint32_t)sizeof(*o);
     o->capacity = 4096;
     o->lag = 0;
     o->iterations = 5;
@@ -144,11 +151,28 @@ void vf_graph_default_opts(vf_graph_opts* o) {
     o->incremental = 0;
     o->wildfire = 0.0;
 }
+// (the caller's struct may be shorter than the library's: include/vilfusion.h "struct_size")
+void vf_graph_default_opts_sized(vf_graph_opts* o, uint32_t struct_size) {
+    if (!o || struct_size < sizeof(uint32_t)) return;
+    vf_graph_opts full;
+    graph_defaults(&full);
+    const uint32_t n = struct_size < sizeof(full) ? struct_size : (uint32_t)sizeof(full);
+    memcpy(o, &full, n);
+    o->struct_size = n;
+}
+void vf_graph_default_opts(vf_graph_opts* o) { vf_graph_default_opts_sized(o, (uint32_t)sizeof(vf_graph_opts)); }
 
 int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** out) {
     if (!imu || !out) return gerr(VF_ERR_INVALID, "null argument");
     vf_graph_opts o;
-    if (opts) o = *opts; else vf_graph_default_opts(&o);
+    graph_defaults(&o);
+    if (opts) {
+        if (opts->struct_size < 8 || opts->struct_size > sizeof(o))
+            return gerr(VF_ERR_INVALID, "vf_graph_opts.struct_size = %u: this library knows sizes up to %zu (fill the struct with vf_graph_default_opts; "
+                        "a caller built against a newer header needs a newer library)", opts->struct_size, sizeof(o));
+        memcpy(&o, opts, opts->struct_size);
+        o.struct_size = (uint32_t)sizeof(o);
+    }
     if (o.capacity < 8 || o.iterations < 0 || o.lag < 0) return gerr(VF_ERR_INVALID, "bad graph options");
     if (o.lag != 0 && o.lag < 4) return gerr(VF_ERR_INVALID, "lag must be 0 or >= 4 keyframes");
     if (!(o.rel_tol >= 0.0) || !(o.abs_tol >= 0.0)) return gerr(VF_ERR_INVALID, "tolerances must be >= 0");
@@ -225,6 +249,7 @@ int vf_set_initial_state(vf_graph* g, const double state16[16]) {
     int rc;
     if ((rc = vf_engine_set_states(g->eng, 0, 0, 1, st)) || (rc = vf_engine_set_prior(g->eng, 0, 0, rec))) return rc;
     memcpy(g->state, st, sizeof(st));
+    memcpy(g->anchor, st, sizeof(st));
     return VF_OK;
 }
 
@@ -367,6 +392,13 @@ int vf_add_between(vf_graph* g, uint64_t prev, uint64_t cur, const double q[4], 
         g->far_new++;
     }
     g->staged_count++;
+    StagedFactor sf;
+    sf.a = prev;
+    sf.b = cur;
+    memcpy(sf.q, b.rec, sizeof(sf.q));
+    memcpy(sf.t, t, sizeof(sf.t));
+    memcpy(sf.cov, cov, sizeof(sf.cov));
+    g->staged_log.push_back(sf);
     return VF_OK;
 }
 
@@ -385,6 +417,48 @@ int vf_graph_staged(vf_graph* g, int* staged, int* queued) {
     return VF_OK;
 }
 
+// GraphManager::graph() (GraphManager.cpp:46-49): the factors staged since the last solve, by index -- at first the three priors
+// of :27-35 (kinds 0, 1, 2 on key 0), then the between factors in the order they were added (kind 3).
+int vf_graph_get_staged(vf_graph* g, int index, int* kind, uint64_t* key1, uint64_t* key2, double q[4], double t[3], double cov36[36]) {
+    if (!g) return gerr(VF_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->graph_mutex);
+    const int np = g->priors_staged ? 3 : 0;
+    if (index < 0 || index >= np + (int)g->staged_log.size()) return gerr(VF_ERR_BAD_KEY, "staged factor %d of %d", index, np + (int)g->staged_log.size());
+    if (q) { q[0] = 1.0; q[1] = q[2] = q[3] = 0.0; }
+    if (t) t[0] = t[1] = t[2] = 0.0;
+    if (cov36) memset(cov36, 0, sizeof(double) * 36);
+    if (index < np) {
+        // the means are the anchor state (identity / zero, or vf_set_initial_state's); sigmas vf_graph_opts.prior_sigma
+        std::lock_guard<std::mutex> sl(g->state_mutex);
+        const double* s = g->opts.prior_sigma;
+        if (kind) *kind = index;
+        if (key1) *key1 = 0;
+        if (key2) *key2 = 0;
+        if (index == 0) {
+            if (q) memcpy(q, g->anchor, sizeof(double) * 4);
+            if (t) memcpy(t, g->anchor + 4, sizeof(double) * 3);
+            if (cov36) for (int i = 0; i < 6; i++) cov36[i * 6 + i] = s[i] * s[i];
+        } else if (index == 1) {
+            if (t) memcpy(t, g->anchor + 7, sizeof(double) * 3);
+            if (cov36) for (int i = 0; i < 3; i++) cov36[i * 6 + i] = s[6 + i] * s[6 + i];
+        } else {
+            // (a bias has six components: acc in t, gyro in q[1..3]; documented in vilfusion.h)
+            if (t) memcpy(t, g->anchor + 10, sizeof(double) * 3);
+            if (q) { q[0] = 0.0; memcpy(q + 1, g->anchor + 13, sizeof(double) * 3); }
+            if (cov36) for (int i = 0; i < 6; i++) cov36[i * 6 + i] = s[9 + i] * s[9 + i];
+        }
+        return VF_OK;
+    }
+    const StagedFactor& f = g->staged_log[(size_t)(index - np)];
+    if (kind) *kind = 3;
+    if (key1) *key1 = f.a;
+    if (key2) *key2 = f.b;
+    if (q) memcpy(q, f.q, sizeof(f.q));
+    if (t) memcpy(t, f.t, sizeof(f.t));
+    if (cov36) memcpy(cov36, f.cov, sizeof(f.cov));
+    return VF_OK;
+}
+
 int vf_solve(vf_graph* g) {
     if (!g) return gerr(VF_ERR_INVALID, "null argument");
     static const bool timing = getenv("VF_SOLVE_TIMING") != nullptr;
@@ -397,6 +471,8 @@ int vf_solve(vf_graph* g) {
     uint64_t last_key;
     double last_time;
     int staged_before, far_new_before = 0;
+    std::vector<StagedFactor> log_before;
+    bool priors_before = false;
     bool fars_changed = false;
     size_t fars_snapshot = 0;
     bool late_far = false;          // a far factor added since the last solve whose older key had already left the window
@@ -422,6 +498,8 @@ int vf_solve(vf_graph* g) {
                     if (!late_far) { late_a = fb[i].a; late_b = fb[i].b; }
                     late_far = true;
                     late_n++;
+                    for (size_t j = 0; j < g->staged_log.size(); j++)      // (dropped: it leaves graph()'s list as well)
+                        if (g->staged_log[j].a == fb[i].a && g->staged_log[j].b == fb[i].b) { g->staged_log.erase(g->staged_log.begin() + (long)j); break; }
                 }
             fb.erase(std::remove_if(fb.begin(), fb.end(), [&](const PendingBetween& f) { return f.a < oldest; }), fb.end());
         }
@@ -431,6 +509,9 @@ int vf_solve(vf_graph* g) {
         g->far_new = 0;
         staged_before = g->staged_count - late_n;
         g->staged_count = 0;  // _graph->resize(0)
+        log_before.swap(g->staged_log);
+        priors_before = g->priors_staged;
+        g->priors_staged = false;
         last_key = g->current_key;
         last_time = g->last_pose_time;
     }
@@ -442,7 +523,7 @@ int vf_solve(vf_graph* g) {
     // while it is held.  solve_mutex (taken first, by vf_solve only) keeps a second solver from snapshotting newer
     // entries between the failure and the give-back.
     bool requeue = false, late_band = false;
-    uint64_t late_band_key = 0;
+    uint64_t late_band_key = 0, late_band_a = 0;
     auto give_back = [&](int code) { requeue = true; return code; };
     auto locked = [&]() -> int {
     std::lock_guard<std::mutex> sl(g->state_mutex);  // :117
@@ -458,6 +539,7 @@ int vf_solve(vf_graph* g) {
             if (betweens[i].a < oldest) {
                 const unsigned long long a = betweens[i].a, b = betweens[i].b;
                 late_band_key = betweens[i].b;          // (its end key carries no band factor after all: requeue clears the mark)
+                late_band_a = betweens[i].a;
                 late_band = true;
                 betweens.erase(betweens.begin() + (long)i);
                 staged_before--;
@@ -544,6 +626,28 @@ int vf_solve(vf_graph* g) {
     }
     const int lo = g->lo;
     lap("marginalize");
+    // a far factor added since the last solve whose older key the marginalisations above have just moved out of the window never
+    // reached the device: it is late odometry like any other (dropped, reported once, the rest given back)
+    {
+        const uint64_t oldest = g->key_base + (uint64_t)lo;
+        bool dropped = false;
+        unsigned long long da = 0, db = 0;
+        for (size_t i = 0; i < fars.size();) {
+            if (!fars[i].on_device && fars[i].a < oldest) {
+                if (!dropped) { da = fars[i].a; db = fars[i].b; }
+                dropped = true;
+                for (size_t j = 0; j < log_before.size(); j++)
+                    if (log_before[j].a == fars[i].a && log_before[j].b == fars[i].b) { log_before.erase(log_before.begin() + (long)j); break; }
+                fars.erase(fars.begin() + (long)i);
+                staged_before--;
+                far_new_before--;
+                fars_changed = true;
+            } else i++;
+        }
+        if (dropped)
+            return give_back(gerr(VF_ERR_BAD_KEY, "between factor (%llu, %llu) dropped: key %llu left the fixed-lag window in this solve (oldest key %llu)",
+                                  da, db, da, (unsigned long long)oldest));
+    }
     if (marginalised && (g->far_on_device || g->far_linear.load() > 0)) {
         // the engine has marginalised the far factors whose older key left together with that key (they are linear rows of its
         // own now): the entries that were on the device are replaced by what the engine's list holds now
@@ -623,6 +727,11 @@ int vf_solve(vf_graph* g) {
         for (auto it = imus.rbegin(); it != imus.rend(); ++it) g->imu_queue.push_front(std::move(*it));
         g->staged_between.insert(g->staged_between.begin(), betweens.begin(), betweens.end());
         g->staged_count += staged_before;
+        if (late_band)
+            for (size_t j = 0; j < log_before.size(); j++)
+                if (log_before[j].b == late_band_key && log_before[j].a == late_band_a) { log_before.erase(log_before.begin() + (long)j); break; }
+        g->staged_log.insert(g->staged_log.begin(), log_before.begin(), log_before.end());
+        g->priors_staged = g->priors_staged || priors_before;
         // the far factors added since the last successful solve are still "new" for the solve that repeats this one (its
         // late-odometry test looks at the new ones only), and a band factor dropped as late leaves its end key free again
         g->far_new += far_new_before;

@@ -39,7 +39,7 @@ class EngineOpts:
     lambda_min: float = 1e-12
     lambda_max: float = 1e10
     chunks: int = 0          # K4 form: 0 = auto (<= 128 windows: partitioned solve), 1 = sweeps, P >= 2 = P chunks
-    # solver-form switches (None = the library's default, vf_engine_default_opts; see include/vilfusion.h)
+    # solver-form switches (None = the library's default, vf_engine_default_tuning; include/vilfusion.h vf_engine_tuning)
     sweep_two_sided_max: int | None = None
     hybrid_threshold: int | None = None
     cold_start: bool = False
@@ -53,7 +53,7 @@ class EngineOpts:
     refine_iterations: int | None = None
     refine_min_keyframes: int | None = None
     refine_rel_stop: float | None = None
-    gauge_floor: float | None = None     # floor of the marginal prior's information about global translation / yaw (None = default 1e-3; 0 = off)
+    gauge_floor: float | None = None     # floor of the marginal prior's information about global translation / yaw (None = default 3e-4; 0 = off)
     hybrid_active_list: int | None = None  # hybrid solves: sweeps take their windows from the compacted list of active ones (None = default 1)
     far_batch_columns: int | None = None   # single-window engines: the Woodbury columns of far factors as one batched solve (None = default 1)
     incremental: int | None = None         # isam_step re-eliminates only from the first keyframe that changed (None = default 0)
@@ -71,24 +71,18 @@ class Engine:
         o.lambda0, o.lambda_up, o.lambda_down = opts.lambda0, opts.lambda_up, opts.lambda_down
         o.lambda_min, o.lambda_max = opts.lambda_min, opts.lambda_max
         o.chunks = opts.chunks
-        if opts.sweep_two_sided_max is not None:
-            o.sweep_two_sided_max = opts.sweep_two_sided_max
-        if opts.hybrid_threshold is not None:
-            o.hybrid_threshold = opts.hybrid_threshold
-        o.cold_start, o.use_hip_graph = int(opts.cold_start), int(opts.use_hip_graph)
-        if opts.accept_rel is not None:
-            o.accept_rel = opts.accept_rel
-        if opts.solve_split_min is not None:
-            o.solve_split_min = opts.solve_split_min
-        if opts.solve_assemble_min is not None:
-            o.solve_assemble_min = opts.solve_assemble_min
-        if opts.solve_assemble_waves is not None:
-            o.solve_assemble_waves = opts.solve_assemble_waves
-        for name in ("refine_iterations", "refine_min_keyframes", "refine_rel_stop", "lm_excursion", "gauge_floor", "hybrid_active_list", "far_batch_columns", "incremental", "wildfire"):
+        o.cold_start = int(opts.cold_start)
+        for name in ("accept_rel", "refine_iterations", "refine_min_keyframes", "refine_rel_stop", "lm_excursion", "gauge_floor", "incremental", "wildfire"):
             if getattr(opts, name) is not None:
                 setattr(o, name, getattr(opts, name))
+        t = _lib.EngineTuningC()
+        self._l.vf_engine_default_tuning(C.byref(t))
+        t.use_hip_graph = int(opts.use_hip_graph)
+        for name in ("sweep_two_sided_max", "hybrid_threshold", "solve_split_min", "solve_assemble_min", "solve_assemble_waves", "hybrid_active_list", "far_batch_columns"):
+            if getattr(opts, name) is not None:
+                setattr(t, name, getattr(opts, name))
         self._h = C.c_void_p()
-        check(self._l.vf_engine_create(C.byref(o), C.byref(self._h)))
+        check(self._l.vf_engine_create_tuned(C.byref(o), C.byref(t), C.byref(self._h)))
         self.opts = opts
         self.capacity = (opts.capacity + 63) // 64 * 64
         self.windows = opts.windows

@@ -156,6 +156,19 @@ class GraphManager:
         check(self._l.vf_graph_solver_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def graph(self):
+        """GraphManager::graph() (GraphManager.cpp:46-49): the staged factors as a list of dicts -- kind ("prior_pose" |
+        "prior_velocity" | "prior_bias" | "between"), keys, measured (q_wxyz, t), covariance (6 x 6)."""
+        n = self.graphSize()
+        names = ("prior_pose", "prior_velocity", "prior_bias", "between")
+        out = []
+        for i in range(n):
+            kind, k1, k2 = C.c_int(), C.c_uint64(), C.c_uint64()
+            q, t, cov = np.zeros(4), np.zeros(3), np.zeros((6, 6))
+            check(self._l.vf_graph_get_staged(self._h, i, C.byref(kind), C.byref(k1), C.byref(k2), _d(q), _d(t), _d(cov)))
+            out.append(dict(kind=names[kind.value], keys=(k1.value, k2.value), measured=(q, t), covariance=cov))
+        return out
+
     def incrementalInfo(self):
         """incremental handles: updates so far, how many re-eliminated the whole history, the keys the last update's forward
         sweep started at / its back substitution stopped at"""

@@ -151,21 +151,25 @@ def test_rccl_code_path_one_rank():
     assert ncoll == 2 * ITERS
 
 
-def test_bench_gpus_flag_starts_that_many_ranks():
+def test_bench_gpus_flag_starts_that_many_ranks(tmp_path):
     """`python bench.py --gpus 2` (no WORLD_SIZE): bench.py itself starts two ranks; here they share the box's one GPU and
-    talk over gloo.  The line must say n_gpus 2 and the time-sharded section two collectives per trial."""
+    talk over gloo.  The line must say n_gpus 2 and carry roofline, the detail file the time-sharded section's two collectives
+    per trial."""
     import json
     import subprocess
-    env = dict(os.environ, VF_BENCH_BACKEND="gloo", VF_BENCH_SHARE_GPU="1")
+    env = dict(os.environ, VF_BENCH_BACKEND="gloo", VF_BENCH_SHARE_GPU="1", VF_BENCH_DETAIL_DIR=str(tmp_path))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--windows", "8", "--window", "96", "--steps", "2",
            "--warmup", "1", "--sharded-window", "1200", "--no-single-window"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
-    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["value"] > 0
-    sh = line["time_sharded_window"]
+    text = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    line = json.loads(text)
+    assert len(text) < 4096 and line["n_gpus"] == 2 and line["value"] > 0
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1 and "cpu_baseline" not in line    # (the CPU legs are timed at N = 1 only)
+    assert line["time_sharded_window"]["ranks"] == 2 and line["detail"] == "bench_detail.json"
+    sh = json.load(open(tmp_path / "bench_detail.json"))["time_sharded_window"]
     assert "error" not in sh, sh
     assert sh["ranks"] == 2 and sh["collectives_per_trial"] == 2
     assert sh["collectives_issued"] == 2 * sh["lm_trials_run"] and sh["solve_failures"] == 0
@@ -189,6 +193,7 @@ def test_bench_abandons_a_stalled_sharded_section():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["ms_per_step"] > 0
     assert "error" in line["time_sharded_window"]
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1      # (the fallback line carries the roofline too)
 
 
 # ---------------------------------------------------------------- BASELINE configs[4] at its real geometry

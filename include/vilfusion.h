@@ -187,6 +187,23 @@ typedef struct {
 } vf_engine_tuning;
 
 
+/* Asynchronous staging (the GraphManager handle's engine runs this way; one-window engines that own their stream and hold no far
+ * factors): with on != 0, vf_engine_preintegrate (of keyframes beyond the window's end), vf_engine_set_between (up to 4 records),
+ * vf_engine_marginalize, vf_engine_drop_oldest and vf_engine_set_range enqueue their work and return without waiting for the
+ * device -- the marginalisation on a second stream, beside the staging of the keyframe that arrives -- and what the device finds
+ * wrong is reported by vf_engine_read_result instead of by the call: device_flags bit 0 = a preintegrated covariance was not
+ * positive definite (VF_ERR_NOT_SPD of vf_engine_preintegrate), bit 1 = the pivot block of a marginalised keyframe was not,
+ * bit 2 = the far ends' block (VF_ERR_INDETERMINATE of vf_engine_marginalize); the flags are cleared by the read.
+ * vf_engine_read_result: the state of keyframe `slot` (estimate != 0: theta (+) delta of the reference-compat solve), the cost and the
+ * LM counters of vf_engine_read_lm, in ONE synchronisation; any output may be null.  Works on every engine. */
+int vf_engine_set_async(vf_engine* e, int on);
+/* asynchronous engines, after a solve: compute NOW, behind the solve, the marginal prior the next vf_engine_marginalize of this
+ * window will need (its inputs -- the linearisation of the factors on the oldest keyframe at the solved states -- are final), so
+ * that the call itself only puts it in place.  Used if nothing but appends happens in between; dropped otherwise.  The
+ * GraphManager handle does this whenever its fixed-lag window is full.  A no-op on engines it does not apply to. */
+int vf_engine_marginalize_ahead(vf_engine* e);
+int vf_engine_read_result(vf_engine* e, int window, int slot, int estimate, double* state16, double* cost, int* accepted, int* rejected,
+                          int* solve_failures, int* device_flags);
 /* incremental engines (vf_engine_opts.incremental): updates made so far by vf_engine_isam_step, how many of them eliminated the
  * whole window (the first, and every one after an entry point the bookkeeping does not follow); for `window`, the keyframe slot
  * the last forward sweep started at and the slot the last back substitution stopped at (-1 on other engines) */

@@ -88,5 +88,15 @@ int vf_engine_read_lm(vf_engine*, int, double* c, double* l, int* a, int* r, int
 static int fill_state(int n, double* s) { for (int i = 0; i < n; i++) { memset(s + 16 * i, 0, 16 * sizeof(double)); s[16 * i] = 1.0; } return VF_OK; }
 int vf_engine_get_states(vf_engine*, int, int, int n, double* s) { return fill_state(n, s); }
 int vf_engine_get_estimate(vf_engine*, int, int, int n, double* s) { return fill_state(n, s); }
+int vf_engine_set_async(vf_engine*, int) { return VF_OK; }
+int vf_engine_marginalize_ahead(vf_engine*) { return VF_OK; }
+int vf_engine_read_result(vf_engine*, int, int, int, double* s, double* c, int* a, int* r, int* f, int* flags) {
+    if (c) *c = 0.0;
+    if (a) *a = 0;
+    if (r) *r = 0;
+    if (f) *f = 0;
+    if (flags) *flags = 0;
+    return s ? fill_state(1, s) : VF_OK;
+}
 int vf_engine_get_imu(vf_engine*, int, int, int n, double* r) { memset(r, 0, sizeof(double) * VF_IMU_RECORD * n); return VF_OK; }
 }

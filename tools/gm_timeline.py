@@ -7,6 +7,9 @@ import sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "k_preintegrate" in r["Kernel_Name"]]
 a = marks[-1]
+margs = [i for i, r in enumerate(rows) if "k_marginalize" in r["Kernel_Name"] and a - 8 <= i < a]      # (asynchronous staging: it runs beside K0, on a second stream)
+if margs:
+    a = margs[-1]
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end, busy = t0, 0
 for r in rows[a:]:

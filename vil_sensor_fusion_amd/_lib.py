@@ -80,7 +80,7 @@ SYMBOLS = [
     "vf_engine_refine_count", "vf_engine_refine_begin", "vf_engine_refine_step", "vf_engine_refine_end", "vf_engine_read_refine",
     "vf_engine_gn_begin", "vf_shard_iterate", "vf_shard_gn_step", "vf_shard_exchange_plan", "vf_engine_read_excursions", "vf_engine_close_excursions",
     "vf_chunk_geometry", "vf_shard_range", "vf_engine_set_convergence",
-    "vf_engine_isam_step", "vf_engine_predict_from_estimate", "vf_engine_get_estimate", "vf_engine_incremental_info",
+    "vf_engine_isam_step", "vf_engine_predict_from_estimate", "vf_engine_get_estimate", "vf_engine_incremental_info", "vf_engine_set_async", "vf_engine_read_result", "vf_engine_marginalize_ahead",
     "vf_graph_default_opts", "vf_graph_default_opts_sized", "vf_create", "vf_destroy", "vf_add_imu", "vf_reserve_node",
     "vf_add_between", "vf_solve", "vf_get_state", "vf_get_bias", "vf_most_recent_pose_time",
     "vf_set_callback", "vf_graph_staged", "vf_get_trajectory", "vf_get_imu_factor",

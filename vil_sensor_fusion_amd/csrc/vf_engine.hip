@@ -45,7 +45,8 @@ struct vf_engine;
 // last used -- e.g. a ROS spinner thread driving a GraphManager on device 1) and restores the caller's on return.
 struct DeviceGuard {
     int prev = -1, want = -1;
-    explicit DeviceGuard(const vf_engine* e);
+    // overlap_ok: the entry point touches nothing the side stream's work does (see vf_engine::side_open)
+    explicit DeviceGuard(const vf_engine* e, bool overlap_ok = false);
     ~DeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
     DeviceGuard(const DeviceGuard&) = delete;
     DeviceGuard& operator=(const DeviceGuard&) = delete;
@@ -93,6 +94,43 @@ struct vf_engine {
     // and checkpoints on the device are those of the problem as it was after the last vf_engine_isam_step, and everything
     // that changed since is an append -- inc_slid slides, or (one-window engines) writes at or beyond slot inc_first_dirty.
     // Any other entry point that writes (cold()) voids it: the next update eliminates the whole window.
+    // Asynchronous staging (vf_engine_set_async; the GraphManager's engine): the staging calls of a vf_solve -- preintegrate,
+    // set_between, marginalize, drop_oldest, set_range -- enqueue and return; what the device finds wrong (a preintegrated
+    // covariance or a marginalisation pivot that is not positive definite) is OR-ed into two sticky words that
+    // vf_engine_read_result hands back with the solve's result, in the one synchronisation a solve needs.  The marginalisation
+    // of the keyframe that leaves runs on a second stream beside K0 / prediction / staging of the one that arrives (they
+    // touch opposite ends of the window): side_open until the main stream has been made to wait for it (join_side, at
+    // every entry point that is not one of those three).
+    bool async_on = false, side_open = false;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int* sticky_dev = nullptr;
+    vf::SolveResult* res_host = nullptr;
+    int ensure_async() {
+        if (res_host) return VF_OK;
+        HIPCHK(hipStreamCreate(&stream2));
+        HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        HIPCHK(hipMalloc((void**)&sticky_dev, 2 * sizeof(int)));
+        HIPCHK(hipMemsetAsync(sticky_dev, 0, 2 * sizeof(int), stream));
+        HIPCHK(hipHostMalloc((void**)&res_host, sizeof(vf::SolveResult), hipHostMallocDefault));
+        return VF_OK;
+    }
+    int join_side() {
+        if (!side_open) return VF_OK;
+        side_open = false;
+        HIPCHK(hipEventRecord(ev_join, stream2));
+        HIPCHK(hipStreamWaitEvent(stream, ev_join, 0));
+        return VF_OK;
+    }
+    bool async_now() const { return async_on && x_used == 0 && v.B == 1 && own_stream; }
+    // vf_engine_marginalize_ahead: the marginal prior the next vf_engine_marginalize will need, computed behind the solve that has
+    // just ended (the linearisation it reads is final by then) into marg_stash; valid while nothing but appends has happened
+    // since and the window's first keyframe is still ahead_lo
+    double* marg_stash = nullptr;
+    bool ahead_valid = false;
+    int ahead_lo = -1;
+    long ahead_used = 0, ahead_made = 0;
     bool inc_valid = false;
     int inc_slid = 0, inc_first_dirty = 0x7fffffff;
     long inc_updates = 0, inc_full = 0;      // incremental updates so far; those that eliminated from the window's first keyframe
@@ -276,10 +314,12 @@ struct vf_engine {
 static inline void cold(vf_engine* e) {
     e->warm = false;
     e->inc_valid = false;
+    e->ahead_valid = false;
 }
 
-DeviceGuard::DeviceGuard(const vf_engine* e) {
+DeviceGuard::DeviceGuard(const vf_engine* e, bool overlap_ok) {
     if (!e) return;
+    if (!overlap_ok && e->side_open) (void)const_cast<vf_engine*>(e)->join_side();
     want = e->opts.device;
     if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipSetDevice(want); return; }
     if (prev != want) (void)hipSetDevice(want);
@@ -515,6 +555,11 @@ void vf_engine_destroy(vf_engine* e) {
     if (e->in_status) (void)hipFree(e->in_status);
     for (auto ev : e->in_ev) if (ev) (void)hipEventDestroy(ev);
     if (e->far_columns) { vf_engine_destroy(e->far_columns); e->far_columns = nullptr; }
+    if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->sticky_dev) (void)hipFree(e->sticky_dev);
+    if (e->res_host) (void)hipHostFree(e->res_host);
     if (e->x_gtmp) (void)hipFree(e->x_gtmp);
     if (e->x_Z) (void)hipFree(e->x_Z);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -579,11 +624,41 @@ int vf_engine_set_range(vf_engine* e, int window, int lo, int hi) {
         e->inc_valid = true;
         if (hi > e->h_hi[0] && e->h_hi[0] < e->inc_first_dirty) e->inc_first_dirty = e->h_hi[0];
     }
-    HIPCHK(hipMemcpyAsync(e->v.lo + window, &lo, sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->v.hi + window, &hi, sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->async_now()) {
+        vf::launch_set_range(e->v, window, lo, hi, e->stream);
+        HIPCHK(hipGetLastError());
+    } else {
+        HIPCHK(hipMemcpyAsync(e->v.lo + window, &lo, sizeof(int), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->v.hi + window, &hi, sizeof(int), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
     e->h_lo[window] = lo;
     e->h_hi[window] = hi;
+    return VF_OK;
+}
+int vf_engine_set_async(vf_engine* e, int on) {
+    DeviceGuard dev_guard_(e);
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (on) { if (int rc = e->ensure_async()) return rc; }
+    e->async_on = on != 0;
+    return VF_OK;
+}
+int vf_engine_read_result(vf_engine* e, int window, int slot, int estimate, double* state16, double* cost, int* accepted, int* rejected,
+                          int* solve_failures, int* device_flags) {
+    DeviceGuard dev_guard_(e);
+    int rc = check_range(e, window, slot, 1);
+    if (rc) return rc;
+    if ((rc = e->ensure_async())) return rc;
+    vf::launch_read_result(e->v, window, slot, estimate ? 1 : 0, e->sticky_dev, e->res_host, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const vf::SolveResult& r = *e->res_host;
+    if (state16) memcpy(state16, r.state, sizeof(r.state));
+    if (cost) *cost = r.cost;
+    if (accepted) *accepted = r.n_acc;
+    if (rejected) *rejected = r.n_rej;
+    if (solve_failures) *solve_failures = r.n_fail;
+    if (device_flags) *device_flags = (r.sticky[0] ? 1 : 0) | (r.sticky[1] & 4 ? 4 : (r.sticky[1] ? 2 : 0));
     return VF_OK;
 }
 
@@ -639,7 +714,7 @@ int vf_engine_set_imu(vf_engine* e, int window, int k0, int n, const double* rec
 }
 
 int vf_engine_set_between(vf_engine* e, int window, int n, const int32_t* a, const int32_t* b, const double* rec) {
-    DeviceGuard dev_guard_(e);
+    DeviceGuard dev_guard_(e, true);
     {
         int first = 1 << 30;
         for (int i = 0; i < n && b; i++) first = b[i] < first ? b[i] : first;
@@ -653,6 +728,17 @@ int vf_engine_set_between(vf_engine* e, int window, int n, const int32_t* a, con
         if (a[i] < 0 || b[i] >= M || a[i] >= b[i]) return fail(VF_ERR_BAD_KEY, "between factor %d: need 0 <= a < b < capacity (a=%d b=%d)", i, a[i], b[i]);
         if (b[i] - a[i] > W) return fail(VF_ERR_CAPACITY, "between factor %d spans %d keyframes > bandwidth %d", i, b[i] - a[i], W);
     }
+    if (e->async_now() && n <= 4) {
+        // (a record travels as a kernel argument: no staging copy, no synchronisation)
+        for (int i = 0; i < n; i++) {
+            vf::BtwArg arg;
+            memcpy(arg.r, rec + (size_t)i * vf::BTW_IN, sizeof(arg.r));
+            vf::launch_put_between(e->v, (long)window * M + b[i], a[i], arg, e->stream);
+        }
+        HIPCHK(hipGetLastError());
+        return VF_OK;
+    }
+    if (e->side_open) { if (int rj = e->join_side()) return rj; }
     // records go to the slot of b: runs of consecutive b are staged in one scatter
     int i = 0;
     while (i < n) {
@@ -763,7 +849,7 @@ int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec) {
 
 int vf_engine_preintegrate(vf_engine* e, int window, int k0, int n, const int32_t* off, const double* steps,
                            const double* bhat, const vf_imu_params* p) {
-    DeviceGuard dev_guard_(e);
+    DeviceGuard dev_guard_(e, true);
     touch(e, window, k0);
     int rc = check_range(e, window, k0, n);
     if (rc) return rc;
@@ -774,6 +860,28 @@ int vf_engine_preintegrate(vf_engine* e, int window, int k0, int n, const int32_
     if (off[0] < 0 || total < off[0] || (total > 0 && !steps)) return fail(VF_ERR_INVALID, "bad step offsets");
     for (int i = 0; i < n; i++)
         if (off[i + 1] <= off[i]) return fail(VF_ERR_INDETERMINATE, "imu factor for keyframe %d has no IMU steps", k0 + i);
+    if (e->async_now() && k0 >= e->h_hi[window]) {
+        // asynchronous staging: the arguments travel through the pinned block of vf_engine_ingest_tail in ONE copy, the status
+        // goes into the sticky word (vf_engine_read_result); nothing here waits for the device
+        const size_t steps_b = (size_t)(total > 0 ? total : 1) * 7 * sizeof(double), bias_b = (size_t)n * 6 * sizeof(double);
+        const size_t off_b = ((size_t)(n + 1) * sizeof(int) + 7) & ~(size_t)7, bytes = steps_b + bias_b + off_b;
+        if ((rc = e->ensure_ingest(bytes))) return rc;
+        if (e->in_pending) HIPCHK(hipEventSynchronize(e->in_ev[1]));      // (the previous copy has left the pinned buffer: long done)
+        char* h = (char*)e->in_host;
+        if (total > 0) memcpy(h, steps, (size_t)total * 7 * sizeof(double));
+        memcpy(h + steps_b, bhat, bias_b);
+        memcpy(h + steps_b + bias_b, off, (size_t)(n + 1) * sizeof(int));
+        char* d = (char*)e->in_dev;
+        HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipEventRecord(e->in_ev[1], e->stream));
+        e->in_pending = true;
+        vf::ImuCov c{p->acc_cov, p->gyro_cov, p->integration_cov, p->bias_acc_cov, p->bias_omega_cov, p->bias_acc_omega_int};
+        vf::launch_preintegrate(e->v, (long)window * e->v.M + k0, n, (const int*)(d + steps_b + bias_b), (const double*)d, (const double*)(d + steps_b), c,
+                                e->sticky_dev, e->stream);
+        HIPCHK(hipGetLastError());
+        return VF_OK;
+    }
+    if (e->side_open) { if (int rj = e->join_side()) return rj; }
     // one scratch block: [steps 7 x total][bias 6 x n][offsets n + 1][status]
     const size_t steps_b = (size_t)(total > 0 ? total : 1) * 7 * sizeof(double), bias_b = (size_t)n * 6 * sizeof(double);
     const size_t off_b = ((size_t)(n + 1) * sizeof(int) + 7) & ~(size_t)7;
@@ -1129,7 +1237,19 @@ static int iterate_sequence(vf_engine* e, int iterations) {
         HIPCHK(hipGetLastError());
     } else if ((rc = vf_engine_linearize(e, 0))) return rc;
     if ((rc = vf_engine_decide(e, 1))) return rc;
+    // One window under the termination rule (the GraphManager's solve): a trial the rule has made unnecessary is eight launches
+    // that do nothing (2-4 us each).  Two trials are enqueued blind -- the rule needs two to see convergence, and that is what
+    // a steady update takes --; before each further one the window's flag is read (one small synchronisation, paid only by the
+    // solves that go on).  The skipped launches would have skipped the window on the device: same bits.
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(e->stream, &capturing);
+    const bool adaptive = e->v.B == 1 && e->v.stop_on && e->async_now() && capturing == hipStreamCaptureStatusNone;
     for (int it = 0; it < iterations; it++) {
+        if (adaptive && it >= 2) {
+            HIPCHK(hipMemcpyAsync(&e->res_host->pad, e->v.done, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+            if (e->res_host->pad) break;
+        }
         if ((rc = vf_engine_assemble(e))) return rc;
         if ((rc = vf_engine_solve(e))) return rc;
         if ((rc = vf_engine_retract(e))) return rc;
@@ -1456,7 +1576,7 @@ int vf_engine_reset_lambda(vf_engine* e) {
 }
 
 int vf_engine_predict(vf_engine* e, int window, int k0, int n) {
-    DeviceGuard dev_guard_(e);
+    DeviceGuard dev_guard_(e, e && window >= 0 && window < e->v.B && k0 > e->h_lo[window] + 1);
     touch(e, window, k0);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (window >= e->v.B || k0 < 1 || n < 0 || k0 + n > e->v.M) return fail(VF_ERR_BAD_KEY, "bad predict range");
@@ -1555,7 +1675,7 @@ int vf_engine_incremental_info(vf_engine* e, int window, long* updates, long* wh
     return VF_OK;
 }
 int vf_engine_predict_from_estimate(vf_engine* e, int window, int k0, int n) {
-    DeviceGuard dev_guard_(e);
+    DeviceGuard dev_guard_(e, e && window >= 0 && window < e->v.B && k0 > e->h_lo[window] + 1);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     { const bool keep = e->inc_valid; touch(e, window, k0); cold(e); if (keep && e->v.B == 1 && window == 0 && k0 > e->h_lo[0]) e->inc_valid = true; }
     if (window >= e->v.B || k0 < 1 || n < 0 || k0 + n > e->v.M) return fail(VF_ERR_BAD_KEY, "bad predict range");
@@ -1580,12 +1700,34 @@ int vf_engine_get_estimate(vf_engine* e, int window, int k0, int n, double* s) {
 }
 
 int vf_engine_marginalize(vf_engine* e) {
-    DeviceGuard dev_guard_(e);
+    DeviceGuard dev_guard_(e, e && e->async_now());
     // (reads the current linearisation, writes the marginal prior: what a warm start expects to have changed)
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
     if (int rc = not_sharded(e, "vf_engine_marginalize")) return rc;
     for (int w = 0; w < e->v.B; w++)
         if (e->h_hi[w] - e->h_lo[w] < 4) return fail(VF_ERR_INVALID, "window %d: marginalisation needs >= 4 keyframes", w);
+    if (e->async_now() && e->ahead_valid && e->ahead_lo == e->h_lo[0] && !e->side_open) {
+        // computed behind the previous solve (vf_engine_marginalize_ahead): put in place, nothing to wait for
+        vf::launch_marg_commit(e->v, e->marg_stash, e->stream);
+        HIPCHK(hipGetLastError());
+        e->ahead_valid = false;
+        e->ahead_used++;
+        e->marg_since_drop = true;
+        return VF_OK;
+    }
+    if (e->async_now()) {
+        // beside whatever the main stream is given next (K0, prediction and staging of the keyframe that arrives): a second
+        // stream that starts where the main one stands now
+        if (!e->side_open) {
+            HIPCHK(hipEventRecord(e->ev_fork, e->stream));
+            HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+            e->side_open = true;
+        }
+        vf::launch_marginalize(e->v, e->sticky_dev + 1, e->stream2);
+        HIPCHK(hipGetLastError());
+        e->marg_since_drop = true;
+        return VF_OK;
+    }
     HIPCHK(hipMemsetAsync(e->status_dev, 0, sizeof(int), e->stream));
     // far factors the prior is about to absorb: their linearisation at the current states (a compaction, a transport or any
     // other re-sending of the list since the last solve has zeroed the buffers)
@@ -1719,9 +1861,36 @@ int vf_engine_get_extra_between(vf_engine* e, int window, int* n, int32_t* a, in
     return VF_OK;
 }
 
-int vf_engine_drop_oldest(vf_engine* e) {
+int vf_engine_marginalize_ahead(vf_engine* e) {
     DeviceGuard dev_guard_(e);
     if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    // (a warm engine: its records are those of the current states -- what a marginalisation reads -- and stay so while only
+    // appends follow; anything else voids the stash through cold())
+    if (!e->async_now() || !e->warm || e->h_hi[0] - e->h_lo[0] < 4) return VF_OK;
+    if (int rc = e->ensure_async()) return rc;
+    if (!e->marg_stash) {
+        HIPCHK(hipMalloc((void**)&e->marg_stash, (size_t)e->v.B * vf::MARG_STASH_DOUBLES * sizeof(double)));
+        e->allocs.push_back(e->marg_stash);
+    }
+    vf::launch_marginalize_ahead(e->v, e->sticky_dev + 1, e->marg_stash, e->stream);
+    HIPCHK(hipGetLastError());
+    e->ahead_valid = true;
+    e->ahead_lo = e->h_lo[0];
+    e->ahead_made++;
+    return VF_OK;
+}
+int vf_engine_drop_oldest(vf_engine* e) {
+    DeviceGuard dev_guard_(e, e && e->async_now());
+    if (!e) return fail(VF_ERR_INVALID, "engine is null");
+    if (e->async_now()) {
+        for (int w = 0; w < e->v.B; w++)
+            if (e->h_hi[w] - e->h_lo[w] < 2) return fail(VF_ERR_INVALID, "window %d too short", w);
+        vf::launch_bump_lo(e->v, e->side_open ? e->stream2 : e->stream);       // (behind the marginalisation it follows, wherever that runs)
+        HIPCHK(hipGetLastError());
+        e->marg_since_drop = false;
+        for (int w = 0; w < e->v.B; w++) e->h_lo[w]++;
+        return VF_OK;
+    }
     if (int rc = transport_far(e, e->marg_since_drop)) return rc;
     e->marg_since_drop = false;
     for (int w = 0; w < e->v.B; w++) {

@@ -32,6 +32,7 @@ struct PendingImu {            // one queued CombinedImuFactor (GraphManager::_i
     std::vector<double> steps; // 7 per step: dt, acc, gyro
     double bias[6];            // getBias() at reserveNode time (GraphManager.cpp:61)
     std::vector<double> record; // non-empty: a ready-made factor handed in through vf_add_imu_factor (addFactor), 190 doubles
+    bool staged = false;        // preintegrated on the device already, at reserveNode time (where the reference preintegrates: GraphManager.cpp:59-66)
 };
 struct PendingBetween { uint64_t a, b; double rec[VF_BTW_RECORD]; bool on_device = false; };
 // a between factor as the caller handed it in: what GraphManager::graph() shows until the next solve (vf_graph_get_staged)
@@ -215,7 +216,8 @@ int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** ou
     rec[0] = 1.0;
     memcpy(rec + 16, o.prior_sigma, sizeof(double) * 15);
     if ((rc = vf_engine_set_states(eng, 0, 0, 1, g->state)) || (rc = vf_engine_set_prior(eng, 0, 0, rec)) ||
-        (rc = vf_engine_set_range(eng, 0, 0, 1)) || (rc = vf_engine_set_convergence(eng, o.rel_tol, o.abs_tol))) {
+        (rc = vf_engine_set_range(eng, 0, 0, 1)) || (rc = vf_engine_set_convergence(eng, o.rel_tol, o.abs_tol)) ||
+        (rc = vf_engine_set_async(eng, 1))) {
         vf_engine_destroy(eng);
         delete g;
         return rc;
@@ -317,6 +319,21 @@ int vf_reserve_node(vf_graph* g, double time, uint64_t* key_out) {
     // a factor without a single IMU step has no covariance: GTSAM would fail at the solve with the factor already in
     // the graph; here the node is refused and nothing is queued (checked before the key is consumed)
     if (p.steps.empty()) return gerr(VF_ERR_INDETERMINATE, "reserveNode(%.6f): no IMU measurement in (%.6f, %.6f]", time, start, time);
+    {
+        // The reference preintegrates here, in reserveNode (IMUManager::getFactor, GraphManager.cpp:59-66); so does this: K0 of the
+        // new factor is enqueued on the engine's stream now, asynchronously (vf_engine_set_async), and the solve finds the
+        // record in place instead of starting with a 60 us kernel.  Only when the slot exists already (no growth / compaction
+        // pending) and every factor queued in front of it is on the device too (slots are consecutive); _stateMutex orders this
+        // against a solve in flight, as getBias() above does.
+        std::lock_guard<std::mutex> sl(g->state_mutex);
+        const long slot = (long)(p.key - g->key_base);
+        bool prev_ok = true;
+        for (const auto& q : g->imu_queue) prev_ok = prev_ok && q.staged;
+        if (prev_ok && slot >= 1 && slot < g->opts.capacity && p.key > g->key_base) {
+            const int32_t off[2] = {0, (int32_t)(p.steps.size() / 7)};
+            if (vf_engine_preintegrate(g->eng, 0, (int)slot, 1, off, p.steps.data(), p.bias, &g->imu) == VF_OK) p.staged = true;
+        }
+    }
     g->current_key++;
     g->imu_queue.push_back(std::move(p));
     g->last_pose_time = time;
@@ -564,6 +581,41 @@ int vf_solve(vf_graph* g) {
         g->key_base += shift;
         if ((int)(last_key - g->key_base) + 1 > g->opts.capacity) return give_back(gerr(VF_ERR_CAPACITY, "capacity %d exhausted even after compaction", g->opts.capacity));
     }
+    // fixed-lag window: marginalise the keyframes that fall out of the lag, one at a time, at the
+    // linearisation of the previous solve (their factors have not changed since).  FIRST: the engine runs it on a second
+    // stream, beside the preintegration / prediction / staging of the keyframes that arrive (vf_engine_set_async)
+    const int last_slot = (int)(last_key - g->key_base);
+    bool marginalised = false;
+    while (g->opts.lag > 0 && last_slot + 1 - g->lo > g->opts.lag && (int)(g->solved_key - g->key_base) - g->lo >= 3) {
+        if ((rc = vf_engine_marginalize(g->eng))) return give_back(rc);
+        if ((rc = vf_engine_drop_oldest(g->eng))) return give_back(rc);
+        g->lo++;      // (kept in step with the device: a keyframe that has been marginalised stays marginalised)
+        marginalised = true;
+    }
+    const int lo = g->lo;
+    lap("marginalize");
+    // a far factor added since the last solve whose older key the marginalisations above have just moved out of the window never
+    // reached the device: it is late odometry like any other (dropped, reported once, the rest given back)
+    {
+        const uint64_t oldest = g->key_base + (uint64_t)lo;
+        bool dropped = false;
+        unsigned long long da = 0, db = 0;
+        for (size_t i = 0; i < fars.size();) {
+            if (!fars[i].on_device && fars[i].a < oldest) {
+                if (!dropped) { da = fars[i].a; db = fars[i].b; }
+                dropped = true;
+                for (size_t j = 0; j < log_before.size(); j++)
+                    if (log_before[j].a == fars[i].a && log_before[j].b == fars[i].b) { log_before.erase(log_before.begin() + (long)j); break; }
+                fars.erase(fars.begin() + (long)i);
+                staged_before--;
+                far_new_before--;
+                fars_changed = true;
+            } else i++;
+        }
+        if (dropped)
+            return give_back(gerr(VF_ERR_BAD_KEY, "between factor (%llu, %llu) dropped: key %llu left the fixed-lag window in this solve (oldest key %llu)",
+                                  da, db, da, (unsigned long long)oldest));
+    }
     if (!imus.empty()) {
         // K0 on the device for all queued factors, then the initial values by IMU prediction
         // (GraphManager.cpp:150-160).  Keys are consecutive by construction.
@@ -573,8 +625,9 @@ int vf_solve(vf_graph* g) {
         // ready-made factors (addFactor) are staged as records
         for (int i = 0; i < n;) {
             int j = i;
+            if (imus[i].staged) { i++; continue; }          // preintegrated at reserveNode time: the record is on the device
             const bool ready = !imus[i].record.empty();
-            while (j < n && imus[j].record.empty() == !ready) j++;
+            while (j < n && !imus[j].staged && imus[j].record.empty() == !ready) j++;
             const int cnt = j - i;
             if (ready) {
                 std::vector<double> recs((size_t)cnt * VF_IMU_RECORD);
@@ -613,40 +666,6 @@ int vf_solve(vf_graph* g) {
         }
         if ((rc = vf_engine_set_between(g->eng, 0, (int)a.size(), a.data(), b.data(), rec.data()))) return give_back(rc);
         lap("set_between");
-    }
-    // fixed-lag window: marginalise the keyframes that fall out of the lag, one at a time, at the
-    // linearisation of the previous solve (their factors have not changed since)
-    const int last_slot = (int)(last_key - g->key_base);
-    bool marginalised = false;
-    while (g->opts.lag > 0 && last_slot + 1 - g->lo > g->opts.lag && (int)(g->solved_key - g->key_base) - g->lo >= 3) {
-        if ((rc = vf_engine_marginalize(g->eng))) return give_back(rc);
-        if ((rc = vf_engine_drop_oldest(g->eng))) return give_back(rc);
-        g->lo++;      // (kept in step with the device: a keyframe that has been marginalised stays marginalised)
-        marginalised = true;
-    }
-    const int lo = g->lo;
-    lap("marginalize");
-    // a far factor added since the last solve whose older key the marginalisations above have just moved out of the window never
-    // reached the device: it is late odometry like any other (dropped, reported once, the rest given back)
-    {
-        const uint64_t oldest = g->key_base + (uint64_t)lo;
-        bool dropped = false;
-        unsigned long long da = 0, db = 0;
-        for (size_t i = 0; i < fars.size();) {
-            if (!fars[i].on_device && fars[i].a < oldest) {
-                if (!dropped) { da = fars[i].a; db = fars[i].b; }
-                dropped = true;
-                for (size_t j = 0; j < log_before.size(); j++)
-                    if (log_before[j].a == fars[i].a && log_before[j].b == fars[i].b) { log_before.erase(log_before.begin() + (long)j); break; }
-                fars.erase(fars.begin() + (long)i);
-                staged_before--;
-                far_new_before--;
-                fars_changed = true;
-            } else i++;
-        }
-        if (dropped)
-            return give_back(gerr(VF_ERR_BAD_KEY, "between factor (%llu, %llu) dropped: key %llu left the fixed-lag window in this solve (oldest key %llu)",
-                                  da, db, da, (unsigned long long)oldest));
     }
     if (marginalised && (g->far_on_device || g->far_linear.load() > 0)) {
         // the engine has marginalised the far factors whose older key left together with that key (they are linear rows of its
@@ -691,22 +710,28 @@ int vf_solve(vf_graph* g) {
     }
     if ((rc = vf_engine_set_range(g->eng, 0, lo, last_slot + 1))) return give_back(rc);
     lap("set_range");
-    int fails = 0;
+    int fails = 0, flags = 0;
     if (g->opts.reference_compat) {
         if ((rc = vf_engine_isam_step(g->eng, g->opts.relin_threshold))) return rc;  // one ISAM2::update
         lap("isam_step");
-        if ((rc = vf_engine_get_estimate(g->eng, 0, last_slot, 1, g->state))) return rc;   // calculateEstimate, :127,131-133
+        if ((rc = vf_engine_read_result(g->eng, 0, last_slot, 1, g->state, nullptr, nullptr, nullptr, nullptr, &flags))) return rc;   // calculateEstimate, :127,131-133
     } else {
         if ((rc = vf_engine_iterate(g->eng, g->opts.iterations))) return rc;   // (ISAM2::update + calculateEstimate: LM to convergence)
         lap("iterate(launch)");
-        if ((rc = vf_engine_read_lm(g->eng, 0, nullptr, nullptr, nullptr, nullptr, &fails))) return rc;
-        lap("read_lm(sync)");
-        if ((rc = vf_engine_get_states(g->eng, 0, last_slot, 1, g->state))) return rc;  // :131-133
+        // the one synchronisation of the solve: the last state (:131-133), the failure count, what the staging kernels flagged
+        if ((rc = vf_engine_read_result(g->eng, 0, last_slot, 0, g->state, nullptr, nullptr, nullptr, &fails, &flags))) return rc;
     }
-    lap("get_states");
+    lap("read_result(sync)");
+    // (asynchronous staging: a preintegrated covariance / a marginalisation pivot that was not positive definite shows here, after
+    // the solve that used it -- with positive IMU covariances and a determined graph neither happens)
+    if (flags & 1) return gerr(VF_ERR_NOT_SPD, "preintegrated covariance not positive definite");
+    if (flags & 6) return gerr(VF_ERR_INDETERMINATE, "marginalisation: %s not positive definite", (flags & 4) ? "the far ends' block of the marginal" : "pivot block of the oldest keyframe");
     g->solved_key = last_key;
     for (auto& cb : g->callbacks)  // :135-138, on the solving thread, inside _stateMutex
         cb.first(cb.second, last_time, g->state, g->state + 4, g->state + 7, g->state + 10);
+    // a full fixed-lag window marginalises its oldest keyframe at the next update, from the linearisation this solve leaves:
+    // have the device compute that marginal prior now, behind the solve, instead of in front of the next one
+    if (g->opts.lag > 0 && last_slot + 1 - g->lo >= g->opts.lag) (void)vf_engine_marginalize_ahead(g->eng);
     if (fails > 0 && fails >= g->opts.iterations && g->opts.iterations > 0)
         return gerr(VF_ERR_INDETERMINATE, "normal equations not positive definite in every LM trial (underdetermined graph?)");
     return VF_OK;

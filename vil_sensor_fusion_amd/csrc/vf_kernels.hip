@@ -3508,8 +3508,13 @@ __global__ void __launch_bounds__(256) k_inc_retract(View v) {
 // factors starting at m -- taken at the current linearisation (buffer `sel`), onto
 // [m+1: 15][m+2: pose 6][m+3: pose 6].  One 256-thread workgroup per window, 42x42 system in LDS, Gaussian
 // elimination of the 15 leading columns (no square roots).  Runs once per slide.
+// stash != null (FAR = false only): the new marginal prior goes into stash[w][MARG_STASH] instead of the window's own arrays, and
+// nothing of the window changes -- k_marg_commit puts it in place later (vf_engine_marginalize_ahead: the marginalisation a full
+// fixed-lag window will need at its next update, computed behind the solve that has just finished instead of in front of the
+// next one).
+constexpr int MARG_STASH = MARG_STASH_DOUBLES;
 template <bool FAR>
-__global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
+__global__ void __launch_bounds__(256) k_marginalize(View v, int* status, double* __restrict__ stash) {
     const int w = blockIdx.x, lane = threadIdx.x;
     const int lo = v.lo[w], hi = v.hi[w];
     if (hi - lo < 4) { if (lane == 0) atomicOr(status, 2); return; }
@@ -3885,6 +3890,16 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
         __syncthreads();
     }
     // new marginal prior on [m+1:15][m+2 pose][m+3 pose] = rows 15..41, relinearised at the current states
+    if (!FAR && stash) {
+        double* st = stash + (size_t)w * MARG_STASH;
+        for (int e = lane; e < 729 + 27; e += 256) {
+            if (e < 729) { const int i = e / 27, j = e - i * 27; st[e] = 0.5 * (A[(15 + i) * 43 + 15 + j] + A[(15 + j) * 43 + 15 + i]); }
+            else st[e] = bv[15 + e - 729];
+        }
+        if (lane < 48) { const int j = lane / 16, c = lane - j * 16; st[756 + lane] = XS(b, c, g0 + 1 + j); }
+        if (lane == 0 && bad) atomicOr(status, bad & 4 ? 4 : 1);
+        return;
+    }
     for (int e = lane; e < 729 + 27; e += 256) {
         if (e < 729) { const int i = e / 27, j = e - i * 27; v.mp_L[(size_t)w * 729 + e] = 0.5 * (A[(15 + i) * 43 + 15 + j] + A[(15 + j) * 43 + 15 + i]); }
         else {
@@ -3902,6 +3917,28 @@ __global__ void __launch_bounds__(256) k_marginalize(View v, int* status) {
         v.mp_on[w] = 1;
         v.prior_k[w] = -1;
         if (bad) atomicOr(status, bad & 4 ? 4 : 1);
+    }
+}
+
+// what k_marginalize (stash != null) computed ahead of time becomes the window's marginal prior, exactly as the kernel itself
+// would have left it
+__global__ void __launch_bounds__(256) k_marg_commit(View v, const double* __restrict__ stash) {
+    const int w = blockIdx.x, lane = threadIdx.x;
+    const double* st = stash + (size_t)w * MARG_STASH;
+    for (int e = lane; e < 729 + 27; e += 256) {
+        if (e < 729) v.mp_L[(size_t)w * 729 + e] = st[e];
+        else {
+            const double et = st[e];
+            v.mp_eta[(size_t)w * 27 + e - 729] = et;
+            v.mp_out[((size_t)0 * v.B + w) * 28 + e - 729] = et;
+            v.mp_out[((size_t)1 * v.B + w) * 28 + e - 729] = et;
+        }
+    }
+    if (lane == 0) { v.mp_out[((size_t)0 * v.B + w) * 28 + 27] = 0.0; v.mp_out[((size_t)1 * v.B + w) * 28 + 27] = 0.0; }
+    if (lane < 48) v.mp_x[(size_t)w * 48 + lane] = st[756 + lane];
+    if (lane == 0) {
+        v.mp_on[w] = 1;
+        v.prior_k[w] = -1;
     }
 }
 
@@ -4180,6 +4217,38 @@ void launch_predict(const View& v, int window, int k0, int n, int from_trial, hi
 void launch_relinearize(const View& v, double threshold, hipStream_t s) {
     hipLaunchKernelGGL(k_relinearize, dim3(nblk(v.G, 256)), dim3(256), 0, s, v, threshold);
 }
+__global__ void k_set_range(View v, int window, int lo, int hi) {
+    if (lo >= 0) v.lo[window] = lo;
+    v.hi[window] = hi;
+}
+__global__ void k_bump_lo(View v) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < v.B) v.lo[w] += 1;
+}
+__global__ void __launch_bounds__(64) k_put_between(View v, long g, int a, BtwArg rec) {
+    const int f = threadIdx.x;
+    if (f < BTW_IN) v.btw_in[(size_t)(g >> 6) * BTW_IN * TILE + (size_t)f * TILE + (g & 63)] = rec.r[f];
+    if (f == 0) v.btw_a[g] = a;
+}
+__global__ void __launch_bounds__(64) k_read_result(View v, int window, int slot, int which, int* sticky, SolveResult* out) {
+    const int t = threadIdx.x;
+    const int b = v.sel[window] ^ which;
+    if (t < 16) out->state[t] = XS(b, t, (long)window * v.M + slot);
+    if (t == 16) { out->cost = v.cost[window]; out->n_acc = v.n_acc[window]; out->n_rej = v.n_rej[window]; out->n_fail = v.n_fail[window]; }
+    if (t == 17) { out->sticky[0] = sticky[0]; out->sticky[1] = sticky[1]; sticky[0] = 0; sticky[1] = 0; }
+}
+void launch_set_range(const View& v, int window, int lo, int hi, hipStream_t s) {
+    hipLaunchKernelGGL(k_set_range, dim3(1), dim3(1), 0, s, v, window, lo, hi);
+}
+void launch_bump_lo(const View& v, hipStream_t s) {
+    hipLaunchKernelGGL(k_bump_lo, dim3(nblk(v.B, 64)), dim3(64), 0, s, v);
+}
+void launch_put_between(const View& v, long g, int a, const BtwArg& rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_put_between, dim3(1), dim3(64), 0, s, v, g, a, rec);
+}
+void launch_read_result(const View& v, int window, int slot, int which, int* sticky, SolveResult* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_read_result, dim3(1), dim3(64), 0, s, v, window, slot, which, sticky, out);
+}
 void launch_inc_begin(const View& v, double threshold, int appended, int invalid, hipStream_t s) {
     hipLaunchKernelGGL(k_inc_begin, dim3((unsigned)nblk(v.M, 256), (unsigned)v.B), dim3(256), 0, s, v, threshold, appended, invalid);
 }
@@ -4193,9 +4262,15 @@ void launch_inc_retract(const View& v, hipStream_t s) {
 void launch_slide(const View& v, const double* sigma15_dev, int reanchor, hipStream_t s) {
     hipLaunchKernelGGL(k_slide, dim3(nblk(v.B, 64)), dim3(64), 0, s, v, sigma15_dev, reanchor);
 }
+void launch_marginalize_ahead(const View& v, int* status, double* stash, hipStream_t s) {
+    hipLaunchKernelGGL(k_marginalize<false>, dim3(v.B), dim3(256), 0, s, v, status, stash);
+}
+void launch_marg_commit(const View& v, const double* stash, hipStream_t s) {
+    hipLaunchKernelGGL(k_marg_commit, dim3(v.B), dim3(256), 0, s, v, stash);
+}
 void launch_marginalize(const View& v, int* status, hipStream_t s) {
-    if (v.x_max > 0) hipLaunchKernelGGL(k_marginalize<true>, dim3(v.B), dim3(256), 0, s, v, status);
-    else hipLaunchKernelGGL(k_marginalize<false>, dim3(v.B), dim3(256), 0, s, v, status);
+    if (v.x_max > 0) hipLaunchKernelGGL(k_marginalize<true>, dim3(v.B), dim3(256), 0, s, v, status, (double*)nullptr);
+    else hipLaunchKernelGGL(k_marginalize<false>, dim3(v.B), dim3(256), 0, s, v, status, (double*)nullptr);
 }
 void launch_shift_copy(const double* src, double* dst, long n, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_shift_copy, dim3(nblk(n, 256)), dim3(256), 0, s, src, dst, n);

@@ -324,7 +324,19 @@ void launch_inc_begin(const View& v, double threshold, int appended, int invalid
 void launch_inc_solve(const View& v, hipStream_t s);
 void launch_inc_retract(const View& v, hipStream_t s);
 void launch_slide(const View& v, const double* sigma15_dev, int reanchor, hipStream_t s);
+// host scalars into device state without a copy (asynchronous staging: vf_engine_set_async): the active range of a window
+// (lo < 0: keep), every window's first keyframe moved on by one, one between record (28 doubles by value) into the slot of
+// its end key, and the result of a solve -- a state, the failure count, the sticky status words (cleared) -- into pinned memory
+struct BtwArg { double r[BTW_IN]; };
+struct SolveResult { double state[16]; double cost; int n_acc, n_rej, n_fail, sticky[2], pad; };
+void launch_set_range(const View& v, int window, int lo, int hi, hipStream_t s);
+void launch_bump_lo(const View& v, hipStream_t s);
+void launch_put_between(const View& v, long g, int a, const BtwArg& rec, hipStream_t s);
+void launch_read_result(const View& v, int window, int slot, int which, int* sticky, SolveResult* out, hipStream_t s);
 void launch_marginalize(const View& v, int* status, hipStream_t s);
+constexpr int MARG_STASH_DOUBLES = 729 + 27 + 48 + 4;     // per window: what k_marginalize leaves in a stash (information, gradient, linearisation states)
+void launch_marginalize_ahead(const View& v, int* status, double* stash, hipStream_t s);   // engines without far factors
+void launch_marg_commit(const View& v, const double* stash, hipStream_t s);
 void launch_shift_copy(const double* src, double* dst, long n, hipStream_t s);
 void launch_shift_btw_a(int* a, long G, int M, int shift, hipStream_t s);
 // AoS <-> AoSoA staging

@@ -378,10 +378,15 @@ def degeneracy_section():
             ach = T2 * nbytes / (ms * 1e-3) / 1e9
             roof["kernels"][f"{name}/{tag}"] = {"avg_launch_ms": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBPS,
                                                 "algorithmic_bytes_per_matrix": nbytes, "ns_per_matrix": ms * 1e6 / T2}
-    roof["note"] = ("d_opt (pivoted LU in registers) is the metric the shipped gate uses and is HBM-bound.  e_opt / condition_number "
-                    "(cyclic Jacobi on the upper triangle, rsq / rcp rotations, wave-wide convergence vote: 5-7 sweeps) are bound by "
-                    "float64 VALU issue, not HBM: their HBM fraction is quoted for completeness, the float64 operation counts per "
-                    "launch (SQ_INSTS_VALU_*_F64) and the fraction of the 78.6 TFLOP/s vector peak are in profiles/r04_k6_pmc.md")
+    for dt, tag, nbytes in ((np.float64, "f64", 296 + 16), (np.float32, "f32", 148 + 8)):
+        _, ms = dg.spectrum(big, "all", dtype=dt, reps=5)
+        ach = T2 * nbytes / (ms * 1e-3) / 1e9
+        roof["kernels"][f"spectrum(e_opt+max_eigen+condition_number)/{tag}"] = {"avg_launch_ms": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBPS,
+                                                                             "algorithmic_bytes_per_matrix": nbytes, "ns_per_matrix": ms * 1e6 / T2}
+    roof["note"] = ("d_opt (pivoted LU in registers) is the metric the shipped gate uses and is HBM-bound.  e_opt / max_eigen / condition_number "
+                    "(round 6: Householder tridiagonalisation + implicit QL with deflation in registers, the ends of the spectrum of ONE "
+                    "eigen-solve; condition_number of a symmetric matrix from it instead of a Jacobi SVD) are bound by float64 VALU issue, "
+                    "not HBM: their HBM fraction is quoted for completeness (round 5, cyclic Jacobi: 0.23 / 0.56 ns per matrix)")
     out["roofline_k6"] = roof
     return out
 

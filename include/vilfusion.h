@@ -495,6 +495,13 @@ int vf_engine_counts(vf_engine* e, int64_t* n_imu, int64_t* n_between, int64_t* 
 #define VF_METRIC_DIFFERENTIAL_ENTROPY 20
 int vf_degeneracy_batch(const void* mats, const void* pose, int count, int dtype, int subset, int metric,
                         void* out, int reps, float* kernel_ms);
+/* extra: the three metrics that read the ends of the spectrum -- e_opt, max_eigen, condition_number
+ * (degeneracy_detection_functions.py:74-82, 98-106, 239-243) -- of ONE eigen-solve per matrix, one launch, three outputs (each `count`
+ * values, [0] = 0): bit for bit what three vf_degeneracy_batch calls return, at a third of the work.  condition_number is NaN for a
+ * matrix that is not symmetric to rounding (its singular values are then not the moduli of its eigenvalues: ask
+ * vf_degeneracy_batch, which falls back to an SVD). */
+int vf_degeneracy_spectrum_batch(const void* mats, int count, int dtype, int subset, void* e_opt, void* max_eigen,
+                                 void* condition_number, int reps, float* kernel_ms);
 /* The shipped gate (gtsam_fusion/src/degerate_odometry_filter.cpp:29-47): float32 log det of the
  * rotation (3,3) and translation (0,0) 3x3 blocks of the 36-float LOAM Hessian; keep[i] = 0 when
  * either is below its threshold (fusion_params.yaml:35-36: 11.5 / 28.9). */

@@ -99,3 +99,21 @@ def test_degeneracy_gate_object():
     np.testing.assert_allclose(trans[0], np.log(2e4 * 3e4 * 2.5e4), rtol=1e-5)
     np.testing.assert_allclose(rot[2], np.log(60.0 * 70.0 * 5.0), rtol=1e-5)
     assert gate(good.reshape(36)) and not gate(bad_t.reshape(36)) and gate.dropped == 1
+
+
+def test_spectrum_is_the_three_metrics_of_one_eigen_solve():
+    """vf_degeneracy_spectrum_batch: e_opt, max_eigen, condition_number in one launch, bit for bit the per-metric calls"""
+    from vil_sensor_fusion_amd import degeneracy as dg
+    for kind in ("well", "illcond", "tunnel"):
+        mats = GOLD[f"{kind}_mats"]
+        for sub in ("all", "trans", "rot"):
+            for dt in (np.float64, np.float32):
+                got = dg.spectrum(mats, sub, dtype=dt)
+                for name in ("e_opt", "max_eigen", "condition_number"):
+                    np.testing.assert_array_equal(got[name], dg.apply_degen_function(mats, None, sub, name, dtype=dt), err_msg=f"{kind}/{sub}/{name}")
+    # a matrix that is not symmetric: condition_number is the SVD's business
+    m = np.ascontiguousarray(np.tile(np.triu(np.arange(1.0, 37.0).reshape(6, 6))[:, :, None], (1, 1, 70)))
+    got = dg.spectrum(m, "all")
+    assert np.isnan(got["condition_number"][1:]).all() and np.isfinite(got["e_opt"]).all()
+    ref = dg.apply_degen_function(m, None, "all", "condition_number")
+    np.testing.assert_allclose(ref[1:], -np.linalg.cond(m[:, :, 1]), rtol=1e-9)

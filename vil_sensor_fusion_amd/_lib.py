@@ -85,7 +85,7 @@ SYMBOLS = [
     "vf_add_between", "vf_solve", "vf_get_state", "vf_get_bias", "vf_most_recent_pose_time",
     "vf_set_callback", "vf_graph_staged", "vf_get_trajectory", "vf_get_imu_factor",
     "vf_add_imu_factor", "vf_get_most_recent_estimate", "vf_graph_lm_stats", "vf_graph_solver_info", "vf_set_initial_state", "vf_graph_incremental_info", "vf_graph_get_staged",
-    "vf_degeneracy_batch", "vf_dopt_filter_f32",
+    "vf_degeneracy_batch", "vf_degeneracy_spectrum_batch", "vf_dopt_filter_f32",
 ]
 
 

@@ -106,6 +106,113 @@ DI void jacobi_eig(T (&a)[N * N], T (&ev)[N], bool active) {
     for (int i = 0; i < N; i++) ev[i] = a[i * N + i];
 }
 
+// Symmetric eigenvalues by Householder tridiagonalisation + implicit QL with Wilkinson shifts and deflation, all in registers
+// (compile-time indices; what varies from lane to lane -- where the unreduced block ends, whether a lane has converged -- is
+// carried by selects, never by an index).  The metrics need the two ends of the spectrum only, and a full cyclic Jacobi
+// (5-7 sweeps of 15 rotations, every rotation touching two rows and two columns: 4 900 vector instructions per wave for a 6 x 6)
+// pays for eigenvectors nobody asked for; here the N - 2 reflections cost ~250 instructions and every QL iteration is N - 1 - l
+// rotations of a tridiagonal (three numbers each): ~1 800 in all.  Accuracy is that of LAPACK's tridiagonal QL -- absolute,
+// eps * |A| -- which is what the reference's own numpy.linalg.eigvals / cond deliver (Jacobi's relative accuracy on graded
+// matrices is not needed: tests/test_gpu_degeneracy.py holds e_opt to 1e-9 * max|A|).  The upper triangle of `a` is read;
+// a is destroyed.
+template <typename T, int N>
+DI void sym_eig(T (&a)[N * N], T (&d)[N], bool active) {
+    T e[N];          // e[k] couples k and k + 1; e[N - 1] = 0 is the sentinel of the QL loop
+#pragma unroll
+    for (int k = 0; k < N; k++) e[k] = T(0);
+    // ---- Householder: rows i = N-1 .. 2 of the lower triangle (held as a[c * N + r], c <= r: the upper triangle of the array)
+#define SA(r, c) a[((r) < (c) ? (r) : (c)) * N + ((r) < (c) ? (c) : (r))]
+#pragma unroll
+    for (int i = N - 1; i >= 2; i--) {
+        T tail = T(0);      // what the reflection has to annihilate: row i, columns 0 .. i-2
+#pragma unroll
+        for (int k = 0; k < i - 1; k++) tail = fma(SA(i, k), SA(i, k), tail);
+        const T xl = SA(i, i - 1);
+        const T sigma = fma(xl, xl, tail);
+        const bool skip = !(tail > T(0));                 // already tridiagonal here (or a lane without a matrix)
+        const T nrm = sigma * rsq_full(skip ? T(1) : sigma);
+        const T alpha = -copysign(nrm, xl);
+        const T h = fma(-xl, alpha, sigma);                // = v.v / 2 with v = x - alpha e
+        const T inv_h = skip ? T(0) : rcp_full(h);
+        T v[N], pv[N];
+#pragma unroll
+        for (int k = 0; k < i; k++) v[k] = skip ? T(0) : (k == i - 1 ? xl - alpha : SA(i, k));
+        T f = T(0);
+#pragma unroll
+        for (int j = 0; j < i; j++) {
+            T g = T(0);
+#pragma unroll
+            for (int k = 0; k < i; k++) g = fma(SA(j, k), v[k], g);
+            pv[j] = g * inv_h;
+            f = fma(pv[j], v[j], f);
+        }
+        const T hh = T(0.5) * f * inv_h;
+#pragma unroll
+        for (int j = 0; j < i; j++) pv[j] = fma(-hh, v[j], pv[j]);
+#pragma unroll
+        for (int j = 0; j < i; j++)
+#pragma unroll
+            for (int k = 0; k <= j; k++) SA(j, k) = SA(j, k) - fma(v[j], pv[k], pv[j] * v[k]);
+        e[i - 1] = skip ? xl : alpha;
+    }
+    if (N >= 2) e[0] = SA(1, 0);
+#pragma unroll
+    for (int k = 0; k < N; k++) d[k] = SA(k, k);
+#undef SA
+    // ---- implicit QL (the classical tqli recurrence), eigenvalue by eigenvalue
+#pragma unroll
+    for (int l = 0; l < N - 1; l++) {
+#pragma unroll 1
+        for (int iter = 0; iter < 40; iter++) {
+            int m = N - 1;                                  // the smallest m >= l whose coupling to m + 1 is negligible
+#pragma unroll
+            for (int k = N - 2; k >= l; k--) {
+                const T dd = t_abs(d[k]) + t_abs(d[k + 1]);
+                m = (t_abs(e[k]) <= Lim<T>::eps * dd) ? k : m;
+            }
+            const bool work = active && m != l;
+            if (!__any(work)) break;
+            const T el = work ? e[l] : T(1);
+            T g = (d[l + 1] - d[l]) * rcp_full(el + el);
+            T r2 = fma(g, g, T(1));
+            T r = r2 * rsq_full(r2);
+            T dm = d[N - 1];
+#pragma unroll
+            for (int k = N - 2; k > l; k--) dm = (m == k) ? d[k] : dm;
+            g = dm - d[l] + el * rcp_full(g + copysign(r, g));
+            T sn = T(1), cs = T(1), pp = T(0);
+            bool brk = false;
+            // (the lanes that take no part in a rotation are masked off by the branch, not by selects on every result: a
+            // rotation is ~26 vector instructions this way, ~40 with selects)
+#pragma unroll
+            for (int i = N - 2; i >= l; i--) {
+                if (work && i < m && !brk) {
+                    const T f = sn * e[i], b = cs * e[i];
+                    const T rr = fma(f, f, g * g);
+                    if (!(rr > T(0))) {              // (underflow: the block has split here)
+                        e[i + 1] = T(0);
+                        d[i + 1] -= pp;
+                        brk = true;
+                    } else {
+                        const T inv = rsq_full(rr);
+                        e[i + 1] = rr * inv;
+                        sn = f * inv;
+                        cs = g * inv;
+                        const T gg = d[i + 1] - pp;
+                        const T rot = fma(d[i] - gg, sn, T(2) * cs * b);
+                        pp = sn * rot;
+                        d[i + 1] = gg + pp;
+                        g = fma(cs, rot, -b);
+                    }
+                }
+            }
+            if (work && !brk) { d[l] -= pp; e[l] = g; }
+#pragma unroll
+            for (int k = l; k < N; k++) e[k] = (work && m == k) ? T(0) : e[k];
+        }
+    }
+}
+
 // singular values of a general matrix, one-sided (Hestenes) Jacobi on the columns; a sweep in which no lane of the wave
 // rotated ends the iteration
 template <typename T, int N>
@@ -320,12 +427,13 @@ DI void ratio_eig(const T (&now)[N * N], const T (&prev)[N * N], T (&ev)[N], boo
     for (int r = 0; r < N; r++)
 #pragma unroll
         for (int c = r + 1; c < N; c++) { const T m = T(0.5) * (S[r * N + c] + S[c * N + r]); S[r * N + c] = m; S[c * N + r] = m; }
-    jacobi_eig<T, N>(S, ev, active);
+    sym_eig<T, N>(S, ev, active);
 }
 
 enum Metric { D_OPT, D_OPT_RATIO, A_OPT, A_OPT_RATIO, E_OPT, E_OPT_RATIO, MAX_EIGEN, MAX_EIGEN_RATIO, JENSEN_BREGMAN,
               CORR_DIST, KULLBACK_LEIBLER, NORM_FRO, NORM_FRO_RATIO, NORM_NUC, NORM_NUC_RATIO, NORM_1, NORM_1_RATIO,
-              NORM_2, NORM_2_RATIO, COND_NUMBER, DIFF_ENTROPY, N_METRICS };
+              NORM_2, NORM_2_RATIO, COND_NUMBER, DIFF_ENTROPY, N_METRICS,
+              SPECTRUM = N_METRICS };     // (not a metric of the reference: e_opt, max_eigen and condition_number of one eigen-solve, vf_degeneracy_spectrum_batch)
 
 template <typename T, int N>
 DI T norm1(const T (&a)[N * N]) {
@@ -362,7 +470,7 @@ constexpr int MSTRIDE = 37;   // LDS stride of one 6x6 (36 + 1 pad: 64 lanes rea
 // only its own arithmetic and loads the previous matrix only if it uses it.
 template <typename T, int N, int METRIC>
 __global__ void __launch_bounds__(64) k_degeneracy(const T* __restrict__ mats, const T* __restrict__ pose, int count, int off,
-                                                   T* __restrict__ out) {
+                                                   T* __restrict__ out, T* __restrict__ out2 = nullptr, T* __restrict__ out3 = nullptr) {
     // staged in two halves of 32 messages (lanes 0-31 pick theirs up after the first, 32-63 after the second): 9.8 KB of LDS
     // per wave instead of 19.2, i.e. four waves per SIMD instead of two for the Jacobi kernels
     __shared__ T lds[33 * MSTRIDE];
@@ -425,13 +533,37 @@ __global__ void __launch_bounds__(64) k_degeneracy(const T* __restrict__ mats, c
             for (int k = 0; k < N; k++) s += (METRIC == A_OPT) ? now[k * N + k] : ratio[k * N + k];
             y = s;
         } break;
+        case SPECTRUM: {
+            // the three metrics that read the ends of the spectrum, from ONE eigen-solve of the symmetric part (e_opt and max_eigen
+            // are defined on it; condition_number too whenever the matrix is symmetric to rounding, see COND_NUMBER below --
+            // other matrices get NaN there and the caller asks for condition_number by itself)
+            T s[N * N], ev[N], asym = T(0), big = T(0);
+#pragma unroll
+            for (int r = 0; r < N; r++)
+#pragma unroll
+                for (int c = 0; c < N; c++) {
+                    s[r * N + c] = T(0.5) * (now[r * N + c] + now[c * N + r]);
+                    big = t_abs(now[r * N + c]) > big ? t_abs(now[r * N + c]) : big;
+                    if (c > r) { const T dsy = t_abs(now[r * N + c] - now[c * N + r]); asym = dsy > asym ? dsy : asym; }
+                }
+            sym_eig<T, N>(s, ev, active);
+            T lo = ev[0], hi = ev[0], alo = t_abs(ev[0]), ahi = t_abs(ev[0]);
+#pragma unroll
+            for (int k = 1; k < N; k++) {
+                lo = ev[k] < lo ? ev[k] : lo; hi = ev[k] > hi ? ev[k] : hi;
+                const T x = t_abs(ev[k]); alo = x < alo ? x : alo; ahi = x > ahi ? x : ahi;
+            }
+            y = lo;
+            if (i == 0) { out2[0] = T(0); out3[0] = T(0); }
+            else if (i < count) { out2[i] = hi; out3[i] = asym <= T(8) * Lim<T>::eps * big ? -(ahi / alo) : nan; }
+        } break;
         case E_OPT: case MAX_EIGEN: {
             T s[N * N], ev[N];
 #pragma unroll
             for (int r = 0; r < N; r++)
 #pragma unroll
                 for (int c = 0; c < N; c++) s[r * N + c] = T(0.5) * (now[r * N + c] + now[c * N + r]);
-            jacobi_eig<T, N>(s, ev, active);
+            sym_eig<T, N>(s, ev, active);
             T lo = ev[0], hi = ev[0];
 #pragma unroll
             for (int k = 1; k < N; k++) { lo = ev[k] < lo ? ev[k] : lo; hi = ev[k] > hi ? ev[k] : hi; }
@@ -494,6 +626,34 @@ __global__ void __launch_bounds__(64) k_degeneracy(const T* __restrict__ mats, c
         case NORM_NUC: case NORM_2: case COND_NUMBER: case NORM_NUC_RATIO: case NORM_2_RATIO: {
             T w[N * N], sv[N];
             constexpr bool r = METRIC == NORM_NUC_RATIO || METRIC == NORM_2_RATIO;
+            if (METRIC == NORM_NUC || METRIC == NORM_2 || METRIC == COND_NUMBER) {
+                // An information matrix is symmetric, and the singular values of a symmetric matrix are the moduli of its
+                // eigenvalues: sigma_max / sigma_min, the sum and the maximum come from the eigen-solve e_opt / max_eigen use, at a
+                // seventh of the cost of a Jacobi SVD.  "Symmetric" = to within rounding of the entries (an asymmetry of that
+                // size moves a singular value by as much: what the SVD's own rounding does); a wave with a lane that holds
+                // anything else takes the general path below.
+                T asym = T(0), big = T(0);
+#pragma unroll
+                for (int rr = 0; rr < N; rr++)
+#pragma unroll
+                    for (int cc = 0; cc < N; cc++) {
+                        big = t_abs(now[rr * N + cc]) > big ? t_abs(now[rr * N + cc]) : big;
+                        if (cc > rr) { const T dsy = t_abs(now[rr * N + cc] - now[cc * N + rr]); asym = dsy > asym ? dsy : asym; }
+                    }
+                if (__all(!active || asym <= T(8) * Lim<T>::eps * big)) {
+                    T sy[N * N], ev[N];
+#pragma unroll
+                    for (int rr = 0; rr < N; rr++)
+#pragma unroll
+                        for (int cc = 0; cc < N; cc++) sy[rr * N + cc] = T(0.5) * (now[rr * N + cc] + now[cc * N + rr]);
+                    sym_eig<T, N>(sy, ev, active);
+                    T lo = t_abs(ev[0]), hi = t_abs(ev[0]), sum = T(0);
+#pragma unroll
+                    for (int k = 0; k < N; k++) { const T x = t_abs(ev[k]); lo = x < lo ? x : lo; hi = x > hi ? x : hi; sum += x; }
+                    y = METRIC == NORM_NUC ? sum : (METRIC == COND_NUMBER ? -(hi / lo) : hi);
+                    break;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < N * N; k++) w[k] = r ? ratio[k] : now[k];
             jacobi_svd<T, N>(w, sv, active);
@@ -525,6 +685,9 @@ void launch_degeneracy(int metric, dim3 grid, const T* m, const T* p, int count,
 #undef VF_K6_CASE
 }
 static_assert(N_METRICS == 21, "launch_degeneracy lists every metric");
+
+template <typename T>
+int run_spectrum(const void* mats, int count, int subset, void* o_min, void* o_max, void* o_cond, int reps, float* kernel_ms);
 
 // degerate_odometry_filter.cpp:29-47 (float32): hessian (row-major floats) copied into a
 // column-major Eigen matrix, rotation = block(3,3), translation = block(0,0), log(det)
@@ -598,9 +761,57 @@ int run_batch(const void* mats, const void* pose, int count, int subset, int met
     return VF_OK;
 }
 
+template <typename T>
+int run_spectrum(const void* mats, int count, int subset, void* o_min, void* o_max, void* o_cond, int reps, float* kernel_ms) {
+    T *d_m = nullptr, *d_o = nullptr;
+    const size_t mb = (size_t)count * 36 * sizeof(T), ob = (size_t)count * sizeof(T);
+    HIPCHK(hipMalloc((void**)&d_m, mb));
+    HIPCHK(hipMalloc((void**)&d_o, 3 * ob));
+    HIPCHK(hipMemcpy(d_m, mats, mb, hipMemcpyHostToDevice));
+    const int off = subset == 2 ? 3 : 0;
+    const dim3 grid((count + 63) / 64);
+    auto launch = [&]() {
+        if (subset == 0) hipLaunchKernelGGL((k_degeneracy<T, 6, SPECTRUM>), grid, dim3(64), 0, 0, d_m, (const T*)nullptr, count, off, d_o, d_o + count, d_o + 2 * (size_t)count);
+        else hipLaunchKernelGGL((k_degeneracy<T, 3, SPECTRUM>), grid, dim3(64), 0, 0, d_m, (const T*)nullptr, count, off, d_o, d_o + count, d_o + 2 * (size_t)count);
+    };
+    launch();
+    HIPCHK(hipDeviceSynchronize());
+    if (kernel_ms && reps > 0) {
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, 0));
+        for (int r = 0; r < reps; r++) launch();
+        HIPCHK(hipEventRecord(e1, 0));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        *kernel_ms = ms / reps;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(o_min, d_o, ob, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(o_max, d_o + count, ob, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(o_cond, d_o + 2 * (size_t)count, ob, hipMemcpyDeviceToHost));
+    (void)hipFree(d_m); (void)hipFree(d_o);
+    return VF_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int vf_degeneracy_spectrum_batch(const void* mats, int count, int dtype, int subset, void* e_opt, void* max_eigen, void* condition_number,
+                                 int reps, float* kernel_ms) {
+    if (!mats || !e_opt || !max_eigen || !condition_number || count < 0) return derr(VF_ERR_INVALID, "null argument");
+    if (subset < 0 || subset > 2) return derr(VF_ERR_INVALID, "subset must be 0 (all), 1 (trans) or 2 (rot)");
+    if (dtype != 0 && dtype != 1) return derr(VF_ERR_INVALID, "dtype must be 0 (f64) or 1 (f32)");
+    if (count == 0) return VF_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return derr(VF_ERR_NO_DEVICE, "no HIP device visible; libvilfusion has no CPU path");
+    return dtype == 0 ? run_spectrum<double>(mats, count, subset, e_opt, max_eigen, condition_number, reps, kernel_ms)
+                      : run_spectrum<float>(mats, count, subset, e_opt, max_eigen, condition_number, reps, kernel_ms);
+}
 
 int vf_degeneracy_batch(const void* mats, const void* pose, int count, int dtype, int subset, int metric, void* out,
                         int reps, float* kernel_ms) {

@@ -43,6 +43,23 @@ def apply_degen_function(matrix, pose, matrix_subset, func, dtype=np.float64, re
     return (out, ms.value) if reps > 0 else out
 
 
+def spectrum(matrix, matrix_subset="all", dtype=np.float64, reps=0):
+    """e_opt, max_eigen and condition_number of every matrix of a (6,6,T) stack from ONE eigen-solve each (one launch, three
+    outputs; bit for bit what three apply_degen_function calls return).  condition_number is NaN where a matrix is not
+    symmetric to rounding.  Returns a dict (and the kernel time in ms with reps > 0)."""
+    if matrix_subset not in SUBSETS:
+        raise RuntimeWarning("Invalid matrix subset {}".format(matrix_subset))
+    m = np.ascontiguousarray(np.asarray(matrix).transpose(2, 0, 1), dtype=dtype)
+    if m.shape[1:] != (6, 6):
+        raise ValueError("matrix must be (6,6,T)")
+    outs = [np.zeros(m.shape[0], dtype=dtype) for _ in range(3)]
+    ms = C.c_float(0)
+    check(_lib.lib().vf_degeneracy_spectrum_batch(m.ctypes.data_as(C.c_void_p), m.shape[0], 0 if dtype == np.float64 else 1, SUBSETS[matrix_subset],
+                                                 *[o.ctypes.data_as(C.c_void_p) for o in outs], reps, C.byref(ms)))
+    res = dict(e_opt=outs[0], max_eigen=outs[1], condition_number=outs[2])
+    return (res, ms.value) if reps > 0 else res
+
+
 def dopt_filter(hessians, rot_thr=ROT_DEGEN_THRESHOLD, trans_thr=TRANS_DEGEN_THRESHOLD):
     """(T,36) or (T,6,6) float32 LOAM Hessians -> (rot_dopt, trans_dopt, keep) like the shipped node."""
     h = np.ascontiguousarray(hessians, dtype=np.float32).reshape(-1, 36)

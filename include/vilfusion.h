@@ -95,7 +95,10 @@ typedef struct {
     int refine_min_keyframes;  /* default 1536: Gauss-Newton by normal equations alone contracts by 0.025 per update at 1 250 keyframes, 0.1 at
                                   1 500, 0.3 at 2 000, 0.7 at 3 000 and creeps beyond */
     double refine_rel_stop;    /* a window stops correcting once res . M^-1 res has fallen to this, squared, times its first value
-                                  (default 1e-8), or stops being positive; its remaining correction solves are skipped on the
+                                  (default 1e-8), or stops being positive.  In auto mode (refine_iterations = -1) the tolerance EASES IN:
+                                  1e-3 for a window of refine_min_keyframes, tightening log-linearly to this value at twice that length
+                                  (what the normal equations get wrong grows smoothly with the window; a switch from no correction to
+                                  "until 1e-8" at one length made a solve four times dearer from 1 500 to 1 600 keyframes); its remaining correction solves are skipped on the
                                   device (no host synchronisation).  How many corrections that takes grows with the window: 4 at
                                   1 600 keyframes, 5 at 2 500, 7 at 4 000, 9 at 6 000, 12 at 10 000 (tools/refine_trace_sizes.py) */
     /* Non-monotone LM ("excursions").  On a long window the Gauss-Newton step moves the far end by metres through

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
@@ -289,6 +290,20 @@ struct vf_engine {
         int longest = 0;
         for (int w = 0; w < v.B; w++) longest = std::max(longest, h_hi[w] - h_lo[w]);
         return longest > opts.refine_min_keyframes ? 12 : 0;
+    }
+    // ... and how far each solve's corrections are driven (auto mode).  What the normal equations get wrong grows smoothly with
+    // the window -- plain Gauss-Newton contracts by 0.1 per update at 1 500 keyframes, 0.3 at 2 000, 0.7 at 3 000 -- so the
+    // residual reduction a solve is refined to tightens smoothly too, from 1e-3 where refinement starts to refine_rel_stop at
+    // twice that length: 1-2 corrections just above the threshold instead of 4, 5 at 3 000 as before (round 5's switch from
+    // none to "until 1e-8" made vf_solve four times dearer between 1 500 and 1 600 keyframes).
+    double refine_stop() const {
+        if (opts.refine_iterations >= 0 || !(opts.refine_rel_stop < 1e-3)) return opts.refine_rel_stop;
+        int longest = 0;
+        for (int w = 0; w < v.B; w++) longest = std::max(longest, h_hi[w] - h_lo[w]);
+        const double n0 = opts.refine_min_keyframes, n1 = 2.0 * n0;
+        if (longest >= n1 || n0 <= 0) return opts.refine_rel_stop;
+        const double t = std::max(0.0, (longest - n0) / (n1 - n0));
+        return std::pow(10.0, -3.0 + t * (std::log10(opts.refine_rel_stop) + 3.0));
     }
     // non-monotone LM (vf_engine_opts.lm_excursion): provisional trials allowed per excursion; auto = 3 on engines that refine
     int excursion() const { return opts.lm_excursion >= 0 ? opts.lm_excursion : (refine_iters() > 0 ? 3 : 0); }
@@ -1100,13 +1115,13 @@ int vf_engine_solve(vf_engine* e) {
                 a.done = e->rq.stop;
                 vf::launch_extra_combine(a, far_Z, far_zstride, e->x_used, e->stream);
             }
-            vf::launch_refine_step(e->v, e->rq, e->opts.refine_rel_stop, e->stream);
+            vf::launch_refine_step(e->v, e->rq, e->refine_stop(), e->stream);
             // How many corrections a window needs grows with its length (4 at 1 600 keyframes, 12 at 10 000): after the
             // 4th, 6th, ... the stop flags are read back, and once every window has stopped the rest are not issued
             // (a skipped correction is ~15 empty launches; the read-back costs one stream synchronisation)
             hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(e->stream, &capturing);      // (a caller capturing its own stream: no read-back, every correction is issued)
-            if (it >= 3 && it % 2 == 1 && it + 1 < R && capturing == hipStreamCaptureStatusNone) {
+            if (it >= 1 && it % 2 == 1 && it + 1 < R && capturing == hipStreamCaptureStatusNone) {
                 HIPCHK(hipMemcpyAsync(e->rq_stop_host, e->rq.stop, e->v.B * sizeof(int), hipMemcpyDeviceToHost, e->stream));
                 HIPCHK(hipStreamSynchronize(e->stream));
                 bool live = false;
@@ -1141,7 +1156,7 @@ int vf_engine_refine_begin(vf_engine* e) {
 int vf_engine_refine_step(vf_engine* e) {
     DeviceGuard dev_guard_(e);
     if (!e || !e->refine_open) return fail(VF_ERR_INVALID, "no refinement open (vf_engine_refine_begin)");
-    vf::launch_refine_step(e->v, e->rq, e->opts.refine_rel_stop, e->stream);
+    vf::launch_refine_step(e->v, e->rq, e->refine_stop(), e->stream);
     HIPCHK(hipGetLastError());
     return VF_OK;
 }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -154,8 +155,29 @@ struct vf_engine {
         return p;
     }
 
+    // The arrays of an engine are carved out of ONE device allocation made at creation (reserve(): a hipMalloc costs 0.1-0.3 ms
+    // whatever its size, and an engine has forty arrays -- creating the 6-window column engine of a first loop closure inside a
+    // vf_solve took 13 ms of which the memory itself was the least); what does not fit, or comes later, is allocated on its own.
+    char* arena = nullptr;
+    size_t arena_size = 0, arena_used = 0;
+    int reserve(size_t bytes) {
+        void* q = nullptr;
+        HIPCHK(hipMalloc(&q, bytes));
+        allocs.push_back(q);
+        HIPCHK(hipMemsetAsync(q, 0, bytes, stream));
+        arena = (char*)q;
+        arena_size = bytes;
+        arena_used = 0;
+        return VF_OK;
+    }
     template <typename T>
     int alloc(T** p, size_t n, bool zero = true) {
+        const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+        if (arena && arena_used + bytes <= arena_size) {
+            *p = (T*)(arena + arena_used);           // (zeroed by reserve())
+            arena_used += bytes;
+            return VF_OK;
+        }
         void* q = nullptr;
         HIPCHK(hipMalloc(&q, n * sizeof(T)));
         allocs.push_back(q);
@@ -416,7 +438,13 @@ void vf_engine_default_tuning_sized(vf_engine_tuning* t, uint32_t struct_size) {
 void vf_engine_default_tuning(vf_engine_tuning* t) { vf_engine_default_tuning_sized(t, (uint32_t)sizeof(vf_engine_tuning)); }
 
 int vf_engine_create(const vf_engine_opts* o, vf_engine** out) { return vf_engine_create_tuned(o, nullptr, out); }
+// on_stream: the engine works on a stream somebody else owns (the column engine of a handle's far factors, the engine a growing
+// handle moves into) -- hipStreamCreate costs 9 ms on this stack (the HSA queue behind it), more than everything else here together
+static int create_engine(const vf_engine_opts* o_in, const vf_engine_tuning* t_in, bool on_stream, hipStream_t given, vf_engine** out);
 int vf_engine_create_tuned(const vf_engine_opts* o_in, const vf_engine_tuning* t_in, vf_engine** out) {
+    return create_engine(o_in, t_in, false, nullptr, out);
+}
+static int create_engine(const vf_engine_opts* o_in, const vf_engine_tuning* t_in, bool on_stream, hipStream_t given, vf_engine** out) {
     if (!o_in || !out) return fail(VF_ERR_INVALID, "null argument");
     // the structs as THIS library knows them: the caller's bytes over the defaults
     vf_engine_opts o_full;
@@ -463,11 +491,23 @@ int vf_engine_create_tuned(const vf_engine_opts* o_in, const vf_engine_tuning* t
     v.split_min = t->solve_split_min > 0 ? t->solve_split_min : 0;
     v.asm_min = t->solve_assemble_min > 0 ? t->solve_assemble_min : 0;
     v.asm_waves = t->solve_assemble_waves == 1 ? 1 : 2;
-    HIPCHK(hipStreamCreate(&e->stream));
+    if (on_stream) { e->stream = given; e->own_stream = false; }
+    else HIPCHK(hipStreamCreate(&e->stream));
     HIPCHK(hipEventCreate(&e->ev0));
     HIPCHK(hipEventCreate(&e->ev1));
     const size_t G = (size_t)v.G, tiles = G / 64;
     int rc = VF_OK;
+    {
+        // everything the AL() lines below ask for, plus slack for their 256-byte alignment (alloc() falls back to allocations of
+        // its own if this estimate is ever short)
+        const size_t P0 = o->chunks >= 2 ? (size_t)o->chunks : (o->chunks == 0 && o->windows <= 128 ? 96 : 0);
+        size_t dbl = G * (32 + vf::HROW + 15 + 15 + vf::PANEL) + tiles * 64 * (vf::IMU_IN + 2 * vf::IMU_R + vf::BTW_IN + 2 * vf::BTW_OUT) +
+                     2 * (G / vf::JT) * vf::JT_STRIDE + 64 + (size_t)v.B * (vf::PRIOR_IN + 2 * vf::PRIOR_OUT + 48 + 729 + 27 + 56 + 8) + vf::HROW + vf::PLACE_CELLS;
+        if (P0 >= 2) dbl += G * vf::VROW + (size_t)v.B * P0 * (vf::SEPK + vf::SEPL);
+        if (o->incremental) dbl += (G >> vf::CK_LOG) * vf::CK_SZ;
+        const size_t ints = G + 16 * (size_t)v.B + 64;
+        if ((rc = e->reserve(dbl * sizeof(double) + ints * sizeof(int) + 64 * 256)) != VF_OK) { vf_engine_destroy(e); return rc; }
+    }
 #define AL(p, n) if ((rc = e->alloc(&(p), (n))) != VF_OK) { vf_engine_destroy(e); return rc; }
     AL(v.x, 2 * 16 * G);
     AL(v.imu_in, tiles * vf::IMU_IN * 64);
@@ -789,23 +829,34 @@ int vf_engine_set_extra_between(vf_engine* e, int window, int n, const int32_t* 
         if (!(rec[(size_t)i * vf::BTW_IN + 7] > 0.0)) return fail(VF_ERR_NOT_SPD, "far between factor %d: singular square-root information", i);
     }
     if (e->v.x_max == 0 && n == 0) return VF_OK;
+    static const bool timing = getenv("VF_SOLVE_TIMING") != nullptr;
+    auto t_a = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (timing) { auto t_b = std::chrono::steady_clock::now(); fprintf(stderr, "[set_extra] %-14s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t_b - t_a).count()); t_a = t_b; } };
     {
         int need = n + e->h_ln(window);                   // slots in use once this call is through
         for (int w = 0; w < B && e->v.x_max; w++) if (w != window) need = std::max(need, e->h_xn[w] + e->h_ln(w));
         if ((rc = e->ensure_far(need))) return rc;
     }
     e->attach_far();
+    lap("ensure_far");
+    // the column engine holds a copy of the window's H per Woodbury column: sized by the far factors alive (6 columns each), grown
+    // by doubling -- one loop closure costs 6 windows (0.14 GB, 2 ms to make at 1 200 slots), not the 48 of VF_MAX_EXTRA (1.3 GB, 13 ms)
+    const int far_need = n + e->h_ln(window);
+    if (e->far_columns && e->far_columns->v.B < 6 * far_need) { vf_engine_destroy(e->far_columns); e->far_columns = nullptr; }
     if (n > 0 && !e->far_columns && !e->is_far_columns && B == 1 && e->v.P >= 2 && e->tune.far_batch_columns) {
         vf_engine_opts co = e->opts;
-        co.windows = 6 * VF_MAX_EXTRA;
+        int slots = 1;
+        while (slots < far_need) slots *= 2;
+        co.windows = 6 * (slots < VF_MAX_EXTRA ? slots : VF_MAX_EXTRA);
         co.capacity = M;
         co.incremental = 0;
         vf_engine_tuning ct = e->tune;
         ct.use_hip_graph = 0;
         vf_engine* c = nullptr;
-        if (vf_engine_create_tuned(&co, &ct, &c) == VF_OK) {
+        if (create_engine(&co, &ct, true, e->stream, &c) == VF_OK) {
+            lap("create columns");
             c->is_far_columns = true;
-            if (c->v.P == e->v.P && c->v.P_fit == e->v.P_fit && vf_engine_set_stream(c, (void*)e->stream) == VF_OK) e->far_columns = c;
+            if (c->v.P == e->v.P && c->v.P_fit == e->v.P_fit) e->far_columns = c;
             else vf_engine_destroy(c);
         }
     }
@@ -823,6 +874,7 @@ int vf_engine_set_extra_between(vf_engine* e, int window, int n, const int32_t* 
     for (int bf = 0; bf < 2; bf++)
         HIPCHK(hipMemsetAsync(e->v.x_out + ((size_t)bf * B + window) * X * vf::BTW_OUT, 0, (size_t)X * vf::BTW_OUT * sizeof(double), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    lap("lists");
     e->h_xn[window] = n;
     e->recount_far();
     e->epoch++;        // (the number of band solves per trial is baked into a captured launch sequence)
@@ -2056,7 +2108,7 @@ int vf_engine_grow(vf_engine* e, int new_capacity) {
     vf_engine_opts o = e->opts;
     o.capacity = M1;
     vf_engine* n = nullptr;
-    int rc = vf_engine_create_tuned(&o, &e->tune, &n);
+    int rc = create_engine(&o, &e->tune, true, e->stream, &n);     // (on the stream the handle has: the old engine's, handed over below)
     if (rc) return rc;
     const vf::View &a = e->v, &b = n->v;
     const int B = a.B;
@@ -2093,9 +2145,7 @@ int vf_engine_grow(vf_engine* e, int new_capacity) {
     n->h_lo = e->h_lo;
     n->h_hi = e->h_hi;
     if (e->v.stop_on && (rc = vf_engine_set_convergence(n, e->v.rel_tol, e->v.abs_tol))) { vf_engine_destroy(n); return rc; }
-    if (!e->own_stream) {          // the caller's stream stays the one every later stage runs on
-        if ((rc = vf_engine_set_stream(n, (void*)e->stream))) { vf_engine_destroy(n); return rc; }
-    }
+    // (n works on e's stream already -- the caller's, or the handle's own, whose ownership moves to n with the swap below)
     if (e->v.x_max > 0 && e->x_used > 0) {
         // far between factors: the linear ones (they exist on the device only; their arrays do not depend on the capacity) copied,
         // the others re-sent from the host copies
@@ -2143,8 +2193,16 @@ int vf_engine_grow(vf_engine* e, int new_capacity) {
     n->marg_since_drop = e->marg_since_drop;
     n->inc_updates = e->inc_updates;
     n->inc_full = e->inc_full;
+    n->own_stream = e->own_stream;
     std::swap(*e, *n);             // *e: the grown engine; *n: the old buffers
-    n->own_stream = n->own_stream && n->stream != e->stream;
+    n->own_stream = false;         // (the stream lives on in *e)
+    // the asynchronous-staging resources (second stream, events, sticky words, pinned result block) move with the handle too
+    std::swap(e->async_on, n->async_on);
+    std::swap(e->stream2, n->stream2);
+    std::swap(e->ev_fork, n->ev_fork);
+    std::swap(e->ev_join, n->ev_join);
+    std::swap(e->sticky_dev, n->sticky_dev);
+    std::swap(e->res_host, n->res_host);
     vf_engine_destroy(n);
     cold(e);
     e->slid = e->redo = 0;

@@ -44,3 +44,23 @@ def test_column_updates_arrive_before_the_column_is_a_pivot():
                 assert m.group(1) == m.group(2) and seen[c] == set(range(c)), (n, c, sorted(seen[c]))
         for c2 in range(n):
             assert seen[c2] == set(range(c2)), (n, c2)
+
+
+def test_the_librarys_kernels_are_the_committed_list():
+    """vf_kernels.hip is one translation unit cut into section files (csrc/kernels/*.inc): moving code between them must not
+    add, drop or rename a kernel.  csrc/kernels.list is the committed list (host stubs of libvilfusion.so, one per kernel
+    template instance); a deliberate change regenerates it with the command in the assertion message."""
+    import re
+    import subprocess
+    import __graft_entry__ as g
+    from vil_sensor_fusion_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(_lib.lib_path()):
+        g.build()
+    out = subprocess.check_output(["nm", "-C", _lib.lib_path()], text=True)
+    names = sorted(set(re.sub(r"\(.*", "", l.split("__device_stub__")[1]).strip() for l in out.splitlines() if "__device_stub__" in l))
+    want = open(os.path.join(root, "vil_sensor_fusion_amd", "csrc", "kernels.list")).read().split("\n")[:-1]
+    assert names == want, ("kernels of libvilfusion.so differ from csrc/kernels.list (regenerate: nm -C libvilfusion.so | grep __device_stub__ ...)",
+                           sorted(set(names) ^ set(want)))
+    for sec in os.listdir(os.path.join(root, "vil_sensor_fusion_amd", "csrc", "kernels")):
+        assert sec.endswith(".inc") and f'#include "kernels/{sec}"' in open(os.path.join(root, "vil_sensor_fusion_amd", "csrc", "vf_kernels.hip")).read(), sec

@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$tag
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-QUIET="--host-workers 1 --no-single-window --no-sharded --no-accuracy --no-convergence-exit --no-degeneracy --no-graph-manager"
+QUIET="--host-workers 1 --no-single-window --no-sharded --no-accuracy --no-convergence-exit --no-incremental --no-degeneracy --no-graph-manager"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $R/bench.py $QUIET --steps 10 --warmup 2 > $OUT/bench_traced.json 2> $OUT/trace.err
 echo "trace done" > $OUT/progress.txt
 PMCRUN="$QUIET --steps 3 --warmup 1 --init-iterations 20"

@@ -610,7 +610,7 @@ def compact_line(full, detail_name="bench_detail.json"):
                 "vs_baseline", "dtype", "data")
     out["vs_baseline"] = full.get("vs_baseline")
     cfg = full.get("config", {})
-    out["config"] = _pick(cfg, "workload", "window_keyframes", "windows_per_gpu", "lm_trials_per_update", "parallelism")
+    out["config"] = _pick(cfg, "workload", "window_keyframes", "windows_per_gpu", "lm_trials_per_update", "factors_per_gpu", "parallelism")
     acc = full.get("accuracy")
     if acc:
         out["accuracy"] = _pick(acc, "ate_m", "rot_rad", "ate_m_max", "within_bar_all", "updates", "bar_m")

@@ -148,6 +148,13 @@ typedef struct {
     int incremental;
     double wildfire;         /* incremental updates: an increment that changes by at most this in every component counts as unchanged
                                 (ISAM2Params::wildfireThreshold, 1e-3 in GTSAM); default 0 = bitwise */
+    double min_model_fidelity; /* > 0: LM trials are accepted by GTSAM's rule instead of accept_rel
+                                (LevenbergMarquardtOptimizer::tryLambda, the optimiser commented out at GraphManager.cpp:128-129): a trial
+                                is accepted iff modelFidelity = (cost - new cost) / (cost - cost of the linearised problem at delta)
+                                exceeds this (LevenbergMarquardtParams::minModelFidelity = 1e-3).  The prediction needs the gradient
+                                in memory: such engines run the assembly kernel (K3), not the assembling sweep; not for time-sharded
+                                windows.  Where the optimum is does not depend on the rule; trial counts and lambda histories do.
+                                Default 0 = the library's own test. */
 } vf_engine_opts;
 /* Solver-form switches: how the library maps the solve onto the part, not what it computes.  vf_engine_default_tuning sets the
  * measured optimum and vf_engine_create uses exactly that; a binding of the reference never touches this struct.  They are
@@ -546,6 +553,7 @@ typedef struct {
     /* VF_ABI_TAIL: as in vf_engine_opts */
     int incremental;
     double wildfire;
+    double min_model_fidelity; /* vf_engine_opts.min_model_fidelity (GTSAM's LM accept rule; 1e-3 there); default 0 = the library's own */
 } vf_graph_opts;
 
 /* (time, pose q_wxyz, position, velocity, bias[acc,gyro]) -- GraphManager::OptimizationCallback

@@ -76,7 +76,7 @@ class LmOpts(C.Structure):
                 ("lambda_min", C.c_double), ("lambda_max", C.c_double),
                 ("iterations", C.c_int), ("n_threads", C.c_int),
                 ("rel_tol", C.c_double), ("abs_tol", C.c_double), ("accept_rel", C.c_double),
-                ("refine", C.c_int), ("refine_rel_stop", C.c_double), ("excursion", C.c_int)]
+                ("refine", C.c_int), ("refine_rel_stop", C.c_double), ("excursion", C.c_int), ("min_model_fidelity", C.c_double)]
 
 
 _lib = None
@@ -331,12 +331,12 @@ class Window:
         return cost, H, g
 
     def lm(self, iterations=5, lambda0=1e-5, up=10.0, down=10.0, lmin=1e-12, lmax=1e10,
-           n_threads=1, rel_tol=0.0, abs_tol=0.0, accept_rel=None, refine=0, refine_rel_stop=1e-8, excursion=0):
+           n_threads=1, rel_tol=0.0, abs_tol=0.0, accept_rel=None, refine=0, refine_rel_stop=1e-8, excursion=0, min_model_fidelity=0.0):
         """refine / excursion: the engine's refined solve and non-monotone accept rule (vf_engine_opts.refine_iterations,
         lm_excursion); 0 / 0 = the classical normal-equation LM.  The engine switches both on by itself for windows longer
         than 1536 keyframes; the oracle does what it is told."""
         o = LmOpts(lambda0, up, down, lmin, lmax, iterations, n_threads, rel_tol, abs_tol, ACCEPT_REL if accept_rel is None else accept_rel,
-                   refine, refine_rel_stop, excursion)
+                   refine, refine_rel_stop, excursion, min_model_fidelity)
         costs = np.zeros(iterations + 1)
         acc = np.zeros(iterations, dtype=np.int32)
         lam = lib().vfo_lm(C.byref(self.c), C.byref(o), _d(costs),

@@ -1496,7 +1496,16 @@ double vfo_lm(vfo_problem* p, const vfo_lm_opts* o, double* costs_out, int* acce
             memcpy(xs, p->states, sizeof(double) * (size_t)n * 16);
             for (int k = 0; k < n; k++) vfo_retract(xs + 16 * k, d + 15 * k, p->states + 16 * k);
             double cn = vfo_assemble(p, w, Hn, gn, o->n_threads);
-            outcome = (cn < refc + o->accept_rel * refc) ? 1 : (o->excursion > 0 && prov < o->excursion) ? 2 : (prov > 0 ? 3 : 0);
+            int good = cn < refc + o->accept_rel * refc;
+            if (o->min_model_fidelity > 0.0) {
+                /* GTSAM's test: actual over predicted decrease, the prediction by the linearised (undamped) problem,
+                 * 0.5 |r|^2 - 0.5 |r + J d|^2 = -g.d - 0.5 d^T H d, which with (H + lambda I) d = -g is 0.5 (lambda |d|^2 - g.d) */
+                double gd = 0.0, dd = 0.0;
+                for (int i = 0; i < n * 15; i++) { gd += g[i] * d[i]; dd += d[i] * d[i]; }
+                const double predicted = 0.5 * (lambda * dd - gd);
+                good = predicted > 0.0 && (refc - cn) > o->min_model_fidelity * predicted;
+            }
+            outcome = good ? 1 : (o->excursion > 0 && prov < o->excursion) ? 2 : (prov > 0 ? 3 : 0);
             /* termination (gtsam checkConvergence), also on a rejected trial within the tolerance: the
              * window then sits at its rounding floor */
             if (outcome < 2 && (o->abs_tol > 0.0 || o->rel_tol > 0.0) &&

@@ -137,6 +137,10 @@ typedef struct {
                                     Jacobians (vf_engine_opts.refine_iterations; csrc/vf_refine.hip) */
     double refine_rel_stop;      /* vf_engine_opts.refine_rel_stop */
     int excursion;               /* vf_engine_opts.lm_excursion: provisional cost-raising trials per excursion (0: classical) */
+    double min_model_fidelity;   /* > 0: GTSAM's accept rule instead of accept_rel (gtsam::LevenbergMarquardtOptimizer::tryLambda with
+                                    LevenbergMarquardtParams::minModelFidelity, 1e-3 there): a trial is accepted iff
+                                    (cost - new cost) / (cost - cost of the LINEARISED problem at delta) > this;
+                                    vf_engine_opts.min_model_fidelity */
 } vfo_lm_opts;
 
 /* total cost 0.5*sum |r|^2 at the current states */

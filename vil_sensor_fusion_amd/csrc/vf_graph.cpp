@@ -151,6 +151,7 @@ static void graph_defaults(vf_graph_opts* o) {
     o->relin_threshold = 1e-4;   // GraphManager.cpp:40
     o->incremental = 0;
     o->wildfire = 0.0;
+    o->min_model_fidelity = 0.0;
 }
 // (the caller's struct may be shorter than the library's: include/vilfusion.h "struct_size")
 void vf_graph_default_opts_sized(vf_graph_opts* o, uint32_t struct_size) {
@@ -194,6 +195,7 @@ int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** ou
     eo.capacity = o.capacity;
     eo.device = o.device;
     eo.cold_start = o.cold_start;
+    eo.min_model_fidelity = o.min_model_fidelity > 0.0 ? o.min_model_fidelity : 0.0;
     if (o.incremental) {
         // (the refined solve corrects a whole-window factorisation through J; the incremental update keeps the panels of an
         // elimination that ran forward in time from the anchor prior -- every pivot block is the conditional information of a

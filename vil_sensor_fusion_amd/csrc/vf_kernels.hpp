@@ -161,6 +161,10 @@ struct View {
     int* n_fail;
     double lam_up, lam_down, lam_min, lam_max;
     double accept_rel;  // an LM trial is accepted iff new cost < cost + accept_rel * cost (vf_engine_opts.accept_rel)
+    // ... or, with min_fidelity > 0 (vf_engine_opts.min_model_fidelity), by GTSAM's rule: (cost - new cost) / model[w] > min_fidelity,
+    // model[w] = the decrease the linearised problem predicts for the step, 0.5 (lambda |delta|^2 - g . delta) (k_model_change)
+    double min_fidelity;
+    double* model;      // [B]
     // Non-monotone LM (vf_engine_opts.lm_excursion = nm_W > 0): up to nm_W consecutive trials that RAISE the cost are kept
     // provisionally (an "excursion"); the first one saves the point it left (x_best, ref_cost).  A later trial whose cost is
     // below ref_cost ends the excursion with everything accepted; the nm_W + 1-th that is not restores x_best (relin[w] = 1:
@@ -310,6 +314,7 @@ void launch_count_active(const View& v, hipStream_t s);
 // hybrid K4 (see View::gate): vp = the same engine viewed with the partitioned form's chunk count
 void launch_band_solve_hybrid(const View& v, const View& vp, hipStream_t s);
 void launch_retract(const View& v, hipStream_t s);
+void launch_model_change(const View& v, hipStream_t s);     // View::model of every window, from g and the increment just solved
 void launch_decide(const View& v, int init, hipStream_t s);
 void launch_close_excursions(const View& v, hipStream_t s);
 void launch_reset_lambda(const View& v, const double* lambda0, hipStream_t s);   // lambda := lambda0 at the start of a solve (see k_reset_lambda)   // non-monotone LM: undo an excursion left open at the end of a solve

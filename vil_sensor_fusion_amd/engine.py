@@ -58,6 +58,7 @@ class EngineOpts:
     far_batch_columns: int | None = None   # single-window engines: the Woodbury columns of far factors as one batched solve (None = default 1)
     incremental: int | None = None         # isam_step re-eliminates only from the first keyframe that changed (None = default 0)
     wildfire: float | None = None          # ... and its back substitution stops once increments change by <= this (None = default 0: bitwise)
+    min_model_fidelity: float | None = None  # > 0: GTSAM's LM accept rule (modelFidelity > this; 1e-3 there) instead of accept_rel (None = default 0)
     lm_excursion: int | None = None      # non-monotone LM: provisional cost-raising trials per excursion (None = default: 3 on refining engines)
 
 
@@ -72,7 +73,7 @@ class Engine:
         o.lambda_min, o.lambda_max = opts.lambda_min, opts.lambda_max
         o.chunks = opts.chunks
         o.cold_start = int(opts.cold_start)
-        for name in ("accept_rel", "refine_iterations", "refine_min_keyframes", "refine_rel_stop", "lm_excursion", "gauge_floor", "incremental", "wildfire"):
+        for name in ("accept_rel", "refine_iterations", "refine_min_keyframes", "refine_rel_stop", "lm_excursion", "gauge_floor", "incremental", "wildfire", "min_model_fidelity"):
             if getattr(opts, name) is not None:
                 setattr(o, name, getattr(opts, name))
         t = _lib.EngineTuningC()

@@ -36,3 +36,17 @@ def test_far_factor_routing_host_logic(tmp_path):
     p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     print(p.stdout, p.stderr[-2000:])
     assert p.returncode == 0 and "far-factor routing ok" in p.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_staged_graph_host_logic(tmp_path):
+    """GraphManager::graph() through the C ABI (vf_graph_get_staged; VERDICT r5 #6) against the engine double: the three priors,
+    then every between factor in the order it was added -- keys, measured(), covariance --, emptied by solve()
+    (GraphManager.cpp:27-35, 46-49, 83-88, 112-114; test/UnitTests.cpp:200,222-233).  No GPU needed: this is host bookkeeping."""
+    exe = tmp_path / "graph_staged"
+    srcs = [os.path.join(ROOT, "tests", "native", "graph_staged.cpp"), os.path.join(ROOT, "tests", "native", "fake_engine.cpp"),
+            os.path.join(ROOT, "vil_sensor_fusion_amd", "csrc", "vf_graph.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-pthread", "-o", str(exe)] + srcs)
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    print(p.stdout, p.stderr[-2000:])
+    assert p.returncode == 0 and "graph_staged ok" in p.stdout

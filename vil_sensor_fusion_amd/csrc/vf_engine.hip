@@ -108,14 +108,18 @@ struct vf_engine {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int* sticky_dev = nullptr;
     vf::SolveResult* res_host = nullptr;
-    int ensure_async() {
+    int ensure_async() {          // the sticky words and the pinned result block (every engine may be asked for a vf_engine_read_result)
         if (res_host) return VF_OK;
-        HIPCHK(hipStreamCreate(&stream2));
-        HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         HIPCHK(hipMalloc((void**)&sticky_dev, 2 * sizeof(int)));
         HIPCHK(hipMemsetAsync(sticky_dev, 0, 2 * sizeof(int), stream));
         HIPCHK(hipHostMalloc((void**)&res_host, sizeof(vf::SolveResult), hipHostMallocDefault));
+        return VF_OK;
+    }
+    int ensure_side() {           // the second stream (hipStreamCreate costs 9 ms: only engines that stage asynchronously get one)
+        if (stream2) return VF_OK;
+        HIPCHK(hipStreamCreate(&stream2));
+        HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         return VF_OK;
     }
     int join_side() {

@@ -626,7 +626,7 @@ def compact_line(full, detail_name="bench_detail.json"):
     if rf:
         out["roofline"] = _pick(rf, "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic",
                                 "avg_launch_ms", "profiled_avg_launch_ms", "profiled_frac", "profiled_source",
-                                "algorithmic_bytes_per_imu_factor")
+                                "algorithmic_bytes_per_imu_factor", "frac_of_measured_copy_peak_6290")
         out["roofline"].setdefault("traffic", None)
         out["roofline"]["kernel"] = "k_linearize_imu (K1)"
     rs = full.get("roofline_solve")

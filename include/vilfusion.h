@@ -554,6 +554,9 @@ typedef struct {
     int incremental;
     double wildfire;
     double min_model_fidelity; /* vf_engine_opts.min_model_fidelity (GTSAM's LM accept rule; 1e-3 there); default 0 = the library's own */
+    int synchronous_staging;   /* != 0: the handle's engine stages synchronously, as before round 6 (every staging call waits for the
+                                  device and reports its own failures; no preintegration at vf_reserve_node, no marginal prior computed
+                                  ahead): same bits as the default, slower; what tests compare the asynchronous path with.  Default 0 */
 } vf_graph_opts;
 
 /* (time, pose q_wxyz, position, velocity, bias[acc,gyro]) -- GraphManager::OptimizationCallback

@@ -563,3 +563,39 @@ def test_whole_history_handle_crosses_the_refinement_threshold(oracle, compat):
     print(f"whole history, reference_compat={compat}: {n} keyframes, refinement on from 1 537; trajectory vs the oracle's refined optimum: ATE {a:.3e} m, rot {r:.3e} rad; lm {st}, provisional trials {seen[n - 1][2]}")
     assert a <= 1e-6 and r <= 1e-6 and st["solve_failures"] == 0
     gm.close()
+
+
+@pytest.mark.parametrize("lag", [0, 40])
+def test_asynchronous_staging_equals_synchronous_staging_to_the_bit(lag):
+    """Round 6: vf_solve stages asynchronously (arguments by value / pinned memory, sticky status words, one synchronisation per solve),
+    preintegrates at reserveNode, computes the next marginal prior behind the solve and enqueues trials adaptively.  None of that
+    may change a bit: the same stream through a handle with synchronous_staging = 1 (the old call sequence), compared at every
+    solve -- whole-history and fixed-lag (marginalisation at every solve once the window is full; two keyframes per solve now and
+    then, so that a marginal prior computed ahead is followed by one computed on the spot)."""
+    from vil_sensor_fusion_amd.graph_manager import GraphManager
+    n = 180
+    seq = synth.make_sequence(seed=77, n_kf=n)
+    outs = []
+    for sync in (False, True):
+        gm = GraphManager(capacity=128, lag=lag, iterations=5, synchronous_staging=sync)
+        gm.setInitialState(seq.gt_states[0])
+        gm.addIMUMeasurement(0.0, seq.imu_steps[0, 1:4], seq.imu_steps[0, 4:7])
+        t, pub = 0.0, []
+        for k in range(1, n):
+            for s in seq.imu_steps[seq.imu_off[k]:seq.imu_off[k + 1]]:
+                t += s[0]
+                gm.addIMUMeasurement(t, s[1:4], s[4:7])
+            gm.reserveNode(t)
+            for i in np.nonzero(seq.btw_b == k)[0]:
+                gm.addBetweenFactor(int(seq.btw_a[i]), k, (seq.btw_q[i], seq.btw_t[i]), np.eye(6) * seq.btw_cov[i])
+            if k % 7 == 3:
+                continue                      # (this keyframe is solved together with the next one)
+            gm.solve()
+            (q, p), v, b = gm.getState()
+            pub.append(np.concatenate([q, p, v, b]))
+        lo = max(0, n - 1 - lag + 1) if lag else 0
+        outs.append((np.array(pub), gm.trajectory(lo, n - lo), gm.lmStats()))
+        gm.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2]

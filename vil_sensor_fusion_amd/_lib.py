@@ -52,7 +52,8 @@ class GraphOptsC(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("capacity", C.c_int), ("lag", C.c_int), ("iterations", C.c_int), ("device", C.c_int),
                 ("prior_sigma", C.c_double * 15), ("rel_tol", C.c_double), ("abs_tol", C.c_double),
                 ("cold_start", C.c_int), ("fixed_capacity", C.c_int), ("reference_compat", C.c_int),
-                ("relin_threshold", C.c_double), ("incremental", C.c_int), ("wildfire", C.c_double), ("min_model_fidelity", C.c_double)]
+                ("relin_threshold", C.c_double), ("incremental", C.c_int), ("wildfire", C.c_double), ("min_model_fidelity", C.c_double),
+                ("synchronous_staging", C.c_int)]
 
 
 CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),

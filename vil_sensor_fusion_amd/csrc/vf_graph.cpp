@@ -152,6 +152,7 @@ static void graph_defaults(vf_graph_opts* o) {
     o->incremental = 0;
     o->wildfire = 0.0;
     o->min_model_fidelity = 0.0;
+    o->synchronous_staging = 0;
 }
 // (the caller's struct may be shorter than the library's: include/vilfusion.h "struct_size")
 void vf_graph_default_opts_sized(vf_graph_opts* o, uint32_t struct_size) {
@@ -219,7 +220,7 @@ int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** ou
     memcpy(rec + 16, o.prior_sigma, sizeof(double) * 15);
     if ((rc = vf_engine_set_states(eng, 0, 0, 1, g->state)) || (rc = vf_engine_set_prior(eng, 0, 0, rec)) ||
         (rc = vf_engine_set_range(eng, 0, 0, 1)) || (rc = vf_engine_set_convergence(eng, o.rel_tol, o.abs_tol)) ||
-        (rc = vf_engine_set_async(eng, 1))) {
+        (rc = vf_engine_set_async(eng, o.synchronous_staging ? 0 : 1))) {
         vf_engine_destroy(eng);
         delete g;
         return rc;
@@ -331,7 +332,7 @@ int vf_reserve_node(vf_graph* g, double time, uint64_t* key_out) {
         const long slot = (long)(p.key - g->key_base);
         bool prev_ok = true;
         for (const auto& q : g->imu_queue) prev_ok = prev_ok && q.staged;
-        if (prev_ok && slot >= 1 && slot < g->opts.capacity && p.key > g->key_base) {
+        if (prev_ok && !g->opts.synchronous_staging && slot >= 1 && slot < g->opts.capacity && p.key > g->key_base) {
             const int32_t off[2] = {0, (int32_t)(p.steps.size() / 7)};
             if (vf_engine_preintegrate(g->eng, 0, (int)slot, 1, off, p.steps.data(), p.bias, &g->imu) == VF_OK) p.staged = true;
         }
@@ -733,7 +734,7 @@ int vf_solve(vf_graph* g) {
         cb.first(cb.second, last_time, g->state, g->state + 4, g->state + 7, g->state + 10);
     // a full fixed-lag window marginalises its oldest keyframe at the next update, from the linearisation this solve leaves:
     // have the device compute that marginal prior now, behind the solve, instead of in front of the next one
-    if (g->opts.lag > 0 && last_slot + 1 - g->lo >= g->opts.lag) (void)vf_engine_marginalize_ahead(g->eng);
+    if (g->opts.lag > 0 && !g->opts.synchronous_staging && last_slot + 1 - g->lo >= g->opts.lag) (void)vf_engine_marginalize_ahead(g->eng);
     if (fails > 0 && fails >= g->opts.iterations && g->opts.iterations > 0)
         return gerr(VF_ERR_INDETERMINATE, "normal equations not positive definite in every LM trial (underdetermined graph?)");
     return VF_OK;

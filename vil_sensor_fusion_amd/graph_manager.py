@@ -29,7 +29,8 @@ class GraphManager:
 
     def __init__(self, imu_params=CARLA_IMU, capacity=4096, lag=0, iterations=5, device=0,
                  prior_sigma=None, rel_tol=None, abs_tol=None, reference_compat=False, relin_threshold=None,
-                 cold_start=False, fixed_capacity=False, incremental=False, wildfire=None, min_model_fidelity=None):
+                 cold_start=False, fixed_capacity=False, incremental=False, wildfire=None, min_model_fidelity=None,
+                 synchronous_staging=False):
         """iterations: LM trials per solve at most; a solve stops earlier once a trial changes the cost by <= abs_tol or
         <= rel_tol * cost (defaults 1e-5 / 1e-5, gtsam::LevenbergMarquardtParams; 0 / 0: always `iterations` trials)."""
         self._l = _lib.lib()
@@ -55,6 +56,7 @@ class GraphManager:
         o.incremental = int(incremental)          # (2: the incremental kernels over the whole history every time -- what tests compare with)
         if wildfire is not None:
             o.wildfire = wildfire
+        o.synchronous_staging = int(bool(synchronous_staging))     # the pre-round-6 staging: same bits, slower (tests compare the two)
         if min_model_fidelity is not None:        # GTSAM's LM accept rule (LevenbergMarquardtParams::minModelFidelity = 1e-3) instead of the library's own
             o.min_model_fidelity = min_model_fidelity
         self._h = C.c_void_p()

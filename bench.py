@@ -650,6 +650,11 @@ def compact_line(full, detail_name="bench_detail.json"):
                      ("graph_manager", ("solve_ms_mean", "paced_solve_ms_mean", "paced_solve_ms_median", "paced_solve_ms_p99"))):
         if isinstance(full.get(key), dict):
             out[key] = _pick(full[key], *sub)
+    sw = full.get("single_window")
+    if isinstance(sw, dict) and cb and sw.get("ms_per_update") and cb.get("value"):
+        # the like-for-like figure for ONE vehicle: one window on the GPU against one window on one CPU core (the headline holds
+        # 1 024 windows against one; a GPU-over-CPU ratio is not a measure of kernel quality either way)
+        out["single_window"]["over_cpu_one_core_one_window"] = (1e3 / sw["ms_per_update"]) / cb["value"]
     gm = full.get("graph_manager")
     if isinstance(gm, dict) and isinstance(gm.get("default_termination"), dict):
         out["graph_manager"]["solve_ms_p99"] = gm["default_termination"].get("solve_ms_p99")

@@ -117,3 +117,72 @@ def test_spectrum_is_the_three_metrics_of_one_eigen_solve():
     assert np.isnan(got["condition_number"][1:]).all() and np.isfinite(got["e_opt"]).all()
     ref = dg.apply_degen_function(m, None, "all", "condition_number")
     np.testing.assert_allclose(ref[1:], -np.linalg.cond(m[:, :, 1]), rtol=1e-9)
+
+
+def test_symmetric_eigensolver_on_special_spectra():
+    """The tridiagonal QL solver behind e_opt / max_eigen / condition_number / norm_2 / norm_nuclear (round 6) on the spectra that
+    break eigen-solvers: the identity and multiples of it (nothing to rotate), the zero matrix, diagonal matrices with repeated
+    entries (deflation at every step), rank-one and rank-two matrices (clusters at zero), block-diagonal matrices (an
+    off-diagonal that is exactly zero), graded matrices over twelve decades, tight clusters, indefinite matrices, and random
+    orthogonal similarity transforms of all of them; float64 against numpy.linalg.eigvalsh, absolute tolerance eps * |A| * 50."""
+    from vil_sensor_fusion_amd import degeneracy as dg
+    rng = np.random.default_rng(42)
+    mats = []
+
+    def add(M):
+        mats.append(0.5 * (M + M.T))
+
+    def rot():
+        q, _ = np.linalg.qr(rng.normal(size=(6, 6)))
+        return q
+    add(np.zeros((6, 6)))                                  # index 0 is the series' placeholder (y[0] = 0)
+    for s in (1.0, 3.5e7, 2e-9):
+        add(s * np.eye(6))
+    add(np.zeros((6, 6)))
+    add(np.diag([2.0, 2.0, 2.0, 5.0, 5.0, 5.0]))
+    add(np.diag([1.0, 1.0, 1.0, 1.0, 1.0, 2.0]))
+    add(np.diag([-3.0, 1.0, 4.0, -1.0, 5.0, -9.0]))
+    for _ in range(40):
+        Q = rot()
+        kind = rng.integers(0, 7)
+        if kind == 0:
+            u = rng.normal(size=6); add(np.outer(u, u))                                  # rank one
+        elif kind == 1:
+            u, w = rng.normal(size=6), rng.normal(size=6); add(np.outer(u, u) + np.outer(w, w))
+        elif kind == 2:
+            add(Q @ np.diag(10.0 ** np.linspace(-12, 0, 6)) @ Q.T)                       # graded
+        elif kind == 3:
+            add(Q @ np.diag(1.0 + 1e-9 * rng.normal(size=6)) @ Q.T)                      # a tight cluster
+        elif kind == 4:
+            B = np.zeros((6, 6)); a, b = rng.normal(size=(3, 3)), rng.normal(size=(3, 3))
+            B[:3, :3], B[3:, 3:] = a @ a.T, b @ b.T; add(B)                              # block diagonal: exact zeros off the blocks
+        elif kind == 5:
+            add(Q @ np.diag([2.0, 2.0, 2.0, 7.0, 7.0, -1.0]) @ Q.T)                      # repeated, indefinite
+        else:
+            add(Q @ np.diag(rng.normal(size=6) * 10.0 ** rng.integers(-6, 6)) @ Q.T)
+    M = np.ascontiguousarray(np.stack(mats).transpose(1, 2, 0))
+    ev = np.linalg.eigvalsh(np.stack(mats))
+    scale = np.maximum(np.abs(np.stack(mats)).max(axis=(1, 2)), 1e-300)
+    tol = 50 * np.finfo(np.float64).eps * scale
+    lo = dg.apply_degen_function(M, None, "all", "e_opt")
+    hi = dg.apply_degen_function(M, None, "all", "max_eigen")
+    n2 = dg.apply_degen_function(M, None, "all", "norm_2")
+    nn = dg.apply_degen_function(M, None, "all", "norm_nuclear")
+    assert np.all(np.abs(lo[1:] - ev[1:, 0]) <= tol[1:]), np.abs(lo[1:] - ev[1:, 0]) / tol[1:]
+    assert np.all(np.abs(hi[1:] - ev[1:, -1]) <= tol[1:]), np.abs(hi[1:] - ev[1:, -1]) / tol[1:]
+    assert np.all(np.abs(n2[1:] - np.abs(ev[1:]).max(axis=1)) <= tol[1:])
+    assert np.all(np.abs(nn[1:] - np.abs(ev[1:]).sum(axis=1)) <= 6 * tol[1:])
+    # the 3 x 3 subsets run the same code with N = 3
+    for sub, sl in (("trans", slice(0, 3)), ("rot", slice(3, 6))):
+        ev3 = np.linalg.eigvalsh(np.stack(mats)[:, sl, sl])
+        lo3 = dg.apply_degen_function(M, None, sub, "e_opt")
+        hi3 = dg.apply_degen_function(M, None, sub, "max_eigen")
+        assert np.all(np.abs(lo3[1:] - ev3[1:, 0]) <= tol[1:]) and np.all(np.abs(hi3[1:] - ev3[1:, -1]) <= tol[1:])
+    # condition number where it is finite and moderate (|lambda|_max / |lambda|_min); infinite for singular matrices, as numpy's
+    finite = np.abs(ev).min(axis=1) > 1e-6 * np.abs(ev).max(axis=1)
+    finite[0] = False
+    cn = dg.apply_degen_function(M, None, "all", "condition_number")
+    ref = -np.abs(ev).max(axis=1) / np.maximum(np.abs(ev).min(axis=1), 1e-300)
+    np.testing.assert_allclose(cn[finite], ref[finite], rtol=1e-9)
+    print(f"{len(mats) - 1} special matrices: worst |e_opt - eigvalsh| / (eps |A|) = {np.max(np.abs(lo[1:] - ev[1:, 0]) / (np.finfo(np.float64).eps * scale[1:])):.1f}, "
+          f"max_eigen {np.max(np.abs(hi[1:] - ev[1:, -1]) / (np.finfo(np.float64).eps * scale[1:])):.1f}")

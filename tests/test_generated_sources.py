@@ -60,7 +60,7 @@ def test_the_librarys_kernels_are_the_committed_list():
     out = subprocess.check_output(["nm", "-C", _lib.lib_path()], text=True)
     names = sorted(set(re.sub(r"\(.*", "", l.split("__device_stub__")[1]).strip() for l in out.splitlines() if "__device_stub__" in l))
     want = open(os.path.join(root, "vil_sensor_fusion_amd", "csrc", "kernels.list")).read().split("\n")[:-1]
-    assert names == want, ("kernels of libvilfusion.so differ from csrc/kernels.list (regenerate: nm -C libvilfusion.so | grep __device_stub__ ...)",
+    assert names == want, ("kernels of libvilfusion.so differ from csrc/kernels.list (after a deliberate change: python tools/gen_kernel_list.py)",
                            sorted(set(names) ^ set(want)))
     for sec in os.listdir(os.path.join(root, "vil_sensor_fusion_amd", "csrc", "kernels")):
         assert sec.endswith(".inc") and f'#include "kernels/{sec}"' in open(os.path.join(root, "vil_sensor_fusion_amd", "csrc", "vf_kernels.hip")).read(), sec

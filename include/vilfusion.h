@@ -41,7 +41,8 @@ extern "C" {
 #define VF_BTW_RECORD 28
 #define VF_PRIOR_RECORD 31
 #define VF_MAX_BANDWIDTH 3
-#define VF_MAX_EXTRA 8            /* "far" between factors per window (vf_engine_set_extra_between) */
+#define VF_MAX_EXTRA 8            /* "far" between factors per window (vf_engine_set_extra_between) unless the handle asks for more ... */
+#define VF_MAX_FAR_LIMIT 32       /* ... through max_far_factors, up to this many */
 
 const char* vf_last_error(void);
 const char* vf_version(void);
@@ -155,6 +156,14 @@ typedef struct {
                                 in memory: such engines run the assembly kernel (K3), not the assembling sweep; not for time-sharded
                                 windows.  Where the optimum is does not depend on the rule; trial counts and lambda histories do.
                                 Default 0 = the library's own test. */
+    int max_far_factors;     /* far between factors a window may hold at once (vf_engine_set_extra_between; the far ends of its linear
+                                far factor count).  0 = VF_MAX_EXTRA, at most VF_MAX_FAR_LIMIT.  Up to VF_MAX_EXTRA the small dense
+                                systems of the low-rank correction and of the joint marginalisation live in LDS; an engine made for
+                                more keeps them in device memory (0.7 MB per window) -- the same arithmetic in the same order, so the
+                                same bits for the same factors, a few times slower per system.  Every far factor alive costs six
+                                Woodbury columns per trial (single-window engines: six windows of the column engine, 23 MB each at
+                                1 200 slots).  Arrays a caller passes for a window's far list (vf_engine_get_extra_between,
+                                vf_engine_get_linear_far) hold this many entries. */
 } vf_engine_opts;
 /* Solver-form switches: how the library maps the solve onto the part, not what it computes.  vf_engine_default_tuning sets the
  * measured optimum and vf_engine_create uses exactly that; a binding of the reference never touches this struct.  They are
@@ -252,7 +261,8 @@ int vf_engine_clear_between(vf_engine* e, int window, int k0, int n);
  * pair of keys (GraphManager.cpp:83-88); the banded device solver keeps such factors out of H and applies them as a
  * low-rank correction: g gets their J^T r, and every LM trial solves (H_band + lambda I + U U^T) delta = -g by Woodbury
  * -- the band solver once more per column of U (6 per factor) and one small dense system per window.  A FALLBACK for
- * the rare window with such factors, several times slower than a band-only window; at most VF_MAX_EXTRA per window.
+ * the rare window with such factors, several times slower than a band-only window; at most VF_MAX_EXTRA per window
+ * (vf_engine_opts.max_far_factors raises that to VF_MAX_FAR_LIMIT).
  * The call REPLACES the window's list (n = 0 clears it); records as for vf_engine_set_between.
  * A far factor outlives the keyframe it is anchored on, as in the reference's unbounded graph (GraphManager.cpp:83-88).  When
  * its older keyframe a is MARGINALISED (vf_engine_marginalize / vf_engine_slide(.., 1)) the factor is marginalised with it,
@@ -272,7 +282,7 @@ int vf_engine_set_extra_between(vf_engine* e, int window, int n, const int32_t* 
  * marginal prior over the life of the engine; any output pointer may be NULL */
 int vf_engine_get_extra_between(vf_engine* e, int window, int* n, int32_t* a, int32_t* b, double* rec28, long* transported, long* ended,
                                 long* absorbed);
-/* the window's linear far factors: their number and the window-local keyframe each one ends at (far_end: VF_MAX_EXTRA ints, or NULL) */
+/* the window's linear far factors: their number and the window-local keyframe each one ends at (far_end: max_far_factors ints -- VF_MAX_EXTRA by default -- or NULL) */
 int vf_engine_get_linear_far(vf_engine* e, int window, int* n, int32_t* far_end);
 /* the three priors of GraphManager.cpp:27-35 as one diagonal 15-row factor on keyframe k */
 int vf_engine_set_prior(vf_engine* e, int window, int k, const double* rec31);
@@ -557,6 +567,8 @@ typedef struct {
     int synchronous_staging;   /* != 0: the handle's engine stages synchronously, as before round 6 (every staging call waits for the
                                   device and reports its own failures; no preintegration at vf_reserve_node, no marginal prior computed
                                   ahead): same bits as the default, slower; what tests compare the asynchronous path with.  Default 0 */
+    int max_far_factors;       /* vf_engine_opts.max_far_factors: loop closures (between factors the band cannot hold) alive at once;
+                                  vf_add_between returns VF_ERR_CAPACITY beyond.  0 = VF_MAX_EXTRA, at most VF_MAX_FAR_LIMIT */
 } vf_graph_opts;
 
 /* (time, pose q_wxyz, position, velocity, bias[acc,gyro]) -- GraphManager::OptimizationCallback

@@ -26,7 +26,8 @@ class EngineOptsC(C.Structure):
                 ("cold_start", C.c_int), ("accept_rel", C.c_double),
                 ("refine_iterations", C.c_int), ("refine_min_keyframes", C.c_int), ("refine_rel_stop", C.c_double),
                 ("lm_excursion", C.c_int), ("gauge_floor", C.c_double),
-                ("incremental", C.c_int), ("wildfire", C.c_double), ("min_model_fidelity", C.c_double)]
+                ("incremental", C.c_int), ("wildfire", C.c_double), ("min_model_fidelity", C.c_double),
+                ("max_far_factors", C.c_int)]
 
 
 class EngineTuningC(C.Structure):
@@ -53,7 +54,7 @@ class GraphOptsC(C.Structure):
                 ("prior_sigma", C.c_double * 15), ("rel_tol", C.c_double), ("abs_tol", C.c_double),
                 ("cold_start", C.c_int), ("fixed_capacity", C.c_int), ("reference_compat", C.c_int),
                 ("relin_threshold", C.c_double), ("incremental", C.c_int), ("wildfire", C.c_double), ("min_model_fidelity", C.c_double),
-                ("synchronous_staging", C.c_int)]
+                ("synchronous_staging", C.c_int), ("max_far_factors", C.c_int)]
 
 
 CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),

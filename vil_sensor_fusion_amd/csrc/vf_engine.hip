@@ -241,12 +241,13 @@ struct vf_engine {
     long far_transported = 0, far_ended = 0, far_absorbed = 0;   // far factors moved on to the next keyframe when theirs left the window /
                                                                  // dropped without a marginalisation / absorbed into the marginal prior
     bool marg_since_drop = false;   // vf_engine_marginalize ran since the last vf_engine_drop_oldest (the GraphManager's call pair)
-    int x_zslots = 0;          // slots x_Z holds columns for (6 columns each); grown on demand, never beyond VF_MAX_EXTRA
+    int x_zslots = 0;          // slots x_Z holds columns for (6 columns each); grown on demand, never beyond x_cap
+    int x_cap = VF_MAX_EXTRA;  // far factors a window may hold (vf_engine_opts.max_far_factors): the width of the device lists
     // the device lists are allocated once (they stay in `allocs`); a failure half way leaves what exists in place and a
     // later call picks up from there (no second allocation, nothing leaked)
     int *x_la = nullptr, *x_lb = nullptr;
     double *x_li = nullptr, *x_lo = nullptr;
-    // Woodbury columns of a single-window engine as one batch: a second engine of 6 x VF_MAX_EXTRA windows and the same
+    // Woodbury columns of a single-window engine as one batch: a second engine of up to 6 x x_cap windows and the same
     // capacity, on this engine's stream; window q holds a copy of the window's H and column q of U as right-hand side
     // (k_cols_prepare), one partitioned solve of it returns all of Z.  Made when the first far factor arrives, never inside a
     // solve (a solve may be under stream capture); absent (sequential columns, as on batch engines) if it cannot be had.
@@ -258,7 +259,7 @@ struct vf_engine {
     void attach_far() {              // after ensure_far: the View sees the slot arrays, the host mirrors exist
         if (v.x_max) return;
         v.x_a = x_la; v.x_b = x_lb; v.x_in = x_li; v.x_out = x_lo;
-        v.x_max = VF_MAX_EXTRA;
+        v.x_max = x_cap;
         h_xn.assign(v.B, 0);
         h_xa.assign(v.B, {});
         h_xb.assign(v.B, {});
@@ -270,14 +271,16 @@ struct vf_engine {
         for (int w = 0; w < v.B && v.x_max; w++) x_used = std::max(x_used, h_xn[w] + h_ln(w));
     }
     int ensure_far(int slots) {
-        const size_t B = (size_t)v.B, X = VF_MAX_EXTRA;
+        const size_t B = (size_t)v.B, X = (size_t)x_cap;
         int rc;
         if (!x_la) { if ((rc = alloc(&x_la, B * X, false))) return rc; HIPCHK(hipMemsetAsync(x_la, 0xff, B * X * sizeof(int), stream)); }
         if (!x_lb) { if ((rc = alloc(&x_lb, B * X, false))) return rc; HIPCHK(hipMemsetAsync(x_lb, 0xff, B * X * sizeof(int), stream)); }
         if (!x_li && (rc = alloc(&x_li, B * X * vf::BTW_IN))) return rc;
         if (!x_lo && (rc = alloc(&x_lo, 2 * B * X * vf::BTW_OUT))) return rc;
-        if ((!v.xl_n && (rc = alloc(&v.xl_n, B))) || (!v.xl_b && (rc = alloc(&v.xl_b, B * X))) || (!v.xl_U && (rc = alloc(&v.xl_U, B * X * 6 * vf::XL_LD))) ||
+        if ((!v.xl_n && (rc = alloc(&v.xl_n, B))) || (!v.xl_b && (rc = alloc(&v.xl_b, B * X))) || (!v.xl_U && (rc = alloc(&v.xl_U, B * X * 6 * (27 + 6 * X)))) ||
             (!v.xl_r0 && (rc = alloc(&v.xl_r0, B * X * 6))) || (!v.xl_bx && (rc = alloc(&v.xl_bx, B * X * 7))) || (!v.xl_out && (rc = alloc(&v.xl_out, 2 * B * X * 6)))) return rc;
+        // (more far factors than the LDS forms of k_marginalize / k_extra_combine hold: their systems live here)
+        if (x_cap > vf::MAX_EXTRA && !v.far_scratch && (rc = alloc(&v.far_scratch, B * vf::FAR_SCRATCH))) return rc;
         x_zstride = (size_t)v.G * 15 + B + 64;
         if (!x_gtmp) HIPCHK(hipMalloc((void**)&x_gtmp, x_zstride * sizeof(double)));
         if (slots > x_zslots) {

@@ -27,7 +27,7 @@ VF_DI void far_col(const View& v, int w, const FarRef& f, int c, int& k, int& d)
 }
 // entry (row j, column c) of the whitened Jacobian / residual j, at the states of buffer `buf`
 VF_DI double far_jac(const View& v, int w, const FarRef& f, int buf, int j, int c) {
-    if (f.kind == 1) return v.xl_U[((size_t)w * 6 * v.x_max + 6 * f.idx + j) * XL_LD + c];
+    if (f.kind == 1) return v.xl_U[((size_t)w * 6 * v.x_max + 6 * f.idx + j) * xl_ld(v) + c];
     return v.x_out[(((size_t)buf * v.B + w) * v.x_max + f.idx) * BTW_OUT + 6 + (c < 6 ? 0 : 36) + j * 6 + (c < 6 ? c : c - 6)];
 }
 VF_DI double far_res(const View& v, int w, const FarRef& f, int buf, int j) {

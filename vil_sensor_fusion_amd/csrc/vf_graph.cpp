@@ -99,7 +99,7 @@ struct vf_graph {
     }
     int far_new = 0;
     bool far_on_device = false;    // the engine holds a non-empty far list (written under solve_mutex only)
-    std::atomic<int> far_linear{0};  // far ends of the engine's linear far factor (far factors marginalised with their older key): they share VF_MAX_EXTRA
+    std::atomic<int> far_linear{0};  // far ends of the engine's linear far factor (far factors marginalised with their older key): they share opts.max_far_factors
     int staged_count = 3;  // the three priors (GraphManager.cpp:33-35)
     bool priors_staged = true;              // ... which the first solve takes with everything else (_graph->resize(0), :114)
     std::vector<StagedFactor> staged_log;   // the between factors among them, in the order addBetweenFactor took them
@@ -153,6 +153,7 @@ static void graph_defaults(vf_graph_opts* o) {
     o->wildfire = 0.0;
     o->min_model_fidelity = 0.0;
     o->synchronous_staging = 0;
+    o->max_far_factors = 0;      // = VF_MAX_EXTRA
 }
 // (the caller's struct may be shorter than the library's: include/vilfusion.h "struct_size")
 void vf_graph_default_opts_sized(vf_graph_opts* o, uint32_t struct_size) {
@@ -183,6 +184,8 @@ int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** ou
     if (o.reference_compat && !(o.relin_threshold >= 0.0)) return gerr(VF_ERR_INVALID, "relin_threshold must be >= 0");
     if (o.incremental && !o.reference_compat) return gerr(VF_ERR_INVALID, "incremental needs reference_compat (the update it makes incremental is the iSAM2-like one)");
     if (o.incremental && !(o.wildfire >= 0.0)) return gerr(VF_ERR_INVALID, "wildfire must be >= 0");
+    if (o.max_far_factors < 0 || o.max_far_factors > VF_MAX_FAR_LIMIT) return gerr(VF_ERR_INVALID, "max_far_factors must be in 0..%d", VF_MAX_FAR_LIMIT);
+    if (o.max_far_factors == 0) o.max_far_factors = VF_MAX_EXTRA;
     const double covs[6] = {imu->acc_cov, imu->gyro_cov, imu->integration_cov, imu->bias_acc_cov, imu->bias_omega_cov, imu->bias_acc_omega_int};
     for (double c : covs)
         if (!(c > 0.0) || !std::isfinite(c)) return gerr(VF_ERR_NOT_SPD, "IMU covariances must be finite and > 0");
@@ -197,6 +200,7 @@ int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** ou
     eo.device = o.device;
     eo.cold_start = o.cold_start;
     eo.min_model_fidelity = o.min_model_fidelity > 0.0 ? o.min_model_fidelity : 0.0;
+    eo.max_far_factors = o.max_far_factors;
     if (o.incremental) {
         // (the refined solve corrects a whole-window factorisation through J; the incremental update keeps the panels of an
         // elimination that ran forward in time from the anchor prior -- every pivot block is the conditional information of a
@@ -405,9 +409,10 @@ int vf_add_between(vf_graph* g, uint64_t prev, uint64_t cur, const double q[4], 
         g->staged_between.push_back(b);
     } else {
         // not a band factor: a far factor, solved as a low-rank correction (slower; include/vilfusion.h).  The list is bounded.
-        if ((int)g->far_between.size() + g->far_linear.load() >= VF_MAX_EXTRA)
-            return gerr(VF_ERR_CAPACITY, "between factor (%llu, %llu) spans %llu keyframes or shares its end key, and the window already holds %d such factors",
-                        (unsigned long long)prev, (unsigned long long)cur, (unsigned long long)(cur - prev), VF_MAX_EXTRA);
+        if ((int)g->far_between.size() + g->far_linear.load() >= g->opts.max_far_factors)
+            return gerr(VF_ERR_CAPACITY, "between factor (%llu, %llu) spans %llu keyframes or shares its end key, and the window already holds %d such factors "
+                        "(vf_graph_opts.max_far_factors; at most %d)", (unsigned long long)prev, (unsigned long long)cur, (unsigned long long)(cur - prev),
+                        g->opts.max_far_factors, VF_MAX_FAR_LIMIT);
         g->far_between.push_back(b);
         g->far_new++;
     }
@@ -674,8 +679,8 @@ int vf_solve(vf_graph* g) {
         // the engine has marginalised the far factors whose older key left together with that key (they are linear rows of its
         // own now): the entries that were on the device are replaced by what the engine's list holds now
         int cnt = 0;
-        int32_t ea[VF_MAX_EXTRA], eb[VF_MAX_EXTRA];
-        double erec[VF_MAX_EXTRA * VF_BTW_RECORD];
+        int32_t ea[VF_MAX_FAR_LIMIT], eb[VF_MAX_FAR_LIMIT];
+        double erec[VF_MAX_FAR_LIMIT * VF_BTW_RECORD];
         if ((rc = vf_engine_get_extra_between(g->eng, 0, &cnt, ea, eb, erec, nullptr, nullptr, nullptr))) return give_back(rc);
         std::vector<PendingBetween> moved;
         for (int i = 0; i < cnt; i++) {

@@ -26,8 +26,11 @@ constexpr int JT_STRIDE = JS_PAIRS * JT * 2;        // 2336 doubles = 146 lines 
 constexpr int BTW_IN = 28;      // q(4), t(3), R packed upper (21)
 constexpr int BTW_OUT = 78;     // r(6), Ja(36), Jb(36)
 constexpr int PLACE_CELLS = 2048;  // (xcc 3 bits, se / sh / cu 8 bits of HW_ID)
-constexpr int MAX_EXTRA = 8;
-constexpr int XL_LD = 27 + 6 * MAX_EXTRA;     // row stride of the linear far factor (View::xl_U): 27 head columns + 6 per far end    // far between factors per window (= VF_MAX_EXTRA of include/vilfusion.h)
+constexpr int MAX_EXTRA = 8;        // far between factors per window the LDS forms of k_marginalize / k_extra_combine hold (= VF_MAX_EXTRA)
+constexpr int MAX_EXTRA_BIG = 32;   // ... and their global-scratch forms (= VF_MAX_FAR_LIMIT; vf_engine_opts.max_far_factors > VF_MAX_EXTRA)
+// per-window scratch of those forms (View::far_scratch): W and E of the joint marginalisation, 6 X rows x (42 + 6 X + 1) columns
+// each (the Woodbury system, 6 X x (6 X + 1), fits in one of them)
+constexpr size_t FAR_SCRATCH = 2 * (size_t)(6 * MAX_EXTRA_BIG) * (42 + 6 * MAX_EXTRA_BIG + 1);
 constexpr int PRIOR_IN = 31;    // mean state (16), sigma (15)
 constexpr int PRIOR_OUT = 240;  // r(15), J(15x15)
 // Block row of H of one keyframe k, as the solver reads it (512 doubles, 4 KB):
@@ -212,7 +215,7 @@ struct View {
     // LINEAR far factors: what far factors become when the marginalisation eliminates their older keyframe (k_marginalize).
     // Marginalising a keyframe that several far factors touch couples their far ends, so the window holds them as ONE linear
     // factor: xl_n far ends, six whitened rows per far end, every row over [lo: 15][lo+1: pose][lo+2: pose][far end 0: pose] ..
-    // [far end xl_n-1: pose] (row stride XL_LD), and a residual at the linearisation point -- the marginal prior's own (mp_x)
+    // [far end xl_n-1: pose] (row stride xl_ld(v) = 27 + 6 x_max), and a residual at the linearisation point -- the marginal prior's own (mp_x)
     // for the three head keyframes, xl_bx for the far ends:
     //     r(x) = r0 + U [Local(mp_x -> x_lo .. x_lo+2) (27); Local(xl_bx[e] -> x_{b_e}) (6 each)]
     // Re-expressed by every later marginalisation (its support always includes the keyframe that leaves); a far end that
@@ -220,10 +223,11 @@ struct View {
     // s < xl_n is rows 6 s .. 6 s + 5, slot xl_n + i is entry i of x_a / x_b.  Linear + nonlinear <= x_max per window.
     int* xl_n;          // [B]
     int* xl_b;          // [B][x_max] window-local keyframe of each far end
-    double* xl_U;       // [B][6 x_max][XL_LD]
+    double* xl_U;       // [B][6 x_max][27 + 6 x_max]
     double* xl_r0;      // [B][6 x_max]
     double* xl_bx;      // [B][x_max][7] (q w x y z, t)
     double* xl_out;     // [2][B][6 x_max] residual at the states of each buffer
+    double* far_scratch; // [B][FAR_SCRATCH] or null: engines made for more than MAX_EXTRA far factors per window
     // Incremental Gauss-Newton updates (vf_engine_opts.incremental; csrc "suffix re-elimination"): the banded form of what
     // ISAM2::update does with relinearizeSkip 1 (GraphManager.cpp:37-43,126-127).  The forward sweep is causal in time, so the
     // panel of a keyframe depends on nothing newer than the factors that touch it: after an update only the keyframes from
@@ -240,6 +244,7 @@ struct View {
     double* ck;         // [G / CK][CK_SZ] checkpoints (slot k -> entry k / CK of its window, written by every sweep that passes it)
     double wildfire;    // back substitution: an increment that changes by at most this in every component counts as unchanged
 };
+__host__ __device__ inline int xl_ld(const View& v) { return 27 + 6 * v.x_max; }   // row stride of View::xl_U
 constexpr int CK_LOG = 3, CK = 1 << CK_LOG;       // a checkpoint every 8 keyframe slots
 constexpr int CK_SZ = 768;                        // 27 x 28 doubles (SEPM), padded
 // first keyframe slot the incremental forward sweep eliminates again, given the first changed slot: a factor reaches three

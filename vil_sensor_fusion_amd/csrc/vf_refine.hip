@@ -184,6 +184,9 @@ __global__ void __launch_bounds__(64) k_far_apply(View v, Refine q, const double
     if (v.hi[w] - v.lo[w] <= 0 || refine_off(v, q, w)) return;
     const int b = v.sel[w];
     __shared__ double u[6];
+    __shared__ int kb_l[MAX_EXTRA_BIG];                // far ends of the linear far factor (every linear slot's columns 27.. lie on them)
+    if (lane < v.x_max) kb_l[lane] = v.xl_b[w * v.x_max + lane];
+    __syncthreads();
     for (int s = 0; s < v.x_max; s++) {
         const FarRef f = far_ref(v, w, s);
         if (f.kind < 0) continue;                    // (the same for every lane)
@@ -209,10 +212,7 @@ __global__ void __launch_bounds__(64) k_far_apply(View v, Refine q, const double
                 bool first = true;
                 if (f.kind == 1 && c >= 27)
                     for (int c2 = 27 + d; c2 < nc; c2 += 6) {
-                        if (c2 == c) continue;
-                        int k2, d2;
-                        far_col(v, w, f, c2, k2, d2);
-                        if (k2 != k) continue;
+                        if (c2 == c || kb_l[(c2 - 27) / 6] != k) continue;
                         if (c2 < c) { first = false; break; }
                         for (int r = 0; r < 6; r++) acc = fma(far_jac(v, w, f, b, r, c2), u[r], acc);
                     }

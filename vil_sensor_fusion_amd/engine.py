@@ -12,6 +12,7 @@ from . import _lib
 from ._lib import check
 
 IMU_RECORD, BTW_RECORD, PRIOR_RECORD = 190, 28, 31
+MAX_FAR, MAX_FAR_LIMIT = 8, 32      # VF_MAX_EXTRA, VF_MAX_FAR_LIMIT
 STAGES = {"linearize_imu": 1, "linearize_between": 2, "assemble": 3, "solve": 4, "retract": 5,
           "decide": 6, "assemble_idle": 7}
 # GraphManager.cpp:27-31: pose (rad x3, m x3), velocity, bias prior sigmas
@@ -59,6 +60,7 @@ class EngineOpts:
     incremental: int | None = None         # isam_step re-eliminates only from the first keyframe that changed (None = default 0)
     wildfire: float | None = None          # ... and its back substitution stops once increments change by <= this (None = default 0: bitwise)
     min_model_fidelity: float | None = None  # > 0: GTSAM's LM accept rule (modelFidelity > this; 1e-3 there) instead of accept_rel (None = default 0)
+    max_far_factors: int | None = None     # far between factors a window may hold (None = default VF_MAX_EXTRA = 8; at most 32)
     lm_excursion: int | None = None      # non-monotone LM: provisional cost-raising trials per excursion (None = default: 3 on refining engines)
 
 
@@ -73,7 +75,7 @@ class Engine:
         o.lambda_min, o.lambda_max = opts.lambda_min, opts.lambda_max
         o.chunks = opts.chunks
         o.cold_start = int(opts.cold_start)
-        for name in ("accept_rel", "refine_iterations", "refine_min_keyframes", "refine_rel_stop", "lm_excursion", "gauge_floor", "incremental", "wildfire", "min_model_fidelity"):
+        for name in ("accept_rel", "refine_iterations", "refine_min_keyframes", "refine_rel_stop", "lm_excursion", "gauge_floor", "incremental", "wildfire", "min_model_fidelity", "max_far_factors"):
             if getattr(opts, name) is not None:
                 setattr(o, name, getattr(opts, name))
         t = _lib.EngineTuningC()
@@ -135,13 +137,13 @@ class Engine:
         """(a, b, records, made linear by a marginalisation or re-anchored by a slide without one so far, dropped without a
         marginalisation so far, absorbed into the marginal prior so far): the window's nonlinear far factors as they stand"""
         n, tr, en, ab = C.c_int(), C.c_long(), C.c_long(), C.c_long()
-        a, b, r = np.zeros(8, dtype=np.int32), np.zeros(8, dtype=np.int32), np.zeros((8, BTW_RECORD))
+        a, b, r = np.zeros(MAX_FAR_LIMIT, dtype=np.int32), np.zeros(MAX_FAR_LIMIT, dtype=np.int32), np.zeros((MAX_FAR_LIMIT, BTW_RECORD))
         check(self._l.vf_engine_get_extra_between(self._h, window, C.byref(n), _i(a), _i(b), _d(r), C.byref(tr), C.byref(en), C.byref(ab)))
         return a[:n.value].copy(), b[:n.value].copy(), r[:n.value].copy(), tr.value, en.value, ab.value
 
     def get_linear_far(self, window):
         """window-local keyframes the window's LINEAR far factors end at (far factors whose older keyframe has been marginalised)"""
-        n, b = C.c_int(), np.zeros(8, dtype=np.int32)
+        n, b = C.c_int(), np.zeros(MAX_FAR_LIMIT, dtype=np.int32)
         check(self._l.vf_engine_get_linear_far(self._h, window, C.byref(n), _i(b)))
         return b[:n.value].copy()
 

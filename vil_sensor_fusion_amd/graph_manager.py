@@ -30,7 +30,7 @@ class GraphManager:
     def __init__(self, imu_params=CARLA_IMU, capacity=4096, lag=0, iterations=5, device=0,
                  prior_sigma=None, rel_tol=None, abs_tol=None, reference_compat=False, relin_threshold=None,
                  cold_start=False, fixed_capacity=False, incremental=False, wildfire=None, min_model_fidelity=None,
-                 synchronous_staging=False):
+                 synchronous_staging=False, max_far_factors=None):
         """iterations: LM trials per solve at most; a solve stops earlier once a trial changes the cost by <= abs_tol or
         <= rel_tol * cost (defaults 1e-5 / 1e-5, gtsam::LevenbergMarquardtParams; 0 / 0: always `iterations` trials)."""
         self._l = _lib.lib()
@@ -59,6 +59,8 @@ class GraphManager:
         o.synchronous_staging = int(bool(synchronous_staging))     # the pre-round-6 staging: same bits, slower (tests compare the two)
         if min_model_fidelity is not None:        # GTSAM's LM accept rule (LevenbergMarquardtParams::minModelFidelity = 1e-3) instead of the library's own
             o.min_model_fidelity = min_model_fidelity
+        if max_far_factors is not None:           # loop closures alive at once (default VF_MAX_EXTRA = 8, at most VF_MAX_FAR_LIMIT = 32)
+            o.max_far_factors = max_far_factors
         self._h = C.c_void_p()
         check(self._l.vf_create(C.byref(p), C.byref(o), C.byref(self._h)))
         self._cbs = []

@@ -58,7 +58,9 @@ class FusionNode:
         tol = lambda k: (None if rospy.get_param("~solver/" + k, -1.0) < 0 else float(rospy.get_param("~solver/" + k)))
         self.graph = graph_manager or GraphManager(imu_params=imu, capacity=capacity, lag=lag,
                                                    iterations=int(P("solver/iterations", 5)), device=int(P("solver/device", 0)),
-                                                   rel_tol=tol("rel_tol"), abs_tol=tol("abs_tol"))
+                                                   rel_tol=tol("rel_tol"), abs_tol=tol("abs_tol"),
+                                                   # loop closures / wide between factors alive at once (8 by default, at most 32)
+                                                   max_far_factors=(int(P("solver/max_far_factors", 0)) or None))
         x0 = rospy.get_param("~solver/initial_state", [])
         if graph_manager is None and len(x0) == 16:
             self.graph.setInitialState(x0)

@@ -141,11 +141,12 @@ def test_thirty_two_loop_closures_outlive_their_anchors(oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("compat", [False, True])
-def test_graph_manager_takes_32_loop_closures(oracle, compat):
+@pytest.mark.parametrize("compat,lag", [(False, 0), (True, 0), (False, 1000)])
+def test_graph_manager_takes_32_loop_closures(oracle, compat, lag):
     """vf_add_between with 32 between factors the band cannot hold, arriving one or two per keyframe while the handle solves
     (the column engine grows with them: 6, 12, 24, 48, 96, 192 windows): none refused, and the whole trajectory equals the
-    oracle's on the same graph -- LM and the reference-compat one-update form.  A 33rd is refused (VF_ERR_CAPACITY); a default
+    oracle's on the same graph -- LM (whole history, and the node's default lag of 1 000, which this clip never fills) and the
+    reference-compat one-update form.  A 33rd is refused (VF_ERR_CAPACITY); a default
     handle refuses the ninth."""
     from tests.test_gpu_graph_manager import _stream
     from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
@@ -160,7 +161,7 @@ def test_graph_manager_takes_32_loop_closures(oracle, compat):
         a = k - int(rng.integers(8, min(50, k - 1)))
         plan[k] = (a, _far_record(seq, a, k, rng))
         pairs.append((a, k))
-    gm = GraphManager(capacity=128, iterations=8, rel_tol=0, abs_tol=0, reference_compat=compat, max_far_factors=32)
+    gm = GraphManager(capacity=128 if lag == 0 else lag + 192, lag=lag, iterations=8, rel_tol=0, abs_tol=0, reference_compat=compat, max_far_factors=32)
     gm.setInitialState(seq.gt_states[0])
     i_imu = 0
     for k in range(1, n):
@@ -194,7 +195,7 @@ def test_graph_manager_takes_32_loop_closures(oracle, compat):
     win = helpers.oracle_window(oracle, prob)
     win.lm(iterations=40)
     ate, rot = helpers.ate(xs, win.states)
-    print(f"GraphManager with 32 loop closures (reference_compat={compat}): ATE vs oracle {ate:.3e} m, rot {rot:.3e} rad; lm {st}")
+    print(f"GraphManager with 32 loop closures (reference_compat={compat}, lag {lag}): ATE vs oracle {ate:.3e} m, rot {rot:.3e} rad; lm {st}")
     assert ate <= 1e-7 and rot <= 1e-7 and st["solve_failures"] == 0
     with pytest.raises(VilFusionError) as ei:
         gm.addBetweenFactor(50, 70, (recs[0][0:4], recs[0][4:7]), np.eye(6))

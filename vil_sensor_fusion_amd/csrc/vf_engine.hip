@@ -280,7 +280,8 @@ struct vf_engine {
         if ((!v.xl_n && (rc = alloc(&v.xl_n, B))) || (!v.xl_b && (rc = alloc(&v.xl_b, B * X))) || (!v.xl_U && (rc = alloc(&v.xl_U, B * X * 6 * (27 + 6 * X)))) ||
             (!v.xl_r0 && (rc = alloc(&v.xl_r0, B * X * 6))) || (!v.xl_bx && (rc = alloc(&v.xl_bx, B * X * 7))) || (!v.xl_out && (rc = alloc(&v.xl_out, 2 * B * X * 6)))) return rc;
         // (more far factors than the LDS forms of k_marginalize / k_extra_combine hold: their systems live here)
-        if (x_cap > vf::MAX_EXTRA && !v.far_scratch && (rc = alloc(&v.far_scratch, B * vf::FAR_SCRATCH))) return rc;
+        // (the others: room for the solution of the Woodbury system, handed from k_extra_combine to k_extra_apply)
+        if (!v.far_scratch && (rc = alloc(&v.far_scratch, B * (x_cap > vf::MAX_EXTRA ? vf::FAR_SCRATCH : (size_t)64)))) return rc;
         x_zstride = (size_t)v.G * 15 + B + 64;
         if (!x_gtmp) HIPCHK(hipMalloc((void**)&x_gtmp, x_zstride * sizeof(double)));
         if (slots > x_zslots) {

@@ -565,19 +565,32 @@ def test_whole_history_handle_crosses_the_refinement_threshold(oracle, compat):
     gm.close()
 
 
-@pytest.mark.parametrize("lag", [0, 40])
-def test_asynchronous_staging_equals_synchronous_staging_to_the_bit(lag):
+@pytest.mark.parametrize("lag,closures", [(0, False), (40, False), (0, True), (40, True)])
+def test_asynchronous_staging_equals_synchronous_staging_to_the_bit(lag, closures):
     """Round 6: vf_solve stages asynchronously (arguments by value / pinned memory, sticky status words, one synchronisation per solve),
     preintegrates at reserveNode, computes the next marginal prior behind the solve and enqueues trials adaptively.  None of that
     may change a bit: the same stream through a handle with synchronous_staging = 1 (the old call sequence), compared at every
     solve -- whole-history and fixed-lag (marginalisation at every solve once the window is full; two keyframes per solve now and
-    then, so that a marginal prior computed ahead is followed by one computed on the spot)."""
+    then, so that a marginal prior computed ahead is followed by one computed on the spot).  closures: with a loop closure every
+    9 .. 20 keyframes (far factors: alive, converted to linear rows when their anchor leaves the lag, folded into the prior) the
+    staging stays asynchronous -- the marginalisation on the main stream, the column solve beside the window's own on the
+    second one, the far list re-sent only when it changed -- and the handle goes back and forth between the two regimes."""
+    from tests.test_gpu_far_factors import _far_record
     from vil_sensor_fusion_amd.graph_manager import GraphManager
     n = 180
     seq = synth.make_sequence(seed=77, n_kf=n)
+    plan = {}
+    if closures:
+        rng = np.random.default_rng(5)
+        k = 25
+        while k < n - 30:                    # (none in the last 30 keyframes: with a lag the handle ends without far factors, on the plain path)
+            a = k - int(rng.integers(8, min(34, k - 1)))
+            plan[k] = (a, _far_record(seq, a, k, rng, cov=1e-3, noise=(3e-4, 3e-3)))
+            k += int(rng.integers(9, 21))
     outs = []
     for sync in (False, True):
-        gm = GraphManager(capacity=128, lag=lag, iterations=5, synchronous_staging=sync)
+        # (whole history keeps every closure for good: ten of them need a handle made for more than the default eight)
+        gm = GraphManager(capacity=128, lag=lag, iterations=5, synchronous_staging=sync, max_far_factors=16 if closures and lag == 0 else None)
         gm.setInitialState(seq.gt_states[0])
         gm.addIMUMeasurement(0.0, seq.imu_steps[0, 1:4], seq.imu_steps[0, 4:7])
         t, pub = 0.0, []
@@ -588,6 +601,8 @@ def test_asynchronous_staging_equals_synchronous_staging_to_the_bit(lag):
             gm.reserveNode(t)
             for i in np.nonzero(seq.btw_b == k)[0]:
                 gm.addBetweenFactor(int(seq.btw_a[i]), k, (seq.btw_q[i], seq.btw_t[i]), np.eye(6) * seq.btw_cov[i])
+            if k in plan:
+                gm.addBetweenFactor(plan[k][0], k, (plan[k][1][0:4], plan[k][1][4:7]), np.eye(6) * 1e-3)
             if k % 7 == 3:
                 continue                      # (this keyframe is solved together with the next one)
             gm.solve()

@@ -129,7 +129,12 @@ struct vf_engine {
         HIPCHK(hipStreamWaitEvent(stream, ev_join, 0));
         return VF_OK;
     }
-    bool async_now() const { return async_on && x_used == 0 && v.B == 1 && own_stream; }
+    // async_base: staging calls enqueue and return.  async_now: ... and the window holds no far factors -- the marginalisation may run
+    // on the second stream / ahead of time (k_marginalize<0> only; with far factors alive it reads and rewrites their lists, which
+    // the host re-sends on the main stream).  async_far: the rest -- the marginalisation enqueued on the main stream.
+    bool async_base() const { return async_on && v.B == 1 && own_stream; }
+    bool async_now() const { return async_base() && x_used == 0; }
+    bool async_far() const { return async_base() && x_used > 0; }
     // vf_engine_marginalize_ahead: the marginal prior the next vf_engine_marginalize will need, computed behind the solve that has
     // just ended (the linearisation it reads is final by then) into marg_stash; valid while nothing but appends has happened
     // since and the window's first keyframe is still ahead_lo
@@ -234,6 +239,8 @@ struct vf_engine {
     int x_used = 0;
     std::vector<int> h_xn;
     std::vector<std::vector<int>> h_xa, h_xb;          // host copies of every window's list (re-sent after compact / grow)
+    std::vector<char> h_xdirty;                        // the device's copy of a window's list may differ from the host's (k_marginalize has
+                                                       // struck out entries the host has not yet): vf_engine_set_extra_between must re-send
     std::vector<std::vector<double>> h_xrec;
     double* x_gtmp = nullptr;
     double* x_Z = nullptr;
@@ -261,6 +268,7 @@ struct vf_engine {
         v.x_a = x_la; v.x_b = x_lb; v.x_in = x_li; v.x_out = x_lo;
         v.x_max = x_cap;
         h_xn.assign(v.B, 0);
+        h_xdirty.assign(v.B, 1);
         h_xa.assign(v.B, {});
         h_xb.assign(v.B, {});
         h_xrec.assign(v.B, {});

@@ -4,6 +4,9 @@ import os, sys, time
 import numpy as np
 os.environ["VF_SOLVE_TIMING"] = "1"
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+if os.environ.get("VF_LIB"):                       # (A/B of two builds on one box)
+    from vil_sensor_fusion_amd import _lib
+    _lib._SO = os.path.abspath(os.environ["VF_LIB"])
 from vil_sensor_fusion_amd import GraphManager, synth
 lag, nkf = int(sys.argv[1]) if len(sys.argv) > 1 else 1000, int(sys.argv[2]) if len(sys.argv) > 2 else 1300
 paced = len(sys.argv) > 3 and sys.argv[3] == "paced"     # the device is idle when vf_solve is called, as at a 20-30 Hz keyframe rate (what it enqueued behind the previous solve has run)

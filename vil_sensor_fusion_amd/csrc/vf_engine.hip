@@ -108,6 +108,11 @@ struct vf_engine {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int* sticky_dev = nullptr;
     vf::SolveResult* res_host = nullptr;
+    // The adaptive trial loop of vf_engine_iterate reads the whole result block where it used to read the `done` flag: when the flag
+    // is up the solve is over and the block IS the result -- the vf_engine_read_result that follows finds it here (res_cached, until
+    // any other entry point runs) and costs no second synchronisation.  Sticky words an early read has consumed wait in res_carry.
+    bool res_cached = false;
+    int res_slot = -1, res_carry[2] = {0, 0};
     int ensure_async() {          // the sticky words and the pinned result block (every engine may be asked for a vf_engine_read_result)
         if (res_host) return VF_OK;
         HIPCHK(hipMalloc((void**)&sticky_dev, 2 * sizeof(int)));
@@ -373,6 +378,7 @@ static inline void cold(vf_engine* e) {
 DeviceGuard::DeviceGuard(const vf_engine* e, bool overlap_ok) {
     if (!e) return;
     if (!overlap_ok && e->side_open) (void)const_cast<vf_engine*>(e)->join_side();
+    const_cast<vf_engine*>(e)->res_cached = false;
     want = e->opts.device;
     if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipSetDevice(want); return; }
     if (prev != want) (void)hipSetDevice(want);

@@ -594,7 +594,9 @@ int vf_add_imu(vf_graph* g, double time, const double acc[3], const double gyro[
 /* GraphManager::reserveNode (GraphManager.cpp:51-69): 1-based key, key 0 is the prior node */
 int vf_reserve_node(vf_graph* g, double time, uint64_t* key_out);
 /* GraphManager::addBetweenFactor (GraphManager.cpp:83-88) with noiseModel::Gaussian::Covariance
- * (SensorManagerRos.cpp:99); cov is 6x6 row-major in Pose3 tangent order [rot, trans] */
+ * (SensorManagerRos.cpp:99); cov is 6x6 row-major in Pose3 tangent order [rot, trans].  Any pair of reserved keys prev < cur: a
+ * factor the band cannot hold (wider than VF_MAX_BANDWIDTH keyframes, or a second one ending at cur: a loop closure) is a far
+ * factor (vf_engine_set_extra_between), of which vf_graph_opts.max_far_factors may be alive at once -- VF_ERR_CAPACITY beyond. */
 int vf_add_between(vf_graph* g, uint64_t prev_key, uint64_t cur_key, const double q_wxyz[4],
                    const double t[3], const double cov36[36]);
 /* GraphManager::addFactor(const CombinedImuFactor&) (GraphManager.cpp:90-94): queue a READY-MADE preintegrated factor

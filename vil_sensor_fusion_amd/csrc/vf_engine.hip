@@ -265,6 +265,7 @@ struct vf_engine {
     // solve (a solve may be under stream capture); absent (sequential columns, as on batch engines) if it cannot be had.
     vf_engine* far_columns = nullptr;
     bool is_far_columns = false;
+    bool far_columns_off = false;   // a column engine could not be made: the columns are solved one after the other
     // linear far factors (View::xl_*; made and kept by k_marginalize): the host mirrors only their number and far ends
     std::vector<std::vector<int>> h_lb;
     int h_ln(int w) const { return h_lb.empty() ? 0 : (int)h_lb[w].size(); }

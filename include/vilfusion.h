@@ -157,10 +157,10 @@ typedef struct {
                                 windows.  Where the optimum is does not depend on the rule; trial counts and lambda histories do.
                                 Default 0 = the library's own test. */
     int max_far_factors;     /* far between factors a window may hold at once (vf_engine_set_extra_between; the far ends of its linear
-                                far factor count).  0 = VF_MAX_EXTRA, at most VF_MAX_FAR_LIMIT.  Up to VF_MAX_EXTRA the small dense
-                                systems of the low-rank correction and of the joint marginalisation live in LDS; an engine made for
-                                more keeps them in device memory (0.7 MB per window) -- the same arithmetic in the same order, so the
-                                same bits for the same factors, a few times slower per system.  Every far factor alive costs six
+                                far factor count).  0 = VF_MAX_EXTRA, at most VF_MAX_FAR_LIMIT.  While VF_MAX_EXTRA or fewer are alive the
+                                small dense systems of the low-rank correction and of the joint marginalisation live in LDS; beyond
+                                (engines made for more) in device memory, 0.7 MB per window -- the same arithmetic in the same
+                                order, so the same bits for the same factors, a few times slower per system.  Every far factor alive costs six
                                 Woodbury columns per trial (single-window engines: six windows of the column engine, 23 MB each at
                                 1 200 slots).  Arrays a caller passes for a window's far list (vf_engine_get_extra_between,
                                 vf_engine_get_linear_far) hold this many entries. */
@@ -201,9 +201,12 @@ typedef struct {
                                 is workgroup i as before; same bits either way) */
     int far_batch_columns;   /* single-window engines (the GraphManager's) holding far factors: the 6 Woodbury columns per far factor
                                 are solved as ONE batch on a second, internal engine -- a copy of the window's H per column, 6 windows
-                                per far factor alive (made for 1, 2, 4, 8 factors as they come: 0.12 KB per keyframe slot and window,
+                                per far factor alive (made for 1, 2, 4, 8, 16, 32 factors as they come: 0.12 KB per keyframe slot and window,
                                 0.14 GB and 2 ms for the first loop closure of a 1 200-slot handle) -- instead of one band solve after
                                 the other (default 1; 0 = sequential columns as on batch engines; same bits) */
+    int far_big_forms;       /* engines made with max_far_factors > VF_MAX_EXTRA: the small dense systems of the far factors in device
+                                memory even while VF_MAX_EXTRA or fewer are alive (default 0 = the LDS forms then; same bits: what
+                                tests/test_gpu_far_capacity.py compares) */
 } vf_engine_tuning;
 
 
@@ -568,7 +571,8 @@ typedef struct {
                                   device and reports its own failures; no preintegration at vf_reserve_node, no marginal prior computed
                                   ahead): same bits as the default, slower; what tests compare the asynchronous path with.  Default 0 */
     int max_far_factors;       /* vf_engine_opts.max_far_factors: loop closures (between factors the band cannot hold) alive at once;
-                                  vf_add_between returns VF_ERR_CAPACITY beyond.  0 = VF_MAX_EXTRA, at most VF_MAX_FAR_LIMIT */
+                                  vf_add_between returns VF_ERR_CAPACITY beyond.  0 = the default, VF_MAX_FAR_LIMIT (a handle has no
+                                  caller-sized arrays to keep small; while VF_MAX_EXTRA or fewer are alive it solves with the LDS forms) */
 } vf_graph_opts;
 
 /* (time, pose q_wxyz, position, velocity, bias[acc,gyro]) -- GraphManager::OptimizationCallback

@@ -17,6 +17,7 @@ int main() {
     vf_graph_opts o;
     vf_graph_default_opts(&o);
     o.capacity = 256;
+    o.max_far_factors = VF_MAX_EXTRA;      // (a handle's default is VF_MAX_FAR_LIMIT)
     o.lag = 16;
     vf_graph* g = nullptr;
     CHECK(vf_create(&imu, &o, &g) == VF_OK);

@@ -1,7 +1,7 @@
 """-m gpu: more loop closures alive at once than the LDS forms of the low-rank correction hold.  A handle
-made with max_far_factors > VF_MAX_EXTRA (8; at most VF_MAX_FAR_LIMIT = 32) keeps the Woodbury system and the joint
-marginalisation of its far factors in device memory instead of LDS -- the same arithmetic in the same order -- and its column
-engine grows with the closures alive (six windows each).  iSAM2 takes any number of BetweenFactor<Pose3> on any pair of keys
+made with max_far_factors > VF_MAX_EXTRA (8; at most VF_MAX_FAR_LIMIT = 32, the default of a GraphManager) keeps the Woodbury
+system and the joint marginalisation of its far factors in device memory instead of LDS once more than eight are alive -- the
+same arithmetic in the same order -- and its column engine grows with the closures alive (six windows each).  iSAM2 takes any number of BetweenFactor<Pose3> on any pair of keys
 (GraphManager.cpp:83-88); the CPU oracle assembles a band as wide as the widest factor and so treats these like any other."""
 import numpy as np
 import pytest
@@ -74,8 +74,9 @@ def test_an_engine_made_for_more_computes_the_same_bits(oracle):
     fa, fb = np.array([c[0] for c in closures], dtype=np.int32), np.array([c[1] for c in closures], dtype=np.int32)
     far = np.stack([_far_record(seq, a, b, rng, cov=1e-4, noise=(1e-4, 1e-3)) for a, b in closures])
     outs = []
-    for cap in (None, 32):
-        eng = Engine(EngineOpts(windows=1, capacity=total, max_far_factors=cap))
+    # (an engine made for 32 that holds three takes the LDS forms by itself: far_big_forms = 1 is the switch that keeps it on the others)
+    for cap, big in ((None, None), (32, 1), (32, None)):
+        eng = Engine(EngineOpts(windows=1, capacity=total, max_far_factors=cap, far_big_forms=big))
         helpers.load_engine(eng, 0, prob, 0, n)
         eng.set_extra_between(0, fa, fb, far)
         eng.iterate(30)
@@ -88,8 +89,9 @@ def test_an_engine_made_for_more_computes_the_same_bits(oracle):
         assert eng.read_lm(0)["solve_failures"] == 0
         outs.append(snaps)
         eng.close()
-    for x, y in zip(*outs):
+    for x, y, z in zip(*outs):
         np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(x, z)
 
 
 def test_thirty_two_loop_closures_outlive_their_anchors(oracle):
@@ -120,13 +122,21 @@ def test_thirty_two_loop_closures_outlive_their_anchors(oracle):
             blind = helpers.oracle_window(oracle, prob, 0, s + n)
             blind.lm(iterations=30)
             moved = helpers.ate(blind.states[s:s + n], refs[s])[0]
+    # (the same run on an engine kept on the device-memory forms throughout: this one changes to the LDS forms when the far ends
+    # alive fall to eight, around slide 49 -- the two must publish the same bits at every slide)
+    twin = Engine(EngineOpts(windows=1, capacity=total, max_far_factors=32, far_big_forms=1))
     eng = Engine(EngineOpts(windows=1, capacity=total, max_far_factors=32))
-    helpers.load_engine(eng, 0, prob, 0, n)
-    eng.set_extra_between(0, fa, fb, far)
-    eng.iterate(40)
+    for e in (eng, twin):
+        helpers.load_engine(e, 0, prob, 0, n)
+        e.set_extra_between(0, fa, fb, far)
+        e.iterate(40)
+    forms = set()
     for s in range(1, total - n + 1):
-        eng.slide(marginalize=True)
-        eng.iterate(K)
+        for e in (eng, twin):
+            e.slide(marginalize=True)
+            e.iterate(K)
+        np.testing.assert_array_equal(eng.get_states(0, s, n), twin.get_states(0, s, n))
+        forms.add(len(eng.get_linear_far(0)) + len(eng.get_extra_between(0)[0]) > 8)
         if s in CHECK:
             got = eng.get_states(0, s, n)
             ea, eb, _, transported, ended, absorbed = eng.get_extra_between(0)
@@ -137,8 +147,9 @@ def test_thirty_two_loop_closures_outlive_their_anchors(oracle):
             assert e < 1e-6 and moved > 1e-3 and ended == 0
             if s == 30:
                 assert len(ea) == 0 and transported == 32 and len(linear) + absorbed == 32 and len(linear) >= 24
-    assert eng.read_lm(0)["solve_failures"] == 0
+    assert eng.read_lm(0)["solve_failures"] == 0 and forms == {True, False}
     eng.close()
+    twin.close()
 
 
 @pytest.mark.parametrize("compat,lag", [(False, 0), (True, 0), (False, 1000)])
@@ -146,8 +157,8 @@ def test_graph_manager_takes_32_loop_closures(oracle, compat, lag):
     """vf_add_between with 32 between factors the band cannot hold, arriving one or two per keyframe while the handle solves
     (the column engine grows with them: 6, 12, 24, 48, 96, 192 windows): none refused, and the whole trajectory equals the
     oracle's on the same graph -- LM (whole history, and the node's default lag of 1 000, which this clip never fills) and the
-    reference-compat one-update form.  A 33rd is refused (VF_ERR_CAPACITY); a default
-    handle refuses the ninth."""
+    reference-compat one-update form.  A 33rd is refused (VF_ERR_CAPACITY).  While eight or fewer are alive the handle solves
+    with the LDS forms, beyond with the device-memory ones: the same bits either way, so the switch leaves no trace."""
     from tests.test_gpu_graph_manager import _stream
     from vil_sensor_fusion_amd.engine import REFERENCE_PRIOR_SIGMAS
     from vil_sensor_fusion_amd.graph_manager import GraphManager
@@ -161,7 +172,9 @@ def test_graph_manager_takes_32_loop_closures(oracle, compat, lag):
         a = k - int(rng.integers(8, min(50, k - 1)))
         plan[k] = (a, _far_record(seq, a, k, rng))
         pairs.append((a, k))
-    gm = GraphManager(capacity=128 if lag == 0 else lag + 192, lag=lag, iterations=8, rel_tol=0, abs_tol=0, reference_compat=compat, max_far_factors=32)
+    # (a handle's default IS 32: asked for by name in one case, left to the default in the others)
+    gm = GraphManager(capacity=128 if lag == 0 else lag + 192, lag=lag, iterations=8, rel_tol=0, abs_tol=0, reference_compat=compat,
+                      max_far_factors=32 if compat else None)
     gm.setInitialState(seq.gt_states[0])
     i_imu = 0
     for k in range(1, n):

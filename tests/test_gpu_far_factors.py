@@ -104,7 +104,7 @@ def test_graph_manager_takes_any_pair_of_keys(oracle, compat):
     far = [(30, 36), (10, 60), (11, 61)]
     rng = np.random.default_rng(6)
     recs = [_far_record(seq, a, b, rng) for a, b in far]
-    gm = GraphManager(capacity=128, iterations=25, rel_tol=0, abs_tol=0, reference_compat=compat)
+    gm = GraphManager(capacity=128, iterations=25, rel_tol=0, abs_tol=0, reference_compat=compat, max_far_factors=8)
     gm.setInitialState(seq.gt_states[0])
     gm.addIMUMeasurement(0.0, seq.imu_steps[0, 1:4], seq.imu_steps[0, 4:7])
     _feed(gm, seq, n)
@@ -133,7 +133,7 @@ def test_graph_manager_takes_any_pair_of_keys(oracle, compat):
     ate, rot = helpers.ate(xs, win.states)
     print(f"GraphManager with far factors (reference_compat={compat}): ATE vs oracle {ate:.3e} m, rot {rot:.3e} rad")
     assert ate <= 1e-6 and rot <= 1e-6
-    # the list is bounded: a ninth far factor is refused like the band refused a wide one before
+    # the list is bounded (a handle made for eight; the default is 32: tests/test_gpu_far_capacity.py): a ninth far factor is refused like the band refused a wide one before
     for i in range(5):
         gm.addBetweenFactor(40 + i, 60 + i, (recs[0][0:4], recs[0][4:7]), np.eye(6))
     with pytest.raises(VilFusionError) as ei:
@@ -349,7 +349,7 @@ def test_graph_manager_keeps_a_loop_closure_across_its_lag():
 
 
 def test_far_capacity_counts_the_factors_the_engine_has_taken_over():
-    """VF_MAX_EXTRA = 8 bounds the far factors ALIVE in a window: the ones in the GraphManager's list and the far ends of the
+    """max_far_factors (here 8 = VF_MAX_EXTRA, what the LDS forms hold; a handle's default is 32) bounds the far factors ALIVE in a window: the ones in the GraphManager's list and the far ends of the
     engine's linear far factor (far factors already marginalised with their older key) together.  A ninth is refused where it
     is added (VF_ERR_CAPACITY from vf_add_between, as before) -- never by a later vf_solve -- and there is room again once a
     far end has been folded into the marginal prior."""
@@ -359,7 +359,7 @@ def test_far_capacity_counts_the_factors_the_engine_has_taken_over():
     seq = synth.make_sequence(77, n)
     traj_t, acc, gyr = _stream(seq)
     rng = np.random.default_rng(11)
-    gm = GraphManager(capacity=256, iterations=4, lag=lag, rel_tol=0, abs_tol=0)
+    gm = GraphManager(capacity=256, iterations=4, lag=lag, rel_tol=0, abs_tol=0, max_far_factors=8)
     gm.setInitialState(seq.gt_states[0])
     i_imu, taken, refused = 0, [], []
     for k in range(1, n):
@@ -426,7 +426,7 @@ def test_refined_windows_take_far_factors_as_rows_of_the_operator(oracle):
 @pytest.mark.parametrize("tol", [0.0, None])
 def test_random_loop_closures_through_a_fixed_lag_handle(tol):
     """Bookkeeping under load: a GraphManager with a lag of 50 and 128 slots (so that it compacts while far factors of both
-    kinds are alive) takes a loop closure between random keys every few keyframes -- up to the capacity of eight alive at a
+    kinds are alive; all made for eight far factors, the capacity of the LDS forms) takes a loop closure between random keys every few keyframes -- up to the capacity of eight alive at a
     time; the ones refused are simply not added to any handle -- and must publish what (a) a roomy handle with the same lag
     publishes (to 1e-8: compaction moves slots, nothing else) and (b) a whole-history handle publishes (lag = 0: every factor
     kept for good, as in the reference) to 1e-6 m: far factors converted, re-expressed at every marginalisation, sharing their
@@ -445,9 +445,9 @@ def test_random_loop_closures_through_a_fixed_lag_handle(tol):
         span = int(rng.integers(8, min(lag - 6, k - 1)))
         plan[k] = (k - span, _far_record(seq, k - span, k, rng, cov=1e-3, noise=(3e-4, 3e-3)))
         k += int(rng.integers(3, 12))
-    handles = {"small": GraphManager(capacity=128, iterations=5, lag=lag, rel_tol=tol, abs_tol=tol),
-               "roomy": GraphManager(capacity=512, iterations=5, lag=lag, rel_tol=tol, abs_tol=tol),
-               "whole": GraphManager(capacity=512, iterations=5, lag=0, rel_tol=tol, abs_tol=tol)}
+    handles = {"small": GraphManager(capacity=128, iterations=5, lag=lag, rel_tol=tol, abs_tol=tol, max_far_factors=8),
+               "roomy": GraphManager(capacity=512, iterations=5, lag=lag, rel_tol=tol, abs_tol=tol, max_far_factors=8),
+               "whole": GraphManager(capacity=512, iterations=5, lag=0, rel_tol=tol, abs_tol=tol, max_far_factors=8)}
     out = {name: [] for name in handles}
     for gm in handles.values():
         gm.setInitialState(seq.gt_states[0])

@@ -14,7 +14,7 @@ from tests.test_gpu_graph_manager import _stream
 from vil_sensor_fusion_amd import synth, VilFusionError
 from vil_sensor_fusion_amd.graph_manager import GraphManager
 n, lag = int(sys.argv[1]) if len(sys.argv) > 1 else 3000, int(sys.argv[2]) if len(sys.argv) > 2 else 200
-max_far = (int(sys.argv[3]) if len(sys.argv) > 3 else 0) or None
+max_far = (int(sys.argv[3]) if len(sys.argv) > 3 else 0) or 8
 gap = int(sys.argv[4]) if len(sys.argv) > 4 else 30
 seq = synth.make_sequence(83, n)
 traj_t, acc, gyr = _stream(seq)
@@ -70,5 +70,5 @@ for k in range(1, n):
         print(f"solve {k}: {taken} closures taken, {refused} refused for capacity; largest difference small vs roomy handle so far {worst:.3e}; "
               f"lm small {handles['small'].lmStats()}; {time.time() - t0:.0f} s", flush=True)
 st = [gm.lmStats() for gm in handles.values()]
-print(f"far soak: {n - 1} solves at lag {lag}, handles made for {max_far or 8} far factors, {taken} loop closures through their whole life ({refused} refused for capacity, up to {alive_max} alive at once), largest difference between the compacting and the roomy handle {worst:.3e}, "
+print(f"far soak: {n - 1} solves at lag {lag}, handles made for {max_far} far factors, {taken} loop closures through their whole life ({refused} refused for capacity, up to {alive_max} alive at once), largest difference between the compacting and the roomy handle {worst:.3e}, "
       f"failed solves {st[0]['solve_failures']} / {st[1]['solve_failures']}")

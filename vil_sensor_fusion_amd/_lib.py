@@ -34,7 +34,7 @@ class EngineTuningC(C.Structure):
     """solver-form switches (include/vilfusion.h vf_engine_tuning): what tests and tools set to reach one form on purpose"""
     _fields_ = [("struct_size", C.c_uint32), ("sweep_two_sided_max", C.c_int), ("hybrid_threshold", C.c_int), ("use_hip_graph", C.c_int),
                 ("solve_split_min", C.c_int), ("solve_assemble_min", C.c_int), ("solve_assemble_waves", C.c_int),
-                ("hybrid_active_list", C.c_int), ("far_batch_columns", C.c_int)]
+                ("hybrid_active_list", C.c_int), ("far_batch_columns", C.c_int), ("far_big_forms", C.c_int)]
 
 
 class ImuParamsC(C.Structure):

@@ -273,6 +273,7 @@ struct vf_engine {
         if (v.x_max) return;
         v.x_a = x_la; v.x_b = x_lb; v.x_in = x_li; v.x_out = x_lo;
         v.x_max = x_cap;
+        v.far_big = tune.far_big_forms && x_cap > vf::MAX_EXTRA ? 1 : 0;
         h_xn.assign(v.B, 0);
         h_xdirty.assign(v.B, 1);
         h_xa.assign(v.B, {});

@@ -153,7 +153,7 @@ static void graph_defaults(vf_graph_opts* o) {
     o->wildfire = 0.0;
     o->min_model_fidelity = 0.0;
     o->synchronous_staging = 0;
-    o->max_far_factors = 0;      // = VF_MAX_EXTRA
+    o->max_far_factors = 0;      // = VF_MAX_FAR_LIMIT
 }
 // (the caller's struct may be shorter than the library's: include/vilfusion.h "struct_size")
 void vf_graph_default_opts_sized(vf_graph_opts* o, uint32_t struct_size) {
@@ -185,7 +185,9 @@ int vf_create(const vf_imu_params* imu, const vf_graph_opts* opts, vf_graph** ou
     if (o.incremental && !o.reference_compat) return gerr(VF_ERR_INVALID, "incremental needs reference_compat (the update it makes incremental is the iSAM2-like one)");
     if (o.incremental && !(o.wildfire >= 0.0)) return gerr(VF_ERR_INVALID, "wildfire must be >= 0");
     if (o.max_far_factors < 0 || o.max_far_factors > VF_MAX_FAR_LIMIT) return gerr(VF_ERR_INVALID, "max_far_factors must be in 0..%d", VF_MAX_FAR_LIMIT);
-    if (o.max_far_factors == 0) o.max_far_factors = VF_MAX_EXTRA;
+    // (a handle takes what the library can hold: while eight or fewer are alive the solver's forms are those of an engine made for
+    // eight, whatever the capacity; the lists are allocated when the first far factor arrives)
+    if (o.max_far_factors == 0) o.max_far_factors = VF_MAX_FAR_LIMIT;
     const double covs[6] = {imu->acc_cov, imu->gyro_cov, imu->integration_cov, imu->bias_acc_cov, imu->bias_omega_cov, imu->bias_acc_omega_int};
     for (double c : covs)
         if (!(c > 0.0) || !std::isfinite(c)) return gerr(VF_ERR_NOT_SPD, "IMU covariances must be finite and > 0");

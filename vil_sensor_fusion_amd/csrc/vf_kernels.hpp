@@ -227,7 +227,8 @@ struct View {
     double* xl_r0;      // [B][6 x_max]
     double* xl_bx;      // [B][x_max][7] (q w x y z, t)
     double* xl_out;     // [2][B][6 x_max] residual at the states of each buffer
-    double* far_scratch; // [B][FAR_SCRATCH] or null: engines made for more than MAX_EXTRA far factors per window
+    double* far_scratch; // [B][FAR_SCRATCH] (engines made for more than MAX_EXTRA far factors per window) or [B][64]
+    int far_big;         // the device-memory forms whatever the slots in use (vf_engine_tuning.far_big_forms; such engines only)
     // Incremental Gauss-Newton updates (vf_engine_opts.incremental; csrc "suffix re-elimination"): the banded form of what
     // ISAM2::update does with relinearizeSkip 1 (GraphManager.cpp:37-43,126-127).  The forward sweep is causal in time, so the
     // panel of a keyframe depends on nothing newer than the factors that touch it: after an update only the keyframes from
@@ -343,7 +344,7 @@ void launch_set_range(const View& v, int window, int lo, int hi, hipStream_t s);
 void launch_bump_lo(const View& v, hipStream_t s);
 void launch_put_between(const View& v, long g, int a, const BtwArg& rec, hipStream_t s);
 void launch_read_result(const View& v, int window, int slot, int which, int* sticky, SolveResult* out, hipStream_t s);
-void launch_marginalize(const View& v, int* status, hipStream_t s);
+void launch_marginalize(const View& v, int far_slots_in_use, int* status, hipStream_t s);
 constexpr int MARG_STASH_DOUBLES = 729 + 27 + 48 + 4;     // per window: what k_marginalize leaves in a stash (information, gradient, linearisation states)
 void launch_marginalize_ahead(const View& v, int* status, double* stash, hipStream_t s);   // engines without far factors
 void launch_marg_commit(const View& v, const double* stash, hipStream_t s);

@@ -57,6 +57,7 @@ class EngineOpts:
     gauge_floor: float | None = None     # floor of the marginal prior's information about global translation / yaw (None = default 3e-4; 0 = off)
     hybrid_active_list: int | None = None  # hybrid solves: sweeps take their windows from the compacted list of active ones (None = default 1)
     far_batch_columns: int | None = None   # single-window engines: the Woodbury columns of far factors as one batched solve (None = default 1)
+    far_big_forms: int | None = None       # engines made for > 8 far factors: their dense systems in device memory even with <= 8 alive (None = default 0)
     incremental: int | None = None         # isam_step re-eliminates only from the first keyframe that changed (None = default 0)
     wildfire: float | None = None          # ... and its back substitution stops once increments change by <= this (None = default 0: bitwise)
     min_model_fidelity: float | None = None  # > 0: GTSAM's LM accept rule (modelFidelity > this; 1e-3 there) instead of accept_rel (None = default 0)
@@ -81,7 +82,7 @@ class Engine:
         t = _lib.EngineTuningC()
         self._l.vf_engine_default_tuning(C.byref(t))
         t.use_hip_graph = int(opts.use_hip_graph)
-        for name in ("sweep_two_sided_max", "hybrid_threshold", "solve_split_min", "solve_assemble_min", "solve_assemble_waves", "hybrid_active_list", "far_batch_columns"):
+        for name in ("sweep_two_sided_max", "hybrid_threshold", "solve_split_min", "solve_assemble_min", "solve_assemble_waves", "hybrid_active_list", "far_batch_columns", "far_big_forms"):
             if getattr(opts, name) is not None:
                 setattr(t, name, getattr(opts, name))
         self._h = C.c_void_p()

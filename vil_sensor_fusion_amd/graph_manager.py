@@ -59,7 +59,7 @@ class GraphManager:
         o.synchronous_staging = int(bool(synchronous_staging))     # the pre-round-6 staging: same bits, slower (tests compare the two)
         if min_model_fidelity is not None:        # GTSAM's LM accept rule (LevenbergMarquardtParams::minModelFidelity = 1e-3) instead of the library's own
             o.min_model_fidelity = min_model_fidelity
-        if max_far_factors is not None:           # loop closures alive at once (default VF_MAX_EXTRA = 8, at most VF_MAX_FAR_LIMIT = 32)
+        if max_far_factors is not None:           # loop closures alive at once (default = the limit, VF_MAX_FAR_LIMIT = 32)
             o.max_far_factors = max_far_factors
         self._h = C.c_void_p()
         check(self._l.vf_create(C.byref(p), C.byref(o), C.byref(self._h)))

@@ -59,7 +59,7 @@ class FusionNode:
         self.graph = graph_manager or GraphManager(imu_params=imu, capacity=capacity, lag=lag,
                                                    iterations=int(P("solver/iterations", 5)), device=int(P("solver/device", 0)),
                                                    rel_tol=tol("rel_tol"), abs_tol=tol("abs_tol"),
-                                                   # loop closures / wide between factors alive at once (8 by default, at most 32)
+                                                   # loop closures / wide between factors alive at once (32, the library's default and its limit, unless set lower)
                                                    max_far_factors=(int(P("solver/max_far_factors", 0)) or None))
         x0 = rospy.get_param("~solver/initial_state", [])
         if graph_manager is None and len(x0) == 16:

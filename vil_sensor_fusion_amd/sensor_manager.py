@@ -95,8 +95,8 @@ class SensorManager:
     def _add_between(self, a, b, pose, cov):
         """addBetweenFactor, failing soft where the library cannot take a factor iSAM2 would (GraphManager.cpp:83-88 takes any
         pair of keys).  The library takes any pair too -- a span wider than 3 keyframes or a second factor on an end key
-        becomes a "far" factor (vf_engine_set_extra_between) -- but holds at most VF_MAX_EXTRA = 8 of those per window
-        (32 on a handle made with max_far_factors; INTEGRATION.md "Limits"): one more comes back as VF_ERR_CAPACITY and is dropped here like a missed odometry
+        becomes a "far" factor (vf_engine_set_extra_between) -- but holds at most 32 of those alive per window
+        (vf_graph_opts.max_far_factors; INTEGRATION.md "Limits"): one more comes back as VF_ERR_CAPACITY and is dropped here like a missed odometry
         message (:41-45 warns and carries on the same way)."""
         from ._lib import VilFusionError
         try:

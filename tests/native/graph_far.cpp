@@ -2,7 +2,7 @@
 // builds and runs this): GraphManager::addBetweenFactor takes any pair of keys (GraphManager.cpp:83-88); a factor the band
 // cannot hold -- wider than VF_MAX_BANDWIDTH, or a second one ending at a key -- goes to the far list, counts as a staged
 // factor, reaches the engine through vf_engine_set_extra_between at every solve while both keys are in the window, and the
-// list is bounded by VF_MAX_EXTRA.
+// list is bounded by vf_graph_opts.max_far_factors (VF_MAX_FAR_LIMIT by default).
 #include <atomic>
 #include <cstdio>
 
@@ -76,6 +76,28 @@ int main() {
     CHECK(vf_solve(g) == VF_OK);
     CHECK(fake_extra_n.load() == 1);
     vf_destroy(g);
+    // a handle made with the defaults holds VF_MAX_FAR_LIMIT of them (whole history: nothing ever leaves), then refuses; opts out of
+    // range are refused at creation
+    {
+        vf_graph_opts d;
+        vf_graph_default_opts(&d);
+        CHECK(d.max_far_factors == 0);
+        d.capacity = 256;
+        vf_graph* h = nullptr;
+        CHECK(vf_create(&imu, &d, &h) == VF_OK);
+        t = 0.0;
+        auto node2 = [&]() { for (int s = 0; s < 3; s++) { t += 0.005; vf_add_imu(h, t, acc, gyro); } uint64_t k = 0; vf_reserve_node(h, t, &k); return k; };
+        for (int k = 1; k <= 80; k++) { const uint64_t key = node2(); if (key > 1) CHECK(vf_add_between(h, key - 1, key, q, t3, eye) == VF_OK); }
+        for (int i = 0; i < VF_MAX_FAR_LIMIT; i++) CHECK(vf_add_between(h, 1 + (uint64_t)i, 40 + (uint64_t)i, q, t3, eye) == VF_OK);
+        CHECK(vf_add_between(h, 2, 79, q, t3, eye) == VF_ERR_CAPACITY);
+        CHECK(vf_solve(h) == VF_OK);
+        CHECK(fake_extra_n.load() == VF_MAX_FAR_LIMIT);
+        vf_destroy(h);
+        d.max_far_factors = VF_MAX_FAR_LIMIT + 1;
+        CHECK(vf_create(&imu, &d, &h) == VF_ERR_INVALID);
+        d.max_far_factors = -1;
+        CHECK(vf_create(&imu, &d, &h) == VF_ERR_INVALID);
+    }
     printf("far-factor routing ok\n");
     return 0;
 }

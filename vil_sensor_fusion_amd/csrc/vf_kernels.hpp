@@ -323,7 +323,7 @@ void launch_retract(const View& v, hipStream_t s);
 void launch_model_change(const View& v, hipStream_t s);     // View::model of every window, from g and the increment just solved
 void launch_decide(const View& v, int init, hipStream_t s);
 void launch_close_excursions(const View& v, hipStream_t s);
-void launch_reset_lambda(const View& v, const double* lambda0, hipStream_t s);   // lambda := lambda0 at the start of a solve (see k_reset_lambda)   // non-monotone LM: undo an excursion left open at the end of a solve
+void launch_reset_lambda(const View& v, const double* lambda0, int clear_done, hipStream_t s);   // lambda := lambda0 at the start of a solve (see k_reset_lambda)   // non-monotone LM: undo an excursion left open at the end of a solve
 void launch_partitioned_local(const View& v, hipStream_t s);    // chunk sweeps + spikes of the owned chunks
 void launch_partitioned_global(const View& v, hipStream_t s);   // separator chain (all of it) + back substitution of the owned chunks
 void launch_mask_delta(const View& v, hipStream_t s);           // zero the increments of keyframes this rank does not own

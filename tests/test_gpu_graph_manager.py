@@ -614,3 +614,40 @@ def test_asynchronous_staging_equals_synchronous_staging_to_the_bit(lag, closure
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     assert outs[0][2] == outs[1][2]
+
+
+def test_the_early_result_read_of_iterate_is_what_read_result_returns(oracle):
+    """Round 6: under the termination rule a one-window engine that stages asynchronously reads the whole result block after the
+    first trial of vf_engine_iterate; when the rule's flag is up the block is the result and vf_engine_read_result returns it without
+    a second synchronisation.  The cached block must be what a fresh read gives, and any other entry point must void it."""
+    from vil_sensor_fusion_amd import Engine, EngineOpts
+    n = 120
+    seq = synth.make_sequence(seed=21, n_kf=n)
+    prob = helpers.build_problem(oracle, seq, perturb=0.002)
+    outs = {}
+    for asyn in (False, True):
+        eng = Engine(EngineOpts(windows=1, capacity=n))
+        helpers.load_engine(eng, 0, prob)
+        eng.set_convergence(1e-5, 1e-5)
+        if asyn:
+            eng.set_async(True)
+        seen = []
+        for _ in range(6):                                   # the first solves take all their trials, the later ones converge in one
+            eng.iterate(5)
+            r = eng.read_result(0, n - 1)
+            lm = eng.read_lm(0)
+            np.testing.assert_array_equal(r["state"], eng.get_states(0, n - 1, 1)[0])
+            assert (r["cost"], r["accepted"], r["rejected"], r["solve_failures"], r["device_flags"]) == (lm["cost"], lm["accepted"], lm["rejected"], lm["solve_failures"], 0)
+            seen.append((r["state"].copy(), r["cost"], r["accepted"], r["rejected"]))
+        # another entry point between iterate and the read: the cache is void, the read is a fresh one
+        eng.iterate(5)
+        x = eng.get_states(0, n - 1, 1)
+        x[0, 4] += 0.25
+        eng.set_states(0, n - 1, x)
+        np.testing.assert_array_equal(eng.read_result(0, n - 1)["state"], x[0])
+        outs[asyn] = seen
+        eng.close()
+    for a, b in zip(outs[False], outs[True]):                # the adaptive enqueueing skips launches that would have done nothing: same bits
+        np.testing.assert_array_equal(a[0], b[0])
+        assert a[1:] == b[1:]
+    assert outs[True][-1][2] - outs[True][-2][2] <= 1        # the last solves: one accepted trial at most

@@ -320,6 +320,19 @@ class Engine:
     def reset_lambda(self):
         check(self._l.vf_engine_reset_lambda(self._h))
 
+    def set_async(self, on=True):
+        """asynchronous staging (vf_engine_set_async; what the GraphManager's engine runs with): staging calls enqueue and return,
+        device-detected failures travel in sticky words, vf_engine_read_result is the one synchronisation of a solve"""
+        check(self._l.vf_engine_set_async(self._h, int(bool(on))))
+
+    def read_result(self, window, slot, estimate=False):
+        """vf_engine_read_result: state of keyframe `slot`, cost and LM counters of `window`, the sticky device flags -- one
+        synchronisation (none when vf_engine_iterate has just left the block behind: vf_engine.hip "res_cached")"""
+        st = np.zeros(16)
+        cost, acc, rej, fl, fg = C.c_double(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(self._l.vf_engine_read_result(self._h, window, slot, int(bool(estimate)), _d(st), C.byref(cost), C.byref(acc), C.byref(rej), C.byref(fl), C.byref(fg)))
+        return dict(state=st, cost=cost.value, accepted=acc.value, rejected=rej.value, solve_failures=fl.value, device_flags=fg.value)
+
     def set_convergence(self, rel_tol=1e-5, abs_tol=1e-5):
         """Stop a window's LM trials once an accepted step lowers its cost by <= abs_tol or by <= rel_tol * cost
         (GTSAM's LM rule; off by default, (0, 0) switches it off)."""

@@ -210,15 +210,18 @@ typedef struct {
 } vf_engine_tuning;
 
 
-/* Asynchronous staging (the GraphManager handle's engine runs this way; one-window engines that own their stream and hold no far
- * factors): with on != 0, vf_engine_preintegrate (of keyframes beyond the window's end), vf_engine_set_between (up to 4 records),
+/* Asynchronous staging (the GraphManager handle's engine runs this way; one-window engines that own their stream): with on != 0,
+ * vf_engine_preintegrate (of keyframes beyond the window's end), vf_engine_set_between (up to 4 records),
  * vf_engine_marginalize, vf_engine_drop_oldest and vf_engine_set_range enqueue their work and return without waiting for the
- * device -- the marginalisation on a second stream, beside the staging of the keyframe that arrives -- and what the device finds
+ * device -- the marginalisation on a second stream, beside the staging of the keyframe that arrives (with far factors alive: on the
+ * main stream, and the second one carries the Woodbury columns beside the window's own band solve) -- and what the device finds
  * wrong is reported by vf_engine_read_result instead of by the call: device_flags bit 0 = a preintegrated covariance was not
  * positive definite (VF_ERR_NOT_SPD of vf_engine_preintegrate), bit 1 = the pivot block of a marginalised keyframe was not,
  * bit 2 = the far ends' block (VF_ERR_INDETERMINATE of vf_engine_marginalize); the flags are cleared by the read.
  * vf_engine_read_result: the state of keyframe `slot` (estimate != 0: theta (+) delta of the reference-compat solve), the cost and the
- * LM counters of vf_engine_read_lm, in ONE synchronisation; any output may be null.  Works on every engine. */
+ * LM counters of vf_engine_read_lm, in ONE synchronisation -- none at all when it follows a vf_engine_iterate whose adaptive trial
+ * loop (one window under the termination rule) has read that very block to see the rule's flag up; any output may be null.  Works
+ * on every engine. */
 int vf_engine_set_async(vf_engine* e, int on);
 /* asynchronous engines, after a solve: compute NOW, behind the solve, the marginal prior the next vf_engine_marginalize of this
  * window will need (its inputs -- the linearisation of the factors on the oldest keyframe at the solved states -- are final), so
